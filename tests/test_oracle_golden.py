@@ -1,0 +1,95 @@
+"""Pin the oracle (oracle/sige_oracle.c) to vectors produced by the REAL reference
+(tests/golden/make_golden.py).  CPU-only; runs in the `-m "not gpu"` suite."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from tests import util
+from tests.golden_cases import CASES
+
+
+def _exact_or_swish(case, got, want):
+    if case["act"] == "swish":
+        torch.testing.assert_close(got, want, rtol=util.SWISH_RTOL, atol=util.SWISH_ATOL)
+    else:
+        assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("case", CASES, ids=util.case_ids())
+def test_ops_match_reference(case):
+    g = case["geom"]
+    d = util.tensors(case)
+    idx = oracle.reduce_mask(d["mask"], g.block, g.block_stride, g.offset)
+    assert torch.equal(idx, util.ref(case, "idx"))  # index tensors: bit-exact
+
+    gathered = oracle.gather(d["x"], g.block[0], g.block[1], idx, d["scale"], d["shift"], case["act"],
+                             case["act_first"])
+    _exact_or_swish(case, gathered, util.ref(case, "gather"))
+
+    # downstream ops are fed the REFERENCE's intermediate so each op is pinned on its own
+    conv_in = util.ref(case, "gather")
+    conv = oracle.block_conv(conv_in, d["weight"], d["bias"], g.stride)
+    torch.testing.assert_close(conv, util.ref(case, "conv"), rtol=0, atol=1e-5)
+
+    tiles = util.ref(case, "conv")
+    args = (g.offset[0], g.offset[1], g.stride[0], g.stride[1], idx)
+    assert torch.equal(oracle.scatter(tiles, d["y"], *args, None), util.ref(case, "scatter"))
+    assert torch.equal(oracle.scatter(tiles, d["y"], *args, d["residual"]), util.ref(case, "scatter_res"))
+    assert torch.equal(oracle.scatter(tiles, d["y"], *args, d["residual_c"]), util.ref(case, "scatter_resc"))
+
+    Ho, Wo = d["out_res"]
+    smap = oracle.get_scatter_map(Ho, Wo, *g.block, *g.kernel, *g.offset, *g.stride, idx)
+    assert torch.equal(smap, util.ref(case, "map"))
+
+    sg = oracle.scatter_gather(tiles, d["y"], g.block[0], g.block[1], idx, smap, d["scale2"], d["shift2"],
+                               case["act"], case["act_first"])
+    _exact_or_swish(case, sg, util.ref(case, "sg"))
+
+    idx1 = oracle.reduce_mask(util.shortcut_mask(case, d), 4, 4, 0)
+    assert torch.equal(idx1, util.ref(case, "idx1"))
+    x1 = util.x1_tiles(case, d, idx1.shape[0])
+    swbr = oracle.scatter_with_block_residual(tiles, d["y"], x1, d["y1"], *args[:4], idx, idx1)
+    assert torch.equal(swbr, util.ref(case, "swbr"))
+
+
+def _fixture_names():
+    g = util.golden("masks")
+    return sorted({k.split("/")[0] for k in g.files})
+
+
+@pytest.mark.parametrize("name", _fixture_names())
+def test_mask_helpers_match_reference(name):
+    g = util.golden("masks")
+    shape = g[name + "/shape"]
+    mask = util.unpack(g[name + "/mask"], shape)
+    geoms = {"b6s4p1": ((6, 6), (4, 4), (1, 1)), "b4s4p0": ((4, 4), (4, 4), (0, 0)),
+             "b5s4p0": ((5, 5), (4, 4), (0, 0)), "b5s4p1": ((5, 5), (4, 4), (1, 1))}
+    for gname, (b, s, p) in geoms.items():
+        want = torch.from_numpy(g["%s/reduce/%s" % (name, gname)])
+        assert torch.equal(oracle.reduce_mask(mask, b, s, p), want)
+    for dil in (1, 2, 5):
+        want = util.unpack(g["%s/dilate/%d" % (name, dil)], shape)
+        assert torch.equal(oracle.dilate_mask(mask, dil), want)
+    for min_res, dil in ((8, 1), (8, 2), (4, 1)):
+        pyr = oracle.downsample_mask(mask, min_res=min_res, dilation=dil)
+        keys = [k for k in g.files if k.startswith("%s/pyramid/%d_%d/" % (name, min_res, dil))]
+        assert len(keys) == len(pyr)
+        for (h, w), pm in pyr.items():
+            want = util.unpack(g["%s/pyramid/%d_%d/%dx%d" % (name, min_res, dil, h, w)], (h, w))
+            assert torch.equal(pm, want), (name, min_res, dil, h, w)
+    dm = oracle.dilate_mask(mask, 5)
+    for (h, w), pm in oracle.downsample_mask(dm, min_res=8).items():
+        assert torch.equal(pm, util.unpack(g["%s/ddpm/%dx%d" % (name, h, w)], (h, w)))
+        if min(h, w) >= 16:
+            want = torch.from_numpy(g["%s/ddpm_reduce_b6/%dx%d" % (name, h, w)])
+            assert torch.equal(oracle.reduce_mask(pm, 6, 4, 1), want)
+
+
+def test_example_indices():
+    g, ex = util.golden("masks"), util.golden("example")
+    mask = util.unpack(g["assets_mask/mask"], g["assets_mask/shape"])
+    assert int(mask.sum()) == 10127  # assets/mask.npy has 10127 true px
+    idx = oracle.reduce_mask(mask, 6, 4, 1)
+    assert idx.shape[0] == 783       # SURVEY.md 3a [probe]: 783 active blocks of 4225
+    assert np.array_equal(idx.numpy(), ex["c16_32/idx"])
