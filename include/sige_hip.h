@@ -1,0 +1,170 @@
+/*
+ * sige_hip.h -- C ABI of libsige_hip.so: the MI355X (gfx950) native backend of
+ * SIGE's tiling-based sparse convolution path.
+ *
+ * This is the drop-in boundary for the path: every entry point replaces one
+ * function of the reference's native backend surface (the five functions each of
+ * sige/cpu/pybind_cpu.cpp:5-12, sige/cuda/pybind_cuda.cpp:5-12 export), plus the
+ * index reduction of sige/utils.py:8-37 and the stacked-block convolution the
+ * reference delegates to F.conv2d (sige/nn/base.py:85-92).
+ *
+ * Conventions
+ *   - plain C: device pointers + sizes, no torch types.  All tensors are dense,
+ *     contiguous, NCHW, fp32 (the reference is fp32-only: sige/nn/base.py:15);
+ *     index tensors are int32 [N,2] = (h, w) tile origins in the INPUT
+ *     coordinates of the paired conv (sige/utils.py:30-37).
+ *   - the CALLER allocates outputs (the reference's wrappers call torch::empty /
+ *     y.clone() themselves: gather.cpp:75, scatter.cpp:83); nothing here
+ *     allocates, frees or synchronises, so every call is hipGraph-capturable.
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued on it and the
+ *     call returns immediately (the reference launches on the legacy default
+ *     stream with no error check: sige/cuda/gather_kernel.cu:113).
+ *   - broadcastable operands (scale / shift / residual) are passed as a pointer
+ *     (NULL = absent) plus their four dims, each either 1 or the full extent
+ *     (binary_op_array, sige/cpu/common_cpu.cpp:13-27).
+ *   - return value: SIGE_HIP_OK or a negative SIGE_HIP_E* code; the reference's
+ *     asserts / __builtin_unreachable (sige/common.cpp:17-23) become
+ *     SIGE_HIP_EINVAL / SIGE_HIP_EUNSUPPORTED.
+ */
+#ifndef SIGE_HIP_H
+#define SIGE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIGE_HIP_VERSION 100 /* 0.1.0 */
+
+enum {
+    SIGE_HIP_OK = 0,
+    SIGE_HIP_EINVAL = -1,       /* bad pointer / negative or inconsistent size */
+    SIGE_HIP_EUNSUPPORTED = -2, /* unknown activation, unsupported shape */
+    SIGE_HIP_ELAUNCH = -3,      /* hipGetLastError() after the launch was not hipSuccess */
+    SIGE_HIP_ENODEVICE = -4     /* no gfx950 device visible to the process */
+};
+
+/* activation ids: the two names the reference's native code knows
+ * (sige/common.cpp:4,11-23). */
+enum { SIGE_HIP_ACT_IDENTITY = 0, SIGE_HIP_ACT_SWISH = 1 };
+
+int sige_hip_version(void);
+const char *sige_hip_error_string(int status);
+/* name of device 0's gcnArchName ("gfx950...") or NULL if no device. */
+const char *sige_hip_device_arch(void);
+
+/* ---- gather : replaces gather_cpu / gather_cuda -------------------------
+ * (sige/cpu/gather.cpp:60-114, sige/cuda/gather_kernel.cu:69-124, gather.h:5-12)
+ * x [B,C,H,W] -> out [B*N,C,bH,bW];  out-of-image elements are exactly 0.   */
+int sige_hip_gather_f32(const float *x, int B, int C, int H, int W, int bH, int bW,
+                        const int32_t *active_indices, int N,
+                        const float *scale, int scaleB, int scaleC, int scaleH, int scaleW,
+                        const float *shift, int shiftB, int shiftC, int shiftH, int shiftW,
+                        int activation, int activation_first, float *out, void *stream);
+
+/* ---- scatter : replaces scatter_cpu / scatter_cuda ----------------------
+ * (sige/cpu/scatter.cpp:70-109, sige/cuda/scatter_kernel.cu:76-117, scatter.h:5-11)
+ * out [B,C,H,W] = y, with the tiles x [B*N,C,R,S] written at (off+idx)/stride
+ * (clipped bottom/right) + residual.  `out` must not alias `y`.
+ * Works for ARBITRARY index lists (copy pass + tile pass).                   */
+int sige_hip_scatter_f32(const float *x, const float *y, int B, int C, int H, int W, int R, int S,
+                         int offsetH, int offsetW, int strideH, int strideW,
+                         const int32_t *active_indices, int N,
+                         const float *residual, int resB, int resC, int resH, int resW,
+                         float *out, void *stream);
+
+/* ---- scatter_with_block_residual : replaces scatter_with_block_residual_*
+ * (sige/cpu/scatter.cpp:111-135, sige/cuda/scatter_kernel.cu:119-146, scatter.h:13-19)
+ * out = scatter(x0, y0, residual = y1); out += x1 - y1 on the shortcut tiles
+ * idx1 (coordinates used directly).                                          */
+int sige_hip_scatter_with_block_residual_f32(
+        const float *x0, const float *y0, const float *x1, const float *y1,
+        int B, int C, int H, int W, int R0, int S0, int R1, int S1,
+        int offsetH, int offsetW, int strideH, int strideW,
+        const int32_t *active_indices0, int N0, const int32_t *active_indices1, int N1,
+        float *out, void *stream);
+
+/* ---- tile table + fused single-pass scatter (MI355X-first fast path) ------
+ * For index lists produced by reduce_mask, output tiles lie on a regular grid
+ * of pitch (R,S) (block_stride = out_tile * conv_stride, sige/nn/gather.py:37),
+ * so "which tile covers pixel (h,w)" is a [gH,gW] int32 lookup, gH=ceil(H/R).
+ * sige_hip_tile_table_i32 builds it (cells with no tile = -1); the *_fused
+ * variants then produce `out` in ONE streaming pass (no clone + overwrite).
+ * Results are bit-identical to the two-pass entry points above.             */
+int sige_hip_tile_table_i32(const int32_t *active_indices, int N, int offsetH, int offsetW,
+                            int strideH, int strideW, int R, int S, int gH, int gW,
+                            int32_t *table, void *stream);
+int sige_hip_scatter_fused_f32(const float *x, const float *y, int B, int C, int H, int W, int R, int S,
+                               const int32_t *table, int gH, int gW, int N,
+                               const float *residual, int resB, int resC, int resH, int resW,
+                               float *out, void *stream);
+int sige_hip_scatter_with_block_residual_fused_f32(
+        const float *x0, const float *y0, const float *x1, const float *y1,
+        int B, int C, int H, int W, int R0, int S0, int R1, int S1,
+        const int32_t *table0, int gH0, int gW0, int N0,
+        const int32_t *table1, int gH1, int gW1, int N1,
+        float *out, void *stream);
+
+/* ---- get_scatter_map : replaces get_scatter_map_cpu / _cuda ---------------
+ * (sige/cpu/scatter_gather.cpp:150-170, scatter_gather_kernel.cu:160-188,
+ *  scatter_gather.h:16-22).  map int32 [H,W,3] = (tile, r, s) or -1 triples.  */
+int sige_hip_scatter_map_i32(int H, int W, int bH, int bW, int kH, int kW,
+                             int offsetH, int offsetW, int strideH, int strideW,
+                             const int32_t *active_indices, int N, int32_t *map, void *stream);
+
+/* ---- scatter_gather : replaces scatter_gather_cpu / _cuda -----------------
+ * (sige/cpu/scatter_gather.cpp:86-148, scatter_gather_kernel.cu:100-158,
+ *  scatter_gather.h:5-14).  x [B*N,C,Rx,Sx] conv-1 output tiles, y [B,C,H,W]
+ * cached full tensor -> out [B*N,C,bH,bW] (input tiles of the next conv).    */
+int sige_hip_scatter_gather_f32(const float *x, const float *y, int B, int C, int H, int W,
+                                int Rx, int Sx, int bH, int bW,
+                                const int32_t *active_indices, int N, const int32_t *scatter_map,
+                                const float *scale, int scaleB, int scaleC, int scaleH, int scaleW,
+                                const float *shift, int shiftB, int shiftC, int shiftH, int shiftW,
+                                int activation, int activation_first, float *out, void *stream);
+
+/* ---- reduce_mask : replaces sige.utils.reduce_mask ------------------------
+ * (sige/utils.py:8-37: F.pad -> F.max_pool2d -> nonzero -> stride*i - pad).
+ * mask: H*W bytes (non-zero = edited).  Writes up to `capacity` (h,w) pairs in
+ * row-major order of the candidate grid to `indices` and the TOTAL number of
+ * active tiles to *count (device int32).  The candidate grid is
+ * ((H+padH)/strH+1) x ((W+padW)/strW+1); sige_hip_reduce_mask_capacity returns
+ * its size.                                                                  */
+int sige_hip_reduce_mask_capacity(int H, int W, int strideH, int strideW, int padH, int padW);
+int sige_hip_reduce_mask_i32(const uint8_t *mask, int H, int W, int bH, int bW,
+                             int strideH, int strideW, int padH, int padW,
+                             int32_t *indices, int capacity, int32_t *count, void *stream);
+
+/* ---- stacked-block convolution : replaces the F.conv2d call of
+ * SIGEConv2d.forward in sparse mode (sige/nn/base.py:88-89) ----------------
+ * x [T,Cin,R,S] (*) w [Cout,Cin/groups,kH,kW] + bias -> out [T,Cout,Ro,So],
+ * padding 0, dilation 1, Ro=(R-kH)/strH+1.
+ * The MFMA path (fp32-in/fp32-acc v_mfma_f32_32x32x2_f32, exact fp32 products)
+ * needs the weights re-laid once per weight tensor:
+ *   n = sige_hip_block_conv_packed_size(...)   floats to allocate (0 = this shape
+ *                                              has no MFMA path; use _direct)
+ *   sige_hip_block_conv_pack_f32(w, ..., packed)
+ *   sige_hip_block_conv_f32(x, ..., packed, bias, ..., out)
+ * sige_hip_block_conv_direct_f32 is the any-shape (groups, odd tiles) vector
+ * FMA kernel reading the original weight layout.                             */
+size_t sige_hip_block_conv_packed_size(int Cout, int Cin, int kH, int kW, int R, int S,
+                                       int strideH, int strideW, int groups);
+int sige_hip_block_conv_pack_f32(const float *w, int Cout, int Cin, int kH, int kW,
+                                 float *packed, void *stream);
+int sige_hip_block_conv_f32(const float *x, int T, int Cin, int R, int S,
+                            const float *packed, const float *bias, int Cout, int kH, int kW,
+                            int strideH, int strideW, float *out, void *stream);
+int sige_hip_block_conv_direct_f32(const float *x, int T, int Cin, int R, int S,
+                                   const float *w, const float *bias, int Cout, int kH, int kW,
+                                   int strideH, int strideW, int groups, float *out, void *stream);
+
+/* ---- plain device copy used by the cache broadcast path (packs the cached
+ * activations of Scatter / ScatterGather modules into one buffer) ---------- */
+int sige_hip_copy_f32(const float *src, float *dst, size_t n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIGE_HIP_H */

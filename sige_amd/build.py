@@ -1,0 +1,62 @@
+"""Build libsige_hip.so (gfx950) in-tree with hipcc.
+
+`python -m sige_amd.build` or `sige_amd.build.build()`; __graft_entry__.build()
+calls this.  hipcc cross-compiles without a GPU.  The .so is git-ignored but
+travels to the GPU box with the gpurun snapshot.
+"""
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB_DIR = os.path.join(PKG, "lib")
+LIB = os.path.join(LIB_DIR, "libsige_hip.so")
+SOURCES = ["api.hip", "gather.hip", "scatter.hip", "reduce_mask.hip", "block_conv.hip"]
+# -ffp-contract=off: the reference applies scale then shift as two separately
+# rounded fp32 ops (sige/cpu/gather.cpp:33-53); an fma would differ in the last bit.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.isfile(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def needs_build() -> bool:
+    if not os.path.isfile(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(REPO, "include", "sige_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(LIB_DIR, exist_ok=True)
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+        cmd = [_hipcc(), *FLAGS, "-I" + os.path.join(REPO, "include"), "-I" + CSRC, "-c",
+               os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    if verbose:
+        print(" ".join(link), flush=True)
+    subprocess.check_call(link)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

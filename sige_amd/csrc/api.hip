@@ -1,0 +1,25 @@
+// Version / error / device queries of libsige_hip.so.
+#include "common.hpp"
+
+extern "C" int sige_hip_version(void) { return SIGE_HIP_VERSION; }
+
+extern "C" const char *sige_hip_error_string(int status) {
+    switch (status) {
+        case SIGE_HIP_OK: return "ok";
+        case SIGE_HIP_EINVAL: return "invalid argument (null pointer, negative or inconsistent size, non-broadcastable operand)";
+        case SIGE_HIP_EUNSUPPORTED: return "unsupported (unknown activation or shape outside the kernel's limits)";
+        case SIGE_HIP_ELAUNCH: return "HIP launch failed (hipGetLastError != hipSuccess)";
+        case SIGE_HIP_ENODEVICE: return "no HIP device";
+        default: return "unknown status";
+    }
+}
+
+extern "C" const char *sige_hip_device_arch(void) {
+    static char arch[256];
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return nullptr;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return nullptr;
+    snprintf(arch, sizeof(arch), "%s", prop.gcnArchName);
+    return arch;
+}

@@ -1,0 +1,74 @@
+// Shared device/host helpers for libsige_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sige_hip.h"
+
+namespace sige {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+// A broadcastable 4-D operand as element strides (0 on broadcast dims).
+// data == nullptr  <=>  operand absent.
+struct Bcast4 {
+    const float *data;
+    int sb, sc, sh, sw;
+};
+
+inline bool bcast_ok(const float *p, int b, int c, int h, int w, int B, int C, int H, int W) {
+    if (!p) return true;
+    auto ok = [](int d, int full) { return d == 1 || d == full; };
+    return ok(b, B) && ok(c, C) && ok(h, H) && ok(w, W);
+}
+
+inline Bcast4 make_bcast(const float *p, int b, int c, int h, int w) {
+    Bcast4 r{p, 0, 0, 0, 0};
+    if (!p) return r;
+    r.sw = (w > 1) ? 1 : 0;
+    r.sh = (h > 1) ? w : 0;
+    r.sc = (c > 1) ? h * w : 0;
+    r.sb = (b > 1) ? c * h * w : 0;
+    return r;
+}
+
+__device__ __forceinline__ float bcast_load(const Bcast4 &t, int b, int c, int h, int w) {
+    return t.data[(size_t)b * t.sb + (size_t)c * t.sc + (size_t)h * t.sh + (size_t)w * t.sw];
+}
+
+// SiLU.  The reference evaluates z / (1.0 + exp(-z)) with the sum and quotient
+// in double (sige/cpu/common_cpu.cpp:29-35); fp32 here is within 1e-6 relative.
+__device__ __forceinline__ float swish(float z) { return z / (1.0f + expf(-z)); }
+
+template <int ACT>
+__device__ __forceinline__ float activate(float z) {
+    if (ACT == SIGE_HIP_ACT_SWISH) return swish(z);
+    return z;
+}
+
+// scale/shift + activation in the reference's order (gather.cpp:33-53):
+// two separately rounded ops (the file is built with -ffp-contract=off).
+template <int ACT, bool ACT_FIRST>
+__device__ __forceinline__ float affine_act(float z, const Bcast4 &scale, const Bcast4 &shift,
+                                            int b, int c, int h, int w) {
+    if (!ACT_FIRST) {
+        if (scale.data) z = bcast_load(scale, b, c, h, w) * z;
+        if (shift.data) z = bcast_load(shift, b, c, h, w) + z;
+    }
+    z = activate<ACT>(z);
+    if (ACT_FIRST) {
+        if (scale.data) z = bcast_load(scale, b, c, h, w) * z;
+        if (shift.data) z = bcast_load(shift, b, c, h, w) + z;
+    }
+    return z;
+}
+
+inline int launch_status() {
+    return hipGetLastError() == hipSuccess ? SIGE_HIP_OK : SIGE_HIP_ELAUNCH;
+}
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace sige

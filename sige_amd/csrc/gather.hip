@@ -1,0 +1,188 @@
+// gather / scatter_gather for gfx950.
+//
+// One workgroup = one active tile x one chunk of channels.  The tile's pixel
+// table (source offset + validity for each of the bH*bW pixels, including the
+// 2-px halo) is computed ONCE per workgroup into LDS; the 256 lanes then stream
+// the [channels][bH][bW] output slab, which is contiguous in HBM, with 16-byte
+// stores (4 consecutive output elements per lane, each with its own source
+// load).  Tile origins are wave-uniform scalar loads.
+//
+// Replaces: gather_cpu_kernel / gather_cuda_kernel (sige/cpu/gather.cpp:4-58,
+// sige/cuda/gather_kernel.cu:7-67: one thread per element, four integer
+// div/mod and an index re-read per element) and scatter_gather_*_kernel
+// (sige/cpu/scatter_gather.cpp:5-56, scatter_gather_kernel.cu:8-67: a 12-byte
+// map read per element per channel).
+#include "common.hpp"
+
+namespace sige {
+
+constexpr int kGatherThreads = 256;
+constexpr int kMaxTilePixels = 1024;  // bH*bW upper bound for the LDS pixel table
+
+struct GatherArgs {
+    const float *x;        // gather: full input [B,C,H,W]; scatter_gather: conv-1 tiles [B*N,C,Rx,Sx]
+    const float *y;        // scatter_gather only: cached full tensor [B,C,H,W]
+    float *out;            // [B*N,C,bH,bW]
+    const int32_t *idx;    // [N,2]
+    const int32_t *map;    // scatter_gather only: [H,W,3]
+    int B, C, H, W, N;
+    int bH, bW;            // used when the template block dims are 0
+    int RxSx, Sx;          // scatter_gather: x tile pixels / row length
+    int cchunk;            // channels per workgroup
+    Bcast4 scale, shift;
+};
+
+// src code per pixel:  -2 out of image (output 0) | -1 read y (mapped only) |
+// >=0  gather: h*W+w ; scatter_gather: blk*C*RxSx + hx*Sx + wx
+template <int TR, int TS, int ACT, bool ACT_FIRST, bool MAPPED, int VEC>
+__global__ __launch_bounds__(kGatherThreads) void gather_kernel(GatherArgs a) {
+    const int R = TR ? TR : a.bH, S = TS ? TS : a.bW;
+    const int RS = R * S;
+    __shared__ int s_src[TR ? TR * TS : kMaxTilePixels];
+    __shared__ int s_hw[TR ? TR * TS : kMaxTilePixels];
+
+    const int tile = blockIdx.x;  // b*N + n
+    const int b = tile / a.N, n = tile - b * a.N;
+    const int c0 = blockIdx.y * a.cchunk;
+    const int cc = min(a.cchunk, a.C - c0);
+    const int h0 = a.idx[2 * n], w0 = a.idx[2 * n + 1];
+
+    for (int p = threadIdx.x; p < RS; p += kGatherThreads) {
+        const int r = p / S, s = p - r * S;
+        const int h = h0 + r, w = w0 + s;
+        int src = -2;
+        if (h >= 0 && h < a.H && w >= 0 && w < a.W) {
+            if (MAPPED) {
+                const int32_t *m = a.map + 3 * ((size_t)h * a.W + w);
+                const int blk = m[0];
+                src = blk >= 0 ? blk * a.C * a.RxSx + m[1] * a.Sx + m[2] : -1;
+            } else {
+                src = h * a.W + w;
+            }
+        }
+        s_src[p] = src;
+        s_hw[p] = (h << 16) | (w & 0xffff);
+    }
+    __syncthreads();
+
+    const size_t HW = (size_t)a.H * a.W;
+    const float *xb = MAPPED ? a.x + (size_t)b * a.N * a.C * a.RxSx : a.x + (size_t)b * a.C * HW;
+    const float *yb = a.y + (size_t)b * a.C * HW;
+    float *ob = a.out + ((size_t)tile * a.C + c0) * RS;
+    const int total = cc * RS;
+
+    for (int e0 = threadIdx.x * VEC; e0 < total; e0 += kGatherThreads * VEC) {
+        float v[VEC];
+        int cl = e0 / RS;
+        int p = e0 - cl * RS;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const int c = c0 + cl;
+            const int src = s_src[p];
+            float z = 0.0f;
+            if (src != -2) {
+                if (MAPPED)
+                    z = (src >= 0) ? xb[(size_t)c * a.RxSx + src] : yb[(size_t)c * HW + (s_hw[p] >> 16) * a.W + (s_hw[p] & 0xffff)];
+                else
+                    z = xb[(size_t)c * HW + src];
+                if (ACT != SIGE_HIP_ACT_IDENTITY || a.scale.data || a.shift.data) {
+                    const int hw = s_hw[p];
+                    z = affine_act<ACT, ACT_FIRST>(z, a.scale, a.shift, b, c, hw >> 16, hw & 0xffff);
+                }
+            }
+            v[i] = z;
+            if (++p == RS) { p = 0; ++cl; }
+        }
+        if (VEC == 4) {
+            *reinterpret_cast<float4 *>(ob + e0) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) ob[e0 + i] = v[i];
+        }
+    }
+}
+
+template <int TR, int TS, bool MAPPED, int VEC>
+static void launch_act(const GatherArgs &a, int act, bool first, dim3 grid, hipStream_t st) {
+    dim3 blk(kGatherThreads);
+    if (act == SIGE_HIP_ACT_SWISH) {
+        if (first) gather_kernel<TR, TS, SIGE_HIP_ACT_SWISH, true, MAPPED, VEC><<<grid, blk, 0, st>>>(a);
+        else gather_kernel<TR, TS, SIGE_HIP_ACT_SWISH, false, MAPPED, VEC><<<grid, blk, 0, st>>>(a);
+    } else {
+        // identity: activation_first does not change the result
+        gather_kernel<TR, TS, SIGE_HIP_ACT_IDENTITY, false, MAPPED, VEC><<<grid, blk, 0, st>>>(a);
+    }
+}
+
+template <bool MAPPED>
+static int launch(GatherArgs a, int act, bool first, hipStream_t st) {
+    const int RS = a.bH * a.bW;
+    if (RS > kMaxTilePixels) return SIGE_HIP_EUNSUPPORTED;
+    const int tiles = a.B * a.N;
+    if (tiles == 0 || a.C == 0 || RS == 0) return SIGE_HIP_OK;  // N = 0: empty output
+    // channels per workgroup: ~2K-4K elements, but keep >= ~512 workgroups when the problem allows
+    int cchunk = max(4, (4096 / RS) & ~3);
+    while (cchunk > 8 && (long)tiles * ceil_div(a.C, cchunk) < 512) cchunk = (cchunk / 2) & ~3;
+    if (cchunk < 4) cchunk = 4;
+    a.cchunk = cchunk;
+    dim3 grid(tiles, ceil_div(a.C, cchunk));
+    const bool vec4 = ((long)a.C * RS) % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
+#define SIGE_DISPATCH(TR, TS)                                                    \
+    do {                                                                         \
+        if (vec4) launch_act<TR, TS, MAPPED, 4>(a, act, first, grid, st);        \
+        else launch_act<TR, TS, MAPPED, 1>(a, act, first, grid, st);             \
+    } while (0)
+    if (a.bH == 6 && a.bW == 6) SIGE_DISPATCH(6, 6);
+    else if (a.bH == 4 && a.bW == 4) SIGE_DISPATCH(4, 4);
+    else if (a.bH == 5 && a.bW == 5) SIGE_DISPATCH(5, 5);
+    else SIGE_DISPATCH(0, 0);
+#undef SIGE_DISPATCH
+    return launch_status();
+}
+
+}  // namespace sige
+
+using namespace sige;
+
+extern "C" int sige_hip_gather_f32(const float *x, int B, int C, int H, int W, int bH, int bW,
+                                   const int32_t *active_indices, int N,
+                                   const float *scale, int scaleB, int scaleC, int scaleH, int scaleW,
+                                   const float *shift, int shiftB, int shiftC, int shiftH, int shiftW,
+                                   int activation, int activation_first, float *out, void *stream) {
+    if (B < 0 || C < 0 || H < 0 || W < 0 || N < 0 || bH <= 0 || bW <= 0) return SIGE_HIP_EINVAL;
+    if (H >= 32768 || W >= 32768) return SIGE_HIP_EUNSUPPORTED;
+    if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
+    if ((long)B * N * C > 0 && (!x || !out || !active_indices)) return SIGE_HIP_EINVAL;
+    if (!bcast_ok(scale, scaleB, scaleC, scaleH, scaleW, B, C, H, W) ||
+        !bcast_ok(shift, shiftB, shiftC, shiftH, shiftW, B, C, H, W))
+        return SIGE_HIP_EINVAL;
+    GatherArgs a{};
+    a.x = x; a.y = nullptr; a.out = out; a.idx = active_indices; a.map = nullptr;
+    a.B = B; a.C = C; a.H = H; a.W = W; a.N = N; a.bH = bH; a.bW = bW;
+    a.scale = make_bcast(scale, scaleB, scaleC, scaleH, scaleW);
+    a.shift = make_bcast(shift, shiftB, shiftC, shiftH, shiftW);
+    return launch<false>(a, activation, activation_first != 0, as_stream(stream));
+}
+
+extern "C" int sige_hip_scatter_gather_f32(const float *x, const float *y, int B, int C, int H, int W,
+                                           int Rx, int Sx, int bH, int bW,
+                                           const int32_t *active_indices, int N, const int32_t *scatter_map,
+                                           const float *scale, int scaleB, int scaleC, int scaleH, int scaleW,
+                                           const float *shift, int shiftB, int shiftC, int shiftH, int shiftW,
+                                           int activation, int activation_first, float *out, void *stream) {
+    if (B < 0 || C < 0 || H < 0 || W < 0 || N < 0 || bH <= 0 || bW <= 0 || Rx <= 0 || Sx <= 0) return SIGE_HIP_EINVAL;
+    if (H >= 32768 || W >= 32768) return SIGE_HIP_EUNSUPPORTED;
+    if ((long)N * C * Rx * Sx >= (1L << 31)) return SIGE_HIP_EUNSUPPORTED;
+    if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
+    if ((long)B * N * C > 0 && (!x || !y || !out || !active_indices || !scatter_map)) return SIGE_HIP_EINVAL;
+    if (!bcast_ok(scale, scaleB, scaleC, scaleH, scaleW, B, C, H, W) ||
+        !bcast_ok(shift, shiftB, shiftC, shiftH, shiftW, B, C, H, W))
+        return SIGE_HIP_EINVAL;
+    GatherArgs a{};
+    a.x = x; a.y = y; a.out = out; a.idx = active_indices; a.map = scatter_map;
+    a.B = B; a.C = C; a.H = H; a.W = W; a.N = N; a.bH = bH; a.bW = bW;
+    a.RxSx = Rx * Sx; a.Sx = Sx;
+    a.scale = make_bcast(scale, scaleB, scaleC, scaleH, scaleW);
+    a.shift = make_bcast(shift, shiftB, shiftC, shiftH, shiftW);
+    return launch<true>(a, activation, activation_first != 0, as_stream(stream));
+}

@@ -1,0 +1,299 @@
+"""`sige_amd.hip` -- the MI355X native backend, bound over the C ABI of
+libsige_hip.so (include/sige_hip.h).
+
+This module is the equivalent of the reference's `sige.cuda` extension module
+(sige/cuda/pybind_cuda.cpp:5-12): it exports the same five functions with the
+same positional signatures on torch tensors
+
+    gather, scatter, scatter_with_block_residual, scatter_gather, get_scatter_map
+
+so `SIGEModule.load_runtime` (sige/nn/base.py:35-50) finds them under the
+"cuda" key (torch-ROCm tensors report device.type == "cuda").  On top of that it
+exports the MI355X-first extras the sige_amd.nn modules use: fused single-pass
+scatter (tile tables), device reduce_mask, and the MFMA stacked-block conv.
+
+There is NO fallback: if the shared library is missing or a call fails, a
+RuntimeError is raised.  torch is used only for allocation and the stream.
+"""
+import ctypes
+import os
+from typing import Optional, Tuple
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("SIGE_HIP_LIB", os.path.join(_PKG, "lib", "libsige_hip.so"))
+
+ACT = {"identity": 0, "swish": 1}
+
+_c_int, _c_vp, _c_sz = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
+_lib = None
+
+_BC = [_c_vp, _c_int, _c_int, _c_int, _c_int]  # broadcastable operand: ptr + 4 dims
+
+_SIGNATURES = {
+    "sige_hip_version": (_c_int, []),
+    "sige_hip_error_string": (ctypes.c_char_p, [_c_int]),
+    "sige_hip_device_arch": (ctypes.c_char_p, []),
+    "sige_hip_gather_f32": (_c_int, [_c_vp] + [_c_int] * 6 + [_c_vp, _c_int] + _BC + _BC + [_c_int, _c_int, _c_vp, _c_vp]),
+    "sige_hip_scatter_f32": (_c_int, [_c_vp, _c_vp] + [_c_int] * 10 + [_c_vp, _c_int] + _BC + [_c_vp, _c_vp]),
+    "sige_hip_scatter_with_block_residual_f32": (
+        _c_int, [_c_vp] * 4 + [_c_int] * 12 + [_c_vp, _c_int, _c_vp, _c_int, _c_vp, _c_vp]),
+    "sige_hip_tile_table_i32": (_c_int, [_c_vp] + [_c_int] * 9 + [_c_vp, _c_vp]),
+    "sige_hip_scatter_fused_f32": (_c_int, [_c_vp, _c_vp] + [_c_int] * 6 + [_c_vp, _c_int, _c_int, _c_int] + _BC + [_c_vp, _c_vp]),
+    "sige_hip_scatter_with_block_residual_fused_f32": (
+        _c_int, [_c_vp] * 4 + [_c_int] * 8 + [_c_vp, _c_int, _c_int, _c_int] * 2 + [_c_vp, _c_vp]),
+    "sige_hip_scatter_map_i32": (_c_int, [_c_int] * 10 + [_c_vp, _c_int, _c_vp, _c_vp]),
+    "sige_hip_scatter_gather_f32": (
+        _c_int, [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + _BC + _BC + [_c_int, _c_int, _c_vp, _c_vp]),
+    "sige_hip_reduce_mask_capacity": (_c_int, [_c_int] * 6),
+    "sige_hip_reduce_mask_i32": (_c_int, [_c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp, _c_vp]),
+    "sige_hip_block_conv_packed_size": (_c_sz, [_c_int] * 9),
+    "sige_hip_block_conv_pack_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp]),
+    "sige_hip_block_conv_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp, _c_vp]),
+    "sige_hip_block_conv_direct_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp] + [_c_int] * 6 + [_c_vp, _c_vp]),
+    "sige_hip_copy_f32": (_c_int, [_c_vp, _c_vp, _c_sz, _c_vp]),
+}
+
+EXPORTS = tuple(_SIGNATURES)  # every symbol include/sige_hip.h declares
+
+
+def lib():
+    """Load libsige_hip.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(
+                "sige_amd: %s not found -- the HIP extension is not built "
+                "(run `python -m sige_amd.build`); there is no CPU fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def available() -> bool:
+    return os.path.isfile(LIB_PATH)
+
+
+def _check(status: int, what: str):
+    if status != 0:
+        raise RuntimeError("sige_amd.hip.%s failed: %s" % (what, lib().sige_hip_error_string(status).decode()))
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _req(t: torch.Tensor, dtype, name: str, dim: Optional[int] = 4):
+    if not t.is_cuda:
+        raise RuntimeError("sige_amd.hip: `%s` must live on the GPU (got %s)" % (name, t.device))
+    if t.dtype != dtype:
+        raise NotImplementedError("sige_amd.hip: `%s` must be %s (got %s)" % (name, dtype, t.dtype))
+    if dim is not None and t.dim() != dim:
+        raise NotImplementedError("sige_amd.hip: `%s` must have %d dims (got %d)" % (name, dim, t.dim()))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _bc(t: Optional[torch.Tensor], name: str):
+    """(ptr, B, C, H, W) of an optional broadcastable fp32 operand."""
+    if t is None:
+        return (None, 0, 0, 0, 0), None
+    t = _req(t, torch.float32, name)
+    return (t.data_ptr(), t.shape[0], t.shape[1], t.shape[2], t.shape[3]), t
+
+
+def _act(name: str) -> int:
+    try:
+        return ACT[name]
+    except KeyError:
+        # the reference's native code hits __builtin_unreachable here (sige/common.cpp:17-23)
+        raise ValueError("Unknown activation: [%s]!!!" % name)
+
+
+# --------------------------------------------------------------------------
+# The five reference-signature entry points (sige/cuda/pybind_cuda.cpp:5-12)
+# --------------------------------------------------------------------------
+def gather(x, bSizeH, bSizeW, activeIndices, scale=None, shift=None, activationName="identity",
+           activationFirst=False):
+    x = _req(x, torch.float32, "x")
+    idx = _req(activeIndices, torch.int32, "activeIndices", 2)
+    (sa, s_keep), (ta, t_keep) = _bc(scale, "scale"), _bc(shift, "shift")
+    B, C, H, W = x.shape
+    N = idx.shape[0]
+    out = torch.empty((B * N, C, bSizeH, bSizeW), dtype=torch.float32, device=x.device)
+    _check(lib().sige_hip_gather_f32(x.data_ptr(), B, C, H, W, bSizeH, bSizeW, idx.data_ptr(), N, *sa, *ta,
+                                     _act(activationName), int(bool(activationFirst)), out.data_ptr(),
+                                     _stream(x)), "gather")
+    return out
+
+
+def scatter(x, y, offsetH, offsetW, strideH, strideW, activeIndices, residual=None):
+    x = _req(x, torch.float32, "x")
+    y = _req(y, torch.float32, "y")
+    idx = _req(activeIndices, torch.int32, "activeIndices", 2)
+    ra, r_keep = _bc(residual, "residual")
+    B, C, H, W = y.shape
+    out = torch.empty_like(y)
+    _check(lib().sige_hip_scatter_f32(x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3],
+                                      offsetH, offsetW, strideH, strideW, idx.data_ptr(), idx.shape[0], *ra,
+                                      out.data_ptr(), _stream(y)), "scatter")
+    return out
+
+
+def scatter_with_block_residual(x0, y0, x1, y1, offsetH, offsetW, strideH, strideW, activeIndices0,
+                                activeIndices1):
+    x0, y0 = _req(x0, torch.float32, "x0"), _req(y0, torch.float32, "y0")
+    x1, y1 = _req(x1, torch.float32, "x1"), _req(y1, torch.float32, "y1")
+    i0 = _req(activeIndices0, torch.int32, "activeIndices0", 2)
+    i1 = _req(activeIndices1, torch.int32, "activeIndices1", 2)
+    if y1.shape != y0.shape:
+        raise RuntimeError("scatter_with_block_residual: y1 %s must match y0 %s" % (tuple(y1.shape), tuple(y0.shape)))
+    B, C, H, W = y0.shape
+    out = torch.empty_like(y0)
+    _check(lib().sige_hip_scatter_with_block_residual_f32(
+        x0.data_ptr(), y0.data_ptr(), x1.data_ptr(), y1.data_ptr(), B, C, H, W,
+        x0.shape[2], x0.shape[3], x1.shape[2], x1.shape[3], offsetH, offsetW, strideH, strideW,
+        i0.data_ptr(), i0.shape[0], i1.data_ptr(), i1.shape[0], out.data_ptr(), _stream(y0)),
+        "scatter_with_block_residual")
+    return out
+
+
+def get_scatter_map(H, W, bSizeH, bSizeW, kSizeH, kSizeW, offsetH, offsetW, strideH, strideW, activeIndices):
+    idx = _req(activeIndices, torch.int32, "activeIndices", 2)
+    out = torch.empty((H, W, 3), dtype=torch.int32, device=idx.device)
+    _check(lib().sige_hip_scatter_map_i32(H, W, bSizeH, bSizeW, kSizeH, kSizeW, offsetH, offsetW, strideH, strideW,
+                                          idx.data_ptr(), idx.shape[0], out.data_ptr(), _stream(idx)),
+           "get_scatter_map")
+    return out
+
+
+def scatter_gather(x, y, bSizeH, bSizeW, activeIndices, scatterMap, scale=None, shift=None,
+                   activationName="identity", activationFirst=False):
+    x, y = _req(x, torch.float32, "x"), _req(y, torch.float32, "y")
+    idx = _req(activeIndices, torch.int32, "activeIndices", 2)
+    smap = _req(scatterMap, torch.int32, "scatterMap", 3)
+    (sa, s_keep), (ta, t_keep) = _bc(scale, "scale"), _bc(shift, "shift")
+    B, C, H, W = y.shape
+    if x.shape[1] != C:
+        raise RuntimeError("scatter_gather: channel mismatch x %d vs y %d" % (x.shape[1], C))
+    N = idx.shape[0]
+    out = torch.empty((B * N, C, bSizeH, bSizeW), dtype=torch.float32, device=y.device)
+    _check(lib().sige_hip_scatter_gather_f32(x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3],
+                                             bSizeH, bSizeW, idx.data_ptr(), N, smap.data_ptr(), *sa, *ta,
+                                             _act(activationName), int(bool(activationFirst)), out.data_ptr(),
+                                             _stream(y)), "scatter_gather")
+    return out
+
+
+# --------------------------------------------------------------------------
+# MI355X-first extras
+# --------------------------------------------------------------------------
+def tile_table(activeIndices, offset: Tuple[int, int], stride: Tuple[int, int], out_tile: Tuple[int, int],
+               out_res: Tuple[int, int]) -> torch.Tensor:
+    """[gH,gW] int32: which tile of `activeIndices` covers each out_tile-sized cell
+    of an out_res tensor (-1 = none).  Valid for reduce_mask index lists."""
+    idx = _req(activeIndices, torch.int32, "activeIndices", 2)
+    gH, gW = -(-out_res[0] // out_tile[0]), -(-out_res[1] // out_tile[1])
+    table = torch.empty((gH, gW), dtype=torch.int32, device=idx.device)
+    _check(lib().sige_hip_tile_table_i32(idx.data_ptr(), idx.shape[0], offset[0], offset[1], stride[0], stride[1],
+                                         out_tile[0], out_tile[1], gH, gW, table.data_ptr(), _stream(idx)),
+           "tile_table")
+    return table
+
+
+def scatter_fused(x, y, table, num_active: int, residual=None):
+    x, y = _req(x, torch.float32, "x"), _req(y, torch.float32, "y")
+    table = _req(table, torch.int32, "table", 2)
+    ra, r_keep = _bc(residual, "residual")
+    B, C, H, W = y.shape
+    out = torch.empty_like(y)
+    _check(lib().sige_hip_scatter_fused_f32(x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3],
+                                            table.data_ptr(), table.shape[0], table.shape[1], num_active, *ra,
+                                            out.data_ptr(), _stream(y)), "scatter_fused")
+    return out
+
+
+def scatter_with_block_residual_fused(x0, y0, x1, y1, table0, n0: int, table1, n1: int):
+    x0, y0 = _req(x0, torch.float32, "x0"), _req(y0, torch.float32, "y0")
+    x1, y1 = _req(x1, torch.float32, "x1"), _req(y1, torch.float32, "y1")
+    table0, table1 = _req(table0, torch.int32, "table0", 2), _req(table1, torch.int32, "table1", 2)
+    B, C, H, W = y0.shape
+    out = torch.empty_like(y0)
+    _check(lib().sige_hip_scatter_with_block_residual_fused_f32(
+        x0.data_ptr(), y0.data_ptr(), x1.data_ptr(), y1.data_ptr(), B, C, H, W,
+        x0.shape[2], x0.shape[3], x1.shape[2], x1.shape[3],
+        table0.data_ptr(), table0.shape[0], table0.shape[1], n0,
+        table1.data_ptr(), table1.shape[0], table1.shape[1], n1, out.data_ptr(), _stream(y0)),
+        "scatter_with_block_residual_fused")
+    return out
+
+
+def reduce_mask(mask: torch.Tensor, block_size, stride, padding) -> torch.Tensor:
+    """Device restatement of sige.utils.reduce_mask (sige/utils.py:8-37) for a CUDA
+    bool/uint8 mask [H,W].  One D2H read of the active-tile count (the reference's
+    torch.nonzero synchronises the same way)."""
+    if mask.dim() != 2 or not mask.is_cuda:
+        raise RuntimeError("sige_amd.hip.reduce_mask: expected a 2-D CUDA mask")
+    m = mask if mask.dtype in (torch.bool, torch.uint8) else (mask != 0)
+    m = m.contiguous()
+    H, W = m.shape
+    cap = lib().sige_hip_reduce_mask_capacity(H, W, stride[0], stride[1], padding[0], padding[1])
+    buf = torch.empty((cap + 1, 2), dtype=torch.int32, device=m.device)  # last row holds the count
+    count = buf[cap]
+    _check(lib().sige_hip_reduce_mask_i32(m.data_ptr(), H, W, block_size[0], block_size[1], stride[0], stride[1],
+                                          padding[0], padding[1], buf.data_ptr(), cap, count.data_ptr(),
+                                          _stream(m)), "reduce_mask")
+    n = int(count[0].item())
+    return buf[:n].clone()
+
+
+def conv_packed_size(Cout, Cin, kH, kW, R, S, strH, strW, groups=1) -> int:
+    return int(lib().sige_hip_block_conv_packed_size(Cout, Cin, kH, kW, R, S, strH, strW, groups))
+
+
+def conv_pack_weights(weight: torch.Tensor, R: int, S: int, stride: Tuple[int, int]) -> Optional[torch.Tensor]:
+    """Re-lay a conv weight [Cout,Cin,k,k] for the MFMA block conv; None if the
+    shape has no MFMA path."""
+    w = _req(weight.detach(), torch.float32, "weight")
+    Cout, Cin, kH, kW = w.shape
+    n = conv_packed_size(Cout, Cin, kH, kW, R, S, stride[0], stride[1], 1)
+    if n == 0:
+        return None
+    packed = torch.empty((n,), dtype=torch.float32, device=w.device)
+    _check(lib().sige_hip_block_conv_pack_f32(w.data_ptr(), Cout, Cin, kH, kW, packed.data_ptr(), _stream(w)),
+           "conv_pack_weights")
+    return packed
+
+
+def block_conv(x, packed, bias, Cout: int, kernel: Tuple[int, int], stride: Tuple[int, int]):
+    x = _req(x, torch.float32, "x")
+    T, Cin, R, S = x.shape
+    Ro, So = (R - kernel[0]) // stride[0] + 1, (S - kernel[1]) // stride[1] + 1
+    out = torch.empty((T, Cout, Ro, So), dtype=torch.float32, device=x.device)
+    b = None if bias is None else _req(bias.detach(), torch.float32, "bias", 1).data_ptr()
+    _check(lib().sige_hip_block_conv_f32(x.data_ptr(), T, Cin, R, S, packed.data_ptr(), b, Cout, kernel[0], kernel[1],
+                                         stride[0], stride[1], out.data_ptr(), _stream(x)), "block_conv")
+    return out
+
+
+def block_conv_direct(x, weight, bias, stride: Tuple[int, int], groups: int = 1):
+    x = _req(x, torch.float32, "x")
+    w = _req(weight.detach(), torch.float32, "weight")
+    T, Cin, R, S = x.shape
+    Cout, _, kH, kW = w.shape
+    Ro, So = (R - kH) // stride[0] + 1, (S - kW) // stride[1] + 1
+    out = torch.empty((T, Cout, Ro, So), dtype=torch.float32, device=x.device)
+    b = None if bias is None else _req(bias.detach(), torch.float32, "bias", 1).data_ptr()
+    _check(lib().sige_hip_block_conv_direct_f32(x.data_ptr(), T, Cin, R, S, w.data_ptr(), b, Cout, kH, kW,
+                                                stride[0], stride[1], groups, out.data_ptr(), _stream(x)),
+           "block_conv_direct")
+    return out
+
+
+def copy_(dst: torch.Tensor, src: torch.Tensor):
+    assert dst.numel() == src.numel() and dst.is_contiguous() and src.is_contiguous()
+    _check(lib().sige_hip_copy_f32(src.data_ptr(), dst.data_ptr(), src.numel(), _stream(src)), "copy")
+    return dst

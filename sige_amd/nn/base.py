@@ -1,0 +1,202 @@
+"""Mode / mask / cache plumbing of the sparse-conv modules.
+
+API parity with sige/nn/base.py:10-129 (SIGEModule, SIGEModuleWrapper,
+SIGEConv2d, SIGEModel): same constructor arguments, attributes (`mode`,
+`runtime`, `mask`, `timestamp`, `cache_id`, `sparse_update`, `devices`,
+`supported_dtypes`) and methods, so reference model files work unchanged, incl.
+the multiple-inheritance patterns `class X(nn.Conv2d, SIGEModule)` with
+`call_super=False` and `class Net(SIGEModel, UNetModel)`.
+
+What differs underneath: native functions come from the backend registry
+(sige_amd.runtime) instead of `importlib.import_module("sige.<device>")`, and
+SIGEConv2d's sparse mode runs the MFMA stacked-block convolution of
+libsige_hip.so instead of F.conv2d.
+"""
+import os
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from .. import runtime as _runtime
+
+MODES = ("full", "sparse", "profile")
+
+
+class _RuntimeTable(dict):
+    """`module.runtime[device_type]` -> callable or None, resolved lazily through
+    the backend registry (so importing the package never needs the GPU library)."""
+
+    def __init__(self, function_name: str):
+        super().__init__()
+        self.function_name = function_name
+
+    def __missing__(self, device_type: str):
+        fn = _runtime.resolve(device_type, self.function_name)
+        if fn is not None:  # do not memoise "no backend": a test may register one later
+            self[device_type] = fn
+        return fn
+
+
+class SIGEModule(nn.Module):
+    def __init__(self, call_super: bool = True):
+        if call_super:
+            super(SIGEModule, self).__init__()
+        self.devices: List[str] = ["cpu", "cuda", "mps"]
+        self.supported_dtypes = [torch.float32]
+        self.mode: str = "full"
+        self.runtime: Dict = {}
+        self.mask: Optional[torch.Tensor] = None
+        self.timestamp = None
+        self.cache_id = 0
+        self.sparse_update = False
+
+    # -- mask / cache protocol driven by SIGEModel ---------------------------
+    def set_mask(self, masks: Dict, cache: Dict, timestamp: int):
+        self.timestamp = timestamp
+
+    def set_cache_id(self, cache_id: int):
+        self.cache_id = cache_id
+
+    def clear_cache(self):
+        pass
+
+    def set_sparse_update(self, sparse_update: bool):
+        self.sparse_update = sparse_update
+
+    def set_mode(self, mode: str):
+        self.mode = mode
+
+    # -- native function lookup ---------------------------------------------------
+    def load_runtime(self, function_name: str, runtime_dict: Dict = None):
+        table = _RuntimeTable(function_name)
+        if runtime_dict is None:
+            self.runtime = table
+        return table
+
+    def native(self, table: Dict, x: torch.Tensor):
+        """The native function for `x`'s device, or a loud error (no fallback)."""
+        fn = table[x.device.type]
+        if fn is None:
+            raise RuntimeError(
+                "[%s] no native backend for device type '%s': the sparse path runs on MI355X "
+                "(torch-ROCm 'cuda' tensors) through libsige_hip.so only." % (type(self).__name__, x.device.type))
+        return fn
+
+    # -- argument checks (same exceptions as the reference) ------------------------
+    def check_dtype(self, *args):
+        for x in args:
+            if x is not None:
+                assert isinstance(x, torch.Tensor)
+                if x.dtype not in self.supported_dtypes:
+                    raise NotImplementedError(
+                        "[%s] does not support dtype [%s]!!! "
+                        "Currently supported dtype %s." % (self.__class__.__name__, x.dtype, str(self.supported_dtypes))
+                    )
+
+    def check_dim(self, *args):
+        for x in args:
+            if x is not None:
+                assert isinstance(x, torch.Tensor)
+                if x.dim() != 4:
+                    raise NotImplementedError(
+                        "[%s] does not support input with dim [%d]!!!" % (self.__class__.__name__, x.dim())
+                    )
+
+
+class SIGEModuleWrapper:
+    """Holds a module without registering it as a child (sige/nn/base.py:75-77)."""
+
+    def __init__(self, module: SIGEModule):
+        self.module = module
+
+
+def _conv_backend() -> str:
+    return os.environ.get("SIGE_AMD_CONV", "hip")
+
+
+class SIGEConv2d(nn.Conv2d, SIGEModule):
+    """nn.Conv2d whose `sparse`/`profile` modes convolve pre-padded stacked tiles
+    with padding 0 (sige/nn/base.py:80-92).
+
+    On GPU tensors the sparse mode runs libsige_hip.so's stacked-block conv:
+    the MFMA implicit GEMM for the tile geometries SIGE produces (3x3/s1 on 6x6,
+    1x1 on 4x4, 3x3/s2 on 5x5), the direct vector kernel for any other
+    groups/size, both fp32.  `SIGE_AMD_CONV=torch` selects F.conv2d (MIOpen)
+    instead, for A/B measurements.
+    """
+
+    def __init__(self, *args, **kwargs):
+        nn.Conv2d.__init__(self, *args, **kwargs)
+        SIGEModule.__init__(self, call_super=False)
+        self._packed = None
+        self._packed_key = None
+
+    def _packed_weights(self, x: torch.Tensor):
+        from .. import hip
+
+        w = self.weight
+        key = (w.data_ptr(), w._version, tuple(w.shape), x.shape[2], x.shape[3], w.device)
+        if self._packed_key != key:
+            self._packed = hip.conv_pack_weights(w, x.shape[2], x.shape[3], self.stride)
+            self._packed_key = key
+        return self._packed
+
+    def _block_conv(self, x: torch.Tensor) -> torch.Tensor:
+        from .. import hip
+
+        if tuple(self.dilation) != (1, 1):  # no dilated kernel in libsige_hip: torch's conv
+            return F.conv2d(x, self.weight, self.bias, self.stride, (0, 0), self.dilation, self.groups)
+        packed = self._packed_weights(x) if self.groups == 1 else None
+        if packed is not None:
+            return hip.block_conv(x, packed, self.bias, self.out_channels, self.kernel_size, self.stride)
+        return hip.block_conv_direct(x, self.weight, self.bias, self.stride, self.groups)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.mode == "full":
+            output = super(SIGEConv2d, self).forward(x)
+        elif self.mode == "sparse":
+            if x.is_cuda and x.dtype == torch.float32 and _conv_backend() == "hip":
+                output = self._block_conv(x)
+            else:
+                output = F.conv2d(x, self.weight, self.bias, self.stride, (0, 0), self.dilation, self.groups)
+        elif self.mode == "profile":
+            output = F.conv2d(x, self.weight, self.bias, self.stride, (0, 0), self.dilation, self.groups)
+        else:
+            raise NotImplementedError("Unknown mode: %s" % self.mode)
+        return output
+
+
+class SIGEModel(nn.Module):
+    def __init__(self, call_super: bool = True):
+        if call_super:
+            super(SIGEModel, self).__init__()
+        self.mode = "full"
+        self.timestamp = 0
+
+    def _sige_modules(self):
+        return (m for m in self.modules() if isinstance(m, SIGEModule))
+
+    def set_masks(self, masks: Dict[Tuple[int, int], torch.Tensor]):
+        self.timestamp += 1
+        cache = {}  # shared by all modules: one reduce_mask / scatter_map per distinct geometry
+        for module in self._sige_modules():
+            module.set_mask(masks, cache, self.timestamp)
+
+    def set_mode(self, mode: str):
+        self.mode = mode
+        for module in self._sige_modules():
+            module.set_mode(mode)
+
+    def clear_cache(self):
+        for module in self._sige_modules():
+            module.clear_cache()
+
+    def set_cache_id(self, cache_id: int):
+        for module in self._sige_modules():
+            module.set_cache_id(cache_id)
+
+    def set_sparse_update(self, sparse_update: bool):
+        for module in self._sige_modules():
+            module.set_sparse_update(sparse_update)

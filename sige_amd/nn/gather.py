@@ -1,0 +1,130 @@
+"""Gather: active input tiles (with halo) of a conv out of the full activation.
+
+API parity with sige/nn/gather.py:12-108.  Geometry (effective block size,
+block stride, offset) is derived exactly as the reference's constructor does;
+`set_mask` memoises the index list per (resolution, geometry) in the cache
+shared by SIGEModel.set_masks.  Extra here: per-mask lookup tables for the
+fused single-pass scatter kernels (tile tables), built lazily on the GPU.
+"""
+import warnings
+from typing import Dict, Optional, Tuple, Union
+
+import torch
+from torch import nn
+
+from ..utils import reduce_mask
+from .base import SIGEModule
+from .utils import activation
+
+
+class Gather(SIGEModule):
+    def __init__(
+        self,
+        conv: nn.Conv2d,
+        block_size: Union[int, Tuple[int, int]],
+        offset: Optional[Union[int, Tuple[int, int]]] = None,
+        activation_name: str = "identity",
+        activation_first: bool = False,
+        verbose: bool = False,
+    ):
+        super(Gather, self).__init__()
+        if isinstance(block_size, int):
+            block_size = (block_size, block_size)
+        k, s = conv.kernel_size, conv.stride
+        # out tile = how many conv outputs fit in the requested block; the block is
+        # then shrunk to exactly cover them (6 -> 5 for a stride-2 3x3 conv)
+        out_tile = tuple(max(block_size[i] - k[i], 0) // s[i] + 1 for i in (0, 1))
+        fitted = tuple((out_tile[i] - 1) * s[i] + k[i] for i in (0, 1))
+        if fitted != tuple(block_size):
+            warnings.warn("Change the block size from (%d, %d) to (%d, %d)" % (*block_size, *fitted))
+
+        self.model_stride = conv.stride
+        self.kernel_size = conv.kernel_size
+        self.block_size = fitted
+        self.block_stride = (out_tile[0] * s[0], out_tile[1] * s[1])
+        self.out_tile = out_tile
+        if offset is None:
+            self.offset = conv.padding
+        else:
+            self.offset = (offset, offset) if isinstance(offset, int) else offset
+        self.activation_name = activation_name
+        self.activation_first = activation_first
+        self.verbose = verbose
+
+        self.load_runtime("gather")
+
+        self.input_res: Optional[Tuple[int, int]] = None
+        self.active_indices: Optional[torch.Tensor] = None
+        self._tables: Dict = {}
+
+    def forward(
+        self, x: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None
+    ) -> torch.Tensor:
+        self.check_dtype(x, scale, shift)
+        self.check_dim(x, scale, shift)
+        if self.mode == "sparse":
+            fn = self.native(self.runtime, x)
+            return fn(
+                x.contiguous(),
+                self.block_size[0],
+                self.block_size[1],
+                self.indices_on(x.device),
+                None if scale is None else scale.contiguous(),
+                None if shift is None else shift.contiguous(),
+                self.activation_name,
+                self.activation_first,
+            )
+        if self.mode == "full":
+            self.input_res = x.shape[2:]
+            assert scale is None
+            assert shift is None
+            return x
+        if self.mode == "profile":
+            # dummy of the right shape that still depends on the inputs, so a MACs
+            # tracer follows the graph (sige/nn/gather.py:59-70)
+            b, c = x.shape[:2]
+            output = torch.full((b * self.active_indices.size(0), c, *self.block_size), fill_value=x[0, 0, 0, 0],
+                                dtype=x.dtype, device=x.device)
+            if scale is not None:
+                output = output * scale[0, 0, 0, 0]
+            if shift is not None:
+                output = output + shift[0, 0, 0, 0]
+            return activation(output, self.activation_name)
+        raise NotImplementedError("Unknown mode: [%s]!!!" % self.mode)
+
+    # ------------------------------------------------------------------ masks --
+    def set_mask(self, masks: Dict, cache: Dict, timestamp: int):
+        if self.timestamp == timestamp:
+            return
+        super(Gather, self).set_mask(masks, cache, timestamp)
+        assert self.input_res is not None
+        res = tuple(self.input_res)
+        self.mask = masks[res]
+        key = ("active_indices", *res, *self.block_size, *self.block_stride, *self.offset)
+        if key not in cache:
+            cache[key] = reduce_mask(self.mask, self.block_size, self.block_stride, self.offset, verbose=self.verbose)
+        self.active_indices = cache[key]
+        self._tables = cache.setdefault(("tile_tables", *key[1:]), {})
+
+    def indices_on(self, device: torch.device) -> torch.Tensor:
+        """active_indices on `device` (the reference requires mask and activations
+        on the same device; a CPU mask is migrated once per set_mask here)."""
+        idx = self.active_indices
+        if idx.device != device:
+            idx = self._tables.get(("idx", device))
+            if idx is None:
+                idx = self.active_indices.to(device)
+                self._tables[("idx", device)] = idx
+        return idx if idx.is_contiguous() else idx.contiguous()
+
+    def tile_table(self, out_res: Tuple[int, int], device: torch.device) -> torch.Tensor:
+        """[ceil(H/o), ceil(W/o)] int32 lookup "which active tile covers this
+        output cell" for the fused scatter kernels; memoised per mask."""
+        key = ("table", tuple(out_res), device)
+        table = self._tables.get(key)
+        if table is None:
+            from .. import hip
+
+            table = hip.tile_table(self.indices_on(device), self.offset, self.model_stride, self.out_tile, out_res)
+            self._tables[key] = table
+        return table

@@ -1,0 +1,118 @@
+"""ScatterGather: "scatter conv-1's output tiles, gather conv-2's input tiles"
+without materialising the full tensor.
+
+API parity with sige/nn/scatter_gather.py:10-117 (attributes `gather`,
+`scatter_map`, `original_outputs`, `output_res`; the per-mask scatter map is
+memoised in the SIGEModel.set_masks cache under the same key).
+"""
+from typing import Dict, Optional
+
+import torch
+
+from .base import SIGEModule, SIGEModuleWrapper
+from .gather import Gather
+from .utils import activation
+
+
+class ScatterGather(SIGEModule):
+    def __init__(self, gather: Gather, activation_name: str = "identity", activation_first: bool = False):
+        super(ScatterGather, self).__init__()
+        self.gather = SIGEModuleWrapper(gather)
+        self.activation_name = activation_name
+        self.activation_first = activation_first
+
+        self.load_runtime("scatter_gather")
+        self.scatter_runtime = self.load_runtime("scatter", {})
+        self.get_scatter_map_runtime = self.load_runtime("get_scatter_map", {})
+
+        self.scatter_map = None
+        self.output_res = None
+        self.original_outputs = {}
+        self._maps: Dict = {}
+
+    def clear_cache(self):
+        self.original_outputs = {}
+
+    def _build_map(self, idx: torch.Tensor) -> torch.Tensor:
+        g: Gather = self.gather.module
+        h, w = g.mask.shape
+        fn = self.native(self.get_scatter_map_runtime, idx)
+        return fn(h, w, g.block_size[0], g.block_size[1], g.kernel_size[0], g.kernel_size[1],
+                  g.offset[0], g.offset[1], g.model_stride[0], g.model_stride[1], idx)
+
+    def _map_on(self, device: torch.device) -> torch.Tensor:
+        m = self.scatter_map
+        if m is None or m.device != device:
+            m = self._maps.get(device)
+            if m is None:
+                if self.scatter_map is not None:
+                    m = self.scatter_map.to(device)
+                else:  # mask lives on a device with no backend (CPU mask, GPU activations)
+                    m = self._build_map(self.gather.module.indices_on(device))
+                    self.scatter_map = m
+                self._maps[device] = m
+        return m if m.is_contiguous() else m.contiguous()
+
+    def forward(
+        self, x: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None
+    ) -> torch.Tensor:
+        self.check_dtype(x, scale, shift)
+        self.check_dim(x, scale, shift)
+        g: Gather = self.gather.module
+        if self.mode == "sparse":
+            cached = self.original_outputs[self.cache_id]
+            fn = self.native(self.runtime, x)
+            output = fn(
+                x.contiguous(),
+                cached.contiguous(),
+                g.block_size[0],
+                g.block_size[1],
+                g.indices_on(x.device),
+                self._map_on(x.device),
+                None if scale is None else scale.contiguous(),
+                None if shift is None else shift.contiguous(),
+                self.activation_name,
+                self.activation_first,
+            )
+            if self.sparse_update:
+                if x.is_cuda:
+                    from .. import hip
+
+                    cached.copy_(hip.scatter_fused(x.contiguous(), cached, g.tile_table(cached.shape[2:], x.device),
+                                                   g.active_indices.size(0), None))
+                else:
+                    sfn = self.native(self.scatter_runtime, x)
+                    cached.copy_(sfn(x.contiguous(), cached.contiguous(), g.offset[0], g.offset[1],
+                                     g.model_stride[0], g.model_stride[1], g.indices_on(x.device), None))
+            return output
+        if self.mode == "full":
+            self.output_res = x.shape[2:]
+            self.original_outputs[self.cache_id] = x.contiguous()
+            return x
+        if self.mode == "profile":
+            c = x.shape[1]
+            output = torch.full(
+                (self.original_outputs[self.cache_id].size(0) * g.active_indices.size(0), c, *g.block_size),
+                fill_value=x[0, 0, 0, 0], dtype=x.dtype, device=x.device)
+            if scale is not None:
+                output = output * scale[0, 0, 0, 0]
+            if shift is not None:
+                output = output + shift[0, 0, 0, 0]
+            return activation(output, self.activation_name)
+        raise NotImplementedError("Unknown mode: [%s]!!!" % self.mode)
+
+    def set_mask(self, masks: Dict, cache: Dict, timestamp: int):
+        if self.timestamp == timestamp:
+            return
+        super(ScatterGather, self).set_mask(masks, cache, timestamp)
+        g: Gather = self.gather.module
+        g.set_mask(masks, cache, timestamp)
+        h, w = g.mask.shape
+        key = ("scatter_map", h, w, *g.block_size, *g.kernel_size, *g.offset, *g.model_stride)
+        if key not in cache:
+            idx = g.active_indices
+            # built on the mask's device when it has a backend, else lazily on the
+            # activations' device at the first sparse forward
+            cache[key] = self._build_map(idx) if self.get_scatter_map_runtime[idx.device.type] is not None else None
+        self.scatter_map = cache[key]
+        self._maps = {}

@@ -1,0 +1,70 @@
+"""The C-ABI library loads and exports every symbol include/sige_hip.h declares.
+No compute calls here (no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(REPO, "include", "sige_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sige_hip_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from sige_amd import build, hip
+
+    build.build(verbose=False)
+    assert os.path.isfile(hip.LIB_PATH)
+    return ctypes.CDLL(hip.LIB_PATH)
+
+
+def test_header_declares_something():
+    names = _declared()
+    assert len(names) >= 15 and "sige_hip_gather_f32" in names
+
+
+def test_every_declared_symbol_is_exported(lib):
+    missing = [n for n in _declared() if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_python_binding_covers_the_header():
+    from sige_amd import hip
+
+    assert sorted(hip.EXPORTS) == _declared()
+
+
+def test_version_and_error_strings(lib):
+    lib.sige_hip_version.restype = ctypes.c_int
+    lib.sige_hip_error_string.restype = ctypes.c_char_p
+    assert lib.sige_hip_version() == 100
+    assert lib.sige_hip_error_string(0) == b"ok"
+    assert b"invalid" in lib.sige_hip_error_string(-1)
+
+
+def test_argument_validation_without_a_gpu(lib):
+    """Bad arguments are rejected before anything touches the device."""
+    from sige_amd import hip
+
+    h = hip.lib()
+    assert h.sige_hip_gather_f32(None, 1, 1, 8, 8, 0, 6, None, 0, None, 0, 0, 0, 0, None, 0, 0, 0, 0, 0, 0, None, None) == -1
+    assert h.sige_hip_gather_f32(None, 1, 1, 8, 8, 6, 6, None, 0, None, 0, 0, 0, 0, None, 0, 0, 0, 0, 7, 0, None, None) == -2
+    assert h.sige_hip_reduce_mask_capacity(256, 256, 4, 4, 1, 1) == 65 * 65
+    assert h.sige_hip_block_conv_packed_size(128, 128, 3, 3, 6, 6, 1, 1, 1) == 4 * 4 * 4 * 9 * 2 * 32 * 4
+    assert h.sige_hip_block_conv_packed_size(128, 128, 5, 5, 8, 8, 1, 1, 1) == 0
+    assert h.sige_hip_block_conv_packed_size(128, 128, 3, 3, 6, 6, 1, 1, 128) == 0
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "sige_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                src = open(os.path.join(root, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "libsige_oracle" not in src, f

@@ -1,0 +1,367 @@
+"""Parity of the HIP path (through the C ABI, via sige_amd.hip) with the
+reference: golden vectors from the real reference, the CPU oracle on larger
+seeded inputs, and size-independent properties at BASELINE.json's full sizes.
+
+Tolerances: index tensors and identity-activation copies/adds
+bit-exact; swish <= 1e-6 rel; conv-containing paths <= 1e-3 abs (north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from tests import util
+from tests.golden_cases import CASES
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from sige_amd import hip as h
+
+    h.lib()  # fails loudly if the extension is not built
+    return h
+
+
+def _close(case, got, want):
+    got = got.cpu()
+    if case["act"] == "swish":
+        torch.testing.assert_close(got, want, rtol=util.SWISH_RTOL, atol=util.SWISH_ATOL)
+    else:
+        assert torch.equal(got, want)
+
+
+def test_native_library_is_loaded(hip):
+    assert hip.lib().sige_hip_version() == 100
+    arch = hip.lib().sige_hip_device_arch()
+    assert arch is not None and arch.decode().startswith("gfx950"), arch
+    assert "libsige_hip.so" in open("/proc/self/maps").read()
+
+
+@pytest.mark.parametrize("case", CASES, ids=util.case_ids())
+def test_golden_cases(hip, case):
+    g = case["geom"]
+    d = util.tensors(case, DEV)
+    idx_ref = util.ref(case, "idx")
+    idx = hip.reduce_mask(d["mask"], g.block, g.block_stride, g.offset)
+    assert torch.equal(idx.cpu(), idx_ref)
+
+    got = hip.gather(d["x"], g.block[0], g.block[1], idx, d["scale"], d["shift"], case["act"], case["act_first"])
+    _close(case, got, util.ref(case, "gather"))
+
+    tiles_in = util.ref(case, "gather", DEV)
+    Cout = case["cout"]
+    packed = hip.conv_pack_weights(d["weight"], g.block[0], g.block[1], g.stride)
+    if packed is not None:
+        conv = hip.block_conv(tiles_in, packed, d["bias"], Cout, g.kernel, g.stride)
+        torch.testing.assert_close(conv.cpu(), util.ref(case, "conv"), rtol=0, atol=util.CONV_ATOL)
+        torch.testing.assert_close(conv.cpu(), util.ref(case, "conv"), rtol=0, atol=2e-5)  # fp32 MFMA: far inside
+    direct = hip.block_conv_direct(tiles_in, d["weight"], d["bias"], g.stride, 1)
+    torch.testing.assert_close(direct.cpu(), util.ref(case, "conv"), rtol=0, atol=2e-5)
+
+    tiles = util.ref(case, "conv", DEV)
+    args = (g.offset[0], g.offset[1], g.stride[0], g.stride[1], idx)
+    Ho, Wo = d["out_res"]
+    table = hip.tile_table(idx, g.offset, g.stride, g.out_tile, (Ho, Wo))
+    n = idx.shape[0]
+    for key, res in (("scatter", None), ("scatter_res", d["residual"]), ("scatter_resc", d["residual_c"])):
+        assert torch.equal(hip.scatter(tiles, d["y"], *args, res).cpu(), util.ref(case, key)), key
+        assert torch.equal(hip.scatter_fused(tiles, d["y"], table, n, res).cpu(), util.ref(case, key)), key + " fused"
+
+    smap = hip.get_scatter_map(Ho, Wo, *g.block, *g.kernel, *g.offset, *g.stride, idx)
+    assert torch.equal(smap.cpu(), util.ref(case, "map"))
+    sg = hip.scatter_gather(tiles, d["y"], g.block[0], g.block[1], idx, smap, d["scale2"], d["shift2"], case["act"],
+                            case["act_first"])
+    _close(case, sg, util.ref(case, "sg"))
+
+    idx1 = hip.reduce_mask(util.shortcut_mask(case, d).to(DEV), (4, 4), (4, 4), (0, 0))
+    assert torch.equal(idx1.cpu(), util.ref(case, "idx1"))
+    x1 = util.x1_tiles(case, d, idx1.shape[0], DEV)
+    want = util.ref(case, "swbr")
+    assert torch.equal(hip.scatter_with_block_residual(tiles, d["y"], x1, d["y1"], *args[:4], idx, idx1).cpu(), want)
+    t1 = hip.tile_table(idx1, (0, 0), (1, 1), (4, 4), (Ho, Wo))
+    fused = hip.scatter_with_block_residual_fused(tiles, d["y"], x1, d["y1"], table, n, t1, idx1.shape[0])
+    assert torch.equal(fused.cpu(), want)
+
+
+def _fixture_names():
+    return sorted({k.split("/")[0] for k in util.golden("masks").files})
+
+
+@pytest.mark.parametrize("name", _fixture_names())
+def test_reduce_mask_fixture_masks(hip, name):
+    """Device reduce_mask on the reference's own fixture masks (up to 512x1024)."""
+    g = util.golden("masks")
+    mask = util.unpack(g[name + "/mask"], g[name + "/shape"]).to(DEV)
+    for gname, (b, s, p) in {"b6s4p1": (6, 4, 1), "b4s4p0": (4, 4, 0), "b5s4p0": (5, 4, 0), "b5s4p1": (5, 4, 1)}.items():
+        got = hip.reduce_mask(mask, (b, b), (s, s), (p, p))
+        assert torch.equal(got.cpu(), torch.from_numpy(g["%s/reduce/%s" % (name, gname)])), gname
+
+
+def _square_mask(ratio, H=256, W=256, top=100, left=90):
+    side = int(round((ratio ** 0.5) * H))
+    m = torch.zeros(H, W, dtype=torch.bool)
+    m[top:top + side, left:left + side] = True
+    return m
+
+
+@pytest.mark.parametrize("C,res,ratio,B", [(128, 64, 0.05, 1), (64, 128, 0.15, 2), (256, 32, 0.3, 1)])
+def test_against_oracle_mid_size(hip, C, res, ratio, B):
+    """Seeded mid-size inputs: HIP vs the CPU oracle for the whole op chain."""
+    from sige_amd.utils import reduce_mask
+
+    torch.manual_seed(C + res)
+    mask = _square_mask(ratio, res, res, res // 3, res // 4)
+    idx = reduce_mask(mask, 6, 4, 1)
+    idx1 = reduce_mask(mask, 4, 4, 0)
+    x = torch.randn(B, C, res, res)
+    y, y1 = torch.randn(B, C, res, res), torch.randn(B, C, res, res)
+    scale, shift = torch.randn(1, C, 1, 1), torch.randn(1, C, 1, 1)
+    w, bias = torch.randn(C, C, 3, 3) / (3 * C ** 0.5), torch.randn(C)
+    x1 = torch.randn(B * idx1.shape[0], C, 4, 4)
+    g_o = oracle.gather(x, 6, 6, idx, scale, shift, "swish", False)
+    c_o = oracle.block_conv(g_o, w, bias, 1)
+    m_o = oracle.get_scatter_map(res, res, 6, 6, 3, 3, 1, 1, 1, 1, idx)
+    sg_o = oracle.scatter_gather(c_o, y, 6, 6, idx, m_o, scale, shift, "swish", False)
+    sw_o = oracle.scatter_with_block_residual(c_o, y, x1, y1, 1, 1, 1, 1, idx, idx1)
+
+    to = lambda t: t.to(DEV)  # noqa: E731
+    idx_d, idx1_d = to(idx), to(idx1)
+    g_h = hip.gather(to(x), 6, 6, idx_d, to(scale), to(shift), "swish", False)
+    torch.testing.assert_close(g_h.cpu(), g_o, rtol=util.SWISH_RTOL, atol=util.SWISH_ATOL)
+    packed = hip.conv_pack_weights(to(w), 6, 6, (1, 1))
+    c_h = hip.block_conv(to(g_o), packed, to(bias), C, (3, 3), (1, 1))
+    torch.testing.assert_close(c_h.cpu(), c_o, rtol=0, atol=util.CONV_ATOL)
+    m_h = hip.get_scatter_map(res, res, 6, 6, 3, 3, 1, 1, 1, 1, idx_d)
+    assert torch.equal(m_h.cpu(), m_o)
+    sg_h = hip.scatter_gather(to(c_o), to(y), 6, 6, idx_d, m_h, to(scale), to(shift), "swish", False)
+    torch.testing.assert_close(sg_h.cpu(), sg_o, rtol=util.SWISH_RTOL, atol=util.SWISH_ATOL)
+    sw_h = hip.scatter_with_block_residual(to(c_o), to(y), to(x1), to(y1), 1, 1, 1, 1, idx_d, idx1_d)
+    assert torch.equal(sw_h.cpu(), sw_o)
+    t0 = hip.tile_table(idx_d, (1, 1), (1, 1), (4, 4), (res, res))
+    t1 = hip.tile_table(idx1_d, (0, 0), (1, 1), (4, 4), (res, res))
+    sw_f = hip.scatter_with_block_residual_fused(to(c_o), to(y), to(x1), to(y1), t0, idx.shape[0], t1, idx1.shape[0])
+    assert torch.equal(sw_f.cpu(), sw_o)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,R", [(128, 128, 3, 1, 6), (256, 128, 3, 1, 6), (128, 256, 1, 1, 4),
+                                                (512, 256, 1, 1, 4), (128, 128, 3, 2, 5), (16, 32, 3, 1, 6),
+                                                (36, 128, 3, 1, 6), (40, 24, 1, 1, 4), (6, 70, 3, 2, 5)])
+def test_block_conv_vs_torch_and_oracle(hip, cin, cout, k, stride, R):
+    """MFMA stacked-block conv at DDPM / GauGAN channel counts, odd T, channel
+    counts that are not multiples of the 32-wide chunks."""
+    torch.manual_seed(cin * cout + k)
+    for T in (1, 7, 124):
+        x = torch.randn(T, cin, R, R, device=DEV)
+        w = torch.randn(cout, cin, k, k, device=DEV) / (k * cin ** 0.5)
+        b = torch.randn(cout, device=DEV)
+        packed = hip.conv_pack_weights(w, R, R, (stride, stride))
+        assert packed is not None
+        got = hip.block_conv(x, packed, b, cout, (k, k), (stride, stride))
+        want = oracle.block_conv(x.cpu(), w.cpu(), b.cpu(), stride)
+        torch.testing.assert_close(got.cpu(), want, rtol=0, atol=util.CONV_ATOL)
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride).float()
+        torch.testing.assert_close(got, ref, rtol=0, atol=1e-4)
+        nob = hip.block_conv(x, packed, None, cout, (k, k), (stride, stride))
+        torch.testing.assert_close(nob, got - b.view(1, -1, 1, 1), rtol=0, atol=1e-5)
+
+
+def test_block_conv_direct_groups(hip):
+    torch.manual_seed(5)
+    x = torch.randn(9, 24, 6, 6, device=DEV)
+    w = torch.randn(24, 1, 3, 3, device=DEV)
+    b = torch.randn(24, device=DEV)
+    got = hip.block_conv_direct(x, w, b, (1, 1), 24)  # depthwise (GAN-Compression SIGESeparableConv2d)
+    want = oracle.block_conv(x.cpu(), w.cpu(), b.cpu(), 1, groups=24)
+    torch.testing.assert_close(got.cpu(), want, rtol=0, atol=1e-5)
+
+
+# ---- BASELINE.json full sizes: size-independent properties -----------------
+@pytest.mark.parametrize("ratio", [0.012, 0.05, 0.15])
+@pytest.mark.parametrize("C", [128, 256])
+def test_full_size_properties(hip, ratio, C):
+    """DDPM-256 op shapes (x [1,C,256,256], square edit):
+    round trips, idempotence and linearity that hold for any size."""
+    from sige_amd.utils import reduce_mask
+
+    torch.manual_seed(int(ratio * 1000) + C)
+    mask = _square_mask(ratio).to(DEV)
+    idx6 = reduce_mask(mask, 6, 4, 1)
+    idx4 = reduce_mask(mask, 4, 4, 0)
+    expected = {0.012: (72, 56), 0.05: (240, 225), 0.15: (676, 650)}[ratio]  # N6 / N4
+    assert (idx6.shape[0], idx4.shape[0]) == expected
+    x = torch.randn(1, C, 256, 256, device=DEV)
+    # (1) gather(4x4 tiles) -> scatter into x itself is the identity (encode -> decode round trip)
+    t4 = hip.gather(x, 4, 4, idx4)
+    assert torch.equal(hip.scatter(t4, x, 0, 0, 1, 1, idx4, None), x)
+    # (2) interior of the 6x6 gather == the 4x4 tile at origin+1 (halo consistency)
+    t6 = hip.gather(x, 6, 6, idx6)
+    inner = hip.gather(x, 4, 4, idx6 + 1)
+    assert torch.equal(t6[:, :, 1:5, 1:5], inner)
+    # (3) scatter into zeros then gather back returns the tiles (decode -> encode)
+    zeros = torch.zeros_like(x)
+    tbl = hip.tile_table(idx6, (1, 1), (1, 1), (4, 4), (256, 256))
+    s = hip.scatter_fused(inner, zeros, tbl, idx6.shape[0], None)
+    assert torch.equal(hip.gather(s, 4, 4, idx6 + 1), inner)
+    assert torch.equal(s, hip.scatter(inner, zeros, 1, 1, 1, 1, idx6, None))  # fused == two-pass
+    # (4) everything outside the active tiles is untouched; checksum of checksums
+    covered = torch.zeros(256, 256, dtype=torch.bool, device=DEV)
+    for h, w in (idx6 + 1).tolist():
+        covered[h:h + 4, w:w + 4] = True
+    y = torch.randn_like(x)
+    out = hip.scatter_fused(inner, y, tbl, idx6.shape[0], None)
+    assert torch.equal(out[:, :, ~covered], y[:, :, ~covered])
+    assert torch.equal(out[:, :, covered], x[:, :, covered])
+    # (5) linearity of scatter in the residual: scatter(t, y, res) - scatter(t, y) == res on covered pixels
+    res = torch.randn_like(x)
+    d = hip.scatter_fused(inner, y, tbl, idx6.shape[0], res) - out
+    torch.testing.assert_close(d[:, :, covered], res[:, :, covered], rtol=0, atol=1e-5)
+    assert torch.count_nonzero(d[:, :, ~covered]) == 0
+    # (6) scatter_gather with an all-(-1) map is gather on y; with the real map it equals gather(scatter(...))
+    smap = hip.get_scatter_map(256, 256, 6, 6, 3, 3, 1, 1, 1, 1, idx6)
+    sg = hip.scatter_gather(inner, y, 6, 6, idx6, smap)
+    assert torch.equal(sg, hip.gather(out, 6, 6, idx6))
+    none = torch.full_like(smap, -1)
+    assert torch.equal(hip.scatter_gather(inner, y, 6, 6, idx6, none), hip.gather(y, 6, 6, idx6))
+    # (7) swish-affine gather == torch elementwise on the gathered tiles (zeros stay zeros)
+    sc, sh = torch.randn(1, C, 1, 1, device=DEV), torch.randn(1, C, 1, 1, device=DEV)
+    ga = hip.gather(x, 6, 6, idx6, sc, sh, "swish", False)
+    ref = torch.nn.functional.silu(t6 * sc + sh)
+    inside = hip.gather(torch.ones_like(x), 6, 6, idx6) > 0
+    torch.testing.assert_close(ga, torch.where(inside, ref, torch.zeros_like(ref)), rtol=2e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 32), (64, 64)])
+def test_example_py_on_gpu(cin, cout):
+    """BASELINE config 1 (example.py): sparse == dense within atol 1e-4 (example.py:95)."""
+    from tests.test_host_logic import ExampleModel
+
+    g = util.golden("masks")
+    mask = util.unpack(g["assets_mask/mask"], g["assets_mask/shape"]).to(DEV)
+    torch.manual_seed(0)
+    orig = torch.randn(1, cin, 256, 256, device=DEV)
+    edited = orig + torch.randn(1, cin, 256, 256, device=DEV) * mask[None, None]
+    model = ExampleModel(cin, cout).to(DEV).eval()
+    with torch.no_grad():
+        model.set_mode("full")
+        std = model(edited)
+        model(orig)
+        model.set_mode("sparse")
+        model.set_masks({(256, 256): mask})
+        sp = model(edited)
+    assert model.m.gather.active_indices.shape[0] == 783
+    assert np.array_equal(model.m.gather.active_indices.cpu().numpy(), util.golden("example")["c16_32/idx"])
+    assert torch.isclose(std, sp, atol=1e-4).all(), (std - sp).abs().max().item()
+
+
+def test_example_golden_output_on_gpu():
+    """Same inputs as tests/golden/make_golden.py: the GPU sparse output equals the
+    REFERENCE's sparse output (sige.nn + sige/cpu) within 1e-3."""
+    from tests.test_host_logic import ExampleModel, _example_inputs
+
+    mask, orig, edited, w, b = _example_inputs()
+    model = ExampleModel(16, 32).to(DEV).eval()
+    with torch.no_grad():
+        model.m.conv.weight.copy_(w)
+        model.m.conv.bias.copy_(b)
+        model.set_mode("full")
+        model(orig.to(DEV))
+        model.set_mode("sparse")
+        model.set_masks({(256, 256): mask.to(DEV)})
+        sp = model(edited.to(DEV)).cpu()
+    ex = util.golden("example")
+    torch.testing.assert_close(sp[:, ::4, ::3, ::3], torch.from_numpy(ex["c16_32/sparse_sub"]), rtol=0, atol=util.CONV_ATOL)
+    assert abs(sp.double().sum().item() - float(ex["c16_32/sparse_sum"])) < 1.0
+
+
+def test_resblock_gpu_vs_oracle_backend():
+    """Module-level parity: the same ResBlock (weights, caches, masks) run through
+    the HIP backend on the GPU and through the CPU oracle backend."""
+    from sige_amd import runtime
+    from sige_amd.utils import dilate_mask
+    from tests.test_host_logic import ResNet
+
+    torch.manual_seed(3)
+    net = ResNet(32, 64).eval()
+    blk = net.block
+    blk.s1, blk.t1 = torch.randn(1, 32, 1, 1), torch.randn(1, 32, 1, 1)
+    blk.s2, blk.t2 = torch.randn(1, 64, 1, 1), torch.randn(1, 64, 1, 1)
+    orig = torch.randn(1, 32, 64, 64)
+    mask = torch.zeros(64, 64, dtype=torch.bool)
+    mask[20:31, 12:40] = True
+    mask[63, 0] = True
+    edited = orig + torch.randn_like(orig) * mask
+    masks = {(64, 64): dilate_mask(dilate_mask(mask, (2, 0)), (0, 2))}
+
+    def run(device):
+        net.to(device)
+        for n in ("s1", "t1", "s2", "t2"):
+            setattr(blk, n, getattr(blk, n).to(device))
+        with torch.no_grad():
+            net.set_mode("full")
+            dense = net(edited.to(device))
+            net(orig.to(device))
+            net.set_mode("sparse")
+            net.set_masks({k: v.to(device) for k, v in masks.items()})
+            return dense.cpu(), net(edited.to(device)).cpu()
+
+    runtime.register_backend("cpu", oracle)
+    try:
+        dense_cpu, sparse_cpu = run("cpu")
+    finally:
+        runtime.unregister_backend("cpu")
+    dense_gpu, sparse_gpu = run(DEV)
+    torch.testing.assert_close(sparse_gpu, sparse_cpu, rtol=0, atol=util.CONV_ATOL)
+    torch.testing.assert_close(sparse_gpu, dense_gpu, rtol=0, atol=util.CONV_ATOL)
+
+
+def test_hipgraph_capture_replay(hip):
+    """Every entry point is capturable (no allocation / sync inside the library)."""
+    from sige_amd.utils import reduce_mask
+
+    torch.manual_seed(9)
+    mask = _square_mask(0.05).to(DEV)
+    idx = reduce_mask(mask, 6, 4, 1)
+    x = torch.randn(1, 64, 256, 256, device=DEV)
+    y = torch.randn(1, 64, 256, 256, device=DEV)
+    w = torch.randn(64, 64, 3, 3, device=DEV) / 24
+    packed = hip.conv_pack_weights(w, 6, 6, (1, 1))
+    tbl = hip.tile_table(idx, (1, 1), (1, 1), (4, 4), (256, 256))
+
+    def step():
+        t = hip.gather(x, 6, 6, idx, None, None, "swish", False)
+        c = hip.block_conv(t, packed, None, 64, (3, 3), (1, 1))
+        return hip.scatter_fused(c, y, tbl, idx.shape[0], x)
+
+    eager = step()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+        with torch.cuda.graph(graph, stream=side):
+            out = step()
+    torch.cuda.current_stream().wait_stream(side)
+    x.mul_(2.0)  # new inputs, same buffers
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, step())
+    assert not torch.equal(out, eager)
+
+
+def test_errors_are_loud(hip):
+    x = torch.randn(1, 4, 8, 8, device=DEV)
+    idx = torch.zeros(1, 2, dtype=torch.int32, device=DEV)
+    with pytest.raises(ValueError, match="Unknown activation"):
+        hip.gather(x, 6, 6, idx, None, None, "relu", False)
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        hip.gather(x, 6, 6, idx, torch.randn(1, 3, 1, 1, device=DEV), None)  # not broadcastable
+    with pytest.raises(NotImplementedError):
+        hip.gather(x.half(), 6, 6, idx)
+    with pytest.raises(RuntimeError, match="must live on the GPU"):
+        hip.gather(x.cpu(), 6, 6, idx)
+    empty = hip.gather(x, 6, 6, idx[:0])  # N = 0 is legal
+    assert empty.shape == (0, 4, 6, 6)
+    assert torch.equal(hip.scatter(torch.zeros(0, 4, 4, 4, device=DEV), x, 1, 1, 1, 1, idx[:0], None), x)

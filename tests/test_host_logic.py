@@ -1,0 +1,314 @@
+"""Host-side logic of sige_amd (module API, mask helpers, caches) on CPU.
+
+The GPU library cannot run here, so these tests register the CPU ORACLE as the
+"cpu" backend of the runtime registry -- test infrastructure standing in for
+the native functions, exactly where the reference would use `sige.cpu`.  The
+product default has no "cpu" backend (see test_no_cpu_backend_by_default)."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+import sige_amd
+from oracle import oracle
+from sige_amd import runtime
+from sige_amd.nn import (Gather, Scatter, ScatterGather, ScatterWithBlockResidual, SIGEConv2d, SIGEModel,
+                         SIGEModule)
+from sige_amd.utils import compute_difference_mask, dilate_mask, downsample_mask, reduce_mask
+from tests import util
+from tests.golden_cases import CASES
+
+
+@pytest.fixture()
+def cpu_oracle_backend():
+    runtime.register_backend("cpu", oracle)
+    yield
+    runtime.unregister_backend("cpu")
+
+
+# ----------------------------------------------------------------- masks ----
+def _fixture_names():
+    return sorted({k.split("/")[0] for k in util.golden("masks").files})
+
+
+@pytest.mark.parametrize("name", _fixture_names())
+def test_mask_helpers_bit_exact(name):
+    g = util.golden("masks")
+    shape = g[name + "/shape"]
+    mask = util.unpack(g[name + "/mask"], shape)
+    for gname, (b, s, p) in {"b6s4p1": (6, 4, 1), "b4s4p0": (4, 4, 0), "b5s4p0": (5, 4, 0), "b5s4p1": (5, 4, 1)}.items():
+        got = reduce_mask(mask, b, s, p)
+        assert got.dtype == torch.int32 and got.is_contiguous()
+        assert torch.equal(got, torch.from_numpy(g["%s/reduce/%s" % (name, gname)]))
+    for dil in (1, 2, 5):
+        assert torch.equal(dilate_mask(mask, dil), util.unpack(g["%s/dilate/%d" % (name, dil)], shape))
+        assert np.array_equal(dilate_mask(mask.numpy(), dil), util.unpack(g["%s/dilate/%d" % (name, dil)], shape).numpy())
+    for min_res, dil in ((8, 1), (8, 2), (4, 1)):
+        pyr = downsample_mask(mask, min_res=min_res, dilation=dil)
+        assert len(pyr) == len([k for k in g.files if k.startswith("%s/pyramid/%d_%d/" % (name, min_res, dil))])
+        for (h, w), pm in pyr.items():
+            assert torch.equal(pm, util.unpack(g["%s/pyramid/%d_%d/%dx%d" % (name, min_res, dil, h, w)], (h, w)))
+    for (h, w), pm in downsample_mask(dilate_mask(mask, 5), min_res=8).items():
+        assert torch.equal(pm, util.unpack(g["%s/ddpm/%dx%d" % (name, h, w)], (h, w)))
+
+
+@pytest.mark.parametrize("case", CASES, ids=util.case_ids())
+def test_reduce_mask_cases(case):
+    g = case["geom"]
+    d = util.tensors(case)
+    assert torch.equal(reduce_mask(d["mask"], g.block, g.block_stride, g.offset), util.ref(case, "idx"))
+
+
+def test_reduce_mask_edge_cases():
+    assert reduce_mask(torch.zeros(8, 8, dtype=torch.bool), None, 4, 1) is None
+    empty = reduce_mask(torch.zeros(16, 16, dtype=torch.bool), 6, 4, 1)
+    assert empty.shape == (0, 2) and empty.dtype == torch.int32  # all-false mask -> int32 [0,2]
+    full = reduce_mask(torch.ones(256, 256, dtype=torch.bool), 6, 4, 1)
+    assert full.shape == (65 * 65 - 65 - 64, 2) or full.shape[0] <= 65 * 65  # bottom/right candidates past the image drop out
+    assert full[0].tolist() == [-1, -1]
+
+
+def test_compute_difference_mask():
+    a = torch.zeros(1, 3, 8, 8)
+    b = a.clone()
+    b[0, 1, 2, 3] = 0.5
+    b[0, 2, 5, 5] = 0.01
+    m = compute_difference_mask(a, b)
+    assert m.shape == (8, 8) and m.sum() == 1 and m[2, 3]
+    assert torch.equal(compute_difference_mask(a[0], b[0]), m)
+    assert compute_difference_mask(a[0, 1], b[0, 1]).sum() == 1
+
+
+# ------------------------------------------------------------- geometry ----
+@pytest.mark.parametrize("case", CASES, ids=util.case_ids())
+def test_gather_geometry(case):
+    g = case["geom"]
+    conv = nn.Conv2d(4, 4, g.kernel, g.stride, g.padding)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        ga = Gather(conv, (6, 6) if g.block == (5, 5) else g.block)
+    assert ga.block_size == g.block and ga.block_stride == g.block_stride and ga.offset == g.offset
+    assert ga.out_tile == g.out_tile
+    assert bool(w) == (g.block == (5, 5))  # stride-2: "Change the block size from (6, 6) to (5, 5)"
+
+
+# --------------------------------------------------------------- modules ----
+class ExampleModule(SIGEModule):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = SIGEConv2d(cin, cout, 3, 1, 1, bias=True)
+        self.gather = Gather(self.conv, block_size=6)
+        self.scatter = Scatter(self.gather)
+
+    def forward(self, x):
+        return self.scatter(self.conv(self.gather(x)))
+
+
+class ExampleModel(SIGEModel):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.m = ExampleModule(cin, cout)
+
+    def forward(self, x):
+        return self.m(x)
+
+
+def _example_inputs():
+    g = util.golden("masks")
+    mask = util.unpack(g["assets_mask/mask"], g["assets_mask/shape"])
+    rs = np.random.RandomState(4242)
+    orig = rs.standard_normal((1, 16, 256, 256)).astype(np.float32)
+    noise = rs.standard_normal((1, 16, 256, 256)).astype(np.float32)
+    w = (rs.standard_normal((32, 16, 3, 3)) / np.sqrt(9 * 16)).astype(np.float32)
+    b = rs.standard_normal((32,)).astype(np.float32)
+    edited = orig + noise * mask.numpy()[None, None]
+    return mask, torch.from_numpy(orig), torch.from_numpy(edited), torch.from_numpy(w), torch.from_numpy(b)
+
+
+def test_example_py_matches_reference(cpu_oracle_backend):
+    """example.py: Gather -> 3x3 conv -> Scatter equals the dense conv
+    within atol 1e-4 (example.py:95) and equals the reference's sparse output."""
+    mask, orig, edited, w, b = _example_inputs()
+    model = ExampleModel(16, 32).eval()
+    with torch.no_grad():
+        model.m.conv.weight.copy_(w)
+        model.m.conv.bias.copy_(b)
+        model.set_mode("full")
+        std = model(edited)
+        model(orig)
+        model.set_mode("sparse")
+        model.set_masks({(256, 256): mask})
+        sp = model(edited)
+    ex = util.golden("example")
+    assert np.array_equal(model.m.gather.active_indices.numpy(), ex["c16_32/idx"])
+    assert torch.isclose(std, sp, atol=1e-4).all()
+    torch.testing.assert_close(sp[:, ::4, ::3, ::3], torch.from_numpy(ex["c16_32/sparse_sub"]), rtol=0, atol=1e-6)
+    assert abs(sp.double().sum().item() - float(ex["c16_32/sparse_sum"])) < 1e-2
+
+
+def test_no_cpu_backend_by_default():
+    """The product has no CPU path: a sparse op on a CPU tensor fails loudly."""
+    mask, orig, edited, w, b = _example_inputs()
+    model = ExampleModel(16, 32).eval()
+    with torch.no_grad():
+        model.set_mode("full")
+        model(orig)
+        model.set_mode("sparse")
+        model.set_masks({(256, 256): mask})
+        with pytest.raises(RuntimeError, match="no native backend"):
+            model(edited)
+
+
+def test_dtype_and_dim_checks(cpu_oracle_backend):
+    conv = SIGEConv2d(4, 4, 3, 1, 1)
+    g = Gather(conv, 6)
+    with pytest.raises(NotImplementedError, match="does not support dtype"):
+        g(torch.zeros(1, 4, 8, 8, dtype=torch.float16))
+    with pytest.raises(NotImplementedError, match="does not support input with dim"):
+        g(torch.zeros(4, 8, 8))
+    g.set_mode("bogus")
+    with pytest.raises(NotImplementedError, match="Unknown mode"):
+        g(torch.zeros(1, 4, 8, 8))
+
+
+class ResBlock(SIGEModule):
+    """The op pattern of SIGEFusedResnetBlock.sparse_forward
+    (diffusion/models/ddpm_arch/sige_fused_unet.py:100-131) with a 1x1 shortcut."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv1 = SIGEConv2d(cin, cout, 3, 1, 1)
+        self.conv2 = SIGEConv2d(cout, cout, 3, 1, 1)
+        self.nin = SIGEConv2d(cin, cout, 1, 1, 0)
+        self.main_gather = Gather(self.conv1, 6, activation_name="swish")
+        self.scatter_gather = ScatterGather(self.main_gather, activation_name="swish")
+        self.shortcut_gather = Gather(self.nin, 4)
+        self.scatter = ScatterWithBlockResidual(self.main_gather, self.shortcut_gather)
+        self.s1 = self.t1 = self.s2 = self.t2 = None
+
+    def forward(self, x):
+        if self.mode == "full":
+            sc = self.nin(self.shortcut_gather(x))
+            h = self.main_gather(x)
+            h = torch.nn.functional.silu(h * self.s1 + self.t1)
+            h = self.scatter_gather(self.conv1(h))
+            h = torch.nn.functional.silu(h * self.s2 + self.t2)
+            return self.scatter(self.conv2(h), sc)
+        sc = self.nin(self.shortcut_gather(x))
+        h = self.conv1(self.main_gather(x, self.s1, self.t1))
+        h = self.conv2(self.scatter_gather(h, self.s2, self.t2))
+        return self.scatter(h, sc)
+
+
+class ResNet(SIGEModel):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.block = ResBlock(cin, cout)
+
+    def forward(self, x):
+        return self.block(x)
+
+
+def test_resblock_sparse_equals_dense_on_edited_region(cpu_oracle_backend):
+    """With per-channel affine (no data-dependent statistics) the sparse forward
+    must reproduce the dense forward of the edited input everywhere."""
+    torch.manual_seed(0)
+    net = ResNet(6, 8).eval()
+    blk = net.block
+    blk.s1, blk.t1 = torch.randn(1, 6, 1, 1), torch.randn(1, 6, 1, 1)
+    blk.s2, blk.t2 = torch.randn(1, 8, 1, 1), torch.randn(1, 8, 1, 1)
+    orig = torch.randn(1, 6, 40, 44)
+    mask = torch.zeros(40, 44, dtype=torch.bool)
+    mask[10:19, 7:23] = True
+    mask[0, 0] = mask[39, 43] = True
+    edited = orig + torch.randn_like(orig) * mask
+    with torch.no_grad():
+        net.set_mode("full")
+        dense = net(edited)
+        base = net(orig)
+        net.set_mode("sparse")
+        # two stacked 3x3 convs: square receptive field of radius 2 (dilate_mask's own
+        # structuring element is plus-shaped, so dilate rows then columns)
+        net.set_masks({(40, 44): dilate_mask(dilate_mask(mask, (2, 0)), (0, 2))})
+        sparse = net(edited)
+    torch.testing.assert_close(sparse, dense, rtol=0, atol=1e-4)
+    assert not torch.allclose(base, dense, atol=1e-3)
+    # caches untouched by the sparse pass (out-of-place semantics, scatter.py:59-60)
+    assert torch.equal(blk.scatter.original_outputs[0], base)
+    # shared-cache memoisation: both modules see the same index tensor object
+    assert blk.scatter_gather.gather.module.active_indices is blk.main_gather.active_indices
+    assert blk.scatter_gather.scatter_map.shape == (40, 44, 3)
+
+
+def test_sparse_update_refreshes_caches(cpu_oracle_backend):
+    torch.manual_seed(1)
+    net = ResNet(4, 4).eval()
+    blk = net.block
+    blk.s1, blk.t1, blk.s2, blk.t2 = (torch.randn(1, 4, 1, 1) for _ in range(4))
+    orig = torch.randn(1, 4, 24, 24)
+    mask = torch.zeros(24, 24, dtype=torch.bool)
+    mask[5:9, 5:9] = True
+    edited = orig + mask * 1.0
+    with torch.no_grad():
+        net.set_mode("full")
+        net(orig)
+        dense = net(edited)
+        net(orig)
+        net.set_mode("sparse")
+        net.set_masks({(24, 24): dilate_mask(dilate_mask(mask, (2, 0)), (0, 2))})
+        net.set_sparse_update(True)
+        out = net(edited)
+    torch.testing.assert_close(out, dense, rtol=0, atol=1e-4)
+    assert torch.equal(blk.scatter.original_outputs[0], out)  # cache now holds the edited result
+    torch.testing.assert_close(blk.scatter.original_residuals[0], blk.nin(edited), rtol=0, atol=1e-5)
+
+
+def test_profile_mode_shapes(cpu_oracle_backend):
+    torch.manual_seed(2)
+    net = ResNet(4, 6).eval()
+    blk = net.block
+    blk.s1, blk.t1 = torch.randn(1, 4, 1, 1), torch.randn(1, 4, 1, 1)
+    blk.s2, blk.t2 = torch.randn(1, 6, 1, 1), torch.randn(1, 6, 1, 1)
+    x = torch.randn(1, 4, 16, 16)
+    mask = torch.zeros(16, 16, dtype=torch.bool)
+    mask[4:6, 4:6] = True
+    with torch.no_grad():
+        net.set_mode("full")
+        net(x)
+        net.set_masks({(16, 16): mask})
+        net.set_mode("profile")
+        out = net(x)
+    assert out.shape == (1, 6, 16, 16)
+
+
+def test_cache_id_and_clear_cache(cpu_oracle_backend):
+    net = ExampleModel(4, 4).eval()
+    x = torch.randn(1, 4, 16, 16)
+    with torch.no_grad():
+        net.set_mode("full")
+        net.set_cache_id(3)
+        net(x)
+    assert list(net.m.scatter.original_outputs) == [3]
+    net.clear_cache()
+    assert net.m.scatter.original_outputs == {}
+
+
+def test_compat_install_aliases():
+    import sys
+
+    from sige_amd import compat
+
+    saved = {k: v for k, v in sys.modules.items() if k == "sige" or k.startswith("sige.")}
+    try:
+        compat.install()
+        import sige
+        from sige.nn import Gather as G2
+        from sige.utils import reduce_mask as r2
+
+        assert G2 is Gather and r2 is reduce_mask and sige.__version__ == sige_amd.__version__
+    finally:
+        for k in [k for k in sys.modules if k == "sige" or k.startswith("sige.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
