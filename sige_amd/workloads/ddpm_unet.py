@@ -1,0 +1,322 @@
+"""DDPM 256x256 U-Net workload (LSUN-Church configuration) built on sige_amd.nn.
+
+This is the benchmark harness for BASELINE.json configs[1]/[4]: the network the
+reference's headline numbers are quoted on (diffusion/configs/
+church_ddpm256-sige.yml: ch 128, mult 1,1,2,2,4,4, 2 res-blocks per level,
+attention at 16x16, SIGE tiles 6/4, sparse at resolutions >= 64).  It follows
+the public DDPM checkpoint layout (parameter names `down.{l}.block.{i}.conv1`,
+`mid.block_1`, `up.{l}.upsample.conv`, `temb.dense.{k}`, ...), so a state dict of
+the reference's SIGEFusedUNet (diffusion/models/ddpm_arch/sige_fused_unet.py:
+251-434) loads into it -- tests/test_reference_models.py checks that both
+produce the same full and sparse outputs.
+
+Sparse-mode contract (what SIGE caches):
+  * GroupNorm statistics are NOT recomputed: the full pass stores per-channel
+    (scale, shift) = (gamma/sigma, beta - mu*gamma/sigma) of the original image,
+    with the timestep-embedding add folded into the second shift; the sparse
+    pass feeds them to Gather / ScatterGather as the fused affine + SiLU.
+  * resolutions below `sparse_threshold` run dense convs on the cached affine.
+"""
+import math
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from ..nn import Gather, Scatter, ScatterGather, ScatterWithBlockResidual, SIGEConv2d, SIGEModel, SIGEModule
+
+
+@dataclass
+class DDPMConfig:
+    ch: int = 128
+    ch_mult: Tuple[int, ...] = (1, 1, 2, 2, 4, 4)
+    num_res_blocks: int = 2
+    attn_resolutions: Tuple[int, ...] = (16,)
+    in_ch: int = 3
+    out_ch: int = 3
+    resolution: int = 256
+    main_block: Optional[int] = 6       # tile edge for 3x3 convs
+    shortcut_block: Optional[int] = 4   # tile edge for 1x1 convs
+    sparse_threshold: int = 64
+    groups: int = 32
+    eps: float = 1e-6
+    # The reference's SIGEFusedAttnBlock stores its cached (scale, shift) un-keyed
+    # (sige_fused_unet.py:170) and then indexes them with cache_id, so its sparse
+    # pass normalises every channel with channel 0's statistics.  True reproduces
+    # that (bit-for-bit model-level parity tests); False is the intended math.
+    reference_attn_quirk: bool = False
+
+
+def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    half = dim // 2
+    freq = torch.exp(torch.arange(half, dtype=torch.float32, device=t.device) * (-math.log(10000) / (half - 1)))
+    arg = t.float()[:, None] * freq[None, :]
+    emb = torch.cat([arg.sin(), arg.cos()], dim=1)
+    return F.pad(emb, (0, 1)) if dim % 2 else emb
+
+
+def norm_affine(x: torch.Tensor, norm: nn.GroupNorm):
+    """Per-channel (scale, shift) with GroupNorm(x) == x * scale + shift, batch 1."""
+    n, c, h, w = x.shape
+    assert n == 1, "SIGE caches one original image"
+    g = norm.num_groups
+    var, mean = torch.var_mean(x.reshape(g, -1), dim=1, unbiased=False)
+    inv = torch.rsqrt(var + norm.eps).repeat_interleave(c // g)
+    mu = mean.repeat_interleave(c // g)
+    scale = inv * norm.weight
+    shift = norm.bias - mu * scale
+    return scale, shift
+
+
+def _as4(v: torch.Tensor) -> torch.Tensor:
+    return v.reshape(1, -1, 1, 1)
+
+
+class ResBlock(SIGEModule):
+    def __init__(self, cfg: DDPMConfig, cin: int, cout: int, sparse: bool):
+        super().__init__()
+        self.cin, self.cout = cin, cout
+        self.sparse_main = sparse and cfg.main_block is not None
+        Conv = SIGEConv2d if self.sparse_main else nn.Conv2d
+        self.norm1 = nn.GroupNorm(cfg.groups, cin, eps=cfg.eps)
+        self.conv1 = Conv(cin, cout, 3, 1, 1)
+        self.norm2 = nn.GroupNorm(cfg.groups, cout, eps=cfg.eps)
+        self.conv2 = Conv(cout, cout, 3, 1, 1)
+        self.sparse_shortcut = False
+        if self.sparse_main:
+            self.main_gather = Gather(self.conv1, cfg.main_block, activation_name="swish")
+            self.scatter_gather = ScatterGather(self.main_gather, activation_name="swish")
+        if cin != cout:
+            self.sparse_shortcut = self.sparse_main and cfg.shortcut_block is not None
+            self.nin_shortcut = (SIGEConv2d if self.sparse_shortcut else nn.Conv2d)(cin, cout, 1, 1, 0)
+            if self.sparse_shortcut:
+                self.shortcut_gather = Gather(self.nin_shortcut, cfg.shortcut_block)
+                self.scatter = ScatterWithBlockResidual(self.main_gather, self.shortcut_gather)
+        if self.sparse_main and not self.sparse_shortcut:
+            self.scatter = Scatter(self.main_gather)
+        self.affine = {}  # cache_id -> (scale1, shift1, scale2, shift2) as [1,C,1,1]
+
+    def clear_cache(self):
+        self.affine = {}
+
+    def forward(self, x: torch.Tensor, temb: Optional[torch.Tensor]) -> torch.Tensor:
+        if self.mode == "full":
+            return self._full(x, temb)
+        if self.mode in ("sparse", "profile"):
+            return self._sparse(x)
+        raise NotImplementedError("Unknown mode [%s]!!!" % self.mode)
+
+    def _shortcut(self, x):
+        if self.cin == self.cout:
+            return x
+        if self.sparse_shortcut:
+            x = self.shortcut_gather(x)
+        return self.nin_shortcut(x)
+
+    def _full(self, x, temb):
+        skip = self._shortcut(x)
+        h = self.main_gather(x) if self.sparse_main else x  # records the input resolution
+        s1, t1 = norm_affine(h, self.norm1)
+        h = self.conv1(F.silu(h * _as4(s1) + _as4(t1)))
+        if self.sparse_main:
+            h = self.scatter_gather(h)
+        te = temb.reshape(-1)
+        s2, t2 = norm_affine(h + _as4(te), self.norm2)
+        t2 = t2 + te * s2  # fold the timestep-embedding add into the cached shift
+        self.affine[self.cache_id] = tuple(_as4(v).contiguous() for v in (s1, t1, s2, t2))
+        h = self.conv2(F.silu(h * _as4(s2) + _as4(t2)))
+        return self.scatter(h, skip) if self.sparse_main else h + skip
+
+    def _sparse(self, x):
+        s1, t1, s2, t2 = self.affine[self.cache_id]
+        skip = self._shortcut(x)
+        if self.sparse_main:
+            h = self.conv1(self.main_gather(x, s1, t1))
+            h = self.conv2(self.scatter_gather(h, s2, t2))
+            return self.scatter(h, skip)
+        h = self.conv1(F.silu(x * s1 + t1))
+        h = self.conv2(F.silu(h * s2 + t2))
+        return h + skip
+
+
+class AttnBlock(SIGEModule):
+    def __init__(self, cfg: DDPMConfig, ch: int, sparse: bool):
+        super().__init__()
+        self.ch = ch
+        self.quirk = cfg.reference_attn_quirk
+        self.sparse = sparse and cfg.shortcut_block is not None
+        Conv = SIGEConv2d if self.sparse else nn.Conv2d
+        self.norm = nn.GroupNorm(cfg.groups, ch, eps=cfg.eps)
+        self.qkv = Conv(ch, 3 * ch, 1, 1, 0)
+        self.proj_out = Conv(ch, ch, 1, 1, 0)
+        if self.sparse:
+            self.gather1 = Gather(self.qkv, cfg.shortcut_block)
+            self.scatter1 = Scatter(self.gather1)
+            self.gather2 = Gather(self.proj_out, cfg.shortcut_block)
+            self.scatter2 = Scatter(self.gather2)
+        self.affine = {}
+
+    def clear_cache(self):
+        self.affine = {}
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.mode == "full":
+            h = self.gather1(x) if self.sparse else x
+            s, t = norm_affine(h, self.norm)
+            self.affine[self.cache_id] = (_as4(s).contiguous(), _as4(t).contiguous())
+            h = h * _as4(s) + _as4(t)
+        else:
+            s, t = self.affine[self.cache_id]
+            if self.quirk:
+                s, t = s[:, :1].expand_as(s).contiguous(), t[:, :1].expand_as(t).contiguous()
+            h = self.gather1(x, s, t) if self.sparse else x * s + t
+        qkv = self.qkv(h)
+        if self.sparse:
+            qkv = self.scatter1(qkv)
+        b, _, hh, ww = qkv.shape
+        q, k, v = qkv.reshape(b, 3, self.ch, hh * ww).unbind(1)
+        attn = torch.softmax(torch.bmm(q.transpose(1, 2), k) * (self.ch ** -0.5), dim=2)  # [b, hw(q), hw(k)]
+        h = torch.bmm(v, attn.transpose(1, 2)).reshape(b, self.ch, hh, ww)
+        if self.sparse:
+            h = self.gather2(h)
+        h = self.proj_out(h)
+        return self.scatter2(h, x) if self.sparse else h + x
+
+
+class Upsample(SIGEModule):
+    """nearest x2 then a tiled 3x3 conv (always tiled, as in the reference)."""
+
+    def __init__(self, cfg: DDPMConfig, ch: int):
+        super().__init__()
+        self.conv = SIGEConv2d(ch, ch, 3, 1, 1)
+        self.gather = Gather(self.conv, cfg.main_block)
+        self.scatter = Scatter(self.gather)
+
+    def forward(self, x):
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+        return self.scatter(self.conv(self.gather(x)))
+
+
+class Downsample(SIGEModule):
+    """3x3 stride-2 conv with (0,1,0,1) zero padding; tiled when `sparse` (the
+    gather's zero fill past the bottom/right border IS the padding then)."""
+
+    def __init__(self, cfg: DDPMConfig, ch: int, sparse: bool):
+        super().__init__()
+        self.sparse = sparse
+        self.conv = (SIGEConv2d if sparse else nn.Conv2d)(ch, ch, 3, 2, 0)
+        if sparse:
+            self.gather = Gather(self.conv, cfg.main_block)
+            self.scatter = Scatter(self.gather)
+
+    def forward(self, x):
+        if not self.sparse:
+            return self.conv(F.pad(x, (0, 1, 0, 1)))
+        x = self.gather(x)
+        if self.mode == "full":
+            x = F.pad(x, (0, 1, 0, 1))
+        return self.scatter(self.conv(x))
+
+
+class DDPMSparseUNet(SIGEModel):
+    def __init__(self, cfg: DDPMConfig = DDPMConfig()):
+        super().__init__()
+        self.cfg = cfg
+        ch, mult = cfg.ch, tuple(cfg.ch_mult)
+        self.ch, self.temb_ch = ch, 4 * ch
+        self.num_levels = len(mult)
+        self.resolution = cfg.resolution
+        self.conv_in = nn.Conv2d(cfg.in_ch, ch, 3, 1, 1)
+        temb_slices = []
+
+        res = cfg.resolution
+        in_mult = (1,) + mult
+        self.down = nn.ModuleList()
+        cur = ch
+        for lvl in range(self.num_levels):
+            stage = nn.Module()
+            stage.block, stage.attn = nn.ModuleList(), nn.ModuleList()
+            cur, cout = ch * in_mult[lvl], ch * mult[lvl]
+            sparse = res >= cfg.sparse_threshold
+            for _ in range(cfg.num_res_blocks):
+                stage.block.append(ResBlock(cfg, cur, cout, sparse))
+                temb_slices.append(cout)
+                cur = cout
+                if res in cfg.attn_resolutions:
+                    stage.attn.append(AttnBlock(cfg, cur, sparse))
+            if lvl != self.num_levels - 1:
+                stage.downsample = Downsample(cfg, cur, sparse)
+                res //= 2
+            self.down.append(stage)
+
+        self.mid = nn.Module()
+        self.mid.block_1 = ResBlock(cfg, cur, cur, False)
+        self.mid.attn_1 = AttnBlock(cfg, cur, False)
+        self.mid.block_2 = ResBlock(cfg, cur, cur, False)
+        temb_slices += [cur, cur]
+
+        ups = []
+        for lvl in reversed(range(self.num_levels)):
+            stage = nn.Module()
+            stage.block, stage.attn = nn.ModuleList(), nn.ModuleList()
+            cout = ch * mult[lvl]
+            sparse = res >= cfg.sparse_threshold
+            for i in range(cfg.num_res_blocks + 1):
+                skip = ch * (in_mult[lvl] if i == cfg.num_res_blocks else mult[lvl])
+                stage.block.append(ResBlock(cfg, cur + skip, cout, sparse))
+                temb_slices.append(cout)
+                cur = cout
+                if res in cfg.attn_resolutions:
+                    stage.attn.append(AttnBlock(cfg, cur, sparse))
+            if lvl != 0:
+                stage.upsample = Upsample(cfg, cur)
+                res *= 2
+            ups.insert(0, stage)
+        self.up = nn.ModuleList(ups)
+
+        self.temb_slices = temb_slices
+        self.temb = nn.Module()
+        self.temb.dense = nn.ModuleList([nn.Linear(ch, self.temb_ch), nn.Linear(self.temb_ch, self.temb_ch),
+                                         nn.Linear(self.temb_ch, sum(temb_slices))])
+        self.norm_out = nn.GroupNorm(cfg.groups, cur, eps=cfg.eps)
+        self.conv_out = nn.Conv2d(cur, cfg.out_ch, 3, 1, 1)
+
+    def _temb(self, t):
+        if self.mode != "full":
+            return None  # folded into the cached shifts
+        e = timestep_embedding(t, self.ch)
+        e = F.silu(self.temb.dense[0](e))
+        e = F.silu(self.temb.dense[1](e))
+        return list(torch.split(self.temb.dense[2](e), self.temb_slices, dim=1))
+
+    def forward(self, x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        assert x.shape[2] == x.shape[3] == self.resolution
+        temb = self._temb(t)
+        nxt = (lambda: temb.pop(0)) if temb is not None else (lambda: None)
+
+        hs = [self.conv_in(x)]
+        for lvl, stage in enumerate(self.down):
+            for i, block in enumerate(stage.block):
+                h = block(hs[-1], nxt())
+                if len(stage.attn):
+                    h = stage.attn[i](h)
+                hs.append(h)
+            if lvl != self.num_levels - 1:
+                hs.append(stage.downsample(hs[-1]))
+
+        h = self.mid.block_1(hs[-1], nxt())
+        h = self.mid.attn_1(h)
+        h = self.mid.block_2(h, nxt())
+
+        for lvl in reversed(range(self.num_levels)):
+            stage = self.up[lvl]
+            for i, block in enumerate(stage.block):
+                h = block(torch.cat([h, hs.pop()], dim=1), nxt())
+                if len(stage.attn):
+                    h = stage.attn[i](h)
+            if lvl != 0:
+                h = stage.upsample(h)
+        return self.conv_out(F.silu(self.norm_out(h)))
+

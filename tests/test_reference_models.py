@@ -1,0 +1,47 @@
+"""Model-level drop-in checks against the REAL reference (build container only:
+needs /root/reference).  Each stack runs in its own process (the reference's
+`sige` package and ours cannot share one interpreter)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.reference
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _run(stack, state, out, ch=32, ratio=0.05):
+    cmd = [sys.executable, os.path.join(HERE, "ref_runner.py"), "--stack", stack, "--state", state, "--out", out,
+           "--ch", str(ch), "--ratio", str(ratio)]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, res.stderr[-3000:]
+    return np.load(out)
+
+
+@pytest.fixture(scope="module")
+def reference_run(tmp_path_factory):
+    d = tmp_path_factory.mktemp("ddpm")
+    state = str(d / "state.pt")
+    return state, d, _run("reference", state, str(d / "ref.npz"))
+
+
+def test_unchanged_reference_model_runs_on_sige_amd(reference_run):
+    """diffusion/models/ddpm_arch/sige_fused_unet.py, unmodified, on top of sige_amd's
+    module API: same full and sparse outputs as on the reference's own stack."""
+    state, d, ref = reference_run
+    ours = _run("ours-refmodel", state, str(d / "ours_refmodel.npz"))
+    np.testing.assert_allclose(ours["full"], ref["full"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(ours["sparse"], ref["sparse"], rtol=0, atol=1e-4)
+
+
+def test_workload_unet_equals_reference_model(reference_run):
+    """The benchmark harness U-Net loads the reference model's state dict and
+    reproduces its full and sparse outputs."""
+    state, d, ref = reference_run
+    ours = _run("ours-workload", state, str(d / "ours_workload.npz"))
+    np.testing.assert_allclose(ours["full"], ref["full"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(ours["sparse"], ref["sparse"], rtol=0, atol=2e-4)
+    # sanity: the sparse output is a real function of the edit
+    assert np.abs(ref["sparse"] - ref["full"]).max() > 1e-2
