@@ -97,6 +97,7 @@ class ResBlock(SIGEModule):
         if self.sparse_main and not self.sparse_shortcut:
             self.scatter = Scatter(self.main_gather)
         self.affine = {}  # cache_id -> (scale1, shift1, scale2, shift2) as [1,C,1,1]
+        self.plain = False
 
     def clear_cache(self):
         self.affine = {}
@@ -115,7 +116,17 @@ class ResBlock(SIGEModule):
             x = self.shortcut_gather(x)
         return self.nin_shortcut(x)
 
+    def _plain(self, x, temb):
+        """Dense forward with stock GroupNorm and no caching (the "original model"
+        baseline the speedup is quoted against)."""
+        skip = x if self.cin == self.cout else self.nin_shortcut(x)
+        h = self.conv1(F.silu(self.norm1(x)))
+        h = self.conv2(F.silu(self.norm2(h + temb.reshape(1, -1, 1, 1))))
+        return h + skip
+
     def _full(self, x, temb):
+        if self.plain:
+            return self._plain(x, temb)
         skip = self._shortcut(x)
         h = self.main_gather(x) if self.sparse_main else x  # records the input resolution
         s1, t1 = norm_affine(h, self.norm1)
@@ -157,12 +168,15 @@ class AttnBlock(SIGEModule):
             self.gather2 = Gather(self.proj_out, cfg.shortcut_block)
             self.scatter2 = Scatter(self.gather2)
         self.affine = {}
+        self.plain = False
 
     def clear_cache(self):
         self.affine = {}
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if self.mode == "full":
+        if self.mode == "full" and self.plain:
+            h = self.norm(x)
+        elif self.mode == "full":
             h = self.gather1(x) if self.sparse else x
             s, t = norm_affine(h, self.norm)
             self.affine[self.cache_id] = (_as4(s).contiguous(), _as4(t).contiguous())
@@ -172,17 +186,18 @@ class AttnBlock(SIGEModule):
             if self.quirk:
                 s, t = s[:, :1].expand_as(s).contiguous(), t[:, :1].expand_as(t).contiguous()
             h = self.gather1(x, s, t) if self.sparse else x * s + t
+        plain = self.mode == "full" and self.plain
         qkv = self.qkv(h)
-        if self.sparse:
+        if self.sparse and not plain:
             qkv = self.scatter1(qkv)
         b, _, hh, ww = qkv.shape
         q, k, v = qkv.reshape(b, 3, self.ch, hh * ww).unbind(1)
         attn = torch.softmax(torch.bmm(q.transpose(1, 2), k) * (self.ch ** -0.5), dim=2)  # [b, hw(q), hw(k)]
         h = torch.bmm(v, attn.transpose(1, 2)).reshape(b, self.ch, hh, ww)
-        if self.sparse:
+        if self.sparse and not plain:
             h = self.gather2(h)
         h = self.proj_out(h)
-        return self.scatter2(h, x) if self.sparse else h + x
+        return self.scatter2(h, x) if (self.sparse and not plain) else h + x
 
 
 class Upsample(SIGEModule):
@@ -193,9 +208,12 @@ class Upsample(SIGEModule):
         self.conv = SIGEConv2d(ch, ch, 3, 1, 1)
         self.gather = Gather(self.conv, cfg.main_block)
         self.scatter = Scatter(self.gather)
+        self.plain = False
 
     def forward(self, x):
         x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+        if self.plain and self.mode == "full":
+            return self.conv(x)
         return self.scatter(self.conv(self.gather(x)))
 
 
@@ -206,13 +224,14 @@ class Downsample(SIGEModule):
     def __init__(self, cfg: DDPMConfig, ch: int, sparse: bool):
         super().__init__()
         self.sparse = sparse
+        self.plain = False
         self.conv = (SIGEConv2d if sparse else nn.Conv2d)(ch, ch, 3, 2, 0)
         if sparse:
             self.gather = Gather(self.conv, cfg.main_block)
             self.scatter = Scatter(self.gather)
 
     def forward(self, x):
-        if not self.sparse:
+        if not self.sparse or (self.plain and self.mode == "full"):
             return self.conv(F.pad(x, (0, 1, 0, 1)))
         x = self.gather(x)
         if self.mode == "full":
@@ -282,6 +301,12 @@ class DDPMSparseUNet(SIGEModel):
                                          nn.Linear(self.temb_ch, sum(temb_slices))])
         self.norm_out = nn.GroupNorm(cfg.groups, cur, eps=cfg.eps)
         self.conv_out = nn.Conv2d(cur, cfg.out_ch, 3, 1, 1)
+
+    def set_plain_dense(self, plain: bool):
+        """full mode = stock dense U-Net (F.group_norm, no cache bookkeeping)."""
+        for m in self.modules():
+            if isinstance(m, (ResBlock, AttnBlock, Upsample, Downsample)):
+                m.plain = plain
 
     def _temb(self, t):
         if self.mode != "full":

@@ -1,0 +1,126 @@
+"""Multi-process path on CPU (gloo, world_size 2): rank 0 owns the original image's
+cache, one broadcast distributes it, each rank runs its own edit."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _build():
+    from tests.test_host_logic import ResNet
+
+    torch.manual_seed(11)
+    net = ResNet(8, 12).eval()
+    blk = net.block
+    blk.s1, blk.t1 = torch.randn(1, 8, 1, 1), torch.randn(1, 8, 1, 1)
+    blk.s2, blk.t2 = torch.randn(1, 12, 1, 1), torch.randn(1, 12, 1, 1)
+    return net
+
+
+def _inputs():
+    g = torch.Generator().manual_seed(5)
+    orig = torch.randn(1, 8, 32, 32, generator=g)
+    edits = []
+    for r in range(4):
+        m = torch.zeros(32, 32, dtype=torch.bool)
+        m[4 + 5 * r:9 + 5 * r, 6 + 3 * r:14 + 3 * r] = True
+        edits.append((m, orig + torch.randn(1, 8, 32, 32, generator=g) * m))
+    return orig, edits
+
+
+def _sparse(net, mask, x):
+    from sige_amd.utils import dilate_mask
+
+    net.set_masks({(32, 32): dilate_mask(dilate_mask(mask, (2, 0)), (0, 2))})
+    net.set_mode("sparse")
+    return net(x)
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle
+    from sige_amd import parallel, runtime
+
+    runtime.register_backend("cpu", oracle)
+    net = _build()
+    orig, edits = _inputs()
+    with torch.no_grad():
+        net.set_mode("full")
+        # rank 0 holds the true original; the others only need the cache SLOTS (shapes)
+        net(orig if rank == 0 else torch.zeros_like(orig))
+        flat = parallel.pack_caches(net)
+        parallel.broadcast_cache(flat, src=0)
+        mine = parallel.shard(list(range(len(edits))))
+        outs = {i: _sparse(net, *edits[i]) for i in mine}
+    torch.save({"outs": outs, "flat_sum": float(flat.double().sum())}, os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_cache_broadcast_and_sharded_edits(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(tmp_path / ("rank%d.pt" % r)) for r in range(world)]
+    assert res[0]["flat_sum"] == res[1]["flat_sum"]  # identical caches after the broadcast
+    assert sorted(res[0]["outs"]) == [0, 2] and sorted(res[1]["outs"]) == [1, 3]
+
+    # single-process ground truth
+    from oracle import oracle
+    from sige_amd import runtime
+
+    runtime.register_backend("cpu", oracle)
+    try:
+        net = _build()
+        orig, edits = _inputs()
+        with torch.no_grad():
+            for i, (m, x) in enumerate(edits):
+                net.set_mode("full")
+                dense = net(x)
+                net(orig)
+                want = _sparse(net, m, x)
+                got = res[i % world]["outs"][i]
+                assert torch.equal(got, want)
+                torch.testing.assert_close(got, dense, rtol=0, atol=1e-4)
+    finally:
+        runtime.unregister_backend("cpu")
+
+
+def test_pack_caches_keeps_results_and_aliases_buffer():
+    from oracle import oracle
+    from sige_amd import parallel, runtime
+
+    runtime.register_backend("cpu", oracle)
+    try:
+        net = _build()
+        orig, edits = _inputs()
+        with torch.no_grad():
+            net.set_mode("full")
+            net(orig)
+            before = _sparse(net, *edits[0])
+            flat = parallel.pack_caches(net)
+            after = _sparse(net, *edits[0])
+            assert torch.equal(before, after)
+            flat.zero_()  # the caches ARE the buffer now
+            assert float(net.block.scatter.original_outputs[0].abs().sum()) == 0.0
+    finally:
+        runtime.unregister_backend("cpu")
+
+
+def test_pack_caches_requires_full_pass():
+    from sige_amd import parallel
+
+    with pytest.raises(RuntimeError, match="full"):
+        parallel.pack_caches(_build())
