@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Profiling target: K hipGraph replays of one sparse (or dense) DDPM-256 U-Net
+forward, separated from all set-up work by a 0.5 s idle gap so that
+tools/trace_summary.py can isolate them in a rocprofv3 kernel trace.
+
+    rocprofv3 --kernel-trace --output-format csv -d OUT -o fwd -- \
+        python tools/profile_forward.py --ratio 0.012 --replays 50
+"""
+import argparse
+import os
+import sys
+import time
+import warnings
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+warnings.simplefilter("ignore")
+
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from sige_amd.utils import dilate_mask, downsample_mask  # noqa: E402
+from sige_amd.workloads.ddpm_unet import DDPMConfig, DDPMSparseUNet  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ratio", type=float, default=0.012)
+    ap.add_argument("--replays", type=int, default=50)
+    ap.add_argument("--mode", default="sparse", choices=["sparse", "dense", "eager"])
+    a = ap.parse_args()
+    dev = torch.device("cuda")
+    torch.backends.cudnn.benchmark = True
+    torch.manual_seed(0)
+    model = DDPMSparseUNet(DDPMConfig()).to(dev).eval()
+    gen = torch.Generator().manual_seed(1)
+    x0 = torch.randn(1, 3, 256, 256, generator=gen).to(dev)
+    noise = torch.randn(1, 3, 256, 256, generator=gen).to(dev)
+    t = torch.zeros(1, device=dev)
+    mask = bench.square_mask(a.ratio).to(dev)
+    x1 = x0 + noise * mask
+    with torch.no_grad():
+        model.set_mode("full")
+        if a.mode == "dense":
+            model.set_plain_dense(True)
+        else:
+            model(x0, t)
+            model.set_masks(downsample_mask(dilate_mask(mask, 5), 8))
+            model.set_mode("sparse")
+        if a.mode == "eager":
+            for _ in range(3):
+                model(x1, t)
+            torch.cuda.synchronize()
+            time.sleep(0.5)
+            for _ in range(a.replays):
+                model(x1, t)
+        else:
+            g, _ = bench.capture(model, x1, t)
+            g.replay()
+            torch.cuda.synchronize()
+            time.sleep(0.5)
+            for _ in range(a.replays):
+                g.replay()
+        torch.cuda.synchronize()
+    print("done", a.mode, a.ratio, a.replays)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Summarise the final burst of a rocprofv3 kernel trace (CSV): everything after
+the last idle gap >= --gap-ms is aggregated per kernel name and divided by the
+number of replays.  Writes a small CSV (suitable for profiles/) and prints the top."""
+import argparse
+import csv
+import re
+from collections import defaultdict
+
+
+def short(name: str) -> str:
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"\s+", " ", name)
+    return name[:160]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("trace")
+    ap.add_argument("--replays", type=int, required=True)
+    ap.add_argument("--gap-ms", type=float, default=200.0)
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--top", type=int, default=40)
+    a = ap.parse_args()
+    rows = []
+    with open(a.trace) as f:
+        rd = csv.DictReader(f)
+        for r in rd:
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    cut = 0
+    for i in range(1, len(rows)):
+        if rows[i][0] - rows[i - 1][1] >= a.gap_ms * 1e6:
+            cut = i
+    burst = rows[cut:]
+    span = (burst[-1][1] - burst[0][0]) / 1e6
+    agg = defaultdict(lambda: [0, 0])
+    for s, e, n in burst:
+        agg[short(n)][0] += 1
+        agg[short(n)][1] += e - s
+    busy = sum(v[1] for v in agg.values()) / 1e6
+    out = sorted(agg.items(), key=lambda kv: -kv[1][1])
+    with open(a.out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["# burst of %d kernels after the last %.0f ms idle gap; %d replays; wall %.3f ms/replay; "
+                    "kernel-busy %.3f ms/replay" % (len(burst), a.gap_ms, a.replays, span / a.replays, busy / a.replays)])
+        w.writerow(["kernel", "launches_per_replay", "avg_us", "us_per_replay", "pct_of_busy"])
+        for name, (cnt, ns) in out:
+            w.writerow([name, round(cnt / a.replays, 2), round(ns / cnt / 1e3, 2), round(ns / a.replays / 1e3, 2),
+                        round(100.0 * ns / (busy * 1e6), 2)])
+    print("wall %.3f ms/replay, kernel-busy %.3f ms/replay, %d kernels/replay" % (span / a.replays, busy / a.replays, len(burst) // a.replays))
+    for name, (cnt, ns) in out[: a.top]:
+        print("%7.1f us/replay %6.1f launches avg %8.2f us  %s" % (ns / a.replays / 1e3, cnt / a.replays, ns / cnt / 1e3, name[:110]))
+
+
+if __name__ == "__main__":
+    main()
