@@ -141,8 +141,9 @@ int sige_hip_reduce_mask_i32(const uint8_t *mask, int H, int W, int bH, int bW,
  * SIGEConv2d.forward in sparse mode (sige/nn/base.py:88-89) ----------------
  * x [T,Cin,R,S] (*) w [Cout,Cin/groups,kH,kW] + bias -> out [T,Cout,Ro,So],
  * padding 0, dilation 1, Ro=(R-kH)/strH+1.
- * The MFMA path (fp32-in/fp32-acc v_mfma_f32_32x32x2_f32, exact fp32 products)
- * needs the weights re-laid once per weight tensor:
+ * The MFMA path (fp32-in/fp32-acc v_mfma_f32_32x32x2_f32 / 16x16x4_f32, exact
+ * fp32 products; the library picks the tile by grid size) needs the weights
+ * re-laid once per weight tensor (both tile layouts, back to back):
  *   n = sige_hip_block_conv_packed_size(...)   floats to allocate (0 = this shape
  *                                              has no MFMA path; use _direct)
  *   sige_hip_block_conv_pack_f32(w, ..., packed)
@@ -159,6 +160,33 @@ int sige_hip_block_conv_f32(const float *x, int T, int Cin, int R, int S,
 int sige_hip_block_conv_direct_f32(const float *x, int T, int Cin, int R, int S,
                                    const float *w, const float *bias, int Cout, int kH, int kW,
                                    int strideH, int strideW, int groups, float *out, void *stream);
+
+/* ---- fused gather -> conv and scatter_gather -> conv ------------------------
+ * The same MFMA conv with the producer of its input tiles fused into the
+ * prologue: the [B*N,Cin,bH,bW] tile tensor of gather (sige/cpu/gather.cpp:4-58)
+ * resp. scatter_gather (sige/cpu/scatter_gather.cpp:5-56) is staged straight
+ * into LDS and never written to HBM.  Equivalent to
+ *     sige_hip_gather_f32(...)          ; sige_hip_block_conv_f32(...)
+ *     sige_hip_scatter_gather_f32(...)  ; sige_hip_block_conv_f32(...)
+ * for activation_first = 0 and a per-(batch,channel) affine (scale/shift dims
+ * [1|B, 1|C, 1, 1], which is what every caller in the reference passes:
+ * sige_fused_unet.py:111,118-120); anything else -> SIGE_HIP_EUNSUPPORTED and
+ * the caller uses the two-call form.  out [B*N,Cout,Ro,So].                   */
+int sige_hip_gather_conv_f32(const float *x, int B, int Cin, int H, int W, int bH, int bW,
+                             const int32_t *active_indices, int N,
+                             const float *scale, int scaleB, int scaleC, int scaleH, int scaleW,
+                             const float *shift, int shiftB, int shiftC, int shiftH, int shiftW,
+                             int activation,
+                             const float *packed, const float *bias, int Cout, int kH, int kW,
+                             int strideH, int strideW, float *out, void *stream);
+int sige_hip_scatter_gather_conv_f32(const float *x, const float *y, int B, int Cin, int H, int W,
+                                     int Rx, int Sx, int bH, int bW,
+                                     const int32_t *active_indices, int N, const int32_t *scatter_map,
+                                     const float *scale, int scaleB, int scaleC, int scaleH, int scaleW,
+                                     const float *shift, int shiftB, int shiftC, int shiftH, int shiftW,
+                                     int activation,
+                                     const float *packed, const float *bias, int Cout, int kH, int kW,
+                                     int strideH, int strideW, float *out, void *stream);
 
 /* ---- plain device copy used by the cache broadcast path (packs the cached
  * activations of Scatter / ScatterGather modules into one buffer) ---------- */

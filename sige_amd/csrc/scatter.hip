@@ -165,17 +165,32 @@ __global__ __launch_bounds__(kThreads) void fused_scatter_kernel(FusedArgs a) {
         if (VEC == 4) {
             const float4 t = *reinterpret_cast<const float4 *>(a.y0 + q);
             v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-            if (BLOCK_RES) {
-                const float4 s = *reinterpret_cast<const float4 *>(a.y1 + q);
-                r1[0] = s.x; r1[1] = s.y; r1[2] = s.z; r1[3] = s.w;
-            }
         } else {
             v[0] = a.y0[q];
-            if (BLOCK_RES) r1[0] = a.y1[q];
+        }
+        // tile lookups first: the cached shortcut tensor y1 is only needed where a
+        // main or a shortcut tile covers the pixels (a few % of the plane)
+        int t0v[VEC], t1v[VEC];
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const int ww = w + i;
+            if (TS == 4 && VEC == 4) t0v[i] = (i == 0) ? a.table0[(h / a.R0) * a.gW0 + (w >> 2)] : t0v[0];
+            else t0v[i] = a.table0[(h / a.R0) * a.gW0 + ww / a.S0];
+            t1v[i] = BLOCK_RES ? a.table1[(h / a.R1) * a.gW1 + ww / a.S1] : -1;
+            any |= (t0v[i] >= 0) | (t1v[i] >= 0);
+        }
+        if (BLOCK_RES && any) {
+            if (VEC == 4) {
+                const float4 s = *reinterpret_cast<const float4 *>(a.y1 + q);
+                r1[0] = s.x; r1[1] = s.y; r1[2] = s.z; r1[3] = s.w;
+            } else {
+                r1[0] = a.y1[q];
+            }
         }
         if (TS == 4 && VEC == 4) {
             // main tiles: 4 wide, w % 4 == 0  ->  one tile, one 16-byte row of it
-            const int t0 = a.table0[(h / a.R0) * a.gW0 + (w >> 2)];
+            const int t0 = t0v[0];
             if (t0 >= 0) {
                 const float4 t = *reinterpret_cast<const float4 *>(x0b + (size_t)t0 * a.C * RS0 + (h % a.R0) * 4);
                 const float xv[4] = {t.x, t.y, t.z, t.w};
@@ -191,7 +206,7 @@ __global__ __launch_bounds__(kThreads) void fused_scatter_kernel(FusedArgs a) {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 const int ww = w + i;
-                const int t0 = a.table0[(h / a.R0) * a.gW0 + ww / a.S0];
+                const int t0 = t0v[i];
                 if (t0 >= 0) {
                     float z = x0b[(size_t)t0 * a.C * RS0 + (h % a.R0) * a.S0 + ww % a.S0];
                     if (BLOCK_RES) z = r1[i] + z;
@@ -204,7 +219,7 @@ __global__ __launch_bounds__(kThreads) void fused_scatter_kernel(FusedArgs a) {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 const int ww = w + i;
-                const int t1 = a.table1[(h / a.R1) * a.gW1 + ww / a.S1];
+                const int t1 = t1v[i];
                 if (t1 >= 0) v[i] += x1b[(size_t)t1 * a.C * RS1 + (h % a.R1) * a.S1 + ww % a.S1] - r1[i];
             }
         }

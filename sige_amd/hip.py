@@ -51,6 +51,11 @@ _SIGNATURES = {
     "sige_hip_block_conv_packed_size": (_c_sz, [_c_int] * 9),
     "sige_hip_block_conv_pack_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp]),
     "sige_hip_block_conv_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp, _c_vp]),
+    "sige_hip_gather_conv_f32": (
+        _c_int, [_c_vp] + [_c_int] * 6 + [_c_vp, _c_int] + _BC + _BC + [_c_int, _c_vp, _c_vp] + [_c_int] * 5 + [_c_vp, _c_vp]),
+    "sige_hip_scatter_gather_conv_f32": (
+        _c_int, [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + _BC + _BC + [_c_int, _c_vp, _c_vp]
+        + [_c_int] * 5 + [_c_vp, _c_vp]),
     "sige_hip_block_conv_direct_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp] + [_c_int] * 6 + [_c_vp, _c_vp]),
     "sige_hip_copy_f32": (_c_int, [_c_vp, _c_vp, _c_sz, _c_vp]),
 }
@@ -276,6 +281,51 @@ def block_conv(x, packed, bias, Cout: int, kernel: Tuple[int, int], stride: Tupl
     b = None if bias is None else _req(bias.detach(), torch.float32, "bias", 1).data_ptr()
     _check(lib().sige_hip_block_conv_f32(x.data_ptr(), T, Cin, R, S, packed.data_ptr(), b, Cout, kernel[0], kernel[1],
                                          stride[0], stride[1], out.data_ptr(), _stream(x)), "block_conv")
+    return out
+
+
+def _channel_affine(t: Optional[torch.Tensor]) -> bool:
+    return t is None or (t.dim() == 4 and t.shape[2] == 1 and t.shape[3] == 1)
+
+
+def fusable_affine(scale, shift, activation_first: bool) -> bool:
+    """True if gather_conv / scatter_gather_conv can absorb this gather."""
+    return (not activation_first) and _channel_affine(scale) and _channel_affine(shift)
+
+
+def gather_conv(x, block: Tuple[int, int], activeIndices, scale, shift, activationName: str,
+                packed, bias, Cout: int, kernel: Tuple[int, int], stride: Tuple[int, int]):
+    """gather(x, ...) followed by the stacked-block conv, in one kernel."""
+    x = _req(x, torch.float32, "x")
+    idx = _req(activeIndices, torch.int32, "activeIndices", 2)
+    (sa, s_keep), (ta, t_keep) = _bc(scale, "scale"), _bc(shift, "shift")
+    B, C, H, W = x.shape
+    N = idx.shape[0]
+    Ro, So = (block[0] - kernel[0]) // stride[0] + 1, (block[1] - kernel[1]) // stride[1] + 1
+    out = torch.empty((B * N, Cout, Ro, So), dtype=torch.float32, device=x.device)
+    b = None if bias is None else _req(bias.detach(), torch.float32, "bias", 1).data_ptr()
+    _check(lib().sige_hip_gather_conv_f32(x.data_ptr(), B, C, H, W, block[0], block[1], idx.data_ptr(), N, *sa, *ta,
+                                          _act(activationName), packed.data_ptr(), b, Cout, kernel[0], kernel[1],
+                                          stride[0], stride[1], out.data_ptr(), _stream(x)), "gather_conv")
+    return out
+
+
+def scatter_gather_conv(x, y, block: Tuple[int, int], activeIndices, scatterMap, scale, shift, activationName: str,
+                        packed, bias, Cout: int, kernel: Tuple[int, int], stride: Tuple[int, int]):
+    """scatter_gather(x, y, ...) followed by the stacked-block conv, in one kernel."""
+    x, y = _req(x, torch.float32, "x"), _req(y, torch.float32, "y")
+    idx = _req(activeIndices, torch.int32, "activeIndices", 2)
+    smap = _req(scatterMap, torch.int32, "scatterMap", 3)
+    (sa, s_keep), (ta, t_keep) = _bc(scale, "scale"), _bc(shift, "shift")
+    B, C, H, W = y.shape
+    N = idx.shape[0]
+    Ro, So = (block[0] - kernel[0]) // stride[0] + 1, (block[1] - kernel[1]) // stride[1] + 1
+    out = torch.empty((B * N, Cout, Ro, So), dtype=torch.float32, device=y.device)
+    b = None if bias is None else _req(bias.detach(), torch.float32, "bias", 1).data_ptr()
+    _check(lib().sige_hip_scatter_gather_conv_f32(
+        x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3], block[0], block[1], idx.data_ptr(), N,
+        smap.data_ptr(), *sa, *ta, _act(activationName), packed.data_ptr(), b, Cout, kernel[0], kernel[1],
+        stride[0], stride[1], out.data_ptr(), _stream(y)), "scatter_gather_conv")
     return out
 
 

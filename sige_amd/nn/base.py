@@ -20,6 +20,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from .. import runtime as _runtime
+from . import deferred
 
 MODES = ("full", "sparse", "profile")
 
@@ -147,8 +148,19 @@ class SIGEConv2d(nn.Conv2d, SIGEModule):
         from .. import hip
 
         if tuple(self.dilation) != (1, 1):  # no dilated kernel in libsige_hip: torch's conv
-            return F.conv2d(x, self.weight, self.bias, self.stride, (0, 0), self.dilation, self.groups)
+            return F.conv2d(deferred.resolve(x), self.weight, self.bias, self.stride, (0, 0), self.dilation,
+                            self.groups)
         packed = self._packed_weights(x) if self.groups == 1 else None
+        spec = x.spec if isinstance(x, deferred.DeferredTiles) else None
+        if packed is not None and spec is not None:
+            # the producer of the tiles has not run: fuse it into the conv's prologue
+            common = (packed, self.bias, self.out_channels, self.kernel_size, self.stride)
+            if spec["kind"] == "gather":
+                return hip.gather_conv(spec["x"], spec["block"], spec["idx"], spec["scale"], spec["shift"],
+                                       spec["act"], *common)
+            return hip.scatter_gather_conv(spec["x"], spec["y"], spec["block"], spec["idx"], spec["map"],
+                                           spec["scale"], spec["shift"], spec["act"], *common)
+        x = deferred.resolve(x)
         if packed is not None:
             return hip.block_conv(x, packed, self.bias, self.out_channels, self.kernel_size, self.stride)
         return hip.block_conv_direct(x, self.weight, self.bias, self.stride, self.groups)

@@ -1,0 +1,110 @@
+"""Deferred tile tensors: how gather -> conv fusion happens under an UNCHANGED
+module API.
+
+The reference's models call `Gather` (or `ScatterGather`) and then, as a separate
+module, the conv that consumes the tiles (sige_fused_unet.py:118-125).  To fuse
+the two into one MFMA kernel without touching that calling convention, the
+sparse-mode Gather / ScatterGather return a `DeferredTiles`: a tensor subclass
+with the right shape / dtype / device but no storage, remembering how to produce
+its values.
+
+  * consumed by `SIGEConv2d` -> the conv launches `gather_conv` /
+    `scatter_gather_conv` (tiles staged straight into LDS, never written to HBM);
+  * touched by ANY other torch operation (`tiles * (1 + gamma)`, `.view`,
+    `torch.cat`, printing, ...) -> it materialises itself through the ordinary
+    gather kernel first and the operation proceeds on the real tensor, so model
+    code that post-processes tiles (GauGAN's SPADE modulation, SD attention)
+    keeps working unchanged.
+"""
+import os
+from typing import Callable, Optional
+
+import torch
+from torch.utils._pytree import tree_map
+
+FORCE_ON_CPU = False  # tests: exercise the mechanism without a GPU
+
+
+def fusion_enabled() -> bool:
+    return os.environ.get("SIGE_AMD_FUSE", "1") != "0"
+
+
+_METADATA = None
+
+
+def _metadata_funcs():
+    global _METADATA
+    if _METADATA is None:
+        T = torch.Tensor
+        _METADATA = {
+            T.shape.__get__, T.dtype.__get__, T.device.__get__, T.ndim.__get__, T.is_cuda.__get__,
+            T.requires_grad.__get__, T.layout.__get__, T.is_sparse.__get__, T.is_quantized.__get__,
+            T.is_meta.__get__, T.names.__get__, T.grad_fn.__get__, T.is_leaf.__get__,
+            T.size, T.dim, T.numel, T.nelement, T.stride, T.is_contiguous, T.is_floating_point, T.is_complex,
+            T.element_size, T.get_device, T.__len__,
+        }
+    return _METADATA
+
+
+class DeferredTiles(torch.Tensor):
+    @staticmethod
+    def __new__(cls, shape, dtype, device, thunk: Callable[[], torch.Tensor], spec: dict):
+        t = torch.Tensor._make_wrapper_subclass(cls, tuple(shape), dtype=dtype, device=device, requires_grad=False)
+        t._thunk = thunk
+        t._spec = spec
+        t._value = None
+        return t
+
+    @property
+    def spec(self) -> Optional[dict]:
+        """Fusion recipe, or None once the tiles have been materialised."""
+        return self._spec if self._value is None else None
+
+    def materialize(self) -> torch.Tensor:
+        if self._value is None:
+            self._value = self._thunk()
+            self._thunk = None
+            self._spec = None
+        return self._value
+
+    def __repr__(self):
+        state = "pending" if self._value is None else "materialized"
+        return "DeferredTiles(shape=%s, %s)" % (tuple(self.shape), state)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in _metadata_funcs():
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **kwargs)
+        if func is torch.Tensor.contiguous and len(args) == 1 and not kwargs:
+            return args[0]  # dense NCHW by construction
+
+        def real(a):
+            return a.materialize() if isinstance(a, DeferredTiles) else a
+
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*tree_map(real, args), **tree_map(real, kwargs))
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        def real(a):
+            return a.materialize() if isinstance(a, DeferredTiles) else a
+
+        return func(*tree_map(real, args), **tree_map(real, kwargs or {}))
+
+
+def resolve(x: torch.Tensor) -> torch.Tensor:
+    """The real tensor behind `x` (materialising a pending DeferredTiles)."""
+    return x.materialize() if isinstance(x, DeferredTiles) else x
+
+
+def defer_ok(x: torch.Tensor, scale, shift, activation_first: bool, sparse_update: bool) -> bool:
+    if not fusion_enabled() or sparse_update or activation_first:
+        return False
+    if not (x.is_cuda or FORCE_ON_CPU):
+        return False
+    for t in (scale, shift):
+        if t is not None and (t.dim() != 4 or t.shape[2] != 1 or t.shape[3] != 1):
+            return False
+    return True

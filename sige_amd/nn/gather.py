@@ -13,6 +13,7 @@ import torch
 from torch import nn
 
 from ..utils import reduce_mask
+from . import deferred
 from .base import SIGEModule
 from .utils import activation
 
@@ -64,16 +65,23 @@ class Gather(SIGEModule):
         self.check_dim(x, scale, shift)
         if self.mode == "sparse":
             fn = self.native(self.runtime, x)
-            return fn(
-                x.contiguous(),
-                self.block_size[0],
-                self.block_size[1],
-                self.indices_on(x.device),
-                None if scale is None else scale.contiguous(),
-                None if shift is None else shift.contiguous(),
-                self.activation_name,
-                self.activation_first,
-            )
+            x = deferred.resolve(x).contiguous()
+            idx = self.indices_on(x.device)
+            scale = None if scale is None else scale.contiguous()
+            shift = None if shift is None else shift.contiguous()
+            bh, bw = self.block_size
+            act, first = self.activation_name, self.activation_first
+
+            def run():
+                return fn(x, bh, bw, idx, scale, shift, act, first)
+
+            if deferred.defer_ok(x, scale, shift, first, self.sparse_update):
+                # not computed yet: a SIGEConv2d consumer fuses it into its prologue,
+                # any other consumer materialises it through the gather kernel
+                return deferred.DeferredTiles(
+                    (x.shape[0] * idx.shape[0], x.shape[1], bh, bw), x.dtype, x.device, run,
+                    dict(kind="gather", x=x, block=(bh, bw), idx=idx, scale=scale, shift=shift, act=act))
+            return run()
         if self.mode == "full":
             self.input_res = x.shape[2:]
             assert scale is None

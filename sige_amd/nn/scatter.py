@@ -13,6 +13,7 @@ from typing import Optional
 
 import torch
 
+from . import deferred
 from .base import SIGEModule, SIGEModuleWrapper
 from .gather import Gather
 
@@ -37,6 +38,7 @@ class Scatter(SIGEModule):
         self.check_dtype(x, residual)
         self.check_dim(x, residual)
         if self.mode == "sparse":
+            x = deferred.resolve(x)
             g: Gather = self.gather.module
             cached = self.original_outputs[self.cache_id]
             if _fused_ok(x):
@@ -91,6 +93,7 @@ class ScatterWithBlockResidual(SIGEModule):
         self.check_dtype(x, residual)
         self.check_dim(x, residual)
         if self.mode == "sparse":
+            x, residual = deferred.resolve(x), deferred.resolve(residual)
             mg: Gather = self.main_gather.module
             sg: Gather = self.shortcut_gather.module
             y0 = self.original_outputs[self.cache_id]

@@ -9,6 +9,7 @@ from typing import Dict, Optional
 
 import torch
 
+from . import deferred
 from .base import SIGEModule, SIGEModuleWrapper
 from .gather import Gather
 from .utils import activation
@@ -62,18 +63,22 @@ class ScatterGather(SIGEModule):
         if self.mode == "sparse":
             cached = self.original_outputs[self.cache_id]
             fn = self.native(self.runtime, x)
-            output = fn(
-                x.contiguous(),
-                cached.contiguous(),
-                g.block_size[0],
-                g.block_size[1],
-                g.indices_on(x.device),
-                self._map_on(x.device),
-                None if scale is None else scale.contiguous(),
-                None if shift is None else shift.contiguous(),
-                self.activation_name,
-                self.activation_first,
-            )
+            x = deferred.resolve(x).contiguous()
+            idx, smap = g.indices_on(x.device), self._map_on(x.device)
+            scale = None if scale is None else scale.contiguous()
+            shift = None if shift is None else shift.contiguous()
+            bh, bw = g.block_size
+            act, first = self.activation_name, self.activation_first
+
+            def run():
+                return fn(x, cached.contiguous(), bh, bw, idx, smap, scale, shift, act, first)
+
+            if deferred.defer_ok(x, scale, shift, first, self.sparse_update):
+                return deferred.DeferredTiles(
+                    (cached.shape[0] * idx.shape[0], x.shape[1], bh, bw), x.dtype, x.device, run,
+                    dict(kind="scatter_gather", x=x, y=cached, block=(bh, bw), idx=idx, map=smap, scale=scale,
+                         shift=shift, act=act))
+            output = run()
             if self.sparse_update:
                 if x.is_cuda:
                     from .. import hip

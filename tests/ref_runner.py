@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--ratio", type=float, default=0.05)
     ap.add_argument("--state", required=True, help="state-dict file (written by `reference`, read by the others)")
     ap.add_argument("--out", required=True)
+    ap.add_argument("--deferred", action="store_true", help="force DeferredTiles on CPU (fusion mechanism)")
     a = ap.parse_args()
 
     sys.path = [p for p in sys.path if os.path.abspath(p or ".") not in (REPO, HERE)]
@@ -62,6 +63,10 @@ def main():
 
         compat.install()
         runtime.register_backend("cpu", oracle)
+        if a.deferred:
+            from sige_amd.nn import deferred
+
+            deferred.FORCE_ON_CPU = True
     from sige.utils import dilate_mask, downsample_mask
 
     cfg = yaml.safe_load(open(os.path.join(REF, "diffusion", "configs", "church_ddpm256-sige.yml")))

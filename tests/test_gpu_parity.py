@@ -167,6 +167,80 @@ def test_block_conv_vs_torch_and_oracle(hip, cin, cout, k, stride, R):
         torch.testing.assert_close(nob, got - b.view(1, -1, 1, 1), rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize("C,cout,res,ratio,B", [(128, 128, 64, 0.05, 1), (64, 96, 128, 0.15, 2), (256, 256, 32, 0.3, 1),
+                                                 (48, 40, 64, 0.02, 1), (128, 128, 256, 0.15, 1)])
+def test_fused_gather_conv_equals_two_kernels(hip, C, cout, res, ratio, B):
+    """gather_conv / scatter_gather_conv == gather / scatter_gather followed by
+    block_conv, bit for bit (same staging values, same MFMA order), for the three
+    tile geometries and both MFMA tile sizes."""
+    from sige_amd.utils import reduce_mask
+
+    torch.manual_seed(C + res + B)
+    mask = _square_mask(ratio, res, res, res // 3, res // 4).to(DEV)
+    mask[0, 0] = mask[res - 1, res - 1] = True  # border tiles: zero fill inside the fused prologue
+    x = torch.randn(B, C, res, res, device=DEV)
+    y = torch.randn(B, C, res, res, device=DEV)
+    bias = torch.randn(cout, device=DEV)
+    for k, s, blk, off, scale_shape in ((3, 1, 6, 1, (1, C, 1, 1)), (1, 1, 4, 0, None), (3, 2, 5, 0, (B, C, 1, 1)),
+                                        (3, 1, 6, 1, None)):
+        idx = reduce_mask(mask, blk, 4, off)
+        w = torch.randn(cout, C, k, k, device=DEV) / (k * C ** 0.5)
+        packed = hip.conv_pack_weights(w, blk, blk, (s, s))
+        scale = None if scale_shape is None else torch.randn(*scale_shape, device=DEV)
+        shift = None if scale_shape is None else torch.randn(*scale_shape, device=DEV)
+        act = "swish" if scale_shape is not None else "identity"
+        tiles = hip.gather(x, blk, blk, idx, scale, shift, act, False)
+        two = hip.block_conv(tiles, packed, bias, cout, (k, k), (s, s))
+        one = hip.gather_conv(x, (blk, blk), idx, scale, shift, act, packed, bias, cout, (k, k), (s, s))
+        assert torch.equal(one, two), (k, s, (one - two).abs().max().item())
+        ref = torch.nn.functional.conv2d(tiles.double(), w.double(), bias.double(), s).float()
+        torch.testing.assert_close(one, ref, rtol=0, atol=1e-4)
+        if k == 3 and s == 1:
+            smap = hip.get_scatter_map(res, res, 6, 6, 3, 3, 1, 1, 1, 1, idx)
+            t4 = torch.randn(B * idx.shape[0], C, 4, 4, device=DEV)
+            sg = hip.scatter_gather(t4, y, 6, 6, idx, smap, scale, shift, act, False)
+            two = hip.block_conv(sg, packed, bias, cout, (3, 3), (1, 1))
+            one = hip.scatter_gather_conv(t4, y, (6, 6), idx, smap, scale, shift, act, packed, bias, cout, (3, 3),
+                                          (1, 1))
+            assert torch.equal(one, two)
+
+
+def test_deferred_fusion_in_modules():
+    """Module level: with fusion on, Gather returns DeferredTiles and the ResBlock
+    output is bit-identical to the unfused run (SIGE_AMD_FUSE=0)."""
+    import os
+
+    from sige_amd.nn import deferred
+    from sige_amd.utils import dilate_mask
+    from tests.test_host_logic import ResNet
+
+    torch.manual_seed(4)
+    net = ResNet(64, 128).to(DEV).eval()
+    blk = net.block
+    blk.s1, blk.t1 = torch.randn(1, 64, 1, 1, device=DEV), torch.randn(1, 64, 1, 1, device=DEV)
+    blk.s2, blk.t2 = torch.randn(1, 128, 1, 1, device=DEV), torch.randn(1, 128, 1, 1, device=DEV)
+    orig = torch.randn(1, 64, 64, 64, device=DEV)
+    mask = torch.zeros(64, 64, dtype=torch.bool, device=DEV)
+    mask[20:31, 12:40] = True
+    edited = orig + torch.randn_like(orig) * mask
+    with torch.no_grad():
+        net.set_mode("full")
+        dense = net(edited)
+        net(orig)
+        net.set_mode("sparse")
+        net.set_masks({(64, 64): dilate_mask(dilate_mask(mask, (2, 0)), (0, 2))})
+        assert isinstance(blk.main_gather(edited, blk.s1, blk.t1), deferred.DeferredTiles)
+        fused = net(edited)
+        os.environ["SIGE_AMD_FUSE"] = "0"
+        try:
+            assert not isinstance(blk.main_gather(edited, blk.s1, blk.t1), deferred.DeferredTiles)
+            unfused = net(edited)
+        finally:
+            del os.environ["SIGE_AMD_FUSE"]
+    assert torch.equal(fused, unfused)
+    torch.testing.assert_close(fused, dense, rtol=0, atol=util.CONV_ATOL)
+
+
 def test_block_conv_direct_groups(hip):
     torch.manual_seed(5)
     x = torch.randn(9, 24, 6, 6, device=DEV)

@@ -312,3 +312,54 @@ def test_compat_install_aliases():
         for k in [k for k in sys.modules if k == "sige" or k.startswith("sige.")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+# ------------------------------------------------------- deferred tiles ----
+def test_deferred_tiles_behave_like_tensors():
+    from sige_amd.nn.deferred import DeferredTiles
+
+    calls = []
+
+    def thunk():
+        calls.append(1)
+        return torch.arange(24, dtype=torch.float32).reshape(2, 3, 2, 2)
+
+    t = DeferredTiles((2, 3, 2, 2), torch.float32, torch.device("cpu"), thunk, dict(kind="gather"))
+    assert t.shape == (2, 3, 2, 2) and t.dim() == 4 and t.dtype == torch.float32 and t.size(1) == 3
+    assert t.contiguous() is t and not calls and t.spec is not None  # metadata never materialises
+    y = t * 2  # any real op does, exactly once
+    assert calls == [1] and t.spec is None and type(y) is torch.Tensor and y[1, 2, 1, 1] == 46
+    assert torch.equal(torch.cat([t, t])[2:], t.materialize()) and calls == [1]
+    assert torch.equal(t.view(2, -1), t.materialize().view(2, -1))
+
+
+def test_forced_deferral_matches_eager(cpu_oracle_backend, monkeypatch):
+    """Gather / ScatterGather return DeferredTiles; convs, scatters and arbitrary
+    torch ops downstream see exactly the eager values."""
+    from sige_amd.nn import deferred
+
+    torch.manual_seed(0)
+    net = ResNet(6, 8).eval()
+    blk = net.block
+    blk.s1, blk.t1 = torch.randn(1, 6, 1, 1), torch.randn(1, 6, 1, 1)
+    blk.s2, blk.t2 = torch.randn(1, 8, 1, 1), torch.randn(1, 8, 1, 1)
+    orig = torch.randn(1, 6, 40, 44)
+    mask = torch.zeros(40, 44, dtype=torch.bool)
+    mask[10:19, 7:23] = True
+    edited = orig + torch.randn_like(orig) * mask
+    with torch.no_grad():
+        net.set_mode("full")
+        net(orig)
+        net.set_mode("sparse")
+        net.set_masks({(40, 44): dilate_mask(dilate_mask(mask, (2, 0)), (0, 2))})
+        eager = net(edited)
+        monkeypatch.setattr(deferred, "FORCE_ON_CPU", True)
+        tiles = blk.main_gather(edited, blk.s1, blk.t1)
+        assert isinstance(tiles, deferred.DeferredTiles) and tiles.spec["kind"] == "gather"
+        lazy = net(edited)
+        assert torch.equal(lazy, eager)
+        # spatially varying affine or sparse_update: no deferral
+        full_scale = torch.randn(1, 6, 40, 44)
+        assert not isinstance(blk.main_gather(edited, full_scale, None), deferred.DeferredTiles)
+        net.set_sparse_update(True)
+        assert not isinstance(blk.main_gather(edited, blk.s1, blk.t1), deferred.DeferredTiles)

@@ -12,9 +12,9 @@ pytestmark = pytest.mark.reference
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run(stack, state, out, ch=32, ratio=0.05):
+def _run(stack, state, out, ch=32, ratio=0.05, extra=()):
     cmd = [sys.executable, os.path.join(HERE, "ref_runner.py"), "--stack", stack, "--state", state, "--out", out,
-           "--ch", str(ch), "--ratio", str(ratio)]
+           "--ch", str(ch), "--ratio", str(ratio), *extra]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
     assert res.returncode == 0, res.stderr[-3000:]
     return np.load(out)
@@ -45,3 +45,12 @@ def test_workload_unet_equals_reference_model(reference_run):
     np.testing.assert_allclose(ours["sparse"], ref["sparse"], rtol=0, atol=2e-4)
     # sanity: the sparse output is a real function of the edit
     assert np.abs(ref["sparse"] - ref["full"]).max() > 1e-2
+
+
+def test_unchanged_reference_model_with_deferred_tiles(reference_run):
+    """Same as above with Gather/ScatterGather returning DeferredTiles (the
+    gather->conv fusion hook): the unchanged model file must not notice."""
+    state, d, ref = reference_run
+    ours = _run("ours-refmodel", state, str(d / "ours_deferred.npz"), extra=("--deferred",))
+    np.testing.assert_allclose(ours["full"], ref["full"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(ours["sparse"], ref["sparse"], rtol=0, atol=1e-4)
