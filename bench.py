@@ -45,7 +45,7 @@ def square_mask(ratio, H=256, W=256, top=100, left=90):
 
 # ------------------------------------------------------------------ op trace --
 TRACED = ("gather", "scatter_gather", "scatter_fused", "scatter_with_block_residual_fused", "block_conv",
-          "block_conv_direct")
+          "block_conv_direct", "gather_conv", "scatter_gather_conv")
 
 
 class Tracer:
@@ -94,6 +94,16 @@ def op_cost(name, a):
         x, cout, kernel, stride = a[0], a[3], a[4], a[5]
         T, cin, R, S = x.shape
         ro, so = (R - kernel[0]) // stride[0] + 1, (S - kernel[1]) // stride[1] + 1
+        return "block_conv_mfma", 0, 2 * T * ro * so * cout * cin * kernel[0] * kernel[1]
+    if name in ("gather_conv", "scatter_gather_conv"):
+        # fused producer + conv: MFMA-bound; flops of the conv only (the gather adds no flops worth counting)
+        if name == "gather_conv":
+            x, block, idx, cout, kernel, stride = a[0], a[1], a[2], a[8], a[9], a[10]
+            T, cin = x.shape[0] * idx.shape[0], x.shape[1]
+        else:
+            y, block, idx, cout, kernel, stride = a[1], a[2], a[3], a[10], a[11], a[12]
+            T, cin = y.shape[0] * idx.shape[0], y.shape[1]
+        ro, so = (block[0] - kernel[0]) // stride[0] + 1, (block[1] - kernel[1]) // stride[1] + 1
         return "block_conv_mfma", 0, 2 * T * ro * so * cout * cin * kernel[0] * kernel[1]
     if name == "block_conv_direct":
         x, w, stride, groups = a[0], a[1], a[3], a[4]
@@ -198,9 +208,16 @@ def cpu_baseline(cfg_ratio, seconds):
     except Exception:
         ref = None
     kind = "reference" if ref is not None else "port"
-    cores = os.cpu_count() or 1
+    # threads actually used: the affinity mask, capped -- OpenMP over 256 hardware
+    # threads on loops this small is slower than 16-32 (measured on the GPU box)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, int(os.environ.get("SIGE_CPU_THREADS", "32"))))
     torch.set_num_threads(cores)
     oracle.set_num_threads(cores)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     runtime.register_backend("cpu", ref if ref is not None else oracle)
     try:
         torch.manual_seed(0)
@@ -426,7 +443,8 @@ def main():
                 gs, _ = capture(model, xs, t)
                 k = max(20, args.steps // 4)
                 ms = timed_replays(gs, k, 5, 1) * 1e3 / k
-                n256 = max((a[3].shape[0] for n, a, kk, o in tr if n == "gather" and a[0].shape[2] == 256), default=0)
+                n256 = max([a[3].shape[0] for n, a, kk, o in tr if n == "gather" and a[0].shape[2] == 256]
+                           + [a[2].shape[0] for n, a, kk, o in tr if n == "gather_conv" and a[0].shape[2] == 256] + [0])
                 sweep.append({"edit_ratio": r, "forward_ms": round(ms, 3), "speedup_vs_dense": round(dense_ms / ms, 2),
                               "active_tiles_256": n256, "block_conv_GFLOP": round(flops / 1e9, 2)})
                 del gs, tr
