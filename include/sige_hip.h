@@ -188,6 +188,33 @@ int sige_hip_scatter_gather_conv_f32(const float *x, const float *y, int B, int 
                                      const float *packed, const float *bias, int Cout, int kH, int kW,
                                      int strideH, int strideW, float *out, void *stream);
 
+/* ---- dense layers through the same kernel ("all tiles active") ---------------
+ * the U-Net's low-resolution dense blocks in sparse mode
+ * (sige_fused_unet.py:112-114,121-123: h*scale+shift -> swish -> nn.Conv2d ->
+ * + skip) as ONE launch: gather-conv whose input channels may come from two
+ * tensors (x [B,C1,H,W] and x2 [B,C2,H,W]: a fused torch.cat), whose output
+ * tiles are written straight into out [B,Cout,Ho,Wo] at (offset+idx)/stride
+ * (clipped) plus an optional residual [B,Cout,Ho,Wo].  With the index list of
+ * ALL tiles this is a dense conv with padding = offset.  scale/shift: [1|B, 1|Cin]. */
+int sige_hip_gather_conv_nchw_f32(const float *x, const float *x2, int B, int C1, int C2, int H, int W,
+                                  int bH, int bW, const int32_t *active_indices, int N,
+                                  const float *scale, int scaleB, int scaleC,
+                                  const float *shift, int shiftB, int shiftC,
+                                  int activation,
+                                  const float *packed, const float *bias, int Cout, int kH, int kW,
+                                  int strideH, int strideW, int offsetH, int offsetW,
+                                  const float *residual, int Ho, int Wo, float *out, void *stream);
+
+/* per-group mean / rstd of a [B,C,H,W] tensor -> per-channel (scale, shift) with
+ * GroupNorm(x) == x*scale + shift  (scale = gamma*rstd, shift = beta - mean*scale):
+ * the producer of the cached affine (diffusion/models/common.py:37-57) as two
+ * streaming launches.  `workspace`: 2*B*groups*ceil(...) floats, see
+ * sige_hip_group_norm_affine_workspace. */
+size_t sige_hip_group_norm_affine_workspace(int B, int C, int H, int W, int groups);
+int sige_hip_group_norm_affine_f32(const float *x, int B, int C, int H, int W, int groups, float eps,
+                                   const float *gamma, const float *beta, float *workspace,
+                                   float *scale, float *shift, void *stream);
+
 /* ---- plain device copy used by the cache broadcast path (packs the cached
  * activations of Scatter / ScatterGather modules into one buffer) ---------- */
 int sige_hip_copy_f32(const float *src, float *dst, size_t n, void *stream);

@@ -41,6 +41,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { SRC_TILES = 0, SRC_GATHER = 1, SRC_SCATTER_GATHER = 2 };
+enum { DST_TILES = 0, DST_NCHW = 1 };
 
 template <int MT_> struct Mfma;
 template <> struct Mfma<32> {
@@ -94,6 +95,13 @@ struct ConvArgs {
     int RxSx, Sx;
     const float *scale, *shift;  // per-(batch, channel) affine of the gather modes
     int scale_sb, scale_sc, shift_sb, shift_sc;
+    // GATHER: channels [0,Csplit) come from x, [Csplit,Cin) from x2 (a fused torch.cat)
+    const float *x2;
+    int Csplit;
+    // DST_NCHW: write the output tiles straight into a full tensor [B,Cout,Ho,Wo] at
+    // ((off+idx)/stride), clipped, + residual[B,Cout,Ho,Wo] (dense layers: all tiles active)
+    const float *residual;
+    int Ho, Wo, offH, offW, strH, strW;
 };
 
 // ---- weight packing -------------------------------------------------------
@@ -126,7 +134,7 @@ static size_t packed_floats(int Cout, int Cin, int KK, int MT) {
 }
 
 // ---- the MFMA kernel ---------------------------------------------------------
-template <typename G, int SRC, int ACT, int VEC>
+template <typename G, int SRC, int ACT, int VEC, int DST>
 __global__ __launch_bounds__(256) void block_conv_mfma_kernel(ConvArgs a) {
     using M = Mfma<G::MT>;
     constexpr int LDS_FLOATS = cmax(2 * G::BUF, 4 * G::MT * G::RED);
@@ -225,7 +233,8 @@ __global__ __launch_bounds__(256) void block_conv_mfma_kernel(ConvArgs a) {
                     if (src != -2) {
                         st_ok |= 1u << i;
                         if (SRC == SRC_GATHER) {
-                            z = a.x[((size_t)b * Cin + c) * HW + src];
+                            z = (c < a.Csplit) ? a.x[((size_t)b * a.Csplit + c) * HW + src]
+                                               : a.x2[((size_t)b * (Cin - a.Csplit) + (c - a.Csplit)) * HW + src];
                         } else if (src >= 0) {
                             z = a.x[((size_t)b * a.N * Cin + c) * a.RxSx + src];
                         } else {
@@ -342,7 +351,44 @@ __global__ __launch_bounds__(256) void block_conv_mfma_kernel(ConvArgs a) {
         if (t < a.T && co < a.Cout) {
             const float bb = a.bias ? a.bias[co] : 0.0f;
             s.x += bb; s.y += bb; s.z += bb; s.w += bb;
-            *reinterpret_cast<float4 *>(a.out + ((size_t)t * a.Cout + co) * G::PX + p4 * 4) = s;
+            if (DST == DST_TILES) {
+                *reinterpret_cast<float4 *>(a.out + ((size_t)t * a.Cout + co) * G::PX + p4 * 4) = s;
+            } else {
+                const int b = t / a.N, n = t - b * a.N;
+                const int h0 = (a.offH + a.idx[2 * n]) / a.strH, w0 = (a.offW + a.idx[2 * n + 1]) / a.strW;
+                const size_t plane = ((size_t)b * a.Cout + co) * a.Ho * a.Wo;
+                const float sv[4] = {s.x, s.y, s.z, s.w};
+                if (G::RO == 4) {
+                    // one 4-pixel output row of the tile
+                    const int h = h0 + p4;
+                    if (h >= 0 && h < a.Ho) {
+                        const size_t q = plane + (size_t)h * a.Wo + w0;
+                        if (w0 >= 0 && w0 + 3 < a.Wo && ((q & 3) == 0)) {
+                            float4 o = s;
+                            if (a.residual) {
+                                const float4 r = *reinterpret_cast<const float4 *>(a.residual + q);
+                                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+                            }
+                            *reinterpret_cast<float4 *>(a.out + q) = o;
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (w0 + i >= 0 && w0 + i < a.Wo)
+                                    a.out[q + i] = sv[i] + (a.residual ? a.residual[q + i] : 0.0f);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int pp = p4 * 4 + i;
+                        const int h = h0 + pp / G::RO, w = w0 + pp % G::RO;
+                        if (h >= 0 && h < a.Ho && w >= 0 && w < a.Wo) {
+                            const size_t q = plane + (size_t)h * a.Wo + w;
+                            a.out[q] = sv[i] + (a.residual ? a.residual[q] : 0.0f);
+                        }
+                    }
+                }
+            }
         }
     }
 }
@@ -379,42 +425,42 @@ static int mfma_kind(int kH, int kW, int R, int S, int strH, int strW, int group
     return 0;
 }
 
-template <typename G, int SRC>
+template <typename G, int SRC, int DST>
 static void launch_geo(ConvArgs a, int act, hipStream_t st) {
     a.nchunks = ceil_div(a.Cin, G::CC);
     dim3 grid(ceil_div(a.T, G::TPB), ceil_div(a.Cout, G::MT));
     if (SRC == SRC_TILES) {
         const bool vec = ((long)a.Cin * G::RS) % 4 == 0 && (G::RS % 4 == 0 || a.Cin % 4 == 0) &&
                          (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
-        if (vec) block_conv_mfma_kernel<G, SRC_TILES, 0, 4><<<grid, 256, 0, st>>>(a);
-        else block_conv_mfma_kernel<G, SRC_TILES, 0, 1><<<grid, 256, 0, st>>>(a);
+        if (vec) block_conv_mfma_kernel<G, SRC_TILES, 0, 4, DST_TILES><<<grid, 256, 0, st>>>(a);
+        else block_conv_mfma_kernel<G, SRC_TILES, 0, 1, DST_TILES><<<grid, 256, 0, st>>>(a);
     } else if (act == SIGE_HIP_ACT_SWISH) {
-        block_conv_mfma_kernel<G, SRC, SIGE_HIP_ACT_SWISH, 1><<<grid, 256, 0, st>>>(a);
+        block_conv_mfma_kernel<G, SRC, SIGE_HIP_ACT_SWISH, 1, DST><<<grid, 256, 0, st>>>(a);
     } else {
-        block_conv_mfma_kernel<G, SRC, SIGE_HIP_ACT_IDENTITY, 1><<<grid, 256, 0, st>>>(a);
+        block_conv_mfma_kernel<G, SRC, SIGE_HIP_ACT_IDENTITY, 1, DST><<<grid, 256, 0, st>>>(a);
     }
 }
 
 // Tile choice: 32x32 tiles unless that leaves most of the 256 CUs idle.
-template <int KH, int STR, int R, int SRC>
+template <int KH, int STR, int R, int SRC, int DST>
 static void launch_kind(ConvArgs a, int act, hipStream_t st) {
     using G32 = ConvGeo<KH, STR, R, 32>;
     using G16 = ConvGeo<KH, STR, R, 16>;
     const long blocks32 = (long)ceil_div(a.T, G32::TPB) * ceil_div(a.Cout, 32);
     if (blocks32 >= 192) {
-        launch_geo<G32, SRC>(a, act, st);
+        launch_geo<G32, SRC, DST>(a, act, st);
     } else {
         a.packed += packed_floats(a.Cout, a.Cin, KH * KH, 32);  // the MT=16 layout follows the MT=32 one
-        launch_geo<G16, SRC>(a, act, st);
+        launch_geo<G16, SRC, DST>(a, act, st);
     }
 }
 
-template <int SRC>
+template <int SRC, int DST = DST_TILES>
 static int launch_conv(const ConvArgs &a, int act, int kH, int kW, int R, int S, int strH, int strW, hipStream_t st) {
     switch (mfma_kind(kH, kW, R, S, strH, strW, 1)) {
-        case 1: launch_kind<3, 1, 6, SRC>(a, act, st); break;
-        case 2: launch_kind<1, 1, 4, SRC>(a, act, st); break;
-        case 3: launch_kind<3, 2, 5, SRC>(a, act, st); break;
+        case 1: launch_kind<3, 1, 6, SRC, DST>(a, act, st); break;
+        case 2: launch_kind<1, 1, 4, SRC, DST>(a, act, st); break;
+        case 3: launch_kind<3, 2, 5, SRC, DST>(a, act, st); break;
         default: return SIGE_HIP_EUNSUPPORTED;
     }
     return launch_status();
@@ -485,9 +531,37 @@ extern "C" int sige_hip_gather_conv_f32(const float *x, int B, int Cin, int H, i
     ConvArgs a{};
     a.x = x; a.idx = active_indices; a.packed = packed; a.bias = bias; a.out = out;
     a.T = B * N; a.Cin = Cin; a.Cout = Cout; a.B = B; a.N = N; a.H = H; a.W = W;
+    a.Csplit = Cin;
     a.scale = scale; a.scale_sb = scaleB > 1 ? scaleC : 0; a.scale_sc = scaleC > 1 ? 1 : 0;
     a.shift = shift; a.shift_sb = shiftB > 1 ? shiftC : 0; a.shift_sc = shiftC > 1 ? 1 : 0;
     return launch_conv<SRC_GATHER>(a, activation, kH, kW, bH, bW, strideH, strideW, as_stream(stream));
+}
+
+extern "C" int sige_hip_gather_conv_nchw_f32(const float *x, const float *x2, int B, int C1, int C2, int H, int W,
+                                             int bH, int bW, const int32_t *active_indices, int N,
+                                             const float *scale, int scaleB, int scaleC,
+                                             const float *shift, int shiftB, int shiftC,
+                                             int activation,
+                                             const float *packed, const float *bias, int Cout, int kH, int kW,
+                                             int strideH, int strideW, int offsetH, int offsetW,
+                                             const float *residual, int Ho, int Wo, float *out, void *stream) {
+    const int Cin = C1 + C2;
+    if (B < 0 || C1 <= 0 || C2 < 0 || Cout <= 0 || H <= 0 || W <= 0 || N < 0 || Ho <= 0 || Wo <= 0) return SIGE_HIP_EINVAL;
+    if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
+    if ((scale && !((scaleB == 1 || scaleB == B) && (scaleC == 1 || scaleC == Cin))) ||
+        (shift && !((shiftB == 1 || shiftB == B) && (shiftC == 1 || shiftC == Cin))))
+        return SIGE_HIP_EINVAL;
+    if ((long)H * W >= (1L << 31)) return SIGE_HIP_EUNSUPPORTED;
+    if ((long)B * N == 0) return SIGE_HIP_OK;
+    if (!x || (C2 && !x2) || !packed || !out || !active_indices) return SIGE_HIP_EINVAL;
+    if (reinterpret_cast<uintptr_t>(packed) & 15) return SIGE_HIP_EINVAL;
+    ConvArgs a{};
+    a.x = x; a.x2 = x2; a.Csplit = C1; a.idx = active_indices; a.packed = packed; a.bias = bias; a.out = out;
+    a.T = B * N; a.Cin = Cin; a.Cout = Cout; a.B = B; a.N = N; a.H = H; a.W = W;
+    a.scale = scale; a.scale_sb = scaleB > 1 ? scaleC : 0; a.scale_sc = scaleC > 1 ? 1 : 0;
+    a.shift = shift; a.shift_sb = shiftB > 1 ? shiftC : 0; a.shift_sc = shiftC > 1 ? 1 : 0;
+    a.residual = residual; a.Ho = Ho; a.Wo = Wo; a.offH = offsetH; a.offW = offsetW; a.strH = strideH; a.strW = strideW;
+    return launch_conv<SRC_GATHER, DST_NCHW>(a, activation, kH, kW, bH, bW, strideH, strideW, as_stream(stream));
 }
 
 extern "C" int sige_hip_scatter_gather_conv_f32(const float *x, const float *y, int B, int Cin, int H, int W,

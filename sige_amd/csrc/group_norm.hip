@@ -1,0 +1,103 @@
+// GroupNorm statistics -> per-channel affine, for gfx950.
+//
+// The cached-affine contract of SIGE (diffusion/models/common.py:37-57): the
+// full pass turns GroupNorm into per-channel (scale, shift) so that the sparse
+// pass can fuse "normalise + SiLU" into a gather.  PyTorch's generic
+// RowwiseMoments kernel uses ONE workgroup per (batch, group) -- 32 workgroups on
+// a 256-CU chip, 171 us for the U-Net's output norm [1,128,256,256].  Here each
+// (batch, group) is split over many workgroups (16-byte streaming loads, wave
+// shuffle + LDS reduction, partial sums in a workspace), and a second tiny
+// launch combines the partials in fp64 and emits scale/shift.
+#include "common.hpp"
+
+namespace sige {
+
+constexpr int kGNThreads = 256;
+
+__global__ __launch_bounds__(kGNThreads) void gn_partial_kernel(const float *__restrict__ x, size_t group_elems,
+                                                                int splits, float *__restrict__ ws) {
+    // grid: (splits, B*groups); each block reduces a contiguous slice of one group
+    const int bg = blockIdx.y, sp = blockIdx.x;
+    const size_t per = ((group_elems / 4 + splits - 1) / splits) * 4;
+    const size_t lo = (size_t)sp * per, hi = min(group_elems, lo + per);
+    const float *g = x + (size_t)bg * group_elems;
+    float s = 0.f, ss = 0.f;
+    if (((reinterpret_cast<uintptr_t>(g) | (lo * 4)) & 15) == 0) {
+        const size_t n4 = hi > lo ? (hi - lo) / 4 : 0;
+        const float4 *g4 = reinterpret_cast<const float4 *>(g + lo);
+        for (size_t i = threadIdx.x; i < n4; i += kGNThreads) {
+            const float4 v = g4[i];
+            s += (v.x + v.y) + (v.z + v.w);
+            ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+        for (size_t i = lo + n4 * 4 + threadIdx.x; i < hi; i += kGNThreads) { const float v = g[i]; s += v; ss += v * v; }
+    } else {
+        for (size_t i = lo + threadIdx.x; i < hi; i += kGNThreads) { const float v = g[i]; s += v; ss += v * v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o); ss += __shfl_down(ss, o); }
+    __shared__ float sh[2][kGNThreads / kWave];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sh[0][wave] = s; sh[1][wave] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, b = 0.f;
+        for (int w = 0; w < kGNThreads / kWave; ++w) { a += sh[0][w]; b += sh[1][w]; }
+        ws[((size_t)bg * splits + sp) * 2] = a;
+        ws[((size_t)bg * splits + sp) * 2 + 1] = b;
+    }
+}
+
+__global__ void gn_finish_kernel(const float *__restrict__ ws, int splits, int B, int C, int groups,
+                                 double group_elems, float eps, const float *__restrict__ gamma,
+                                 const float *__restrict__ beta, float *__restrict__ scale,
+                                 float *__restrict__ shift) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // b*C + c
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C;
+    const int g = c / (C / groups);
+    double s = 0.0, ss = 0.0;
+    const float *p = ws + ((size_t)(b * groups + g) * splits) * 2;
+    for (int k = 0; k < splits; ++k) { s += p[2 * k]; ss += p[2 * k + 1]; }
+    const double mean = s / group_elems;
+    double var = ss / group_elems - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
+    const float sc = ga * rstd;
+    scale[i] = sc;
+    shift[i] = be - (float)mean * sc;
+}
+
+static int gn_splits(size_t group_elems) {
+    // ~64 KiB of input per workgroup, at most 64 splits per group
+    size_t s = (group_elems + 16383) / 16384;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return (int)s;
+}
+
+}  // namespace sige
+
+using namespace sige;
+
+extern "C" size_t sige_hip_group_norm_affine_workspace(int B, int C, int H, int W, int groups) {
+    if (B <= 0 || C <= 0 || groups <= 0 || C % groups) return 0;
+    const size_t ge = (size_t)(C / groups) * H * W;
+    return (size_t)B * groups * gn_splits(ge) * 2;
+}
+
+extern "C" int sige_hip_group_norm_affine_f32(const float *x, int B, int C, int H, int W, int groups, float eps,
+                                              const float *gamma, const float *beta, float *workspace,
+                                              float *scale, float *shift, void *stream) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || groups <= 0 || C % groups) return SIGE_HIP_EINVAL;
+    if (!x || !workspace || !scale || !shift) return SIGE_HIP_EINVAL;
+    if ((long)B * groups > 65535) return SIGE_HIP_EUNSUPPORTED;
+    const size_t ge = (size_t)(C / groups) * H * W;
+    const int splits = gn_splits(ge);
+    hipStream_t st = as_stream(stream);
+    gn_partial_kernel<<<dim3(splits, B * groups), kGNThreads, 0, st>>>(x, ge, splits, workspace);
+    gn_finish_kernel<<<ceil_div(B * C, 256), 256, 0, st>>>(workspace, splits, B, C, groups, (double)ge, eps, gamma, beta,
+                                                          scale, shift);
+    return launch_status();
+}

@@ -56,6 +56,11 @@ _SIGNATURES = {
     "sige_hip_scatter_gather_conv_f32": (
         _c_int, [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + _BC + _BC + [_c_int, _c_vp, _c_vp]
         + [_c_int] * 5 + [_c_vp, _c_vp]),
+    "sige_hip_gather_conv_nchw_f32": (
+        _c_int, [_c_vp, _c_vp] + [_c_int] * 7 + [_c_vp, _c_int] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
+        + [_c_int] * 7 + [_c_vp, _c_int, _c_int, _c_vp, _c_vp]),
+    "sige_hip_group_norm_affine_workspace": (_c_sz, [_c_int] * 5),
+    "sige_hip_group_norm_affine_f32": (_c_int, [_c_vp] + [_c_int] * 5 + [ctypes.c_float] + [_c_vp] * 6),
     "sige_hip_block_conv_direct_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp] + [_c_int] * 6 + [_c_vp, _c_vp]),
     "sige_hip_copy_f32": (_c_int, [_c_vp, _c_vp, _c_sz, _c_vp]),
 }
@@ -327,6 +332,80 @@ def scatter_gather_conv(x, y, block: Tuple[int, int], activeIndices, scatterMap,
         smap.data_ptr(), *sa, *ta, _act(activationName), packed.data_ptr(), b, Cout, kernel[0], kernel[1],
         stride[0], stride[1], out.data_ptr(), _stream(y)), "scatter_gather_conv")
     return out
+
+
+_all_tiles_cache = {}
+
+
+def all_tiles(H: int, W: int, out_tile: Tuple[int, int], stride: Tuple[int, int], offset: Tuple[int, int],
+              device) -> torch.Tensor:
+    """Index list [N,2] of EVERY tile of an H x W input (a dense layer seen as
+    "all tiles active"): origins (o*s*i - off, o*s*j - off), one per o x o output cell."""
+    key = (H, W, tuple(out_tile), tuple(stride), tuple(offset), str(device))
+    idx = _all_tiles_cache.get(key)
+    if idx is None:
+        ph, pw = out_tile[0] * stride[0], out_tile[1] * stride[1]
+        nh, nw = -(-H // ph), -(-W // pw)
+        hh = torch.arange(nh, dtype=torch.int32) * ph - offset[0]
+        ww = torch.arange(nw, dtype=torch.int32) * pw - offset[1]
+        idx = torch.stack(torch.meshgrid(hh, ww, indexing="ij"), dim=-1).reshape(-1, 2).contiguous().to(device)
+        _all_tiles_cache[key] = idx
+    return idx
+
+
+def gather_conv_nchw(x, x2, block: Tuple[int, int], activeIndices, scale, shift, activationName: str,
+                     packed, bias, Cout: int, kernel: Tuple[int, int], stride: Tuple[int, int],
+                     offset: Tuple[int, int], out_res: Tuple[int, int], residual=None):
+    """conv(act(cat(x, x2) * scale + shift)) + residual over the listed tiles, written
+    straight into a fresh [B,Cout,Ho,Wo] tensor (pixels no tile covers are NOT written:
+    pass the all-tiles list for a dense layer)."""
+    x = _req(x, torch.float32, "x")
+    B, C1, H, W = x.shape
+    C2 = 0
+    if x2 is not None:
+        x2 = _req(x2, torch.float32, "x2")
+        C2 = x2.shape[1]
+    idx = _req(activeIndices, torch.int32, "activeIndices", 2)
+
+    def cvec(t, name):
+        if t is None:
+            return (None, 0, 0), None
+        t = _req(t, torch.float32, name)
+        if t.shape[2] != 1 or t.shape[3] != 1:
+            raise RuntimeError("gather_conv_nchw: `%s` must be [1|B, 1|C, 1, 1]" % name)
+        return (t.data_ptr(), t.shape[0], t.shape[1]), t
+
+    (sa, s_keep), (ta, t_keep) = cvec(scale, "scale"), cvec(shift, "shift")
+    Ho, Wo = out_res
+    out = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    r = None
+    if residual is not None:
+        residual = _req(residual, torch.float32, "residual")
+        if tuple(residual.shape) != tuple(out.shape):
+            raise RuntimeError("gather_conv_nchw: residual %s != output %s" % (tuple(residual.shape), tuple(out.shape)))
+        r = residual.data_ptr()
+    b = None if bias is None else _req(bias.detach(), torch.float32, "bias", 1).data_ptr()
+    _check(lib().sige_hip_gather_conv_nchw_f32(
+        x.data_ptr(), None if x2 is None else x2.data_ptr(), B, C1, C2, H, W, block[0], block[1], idx.data_ptr(),
+        idx.shape[0], *sa, *ta, _act(activationName), packed.data_ptr(), b, Cout, kernel[0], kernel[1],
+        stride[0], stride[1], offset[0], offset[1], r, Ho, Wo, out.data_ptr(), _stream(x)), "gather_conv_nchw")
+    return out
+
+
+def group_norm_affine(x, groups: int, eps: float, gamma=None, beta=None):
+    """Per-channel (scale, shift) [B,C,1,1] with GroupNorm(x) == x*scale + shift."""
+    x = _req(x, torch.float32, "x")
+    B, C, H, W = x.shape
+    n = int(lib().sige_hip_group_norm_affine_workspace(B, C, H, W, groups))
+    if n == 0:
+        raise RuntimeError("group_norm_affine: channels %d not divisible by groups %d" % (C, groups))
+    buf = torch.empty(n + 2 * B * C, dtype=torch.float32, device=x.device)
+    scale, shift = buf[n:n + B * C].view(B, C, 1, 1), buf[n + B * C:].view(B, C, 1, 1)
+    ga = None if gamma is None else _req(gamma.detach(), torch.float32, "gamma", 1).data_ptr()
+    be = None if beta is None else _req(beta.detach(), torch.float32, "beta", 1).data_ptr()
+    _check(lib().sige_hip_group_norm_affine_f32(x.data_ptr(), B, C, H, W, groups, eps, ga, be, buf.data_ptr(),
+                                                scale.data_ptr(), shift.data_ptr(), _stream(x)), "group_norm_affine")
+    return scale, shift
 
 
 def block_conv_direct(x, weight, bias, stride: Tuple[int, int], groups: int = 1):

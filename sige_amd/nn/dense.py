@@ -1,0 +1,104 @@
+"""Dense layers of a SIGE network through the tile kernels.
+
+In sparse mode the reference still runs the low-resolution blocks densely, as
+separate torch ops: `h * scale + shift`, `swish`, `nn.Conv2d`, `+ skip`, after a
+`torch.cat` on the up path (sige_fused_unet.py:112-114,121-123,416).  On MI355X
+that is ~10 launch-bound kernels per block.  `fused_conv2d` runs the same math
+as ONE launch of the MFMA tile kernel with every tile active:
+
+    out = conv(act(cat(x, x2) * scale + shift)) + residual
+
+(zero padding = the gather's zero fill, so padded pixels are 0 AFTER the
+affine/activation exactly like padding the activated tensor).  On tensors that
+are not on the GPU it evaluates the identical expression with torch ops -- this
+is the reference's own implementation of these dense layers, not a fallback of
+the sparse path.
+"""
+from typing import Optional, Tuple
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+_GEOMETRY = {
+    # (kernel, stride, padding) -> (tile block, out tile, gather offset)
+    ((3, 3), (1, 1), (1, 1)): ((6, 6), (4, 4), (1, 1)),
+    ((1, 1), (1, 1), (0, 0)): ((4, 4), (4, 4), (0, 0)),
+    ((3, 3), (2, 2), (0, 0)): ((5, 5), (2, 2), (0, 0)),  # with (0,1,0,1) zero padding supplied by the zero fill
+}
+
+
+def _packed(conv: nn.Conv2d, block):
+    from .. import hip
+
+    w = conv.weight
+    key = (w.data_ptr(), w._version, tuple(w.shape), block, w.device)
+    if getattr(conv, "_sige_packed_key", None) != key:
+        conv._sige_packed = hip.conv_pack_weights(w, block[0], block[1], conv.stride)
+        conv._sige_packed_key = key
+    return conv._sige_packed
+
+
+def fusable(conv: nn.Conv2d) -> bool:
+    geo = (tuple(conv.kernel_size), tuple(conv.stride), tuple(conv.padding))
+    return geo in _GEOMETRY and conv.groups == 1 and tuple(conv.dilation) == (1, 1)
+
+
+def _act(x, name):
+    if name == "swish":
+        return F.silu(x)
+    if name == "identity":
+        return x
+    raise ValueError("Unknown activation: [%s]!!!" % name)
+
+
+def fused_conv2d(conv: nn.Conv2d, x: torch.Tensor, scale: Optional[torch.Tensor] = None,
+                 shift: Optional[torch.Tensor] = None, activation_name: str = "identity",
+                 x2: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+                 pad_bottom_right: bool = False) -> torch.Tensor:
+    """conv(act(cat(x, x2) * scale + shift)) + residual.  scale/shift: [1|B, C, 1, 1].
+    `pad_bottom_right`: the DDPM downsample's (0,1,0,1) zero padding (stride-2 convs)."""
+    if x.is_cuda and x.dtype == torch.float32 and fusable(conv):
+        from .. import hip
+
+        block, out_tile, offset = _GEOMETRY[(tuple(conv.kernel_size), tuple(conv.stride), tuple(conv.padding))]
+        B, _, H, W = x.shape
+        if conv.stride[0] == 2:
+            if not pad_bottom_right:
+                raise NotImplementedError("stride-2 fused conv expects the (0,1,0,1) padding of the DDPM downsample")
+            Ho, Wo = (H + 1 - 3) // 2 + 1, (W + 1 - 3) // 2 + 1
+        else:
+            Ho, Wo = H, W
+        idx = hip.all_tiles(H, W, out_tile, conv.stride, offset, x.device)
+        return hip.gather_conv_nchw(x.contiguous(), None if x2 is None else x2.contiguous(), block, idx,
+                                    scale, shift, activation_name, _packed(conv, block), conv.bias,
+                                    conv.out_channels, conv.kernel_size, conv.stride, offset, (Ho, Wo),
+                                    None if residual is None else residual.contiguous())
+    h = x if x2 is None else torch.cat([x, x2], dim=1)
+    if scale is not None:
+        h = h * scale
+    if shift is not None:
+        h = h + shift
+    h = _act(h, activation_name)
+    if pad_bottom_right:
+        h = F.pad(h, (0, 1, 0, 1))
+    h = conv(h)
+    return h if residual is None else h + residual
+
+
+def group_norm_affine(x: torch.Tensor, norm: nn.GroupNorm) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(scale, shift) as [B,C,1,1] with GroupNorm(x) == x*scale + shift."""
+    if x.is_cuda and x.dtype == torch.float32:
+        from .. import hip
+
+        return hip.group_norm_affine(x, norm.num_groups, norm.eps, norm.weight, norm.bias)
+    B, C = x.shape[:2]
+    g = norm.num_groups
+    var, mean = torch.var_mean(x.reshape(B, g, -1), dim=2, unbiased=False)
+    inv = torch.rsqrt(var + norm.eps).repeat_interleave(C // g, dim=1)
+    mu = mean.repeat_interleave(C // g, dim=1)
+    w = norm.weight if norm.weight is not None else torch.ones(C, device=x.device)
+    b = norm.bias if norm.bias is not None else torch.zeros(C, device=x.device)
+    scale = inv * w
+    shift = b - mu * scale
+    return scale.reshape(B, C, 1, 1), shift.reshape(B, C, 1, 1)

@@ -26,6 +26,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from ..nn import Gather, Scatter, ScatterGather, ScatterWithBlockResidual, SIGEConv2d, SIGEModel, SIGEModule
+from ..nn.dense import fused_conv2d, group_norm_affine
 
 
 @dataclass
@@ -102,11 +103,16 @@ class ResBlock(SIGEModule):
     def clear_cache(self):
         self.affine = {}
 
-    def forward(self, x: torch.Tensor, temb: Optional[torch.Tensor]) -> torch.Tensor:
+    def forward(self, x, temb: Optional[torch.Tensor]) -> torch.Tensor:
+        """`x` may be a pair (h, skip): the up path's torch.cat, which the dense
+        sparse-mode blocks fold into their convs' two-pointer input."""
+        pair = x if isinstance(x, (tuple, list)) else None
         if self.mode == "full":
-            return self._full(x, temb)
+            return self._full(torch.cat(pair, dim=1) if pair else x, temb)
         if self.mode in ("sparse", "profile"):
-            return self._sparse(x)
+            if pair and not self.sparse_main and self.mode == "sparse":
+                return self._sparse_dense(pair[0], pair[1])
+            return self._sparse(torch.cat(pair, dim=1) if pair else x)
         raise NotImplementedError("Unknown mode [%s]!!!" % self.mode)
 
     def _shortcut(self, x):
@@ -147,9 +153,17 @@ class ResBlock(SIGEModule):
             h = self.conv1(self.main_gather(x, s1, t1))
             h = self.conv2(self.scatter_gather(h, s2, t2))
             return self.scatter(h, skip)
-        h = self.conv1(F.silu(x * s1 + t1))
-        h = self.conv2(F.silu(h * s2 + t2))
-        return h + skip
+        return self._sparse_dense(x, None)
+
+    def _sparse_dense(self, x, x2):
+        """Dense block on the cached affine: 2-3 fused launches (shortcut 1x1, conv1, conv2+skip)."""
+        s1, t1, s2, t2 = self.affine[self.cache_id]
+        if self.cin == self.cout:
+            skip = x if x2 is None else torch.cat([x, x2], dim=1)
+        else:
+            skip = fused_conv2d(self.nin_shortcut, x, x2=x2)
+        h = fused_conv2d(self.conv1, x, s1, t1, "swish", x2=x2)
+        return fused_conv2d(self.conv2, h, s2, t2, "swish", residual=skip)
 
 
 class AttnBlock(SIGEModule):
@@ -185,6 +199,8 @@ class AttnBlock(SIGEModule):
             s, t = self.affine[self.cache_id]
             if self.quirk:
                 s, t = s[:, :1].expand_as(s).contiguous(), t[:, :1].expand_as(t).contiguous()
+            if not self.sparse and self.mode == "sparse":
+                return self._dense_sparse(x, s, t)
             h = self.gather1(x, s, t) if self.sparse else x * s + t
         plain = self.mode == "full" and self.plain
         qkv = self.qkv(h)
@@ -198,6 +214,17 @@ class AttnBlock(SIGEModule):
             h = self.gather2(h)
         h = self.proj_out(h)
         return self.scatter2(h, x) if (self.sparse and not plain) else h + x
+
+
+    def _attention(self, qkv):
+        b, _, hh, ww = qkv.shape
+        q, k, v = qkv.reshape(b, 3, self.ch, hh * ww).unbind(1)
+        attn = torch.softmax(torch.bmm(q.transpose(1, 2), k) * (self.ch ** -0.5), dim=2)
+        return torch.bmm(v, attn.transpose(1, 2)).reshape(b, self.ch, hh, ww)
+
+    def _dense_sparse(self, x, s, t):
+        qkv = fused_conv2d(self.qkv, x, s, t, "identity")
+        return fused_conv2d(self.proj_out, self._attention(qkv), residual=x)
 
 
 class Upsample(SIGEModule):
@@ -231,6 +258,8 @@ class Downsample(SIGEModule):
             self.scatter = Scatter(self.gather)
 
     def forward(self, x):
+        if not self.sparse and self.mode == "sparse":
+            return fused_conv2d(self.conv, x, pad_bottom_right=True)
         if not self.sparse or (self.plain and self.mode == "full"):
             return self.conv(F.pad(x, (0, 1, 0, 1)))
         x = self.gather(x)
@@ -338,10 +367,14 @@ class DDPMSparseUNet(SIGEModel):
         for lvl in reversed(range(self.num_levels)):
             stage = self.up[lvl]
             for i, block in enumerate(stage.block):
-                h = block(torch.cat([h, hs.pop()], dim=1), nxt())
+                h = block((h, hs.pop()), nxt())
                 if len(stage.attn):
                     h = stage.attn[i](h)
             if lvl != 0:
                 h = stage.upsample(h)
+        if self.mode == "sparse":
+            # the output norm is a TRUE GroupNorm of the edited activation (sige_fused_unet.py:430-432)
+            so, to = group_norm_affine(h, self.norm_out)
+            return fused_conv2d(self.conv_out, h, so, to, "swish")
         return self.conv_out(F.silu(self.norm_out(h)))
 

@@ -241,6 +241,86 @@ def test_deferred_fusion_in_modules():
     torch.testing.assert_close(fused, dense, rtol=0, atol=util.CONV_ATOL)
 
 
+@pytest.mark.parametrize("res,c1,c2,cout,k,stride", [(32, 256, 0, 256, 3, 1), (16, 512, 512, 512, 3, 1), (8, 512, 256, 512, 1, 1),
+                                                     (32, 96, 40, 72, 3, 1), (16, 512, 0, 1536, 1, 1), (32, 256, 0, 256, 3, 2),
+                                                     (256, 128, 0, 3, 3, 1), (18, 64, 0, 64, 3, 1)])
+def test_dense_fused_conv_vs_torch(res, c1, c2, cout, k, stride):
+    """Dense layers as all-tiles gather-conv: conv(swish(cat(x,x2)*s+t)) + residual == torch."""
+    from torch import nn
+
+    from sige_amd.nn.dense import fused_conv2d
+
+    torch.manual_seed(res + c1 + k)
+    B = 1
+    conv = nn.Conv2d(c1 + c2, cout, k, stride, 0 if stride == 2 else k // 2).to(DEV)
+    x = torch.randn(B, c1, res, res, device=DEV)
+    x2 = torch.randn(B, c2, res, res, device=DEV) if c2 else None
+    s, t = torch.randn(1, c1 + c2, 1, 1, device=DEV), torch.randn(1, c1 + c2, 1, 1, device=DEV)
+    ro = res if stride == 1 else res // 2
+    residual = torch.randn(B, cout, ro, ro, device=DEV)
+    with torch.no_grad():
+        got = fused_conv2d(conv, x, s, t, "swish", x2=x2, residual=residual, pad_bottom_right=stride == 2)
+        h = x if x2 is None else torch.cat([x, x2], 1)
+        h = torch.nn.functional.silu(h * s + t)
+        if stride == 2:
+            h = torch.nn.functional.pad(h, (0, 1, 0, 1))
+        want = torch.nn.functional.conv2d(h.double(), conv.weight.double(), conv.bias.double(), stride,
+                                          conv.padding).float() + residual
+        torch.testing.assert_close(got, want, rtol=0, atol=2e-4)
+        plain = fused_conv2d(conv, x, x2=x2, pad_bottom_right=stride == 2)
+        h = x if x2 is None else torch.cat([x, x2], 1)
+        if stride == 2:
+            h = torch.nn.functional.pad(h, (0, 1, 0, 1))
+        torch.testing.assert_close(plain, conv(h), rtol=0, atol=2e-4)
+
+
+@pytest.mark.parametrize("shape,groups", [((1, 128, 256, 256), 32), ((2, 64, 17, 23), 32), ((1, 512, 8, 8), 32)])
+def test_group_norm_affine_vs_torch(hip, shape, groups):
+    torch.manual_seed(shape[1])
+    x = torch.randn(*shape, device=DEV) * 3 + 1.5
+    gamma, beta = torch.randn(shape[1], device=DEV), torch.randn(shape[1], device=DEV)
+    scale, shift = hip.group_norm_affine(x, groups, 1e-6, gamma, beta)
+    want = torch.nn.functional.group_norm(x.double(), groups, gamma.double(), beta.double(), 1e-6).float()
+    torch.testing.assert_close(x * scale + shift, want, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("ratio", [0.012, 0.15])
+def test_ddpm_unet_gpu_vs_oracle_backend(ratio):
+    """Model level (BASELINE configs[1] shape, ch 32 to keep the CPU side short): the
+    sparse forward on the GPU (HIP kernels, fused paths) equals the same network on the
+    CPU with the oracle as native backend, within 1e-3."""
+    from sige_amd import runtime
+    from sige_amd.utils import dilate_mask, downsample_mask
+    from sige_amd.workloads.ddpm_unet import DDPMConfig, DDPMSparseUNet
+
+    torch.manual_seed(0)
+    model = DDPMSparseUNet(DDPMConfig(ch=32)).eval()
+    x0 = torch.randn(1, 3, 256, 256)
+    mask = _square_mask(ratio)
+    x1 = x0 + torch.randn(1, 3, 256, 256) * mask
+    t = torch.zeros(1)
+
+    def run(device):
+        model.to(device)
+        model.clear_cache()
+        with torch.no_grad():
+            model.set_mode("full")
+            full = model(x0.to(device), t.to(device))
+            model.set_masks(downsample_mask(dilate_mask(mask.to(device), 5), 8))
+            model.set_mode("sparse")
+            return full.cpu(), model(x1.to(device), t.to(device)).cpu()
+
+    runtime.register_backend("cpu", oracle)
+    try:
+        full_c, sparse_c = run("cpu")
+    finally:
+        runtime.unregister_backend("cpu")
+    full_g, sparse_g = run(DEV)
+    torch.testing.assert_close(full_g, full_c, rtol=0, atol=util.CONV_ATOL)
+    torch.testing.assert_close(sparse_g, sparse_c, rtol=0, atol=util.CONV_ATOL)
+    assert (sparse_c - full_c).abs().max() > 1e-2
+
+
 def test_block_conv_direct_groups(hip):
     torch.manual_seed(5)
     x = torch.randn(9, 24, 6, 6, device=DEV)
