@@ -160,6 +160,10 @@ int sige_hip_block_conv_f32(const float *x, int T, int Cin, int R, int S,
 int sige_hip_block_conv_direct_f32(const float *x, int T, int Cin, int R, int S,
                                    const float *w, const float *bias, int Cout, int kH, int kW,
                                    int strideH, int strideW, int groups, float *out, void *stream);
+/* Tuning knob (process-wide, not thread-safe): pin the MFMA kernel's output block to
+ * mt pixels x (nb*mt) output channels, mt in {16, 32}, nb in {1, 2}; (0, 0) restores the
+ * per-launch choice.  Results do not depend on it beyond fp32 summation order. */
+int sige_hip_block_conv_force_tile(int mt, int nb);
 
 /* ---- fused gather -> conv and scatter_gather -> conv ------------------------
  * The same MFMA conv with the producer of its input tiles fused into the
@@ -214,6 +218,16 @@ size_t sige_hip_group_norm_affine_workspace(int B, int C, int H, int W, int grou
 int sige_hip_group_norm_affine_f32(const float *x, int B, int C, int H, int W, int groups, float eps,
                                    const float *gamma, const float *beta, float *workspace,
                                    float *scale, float *shift, void *stream);
+
+/* ---- single-head spatial self-attention of the U-Net's dense AttnBlock ------
+ * (diffusion/models/ddpm_arch/unet.py AttnBlock.forward, reached from
+ * sige_fused_unet.py:186-199): qkv [B,3C,HW] = q, k, v stacked on the channel axis,
+ * out[b,c,i] = sum_j v[b,c,j] * softmax_j(scale * sum_c' q[b,c',i] k[b,c',j]).
+ * Two launches (score tiles, then softmax + value product); `workspace` holds the
+ * [B,HW,HW] scores (sige_hip_attention_workspace floats).  HW and C multiples of 16. */
+size_t sige_hip_attention_workspace(int B, int C, int HW);
+int sige_hip_attention_f32(const float *qkv, int B, int C, int HW, float scale, float *workspace,
+                           float *out, void *stream);
 
 /* ---- plain device copy used by the cache broadcast path (packs the cached
  * activations of Scatter / ScatterGather modules into one buffer) ---------- */

@@ -1,0 +1,9 @@
+// 3x3 stride-2 tiles (5x5 in): explicit instantiations of the MFMA stacked-block conv.
+#include "conv_mfma.hpp"
+// (25 staging slots per lane: only the single-accumulator forms fit the register file)
+namespace sige {
+using G16 = ConvGeo<3, 2, 5, 16>;
+using G32 = ConvGeo<3, 2, 5, 32>;
+SIGE_CONV_INSTANTIATE(G16, 1)
+SIGE_CONV_INSTANTIATE(G32, 1)
+}  // namespace sige

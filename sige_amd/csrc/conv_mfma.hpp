@@ -1,0 +1,458 @@
+// Stacked-block convolution on the fp32 matrix cores of gfx950 (kernel template).
+//
+//   x tiles [T,Cin,R,S] (*) w [Cout,Cin,k,k] -> out tiles [T,Cout,Ro,So], padding 0
+//
+// as ONE LDS-tiled implicit GEMM, M = T*Ro*So output pixels, N = Cout,
+// K = Cin*k*k, exact fp32 products and fp32 accumulation
+// (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32) -- optionally with the
+// producer of the tiles (Gather: sige/cpu/gather.cpp:4-58, ScatterGather:
+// sige/cpu/scatter_gather.cpp:5-56) fused into the staging path, so that the
+// [T,Cin,R,S] tensor the reference materialises between gather_cuda and
+// F.conv2d (sige/nn/gather.py:80-89 -> sige/nn/base.py:88-89) never exists.
+//
+// Work decomposition (MI355X: 256 CUs x 4 SIMDs, f32 MFMA = 64 FLOP/clk/SIMD,
+// saturated by ONE wave per SIMD):
+//   workgroup = 256 lanes = 4 waves -> one MT x (NB*MT) output block, full K.
+//   The four waves split K (each owns a quarter of every channel chunk) and
+//   reduce through LDS at the end, so even a conv with 18 active tiles spreads
+//   over >= 256 workgroups.  MT in {16, 32} and NB in {1, 2} are picked per
+//   launch so that the grid still covers the chip.
+//   A (im2col of the input tiles) is never materialised: raw input tiles of a
+//   channel chunk live in LDS as [tile][channel][R][S]; an MFMA lane reads its
+//   A element with one ds_read_b32 at a compile-time offset from a per-lane base.
+//   B (weights) is pre-packed once per weight tensor in exactly the order the
+//   lanes consume it: every B access is a coalesced 16-byte-per-lane load
+//   straight into registers (no reuse across the K-split waves -> no LDS hop).
+//
+// Software pipeline (all index math hoisted out of the K loop):
+//   every lane owns NS fixed staging slots (tile, channel-in-chunk, pixel).  The
+//   raw values of chunk c+1 sit in registers while the MFMAs of chunk c run;
+//   between MFMA groups each slot is finished (cached-GroupNorm affine + SiLU,
+//   rounded like the reference: scale, then shift, then activation), written to
+//   the other LDS buffer, and its register immediately re-issued as the load of
+//   chunk c+2.  B registers are re-issued the same way right after their last
+//   MFMA.  So every global load has a full chunk of MFMA time to land and the
+//   VALU work of the staging is spread between matrix instructions.
+#pragma once
+#include <type_traits>
+
+#include "common.hpp"
+
+namespace sige {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { SRC_TILES = 0, SRC_GATHER = 1, SRC_SCATTER_GATHER = 2 };
+enum { DST_TILES = 0, DST_NCHW = 1 };
+
+template <int MT_> struct Mfma;
+template <> struct Mfma<32> {
+    using acc_t = f32x16;
+    static constexpr int REGS = 16;
+    __device__ static __forceinline__ acc_t op(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mfma<16> {
+    using acc_t = f32x4;
+    static constexpr int REGS = 4;
+    __device__ static __forceinline__ acc_t op(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+};
+
+template <int KH, int STR, int R_, int MT_>
+struct ConvGeo {
+    static constexpr int K = KH, S = STR, R = R_, MT = MT_;
+    static constexpr int KK = KH * KH;
+    static constexpr int RS = R_ * R_;
+    static constexpr int RO = (R_ - KH) / STR + 1;
+    static constexpr int PX = RO * RO;                 // output pixels per tile: 16 or 4
+    static constexpr int NL = 64 / MT_;                // k values per MFMA = lane groups (2 or 4)
+    static constexpr int TPB = MT_ / PX;               // tiles per M block
+    static constexpr int CW = (KK == 1 ? 16 : 4) * NL; // channels per wave per chunk
+    static constexpr int CC = 4 * CW;                  // channels per LDS chunk
+    static constexpr int L = (CW / NL) * KK;           // MFMA k-steps per wave per chunk (36 or 16)
+    static constexpr int F = L / 4;                    // 16-byte weight loads per lane per chunk and N sub-block
+    static constexpr int TILE_FLOATS = CC * RS;        // floats of one staged tile
+    static constexpr int BUF = TPB * TILE_FLOATS;      // floats per LDS stage, laid out [tile][channel][R][S]
+    static constexpr int RED = MT_ + 4;                // padded pixel stride of the reduction buffer
+    static_assert(L % 4 == 0, "wave slice must be a whole number of float4 weight loads");
+    static_assert(MT_ % PX == 0 && TPB >= 1, "tile pixels must divide the M block");
+    static_assert(BUF % 256 == 0, "every lane owns the same number of staging slots");
+};
+
+__host__ __device__ constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+// compile-time loop: f(integral_constant<int, I>) for I in [I0, N) -- a guaranteed full unroll
+// (the MFMA body is too large for `#pragma unroll` to accept)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+struct ConvArgs {
+    const float *x;       // TILES: [T,Cin,R,S] | GATHER: [B,Csplit,H,W] | SCATTER_GATHER: conv-1 tiles [B*N,Cin,Rx,Sx]
+    const float *y;       // SCATTER_GATHER: cached full tensor [B,Cin,H,W]
+    const int32_t *idx;   // gather modes / DST_NCHW: [N,2]
+    const int32_t *map;   // SCATTER_GATHER: [H,W,3]
+    const float *packed;
+    const float *bias;
+    float *out;
+    int T, Cin, Cout, nchunks;
+    int B, N, H, W;
+    int RxSx, Sx;
+    const float *scale, *shift;  // per-(batch, channel) affine of the gather modes (same broadcast shape)
+    int aff_sb, aff_sc;          // element strides of scale / shift over (batch, channel)
+    // GATHER: channels [0,Csplit) come from x, [Csplit,Cin) from x2 (a fused torch.cat)
+    const float *x2;
+    int Csplit;
+    // DST_NCHW: write the output tiles straight into a full tensor [B,Cout,Ho,Wo] at
+    // ((off+idx)/stride), clipped, + residual[B,Cout,Ho,Wo] (dense layers: all tiles active)
+    const float *residual;
+    int Ho, Wo, offH, offW, strH, strW;
+    // grid decomposition: blockIdx.x -> (mb, ng); ng_fast = consecutive workgroups (= consecutive
+    // XCDs) take different output-channel blocks, so each XCD's L2 streams 1/8 of the weights
+    int mbk, ngk, ng_fast;
+};
+
+// SiLU for the fused staging path: v_exp_f32 + v_rcp_f32 (each <= 1 ulp) instead of
+// expf + IEEE division; |relative error| ~1e-6 (the standalone gather keeps the
+// exact form).  z -> -inf: e = +inf, r = 0, result -0 (true value -0).
+__device__ __forceinline__ float swish_fast(float z) {
+    const float e = __builtin_amdgcn_exp2f(z * -1.44269504088896341f);
+    return z * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// MODE: what the staging path applies to a gathered value
+//   0 raw copy | 1 scale*x + shift, then SiLU | 2 scale*x + shift   (both scale and shift present)
+enum { MODE_RAW = 0, MODE_AFFINE_SWISH = 1, MODE_AFFINE = 2 };
+
+template <typename G, int NB, int SRC, int MODE, int DST>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+    using M = Mfma<G::MT>;
+    constexpr int NACC = (G::MT == 16 && NB == 1) ? 2 : 1;  // 16x16x4: 40-cycle dependent latency vs 32-cycle issue
+    constexpr int LDS_FLOATS = cmax(2 * G::BUF, 4 * NB * G::MT * G::RED);
+    __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int kq = lane / G::MT, j = lane % G::MT;
+    int mb, ng;
+    if (a.ng_fast) { ng = blockIdx.x % a.ngk; mb = blockIdx.x / a.ngk; }
+    else { mb = blockIdx.x % a.mbk; ng = blockIdx.x / a.mbk; }
+    const int Cin = a.Cin;
+    const int HW = a.H * a.W;
+
+    // ---- staging slots ------------------------------------------------------
+    // element sources: slot i = LDS float (tid + 256 i) = [t_l][c_l][p];  TILES: float4 units
+    constexpr int NS = (SRC == SRC_TILES) ? (G::BUF / 4 + 255) / 256 : G::BUF / 256;
+    static_assert(NS <= 32, "one validity bit per slot");
+    float st_z[SRC == SRC_TILES ? 1 : NS];
+    float4 st_q[SRC == SRC_TILES ? NS : 1];
+    float st_sc[SRC == SRC_TILES ? 1 : NS], st_sh[SRC == SRC_TILES ? 1 : NS];
+    int s_off[NS];   // GATHER: x-side element offset at channel c_l (-1 = zero fill) | SG: element offset at c_l | TILES: float offset in the tile slab
+    int s_aux[NS];   // GATHER: x2-side offset | SG: channel stride (HW or RxSx), sign bit = take y | TILES: tile index
+    int s_cl[SRC == SRC_TILES ? 1 : NS];    // channel within the chunk
+    int s_aff[SRC == SRC_TILES ? 1 : NS];   // element offset into scale / shift at channel c_l
+    unsigned st_ok = 0;                     // bit i: the value in flight for slot i is real data (else exactly 0)
+
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int v = tid + 256 * i;
+        if (SRC == SRC_TILES) {
+            constexpr int U4 = G::TILE_FLOATS / 4;
+            const int t_l = v / U4, e = (v - t_l * U4) * 4;
+            const int t = mb * G::TPB + t_l;
+            // offset of the slot within its tile's [Cin,R,S] slab at chunk 0; -1: past the block / last tile
+            s_off[i] = (v < G::BUF / 4 && t < a.T) ? e : -1;
+            s_aux[i] = t;
+        } else {
+            const int t_l = v / G::TILE_FLOATS, rem = v - t_l * G::TILE_FLOATS;
+            const int c_l = rem / G::RS, p = rem - c_l * G::RS;
+            const int t = mb * G::TPB + t_l;
+            int off = -1, aux = 0, b = 0;
+            if (t < a.T) {
+                b = t / a.N;
+                const int n = t - b * a.N;
+                const int h = a.idx[2 * n] + p / G::R, w = a.idx[2 * n + 1] + p % G::R;
+                if (h >= 0 && h < a.H && w >= 0 && w < a.W) {
+                    const int hw = h * a.W + w;
+                    if (SRC == SRC_GATHER) {
+                        off = (b * a.Csplit + c_l) * HW + hw;
+                        aux = (b * (Cin - a.Csplit) + c_l - a.Csplit) * HW + hw;
+                    } else {
+                        const int32_t *m = a.map + 3 * (size_t)hw;
+                        const int blk = m[0];
+                        if (blk >= 0) {
+                            off = ((b * a.N + blk) * Cin + c_l) * a.RxSx + m[1] * a.Sx + m[2];
+                            aux = a.RxSx;
+                        } else {
+                            off = (b * Cin + c_l) * HW + hw;
+                            aux = HW | (int)0x80000000;
+                        }
+                    }
+                }
+            }
+            s_off[i] = off; s_aux[i] = aux; s_cl[i] = c_l; s_aff[i] = b * a.aff_sb + c_l * a.aff_sc;
+        }
+    }
+
+    // issue the global loads of slot i for channel chunk `chunk`.  Branch-free, and nothing here
+    // touches the loaded values (so no s_waitcnt lands next to the loads): invalid slots read
+    // element 0 of their source; the slot's st_ok bit makes slot_store write an exact 0 instead.
+    auto slot_load = [&](int i, int chunk) {
+        const int c0 = chunk * G::CC;
+        if (SRC == SRC_TILES) {
+            const int valid = min(G::CC, Cin - c0) * G::RS;
+            const bool ok = s_off[i] >= 0 && s_off[i] < valid;
+            const size_t o = ok ? ((size_t)s_aux[i] * Cin + c0) * G::RS + s_off[i] : 0;
+            st_q[i] = *reinterpret_cast<const float4 *>(a.x + o);
+            st_ok = ok ? (st_ok | (1u << i)) : (st_ok & ~(1u << i));
+        } else {
+            const int c = c0 + s_cl[i];
+            const bool ok = s_off[i] >= 0 && c < Cin;
+            const float *base;
+            unsigned o;
+            if (SRC == SRC_GATHER) {
+                const bool first = c < a.Csplit;
+                base = first ? a.x : a.x2;
+                o = (unsigned)((first ? s_off[i] : s_aux[i]) + c0 * HW);
+            } else {
+                base = s_aux[i] < 0 ? a.y : a.x;
+                o = (unsigned)(s_off[i] + c0 * (s_aux[i] & 0x7fffffff));
+            }
+            st_z[i] = base[ok ? o : 0u];
+            st_ok = ok ? (st_ok | (1u << i)) : (st_ok & ~(1u << i));
+            if (MODE != MODE_RAW) {
+                const unsigned ao = ok ? (unsigned)(s_aff[i] + c0 * a.aff_sc) : 0u;
+                st_sc[i] = a.scale[ao];
+                st_sh[i] = a.shift[ao];
+            }
+        }
+    };
+    // finish slot i (affine + activation) and write it to LDS stage `buf`
+    auto slot_store = [&](int i, float *buf) {
+        const bool ok = (st_ok >> i) & 1u;
+        if (SRC == SRC_TILES) {
+            float4 q = st_q[i];
+            if (!ok) q = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tid + 256 * i < G::BUF / 4) *reinterpret_cast<float4 *>(buf + 4 * (tid + 256 * i)) = q;
+        } else {
+            // scale, then shift, then activation: two separately rounded ops as in the reference
+            // (gather.cpp:33-53; built with -ffp-contract=off).  Zero-filled elements are exactly 0
+            // and are NOT passed through the affine / activation (gather.cpp:27-30).
+            float z = st_z[i];
+            if (MODE != MODE_RAW) {
+                z = st_sc[i] * z;
+                z = st_sh[i] + z;
+            }
+            if (MODE == MODE_AFFINE_SWISH) z = swish_fast(z);
+            buf[tid + 256 * i] = ok ? z : 0.f;
+        }
+    };
+
+    // ---- B: F float4 per lane per chunk and N sub-block, contiguous per (ng, chunk, wave) ----
+    const int ngtot = (a.Cout + G::MT - 1) / G::MT;
+    const float4 *wp[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int g = min(ng * NB + nb, ngtot - 1);  // past-the-end sub-blocks re-read the last one; stores are masked
+        wp[nb] = reinterpret_cast<const float4 *>(a.packed) + ((size_t)g * a.nchunks * 4 + wave) * G::F * 64 + lane;
+    }
+    float4 bset[2][NB][G::F];
+    auto b_load = [&](float4 &dst, int nb, int f, int chunk) { dst = wp[nb][((size_t)chunk * 4 * G::F + f) * 64]; };
+
+    typename M::acc_t acc[NB][NACC];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int q = 0; q < NACC; ++q)
+#pragma unroll
+            for (int i = 0; i < M::REGS; ++i) acc[nb][q][i] = 0.0f;
+
+    // A: this lane's output pixel = row j of the M block
+    const int tl = j / G::PX, px = j % G::PX;
+    const int oy = px / G::RO, ox = px % G::RO;
+    const int a_base = tl * G::TILE_FLOATS + (wave * G::CW + kq) * G::RS + oy * G::S * G::R + ox * G::S;
+
+    // ---- prologue: chunk 0 -> LDS[0]; chunk 1 -> staging registers; B sets 0 and 1 ----
+    const int last = a.nchunks - 1;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) slot_load(i, 0);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int f = 0; f < G::F; ++f) b_load(bset[0][nb][f], nb, f, 0);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        slot_store(i, smem);
+        slot_load(i, min(1, last));
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int f = 0; f < G::F; ++f) b_load(bset[1][nb][f], nb, f, min(1, last));
+    __syncthreads();
+
+    // one chunk: MFMAs on LDS[PAR] with B set PAR; staging registers (chunk+1) -> LDS[PAR^1],
+    // re-issued as chunk+2; B set PAR re-issued as chunk+2.  Loads past the last chunk re-read it.
+    auto body = [&](auto par_tag, int chunk) {
+        constexpr int PAR = decltype(par_tag)::value;
+        const float *as = smem + PAR * G::BUF + a_base;
+        float *nxt = smem + (PAR ^ 1) * G::BUF;
+        const int c2 = min(chunk + 2, last);
+        // A values are read one group of 4 k-steps ahead of the MFMAs that use them
+        constexpr int NG = G::L / 4;
+        auto a_off = [](int u) { return (u / G::KK) * G::NL * G::RS + ((u % G::KK) / G::K) * G::R + ((u % G::KK) % G::K); };
+        float av[2][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) av[0][e] = as[a_off(e)];
+        static_for<0, NG>([&](auto g_tag) {
+            constexpr int g = decltype(g_tag)::value;
+            if constexpr (g + 1 < NG) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) av[(g + 1) & 1][e] = as[a_off(4 * (g + 1) + e)];
+            }
+            static_for<0, 4>([&](auto e_tag) {
+                constexpr int e = decltype(e_tag)::value;
+                constexpr int u = 4 * g + e;
+                static_for<0, NB>([&](auto nb_tag) {
+                    constexpr int nb = decltype(nb_tag)::value;
+                    const float4 bq = bset[PAR][nb][g];
+                    const float bv = (e == 0) ? bq.x : (e == 1) ? bq.y : (e == 2) ? bq.z : bq.w;
+                    acc[nb][u % NACC] = M::op(av[g & 1][e], bv, acc[nb][u % NACC]);
+                });
+                // staging slots spread evenly over the k-steps
+                static_for<(u * NS) / G::L, ((u + 1) * NS) / G::L>([&](auto i_tag) {
+                    constexpr int i = decltype(i_tag)::value;
+                    slot_store(i, nxt);
+                    slot_load(i, c2);
+                });
+            });
+            static_for<0, NB>([&](auto nb_tag) {
+                constexpr int nb = decltype(nb_tag)::value;
+                b_load(bset[PAR][nb][g], nb, g, c2);
+            });
+        });
+        __syncthreads();
+    };
+
+    for (int chunk = 0; chunk < a.nchunks; chunk += 2) {
+        body(std::integral_constant<int, 0>{}, chunk);
+        if (chunk + 1 < a.nchunks) body(std::integral_constant<int, 1>{}, chunk + 1);
+    }
+
+    // ---- K-split reduction across the 4 waves, bias, store -----------------
+    // MT=32: reg r of lane (kq, j): pixel row = (r&3) + 8*(r>>2) + 4*kq ; MT=16: row = 4*kq + r ; column (cout) = j
+    float *red = smem;  // safe: the loop ended with a barrier
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        typename M::acc_t s = acc[nb][0];
+        if (NACC == 2) {
+#pragma unroll
+            for (int i = 0; i < M::REGS; ++i) s[i] += acc[nb][NACC - 1][i];
+        }
+        float *r = red + ((wave * NB + nb) * G::MT + j) * G::RED;
+        if (G::MT == 32) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4 *>(r + 8 * g + 4 * kq) = make_float4(s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]);
+        } else {
+            *reinterpret_cast<float4 *>(r + 4 * kq) = make_float4(s[0], s[1], s[2], s[3]);
+        }
+    }
+    __syncthreads();
+
+    // one float4 (4 consecutive pixels of one tile and one output channel) per lane and step
+    constexpr int P4 = G::PX / 4;                       // float4 per (tile, channel)
+    constexpr int UNITS_NB = G::MT * G::MT / 4;         // float4 units per N sub-block
+    constexpr int OUT_UNITS = NB * UNITS_NB;
+#pragma unroll
+    for (int o = tid; o < OUT_UNITS; o += 256) {
+        const int nb = o / UNITS_NB, o1 = o - nb * UNITS_NB;
+        const int p4 = o1 % P4;
+        const int co_l = (o1 / P4) % G::MT;
+        const int t_l = o1 / (P4 * G::MT);
+        const int rrow = t_l * G::PX + p4 * 4;
+        const float *r0 = red + (nb * G::MT + co_l) * G::RED + rrow;
+        float4 s = *reinterpret_cast<const float4 *>(r0);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float4 v = *reinterpret_cast<const float4 *>(r0 + w * NB * G::MT * G::RED);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const int t = mb * G::TPB + t_l, co = (ng * NB + nb) * G::MT + co_l;
+        if (t < a.T && co < a.Cout) {
+            const float bb = a.bias ? a.bias[co] : 0.0f;
+            s.x += bb; s.y += bb; s.z += bb; s.w += bb;
+            if (DST == DST_TILES) {
+                *reinterpret_cast<float4 *>(a.out + ((size_t)t * a.Cout + co) * G::PX + p4 * 4) = s;
+            } else {
+                const int b = t / a.N, n = t - b * a.N;
+                const int h0 = (a.offH + a.idx[2 * n]) / a.strH, w0 = (a.offW + a.idx[2 * n + 1]) / a.strW;
+                const size_t plane = ((size_t)b * a.Cout + co) * a.Ho * a.Wo;
+                const float sv[4] = {s.x, s.y, s.z, s.w};
+                if (G::RO == 4) {
+                    // one 4-pixel output row of the tile
+                    const int h = h0 + p4;
+                    if (h >= 0 && h < a.Ho) {
+                        const size_t q = plane + (size_t)h * a.Wo + w0;
+                        if (w0 >= 0 && w0 + 3 < a.Wo && ((q & 3) == 0)) {
+                            float4 ov = s;
+                            if (a.residual) {
+                                const float4 rr = *reinterpret_cast<const float4 *>(a.residual + q);
+                                ov.x += rr.x; ov.y += rr.y; ov.z += rr.z; ov.w += rr.w;
+                            }
+                            *reinterpret_cast<float4 *>(a.out + q) = ov;
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (w0 + i >= 0 && w0 + i < a.Wo)
+                                    a.out[q + i] = sv[i] + (a.residual ? a.residual[q + i] : 0.0f);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int pp = p4 * 4 + i;
+                        const int h = h0 + pp / G::RO, w = w0 + pp % G::RO;
+                        if (h >= 0 && h < a.Ho && w >= 0 && w < a.Wo) {
+                            const size_t q = plane + (size_t)h * a.Wo + w;
+                            a.out[q] = sv[i] + (a.residual ? a.residual[q] : 0.0f);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- launch ------------------------------------------------------------------
+template <typename G, int NB, int SRC, int DST>
+void launch_conv_geo(ConvArgs a, int act, hipStream_t st);
+
+// mode: MODE_* (host side maps (scale, shift, activation) onto it)
+#define SIGE_CONV_LAUNCH3(G, NB, SRC, DST)                                                                \
+    template <> void launch_conv_geo<G, NB, SRC, DST>(ConvArgs a, int mode, hipStream_t st) {             \
+        const int grid = a.mbk * a.ngk;                                                                   \
+        if (mode == MODE_AFFINE_SWISH) conv_mfma_kernel<G, NB, SRC, MODE_AFFINE_SWISH, DST><<<grid, 256, 0, st>>>(a); \
+        else if (mode == MODE_AFFINE) conv_mfma_kernel<G, NB, SRC, MODE_AFFINE, DST><<<grid, 256, 0, st>>>(a);        \
+        else conv_mfma_kernel<G, NB, SRC, MODE_RAW, DST><<<grid, 256, 0, st>>>(a);                        \
+    }
+
+// explicit-instantiation helper used by the per-geometry translation units
+#define SIGE_CONV_INSTANTIATE(G, NB)                                                                     \
+    template <> void launch_conv_geo<G, NB, SRC_TILES, DST_TILES>(ConvArgs a, int, hipStream_t st) {     \
+        conv_mfma_kernel<G, NB, SRC_TILES, MODE_RAW, DST_TILES><<<a.mbk * a.ngk, 256, 0, st>>>(a);       \
+    }                                                                                                     \
+    SIGE_CONV_LAUNCH3(G, NB, SRC_GATHER, DST_TILES)                                                       \
+    SIGE_CONV_LAUNCH3(G, NB, SRC_GATHER, DST_NCHW)                                                        \
+    SIGE_CONV_LAUNCH3(G, NB, SRC_SCATTER_GATHER, DST_TILES)
+
+}  // namespace sige

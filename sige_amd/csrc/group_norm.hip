@@ -18,7 +18,7 @@ __global__ __launch_bounds__(kGNThreads) void gn_partial_kernel(const float *__r
                                                                 int splits, float *__restrict__ ws) {
     // grid: (splits, B*groups); each block reduces a contiguous slice of one group
     const int bg = blockIdx.y, sp = blockIdx.x;
-    const size_t per = ((group_elems / 4 + splits - 1) / splits) * 4;
+    const size_t per = (((group_elems + 3) / 4 + splits - 1) / splits) * 4;
     const size_t lo = (size_t)sp * per, hi = min(group_elems, lo + per);
     const float *g = x + (size_t)bg * group_elems;
     float s = 0.f, ss = 0.f;

@@ -62,6 +62,9 @@ _SIGNATURES = {
     "sige_hip_group_norm_affine_workspace": (_c_sz, [_c_int] * 5),
     "sige_hip_group_norm_affine_f32": (_c_int, [_c_vp] + [_c_int] * 5 + [ctypes.c_float] + [_c_vp] * 6),
     "sige_hip_block_conv_direct_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp] + [_c_int] * 6 + [_c_vp, _c_vp]),
+    "sige_hip_block_conv_force_tile": (_c_int, [_c_int, _c_int]),
+    "sige_hip_attention_workspace": (_c_sz, [_c_int] * 3),
+    "sige_hip_attention_f32": (_c_int, [_c_vp, _c_int, _c_int, _c_int, ctypes.c_float, _c_vp, _c_vp, _c_vp]),
     "sige_hip_copy_f32": (_c_int, [_c_vp, _c_vp, _c_sz, _c_vp]),
 }
 
@@ -278,6 +281,11 @@ def conv_pack_weights(weight: torch.Tensor, R: int, S: int, stride: Tuple[int, i
     return packed
 
 
+def conv_force_tile(mt: int = 0, nb: int = 0):
+    """Benchmark knob: pin the MFMA conv's output block (0, 0 = automatic)."""
+    _check(lib().sige_hip_block_conv_force_tile(mt, nb), "conv_force_tile")
+
+
 def block_conv(x, packed, bias, Cout: int, kernel: Tuple[int, int], stride: Tuple[int, int]):
     x = _req(x, torch.float32, "x")
     T, Cin, R, S = x.shape
@@ -406,6 +414,24 @@ def group_norm_affine(x, groups: int, eps: float, gamma=None, beta=None):
     _check(lib().sige_hip_group_norm_affine_f32(x.data_ptr(), B, C, H, W, groups, eps, ga, be, buf.data_ptr(),
                                                 scale.data_ptr(), shift.data_ptr(), _stream(x)), "group_norm_affine")
     return scale, shift
+
+
+def attention_supported(C: int, HW: int) -> bool:
+    return C % 16 == 0 and HW % 16 == 0 and HW <= 4096 and (16 * (HW + 4) + 64 * 260) * 4 <= 160 * 1024
+
+
+def attention(qkv: torch.Tensor, scale: float) -> torch.Tensor:
+    """softmax(scale * q^T k) applied to v for qkv [B,3C,H,W] (q, k, v stacked on the
+    channel axis, one head): [B,C,H,W]."""
+    qkv = _req(qkv, torch.float32, "qkv")
+    B, C3, H, W = qkv.shape
+    C, HW = C3 // 3, H * W
+    n = int(lib().sige_hip_attention_workspace(B, C, HW))
+    ws = torch.empty(n, dtype=torch.float32, device=qkv.device)
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=qkv.device)
+    _check(lib().sige_hip_attention_f32(qkv.data_ptr(), B, C, HW, float(scale), ws.data_ptr(), out.data_ptr(),
+                                        _stream(qkv)), "attention")
+    return out
 
 
 def block_conv_direct(x, weight, bias, stride: Tuple[int, int], groups: int = 1):

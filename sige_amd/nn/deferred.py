@@ -99,12 +99,21 @@ def resolve(x: torch.Tensor) -> torch.Tensor:
     return x.materialize() if isinstance(x, DeferredTiles) else x
 
 
-def defer_ok(x: torch.Tensor, scale, shift, activation_first: bool, sparse_update: bool) -> bool:
+def defer_ok(x: torch.Tensor, scale, shift, activation_first: bool, sparse_update: bool,
+             activation_name: str = "identity") -> bool:
+    """Can the fused gather->conv kernels express this gather?  They stage
+    `act(scale * x + shift)` with scale and shift either both absent (and no
+    activation) or both present with ONE per-(batch, channel) shape [1|B, 1|C, 1, 1]
+    -- what every caller in the reference passes (sige_fused_unet.py:111,118-120)."""
     if not fusion_enabled() or sparse_update or activation_first:
         return False
     if not (x.is_cuda or FORCE_ON_CPU):
         return False
+    if (scale is None) != (shift is None):
+        return False
+    if scale is None:
+        return activation_name == "identity"
     for t in (scale, shift):
-        if t is not None and (t.dim() != 4 or t.shape[2] != 1 or t.shape[3] != 1):
+        if t.dim() != 4 or t.shape[2] != 1 or t.shape[3] != 1:
             return False
-    return True
+    return tuple(scale.shape) == tuple(shift.shape)

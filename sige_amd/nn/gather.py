@@ -75,7 +75,7 @@ class Gather(SIGEModule):
             def run():
                 return fn(x, bh, bw, idx, scale, shift, act, first)
 
-            if deferred.defer_ok(x, scale, shift, first, self.sparse_update):
+            if deferred.defer_ok(x, scale, shift, first, self.sparse_update, act):
                 # not computed yet: a SIGEConv2d consumer fuses it into its prologue,
                 # any other consumer materialises it through the gather kernel
                 return deferred.DeferredTiles(

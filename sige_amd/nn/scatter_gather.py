@@ -73,7 +73,7 @@ class ScatterGather(SIGEModule):
             def run():
                 return fn(x, cached.contiguous(), bh, bw, idx, smap, scale, shift, act, first)
 
-            if deferred.defer_ok(x, scale, shift, first, self.sparse_update):
+            if deferred.defer_ok(x, scale, shift, first, self.sparse_update, act):
                 return deferred.DeferredTiles(
                     (cached.shape[0] * idx.shape[0], x.shape[1], bh, bw), x.dtype, x.device, run,
                     dict(kind="scatter_gather", x=x, y=cached, block=(bh, bw), idx=idx, map=smap, scale=scale,

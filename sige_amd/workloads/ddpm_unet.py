@@ -218,6 +218,11 @@ class AttnBlock(SIGEModule):
 
     def _attention(self, qkv):
         b, _, hh, ww = qkv.shape
+        if qkv.is_cuda and qkv.dtype == torch.float32:
+            from .. import hip
+
+            if hip.attention_supported(self.ch, hh * ww):
+                return hip.attention(qkv, self.ch ** -0.5)
         q, k, v = qkv.reshape(b, 3, self.ch, hh * ww).unbind(1)
         attn = torch.softmax(torch.bmm(q.transpose(1, 2), k) * (self.ch ** -0.5), dim=2)
         return torch.bmm(v, attn.transpose(1, 2)).reshape(b, self.ch, hh, ww)
