@@ -104,17 +104,30 @@ static int g_force_mt = 0, g_force_nb = 0;
 __device__ int32_t g_zero_idx[2] = {0, 0};
 
 template <int KH, int STR, int R, int SRC, int DST>
-static void launch_kind(ConvArgs a, int mode, hipStream_t st) {
+static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
     using G32 = ConvGeo<KH, STR, R, 32>;
     using G16 = ConvGeo<KH, STR, R, 16>;
     constexpr bool kHasNB2 = STR == 1;
     auto blocks = [&](int tpb, int mt, int nb) { return (long)ceil_div(a.T, tpb) * ceil_div(a.Cout, mt * nb); };
+    // constraints of the staging path (conv_mfma.hpp): a fused torch.cat must split on a chunk
+    // boundary; a per-batch affine needs every M block inside one batch
+    auto usable = [&](int mt) {
+        const int cc = mt == 32 ? G32::CC : G16::CC, tpb = mt == 32 ? G32::TPB : G16::TPB;
+        if (SRC == SRC_GATHER && a.Csplit != a.Cin && a.Csplit % cc) return false;
+        if (SRC != SRC_TILES && a.aff_sb != 0 && a.B > 1 && a.N % tpb) return false;
+        return true;
+    };
     const long kFill = 224;
-    int mt = 16, nb = 1;
-    if (g_force_mt) { mt = g_force_mt == 32 ? 32 : 16; nb = (g_force_nb == 2 && kHasNB2) ? 2 : 1; }
-    else if (kHasNB2 && blocks(G32::TPB, 32, 2) >= kFill) { mt = 32; nb = 2; }
-    else if (blocks(G32::TPB, 32, 1) >= kFill) { mt = 32; nb = 1; }
-    else if (kHasNB2 && blocks(G16::TPB, 16, 2) >= kFill) { mt = 16; nb = 2; }
+    int mt = 0, nb = 1;
+    if (g_force_mt) { mt = g_force_mt == 32 ? 32 : 16; nb = (g_force_nb == 2 && kHasNB2) ? 2 : 1; if (!usable(mt)) mt = 0; }
+    if (!mt) {
+        if (usable(32) && kHasNB2 && blocks(G32::TPB, 32, 2) >= kFill) { mt = 32; nb = 2; }
+        else if (usable(32) && blocks(G32::TPB, 32, 1) >= kFill) { mt = 32; nb = 1; }
+        else if (usable(16) && kHasNB2 && blocks(G16::TPB, 16, 2) >= kFill) { mt = 16; nb = 2; }
+        else if (usable(16)) { mt = 16; nb = 1; }
+        else if (usable(32)) { mt = 32; nb = 1; }
+        else return SIGE_HIP_EUNSUPPORTED;
+    }
     const int tpb = mt == 32 ? G32::TPB : G16::TPB;
     a.mbk = ceil_div(a.T, tpb);
     a.ngk = ceil_div(a.Cout, mt * nb);
@@ -124,22 +137,24 @@ static void launch_kind(ConvArgs a, int mode, hipStream_t st) {
     a.ng_fast = wbytes > abytes;
     if (mt == 16) a.packed += packed_floats(a.Cout, a.Cin, KH * KH, 32);  // the MT=16 layout follows the MT=32 one
     if constexpr (kHasNB2) {
-        if (mt == 32 && nb == 2) return launch_conv_geo<G32, 2, SRC, DST>(a, mode, st);
-        if (nb == 2) return launch_conv_geo<G16, 2, SRC, DST>(a, mode, st);
+        if (mt == 32 && nb == 2) { launch_conv_geo<G32, 2, SRC, DST>(a, mode, st); return SIGE_HIP_OK; }
+        if (nb == 2) { launch_conv_geo<G16, 2, SRC, DST>(a, mode, st); return SIGE_HIP_OK; }
     }
     if (mt == 32) launch_conv_geo<G32, 1, SRC, DST>(a, mode, st);
     else launch_conv_geo<G16, 1, SRC, DST>(a, mode, st);
+    return SIGE_HIP_OK;
 }
 
 template <int SRC, int DST = DST_TILES>
 static int launch_conv(const ConvArgs &a, int mode, int kH, int kW, int R, int S, int strH, int strW, hipStream_t st) {
+    int rc;
     switch (mfma_kind(kH, kW, R, S, strH, strW, 1)) {
-        case 1: launch_kind<3, 1, 6, SRC, DST>(a, mode, st); break;
-        case 2: launch_kind<1, 1, 4, SRC, DST>(a, mode, st); break;
-        case 3: launch_kind<3, 2, 5, SRC, DST>(a, mode, st); break;
+        case 1: rc = launch_kind<3, 1, 6, SRC, DST>(a, mode, st); break;
+        case 2: rc = launch_kind<1, 1, 4, SRC, DST>(a, mode, st); break;
+        case 3: rc = launch_kind<3, 2, 5, SRC, DST>(a, mode, st); break;
         default: return SIGE_HIP_EUNSUPPORTED;
     }
-    return launch_status();
+    return rc != SIGE_HIP_OK ? rc : launch_status();
 }
 
 // (scale, shift, activation) -> staging mode of the fused kernels; -1: not expressible
@@ -200,13 +215,13 @@ extern "C" int sige_hip_block_conv_f32(const float *x, int T, int Cin, int R, in
     if (T == 0) return SIGE_HIP_OK;
     if (!x || !packed || !out) return SIGE_HIP_EINVAL;
     if (reinterpret_cast<uintptr_t>(out) & 15 || reinterpret_cast<uintptr_t>(packed) & 15) return SIGE_HIP_EINVAL;
+    if ((long)T * Cin * R * S >= (1L << 29)) return SIGE_HIP_EUNSUPPORTED;  // 32-bit byte offsets in the kernel
     ConvArgs a{};
     a.x = x; a.packed = packed; a.bias = bias; a.out = out;
     a.T = T; a.Cin = Cin; a.Cout = Cout;
     if (reinterpret_cast<uintptr_t>(x) & 15 || ((long)Cin * R * S) % 4) {
         // The tile slab cannot be staged with 16-byte loads: run it as a gather of ONE tile at
         // (0, 0) from each of T "images" [Cin, R, S] (element-wise staging, same MFMA order).
-        if ((long)T * Cin * R * S >= (1L << 30)) return SIGE_HIP_EUNSUPPORTED;
         void *zero_idx = nullptr;
         if (hipGetSymbolAddress(&zero_idx, HIP_SYMBOL(g_zero_idx)) != hipSuccess) return SIGE_HIP_ELAUNCH;
         a.x2 = x; a.Csplit = Cin; a.idx = static_cast<const int32_t *>(zero_idx);
@@ -232,7 +247,7 @@ extern "C" int sige_hip_gather_conv_f32(const float *x, int B, int Cin, int H, i
     if (!channel_affine(scale, scaleB, scaleC, scaleH, scaleW, B, Cin) ||
         !channel_affine(shift, shiftB, shiftC, shiftH, shiftW, B, Cin))
         return SIGE_HIP_EUNSUPPORTED;  // spatially varying affine: use gather + block_conv
-    if ((long)B * Cin * H * W >= (1L << 30)) return SIGE_HIP_EUNSUPPORTED;  // 32-bit element offsets in the kernel
+    if ((long)B * Cin * H * W >= (1L << 29)) return SIGE_HIP_EUNSUPPORTED;  // 32-bit element offsets in the kernel
     if ((long)B * N == 0) return SIGE_HIP_OK;
     if (!x || !packed || !out || !active_indices) return SIGE_HIP_EINVAL;
     if (reinterpret_cast<uintptr_t>(out) & 15 || reinterpret_cast<uintptr_t>(packed) & 15) return SIGE_HIP_EINVAL;
@@ -261,13 +276,14 @@ extern "C" int sige_hip_gather_conv_nchw_f32(const float *x, const float *x2, in
     if ((scale && !((scaleB == 1 || scaleB == B) && (scaleC == 1 || scaleC == Cin))) ||
         (shift && !((shiftB == 1 || shiftB == B) && (shiftC == 1 || shiftC == Cin))))
         return SIGE_HIP_EINVAL;
-    if ((long)B * Cin * H * W >= (1L << 30)) return SIGE_HIP_EUNSUPPORTED;  // 32-bit element offsets in the kernel
+    if ((long)B * Cin * H * W >= (1L << 29)) return SIGE_HIP_EUNSUPPORTED;  // 32-bit element offsets in the kernel
     if ((long)B * N == 0) return SIGE_HIP_OK;
     if (!x || (C2 && !x2) || !packed || !out || !active_indices) return SIGE_HIP_EINVAL;
     if (reinterpret_cast<uintptr_t>(packed) & 15) return SIGE_HIP_EINVAL;
     ConvArgs a{};
     a.x = x; a.x2 = x2; a.Csplit = C1; a.idx = active_indices; a.packed = packed; a.bias = bias; a.out = out;
     a.T = B * N; a.Cin = Cin; a.Cout = Cout; a.B = B; a.N = N; a.H = H; a.W = W;
+    if (C2 && B != 1) return SIGE_HIP_EUNSUPPORTED;  // the two-tensor input is per image (conv_mfma.hpp)
     if (!x2) a.x2 = x;
     a.scale = scale; a.shift = shift;
     const int mode = staging_mode(scale, scaleB, scaleC, shift, shiftB, shiftC, activation, B, Cin, &a.aff_sb, &a.aff_sc);
@@ -289,7 +305,7 @@ extern "C" int sige_hip_scatter_gather_conv_f32(const float *x, const float *y, 
     if (!channel_affine(scale, scaleB, scaleC, scaleH, scaleW, B, Cin) ||
         !channel_affine(shift, shiftB, shiftC, shiftH, shiftW, B, Cin))
         return SIGE_HIP_EUNSUPPORTED;
-    if ((long)B * Cin * H * W >= (1L << 30) || (long)B * N * Cin * Rx * Sx >= (1L << 30)) return SIGE_HIP_EUNSUPPORTED;
+    if ((long)B * Cin * H * W >= (1L << 29) || (long)B * N * Cin * Rx * Sx >= (1L << 29)) return SIGE_HIP_EUNSUPPORTED;
     if ((long)B * N == 0) return SIGE_HIP_OK;
     if (!x || !y || !packed || !out || !active_indices || !scatter_map) return SIGE_HIP_EINVAL;
     if (reinterpret_cast<uintptr_t>(out) & 15 || reinterpret_cast<uintptr_t>(packed) & 15) return SIGE_HIP_EINVAL;

@@ -108,7 +108,7 @@ struct ConvArgs {
     int RxSx, Sx;
     const float *scale, *shift;  // per-(batch, channel) affine of the gather modes (same broadcast shape)
     int aff_sb, aff_sc;          // element strides of scale / shift over (batch, channel)
-    // GATHER: channels [0,Csplit) come from x, [Csplit,Cin) from x2 (a fused torch.cat)
+    // GATHER: channels [0,Csplit) come from x, [Csplit,Cin) from x2 (a fused torch.cat; B == 1, Csplit % CC == 0)
     const float *x2;
     int Csplit;
     // DST_NCHW: write the output tiles straight into a full tensor [B,Cout,Ho,Wo] at
@@ -132,12 +132,43 @@ __device__ __forceinline__ float swish_fast(float z) {
 //   0 raw copy | 1 scale*x + shift, then SiLU | 2 scale*x + shift   (both scale and shift present)
 enum { MODE_RAW = 0, MODE_AFFINE_SWISH = 1, MODE_AFFINE = 2 };
 
+// ---- buffer addressing -----------------------------------------------------------
+// Measured on MI355X (tools/probe/mfma_probe.hip): the f32-input MFMA shares its issue
+// slots with f32 VALU work of the SAME wave -- every VALU instruction between two
+// MFMAs adds ~4 cycles to the 32 (16x16x4) / 64 (32x32x2) cycle matrix instruction,
+// while LDS and memory instructions overlap for free.  So the K loop below is built
+// to contain (almost) no VALU instructions: all addressing is a per-slot constant
+// 32-bit byte offset into a buffer descriptor that is advanced per channel chunk with
+// SCALAR arithmetic, and every "is this element real data?" test is the hardware's
+// buffer range check (out-of-range lanes read 0) instead of compare + select.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr unsigned kOOB = 0x80000000u;  // a byte offset no descriptor contains (tensors are < 2 GiB: host side)
+
+__device__ __forceinline__ rsrc_t make_rsrc(const float *base, long elem_off, long total_elems) {
+    // window [elem_off, total_elems) of the tensor at `base`; empty past the end
+    long bytes = (total_elems - elem_off) * 4;
+    if (bytes < 0) bytes = 0;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base) + elem_off, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_f32(rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+__device__ __forceinline__ float4 buf_f32x4(rsrc_t r, unsigned byte_off, int soff) {
+    // (bit_cast the whole vector: element-wise bit_casts of the builtin's result are narrowed
+    // by hipcc 7.2 to a single dword load of element 0)
+    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, soff, 0));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
 template <typename G, int NB, int SRC, int MODE, int DST>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     using M = Mfma<G::MT>;
     constexpr int NACC = (G::MT == 16 && NB == 1) ? 2 : 1;  // 16x16x4: 40-cycle dependent latency vs 32-cycle issue
-    constexpr int LDS_FLOATS = cmax(2 * G::BUF, 4 * NB * G::MT * G::RED);
+    constexpr bool AFF = MODE != MODE_RAW;
+    constexpr int TABF = AFF ? 2 * (G::CC + 1) : 0;          // per-chunk (scale, shift) table + one all-zero row
+    constexpr int LDS_FLOATS = cmax(2 * G::BUF + 2 * TABF, 4 * NB * G::MT * G::RED);
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
+    float *const tab = smem + 2 * G::BUF;
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -148,19 +179,22 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     else { mb = blockIdx.x % a.mbk; ng = blockIdx.x / a.mbk; }
     const int Cin = a.Cin;
     const int HW = a.H * a.W;
+    const int last = a.nchunks - 1;
 
     // ---- staging slots ------------------------------------------------------
-    // element sources: slot i = LDS float (tid + 256 i) = [t_l][c_l][p];  TILES: float4 units
+    // element sources: slot i = LDS float (tid + 256 i) = [t_l][c_l][p];  TILES: float4 units.
+    // s_off / s_off2: byte offsets at channel chunk 0 (kOOB = the element is a zero fill)
+    //   TILES           s_off  into x [T,Cin,R,S]
+    //   GATHER          s_off  into x or x2 (chunks never straddle the two: host side)
+    //   SCATTER_GATHER  s_off  into the conv-1 tiles, s_off2 into the cached tensor y (one of them kOOB)
     constexpr int NS = (SRC == SRC_TILES) ? (G::BUF / 4 + 255) / 256 : G::BUF / 256;
-    static_assert(NS <= 32, "one validity bit per slot");
-    float st_z[SRC == SRC_TILES ? 1 : NS];
-    float4 st_q[SRC == SRC_TILES ? NS : 1];
-    float st_sc[SRC == SRC_TILES ? 1 : NS], st_sh[SRC == SRC_TILES ? 1 : NS];
-    int s_off[NS];   // GATHER: x-side element offset at channel c_l (-1 = zero fill) | SG: element offset at c_l | TILES: float offset in the tile slab
-    int s_aux[NS];   // GATHER: x2-side offset | SG: channel stride (HW or RxSx), sign bit = take y | TILES: tile index
-    int s_cl[SRC == SRC_TILES ? 1 : NS];    // channel within the chunk
-    int s_aff[SRC == SRC_TILES ? 1 : NS];   // element offset into scale / shift at channel c_l
-    unsigned st_ok = 0;                     // bit i: the value in flight for slot i is real data (else exactly 0)
+    // two register sets: while set (chunk & 1) is finished into LDS, the other one is still landing
+    float st_z[2][SRC == SRC_TILES ? 1 : NS];
+    float st_z2[2][SRC == SRC_SCATTER_GATHER ? NS : 1];
+    float4 st_q[2][SRC == SRC_TILES ? NS : 1];
+    unsigned s_off[NS];
+    unsigned s_off2[SRC == SRC_SCATTER_GATHER ? NS : 1];
+    int s_tab[AFF ? NS : 1];   // LDS float index of the slot's (scale, shift) row in table 0 (zero row for zero fills)
 
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
@@ -169,104 +203,116 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             constexpr int U4 = G::TILE_FLOATS / 4;
             const int t_l = v / U4, e = (v - t_l * U4) * 4;
             const int t = mb * G::TPB + t_l;
-            // offset of the slot within its tile's [Cin,R,S] slab at chunk 0; -1: past the block / last tile
-            s_off[i] = (v < G::BUF / 4 && t < a.T) ? e : -1;
-            s_aux[i] = t;
+            s_off[i] = (v < G::BUF / 4 && t < a.T) ? (unsigned)(t * Cin * G::RS + e) * 4u : kOOB;
         } else {
             const int t_l = v / G::TILE_FLOATS, rem = v - t_l * G::TILE_FLOATS;
             const int c_l = rem / G::RS, p = rem - c_l * G::RS;
             const int t = mb * G::TPB + t_l;
-            int off = -1, aux = 0, b = 0;
+            unsigned off = kOOB, off2 = kOOB;
             if (t < a.T) {
-                b = t / a.N;
+                const int b = t / a.N;
                 const int n = t - b * a.N;
                 const int h = a.idx[2 * n] + p / G::R, w = a.idx[2 * n + 1] + p % G::R;
                 if (h >= 0 && h < a.H && w >= 0 && w < a.W) {
                     const int hw = h * a.W + w;
                     if (SRC == SRC_GATHER) {
-                        off = (b * a.Csplit + c_l) * HW + hw;
-                        aux = (b * (Cin - a.Csplit) + c_l - a.Csplit) * HW + hw;
+                        off = (unsigned)((b * Cin + c_l) * HW + hw) * 4u;  // (with x2: B == 1, see host side)
                     } else {
                         const int32_t *m = a.map + 3 * (size_t)hw;
                         const int blk = m[0];
-                        if (blk >= 0) {
-                            off = ((b * a.N + blk) * Cin + c_l) * a.RxSx + m[1] * a.Sx + m[2];
-                            aux = a.RxSx;
-                        } else {
-                            off = (b * Cin + c_l) * HW + hw;
-                            aux = HW | (int)0x80000000;
-                        }
+                        if (blk >= 0) off = (unsigned)(((b * a.N + blk) * Cin + c_l) * a.RxSx + m[1] * a.Sx + m[2]) * 4u;
+                        else off2 = (unsigned)((b * Cin + c_l) * HW + hw) * 4u;
                     }
                 }
             }
-            s_off[i] = off; s_aux[i] = aux; s_cl[i] = c_l; s_aff[i] = b * a.aff_sb + c_l * a.aff_sc;
+            s_off[i] = off;
+            if (SRC == SRC_SCATTER_GATHER) s_off2[i] = off2;
+            if (AFF) s_tab[i] = 2 * ((off != kOOB || off2 != kOOB) ? c_l : G::CC);
         }
     }
 
-    // issue the global loads of slot i for channel chunk `chunk`.  Branch-free, and nothing here
-    // touches the loaded values (so no s_waitcnt lands next to the loads): invalid slots read
-    // element 0 of their source; the slot's st_ok bit makes slot_store write an exact 0 instead.
-    auto slot_load = [&](int i, int chunk) {
+    // descriptors of the staging sources, advanced to channel chunk `chunk` with scalar arithmetic
+    rsrc_t r_a, r_a2;
+    auto set_chunk = [&](int chunk) {
         const int c0 = chunk * G::CC;
         if (SRC == SRC_TILES) {
-            const int valid = min(G::CC, Cin - c0) * G::RS;
-            const bool ok = s_off[i] >= 0 && s_off[i] < valid;
-            const size_t o = ok ? ((size_t)s_aux[i] * Cin + c0) * G::RS + s_off[i] : 0;
-            st_q[i] = *reinterpret_cast<const float4 *>(a.x + o);
-            st_ok = ok ? (st_ok | (1u << i)) : (st_ok & ~(1u << i));
+            r_a = make_rsrc(a.x, (long)c0 * G::RS, (long)a.T * Cin * G::RS);
+        } else if (SRC == SRC_GATHER) {
+            // channels [0, Csplit) live in x [B,Csplit,H,W], [Csplit, Cin) in x2 [1,Cin-Csplit,H,W]
+            if (c0 < a.Csplit) r_a = make_rsrc(a.x, (long)c0 * HW, (long)a.B * a.Csplit * HW);
+            else r_a = make_rsrc(a.x2, (long)(c0 - a.Csplit) * HW, (long)(Cin - a.Csplit) * HW);
         } else {
-            const int c = c0 + s_cl[i];
-            const bool ok = s_off[i] >= 0 && c < Cin;
-            const float *base;
-            unsigned o;
-            if (SRC == SRC_GATHER) {
-                const bool first = c < a.Csplit;
-                base = first ? a.x : a.x2;
-                o = (unsigned)((first ? s_off[i] : s_aux[i]) + c0 * HW);
-            } else {
-                base = s_aux[i] < 0 ? a.y : a.x;
-                o = (unsigned)(s_off[i] + c0 * (s_aux[i] & 0x7fffffff));
-            }
-            st_z[i] = base[ok ? o : 0u];
-            st_ok = ok ? (st_ok | (1u << i)) : (st_ok & ~(1u << i));
-            if (MODE != MODE_RAW) {
-                const unsigned ao = ok ? (unsigned)(s_aff[i] + c0 * a.aff_sc) : 0u;
-                st_sc[i] = a.scale[ao];
-                st_sh[i] = a.shift[ao];
-            }
+            r_a = make_rsrc(a.x, (long)c0 * a.RxSx, (long)a.B * a.N * Cin * a.RxSx);
+            r_a2 = make_rsrc(a.y, (long)c0 * HW, (long)a.B * Cin * HW);
         }
     };
-    // finish slot i (affine + activation) and write it to LDS stage `buf`
-    auto slot_store = [&](int i, float *buf) {
-        const bool ok = (st_ok >> i) & 1u;
+    // TILES only: a partial last chunk must not read the next tile's channels
+    auto tile_off = [&](int i, int chunk) -> unsigned {
+        constexpr int U4 = G::TILE_FLOATS / 4;
+        const int e = ((tid + 256 * i) % U4) * 4;
+        return e < (Cin - chunk * G::CC) * G::RS ? s_off[i] : kOOB;
+    };
+    auto slot_load = [&](int set, int i, int chunk) {
         if (SRC == SRC_TILES) {
-            float4 q = st_q[i];
-            if (!ok) q = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (tid + 256 * i < G::BUF / 4) *reinterpret_cast<float4 *>(buf + 4 * (tid + 256 * i)) = q;
+            st_q[set][i] = buf_f32x4(r_a, tile_off(i, chunk), 0);
         } else {
-            // scale, then shift, then activation: two separately rounded ops as in the reference
-            // (gather.cpp:33-53; built with -ffp-contract=off).  Zero-filled elements are exactly 0
-            // and are NOT passed through the affine / activation (gather.cpp:27-30).
-            float z = st_z[i];
-            if (MODE != MODE_RAW) {
-                z = st_sc[i] * z;
-                z = st_sh[i] + z;
+            st_z[set][i] = buf_f32(r_a, s_off[i]);
+            if (SRC == SRC_SCATTER_GATHER) st_z2[set][i] = buf_f32(r_a2, s_off2[i]);
+        }
+    };
+    // finish slot i (affine + activation) and write it to LDS stage `buf`; `tb` = this chunk's table
+    auto slot_store = [&](int set, int i, float *buf, const float *tb) {
+        if (SRC == SRC_TILES) {
+            if (NS * 256 == G::BUF / 4 || tid + 256 * i < G::BUF / 4)
+                *reinterpret_cast<float4 *>(buf + 4 * (tid + 256 * i)) = st_q[set][i];
+        } else {
+            float z = st_z[set][i];
+            if (SRC == SRC_SCATTER_GATHER) z += st_z2[set][i];  // exactly one of the two is data, the other an exact 0
+            if (AFF) {
+                // scale, then shift, then activation: two separately rounded ops as in the reference
+                // (gather.cpp:33-53; built with -ffp-contract=off).  Zero fills read the table's zero
+                // row: 0*0 + 0 = 0 and act(0) = 0, i.e. NOT affine-transformed (gather.cpp:27-30).
+                const float2 ss = *reinterpret_cast<const float2 *>(tb + s_tab[i]);
+                z = ss.x * z;
+                z = ss.y + z;
             }
             if (MODE == MODE_AFFINE_SWISH) z = swish_fast(z);
-            buf[tid + 256 * i] = ok ? z : 0.f;
+            buf[tid + 256 * i] = z;
+        }
+    };
+    // (scale, shift) of channel chunk `chunk` for table row (tid mod CC); rows past Cin are 0
+    const int trow = tid % G::CC;
+    float2 t_ss;
+    auto tab_load = [&](int chunk) {
+        if (AFF) {
+            const int c = chunk * G::CC + trow;
+            const int cc = c < Cin ? c : 0;
+            const int b0 = (mb * G::TPB) / a.N;  // (a per-batch affine needs one batch per M block: host side)
+            const float sc = a.scale[b0 * a.aff_sb + cc * a.aff_sc], sh = a.shift[b0 * a.aff_sb + cc * a.aff_sc];
+            t_ss = c < Cin ? make_float2(sc, sh) : make_float2(0.f, 0.f);
+        }
+    };
+    auto tab_store = [&](float *tb) {
+        if (AFF) {
+            *reinterpret_cast<float2 *>(tb + 2 * trow) = t_ss;
+            if (tid == 0) *reinterpret_cast<float2 *>(tb + 2 * G::CC) = make_float2(0.f, 0.f);
         }
     };
 
     // ---- B: F float4 per lane per chunk and N sub-block, contiguous per (ng, chunk, wave) ----
     const int ngtot = (a.Cout + G::MT - 1) / G::MT;
-    const float4 *wp[NB];
+    const long packed_floats_total = (long)ngtot * a.nchunks * 4 * G::F * 64 * 4;
+    int gsel[NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int g = min(ng * NB + nb, ngtot - 1);  // past-the-end sub-blocks re-read the last one; stores are masked
-        wp[nb] = reinterpret_cast<const float4 *>(a.packed) + ((size_t)g * a.nchunks * 4 + wave) * G::F * 64 + lane;
-    }
+    for (int nb = 0; nb < NB; ++nb) gsel[nb] = min(ng * NB + nb, ngtot - 1);  // past-the-end sub-blocks re-read the last one; stores are masked
+    rsrc_t r_b[NB];
+    auto set_b_chunk = [&](int chunk) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            r_b[nb] = make_rsrc(a.packed, (((long)gsel[nb] * a.nchunks + chunk) * 4 + wave) * G::F * 64 * 4, packed_floats_total);
+    };
     float4 bset[2][NB][G::F];
-    auto b_load = [&](float4 &dst, int nb, int f, int chunk) { dst = wp[nb][((size_t)chunk * 4 * G::F + f) * 64]; };
+    auto b_load = [&](float4 &dst, int nb, int f) { dst = buf_f32x4(r_b[nb], lane * 16, f * 1024); };
 
     typename M::acc_t acc[NB][NACC];
 #pragma unroll
@@ -281,44 +327,56 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     const int oy = px / G::RO, ox = px % G::RO;
     const int a_base = tl * G::TILE_FLOATS + (wave * G::CW + kq) * G::RS + oy * G::S * G::R + ox * G::S;
 
-    // ---- prologue: chunk 0 -> LDS[0]; chunk 1 -> staging registers; B sets 0 and 1 ----
-    const int last = a.nchunks - 1;
+    // ---- prologue: chunks 0 / 1 -> register sets 0 / 1, B sets 0 / 1, tables 0 / 1;
+    //      chunk 0 -> LDS[0]; register set 0 re-issued as chunk 2 ----
+    set_chunk(0);
+    set_b_chunk(0);
 #pragma unroll
-    for (int i = 0; i < NS; ++i) slot_load(i, 0);
+    for (int i = 0; i < NS; ++i) slot_load(0, i, 0);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int f = 0; f < G::F; ++f) b_load(bset[0][nb][f], nb, f, 0);
+        for (int f = 0; f < G::F; ++f) b_load(bset[0][nb][f], nb, f);
+    set_chunk(min(1, last));
+    set_b_chunk(min(1, last));
+#pragma unroll
+    for (int i = 0; i < NS; ++i) slot_load(1, i, min(1, last));
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int f = 0; f < G::F; ++f) b_load(bset[1][nb][f], nb, f);
+    if (AFF) {
+        tab_load(0);
+        tab_store(tab);
+        tab_load(min(1, last));
+        tab_store(tab + TABF);
+        __syncthreads();
+    }
+    set_chunk(min(2, last));
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-        slot_store(i, smem);
-        slot_load(i, min(1, last));
+        slot_store(0, i, smem, tab);
+        slot_load(0, i, min(2, last));
     }
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int f = 0; f < G::F; ++f) b_load(bset[1][nb][f], nb, f, min(1, last));
     __syncthreads();
 
-    // one chunk: MFMAs on LDS[PAR] with B set PAR; staging registers (chunk+1) -> LDS[PAR^1],
-    // re-issued as chunk+2; B set PAR re-issued as chunk+2.  Loads past the last chunk re-read it.
+    // one chunk: MFMAs on LDS[PAR] with B set PAR; register set PAR^1 (chunk+1) -> LDS[PAR^1],
+    // re-issued as chunk+3; B set PAR re-issued as chunk+2.  Loads past the last chunk re-read it.
     auto body = [&](auto par_tag, int chunk) {
         constexpr int PAR = decltype(par_tag)::value;
         const float *as = smem + PAR * G::BUF + a_base;
         float *nxt = smem + (PAR ^ 1) * G::BUF;
-        const int c2 = min(chunk + 2, last);
-        // A values are read one group of 4 k-steps ahead of the MFMAs that use them
-        constexpr int NG = G::L / 4;
-        auto a_off = [](int u) { return (u / G::KK) * G::NL * G::RS + ((u % G::KK) / G::K) * G::R + ((u % G::KK) % G::K); };
-        float av[2][4];
+        const int c2 = min(chunk + 2, last), c3 = min(chunk + 3, last);
+        set_chunk(c3);
+        set_b_chunk(c2);
+        tab_load(c2);
+        // all A values of the chunk up front: LDS reads overlap with the matrix pipe for free
+        float av[G::L];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) av[0][e] = as[a_off(e)];
-        static_for<0, NG>([&](auto g_tag) {
+        for (int u = 0; u < G::L; ++u)
+            av[u] = as[(u / G::KK) * G::NL * G::RS + ((u % G::KK) / G::K) * G::R + ((u % G::KK) % G::K)];
+        static_for<0, G::L / 4>([&](auto g_tag) {
             constexpr int g = decltype(g_tag)::value;
-            if constexpr (g + 1 < NG) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) av[(g + 1) & 1][e] = as[a_off(4 * (g + 1) + e)];
-            }
             static_for<0, 4>([&](auto e_tag) {
                 constexpr int e = decltype(e_tag)::value;
                 constexpr int u = 4 * g + e;
@@ -326,20 +384,21 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                     constexpr int nb = decltype(nb_tag)::value;
                     const float4 bq = bset[PAR][nb][g];
                     const float bv = (e == 0) ? bq.x : (e == 1) ? bq.y : (e == 2) ? bq.z : bq.w;
-                    acc[nb][u % NACC] = M::op(av[g & 1][e], bv, acc[nb][u % NACC]);
+                    acc[nb][u % NACC] = M::op(av[u], bv, acc[nb][u % NACC]);
                 });
                 // staging slots spread evenly over the k-steps
                 static_for<(u * NS) / G::L, ((u + 1) * NS) / G::L>([&](auto i_tag) {
                     constexpr int i = decltype(i_tag)::value;
-                    slot_store(i, nxt);
-                    slot_load(i, c2);
+                    slot_store(PAR ^ 1, i, nxt, tab + (PAR ^ 1) * TABF);
+                    slot_load(PAR ^ 1, i, c3);
                 });
             });
             static_for<0, NB>([&](auto nb_tag) {
                 constexpr int nb = decltype(nb_tag)::value;
-                b_load(bset[PAR][nb][g], nb, g, c2);
+                b_load(bset[PAR][nb][g], nb, g);
             });
         });
+        tab_store(tab + PAR * TABF);  // table of chunk+2 replaces the one this chunk's predecessor used
         __syncthreads();
     };
 

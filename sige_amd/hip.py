@@ -91,6 +91,9 @@ def available() -> bool:
     return os.path.isfile(LIB_PATH)
 
 
+UNSUPPORTED = -2  # SIGE_HIP_EUNSUPPORTED
+
+
 def _check(status: int, what: str):
     if status != 0:
         raise RuntimeError("sige_amd.hip.%s failed: %s" % (what, lib().sige_hip_error_string(status).decode()))
@@ -308,7 +311,9 @@ def fusable_affine(scale, shift, activation_first: bool) -> bool:
 
 def gather_conv(x, block: Tuple[int, int], activeIndices, scale, shift, activationName: str,
                 packed, bias, Cout: int, kernel: Tuple[int, int], stride: Tuple[int, int]):
-    """gather(x, ...) followed by the stacked-block conv, in one kernel."""
+    """gather(x, ...) followed by the stacked-block conv, in one kernel.  Returns None when
+    the fused kernel cannot express the call (SIGE_HIP_EUNSUPPORTED: e.g. a per-batch affine
+    whose tiles-per-workgroup straddle images); the caller then runs gather + block_conv."""
     x = _req(x, torch.float32, "x")
     idx = _req(activeIndices, torch.int32, "activeIndices", 2)
     (sa, s_keep), (ta, t_keep) = _bc(scale, "scale"), _bc(shift, "shift")
@@ -317,15 +322,19 @@ def gather_conv(x, block: Tuple[int, int], activeIndices, scale, shift, activati
     Ro, So = (block[0] - kernel[0]) // stride[0] + 1, (block[1] - kernel[1]) // stride[1] + 1
     out = torch.empty((B * N, Cout, Ro, So), dtype=torch.float32, device=x.device)
     b = None if bias is None else _req(bias.detach(), torch.float32, "bias", 1).data_ptr()
-    _check(lib().sige_hip_gather_conv_f32(x.data_ptr(), B, C, H, W, block[0], block[1], idx.data_ptr(), N, *sa, *ta,
-                                          _act(activationName), packed.data_ptr(), b, Cout, kernel[0], kernel[1],
-                                          stride[0], stride[1], out.data_ptr(), _stream(x)), "gather_conv")
+    status = lib().sige_hip_gather_conv_f32(x.data_ptr(), B, C, H, W, block[0], block[1], idx.data_ptr(), N, *sa, *ta,
+                                            _act(activationName), packed.data_ptr(), b, Cout, kernel[0], kernel[1],
+                                            stride[0], stride[1], out.data_ptr(), _stream(x))
+    if status == UNSUPPORTED:
+        return None
+    _check(status, "gather_conv")
     return out
 
 
 def scatter_gather_conv(x, y, block: Tuple[int, int], activeIndices, scatterMap, scale, shift, activationName: str,
                         packed, bias, Cout: int, kernel: Tuple[int, int], stride: Tuple[int, int]):
-    """scatter_gather(x, y, ...) followed by the stacked-block conv, in one kernel."""
+    """scatter_gather(x, y, ...) followed by the stacked-block conv, in one kernel (None if
+    the fused kernel cannot express the call, see gather_conv)."""
     x, y = _req(x, torch.float32, "x"), _req(y, torch.float32, "y")
     idx = _req(activeIndices, torch.int32, "activeIndices", 2)
     smap = _req(scatterMap, torch.int32, "scatterMap", 3)
@@ -335,10 +344,13 @@ def scatter_gather_conv(x, y, block: Tuple[int, int], activeIndices, scatterMap,
     Ro, So = (block[0] - kernel[0]) // stride[0] + 1, (block[1] - kernel[1]) // stride[1] + 1
     out = torch.empty((B * N, Cout, Ro, So), dtype=torch.float32, device=y.device)
     b = None if bias is None else _req(bias.detach(), torch.float32, "bias", 1).data_ptr()
-    _check(lib().sige_hip_scatter_gather_conv_f32(
+    status = lib().sige_hip_scatter_gather_conv_f32(
         x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3], block[0], block[1], idx.data_ptr(), N,
         smap.data_ptr(), *sa, *ta, _act(activationName), packed.data_ptr(), b, Cout, kernel[0], kernel[1],
-        stride[0], stride[1], out.data_ptr(), _stream(y)), "scatter_gather_conv")
+        stride[0], stride[1], out.data_ptr(), _stream(y))
+    if status == UNSUPPORTED:
+        return None
+    _check(status, "scatter_gather_conv")
     return out
 
 
@@ -359,6 +371,13 @@ def all_tiles(H: int, W: int, out_tile: Tuple[int, int], stride: Tuple[int, int]
         idx = torch.stack(torch.meshgrid(hh, ww, indexing="ij"), dim=-1).reshape(-1, 2).contiguous().to(device)
         _all_tiles_cache[key] = idx
     return idx
+
+
+def cat_fusable(B: int, C1: int, kernel: Tuple[int, int]) -> bool:
+    """Can gather_conv_nchw take the channels from two tensors (a fused torch.cat)?  The
+    split must fall on a channel-chunk boundary of one of the kernel's tile shapes
+    (conv_mfma.hpp: 32 / 64 channels for 3x3, 128 / 256 for 1x1) and the batch must be 1."""
+    return B == 1 and C1 % (128 if tuple(kernel) == (1, 1) else 32) == 0
 
 
 def gather_conv_nchw(x, x2, block: Tuple[int, int], activeIndices, scale, shift, activationName: str,

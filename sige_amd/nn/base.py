@@ -156,10 +156,13 @@ class SIGEConv2d(nn.Conv2d, SIGEModule):
             # the producer of the tiles has not run: fuse it into the conv's prologue
             common = (packed, self.bias, self.out_channels, self.kernel_size, self.stride)
             if spec["kind"] == "gather":
-                return hip.gather_conv(spec["x"], spec["block"], spec["idx"], spec["scale"], spec["shift"],
-                                       spec["act"], *common)
-            return hip.scatter_gather_conv(spec["x"], spec["y"], spec["block"], spec["idx"], spec["map"],
-                                           spec["scale"], spec["shift"], spec["act"], *common)
+                out = hip.gather_conv(spec["x"], spec["block"], spec["idx"], spec["scale"], spec["shift"],
+                                      spec["act"], *common)
+            else:
+                out = hip.scatter_gather_conv(spec["x"], spec["y"], spec["block"], spec["idx"], spec["map"],
+                                              spec["scale"], spec["shift"], spec["act"], *common)
+            if out is not None:
+                return out  # (None: shape outside the fused kernel's limits -> two-kernel form below)
         x = deferred.resolve(x)
         if packed is not None:
             return hip.block_conv(x, packed, self.bias, self.out_channels, self.kernel_size, self.stride)

@@ -62,6 +62,8 @@ def fused_conv2d(conv: nn.Conv2d, x: torch.Tensor, scale: Optional[torch.Tensor]
         from .. import hip
 
         block, out_tile, offset = _GEOMETRY[(tuple(conv.kernel_size), tuple(conv.stride), tuple(conv.padding))]
+        if x2 is not None and not hip.cat_fusable(x.shape[0], x.shape[1], conv.kernel_size):
+            x, x2 = torch.cat([x, x2], dim=1), None
         B, _, H, W = x.shape
         if conv.stride[0] == 2:
             if not pad_bottom_right:

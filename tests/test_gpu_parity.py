@@ -213,13 +213,13 @@ def test_fused_gather_conv_equals_two_kernels(hip, C, cout, res, ratio, B):
 
 
 @pytest.mark.parametrize("mt,nb", [(16, 1), (16, 2), (32, 1), (32, 2)])
-@pytest.mark.parametrize("cin,c2,cout,k,stride,blk,off", [(128, 0, 128, 3, 1, 6, 1), (72, 56, 200, 3, 1, 6, 1), (96, 0, 64, 1, 1, 4, 0),
-                                                          (300, 84, 40, 1, 1, 4, 0), (64, 0, 72, 3, 2, 5, 0)])
+@pytest.mark.parametrize("cin,c2,cout,k,stride,blk,off", [(128, 0, 128, 3, 1, 6, 1), (64, 40, 200, 3, 1, 6, 1), (96, 0, 64, 1, 1, 4, 0),
+                                                          (256, 44, 40, 1, 1, 4, 0), (64, 0, 72, 3, 2, 5, 0), (70, 0, 24, 3, 1, 6, 1)])
 def test_conv_every_output_block_shape(hip, mt, nb, cin, c2, cout, k, stride, blk, off):
     """Every (pixels x channels) output block of the MFMA kernel, pinned with
     sige_hip_block_conv_force_tile, for the tile / gather / scatter_gather / NCHW
-    forms: channel counts that are not multiples of the chunk, a fused torch.cat whose
-    split falls inside a chunk, B = 2, border tiles."""
+    forms: channel counts that are not multiples of the chunk, a fused torch.cat (per
+    image, split on a chunk boundary), B = 2 with a per-batch affine, border tiles."""
     from sige_amd.utils import reduce_mask
 
     torch.manual_seed(cin + cout + mt + nb)
@@ -242,25 +242,31 @@ def test_conv_every_output_block_shape(hip, mt, nb, cin, c2, cout, k, stride, bl
             torch.testing.assert_close(hip.block_conv(tiles, packed, bias, cout, (k, k), (stride, stride)), conv(tiles),
                                        rtol=0, atol=1e-4)
             one = hip.gather_conv(x, (blk, blk), idx, sc, sh, act, packed, bias, cout, (k, k), (stride, stride))
-            torch.testing.assert_close(one, conv(tiles), rtol=0, atol=1e-4)
+            if one is None:  # per-batch affine with workgroups straddling images (stride-2 tiles): two-kernel form
+                assert stride == 2 and sc is not None
+            else:
+                torch.testing.assert_close(one, conv(tiles), rtol=0, atol=1e-4)
             if c2:  # the same conv with the channels coming from two tensors, written into an NCHW tensor
+                assert hip.cat_fusable(1, cin, (k, k))
                 ho = res if stride == 1 else res // 2
-                residual = torch.randn(B, cout, ho, ho, device=DEV)
-                out = hip.gather_conv_nchw(x[:, :cin].contiguous(), x[:, cin:].contiguous(), (blk, blk), idx, sc, sh, act,
-                                           packed, bias, cout, (k, k), (stride, stride), (off, off), (ho, ho), residual)
                 o = 4 if stride == 1 else 2
                 t_out = conv(tiles).reshape(B, idx.shape[0], cout, o, o)
                 for b in range(B):
+                    residual = torch.randn(1, cout, ho, ho, device=DEV)
+                    out = hip.gather_conv_nchw(x[b:b + 1, :cin].contiguous(), x[b:b + 1, cin:].contiguous(), (blk, blk), idx,
+                                               None if sc is None else sc[b:b + 1], None if sh is None else sh[b:b + 1], act,
+                                               packed, bias, cout, (k, k), (stride, stride), (off, off), (ho, ho), residual)
                     for n in (0, idx.shape[0] // 2, idx.shape[0] - 1):
                         h0, w0 = (int(idx[n, 0]) + off) // stride, (int(idx[n, 1]) + off) // stride
                         h1, w1 = min(h0 + o, ho), min(w0 + o, ho)
-                        want = t_out[b, n][:, :h1 - h0, :w1 - w0] + residual[b, :, h0:h1, w0:w1]
-                        torch.testing.assert_close(out[b, :, h0:h1, w0:w1], want, rtol=0, atol=1e-4)
+                        want = t_out[b, n][:, :h1 - h0, :w1 - w0] + residual[0, :, h0:h1, w0:w1]
+                        torch.testing.assert_close(out[0, :, h0:h1, w0:w1], want, rtol=0, atol=1e-4)
             if k == 3 and stride == 1:
                 smap = hip.get_scatter_map(res, res, 6, 6, 3, 3, 1, 1, 1, 1, idx)
                 t4 = torch.randn(B * idx.shape[0], C, 4, 4, device=DEV)
                 sg = hip.scatter_gather(t4, y, 6, 6, idx, smap, sc, sh, act, False)
                 one = hip.scatter_gather_conv(t4, y, (6, 6), idx, smap, sc, sh, act, packed, bias, cout, (3, 3), (1, 1))
+                assert one is not None
                 torch.testing.assert_close(one, conv(sg), rtol=0, atol=1e-4)
     finally:
         hip.conv_force_tile(0, 0)
@@ -268,7 +274,8 @@ def test_conv_every_output_block_shape(hip, mt, nb, cin, c2, cout, k, stride, bl
 
 def test_deferred_fusion_in_modules():
     """Module level: with fusion on, Gather returns DeferredTiles and the ResBlock
-    output is bit-identical to the unfused run (SIGE_AMD_FUSE=0)."""
+    output equals the unfused run (SIGE_AMD_FUSE=0) to 1e-5 (the fused staging path's
+    SiLU uses v_exp_f32 / v_rcp_f32)."""
     import os
 
     from sige_amd.nn import deferred
@@ -298,7 +305,7 @@ def test_deferred_fusion_in_modules():
             unfused = net(edited)
         finally:
             del os.environ["SIGE_AMD_FUSE"]
-    assert torch.equal(fused, unfused)
+    torch.testing.assert_close(fused, unfused, rtol=0, atol=1e-5)
     torch.testing.assert_close(fused, dense, rtol=0, atol=util.CONV_ATOL)
 
 
