@@ -45,7 +45,10 @@ def square_mask(ratio, H=256, W=256, top=100, left=90):
 
 # ------------------------------------------------------------------ op trace --
 TRACED = ("gather", "scatter_gather", "scatter_fused", "scatter_with_block_residual_fused", "block_conv",
-          "block_conv_direct", "gather_conv", "scatter_gather_conv")
+          "block_conv_direct", "gather_conv", "scatter_gather_conv", "gather_conv_nchw",
+          # channels-last forms (the layout the benchmark runs in)
+          "gather_cl", "scatter_gather_cl", "scatter_cl", "scatter_with_block_residual_cl", "block_conv_cl",
+          "gather_conv_cl", "scatter_gather_conv_cl")
 
 
 class Tracer:
@@ -65,10 +68,38 @@ class Tracer:
             setattr(hip, name, wrapped)
 
 
-def op_cost(name, a):
+def op_cost(name, a, k=None):
     """(family, algorithmic bytes, algorithmic flops) of one traced call --
-    SURVEY.md 8(d): reference out-of-place semantics, fp32."""
+    SURVEY.md 8(d): reference out-of-place semantics, fp32.  In-place scatters
+    (`out=` given) are accounted with the cache-preserving minimum (tile bytes only)
+    under their own family name, never mixed with the out-of-place figure."""
     e = 4
+    k = k or {}
+    if name in ("gather_cl", "scatter_gather_cl"):
+        name = name[:-3]
+    if name == "block_conv_cl":
+        name = "block_conv"
+    if name == "scatter_cl":
+        x, y, idx = a[0], a[1], a[4]
+        res = a[6] if len(a) > 6 else k.get("residual")
+        inplace = (a[7] if len(a) > 7 else k.get("out")) is not None
+        tiles = e * y.shape[0] * idx.shape[0] * y.shape[1] * x.shape[2] * x.shape[3] * (2 + (1 if res is not None else 0))
+        return ("scatter_inplace", tiles, 0) if inplace else ("scatter", 2 * e * y.numel() + tiles, 0)
+    if name == "scatter_with_block_residual_cl":
+        x0, y0, x1, i0, i1 = a[0], a[1], a[2], a[6], a[8]
+        inplace = (a[10] if len(a) > 10 else k.get("out")) is not None
+        B, C = y0.shape[:2]
+        tiles = 3 * e * B * i0.shape[0] * C * x0.shape[2] * x0.shape[3] + 4 * e * B * i1.shape[0] * C * x1.shape[2] * x1.shape[3]
+        return ("scatter_block_residual_inplace", tiles, 0) if inplace else ("scatter_block_residual", 2 * e * y0.numel() + tiles, 0)
+    if name in ("gather_conv_cl", "gather_conv_nchw"):
+        x, x2, block, idx = a[0], a[1], a[2], a[3]
+        cout, kernel, stride = a[9], a[10], a[11]
+        dense = (k.get("full") is not None) if name == "gather_conv_cl" else True
+        T, cin = x.shape[0] * idx.shape[0], x.shape[1] + (0 if x2 is None else x2.shape[1])
+        ro, so = (block[0] - kernel[0]) // stride[0] + 1, (block[1] - kernel[1]) // stride[1] + 1
+        return ("dense_conv_mfma" if dense else "block_conv_mfma"), 0, 2 * T * ro * so * cout * cin * kernel[0] * kernel[1]
+    if name == "scatter_gather_conv_cl":
+        name = "scatter_gather_conv"
     if name == "gather":
         x, bH, bW, idx = a[0], a[1], a[2], a[3]
         B, C = x.shape[:2]
@@ -112,6 +143,10 @@ def op_cost(name, a):
         ro, so = (R - kh) // stride[0] + 1, (S - kw) // stride[1] + 1
         return "block_conv_direct", 0, 2 * T * ro * so * cout * cig * kh * kw
     raise KeyError(name)
+
+
+def a_numel(t):
+    return t.numel()
 
 
 def shape_key(name, a):
@@ -259,6 +294,11 @@ def main():
     ap.add_argument("--sweep", default="0.012,0.05,0.15", help="edit ratios for the sweep section ('' = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--layout", default="nhwc", choices=["nhwc", "nchw"],
+                    help="memory format of the activations: nhwc = torch.channels_last (default), nchw = the reference's")
+    ap.add_argument("--no-inplace-scatter", action="store_true",
+                    help="Scatter modules return a fresh full tensor per call (reference semantics) instead of "
+                         "updating a persistent output buffer")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -286,6 +326,10 @@ def main():
     gen = torch.Generator(device="cpu").manual_seed(1)
     x0 = torch.randn(1, 3, 256, 256, generator=gen).to(dev)
     noise = torch.randn(1, 3, 256, 256, generator=gen).to(dev)
+    if args.layout == "nhwc":
+        model = model.to(memory_format=torch.channels_last)
+        x0, noise = x0.contiguous(memory_format=torch.channels_last), noise.contiguous(memory_format=torch.channels_last)
+    model.set_scatter_inplace(args.layout == "nhwc" and not args.no_inplace_scatter)
     t = torch.zeros(1, device=dev)
 
     def edited(ratio):
@@ -302,6 +346,17 @@ def main():
         gd, _ = capture(model, x1, t)
         dense_ms = timed_replays(gd, max(10, args.steps // 10), 3, 1) * 1e3 / max(10, args.steps // 10)
         del gd
+        dense_by_layout = {args.layout: round(dense_ms, 3)}
+        if args.layout == "nhwc":
+            # the stock model in the reference's own layout too; the baseline is the faster of the two
+            model.to(memory_format=torch.contiguous_format)
+            gd, _ = capture(model, x1.contiguous(), t)
+            d2 = timed_replays(gd, max(10, args.steps // 10), 3, 1) * 1e3 / max(10, args.steps // 10)
+            del gd
+            model.to(memory_format=torch.channels_last)
+            dense_by_layout["nchw"] = round(d2, 3)
+            dense_ms = min(dense_ms, d2)
+        result["dense_forward_ms_by_layout"] = dense_by_layout
         model.set_plain_dense(False)
 
         # ---- cache of the original image: rank 0 computes, RCCL broadcast --------
@@ -347,7 +402,7 @@ def main():
             for name, a, k, orig in trace:
                 key = shape_key(name, a)
                 if key not in per_cfg:
-                    family, nbytes, flops = op_cost(name, a)
+                    family, nbytes, flops = op_cost(name, a, k)
                     us = time_graph_of(lambda: orig(*a, **k), reps=8)
                     per_cfg[key] = dict(family=family, bytes=nbytes, flops=flops, us=us, count=0, call=(orig, a, k))
                 per_cfg[key]["count"] += 1
@@ -366,14 +421,14 @@ def main():
                 if f["flops"]:
                     kernels[name]["GFLOP"] = round(f["flops"] / 1e9, 2)
                     kernels[name]["TFLOPs"] = round(f["flops"] / f["us"] / 1e6, 2)
-            conv = [f for n, f in fam.items() if n.startswith("block_conv")]
+            conv = [f for n, f in fam.items() if n.startswith("block_conv")]  # the active-block (SIGE) convs
             conv_tflops = sum(f["flops"] for f in conv) / max(1e-9, sum(f["us"] for f in conv)) / 1e6
             hot_us = sum(f["us"] for f in fam.values())
             result.update(kernels=kernels, hot_path_us=round(hot_us, 1), block_conv_tflops=round(conv_tflops, 2))
 
             # ---- roofline of the dominant hot-path kernel family ---------------------
             if not args.no_roofline:
-                dom = max(fam, key=lambda n: fam[n]["us"])
+                dom = max((n for n in fam if n != "dense_conv_mfma"), key=lambda n: fam[n]["us"])  # hot path = the SIGE ops
                 cfgs = [c for c in per_cfg.values() if c["family"] == dom]
                 # cold measurement: clone the inputs into >= 6 rotating sets so that the
                 # 256 MiB Infinity Cache does not serve them
@@ -409,10 +464,14 @@ def main():
                             "duration (hipGraph of back-to-back launches, HIP events on the launch stream, "
                             "rotating input sets); traffic: see profiles/ (PMC pass)" % launches}
                 # secondary: the HBM-bound copy-through scatter at its largest shape
-                sc = [c for c in per_cfg.values() if c["family"] in ("scatter", "scatter_block_residual")]
+                sc = [c for c in per_cfg.values() if c["family"].startswith("scatter")]
                 if sc:
-                    c = max(sc, key=lambda c: c["bytes"])
+                    c = max(sc, key=lambda c: a_numel(c["call"][1][1]))
                     orig, a, k = c["call"]
+                    k = dict(k)
+                    k.pop("out", None)  # measure the reference (out-of-place, full copy-through) form of this scatter
+                    if c["family"].endswith("_inplace"):
+                        c = dict(c, family=c["family"][:-8], bytes=c["bytes"] + 2 * 4 * a[1].numel())
                     nsets = 6
                     sets = [tuple(v.clone() if isinstance(v, torch.Tensor) and v.is_floating_point() and v.numel() > 4096
                                   else v for v in a) for _ in range(nsets)]
@@ -439,11 +498,11 @@ def main():
                 tracer.log = []
                 model(xs, t)
                 tr, tracer.log = tracer.log, None
-                flops = sum(op_cost(n, a)[2] for n, a, k, o in tr)
+                flops = sum(op_cost(n, a, k)[2] for n, a, k, o in tr if op_cost(n, a, k)[0] != "dense_conv_mfma")
                 gs, _ = capture(model, xs, t)
                 k = max(20, args.steps // 4)
                 ms = timed_replays(gs, k, 5, 1) * 1e3 / k
-                n256 = max([a[3].shape[0] for n, a, kk, o in tr if n == "gather" and a[0].shape[2] == 256]
+                n256 = max([a[3].shape[0] for n, a, kk, o in tr if n in ("gather", "gather_cl", "gather_conv_cl") and a[0].shape[2] == 256]
                            + [a[2].shape[0] for n, a, kk, o in tr if n == "gather_conv" and a[0].shape[2] == 256] + [0])
                 sweep.append({"edit_ratio": r, "forward_ms": round(ms, 3), "speedup_vs_dense": round(dense_ms / ms, 2),
                               "active_tiles_256": n256, "block_conv_GFLOP": round(flops / 1e9, 2)})
@@ -464,7 +523,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "DDPM 256x256 church U-Net (ch128, mult 1-1-2-2-4-4, %.1fM params, random init), "
-                                   "%.1f%% square edit, one edited image per GPU, hipGraph replay" % (n_params / 1e6, args.ratio * 100),
+                                   "%.1f%% square edit, one edited image per GPU, hipGraph replay, %s activations%s"
+                                   % (n_params / 1e6, args.ratio * 100, args.layout.upper(),
+                                      ", in-place scatter buffers" if (args.layout == "nhwc" and not args.no_inplace_scatter) else ""),
                        "edit_ratio": args.ratio, "batch_per_gpu": 1, "resolution": 256,
                        "parallelism": "dp%d" % world},
             "forward_ms": round(ms_per_step, 4),

@@ -209,6 +209,72 @@ int sige_hip_gather_conv_nchw_f32(const float *x, const float *x2, int B, int C1
                                   int strideH, int strideW, int offsetH, int offsetW,
                                   const float *residual, int Ho, int Wo, float *out, void *stream);
 
+/* ---- channels-last (NHWC) forms of the fused convolutions ----------------------
+ * Same arithmetic, tensors laid out [B,H,W,C] (torch.channels_last) and tiles
+ * [T,R,S,C].  In the reference's NCHW layout a gathered 6x6 window is 6 separate
+ * 24-byte segments per channel; with the channels contiguous every staging load is a
+ * coalesced 16 bytes per lane.  Requirements: channel counts
+ * multiples of 4, 16-byte aligned pointers; scale/shift [1|B, 1|C] as above.
+ *   sige_hip_block_conv_nhwc_f32            x [T,R,S,Cin]              -> out [T,Ro,So,Cout]
+ *   sige_hip_gather_conv_nhwc_f32           x [B,H,W,C1] (+ x2 [1,H,W,C2]: a fused cat)
+ *        to_full = 0 -> out [B*N,Ro,So,Cout];  to_full = 1 -> out [B,Ho,Wo,Cout] written at
+ *        (offset+idx)/stride, clipped, + residual [B,Ho,Wo,Cout] (dense layers)
+ *   sige_hip_scatter_gather_conv_nhwc_f32   x [B*N,Rx,Sx,Cin] tiles, y [B,H,W,Cin] -> out [B*N,Ro,So,Cout] */
+int sige_hip_block_conv_nhwc_f32(const float *x, int T, int Cin, int R, int S,
+                                 const float *packed, const float *bias, int Cout, int kH, int kW,
+                                 int strideH, int strideW, float *out, void *stream);
+int sige_hip_gather_conv_nhwc_f32(const float *x, const float *x2, int B, int C1, int C2, int H, int W,
+                                  int bH, int bW, const int32_t *active_indices, int N,
+                                  const float *scale, int scaleB, int scaleC,
+                                  const float *shift, int shiftB, int shiftC,
+                                  int activation,
+                                  const float *packed, const float *bias, int Cout, int kH, int kW,
+                                  int strideH, int strideW,
+                                  int to_full, int offsetH, int offsetW, const float *residual, int Ho, int Wo,
+                                  float *out, void *stream);
+int sige_hip_scatter_gather_conv_nhwc_f32(const float *x, const float *y, int B, int Cin, int H, int W,
+                                          int Rx, int Sx, int bH, int bW,
+                                          const int32_t *active_indices, int N, const int32_t *scatter_map,
+                                          const float *scale, int scaleB, int scaleC,
+                                          const float *shift, int shiftB, int shiftC,
+                                          int activation,
+                                          const float *packed, const float *bias, int Cout, int kH, int kW,
+                                          int strideH, int strideW, float *out, void *stream);
+
+/* ---- channels-last forms of gather / scatter_gather / scatter ------------------
+ * (materialising forms: the tiles are written to HBM; the fused convs above do not
+ * need them).  scale / shift: [1|B, C].  Results are bit-identical to the NCHW
+ * entry points on the same values.
+ *   sige_hip_scatter_nhwc_f32 / sige_hip_scatter_with_block_residual_nhwc_f32:
+ *     in_place = 0  reference semantics: `out` [B,H,W,C] is a fresh tensor, written in
+ *                   ONE pass (cached tensor outside the tiles, tiles + residual inside);
+ *     in_place = 1  `out` is a buffer that already holds the cached tensor y outside
+ *                   the tiles of this mask (kept by the caller across calls): only the
+ *                   covered pixels are written -- traffic ~ active tiles, not B*H*W*C.
+ *   `table` / gH / gW: the tile table of sige_hip_tile_table_i32.                 */
+int sige_hip_gather_nhwc_f32(const float *x, int B, int C, int H, int W, int bH, int bW,
+                             const int32_t *active_indices, int N,
+                             const float *scale, int scaleB, int scaleC,
+                             const float *shift, int shiftB, int shiftC,
+                             int activation, float *out, void *stream);
+int sige_hip_scatter_gather_nhwc_f32(const float *x, const float *y, int B, int C, int H, int W,
+                                     int Rx, int Sx, int bH, int bW,
+                                     const int32_t *active_indices, int N, const int32_t *scatter_map,
+                                     const float *scale, int scaleB, int scaleC,
+                                     const float *shift, int shiftB, int shiftC,
+                                     int activation, float *out, void *stream);
+int sige_hip_scatter_nhwc_f32(const float *x, const float *y, int B, int C, int H, int W, int R, int S,
+                              int offsetH, int offsetW, int strideH, int strideW,
+                              const int32_t *active_indices, const int32_t *table, int gH, int gW, int N,
+                              const float *residual, int in_place, float *out, void *stream);
+int sige_hip_scatter_with_block_residual_nhwc_f32(
+        const float *x0, const float *y0, const float *x1, const float *y1,
+        int B, int C, int H, int W, int R0, int S0, int R1, int S1,
+        int offsetH, int offsetW, int strideH, int strideW,
+        const int32_t *active_indices0, const int32_t *table0, int gH0, int gW0, int N0,
+        const int32_t *active_indices1, const int32_t *table1, int gH1, int gW1, int N1,
+        int in_place, float *out, void *stream);
+
 /* per-group mean / rstd of a [B,C,H,W] tensor -> per-channel (scale, shift) with
  * GroupNorm(x) == x*scale + shift  (scale = gamma*rstd, shift = beta - mean*scale):
  * the producer of the cached affine (diffusion/models/common.py:37-57) as two
@@ -219,6 +285,12 @@ int sige_hip_group_norm_affine_f32(const float *x, int B, int C, int H, int W, i
                                    const float *gamma, const float *beta, float *workspace,
                                    float *scale, float *shift, void *stream);
 
+/* channels-last form: x [B,H,W,C] */
+size_t sige_hip_group_norm_affine_nhwc_workspace(int B, int C, int H, int W, int groups);
+int sige_hip_group_norm_affine_nhwc_f32(const float *x, int B, int C, int H, int W, int groups, float eps,
+                                        const float *gamma, const float *beta, float *workspace,
+                                        float *scale, float *shift, void *stream);
+
 /* ---- single-head spatial self-attention of the U-Net's dense AttnBlock ------
  * (diffusion/models/ddpm_arch/unet.py AttnBlock.forward, reached from
  * sige_fused_unet.py:186-199): qkv [B,3C,HW] = q, k, v stacked on the channel axis,
@@ -228,6 +300,9 @@ int sige_hip_group_norm_affine_f32(const float *x, int B, int C, int H, int W, i
 size_t sige_hip_attention_workspace(int B, int C, int HW);
 int sige_hip_attention_f32(const float *qkv, int B, int C, int HW, float scale, float *workspace,
                            float *out, void *stream);
+/* channels-last form: qkv [B,HW,3C] -> out [B,HW,C]; C % 64 == 0 */
+int sige_hip_attention_nhwc_f32(const float *qkv, int B, int C, int HW, float scale, float *workspace,
+                                float *out, void *stream);
 
 /* ---- plain device copy used by the cache broadcast path (packs the cached
  * activations of Scatter / ScatterGather modules into one buffer) ---------- */

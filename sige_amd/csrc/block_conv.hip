@@ -72,27 +72,28 @@ static int mfma_kind(int kH, int kW, int R, int S, int strH, int strW, int group
 }
 
 // specialisations defined in the per-geometry translation units
-#define SIGE_CONV_DECLARE(G, NB)                                                             \
-    template <> void launch_conv_geo<G, NB, SRC_TILES, DST_TILES>(ConvArgs, int, hipStream_t);          \
-    template <> void launch_conv_geo<G, NB, SRC_GATHER, DST_TILES>(ConvArgs, int, hipStream_t);         \
-    template <> void launch_conv_geo<G, NB, SRC_GATHER, DST_NCHW>(ConvArgs, int, hipStream_t);          \
-    template <> void launch_conv_geo<G, NB, SRC_SCATTER_GATHER, DST_TILES>(ConvArgs, int, hipStream_t);
+#define SIGE_CONV_DECLARE(G, NB, LAY)                                                                    \
+    template <> void launch_conv_geo<G, NB, SRC_TILES, DST_TILES, LAY>(ConvArgs, int, hipStream_t);          \
+    template <> void launch_conv_geo<G, NB, SRC_GATHER, DST_TILES, LAY>(ConvArgs, int, hipStream_t);         \
+    template <> void launch_conv_geo<G, NB, SRC_GATHER, DST_NCHW, LAY>(ConvArgs, int, hipStream_t);          \
+    template <> void launch_conv_geo<G, NB, SRC_SCATTER_GATHER, DST_TILES, LAY>(ConvArgs, int, hipStream_t);
+#define SIGE_CONV_DECLARE_LAYOUTS(G, NB) SIGE_CONV_DECLARE(G, NB, LAYOUT_NCHW) SIGE_CONV_DECLARE(G, NB, LAYOUT_NHWC)
 using K31_16 = ConvGeo<3, 1, 6, 16>;
 using K31_32 = ConvGeo<3, 1, 6, 32>;
 using K11_16 = ConvGeo<1, 1, 4, 16>;
 using K11_32 = ConvGeo<1, 1, 4, 32>;
 using K32_16 = ConvGeo<3, 2, 5, 16>;
 using K32_32 = ConvGeo<3, 2, 5, 32>;
-SIGE_CONV_DECLARE(K31_16, 1)
-SIGE_CONV_DECLARE(K31_16, 2)
-SIGE_CONV_DECLARE(K31_32, 1)
-SIGE_CONV_DECLARE(K31_32, 2)
-SIGE_CONV_DECLARE(K11_16, 1)
-SIGE_CONV_DECLARE(K11_16, 2)
-SIGE_CONV_DECLARE(K11_32, 1)
-SIGE_CONV_DECLARE(K11_32, 2)
-SIGE_CONV_DECLARE(K32_16, 1)  // stride 2: NB = 1 only (conv_k3s2.hip)
-SIGE_CONV_DECLARE(K32_32, 1)
+SIGE_CONV_DECLARE_LAYOUTS(K31_16, 1)
+SIGE_CONV_DECLARE_LAYOUTS(K31_16, 2)
+SIGE_CONV_DECLARE_LAYOUTS(K31_32, 1)
+SIGE_CONV_DECLARE_LAYOUTS(K31_32, 2)
+SIGE_CONV_DECLARE_LAYOUTS(K11_16, 1)
+SIGE_CONV_DECLARE_LAYOUTS(K11_16, 2)
+SIGE_CONV_DECLARE_LAYOUTS(K11_32, 1)
+SIGE_CONV_DECLARE_LAYOUTS(K11_32, 2)
+SIGE_CONV_DECLARE_LAYOUTS(K32_16, 1)  // stride 2: NB = 1 only (conv_k3s2*.hip)
+SIGE_CONV_DECLARE_LAYOUTS(K32_32, 1)
 
 // Output block of a workgroup: the largest of (MT x NB*MT) in
 //   32x64, 32x32, 16x32, 16x16   (pixels x output channels)
@@ -103,7 +104,7 @@ SIGE_CONV_DECLARE(K32_32, 1)
 static int g_force_mt = 0, g_force_nb = 0;
 __device__ int32_t g_zero_idx[2] = {0, 0};
 
-template <int KH, int STR, int R, int SRC, int DST>
+template <int KH, int STR, int R, int SRC, int DST, int LAY>
 static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
     using G32 = ConvGeo<KH, STR, R, 32>;
     using G16 = ConvGeo<KH, STR, R, 16>;
@@ -137,21 +138,21 @@ static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
     a.ng_fast = wbytes > abytes;
     if (mt == 16) a.packed += packed_floats(a.Cout, a.Cin, KH * KH, 32);  // the MT=16 layout follows the MT=32 one
     if constexpr (kHasNB2) {
-        if (mt == 32 && nb == 2) { launch_conv_geo<G32, 2, SRC, DST>(a, mode, st); return SIGE_HIP_OK; }
-        if (nb == 2) { launch_conv_geo<G16, 2, SRC, DST>(a, mode, st); return SIGE_HIP_OK; }
+        if (mt == 32 && nb == 2) { launch_conv_geo<G32, 2, SRC, DST, LAY>(a, mode, st); return SIGE_HIP_OK; }
+        if (nb == 2) { launch_conv_geo<G16, 2, SRC, DST, LAY>(a, mode, st); return SIGE_HIP_OK; }
     }
-    if (mt == 32) launch_conv_geo<G32, 1, SRC, DST>(a, mode, st);
-    else launch_conv_geo<G16, 1, SRC, DST>(a, mode, st);
+    if (mt == 32) launch_conv_geo<G32, 1, SRC, DST, LAY>(a, mode, st);
+    else launch_conv_geo<G16, 1, SRC, DST, LAY>(a, mode, st);
     return SIGE_HIP_OK;
 }
 
-template <int SRC, int DST = DST_TILES>
+template <int SRC, int DST = DST_TILES, int LAY = LAYOUT_NCHW>
 static int launch_conv(const ConvArgs &a, int mode, int kH, int kW, int R, int S, int strH, int strW, hipStream_t st) {
     int rc;
     switch (mfma_kind(kH, kW, R, S, strH, strW, 1)) {
-        case 1: rc = launch_kind<3, 1, 6, SRC, DST>(a, mode, st); break;
-        case 2: rc = launch_kind<1, 1, 4, SRC, DST>(a, mode, st); break;
-        case 3: rc = launch_kind<3, 2, 5, SRC, DST>(a, mode, st); break;
+        case 1: rc = launch_kind<3, 1, 6, SRC, DST, LAY>(a, mode, st); break;
+        case 2: rc = launch_kind<1, 1, 4, SRC, DST, LAY>(a, mode, st); break;
+        case 3: rc = launch_kind<3, 2, 5, SRC, DST, LAY>(a, mode, st); break;
         default: return SIGE_HIP_EUNSUPPORTED;
     }
     return rc != SIGE_HIP_OK ? rc : launch_status();
@@ -317,6 +318,83 @@ extern "C" int sige_hip_scatter_gather_conv_f32(const float *x, const float *y, 
     const int mode = staging_mode(scale, scaleB, scaleC, shift, shiftB, shiftC, activation, B, Cin, &a.aff_sb, &a.aff_sc);
     if (mode < 0) return SIGE_HIP_EUNSUPPORTED;
     return launch_conv<SRC_SCATTER_GATHER>(a, mode, kH, kW, bH, bW, strideH, strideW, as_stream(stream));
+}
+
+// ---- channels-last (NHWC) forms: the same kernels, tensors laid out [B,H,W,C] / [T,R,S,C] ----
+static bool nhwc_ok(int Cin, int C1, int Cout, const void *p0, const void *p1, const void *p2, const void *p3) {
+    auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return Cin % 4 == 0 && C1 % 4 == 0 && Cout % 4 == 0 && al(p0) && al(p1) && al(p2) && al(p3);
+}
+
+extern "C" int sige_hip_block_conv_nhwc_f32(const float *x, int T, int Cin, int R, int S,
+                                            const float *packed, const float *bias, int Cout, int kH, int kW,
+                                            int strideH, int strideW, float *out, void *stream) {
+    if (T < 0 || Cin <= 0 || Cout <= 0) return SIGE_HIP_EINVAL;
+    if (T == 0) return SIGE_HIP_OK;
+    if (!x || !packed || !out) return SIGE_HIP_EINVAL;
+    if (!nhwc_ok(Cin, Cin, Cout, x, packed, out, bias)) return SIGE_HIP_EUNSUPPORTED;
+    if ((long)T * Cin * R * S >= (1L << 29)) return SIGE_HIP_EUNSUPPORTED;
+    ConvArgs a{};
+    a.x = x; a.packed = packed; a.bias = bias; a.out = out;
+    a.T = T; a.Cin = Cin; a.Cout = Cout;
+    return launch_conv<SRC_TILES, DST_TILES, LAYOUT_NHWC>(a, 0, kH, kW, R, S, strideH, strideW, as_stream(stream));
+}
+
+extern "C" int sige_hip_gather_conv_nhwc_f32(const float *x, const float *x2, int B, int C1, int C2, int H, int W,
+                                             int bH, int bW, const int32_t *active_indices, int N,
+                                             const float *scale, int scaleB, int scaleC,
+                                             const float *shift, int shiftB, int shiftC,
+                                             int activation,
+                                             const float *packed, const float *bias, int Cout, int kH, int kW,
+                                             int strideH, int strideW,
+                                             int to_full, int offsetH, int offsetW, const float *residual, int Ho, int Wo,
+                                             float *out, void *stream) {
+    const int Cin = C1 + C2;
+    if (B < 0 || C1 <= 0 || C2 < 0 || Cout <= 0 || H <= 0 || W <= 0 || N < 0) return SIGE_HIP_EINVAL;
+    if (to_full && (Ho <= 0 || Wo <= 0)) return SIGE_HIP_EINVAL;
+    if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
+    if ((long)B * Cin * H * W >= (1L << 29)) return SIGE_HIP_EUNSUPPORTED;
+    if ((long)B * N == 0) return SIGE_HIP_OK;
+    if (!x || (C2 && !x2) || !packed || !out || !active_indices) return SIGE_HIP_EINVAL;
+    if (C2 && B != 1) return SIGE_HIP_EUNSUPPORTED;
+    if (!nhwc_ok(Cin, C1, Cout, x, C2 ? x2 : x, out, bias) || (reinterpret_cast<uintptr_t>(packed) & 15) ||
+        (reinterpret_cast<uintptr_t>(residual) & 15))
+        return SIGE_HIP_EUNSUPPORTED;
+    ConvArgs a{};
+    a.x = x; a.x2 = C2 ? x2 : x; a.Csplit = C1; a.idx = active_indices; a.packed = packed; a.bias = bias; a.out = out;
+    a.T = B * N; a.Cin = Cin; a.Cout = Cout; a.B = B; a.N = N; a.H = H; a.W = W;
+    a.scale = scale; a.shift = shift;
+    const int mode = staging_mode(scale, scaleB, scaleC, shift, shiftB, shiftC, activation, B, Cin, &a.aff_sb, &a.aff_sc);
+    if (mode < 0) return SIGE_HIP_EUNSUPPORTED;
+    if (to_full) {
+        a.residual = residual; a.Ho = Ho; a.Wo = Wo; a.offH = offsetH; a.offW = offsetW; a.strH = strideH; a.strW = strideW;
+        return launch_conv<SRC_GATHER, DST_NCHW, LAYOUT_NHWC>(a, mode, kH, kW, bH, bW, strideH, strideW, as_stream(stream));
+    }
+    return launch_conv<SRC_GATHER, DST_TILES, LAYOUT_NHWC>(a, mode, kH, kW, bH, bW, strideH, strideW, as_stream(stream));
+}
+
+extern "C" int sige_hip_scatter_gather_conv_nhwc_f32(const float *x, const float *y, int B, int Cin, int H, int W,
+                                                     int Rx, int Sx, int bH, int bW,
+                                                     const int32_t *active_indices, int N, const int32_t *scatter_map,
+                                                     const float *scale, int scaleB, int scaleC,
+                                                     const float *shift, int shiftB, int shiftC,
+                                                     int activation,
+                                                     const float *packed, const float *bias, int Cout, int kH, int kW,
+                                                     int strideH, int strideW, float *out, void *stream) {
+    if (B < 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || N < 0 || Rx <= 0 || Sx <= 0) return SIGE_HIP_EINVAL;
+    if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
+    if ((long)B * Cin * H * W >= (1L << 29) || (long)B * N * Cin * Rx * Sx >= (1L << 29)) return SIGE_HIP_EUNSUPPORTED;
+    if ((long)B * N == 0) return SIGE_HIP_OK;
+    if (!x || !y || !packed || !out || !active_indices || !scatter_map) return SIGE_HIP_EINVAL;
+    if (!nhwc_ok(Cin, Cin, Cout, x, y, out, bias) || (reinterpret_cast<uintptr_t>(packed) & 15)) return SIGE_HIP_EUNSUPPORTED;
+    ConvArgs a{};
+    a.x = x; a.y = y; a.idx = active_indices; a.map = scatter_map; a.packed = packed; a.bias = bias; a.out = out;
+    a.T = B * N; a.Cin = Cin; a.Cout = Cout; a.B = B; a.N = N; a.H = H; a.W = W;
+    a.RxSx = Rx * Sx; a.Sx = Sx;
+    a.scale = scale; a.shift = shift;
+    const int mode = staging_mode(scale, scaleB, scaleC, shift, shiftB, shiftC, activation, B, Cin, &a.aff_sb, &a.aff_sc);
+    if (mode < 0) return SIGE_HIP_EUNSUPPORTED;
+    return launch_conv<SRC_SCATTER_GATHER, DST_TILES, LAYOUT_NHWC>(a, mode, kH, kW, bH, bW, strideH, strideW, as_stream(stream));
 }
 
 extern "C" int sige_hip_block_conv_direct_f32(const float *x, int T, int Cin, int R, int S,

@@ -44,7 +44,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { SRC_TILES = 0, SRC_GATHER = 1, SRC_SCATTER_GATHER = 2 };
-enum { DST_TILES = 0, DST_NCHW = 1 };
+enum { DST_TILES = 0, DST_NCHW = 1 };  // DST_NCHW = "into a full tensor" (in the launch's layout)
 
 template <int MT_> struct Mfma;
 template <> struct Mfma<32> {
@@ -160,15 +160,32 @@ __device__ __forceinline__ float4 buf_f32x4(rsrc_t r, unsigned byte_off, int sof
     return make_float4(v[0], v[1], v[2], v[3]);
 }
 
-template <typename G, int NB, int SRC, int MODE, int DST>
+// Memory layout of every activation / tile tensor a launch touches:
+//   NCHW  [B,C,H,W] / tiles [T,C,R,S]            -- the reference's layout (torch contiguous)
+//   NHWC  [B,H,W,C] / tiles [T,R,S,C]            -- torch channels_last
+// The arithmetic is identical; only the staging addresses and the epilogue differ.  In NCHW
+// a gathered 6x6 window is 6 segments of 24 bytes per channel (one cache line each: the
+// texture-addresser cost of such a wave-load is ~100 cycles, tools/probe/mfma_probe2.hip);
+// in NHWC a pixel's channels are contiguous, so the same chunk is staged with 16-byte
+// fully coalesced loads -- 25x fewer address-processing cycles per byte.
+enum { LAYOUT_NCHW = 0, LAYOUT_NHWC = 1 };
+
+template <typename G, int NB, int SRC, int MODE, int DST, int LAYOUT = LAYOUT_NCHW>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     using M = Mfma<G::MT>;
-    constexpr int NACC = (G::MT == 16 && NB == 1) ? 2 : 1;  // 16x16x4: 40-cycle dependent latency vs 32-cycle issue
+    constexpr bool NHWC = LAYOUT == LAYOUT_NHWC;
+    constexpr bool VEC = NHWC || SRC == SRC_TILES;            // staging slots are float4 units
+    constexpr int NACC = (G::MT == 16 && NB == 1) ? 2 : 1;   // 16x16x4: 40-cycle dependent latency vs 32-cycle issue
     constexpr bool AFF = MODE != MODE_RAW;
-    constexpr int TABF = AFF ? 2 * (G::CC + 1) : 0;          // per-chunk (scale, shift) table + one all-zero row
-    constexpr int LDS_FLOATS = cmax(2 * G::BUF + 2 * TABF, 4 * NB * G::MT * G::RED);
+    // LDS stage of one channel chunk: NCHW [tile][channel][R][S]; NHWC [tile][R][S][LDC] (LDC = CC + 4 pad)
+    constexpr int LDC = G::CC + 4;
+    constexpr int STAGE = NHWC ? G::TPB * G::RS * LDC : G::BUF;
+    constexpr int TROW = G::CC + 4;                            // table row: CC channels + 4 zeros
+    constexpr int TABF = AFF ? 2 * TROW : 0;                   // scale row | shift row
+    constexpr int RP = G::MT + 4;                              // padded row of the reduction buffer
+    constexpr int LDS_FLOATS = cmax(2 * STAGE + 2 * TABF, 4 * NB * G::MT * RP);
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
-    float *const tab = smem + 2 * G::BUF;
+    float *const tab = smem + 2 * STAGE;
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -182,120 +199,170 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     const int last = a.nchunks - 1;
 
     // ---- staging slots ------------------------------------------------------
-    // element sources: slot i = LDS float (tid + 256 i) = [t_l][c_l][p];  TILES: float4 units.
-    // s_off / s_off2: byte offsets at channel chunk 0 (kOOB = the element is a zero fill)
-    //   TILES           s_off  into x [T,Cin,R,S]
-    //   GATHER          s_off  into x or x2 (chunks never straddle the two: host side)
+    // One slot = one LDS unit (a float, or a float4 when VEC) this lane fills for every chunk.
+    // s_off / s_off2: byte offsets at channel chunk 0 into the source window (kOOB = zero fill):
+    //   TILES           s_off  into the tile slab
+    //   GATHER          s_off  into x, s_off2 into x2 (NHWC only: the two have different pitches)
     //   SCATTER_GATHER  s_off  into the conv-1 tiles, s_off2 into the cached tensor y (one of them kOOB)
-    constexpr int NS = (SRC == SRC_TILES) ? (G::BUF / 4 + 255) / 256 : G::BUF / 256;
-    // two register sets: while set (chunk & 1) is finished into LDS, the other one is still landing
-    float st_z[2][SRC == SRC_TILES ? 1 : NS];
-    float st_z2[2][SRC == SRC_SCATTER_GATHER ? NS : 1];
-    float4 st_q[2][SRC == SRC_TILES ? NS : 1];
-    unsigned s_off[NS];
-    unsigned s_off2[SRC == SRC_SCATTER_GATHER ? NS : 1];
-    int s_tab[AFF ? NS : 1];   // LDS float index of the slot's (scale, shift) row in table 0 (zero row for zero fills)
+    constexpr int UNITS = VEC ? (NHWC ? G::TPB * G::RS * G::CC / 4 : G::BUF / 4) : G::BUF;
+    constexpr int NS = (UNITS + 255) / 256;
+    constexpr bool TWO = SRC == SRC_SCATTER_GATHER || (NHWC && SRC == SRC_GATHER);
+    float st_z[2][VEC ? 1 : NS], st_z2[2][(!VEC && TWO) ? NS : 1];
+    float4 st_q[2][VEC ? NS : 1], st_q2[2][(VEC && SRC == SRC_SCATTER_GATHER) ? NS : 1];
+    unsigned s_off[NS], s_off2[TWO ? NS : 1];
+    int s_tab[AFF ? NS : 1];   // float index of the slot's entry in a table row (the zero entries for zero fills)
+    int s_dst[NS];             // LDS float index of the unit inside a stage
+    int s_cl[VEC ? NS : 1];    // first channel of the unit inside the chunk (partial last chunk test)
 
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         const int v = tid + 256 * i;
-        if (SRC == SRC_TILES) {
+        int t_l, c_l, p;  // tile in block, channel in chunk, pixel in tile
+        if (NHWC) {
+            constexpr int UPT = G::RS * G::CC / 4, UPP = G::CC / 4;  // units per tile / per pixel
+            t_l = v / UPT;
+            p = (v - t_l * UPT) / UPP;
+            c_l = ((v - t_l * UPT) - p * UPP) * 4;
+            s_dst[i] = (t_l * G::RS + p) * LDC + c_l;
+        } else if (VEC) {
             constexpr int U4 = G::TILE_FLOATS / 4;
-            const int t_l = v / U4, e = (v - t_l * U4) * 4;
-            const int t = mb * G::TPB + t_l;
-            s_off[i] = (v < G::BUF / 4 && t < a.T) ? (unsigned)(t * Cin * G::RS + e) * 4u : kOOB;
+            t_l = v / U4;
+            const int e = (v - t_l * U4) * 4;
+            c_l = e / G::RS; p = e - c_l * G::RS;  // (a float4 may straddle channels: c_l = its first)
+            s_dst[i] = 4 * v;
         } else {
-            const int t_l = v / G::TILE_FLOATS, rem = v - t_l * G::TILE_FLOATS;
-            const int c_l = rem / G::RS, p = rem - c_l * G::RS;
-            const int t = mb * G::TPB + t_l;
-            unsigned off = kOOB, off2 = kOOB;
-            if (t < a.T) {
+            t_l = v / G::TILE_FLOATS;
+            c_l = (v - t_l * G::TILE_FLOATS) / G::RS;
+            p = (v - t_l * G::TILE_FLOATS) - c_l * G::RS;
+            s_dst[i] = v;
+        }
+        if (VEC) s_cl[i] = c_l;
+        const int t = mb * G::TPB + t_l;
+        unsigned off = kOOB, off2 = kOOB;
+        if (v < UNITS && t < a.T) {
+            if (SRC == SRC_TILES) {
+                off = NHWC ? (unsigned)((t * G::RS + p) * Cin + c_l) * 4u : (unsigned)(t * Cin * G::RS + (v % (G::TILE_FLOATS / 4)) * 4) * 4u;
+            } else {
                 const int b = t / a.N;
                 const int n = t - b * a.N;
                 const int h = a.idx[2 * n] + p / G::R, w = a.idx[2 * n + 1] + p % G::R;
                 if (h >= 0 && h < a.H && w >= 0 && w < a.W) {
                     const int hw = h * a.W + w;
                     if (SRC == SRC_GATHER) {
-                        off = (unsigned)((b * Cin + c_l) * HW + hw) * 4u;  // (with x2: B == 1, see host side)
+                        if (NHWC) {
+                            off = (unsigned)((b * HW + hw) * a.Csplit + c_l) * 4u;
+                            off2 = (unsigned)(hw * (Cin - a.Csplit) + c_l) * 4u;  // (x2: B == 1, host side)
+                        } else {
+                            off = (unsigned)((b * Cin + c_l) * HW + hw) * 4u;     // (with x2: B == 1)
+                        }
                     } else {
                         const int32_t *m = a.map + 3 * (size_t)hw;
                         const int blk = m[0];
-                        if (blk >= 0) off = (unsigned)(((b * a.N + blk) * Cin + c_l) * a.RxSx + m[1] * a.Sx + m[2]) * 4u;
-                        else off2 = (unsigned)((b * Cin + c_l) * HW + hw) * 4u;
+                        if (NHWC) {
+                            if (blk >= 0) off = (unsigned)(((b * a.N + blk) * a.RxSx + m[1] * a.Sx + m[2]) * Cin + c_l) * 4u;
+                            else off2 = (unsigned)((b * HW + hw) * Cin + c_l) * 4u;
+                        } else {
+                            if (blk >= 0) off = (unsigned)(((b * a.N + blk) * Cin + c_l) * a.RxSx + m[1] * a.Sx + m[2]) * 4u;
+                            else off2 = (unsigned)((b * Cin + c_l) * HW + hw) * 4u;
+                        }
                     }
                 }
             }
-            s_off[i] = off;
-            if (SRC == SRC_SCATTER_GATHER) s_off2[i] = off2;
-            if (AFF) s_tab[i] = 2 * ((off != kOOB || off2 != kOOB) ? c_l : G::CC);
         }
+        s_off[i] = off;
+        if (TWO) s_off2[i] = off2;
+        if (AFF) s_tab[i] = (off != kOOB || off2 != kOOB) ? c_l : G::CC;
     }
 
     // descriptors of the staging sources, advanced to channel chunk `chunk` with scalar arithmetic
     rsrc_t r_a, r_a2;
+    bool use2 = false;  // NHWC GATHER: this chunk's channels live in x2
     auto set_chunk = [&](int chunk) {
         const int c0 = chunk * G::CC;
+        const long cstep = NHWC ? 1 : HW;  // elements between consecutive channels of a full tensor
         if (SRC == SRC_TILES) {
-            r_a = make_rsrc(a.x, (long)c0 * G::RS, (long)a.T * Cin * G::RS);
+            r_a = make_rsrc(a.x, (long)c0 * (NHWC ? 1 : G::RS), (long)a.T * Cin * G::RS);
         } else if (SRC == SRC_GATHER) {
             // channels [0, Csplit) live in x [B,Csplit,H,W], [Csplit, Cin) in x2 [1,Cin-Csplit,H,W]
-            if (c0 < a.Csplit) r_a = make_rsrc(a.x, (long)c0 * HW, (long)a.B * a.Csplit * HW);
-            else r_a = make_rsrc(a.x2, (long)(c0 - a.Csplit) * HW, (long)(Cin - a.Csplit) * HW);
+            use2 = c0 >= a.Csplit;
+            if (!use2) r_a = make_rsrc(a.x, c0 * cstep, (long)a.B * a.Csplit * HW);
+            else r_a = make_rsrc(a.x2, (c0 - a.Csplit) * cstep, (long)(Cin - a.Csplit) * HW);
         } else {
-            r_a = make_rsrc(a.x, (long)c0 * a.RxSx, (long)a.B * a.N * Cin * a.RxSx);
-            r_a2 = make_rsrc(a.y, (long)c0 * HW, (long)a.B * Cin * HW);
+            r_a = make_rsrc(a.x, (long)c0 * (NHWC ? 1 : a.RxSx), (long)a.B * a.N * Cin * a.RxSx);
+            r_a2 = make_rsrc(a.y, c0 * cstep, (long)a.B * Cin * HW);
         }
     };
-    // TILES only: a partial last chunk must not read the next tile's channels
-    auto tile_off = [&](int i, int chunk) -> unsigned {
-        constexpr int U4 = G::TILE_FLOATS / 4;
-        const int e = ((tid + 256 * i) % U4) * 4;
-        return e < (Cin - chunk * G::CC) * G::RS ? s_off[i] : kOOB;
+    // float4 units: a partial last chunk must not read past the source's channels
+    // (NCHW tile slab: the next tile; NHWC: the next pixel)
+    auto vec_off = [&](unsigned off, int i, int chunk, int csrc, int cbase) -> unsigned {
+        const int left = csrc - (chunk * G::CC - cbase);  // channels of this source from the chunk start on
+        if (NHWC) return s_cl[i] < left ? off : kOOB;
+        return (int)((tid + 256 * i) % (G::TILE_FLOATS / 4)) * 4 < left * G::RS ? off : kOOB;
     };
     auto slot_load = [&](int set, int i, int chunk) {
-        if (SRC == SRC_TILES) {
-            st_q[set][i] = buf_f32x4(r_a, tile_off(i, chunk), 0);
-        } else {
+        if (!VEC) {
             st_z[set][i] = buf_f32(r_a, s_off[i]);
             if (SRC == SRC_SCATTER_GATHER) st_z2[set][i] = buf_f32(r_a2, s_off2[i]);
+        } else if (SRC == SRC_TILES) {
+            st_q[set][i] = buf_f32x4(r_a, vec_off(s_off[i], i, chunk, Cin, 0), 0);
+        } else if (SRC == SRC_GATHER) {
+            const unsigned o = use2 ? vec_off(s_off2[i], i, chunk, Cin - a.Csplit, a.Csplit) : vec_off(s_off[i], i, chunk, a.Csplit, 0);
+            st_q[set][i] = buf_f32x4(r_a, o, 0);
+        } else {
+            st_q[set][i] = buf_f32x4(r_a, vec_off(s_off[i], i, chunk, Cin, 0), 0);
+            st_q2[set][i] = buf_f32x4(r_a2, vec_off(s_off2[i], i, chunk, Cin, 0), 0);
         }
     };
-    // finish slot i (affine + activation) and write it to LDS stage `buf`; `tb` = this chunk's table
+    // finish slot i (affine + activation) and write it to LDS stage `buf`; `tb` = this chunk's table.
+    //   scale, then shift, then activation: two separately rounded ops as in the reference
+    //   (gather.cpp:33-53; built with -ffp-contract=off).  Zero fills read the table's zero
+    //   entries: 0*0 + 0 = 0 and act(0) = 0, i.e. NOT affine-transformed (gather.cpp:27-30).
+    auto finish = [&](float z, float sc, float sh) -> float {
+        if (AFF) { z = sc * z; z = sh + z; }
+        if (MODE == MODE_AFFINE_SWISH) z = swish_fast(z);
+        return z;
+    };
     auto slot_store = [&](int set, int i, float *buf, const float *tb) {
-        if (SRC == SRC_TILES) {
-            if (NS * 256 == G::BUF / 4 || tid + 256 * i < G::BUF / 4)
-                *reinterpret_cast<float4 *>(buf + 4 * (tid + 256 * i)) = st_q[set][i];
-        } else {
+        if (256 * (i + 1) > UNITS && tid >= UNITS - 256 * i) return;  // (only the last slot of a ragged split)
+        if (!VEC) {
             float z = st_z[set][i];
             if (SRC == SRC_SCATTER_GATHER) z += st_z2[set][i];  // exactly one of the two is data, the other an exact 0
-            if (AFF) {
-                // scale, then shift, then activation: two separately rounded ops as in the reference
-                // (gather.cpp:33-53; built with -ffp-contract=off).  Zero fills read the table's zero
-                // row: 0*0 + 0 = 0 and act(0) = 0, i.e. NOT affine-transformed (gather.cpp:27-30).
-                const float2 ss = *reinterpret_cast<const float2 *>(tb + s_tab[i]);
-                z = ss.x * z;
-                z = ss.y + z;
+            float sc = 0.f, sh = 0.f;
+            if (AFF) { sc = tb[s_tab[i]]; sh = tb[TROW + s_tab[i]]; }
+            buf[s_dst[i]] = finish(z, sc, sh);
+        } else {
+            float4 q = st_q[set][i];
+            if (SRC == SRC_SCATTER_GATHER) {
+                const float4 q2 = st_q2[set][i];
+                q.x += q2.x; q.y += q2.y; q.z += q2.z; q.w += q2.w;
             }
-            if (MODE == MODE_AFFINE_SWISH) z = swish_fast(z);
-            buf[tid + 256 * i] = z;
+            if (AFF) {  // (NHWC only: the 4 values are 4 consecutive channels)
+                const float4 sc = *reinterpret_cast<const float4 *>(tb + s_tab[i]);
+                const float4 sh = *reinterpret_cast<const float4 *>(tb + TROW + s_tab[i]);
+                q.x = finish(q.x, sc.x, sh.x); q.y = finish(q.y, sc.y, sh.y);
+                q.z = finish(q.z, sc.z, sh.z); q.w = finish(q.w, sc.w, sh.w);
+            }
+            *reinterpret_cast<float4 *>(buf + s_dst[i]) = q;
         }
     };
-    // (scale, shift) of channel chunk `chunk` for table row (tid mod CC); rows past Cin are 0
+    // (scale, shift) of channel chunk `chunk` for table entry (tid mod CC); entries past Cin are 0
     const int trow = tid % G::CC;
-    float2 t_ss;
+    float t_sc, t_sh;
     auto tab_load = [&](int chunk) {
         if (AFF) {
             const int c = chunk * G::CC + trow;
             const int cc = c < Cin ? c : 0;
             const int b0 = (mb * G::TPB) / a.N;  // (a per-batch affine needs one batch per M block: host side)
             const float sc = a.scale[b0 * a.aff_sb + cc * a.aff_sc], sh = a.shift[b0 * a.aff_sb + cc * a.aff_sc];
-            t_ss = c < Cin ? make_float2(sc, sh) : make_float2(0.f, 0.f);
+            t_sc = c < Cin ? sc : 0.f;
+            t_sh = c < Cin ? sh : 0.f;
         }
     };
     auto tab_store = [&](float *tb) {
         if (AFF) {
-            *reinterpret_cast<float2 *>(tb + 2 * trow) = t_ss;
-            if (tid == 0) *reinterpret_cast<float2 *>(tb + 2 * G::CC) = make_float2(0.f, 0.f);
+            tb[trow] = t_sc;
+            tb[TROW + trow] = t_sh;
+            if (tid < 4) { tb[G::CC + tid] = 0.f; tb[TROW + G::CC + tid] = 0.f; }
         }
     };
 
@@ -322,10 +389,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < M::REGS; ++i) acc[nb][q][i] = 0.0f;
 
-    // A: this lane's output pixel = row j of the M block
+    // A: this lane's output pixel = row j of the M block; k-step u = (channel group q, tap)
     const int tl = j / G::PX, px = j % G::PX;
     const int oy = px / G::RO, ox = px % G::RO;
-    const int a_base = tl * G::TILE_FLOATS + (wave * G::CW + kq) * G::RS + oy * G::S * G::R + ox * G::S;
+    const int a_base = NHWC ? (tl * G::RS + oy * G::S * G::R + ox * G::S) * LDC + wave * G::CW + kq
+                            : tl * G::TILE_FLOATS + (wave * G::CW + kq) * G::RS + oy * G::S * G::R + ox * G::S;
+    auto a_off = [](int u) {
+        const int q = u / G::KK, tap = u % G::KK, pix = (tap / G::K) * G::R + (tap % G::K);
+        return NHWC ? pix * LDC + q * G::NL : q * G::NL * G::RS + pix;
+    };
 
     // ---- prologue: chunks 0 / 1 -> register sets 0 / 1, B sets 0 / 1, tables 0 / 1;
     //      chunk 0 -> LDS[0]; register set 0 re-issued as chunk 2 ----
@@ -364,8 +436,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     // re-issued as chunk+3; B set PAR re-issued as chunk+2.  Loads past the last chunk re-read it.
     auto body = [&](auto par_tag, int chunk) {
         constexpr int PAR = decltype(par_tag)::value;
-        const float *as = smem + PAR * G::BUF + a_base;
-        float *nxt = smem + (PAR ^ 1) * G::BUF;
+        const float *as = smem + PAR * STAGE + a_base;
+        float *nxt = smem + (PAR ^ 1) * STAGE;
         const int c2 = min(chunk + 2, last), c3 = min(chunk + 3, last);
         set_chunk(c3);
         set_b_chunk(c2);
@@ -373,8 +445,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         // all A values of the chunk up front: LDS reads overlap with the matrix pipe for free
         float av[G::L];
 #pragma unroll
-        for (int u = 0; u < G::L; ++u)
-            av[u] = as[(u / G::KK) * G::NL * G::RS + ((u % G::KK) / G::K) * G::R + ((u % G::KK) % G::K)];
+        for (int u = 0; u < G::L; ++u) av[u] = as[a_off(u)];
         static_for<0, G::L / 4>([&](auto g_tag) {
             constexpr int g = decltype(g_tag)::value;
             static_for<0, 4>([&](auto e_tag) {
@@ -408,7 +479,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     }
 
     // ---- K-split reduction across the 4 waves, bias, store -----------------
-    // MT=32: reg r of lane (kq, j): pixel row = (r&3) + 8*(r>>2) + 4*kq ; MT=16: row = 4*kq + r ; column (cout) = j
+    // MT=32: reg r of lane (kq, j): pixel row m = (r&3) + 8*(r>>2) + 4*kq ; MT=16: m = 4*kq + r ; column (cout) = j
     float *red = smem;  // safe: the loop ended with a barrier
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -417,21 +488,70 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < M::REGS; ++i) s[i] += acc[nb][NACC - 1][i];
         }
-        float *r = red + ((wave * NB + nb) * G::MT + j) * G::RED;
-        if (G::MT == 32) {
+        if (NHWC) {
+            // red[wave][nb][pixel m][cout n]
+            float *r = red + ((wave * NB + nb) * G::MT) * RP + j;
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4 *>(r + 8 * g + 4 * kq) = make_float4(s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]);
+            for (int q = 0; q < M::REGS; ++q) {
+                const int m = G::MT == 32 ? (q & 3) + 8 * (q >> 2) + 4 * kq : 4 * kq + q;
+                r[m * RP] = s[q];
+            }
         } else {
-            *reinterpret_cast<float4 *>(r + 4 * kq) = make_float4(s[0], s[1], s[2], s[3]);
+            // red[wave][nb][cout n][pixel m]
+            float *r = red + ((wave * NB + nb) * G::MT + j) * RP;
+            if (G::MT == 32) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4 *>(r + 8 * g + 4 * kq) = make_float4(s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]);
+            } else {
+                *reinterpret_cast<float4 *>(r + 4 * kq) = make_float4(s[0], s[1], s[2], s[3]);
+            }
         }
     }
     __syncthreads();
 
-    // one float4 (4 consecutive pixels of one tile and one output channel) per lane and step
-    constexpr int P4 = G::PX / 4;                       // float4 per (tile, channel)
     constexpr int UNITS_NB = G::MT * G::MT / 4;         // float4 units per N sub-block
     constexpr int OUT_UNITS = NB * UNITS_NB;
+    if (NHWC) {
+        // one float4 = 4 consecutive output channels of one pixel per lane and step
+#pragma unroll
+        for (int o = tid; o < OUT_UNITS; o += 256) {
+            const int nb = o / UNITS_NB, o1 = o - nb * UNITS_NB;
+            const int n4 = o1 % (G::MT / 4), m = o1 / (G::MT / 4);
+            const float *r0 = red + (nb * G::MT + m) * RP + 4 * n4;
+            float4 s = *reinterpret_cast<const float4 *>(r0);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float4 v = *reinterpret_cast<const float4 *>(r0 + w * NB * G::MT * RP);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            const int t_l = m / G::PX, pxo = m % G::PX;
+            const int t = mb * G::TPB + t_l, co = (ng * NB + nb) * G::MT + 4 * n4;
+            if (t < a.T && co < a.Cout) {  // (Cout % 4 == 0: host side)
+                if (a.bias) {
+                    const float4 bb = *reinterpret_cast<const float4 *>(a.bias + co);
+                    s.x += bb.x; s.y += bb.y; s.z += bb.z; s.w += bb.w;
+                }
+                if (DST == DST_TILES) {
+                    *reinterpret_cast<float4 *>(a.out + ((size_t)t * G::PX + pxo) * a.Cout + co) = s;
+                } else {
+                    const int b = t / a.N, n = t - b * a.N;
+                    const int h = (a.offH + a.idx[2 * n]) / a.strH + pxo / G::RO, w = (a.offW + a.idx[2 * n + 1]) / a.strW + pxo % G::RO;
+                    if (h >= 0 && h < a.Ho && w >= 0 && w < a.Wo) {
+                        const size_t q = (((size_t)b * a.Ho + h) * a.Wo + w) * a.Cout + co;
+                        if (a.residual) {
+                            const float4 rr = *reinterpret_cast<const float4 *>(a.residual + q);
+                            s.x += rr.x; s.y += rr.y; s.z += rr.z; s.w += rr.w;
+                        }
+                        *reinterpret_cast<float4 *>(a.out + q) = s;
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // NCHW: one float4 (4 consecutive pixels of one tile and one output channel) per lane and step
+    constexpr int P4 = G::PX / 4;                       // float4 per (tile, channel)
 #pragma unroll
     for (int o = tid; o < OUT_UNITS; o += 256) {
         const int nb = o / UNITS_NB, o1 = o - nb * UNITS_NB;
@@ -439,11 +559,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         const int co_l = (o1 / P4) % G::MT;
         const int t_l = o1 / (P4 * G::MT);
         const int rrow = t_l * G::PX + p4 * 4;
-        const float *r0 = red + (nb * G::MT + co_l) * G::RED + rrow;
+        const float *r0 = red + (nb * G::MT + co_l) * RP + rrow;
         float4 s = *reinterpret_cast<const float4 *>(r0);
 #pragma unroll
         for (int w = 1; w < 4; ++w) {
-            const float4 v = *reinterpret_cast<const float4 *>(r0 + w * NB * G::MT * G::RED);
+            const float4 v = *reinterpret_cast<const float4 *>(r0 + w * NB * G::MT * RP);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
         const int t = mb * G::TPB + t_l, co = (ng * NB + nb) * G::MT + co_l;
@@ -493,25 +613,25 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 }
 
 // ---- launch ------------------------------------------------------------------
-template <typename G, int NB, int SRC, int DST>
-void launch_conv_geo(ConvArgs a, int act, hipStream_t st);
+template <typename G, int NB, int SRC, int DST, int LAYOUT>
+void launch_conv_geo(ConvArgs a, int mode, hipStream_t st);
 
 // mode: MODE_* (host side maps (scale, shift, activation) onto it)
-#define SIGE_CONV_LAUNCH3(G, NB, SRC, DST)                                                                \
-    template <> void launch_conv_geo<G, NB, SRC, DST>(ConvArgs a, int mode, hipStream_t st) {             \
+#define SIGE_CONV_LAUNCH3(G, NB, SRC, DST, LAY)                                                           \
+    template <> void launch_conv_geo<G, NB, SRC, DST, LAY>(ConvArgs a, int mode, hipStream_t st) {        \
         const int grid = a.mbk * a.ngk;                                                                   \
-        if (mode == MODE_AFFINE_SWISH) conv_mfma_kernel<G, NB, SRC, MODE_AFFINE_SWISH, DST><<<grid, 256, 0, st>>>(a); \
-        else if (mode == MODE_AFFINE) conv_mfma_kernel<G, NB, SRC, MODE_AFFINE, DST><<<grid, 256, 0, st>>>(a);        \
-        else conv_mfma_kernel<G, NB, SRC, MODE_RAW, DST><<<grid, 256, 0, st>>>(a);                        \
+        if (mode == MODE_AFFINE_SWISH) conv_mfma_kernel<G, NB, SRC, MODE_AFFINE_SWISH, DST, LAY><<<grid, 256, 0, st>>>(a); \
+        else if (mode == MODE_AFFINE) conv_mfma_kernel<G, NB, SRC, MODE_AFFINE, DST, LAY><<<grid, 256, 0, st>>>(a);        \
+        else conv_mfma_kernel<G, NB, SRC, MODE_RAW, DST, LAY><<<grid, 256, 0, st>>>(a);                   \
     }
 
 // explicit-instantiation helper used by the per-geometry translation units
-#define SIGE_CONV_INSTANTIATE(G, NB)                                                                     \
-    template <> void launch_conv_geo<G, NB, SRC_TILES, DST_TILES>(ConvArgs a, int, hipStream_t st) {     \
-        conv_mfma_kernel<G, NB, SRC_TILES, MODE_RAW, DST_TILES><<<a.mbk * a.ngk, 256, 0, st>>>(a);       \
+#define SIGE_CONV_INSTANTIATE(G, NB, LAY)                                                                 \
+    template <> void launch_conv_geo<G, NB, SRC_TILES, DST_TILES, LAY>(ConvArgs a, int, hipStream_t st) { \
+        conv_mfma_kernel<G, NB, SRC_TILES, MODE_RAW, DST_TILES, LAY><<<a.mbk * a.ngk, 256, 0, st>>>(a);   \
     }                                                                                                     \
-    SIGE_CONV_LAUNCH3(G, NB, SRC_GATHER, DST_TILES)                                                       \
-    SIGE_CONV_LAUNCH3(G, NB, SRC_GATHER, DST_NCHW)                                                        \
-    SIGE_CONV_LAUNCH3(G, NB, SRC_SCATTER_GATHER, DST_TILES)
+    SIGE_CONV_LAUNCH3(G, NB, SRC_GATHER, DST_TILES, LAY)                                                  \
+    SIGE_CONV_LAUNCH3(G, NB, SRC_GATHER, DST_NCHW, LAY)                                                   \
+    SIGE_CONV_LAUNCH3(G, NB, SRC_SCATTER_GATHER, DST_TILES, LAY)
 
 }  // namespace sige

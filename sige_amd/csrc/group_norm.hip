@@ -77,6 +77,39 @@ static int gn_splits(size_t group_elems) {
     return (int)s;
 }
 
+// ------------------------------------------------------- GroupNorm affine ----
+// x [B,H,W,C]: per (batch, group) sum / sum of squares over H*W pixels x (C/groups) channels
+__global__ __launch_bounds__(kGNThreads) void gn_partial_nhwc_kernel(const float *__restrict__ x, int C, int HW, int groups, int splits,
+                                                            float *__restrict__ ws) {
+    // grid: (splits, B); block: each lane owns channel quad (tid % C4) of pixels (tid / C4) + k * (kGNThreads / C4) in its slice.
+    // Requires C4 <= kGNThreads and kGNThreads % C4 == 0 (host side) so that a lane's channel quad is fixed.
+    const int b = blockIdx.y, sp = blockIdx.x;
+    const int C4 = C / 4, ppb = kGNThreads / C4;
+    const int cq = threadIdx.x % C4, pl = threadIdx.x / C4;
+    const int per = (HW + splits - 1) / splits;
+    const int lo = sp * per, hi = min(HW, lo + per);
+    float s = 0.f, ss = 0.f;
+    const float *xb = x + (size_t)b * HW * C;
+    for (int p = lo + pl; p < hi; p += ppb) {
+        const float4 v = *reinterpret_cast<const float4 *>(xb + (size_t)p * C + cq * 4);
+        s += (v.x + v.y) + (v.z + v.w);
+        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    // combine the lanes of one group: channels per group cg = C / groups; quads per group = cg / 4 (cg % 4 == 0: host side)
+    __shared__ float sh[2][kGNThreads];
+    sh[0][threadIdx.x] = s; sh[1][threadIdx.x] = ss;
+    __syncthreads();
+    const int qpg = C4 / groups;
+    if (threadIdx.x < groups) {
+        float a0 = 0.f, a1 = 0.f;
+        for (int pp = 0; pp < ppb; ++pp)
+            for (int k = 0; k < qpg; ++k) { a0 += sh[0][pp * C4 + threadIdx.x * qpg + k]; a1 += sh[1][pp * C4 + threadIdx.x * qpg + k]; }
+        float *o = ws + (((size_t)b * groups + threadIdx.x) * splits + sp) * 2;
+        o[0] = a0; o[1] = a1;
+    }
+}
+
+
 }  // namespace sige
 
 using namespace sige;
@@ -101,3 +134,31 @@ extern "C" int sige_hip_group_norm_affine_f32(const float *x, int B, int C, int 
                                                           scale, shift);
     return launch_status();
 }
+
+// ---- channels-last form: x [B,H,W,C] ----
+static int gn_nhwc_splits(int HW) {
+    int s = (HW + 255) / 256;  // ~256 pixels per workgroup
+    return s < 1 ? 1 : (s > 256 ? 256 : s);
+}
+
+extern "C" size_t sige_hip_group_norm_affine_nhwc_workspace(int B, int C, int H, int W, int groups) {
+    if (B <= 0 || C <= 0 || groups <= 0 || C % groups) return 0;
+    return (size_t)B * groups * gn_nhwc_splits(H * W) * 2;
+}
+
+extern "C" int sige_hip_group_norm_affine_nhwc_f32(const float *x, int B, int C, int H, int W, int groups, float eps,
+                                                   const float *gamma, const float *beta, float *workspace,
+                                                   float *scale, float *shift, void *stream) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || groups <= 0 || C % groups) return SIGE_HIP_EINVAL;
+    if (!x || !workspace || !scale || !shift) return SIGE_HIP_EINVAL;
+    const int C4 = C / 4;
+    // one lane per channel quad, whole quads per group, whole pixels per 256-lane block
+    if (C % 4 || (C / groups) % 4 || C4 > kGNThreads || kGNThreads % C4 || groups > kGNThreads || B > 65535 || (reinterpret_cast<uintptr_t>(x) & 15)) return SIGE_HIP_EUNSUPPORTED;
+    const int HW = H * W, splits = gn_nhwc_splits(HW);
+    hipStream_t st = as_stream(stream);
+    gn_partial_nhwc_kernel<<<dim3(splits, B), kGNThreads, 0, st>>>(x, C, HW, groups, splits, workspace);
+    gn_finish_kernel<<<ceil_div(B * C, 256), 256, 0, st>>>(workspace, splits, B, C, groups, (double)(C / groups) * HW, eps,
+                                                          gamma, beta, scale, shift);
+    return launch_status();
+}
+

@@ -1,0 +1,379 @@
+// Channels-last (NHWC) forms of the data-movement ops of the SIGE path for gfx950.
+//
+// The reference keeps every activation NCHW (sige/cpu/gather.cpp:4-58,
+// scatter.cpp:4-68, scatter_gather.cpp:5-56).  A SIGE tile is a 6x6 / 4x4 spatial
+// window over ALL channels; in NCHW that is C x 6 separate 24-byte segments, in
+// NHWC it is 36 runs of C contiguous floats -- every lane below moves 16 bytes
+// (4 channels of one pixel) and a wave covers whole 256-byte+ runs.
+//   full tensors [B,H,W,C] (torch.channels_last), tiles [T,R,S,C], C % 4 == 0.
+// Arithmetic and its order are those of the NCHW kernels (gather.hip, scatter.hip):
+// bit-identical results.
+#include "common.hpp"
+
+namespace sige {
+
+constexpr int kT = 256;
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+
+// per-(batch, channel) affine then activation on 4 consecutive channels; scale, then shift:
+// two separately rounded ops (gather.cpp:33-53; -ffp-contract=off), exact expf / division SiLU
+template <int ACT>
+__device__ __forceinline__ float4 affine_act4(float4 z, const float *scale, const float *shift, int so, int c) {
+    if (scale) { const float4 s = ld4(scale + so + c); z.x = s.x * z.x; z.y = s.y * z.y; z.z = s.z * z.z; z.w = s.w * z.w; }
+    if (shift) { const float4 s = ld4(shift + so + c); z.x = s.x + z.x; z.y = s.y + z.y; z.z = s.z + z.z; z.w = s.w + z.w; }
+    z.x = activate<ACT>(z.x); z.y = activate<ACT>(z.y); z.z = activate<ACT>(z.z); z.w = activate<ACT>(z.w);
+    return z;
+}
+
+// ------------------------------------------------------------------ gather ----
+// x [B,H,W,C] -> out [B*N, bH, bW, C]; scale/shift [1|B, C]
+template <int ACT>
+__global__ __launch_bounds__(kT) void gather_nhwc_kernel(const float *__restrict__ x, int B, int C, int H, int W, int bH, int bW,
+                                                        const int32_t *__restrict__ idx, int N,
+                                                        const float *scale, const float *shift, int aff_sb,
+                                                        float *__restrict__ out, long units) {
+    const int C4 = C / 4, RS = bH * bW;
+    for (long u = (long)blockIdx.x * kT + threadIdx.x; u < units; u += (long)gridDim.x * kT) {
+        const int c = (int)(u % C4) * 4;
+        const long tp = u / C4;
+        const int p = (int)(tp % RS);
+        const int t = (int)(tp / RS);
+        const int b = t / N, n = t - b * N;
+        const int h = idx[2 * n] + p / bW, w = idx[2 * n + 1] + p % bW;
+        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (h >= 0 && h < H && w >= 0 && w < W)
+            z = affine_act4<ACT>(ld4(x + (((size_t)b * H + h) * W + w) * C + c), scale, shift, b * aff_sb, c);
+        st4(out + (size_t)u * 4, z);
+    }
+}
+
+// ---------------------------------------------------------- scatter_gather ----
+// x [B*N, Rx, Sx, C] conv-1 tiles, y [B,H,W,C] cached, map [H,W,3] -> out [B*N, bH, bW, C]
+template <int ACT>
+__global__ __launch_bounds__(kT) void scatter_gather_nhwc_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                                int B, int C, int H, int W, int Rx, int Sx, int bH, int bW,
+                                                                const int32_t *__restrict__ idx, int N,
+                                                                const int32_t *__restrict__ map,
+                                                                const float *scale, const float *shift, int aff_sb,
+                                                                float *__restrict__ out, long units) {
+    const int C4 = C / 4, RS = bH * bW;
+    for (long u = (long)blockIdx.x * kT + threadIdx.x; u < units; u += (long)gridDim.x * kT) {
+        const int c = (int)(u % C4) * 4;
+        const long tp = u / C4;
+        const int p = (int)(tp % RS);
+        const int t = (int)(tp / RS);
+        const int b = t / N, n = t - b * N;
+        const int h = idx[2 * n] + p / bW, w = idx[2 * n + 1] + p % bW;
+        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (h >= 0 && h < H && w >= 0 && w < W) {
+            const int32_t *m = map + 3 * ((size_t)h * W + w);
+            const int blk = m[0];
+            const float *src = blk >= 0 ? x + ((((size_t)b * N + blk) * Rx + m[1]) * Sx + m[2]) * C + c
+                                        : y + (((size_t)b * H + h) * W + w) * C + c;
+            z = affine_act4<ACT>(ld4(src), scale, shift, b * aff_sb, c);
+        }
+        st4(out + (size_t)u * 4, z);
+    }
+}
+
+// ------------------------------------------------------------------ scatter ----
+struct ScatterNhwcArgs {
+    const float *x0, *y0, *x1, *y1, *res;  // main tiles, cached tensor, shortcut tiles, cached shortcut tensor, residual
+    float *out;
+    const int32_t *table0, *table1, *idx0, *idx1;
+    int B, C, H, W;
+    int R0, S0, N0, gW0, offH, offW, strH, strW;
+    int R1, S1, N1, gW1;
+};
+
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+// value of output pixel (b,h,w), channels c..c+3, given the tiles covering it (t0 / t1, -1 = none):
+//   out = y0;  main tile: out = x0 + residual (BLOCK_RES: residual = y1);  shortcut tile: out += x1 - y1
+// (scatter.cpp:4-39 then 41-68, same operation order)
+template <bool BLOCK_RES>
+__device__ __forceinline__ float4 scatter_value(const ScatterNhwcArgs &a, int b, int h, int w, int c, int t0, int t1, size_t q) {
+    float4 v;
+    float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (BLOCK_RES && (t0 >= 0 || t1 >= 0)) r1 = ld4(a.y1 + q);
+    if (t0 >= 0) {
+        v = ld4(a.x0 + ((((size_t)b * a.N0 + t0) * a.R0 + h % a.R0) * a.S0 + w % a.S0) * a.C + c);
+        if (BLOCK_RES) v = add4(r1, v);
+        else if (a.res) v = add4(ld4(a.res + q), v);
+    } else {
+        v = ld4(a.y0 + q);
+    }
+    if (BLOCK_RES && t1 >= 0)
+        v = add4(v, sub4(ld4(a.x1 + ((((size_t)b * a.N1 + t1) * a.R1 + h % a.R1) * a.S1 + w % a.S1) * a.C + c), r1));
+    return v;
+}
+
+// reference semantics: a fresh full tensor, ONE streaming pass (no clone + overwrite)
+template <bool BLOCK_RES>
+__global__ __launch_bounds__(kT) void scatter_full_nhwc_kernel(ScatterNhwcArgs a, long units) {
+    const int C4 = a.C / 4;
+    for (long u = (long)blockIdx.x * kT + threadIdx.x; u < units; u += (long)gridDim.x * kT) {
+        const int c = (int)(u % C4) * 4;
+        const long pix = u / C4;
+        const int w = (int)(pix % a.W);
+        const long bh = pix / a.W;
+        const int h = (int)(bh % a.H), b = (int)(bh / a.H);
+        const int t0 = a.table0[(h / a.R0) * a.gW0 + w / a.S0];
+        const int t1 = BLOCK_RES ? a.table1[(h / a.R1) * a.gW1 + w / a.S1] : -1;
+        st4(a.out + (size_t)u * 4, scatter_value<BLOCK_RES>(a, b, h, w, c, t0, t1, (size_t)u * 4));
+    }
+}
+
+// in-place form: `out` already holds y0 outside the covered pixels (a persistent buffer of the
+// Scatter module); only the pixels under a main tile -- and, BLOCK_RES, under a shortcut tile
+// that no main tile covers -- are written.  Traffic ~ active tiles instead of the full tensor.
+template <bool BLOCK_RES>
+__global__ __launch_bounds__(kT) void scatter_tiles_nhwc_kernel(ScatterNhwcArgs a, long units0, long units) {
+    const int C4 = a.C / 4;
+    for (long u = (long)blockIdx.x * kT + threadIdx.x; u < units; u += (long)gridDim.x * kT) {
+        const bool main = u < units0;
+        const long v = main ? u : u - units0;
+        const int R = main ? a.R0 : a.R1, S = main ? a.S0 : a.S1, N = main ? a.N0 : a.N1;
+        const int c = (int)(v % C4) * 4;
+        const long tp = v / C4;
+        const int p = (int)(tp % (R * S));
+        const int t = (int)(tp / (R * S));
+        const int b = t / N, n = t - b * N;
+        int h, w;
+        if (main) { h = (a.offH + a.idx0[2 * n]) / a.strH + p / S; w = (a.offW + a.idx0[2 * n + 1]) / a.strW + p % S; }
+        else { h = a.idx1[2 * n] + p / S; w = a.idx1[2 * n + 1] + p % S; }
+        if (h < 0 || h >= a.H || w < 0 || w >= a.W) continue;
+        int t0, t1;
+        if (main) { t0 = n; t1 = BLOCK_RES ? a.table1[(h / a.R1) * a.gW1 + w / a.S1] : -1; }
+        else { t1 = n; t0 = a.table0[(h / a.R0) * a.gW0 + w / a.S0]; if (t0 >= 0) continue; }  // a main tile writes this pixel
+        const size_t q = ((((size_t)b * a.H + h) * a.W + w) * a.C) + c;
+        st4(a.out + q, scatter_value<BLOCK_RES>(a, b, h, w, c, t0, t1, q));
+    }
+}
+
+static int grid_for(long units) {
+    long g = (units + kT - 1) / kT;
+    return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+// ---------------------------------------------------------------- attention ----
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// qkv [B,HW,3C] (q | k | v on the channel axis).  S[i][j] = scale * sum_c q[i][c] k[j][c]
+__global__ __launch_bounds__(kT) void attn_scores_nhwc_kernel(const float *__restrict__ qkv, int C, int HW, float scale,
+                                                             float *__restrict__ S) {
+    __shared__ float red[4][16][20];
+    const int b = blockIdx.z;
+    const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int kq = lane >> 4, n = lane & 15;
+    const int C3 = 3 * C, cw = C / 4;  // wave w: channels [w*cw, (w+1)*cw), lane group kq: 4 consecutive channels per step of 16
+    const float *qa = qkv + ((size_t)b * HW + i0 + n) * C3 + wave * cw + kq * 4;       // A[m = query][k]
+    const float *kb = qkv + ((size_t)b * HW + j0 + n) * C3 + C + wave * cw + kq * 4;   // B[k][n = key]
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    // each 16-byte load feeds 4 MFMA k-steps; the k order (kq*4 + e within a block of 16 channels)
+    // is the same for A and B, which is all the contraction needs
+    for (int s = 0; s < cw; s += 16) {
+        const float4 a4 = ld4(qa + s), b4 = ld4(kb + s);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][4 * kq + r][n] = acc0[r] + acc1[r];
+    __syncthreads();
+    const int qi = tid >> 4, kj = tid & 15;
+    const float v = (red[0][qi][kj] + red[1][qi][kj]) + (red[2][qi][kj] + red[3][qi][kj]);
+    S[((size_t)b * HW + i0 + qi) * HW + j0 + kj] = v * scale;
+}
+
+// out[i][c] = sum_j softmax_j(S[i][.])[j] v[j][c]:  A[m = query][k = key] = P (LDS), B[k = key][n = channel] = v (global,
+// 64-byte coalesced per lane group).  Workgroup = 16 queries x 64 channels (one 16x16 tile per wave).
+__global__ __launch_bounds__(kT) void attn_apply_nhwc_kernel(const float *__restrict__ qkv, const float *__restrict__ S,
+                                                            int C, int HW, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float P[];  // [16][HW + 4]
+    const int PS = HW + 4;
+    const int b = blockIdx.z;
+    const int i0 = blockIdx.y * 16, c0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    {
+        const int row = tid >> 4, l16 = tid & 15;
+        const float *srow = S + ((size_t)b * HW + i0 + row) * HW;
+        float m = -INFINITY;
+        for (int j = l16 * 4; j < HW; j += 64) {
+            const float4 t = ld4(srow + j);
+            st4(P + row * PS + j, t);
+            m = fmaxf(fmaxf(m, fmaxf(t.x, t.y)), fmaxf(t.z, t.w));
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
+        float sum = 0.f;
+        for (int j = l16 * 4; j < HW; j += 64) {
+            float4 t = ld4(P + row * PS + j);
+            t.x = expf(t.x - m); t.y = expf(t.y - m); t.z = expf(t.z - m); t.w = expf(t.w - m);
+            sum += (t.x + t.y) + (t.z + t.w);
+            st4(P + row * PS + j, t);
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
+        const float inv = 1.0f / sum;
+        for (int j = l16 * 4; j < HW; j += 64) {
+            float4 t = ld4(P + row * PS + j);
+            t.x *= inv; t.y *= inv; t.z *= inv; t.w *= inv;
+            st4(P + row * PS + j, t);
+        }
+    }
+    __syncthreads();
+    const int kq = lane >> 4, n = lane & 15;
+    const int c = c0 + wave * 16 + n;
+    const bool cok = c < C;
+    const float *vb = qkv + (size_t)b * HW * 3 * C + 2 * C + (cok ? c : 0);
+    const float *pa = P + n * PS + kq;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < HW; j += 8) {
+        const float b0 = vb[(size_t)(j + kq) * 3 * C], b1 = vb[(size_t)(j + 4 + kq) * 3 * C];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[j], b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[j + 4], b1, acc1, 0, 0, 0);
+    }
+    // D[row = query 4*kq + r][col = channel n]
+    if (cok) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[((size_t)b * HW + i0 + 4 * kq + r) * C + c] = acc0[r] + acc1[r];
+    }
+}
+
+}  // namespace sige
+
+using namespace sige;
+
+static bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static bool affine_shape(const float *scale, int sB, int sC, const float *shift, int tB, int tC, int B, int C, int *aff_sb) {
+    *aff_sb = 0;
+    for (int k = 0; k < 2; ++k) {
+        const float *p = k ? shift : scale;
+        const int pb = k ? tB : sB, pc = k ? tC : sC;
+        if (!p) continue;
+        if (!((pb == 1 || pb == B) && pc == C) || !al16(p)) return false;
+        if (pb > 1) *aff_sb = C;
+    }
+    if (scale && shift && sB != tB) return false;
+    return true;
+}
+
+extern "C" int sige_hip_gather_nhwc_f32(const float *x, int B, int C, int H, int W, int bH, int bW,
+                                        const int32_t *active_indices, int N,
+                                        const float *scale, int scaleB, int scaleC,
+                                        const float *shift, int shiftB, int shiftC,
+                                        int activation, float *out, void *stream) {
+    if (B < 0 || C <= 0 || H <= 0 || W <= 0 || bH <= 0 || bW <= 0 || N < 0) return SIGE_HIP_EINVAL;
+    if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
+    if ((long)B * N == 0) return SIGE_HIP_OK;
+    if (!x || !out || !active_indices) return SIGE_HIP_EINVAL;
+    int aff_sb;
+    if (C % 4 || !al16(x) || !al16(out) || !affine_shape(scale, scaleB, scaleC, shift, shiftB, shiftC, B, C, &aff_sb))
+        return SIGE_HIP_EUNSUPPORTED;
+    const long units = (long)B * N * bH * bW * (C / 4);
+    hipStream_t st = as_stream(stream);
+    if (activation == SIGE_HIP_ACT_SWISH)
+        gather_nhwc_kernel<SIGE_HIP_ACT_SWISH><<<grid_for(units), kT, 0, st>>>(x, B, C, H, W, bH, bW, active_indices, N, scale, shift, aff_sb, out, units);
+    else
+        gather_nhwc_kernel<SIGE_HIP_ACT_IDENTITY><<<grid_for(units), kT, 0, st>>>(x, B, C, H, W, bH, bW, active_indices, N, scale, shift, aff_sb, out, units);
+    return launch_status();
+}
+
+extern "C" int sige_hip_scatter_gather_nhwc_f32(const float *x, const float *y, int B, int C, int H, int W,
+                                                int Rx, int Sx, int bH, int bW,
+                                                const int32_t *active_indices, int N, const int32_t *scatter_map,
+                                                const float *scale, int scaleB, int scaleC,
+                                                const float *shift, int shiftB, int shiftC,
+                                                int activation, float *out, void *stream) {
+    if (B < 0 || C <= 0 || H <= 0 || W <= 0 || Rx <= 0 || Sx <= 0 || bH <= 0 || bW <= 0 || N < 0) return SIGE_HIP_EINVAL;
+    if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
+    if ((long)B * N == 0) return SIGE_HIP_OK;
+    if (!x || !y || !out || !active_indices || !scatter_map) return SIGE_HIP_EINVAL;
+    int aff_sb;
+    if (C % 4 || !al16(x) || !al16(y) || !al16(out) || !affine_shape(scale, scaleB, scaleC, shift, shiftB, shiftC, B, C, &aff_sb))
+        return SIGE_HIP_EUNSUPPORTED;
+    const long units = (long)B * N * bH * bW * (C / 4);
+    hipStream_t st = as_stream(stream);
+    if (activation == SIGE_HIP_ACT_SWISH)
+        scatter_gather_nhwc_kernel<SIGE_HIP_ACT_SWISH><<<grid_for(units), kT, 0, st>>>(x, y, B, C, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, shift, aff_sb, out, units);
+    else
+        scatter_gather_nhwc_kernel<SIGE_HIP_ACT_IDENTITY><<<grid_for(units), kT, 0, st>>>(x, y, B, C, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, shift, aff_sb, out, units);
+    return launch_status();
+}
+
+extern "C" int sige_hip_scatter_nhwc_f32(const float *x, const float *y, int B, int C, int H, int W, int R, int S,
+                                         int offsetH, int offsetW, int strideH, int strideW,
+                                         const int32_t *active_indices, const int32_t *table, int gH, int gW, int N,
+                                         const float *residual, int in_place, float *out, void *stream) {
+    if (B < 0 || C <= 0 || H <= 0 || W <= 0 || R <= 0 || S <= 0 || N < 0 || strideH <= 0 || strideW <= 0) return SIGE_HIP_EINVAL;
+    if ((long)B * H * W == 0) return SIGE_HIP_OK;
+    if (!y || !out || (N && (!x || !table || !active_indices))) return SIGE_HIP_EINVAL;
+    if (C % 4 || !al16(x) || !al16(y) || !al16(out) || !al16(residual)) return SIGE_HIP_EUNSUPPORTED;
+    if (gH < (H + R - 1) / R || gW < (W + S - 1) / S) return SIGE_HIP_EINVAL;
+    ScatterNhwcArgs a{};
+    a.x0 = x; a.y0 = y; a.res = residual; a.out = out; a.table0 = table; a.idx0 = active_indices;
+    a.B = B; a.C = C; a.H = H; a.W = W; a.R0 = R; a.S0 = S; a.N0 = N; a.gW0 = gW;
+    a.offH = offsetH; a.offW = offsetW; a.strH = strideH; a.strW = strideW;
+    a.R1 = a.S1 = 1;
+    hipStream_t st = as_stream(stream);
+    if (in_place) {
+        const long units = (long)B * N * R * S * (C / 4);
+        if (units) scatter_tiles_nhwc_kernel<false><<<grid_for(units), kT, 0, st>>>(a, units, units);
+    } else {
+        const long units = (long)B * H * W * (C / 4);
+        scatter_full_nhwc_kernel<false><<<grid_for(units), kT, 0, st>>>(a, units);
+    }
+    return launch_status();
+}
+
+extern "C" int sige_hip_scatter_with_block_residual_nhwc_f32(
+        const float *x0, const float *y0, const float *x1, const float *y1,
+        int B, int C, int H, int W, int R0, int S0, int R1, int S1,
+        int offsetH, int offsetW, int strideH, int strideW,
+        const int32_t *active_indices0, const int32_t *table0, int gH0, int gW0, int N0,
+        const int32_t *active_indices1, const int32_t *table1, int gH1, int gW1, int N1,
+        int in_place, float *out, void *stream) {
+    if (B < 0 || C <= 0 || H <= 0 || W <= 0 || R0 <= 0 || S0 <= 0 || R1 <= 0 || S1 <= 0 || N0 < 0 || N1 < 0) return SIGE_HIP_EINVAL;
+    if (strideH <= 0 || strideW <= 0) return SIGE_HIP_EINVAL;
+    if ((long)B * H * W == 0) return SIGE_HIP_OK;
+    if (!y0 || !y1 || !out || !table0 || !table1 || (N0 && (!x0 || !active_indices0)) || (N1 && (!x1 || !active_indices1)))
+        return SIGE_HIP_EINVAL;
+    if (C % 4 || !al16(x0) || !al16(y0) || !al16(x1) || !al16(y1) || !al16(out)) return SIGE_HIP_EUNSUPPORTED;
+    if (gH0 < (H + R0 - 1) / R0 || gW0 < (W + S0 - 1) / S0 || gH1 < (H + R1 - 1) / R1 || gW1 < (W + S1 - 1) / S1) return SIGE_HIP_EINVAL;
+    ScatterNhwcArgs a{};
+    a.x0 = x0; a.y0 = y0; a.x1 = x1; a.y1 = y1; a.out = out;
+    a.table0 = table0; a.table1 = table1; a.idx0 = active_indices0; a.idx1 = active_indices1;
+    a.B = B; a.C = C; a.H = H; a.W = W;
+    a.R0 = R0; a.S0 = S0; a.N0 = N0; a.gW0 = gW0; a.offH = offsetH; a.offW = offsetW; a.strH = strideH; a.strW = strideW;
+    a.R1 = R1; a.S1 = S1; a.N1 = N1; a.gW1 = gW1;
+    hipStream_t st = as_stream(stream);
+    if (in_place) {
+        const long units0 = (long)B * N0 * R0 * S0 * (C / 4), units = units0 + (long)B * N1 * R1 * S1 * (C / 4);
+        if (units) scatter_tiles_nhwc_kernel<true><<<grid_for(units), kT, 0, st>>>(a, units0, units);
+    } else {
+        const long units = (long)B * H * W * (C / 4);
+        scatter_full_nhwc_kernel<true><<<grid_for(units), kT, 0, st>>>(a, units);
+    }
+    return launch_status();
+}
+
+extern "C" int sige_hip_attention_nhwc_f32(const float *qkv, int B, int C, int HW, float scale, float *workspace,
+                                           float *out, void *stream) {
+    if (B <= 0 || C <= 0 || HW <= 0) return SIGE_HIP_EINVAL;
+    if (!qkv || !workspace || !out) return SIGE_HIP_EINVAL;
+    // 16x16 tiles; 4 waves x 16-channel steps of 16-byte loads; P rows in LDS
+    if (HW % 16 || C % 64 || B > 65535 || !al16(qkv) || !al16(workspace)) return SIGE_HIP_EUNSUPPORTED;
+    const size_t lds = (size_t)16 * (HW + 4) * sizeof(float);
+    if (lds > 64 * 1024) return SIGE_HIP_EUNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    attn_scores_nhwc_kernel<<<dim3(HW / 16, HW / 16, B), kT, 0, st>>>(qkv, C, HW, scale, workspace);
+    attn_apply_nhwc_kernel<<<dim3(ceil_div(C, 64), HW / 16, B), kT, lds, st>>>(qkv, workspace, C, HW, out);
+    return launch_status();
+}

@@ -66,6 +66,25 @@ _SIGNATURES = {
     "sige_hip_attention_workspace": (_c_sz, [_c_int] * 3),
     "sige_hip_attention_f32": (_c_int, [_c_vp, _c_int, _c_int, _c_int, ctypes.c_float, _c_vp, _c_vp, _c_vp]),
     "sige_hip_copy_f32": (_c_int, [_c_vp, _c_vp, _c_sz, _c_vp]),
+    # channels-last forms
+    "sige_hip_block_conv_nhwc_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp, _c_vp]),
+    "sige_hip_gather_conv_nhwc_f32": (
+        _c_int, [_c_vp, _c_vp] + [_c_int] * 7 + [_c_vp, _c_int] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
+        + [_c_int] * 5 + [_c_int, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_vp, _c_vp]),
+    "sige_hip_scatter_gather_conv_nhwc_f32": (
+        _c_int, [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
+        + [_c_int] * 5 + [_c_vp, _c_vp]),
+    "sige_hip_gather_nhwc_f32": (
+        _c_int, [_c_vp] + [_c_int] * 6 + [_c_vp, _c_int] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]),
+    "sige_hip_scatter_gather_nhwc_f32": (
+        _c_int, [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]),
+    "sige_hip_scatter_nhwc_f32": (
+        _c_int, [_c_vp, _c_vp] + [_c_int] * 10 + [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_int, _c_vp, _c_vp]),
+    "sige_hip_scatter_with_block_residual_nhwc_f32": (
+        _c_int, [_c_vp] * 4 + [_c_int] * 12 + [_c_vp, _c_vp, _c_int, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]),
+    "sige_hip_group_norm_affine_nhwc_workspace": (_c_sz, [_c_int] * 5),
+    "sige_hip_group_norm_affine_nhwc_f32": (_c_int, [_c_vp] + [_c_int] * 5 + [ctypes.c_float] + [_c_vp] * 6),
+    "sige_hip_attention_nhwc_f32": (_c_int, [_c_vp, _c_int, _c_int, _c_int, ctypes.c_float, _c_vp, _c_vp, _c_vp]),
 }
 
 EXPORTS = tuple(_SIGNATURES)  # every symbol include/sige_hip.h declares
@@ -471,3 +490,222 @@ def copy_(dst: torch.Tensor, src: torch.Tensor):
     assert dst.numel() == src.numel() and dst.is_contiguous() and src.is_contiguous()
     _check(lib().sige_hip_copy_f32(src.data_ptr(), dst.data_ptr(), src.numel(), _stream(src)), "copy")
     return dst
+
+
+# --------------------------------------------------------------------------
+# Channels-last (NHWC) forms.  Tensors keep their logical [B,C,H,W] / [T,C,R,S]
+# shape and carry torch.channels_last strides; every function returns
+# channels_last tensors.  Arithmetic is that of the NCHW functions above.
+# --------------------------------------------------------------------------
+CL = torch.channels_last
+
+
+def is_cl(t: torch.Tensor) -> bool:
+    """True if `t` is a 4-D tensor stored channels-last (and not also plain contiguous,
+    which happens for C == 1 or H == W == 1: those go down the NCHW path)."""
+    return t.dim() == 4 and t.is_contiguous(memory_format=CL) and not t.is_contiguous()
+
+
+def cl_supported(*channel_counts: int) -> bool:
+    return all(c % 4 == 0 for c in channel_counts)
+
+
+def _req_cl(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError("sige_amd.hip: `%s` must live on the GPU (got %s)" % (name, t.device))
+    if t.dtype != torch.float32:
+        raise NotImplementedError("sige_amd.hip: `%s` must be float32 (got %s)" % (name, t.dtype))
+    if t.dim() != 4:
+        raise NotImplementedError("sige_amd.hip: `%s` must have 4 dims (got %d)" % (name, t.dim()))
+    return t if t.is_contiguous(memory_format=CL) else t.contiguous(memory_format=CL)
+
+
+def _empty_cl(shape, device) -> torch.Tensor:
+    return torch.empty(shape, dtype=torch.float32, device=device, memory_format=CL)
+
+
+def _cvec(t: Optional[torch.Tensor], name: str):
+    """(ptr, B, C) of an optional per-(batch, channel) vector [1|B, C, 1, 1]."""
+    if t is None:
+        return (None, 0, 0), None
+    if t.dim() != 4 or t.shape[2] != 1 or t.shape[3] != 1:
+        raise RuntimeError("sige_amd.hip: `%s` must be [1|B, C, 1, 1] for the channels-last path" % name)
+    t = _req(t, torch.float32, name)
+    return (t.data_ptr(), t.shape[0], t.shape[1]), t
+
+
+def _bias_ptr(bias):
+    return None if bias is None else _req(bias.detach(), torch.float32, "bias", 1).data_ptr()
+
+
+def block_conv_cl(x, packed, bias, Cout: int, kernel: Tuple[int, int], stride: Tuple[int, int]):
+    x = _req_cl(x, "x")
+    T, Cin, R, S = x.shape
+    Ro, So = (R - kernel[0]) // stride[0] + 1, (S - kernel[1]) // stride[1] + 1
+    out = _empty_cl((T, Cout, Ro, So), x.device)
+    status = lib().sige_hip_block_conv_nhwc_f32(x.data_ptr(), T, Cin, R, S, packed.data_ptr(), _bias_ptr(bias), Cout,
+                                                kernel[0], kernel[1], stride[0], stride[1], out.data_ptr(), _stream(x))
+    if status == UNSUPPORTED:
+        return None
+    _check(status, "block_conv_cl")
+    return out
+
+
+def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, activationName: str,
+                   packed, bias, Cout: int, kernel: Tuple[int, int], stride: Tuple[int, int],
+                   full: Optional[dict] = None):
+    """Channels-last gather -> conv.  `full` = dict(offset=(oh, ow), out_res=(Ho, Wo), residual=tensor|None)
+    writes the output tiles straight into a [B,Cout,Ho,Wo] tensor (dense layers).  None if unsupported."""
+    x = _req_cl(x, "x")
+    B, C1, H, W = x.shape
+    C2 = 0
+    if x2 is not None:
+        x2 = _req_cl(x2, "x2")
+        C2 = x2.shape[1]
+    idx = _req(activeIndices, torch.int32, "activeIndices", 2)
+    (sa, s_keep), (ta, t_keep) = _cvec(scale, "scale"), _cvec(shift, "shift")
+    N = idx.shape[0]
+    if full is None:
+        Ro, So = (block[0] - kernel[0]) // stride[0] + 1, (block[1] - kernel[1]) // stride[1] + 1
+        out = _empty_cl((B * N, Cout, Ro, So), x.device)
+        fargs = (0, 0, 0, None, 0, 0)
+    else:
+        Ho, Wo = full["out_res"]
+        out = _empty_cl((B, Cout, Ho, Wo), x.device)
+        r = full.get("residual")
+        if r is not None:
+            r = _req_cl(r, "residual")
+            if tuple(r.shape) != tuple(out.shape):
+                raise RuntimeError("gather_conv_cl: residual %s != output %s" % (tuple(r.shape), tuple(out.shape)))
+        fargs = (1, full["offset"][0], full["offset"][1], None if r is None else r.data_ptr(), Ho, Wo)
+    status = lib().sige_hip_gather_conv_nhwc_f32(
+        x.data_ptr(), None if x2 is None else x2.data_ptr(), B, C1, C2, H, W, block[0], block[1], idx.data_ptr(), N,
+        *sa, *ta, _act(activationName), packed.data_ptr(), _bias_ptr(bias), Cout, kernel[0], kernel[1],
+        stride[0], stride[1], *fargs, out.data_ptr(), _stream(x))
+    if status == UNSUPPORTED:
+        return None
+    _check(status, "gather_conv_cl")
+    return out
+
+
+def scatter_gather_conv_cl(x, y, block: Tuple[int, int], activeIndices, scatterMap, scale, shift, activationName: str,
+                           packed, bias, Cout: int, kernel: Tuple[int, int], stride: Tuple[int, int]):
+    x, y = _req_cl(x, "x"), _req_cl(y, "y")
+    idx = _req(activeIndices, torch.int32, "activeIndices", 2)
+    smap = _req(scatterMap, torch.int32, "scatterMap", 3)
+    (sa, s_keep), (ta, t_keep) = _cvec(scale, "scale"), _cvec(shift, "shift")
+    B, C, H, W = y.shape
+    N = idx.shape[0]
+    Ro, So = (block[0] - kernel[0]) // stride[0] + 1, (block[1] - kernel[1]) // stride[1] + 1
+    out = _empty_cl((B * N, Cout, Ro, So), y.device)
+    status = lib().sige_hip_scatter_gather_conv_nhwc_f32(
+        x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3], block[0], block[1], idx.data_ptr(), N,
+        smap.data_ptr(), *sa, *ta, _act(activationName), packed.data_ptr(), _bias_ptr(bias), Cout, kernel[0], kernel[1],
+        stride[0], stride[1], out.data_ptr(), _stream(y))
+    if status == UNSUPPORTED:
+        return None
+    _check(status, "scatter_gather_conv_cl")
+    return out
+
+
+def gather_cl(x, bSizeH, bSizeW, activeIndices, scale=None, shift=None, activationName="identity"):
+    x = _req_cl(x, "x")
+    idx = _req(activeIndices, torch.int32, "activeIndices", 2)
+    (sa, s_keep), (ta, t_keep) = _cvec(scale, "scale"), _cvec(shift, "shift")
+    B, C, H, W = x.shape
+    N = idx.shape[0]
+    out = _empty_cl((B * N, C, bSizeH, bSizeW), x.device)
+    _check(lib().sige_hip_gather_nhwc_f32(x.data_ptr(), B, C, H, W, bSizeH, bSizeW, idx.data_ptr(), N, *sa, *ta,
+                                          _act(activationName), out.data_ptr(), _stream(x)), "gather_cl")
+    return out
+
+
+def scatter_gather_cl(x, y, bSizeH, bSizeW, activeIndices, scatterMap, scale=None, shift=None,
+                      activationName="identity"):
+    x, y = _req_cl(x, "x"), _req_cl(y, "y")
+    idx = _req(activeIndices, torch.int32, "activeIndices", 2)
+    smap = _req(scatterMap, torch.int32, "scatterMap", 3)
+    (sa, s_keep), (ta, t_keep) = _cvec(scale, "scale"), _cvec(shift, "shift")
+    B, C, H, W = y.shape
+    N = idx.shape[0]
+    out = _empty_cl((B * N, C, bSizeH, bSizeW), y.device)
+    _check(lib().sige_hip_scatter_gather_nhwc_f32(x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3],
+                                                  bSizeH, bSizeW, idx.data_ptr(), N, smap.data_ptr(), *sa, *ta,
+                                                  _act(activationName), out.data_ptr(), _stream(y)), "scatter_gather_cl")
+    return out
+
+
+def scatter_cl(x, y, offset, stride, activeIndices, table, residual=None, out: Optional[torch.Tensor] = None):
+    """Channels-last scatter.  `out=None`: reference semantics (a fresh tensor, one pass).
+    `out=buffer`: in-place form -- `buffer` already equals y outside this mask's tiles; only
+    the covered pixels are written and `buffer` is returned."""
+    x, y = _req_cl(x, "x"), _req_cl(y, "y")
+    idx = _req(activeIndices, torch.int32, "activeIndices", 2)
+    table = _req(table, torch.int32, "table", 2)
+    B, C, H, W = y.shape
+    r = None
+    if residual is not None:
+        if tuple(residual.shape) != tuple(y.shape):
+            raise RuntimeError("scatter_cl: the channels-last path takes a full-size residual")
+        r = _req_cl(residual, "residual")
+    in_place = out is not None
+    if out is None:
+        out = _empty_cl(tuple(y.shape), y.device)
+    _check(lib().sige_hip_scatter_nhwc_f32(x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3],
+                                           offset[0], offset[1], stride[0], stride[1], idx.data_ptr(), table.data_ptr(),
+                                           table.shape[0], table.shape[1], idx.shape[0],
+                                           None if r is None else r.data_ptr(), int(in_place), out.data_ptr(),
+                                           _stream(y)), "scatter_cl")
+    return out
+
+
+def scatter_with_block_residual_cl(x0, y0, x1, y1, offset, stride, idx0, table0, idx1, table1,
+                                   out: Optional[torch.Tensor] = None):
+    x0, y0, x1, y1 = _req_cl(x0, "x0"), _req_cl(y0, "y0"), _req_cl(x1, "x1"), _req_cl(y1, "y1")
+    i0, i1 = _req(idx0, torch.int32, "idx0", 2), _req(idx1, torch.int32, "idx1", 2)
+    t0, t1 = _req(table0, torch.int32, "table0", 2), _req(table1, torch.int32, "table1", 2)
+    B, C, H, W = y0.shape
+    in_place = out is not None
+    if out is None:
+        out = _empty_cl(tuple(y0.shape), y0.device)
+    _check(lib().sige_hip_scatter_with_block_residual_nhwc_f32(
+        x0.data_ptr(), y0.data_ptr(), x1.data_ptr(), y1.data_ptr(), B, C, H, W,
+        x0.shape[2], x0.shape[3], x1.shape[2], x1.shape[3], offset[0], offset[1], stride[0], stride[1],
+        i0.data_ptr(), t0.data_ptr(), t0.shape[0], t0.shape[1], i0.shape[0],
+        i1.data_ptr(), t1.data_ptr(), t1.shape[0], t1.shape[1], i1.shape[0],
+        int(in_place), out.data_ptr(), _stream(y0)), "scatter_with_block_residual_cl")
+    return out
+
+
+def group_norm_affine_cl(x, groups: int, eps: float, gamma=None, beta=None):
+    """Channels-last GroupNorm statistics -> (scale, shift) [B,C,1,1]; None if the shape has no kernel."""
+    x = _req_cl(x, "x")
+    B, C, H, W = x.shape
+    n = int(lib().sige_hip_group_norm_affine_nhwc_workspace(B, C, H, W, groups))
+    if n == 0:
+        return None
+    buf = torch.empty(n + 2 * B * C, dtype=torch.float32, device=x.device)
+    scale, shift = buf[n:n + B * C].view(B, C, 1, 1), buf[n + B * C:].view(B, C, 1, 1)
+    ga = None if gamma is None else _req(gamma.detach(), torch.float32, "gamma", 1).data_ptr()
+    be = None if beta is None else _req(beta.detach(), torch.float32, "beta", 1).data_ptr()
+    status = lib().sige_hip_group_norm_affine_nhwc_f32(x.data_ptr(), B, C, H, W, groups, eps, ga, be, buf.data_ptr(),
+                                                       scale.data_ptr(), shift.data_ptr(), _stream(x))
+    if status == UNSUPPORTED:
+        return None
+    _check(status, "group_norm_affine_cl")
+    return scale, shift
+
+
+def attention_cl(qkv: torch.Tensor, scale: float):
+    """Channels-last attention: qkv [B,3C,H,W] stored [B,H,W,3C] -> [B,C,H,W] channels-last; None if unsupported."""
+    qkv = _req_cl(qkv, "qkv")
+    B, C3, H, W = qkv.shape
+    C, HW = C3 // 3, H * W
+    ws = torch.empty(B * HW * HW, dtype=torch.float32, device=qkv.device)
+    out = _empty_cl((B, C, H, W), qkv.device)
+    status = lib().sige_hip_attention_nhwc_f32(qkv.data_ptr(), B, C, HW, float(scale), ws.data_ptr(), out.data_ptr(),
+                                               _stream(qkv))
+    if status == UNSUPPORTED:
+        return None
+    _check(status, "attention_cl")
+    return out

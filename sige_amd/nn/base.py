@@ -155,16 +155,26 @@ class SIGEConv2d(nn.Conv2d, SIGEModule):
         if packed is not None and spec is not None:
             # the producer of the tiles has not run: fuse it into the conv's prologue
             common = (packed, self.bias, self.out_channels, self.kernel_size, self.stride)
+            cl = spec.get("cl", False) and self.out_channels % 4 == 0
             if spec["kind"] == "gather":
-                out = hip.gather_conv(spec["x"], spec["block"], spec["idx"], spec["scale"], spec["shift"],
-                                      spec["act"], *common)
+                if cl:
+                    out = hip.gather_conv_cl(spec["x"], spec.get("x2"), spec["block"], spec["idx"], spec["scale"],
+                                             spec["shift"], spec["act"], *common)
+                else:
+                    out = hip.gather_conv(spec["x"], spec["block"], spec["idx"], spec["scale"], spec["shift"],
+                                          spec["act"], *common)
             else:
-                out = hip.scatter_gather_conv(spec["x"], spec["y"], spec["block"], spec["idx"], spec["map"],
-                                              spec["scale"], spec["shift"], spec["act"], *common)
+                f = hip.scatter_gather_conv_cl if cl else hip.scatter_gather_conv
+                out = f(spec["x"], spec["y"], spec["block"], spec["idx"], spec["map"], spec["scale"], spec["shift"],
+                        spec["act"], *common)
             if out is not None:
                 return out  # (None: shape outside the fused kernel's limits -> two-kernel form below)
         x = deferred.resolve(x)
         if packed is not None:
+            if hip.is_cl(x) and x.shape[1] % 4 == 0 and self.out_channels % 4 == 0:
+                out = hip.block_conv_cl(x, packed, self.bias, self.out_channels, self.kernel_size, self.stride)
+                if out is not None:
+                    return out
             return hip.block_conv(x, packed, self.bias, self.out_channels, self.kernel_size, self.stride)
         return hip.block_conv_direct(x, self.weight, self.bias, self.stride, self.groups)
 
@@ -215,3 +225,13 @@ class SIGEModel(nn.Module):
     def set_sparse_update(self, sparse_update: bool):
         for module in self._sige_modules():
             module.set_sparse_update(sparse_update)
+
+    def set_scatter_inplace(self, inplace: bool):
+        """MI355X-first option (not in the reference): Scatter / ScatterWithBlockResidual modules whose
+        cache is channels-last keep a persistent output buffer and write only the covered pixels into
+        it, instead of producing a fresh clone of the cached tensor per call (sige/cpu/scatter.cpp:83).
+        Values are identical; the returned tensor is only valid until the module's next forward and
+        must not be modified in place by the caller."""
+        for module in self._sige_modules():
+            if hasattr(module, "inplace"):
+                module.inplace = inplace

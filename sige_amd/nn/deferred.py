@@ -117,3 +117,26 @@ def defer_ok(x: torch.Tensor, scale, shift, activation_first: bool, sparse_updat
         if t.dim() != 4 or t.shape[2] != 1 or t.shape[3] != 1:
             return False
     return tuple(scale.shape) == tuple(shift.shape)
+
+
+def channels_last_ok(x: torch.Tensor, scale=None, shift=None, activation_first: bool = False) -> bool:
+    """Take the channels-last (NHWC) kernels for this gather?  `x` must be a GPU tensor stored
+    channels-last with C % 4 == 0, and the affine per-(batch, channel)."""
+    if not x.is_cuda or x.dtype != torch.float32 or activation_first:
+        return False
+    from .. import hip
+
+    if not (hip.is_cl(x) and x.shape[1] % 4 == 0):
+        return False
+    for t in (scale, shift):
+        if t is not None and (t.dim() != 4 or t.shape[1] != x.shape[1] or t.shape[2] != 1 or t.shape[3] != 1):
+            return False
+    return True
+
+
+def keep_layout(x: torch.Tensor) -> torch.Tensor:
+    """Dense copy-free view of `x` for the cache: channels-last tensors stay channels-last,
+    everything else becomes plain contiguous (what the reference stores)."""
+    if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last):
+        return x
+    return x.contiguous()

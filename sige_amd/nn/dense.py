@@ -72,6 +72,12 @@ def fused_conv2d(conv: nn.Conv2d, x: torch.Tensor, scale: Optional[torch.Tensor]
         else:
             Ho, Wo = H, W
         idx = hip.all_tiles(H, W, out_tile, conv.stride, offset, x.device)
+        if hip.is_cl(x) and hip.cl_supported(x.shape[1], 0 if x2 is None else x2.shape[1], conv.out_channels):
+            out = hip.gather_conv_cl(x, x2, block, idx, scale, shift, activation_name, _packed(conv, block), conv.bias,
+                                     conv.out_channels, conv.kernel_size, conv.stride,
+                                     full=dict(offset=offset, out_res=(Ho, Wo), residual=residual))
+            if out is not None:
+                return out
         return hip.gather_conv_nchw(x.contiguous(), None if x2 is None else x2.contiguous(), block, idx,
                                     scale, shift, activation_name, _packed(conv, block), conv.bias,
                                     conv.out_channels, conv.kernel_size, conv.stride, offset, (Ho, Wo),
@@ -93,6 +99,10 @@ def group_norm_affine(x: torch.Tensor, norm: nn.GroupNorm) -> Tuple[torch.Tensor
     if x.is_cuda and x.dtype == torch.float32:
         from .. import hip
 
+        if hip.is_cl(x):
+            r = hip.group_norm_affine_cl(x, norm.num_groups, norm.eps, norm.weight, norm.bias)
+            if r is not None:
+                return r
         return hip.group_norm_affine(x, norm.num_groups, norm.eps, norm.weight, norm.bias)
     B, C = x.shape[:2]
     g = norm.num_groups

@@ -65,7 +65,11 @@ class Gather(SIGEModule):
         self.check_dim(x, scale, shift)
         if self.mode == "sparse":
             fn = self.native(self.runtime, x)
-            x = deferred.resolve(x).contiguous()
+            x = deferred.resolve(x)
+            # channels-last activations stay channels-last (16-byte coalesced tile gathers)
+            cl = deferred.channels_last_ok(x, scale, shift, self.activation_first)
+            if not cl:
+                x = x.contiguous()
             idx = self.indices_on(x.device)
             scale = None if scale is None else scale.contiguous()
             shift = None if shift is None else shift.contiguous()
@@ -73,6 +77,10 @@ class Gather(SIGEModule):
             act, first = self.activation_name, self.activation_first
 
             def run():
+                if cl:
+                    from .. import hip
+
+                    return hip.gather_cl(x, bh, bw, idx, scale, shift, act)
                 return fn(x, bh, bw, idx, scale, shift, act, first)
 
             if deferred.defer_ok(x, scale, shift, first, self.sparse_update, act):
@@ -80,7 +88,7 @@ class Gather(SIGEModule):
                 # any other consumer materialises it through the gather kernel
                 return deferred.DeferredTiles(
                     (x.shape[0] * idx.shape[0], x.shape[1], bh, bw), x.dtype, x.device, run,
-                    dict(kind="gather", x=x, block=(bh, bw), idx=idx, scale=scale, shift=shift, act=act))
+                    dict(kind="gather", x=x, block=(bh, bw), idx=idx, scale=scale, shift=shift, act=act, cl=cl))
             return run()
         if self.mode == "full":
             self.input_res = x.shape[2:]

@@ -22,6 +22,48 @@ def _fused_ok(x: torch.Tensor) -> bool:
     return x.is_cuda
 
 
+def hip_is_cl(t: torch.Tensor) -> bool:
+    from .. import hip
+
+    return hip.is_cl(t)
+
+
+def _cl_ok(cached: torch.Tensor, *others) -> bool:
+    """Channels-last kernels: a channels-last cache with C % 4 == 0 and full-size operands."""
+    if not cached.is_cuda or cached.dtype != torch.float32:
+        return False
+    from .. import hip
+
+    if not (hip.is_cl(cached) and cached.shape[1] % 4 == 0):
+        return False
+    return all(o is None or tuple(o.shape) == tuple(cached.shape) for o in others)
+
+
+class _OutputBuffers:
+    """Persistent outputs of a Scatter module for the in-place mode (SIGEModel.set_scatter_inplace).
+
+    The reference returns `y.clone()` with the tiles written over it (sige/cpu/scatter.cpp:83):
+    two full-tensor passes per call although only the tiles change.  With 288 GB of HBM the
+    module keeps, per cache id, one buffer that already equals the cached tensor outside the
+    current mask's tiles; a forward then writes the covered pixels only.  The buffer is rebuilt
+    (one copy) whenever the cache or the mask changes.  The caller must not modify the returned
+    tensor in place, and it is only valid until the module's next forward."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, cache_id, cached: torch.Tensor, stamp):
+        entry = self.bufs.get(cache_id)
+        key = (stamp, cached.data_ptr(), cached._version, tuple(cached.shape))
+        if entry is None or entry[0] != key:
+            entry = (key, cached.clone(memory_format=torch.preserve_format))
+            self.bufs[cache_id] = entry
+        return entry[1]
+
+    def clear(self):
+        self.bufs = {}
+
+
 class Scatter(SIGEModule):
     def __init__(self, gather: Gather):
         super(Scatter, self).__init__()
@@ -30,9 +72,12 @@ class Scatter(SIGEModule):
         self.load_runtime("scatter")
         self.output_res = None
         self.original_outputs = {}
+        self.inplace = False
+        self._out_bufs = _OutputBuffers()
 
     def clear_cache(self):
         self.original_outputs = {}
+        self._out_bufs.clear()
 
     def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         self.check_dtype(x, residual)
@@ -41,7 +86,13 @@ class Scatter(SIGEModule):
             x = deferred.resolve(x)
             g: Gather = self.gather.module
             cached = self.original_outputs[self.cache_id]
-            if _fused_ok(x):
+            if _cl_ok(cached, residual):
+                from .. import hip
+
+                out = self._out_bufs.get(self.cache_id, cached, g.timestamp) if (self.inplace and not self.sparse_update) else None
+                output = hip.scatter_cl(x, cached, g.offset, g.model_stride, g.indices_on(x.device),
+                                        g.tile_table(cached.shape[2:], x.device), residual, out=out)
+            elif _fused_ok(x):
                 from .. import hip
 
                 output = hip.scatter_fused(
@@ -58,7 +109,7 @@ class Scatter(SIGEModule):
         if self.mode == "full":
             output = x if residual is None else x + residual
             self.output_res = output.shape[2:]
-            self.original_outputs[self.cache_id] = output.contiguous()
+            self.original_outputs[self.cache_id] = deferred.keep_layout(output)
             return output
         if self.mode == "profile":
             c = x.shape[1]
@@ -84,10 +135,13 @@ class ScatterWithBlockResidual(SIGEModule):
         self.output_res = None
         self.original_outputs = {}
         self.original_residuals = {}
+        self.inplace = False
+        self._out_bufs = _OutputBuffers()
 
     def clear_cache(self):
         self.original_outputs = {}
         self.original_residuals = {}
+        self._out_bufs.clear()
 
     def forward(self, x: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
         self.check_dtype(x, residual)
@@ -99,7 +153,15 @@ class ScatterWithBlockResidual(SIGEModule):
             y0 = self.original_outputs[self.cache_id]
             y1 = self.original_residuals[self.cache_id]
             res = y0.shape[2:]
-            if _fused_ok(x):
+            if _cl_ok(y0, y1) and hip_is_cl(y1):
+                from .. import hip
+
+                out = self._out_bufs.get(self.cache_id, y0, (mg.timestamp, sg.timestamp)) \
+                    if (self.inplace and not self.sparse_update) else None
+                output = hip.scatter_with_block_residual_cl(
+                    x, y0, residual, y1, mg.offset, mg.model_stride, mg.indices_on(x.device), mg.tile_table(res, x.device),
+                    sg.indices_on(x.device), sg.tile_table(res, x.device), out=out)
+            elif _fused_ok(x):
                 from .. import hip
 
                 output = hip.scatter_with_block_residual_fused(
@@ -128,8 +190,11 @@ class ScatterWithBlockResidual(SIGEModule):
         if self.mode == "full":
             output = x + residual
             self.output_res = output.shape[2:]
-            self.original_outputs[self.cache_id] = output.contiguous()
-            self.original_residuals[self.cache_id] = residual.contiguous()
+            self.original_outputs[self.cache_id] = deferred.keep_layout(output)
+            cl = self.original_outputs[self.cache_id].is_contiguous(memory_format=torch.channels_last)
+            self.original_residuals[self.cache_id] = (
+                residual.contiguous(memory_format=torch.channels_last) if cl and not residual.is_contiguous()
+                else deferred.keep_layout(residual))
             return output
         if self.mode == "profile":
             c = x.shape[1]

@@ -63,7 +63,10 @@ class ScatterGather(SIGEModule):
         if self.mode == "sparse":
             cached = self.original_outputs[self.cache_id]
             fn = self.native(self.runtime, x)
-            x = deferred.resolve(x).contiguous()
+            x = deferred.resolve(x)
+            # the cache decides the layout: channels-last cache -> channels-last tiles
+            cl = deferred.channels_last_ok(cached, scale, shift, self.activation_first)
+            x = x.contiguous(memory_format=torch.channels_last) if cl else x.contiguous()
             idx, smap = g.indices_on(x.device), self._map_on(x.device)
             scale = None if scale is None else scale.contiguous()
             shift = None if shift is None else shift.contiguous()
@@ -71,13 +74,17 @@ class ScatterGather(SIGEModule):
             act, first = self.activation_name, self.activation_first
 
             def run():
+                if cl:
+                    from .. import hip
+
+                    return hip.scatter_gather_cl(x, cached, bh, bw, idx, smap, scale, shift, act)
                 return fn(x, cached.contiguous(), bh, bw, idx, smap, scale, shift, act, first)
 
             if deferred.defer_ok(x, scale, shift, first, self.sparse_update, act):
                 return deferred.DeferredTiles(
                     (cached.shape[0] * idx.shape[0], x.shape[1], bh, bw), x.dtype, x.device, run,
                     dict(kind="scatter_gather", x=x, y=cached, block=(bh, bw), idx=idx, map=smap, scale=scale,
-                         shift=shift, act=act))
+                         shift=shift, act=act, cl=cl))
             output = run()
             if self.sparse_update:
                 if x.is_cuda:
@@ -92,7 +99,7 @@ class ScatterGather(SIGEModule):
             return output
         if self.mode == "full":
             self.output_res = x.shape[2:]
-            self.original_outputs[self.cache_id] = x.contiguous()
+            self.original_outputs[self.cache_id] = deferred.keep_layout(x)
             return x
         if self.mode == "profile":
             c = x.shape[1]

@@ -70,7 +70,12 @@ def pack_caches(model: torch.nn.Module) -> torch.Tensor:
         t = _get(s)
         if t.dtype != torch.float32:
             raise NotImplementedError("cache tensors are fp32 (got %s)" % t.dtype)
-        view = flat[off:off + t.numel()].view(t.shape)
+        if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous():
+            # keep channels-last caches channels-last: an NHWC block of the flat buffer seen as [B,C,H,W]
+            b, c, h, w = t.shape
+            view = flat[off:off + t.numel()].view(b, h, w, c).permute(0, 3, 1, 2)
+        else:
+            view = flat[off:off + t.numel()].view(t.shape)
         view.copy_(t)
         _set(s, view)
         off += size

@@ -221,6 +221,10 @@ class AttnBlock(SIGEModule):
         if qkv.is_cuda and qkv.dtype == torch.float32:
             from .. import hip
 
+            if hip.is_cl(qkv):
+                out = hip.attention_cl(qkv, self.ch ** -0.5)
+                if out is not None:
+                    return out
             if hip.attention_supported(self.ch, hh * ww):
                 return hip.attention(qkv, self.ch ** -0.5)
         q, k, v = qkv.reshape(b, 3, self.ch, hh * ww).unbind(1)
@@ -355,7 +359,10 @@ class DDPMSparseUNet(SIGEModel):
         temb = self._temb(t)
         nxt = (lambda: temb.pop(0)) if temb is not None else (lambda: None)
 
-        hs = [self.conv_in(x)]
+        h0 = self.conv_in(x)
+        if x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous():
+            h0 = h0.contiguous(memory_format=torch.channels_last)  # (MIOpen may hand back NCHW for 3 input channels)
+        hs = [h0]
         for lvl, stage in enumerate(self.down):
             for i, block in enumerate(stage.block):
                 h = block(hs[-1], nxt())

@@ -1,0 +1,199 @@
+"""GPU parity of the channels-last (NHWC) entry points against the NCHW ones (which
+tests/test_gpu_parity.py pins to the oracle and the golden vectors): same values in,
+same values out -- bit for bit for the data-movement ops, 1e-5 for the convs."""
+import pytest
+import torch
+
+from tests import util  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda")
+CL = torch.channels_last
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from sige_amd import hip as h
+
+    h.lib()
+    return h
+
+
+def _mask(res, ratio=0.2):
+    side = int(round((ratio ** 0.5) * res))
+    m = torch.zeros(res, res, dtype=torch.bool)
+    m[res // 3:res // 3 + side, res // 4:res // 4 + side] = True
+    m[0, 0] = m[res - 1, res - 1] = True
+    return m.to(DEV)
+
+
+def _cl(t):
+    return t.contiguous(memory_format=CL)
+
+
+@pytest.mark.parametrize("B,C,res,blk,off", [(1, 128, 64, 6, 1), (2, 40, 48, 4, 0), (1, 64, 32, 5, 0)])
+@pytest.mark.parametrize("act,aff", [("swish", "bc"), ("identity", "c"), ("identity", None)])
+def test_gather_and_scatter_gather_cl(hip, B, C, res, blk, off, act, aff):
+    from sige_amd.utils import reduce_mask
+
+    torch.manual_seed(B + C + res)
+    x, y = torch.randn(B, C, res, res, device=DEV), torch.randn(B, C, res, res, device=DEV)
+    idx = reduce_mask(_mask(res), blk, 4, off)
+    sc = sh = None
+    if aff:
+        shp = (B if aff == "bc" else 1, C, 1, 1)
+        sc, sh = torch.randn(*shp, device=DEV), torch.randn(*shp, device=DEV)
+    want = hip.gather(x, blk, blk, idx, sc, sh, act, False)
+    got = hip.gather_cl(_cl(x), blk, blk, idx, sc, sh, act)
+    assert hip.is_cl(got)
+    assert torch.equal(got.contiguous(), want)
+    if blk == 6:
+        smap = hip.get_scatter_map(res, res, 6, 6, 3, 3, 1, 1, 1, 1, idx)
+        t4 = torch.randn(B * idx.shape[0], C, 4, 4, device=DEV)
+        want = hip.scatter_gather(t4, y, 6, 6, idx, smap, sc, sh, act, False)
+        got = hip.scatter_gather_cl(_cl(t4), _cl(y), 6, 6, idx, smap, sc, sh, act)
+        assert torch.equal(got.contiguous(), want)
+
+
+@pytest.mark.parametrize("B,C,res", [(1, 128, 64), (2, 36, 52)])
+def test_scatter_cl_full_and_in_place(hip, B, C, res):
+    from sige_amd.utils import reduce_mask
+
+    torch.manual_seed(C)
+    mask = _mask(res)
+    idx0, idx1 = reduce_mask(mask, 6, 4, 1), reduce_mask(mask, 4, 4, 0)
+    n0, n1 = idx0.shape[0], idx1.shape[0]
+    x0, x1 = torch.randn(B * n0, C, 4, 4, device=DEV), torch.randn(B * n1, C, 4, 4, device=DEV)
+    y0, y1, res_t = (torch.randn(B, C, res, res, device=DEV) for _ in range(3))
+    t0 = hip.tile_table(idx0, (1, 1), (1, 1), (4, 4), (res, res))
+    t1 = hip.tile_table(idx1, (0, 0), (1, 1), (4, 4), (res, res))
+    for residual in (None, res_t):
+        want = hip.scatter_fused(x0, y0, t0, n0, residual)
+        got = hip.scatter_cl(_cl(x0), _cl(y0), (1, 1), (1, 1), idx0, t0, None if residual is None else _cl(residual))
+        assert hip.is_cl(got) and torch.equal(got.contiguous(), want)
+        buf = _cl(y0).clone(memory_format=torch.preserve_format)
+        out = hip.scatter_cl(_cl(x0), _cl(y0), (1, 1), (1, 1), idx0, t0, None if residual is None else _cl(residual), out=buf)
+        assert out.data_ptr() == buf.data_ptr() and torch.equal(out.contiguous(), want)
+    want = hip.scatter_with_block_residual_fused(x0, y0, x1, y1, t0, n0, t1, n1)
+    got = hip.scatter_with_block_residual_cl(_cl(x0), _cl(y0), _cl(x1), _cl(y1), (1, 1), (1, 1), idx0, t0, idx1, t1)
+    assert torch.equal(got.contiguous(), want)
+    buf = _cl(y0).clone(memory_format=torch.preserve_format)
+    out = hip.scatter_with_block_residual_cl(_cl(x0), _cl(y0), _cl(x1), _cl(y1), (1, 1), (1, 1), idx0, t0, idx1, t1, out=buf)
+    assert torch.equal(out.contiguous(), want)
+    # a second in-place call with other tiles on the same mask overwrites exactly the covered pixels
+    x0b = torch.randn_like(x0)
+    want = hip.scatter_with_block_residual_fused(x0b, y0, x1, y1, t0, n0, t1, n1)
+    out = hip.scatter_with_block_residual_cl(_cl(x0b), _cl(y0), _cl(x1), _cl(y1), (1, 1), (1, 1), idx0, t0, idx1, t1, out=buf)
+    assert torch.equal(out.contiguous(), want)
+
+
+@pytest.mark.parametrize("mt,nb", [(0, 0), (16, 1), (16, 2), (32, 1), (32, 2)])
+@pytest.mark.parametrize("cin,c2,cout,k,stride,blk,off", [(128, 0, 128, 3, 1, 6, 1), (64, 40, 200, 3, 1, 6, 1), (96, 0, 64, 1, 1, 4, 0),
+                                                          (256, 44, 40, 1, 1, 4, 0), (64, 0, 72, 3, 2, 5, 0), (68, 0, 24, 3, 1, 6, 1)])
+def test_conv_cl_vs_nchw(hip, mt, nb, cin, c2, cout, k, stride, blk, off):
+    from sige_amd.utils import reduce_mask
+
+    torch.manual_seed(cin + cout + mt + nb)
+    B, res = 2, 48
+    C = cin + c2
+    x, y = torch.randn(B, C, res, res, device=DEV), torch.randn(B, C, res, res, device=DEV)
+    w = torch.randn(cout, C, k, k, device=DEV) / (k * C ** 0.5)
+    bias = torch.randn(cout, device=DEV)
+    scale, shift = torch.randn(1, C, 1, 1, device=DEV), torch.randn(1, C, 1, 1, device=DEV)
+    idx = reduce_mask(_mask(res), blk, 4, off)
+    packed = hip.conv_pack_weights(w, blk, blk, (stride, stride))
+    conv = lambda t: torch.nn.functional.conv2d(t.double(), w.double(), bias.double(), stride).float()  # noqa: E731
+    hip.conv_force_tile(mt, nb)
+    try:
+        for act, sc, sh in (("swish", scale, shift), ("identity", scale, shift), ("identity", None, None)):
+            tiles = hip.gather(x, blk, blk, idx, sc, sh, act, False)
+            want = conv(tiles)
+            got = hip.block_conv_cl(_cl(tiles), packed, bias, cout, (k, k), (stride, stride))
+            assert hip.is_cl(got)
+            torch.testing.assert_close(got.contiguous(), want, rtol=0, atol=1e-4)
+            got = hip.gather_conv_cl(_cl(x), None, (blk, blk), idx, sc, sh, act, packed, bias, cout, (k, k), (stride, stride))
+            torch.testing.assert_close(got.contiguous(), want, rtol=0, atol=1e-4)
+            if c2:  # channels from two tensors, straight into a full tensor (per image)
+                ho = res if stride == 1 else res // 2
+                o = 4 if stride == 1 else 2
+                t_out = want.reshape(B, idx.shape[0], cout, o, o)
+                for b in range(B):
+                    residual = torch.randn(1, cout, ho, ho, device=DEV)
+                    out = hip.gather_conv_cl(_cl(x[b:b + 1, :cin]), _cl(x[b:b + 1, cin:]), (blk, blk), idx, sc, sh, act, packed, bias,
+                                             cout, (k, k), (stride, stride),
+                                             full=dict(offset=(off, off), out_res=(ho, ho), residual=_cl(residual)))
+                    assert out is not None and hip.is_cl(out)
+                    for n in (0, idx.shape[0] // 2, idx.shape[0] - 1):
+                        h0, w0 = (int(idx[n, 0]) + off) // stride, (int(idx[n, 1]) + off) // stride
+                        h1, w1 = min(h0 + o, ho), min(w0 + o, ho)
+                        exp = t_out[b, n][:, :h1 - h0, :w1 - w0] + residual[0, :, h0:h1, w0:w1]
+                        torch.testing.assert_close(out[0, :, h0:h1, w0:w1], exp, rtol=0, atol=1e-4)
+            if k == 3 and stride == 1:
+                smap = hip.get_scatter_map(res, res, 6, 6, 3, 3, 1, 1, 1, 1, idx)
+                t4 = torch.randn(B * idx.shape[0], C, 4, 4, device=DEV)
+                sg = hip.scatter_gather(t4, y, 6, 6, idx, smap, sc, sh, act, False)
+                got = hip.scatter_gather_conv_cl(_cl(t4), _cl(y), (6, 6), idx, smap, sc, sh, act, packed, bias, cout, (3, 3), (1, 1))
+                torch.testing.assert_close(got.contiguous(), conv(sg), rtol=0, atol=1e-4)
+    finally:
+        hip.conv_force_tile(0, 0)
+
+
+@pytest.mark.parametrize("shape,groups", [((1, 128, 256, 256), 32), ((2, 64, 17, 23), 16), ((1, 512, 8, 8), 32)])
+def test_group_norm_affine_cl(hip, shape, groups):
+    torch.manual_seed(shape[1])
+    x = torch.randn(*shape, device=DEV) * 3 + 1.5
+    gamma, beta = torch.randn(shape[1], device=DEV), torch.randn(shape[1], device=DEV)
+    r = hip.group_norm_affine_cl(_cl(x), groups, 1e-6, gamma, beta)
+    assert r is not None
+    scale, shift = r
+    want = torch.nn.functional.group_norm(x.double(), groups, gamma.double(), beta.double(), 1e-6).float()
+    torch.testing.assert_close(x * scale + shift, want, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,C,hw", [(1, 512, 16), (1, 512, 8), (2, 64, 12)])
+def test_attention_cl(hip, B, C, hw):
+    torch.manual_seed(C + hw)
+    qkv = torch.randn(B, 3 * C, hw, hw, device=DEV)
+    got = hip.attention_cl(_cl(qkv), C ** -0.5)
+    assert got is not None and hip.is_cl(got)
+    q, k, v = qkv.double().reshape(B, 3, C, hw * hw).unbind(1)
+    attn = torch.softmax(torch.bmm(q.transpose(1, 2), k) * (C ** -0.5), dim=2)
+    want = torch.bmm(v, attn.transpose(1, 2)).reshape(B, C, hw, hw).float()
+    torch.testing.assert_close(got.contiguous(), want, rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("inplace", [False, True])
+def test_ddpm_unet_channels_last_equals_nchw(inplace):
+    """Model level: the DDPM-256 workload run channels-last (and with the persistent in-place
+    scatter buffers) gives the NCHW run's sparse output, for two different edits on one mask."""
+    from sige_amd.utils import dilate_mask, downsample_mask
+    from sige_amd.workloads.ddpm_unet import DDPMConfig, DDPMSparseUNet
+
+    torch.manual_seed(0)
+    model = DDPMSparseUNet(DDPMConfig(ch=32)).to(DEV).eval()
+    x0 = torch.randn(1, 3, 256, 256, device=DEV)
+    mask = torch.zeros(256, 256, dtype=torch.bool, device=DEV)
+    mask[100:140, 90:150] = True
+    edits = [x0 + torch.randn(1, 3, 256, 256, device=DEV) * mask for _ in range(2)]
+    t = torch.zeros(1, device=DEV)
+    masks = downsample_mask(dilate_mask(mask, 5), 8)
+    outs = {}
+    with torch.no_grad():
+        for layout in ("nchw", "nhwc"):
+            fmt = torch.channels_last if layout == "nhwc" else torch.contiguous_format
+            model.to(memory_format=fmt)
+            model.clear_cache()
+            model.set_scatter_inplace(inplace and layout == "nhwc")
+            model.set_mode("full")
+            model(x0.contiguous(memory_format=fmt), t)
+            model.set_masks(masks)
+            model.set_mode("sparse")
+            outs[layout] = [model(e.contiguous(memory_format=fmt), t).contiguous().clone() for e in edits]
+            if layout == "nhwc":  # again, first edit: the in-place buffers must not remember the second one
+                again = model(edits[0].contiguous(memory_format=fmt), t).contiguous()
+                torch.testing.assert_close(again, outs[layout][0], rtol=0, atol=0)
+        model.to(memory_format=torch.contiguous_format)
+    # (the NCHW run itself is pinned to the oracle backend by tests/test_gpu_parity.py)
+    for a, b in zip(outs["nchw"], outs["nhwc"]):
+        torch.testing.assert_close(a, b, rtol=0, atol=1e-4)
+    assert (outs["nhwc"][0] - outs["nhwc"][1]).abs().max() > 1e-3  # the two edits really differ

@@ -37,6 +37,8 @@ def main():
                            dtype=torch.int32, device=dev)
         xs = [torch.randn(1, cin, res, res, device=dev) for _ in range(4)]
         ts = [torch.randn(T, cin, 6, 6, device=dev) for _ in range(4)]
+        xcl = [t.contiguous(memory_format=torch.channels_last) for t in xs]
+        tcl = [t.contiguous(memory_format=torch.channels_last) for t in ts]
         wgt = torch.randn(cout, cin, 3, 3, device=dev) / (3 * cin ** 0.5)
         bias = torch.randn(cout, device=dev)
         sc, sh = torch.randn(1, cin, 1, 1, device=dev), torch.randn(1, cin, 1, 1, device=dev)
@@ -46,6 +48,9 @@ def main():
             "gather_raw": lambda i: hip.gather_conv(xs[i], (6, 6), idx, None, None, "identity", packed, bias, cout, (3, 3), (1, 1)),
             "gather_affine": lambda i: hip.gather_conv(xs[i], (6, 6), idx, sc, sh, "identity", packed, bias, cout, (3, 3), (1, 1)),
             "gather_swish": lambda i: hip.gather_conv(xs[i], (6, 6), idx, sc, sh, "swish", packed, bias, cout, (3, 3), (1, 1)),
+            "cl_tiles": lambda i: hip.block_conv_cl(tcl[i], packed, bias, cout, (3, 3), (1, 1)),
+            "cl_gather_raw": lambda i: hip.gather_conv_cl(xcl[i], None, (6, 6), idx, None, None, "identity", packed, bias, cout, (3, 3), (1, 1)),
+            "cl_gather_swish": lambda i: hip.gather_conv_cl(xcl[i], None, (6, 6), idx, sc, sh, "swish", packed, bias, cout, (3, 3), (1, 1)),
         }
         flop = 2.0 * T * 16 * cout * cin * 9
         for tile in a.tiles.split(","):
