@@ -275,6 +275,16 @@ int sige_hip_scatter_with_block_residual_nhwc_f32(
         const int32_t *active_indices1, const int32_t *table1, int gH1, int gW1, int N1,
         int in_place, float *out, void *stream);
 
+/* ---- 3x3 / padding-1 conv with <= 4 output channels over a full channels-last tensor
+ * (the U-Net's conv_out after norm_out + SiLU, sige_fused_unet.py:430-434, which the
+ * reference runs densely in sparse mode too): out [B,H,W,Cout] = conv(act(scale*x + shift)),
+ * x [B,H,W,C], weight [Cout,C,3,3] (the nn.Conv2d layout), scale / shift [1|B, C] or NULL. */
+int sige_hip_conv3x3_small_cout_nhwc_f32(const float *x, int B, int C, int H, int W,
+                                         const float *scale, int scaleB, int scaleC,
+                                         const float *shift, int shiftB, int shiftC, int activation,
+                                         const float *weight, const float *bias, int Cout,
+                                         float *out, void *stream);
+
 /* per-group mean / rstd of a [B,C,H,W] tensor -> per-channel (scale, shift) with
  * GroupNorm(x) == x*scale + shift  (scale = gamma*rstd, shift = beta - mean*scale):
  * the producer of the cached affine (diffusion/models/common.py:37-57) as two

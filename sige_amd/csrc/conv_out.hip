@@ -1,0 +1,119 @@
+// Output convolution of the U-Net: a 3x3 / padding-1 conv with a handful of output
+// channels (3 for DDPM's conv_out) over the FULL-resolution activation, with the
+// preceding GroupNorm affine + SiLU fused into the input path.
+//
+// In SIGE's sparse mode the reference still runs norm_out / swish / conv_out densely
+// on the whole 256x256x128 tensor (sige_fused_unet.py:430-434).  A 128 -> 3 conv is a
+// poor fit for the matrix cores (3 of 16 output columns used); it is bandwidth-bound
+// (33.5 MB in, 0.8 MB out).  Here: channels-last input, one workgroup per 8x32 pixel
+// tile, the activated (halo-extended) tile of a 32-channel chunk staged once in LDS,
+// every lane accumulates its pixel's COUT outputs with 16-byte LDS reads; weights in LDS.
+#include "common.hpp"
+
+namespace sige {
+
+constexpr int kTH = 8, kTW = 32, kCC = 32;  // tile rows / cols, channels per chunk
+constexpr int kPH = kTH + 2, kPW = kTW + 2;
+constexpr int kLDC = kCC + 4;               // padded pixel pitch in LDS (floats)
+
+template <int COUT, int ACT>
+__global__ __launch_bounds__(256) void conv_out_nhwc_kernel(const float *__restrict__ x, int B, int C, int H, int W,
+                                                           const float *__restrict__ scale, const float *__restrict__ shift, int aff_sb,
+                                                           const float *__restrict__ w,  // [COUT, C, 3, 3]
+                                                           const float *__restrict__ bias, float *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float tile[kPH * kPW * kLDC];
+    __shared__ __attribute__((aligned(16))) float wl[COUT * 9 * kCC];  // [co][tap][c]
+    const int tid = threadIdx.x;
+    const int tx = tid % kTW, ty = tid / kTW;
+    const int tilesW = (W + kTW - 1) / kTW, tilesH = (H + kTH - 1) / kTH;
+    const int b = blockIdx.x / (tilesW * tilesH);
+    const int tr = blockIdx.x % (tilesW * tilesH);
+    const int h0 = (tr / tilesW) * kTH, w0 = (tr % tilesW) * kTW;
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = bias ? bias[co] : 0.f;
+    for (int c0 = 0; c0 < C; c0 += kCC) {
+        __syncthreads();
+        // stage act(scale*x + shift) of the (8+2) x (32+2) pixel window, channels c0..c0+31 (zeros outside the image)
+        for (int u = tid; u < kPH * kPW * (kCC / 4); u += 256) {
+            const int c4 = (u % (kCC / 4)) * 4, p = u / (kCC / 4);
+            const int ph = p / kPW, pw = p % kPW;
+            const int h = h0 + ph - 1, ww = w0 + pw - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (h >= 0 && h < H && ww >= 0 && ww < W && c0 + c4 < C) {
+                v = *reinterpret_cast<const float4 *>(x + (((size_t)b * H + h) * W + ww) * C + c0 + c4);
+                if (scale) {
+                    const float4 s4 = *reinterpret_cast<const float4 *>(scale + b * aff_sb + c0 + c4);
+                    const float4 t4 = *reinterpret_cast<const float4 *>(shift + b * aff_sb + c0 + c4);
+                    v.x = s4.x * v.x; v.y = s4.y * v.y; v.z = s4.z * v.z; v.w = s4.w * v.w;
+                    v.x = t4.x + v.x; v.y = t4.y + v.y; v.z = t4.z + v.z; v.w = t4.w + v.w;
+                }
+                v.x = activate<ACT>(v.x); v.y = activate<ACT>(v.y); v.z = activate<ACT>(v.z); v.w = activate<ACT>(v.w);
+            }
+            *reinterpret_cast<float4 *>(tile + p * kLDC + c4) = v;
+        }
+        for (int u = tid; u < COUT * 9 * kCC; u += 256) {
+            const int c = u % kCC, tap = (u / kCC) % 9, co = u / (kCC * 9);
+            wl[u] = (c0 + c < C) ? w[((size_t)co * C + c0 + c) * 9 + tap] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float *tp = tile + ((ty + tap / 3) * kPW + tx + tap % 3) * kLDC;
+#pragma unroll
+            for (int c4 = 0; c4 < kCC; c4 += 4) {
+                const float4 a = *reinterpret_cast<const float4 *>(tp + c4);
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) {
+                    const float4 q = *reinterpret_cast<const float4 *>(wl + (co * 9 + tap) * kCC + c4);
+                    acc[co] = fmaf(a.x, q.x, acc[co]); acc[co] = fmaf(a.y, q.y, acc[co]);
+                    acc[co] = fmaf(a.z, q.z, acc[co]); acc[co] = fmaf(a.w, q.w, acc[co]);
+                }
+            }
+        }
+    }
+    const int h = h0 + ty, ww = w0 + tx;
+    if (h < H && ww < W) {
+        float *o = out + (((size_t)b * H + h) * W + ww) * COUT;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) o[co] = acc[co];
+    }
+}
+
+}  // namespace sige
+
+using namespace sige;
+
+extern "C" int sige_hip_conv3x3_small_cout_nhwc_f32(const float *x, int B, int C, int H, int W,
+                                                    const float *scale, int scaleB, int scaleC,
+                                                    const float *shift, int shiftB, int shiftC, int activation,
+                                                    const float *weight, const float *bias, int Cout,
+                                                    float *out, void *stream) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || Cout <= 0) return SIGE_HIP_EINVAL;
+    if (!x || !weight || !out) return SIGE_HIP_EINVAL;
+    if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
+    if (Cout > 4 || C % 4 || (reinterpret_cast<uintptr_t>(x) & 15)) return SIGE_HIP_EUNSUPPORTED;
+    if ((scale == nullptr) != (shift == nullptr)) return SIGE_HIP_EUNSUPPORTED;
+    int aff_sb = 0;
+    if (scale) {
+        if (scaleC != C || shiftC != C || scaleB != shiftB || !(scaleB == 1 || scaleB == B)) return SIGE_HIP_EUNSUPPORTED;
+        if ((reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15) return SIGE_HIP_EUNSUPPORTED;
+        aff_sb = scaleB > 1 ? C : 0;
+    }
+    const long blocks = (long)B * ((H + kTH - 1) / kTH) * ((W + kTW - 1) / kTW);
+    if (blocks > 0x7fffffffL) return SIGE_HIP_EUNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+#define SIGE_CO(N)                                                                                                    \
+    if (activation == SIGE_HIP_ACT_SWISH)                                                                             \
+        conv_out_nhwc_kernel<N, SIGE_HIP_ACT_SWISH><<<(int)blocks, 256, 0, st>>>(x, B, C, H, W, scale, shift, aff_sb, weight, bias, out); \
+    else                                                                                                              \
+        conv_out_nhwc_kernel<N, SIGE_HIP_ACT_IDENTITY><<<(int)blocks, 256, 0, st>>>(x, B, C, H, W, scale, shift, aff_sb, weight, bias, out);
+    switch (Cout) {
+        case 1: SIGE_CO(1) break;
+        case 2: SIGE_CO(2) break;
+        case 3: SIGE_CO(3) break;
+        default: SIGE_CO(4) break;
+    }
+#undef SIGE_CO
+    return launch_status();
+}

@@ -48,25 +48,32 @@ __global__ __launch_bounds__(kGNThreads) void gn_partial_kernel(const float *__r
     }
 }
 
-__global__ void gn_finish_kernel(const float *__restrict__ ws, int splits, int B, int C, int groups,
-                                 double group_elems, float eps, const float *__restrict__ gamma,
-                                 const float *__restrict__ beta, float *__restrict__ scale,
-                                 float *__restrict__ shift) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // b*C + c
-    if (i >= B * C) return;
-    const int b = i / C, c = i - b * C;
-    const int g = c / (C / groups);
+// one 64-lane wave per (batch, group): lanes add the split partials in fp64, a shuffle tree
+// combines them, then lane k writes channel k of the group
+__global__ __launch_bounds__(64) void gn_finish_kernel(const float *__restrict__ ws, int splits, int B, int C, int groups,
+                                                      double group_elems, float eps, const float *__restrict__ gamma,
+                                                      const float *__restrict__ beta, float *__restrict__ scale,
+                                                      float *__restrict__ shift) {
+    const int bg = blockIdx.x;  // b*groups + g
+    const int b = bg / groups, g = bg - b * groups;
+    const int lane = threadIdx.x;
     double s = 0.0, ss = 0.0;
-    const float *p = ws + ((size_t)(b * groups + g) * splits) * 2;
-    for (int k = 0; k < splits; ++k) { s += p[2 * k]; ss += p[2 * k + 1]; }
+    const float *p = ws + ((size_t)bg * splits) * 2;
+    for (int k = lane; k < splits; k += 64) { s += p[2 * k]; ss += p[2 * k + 1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
     const double mean = s / group_elems;
     double var = ss / group_elems - mean * mean;
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
-    const float sc = ga * rstd;
-    scale[i] = sc;
-    shift[i] = be - (float)mean * sc;
+    const int cg = C / groups;
+    for (int k = lane; k < cg; k += 64) {
+        const int c = g * cg + k;
+        const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
+        const float sc = ga * rstd;
+        scale[b * C + c] = sc;
+        shift[b * C + c] = be - (float)mean * sc;
+    }
 }
 
 static int gn_splits(size_t group_elems) {
@@ -130,7 +137,7 @@ extern "C" int sige_hip_group_norm_affine_f32(const float *x, int B, int C, int 
     const int splits = gn_splits(ge);
     hipStream_t st = as_stream(stream);
     gn_partial_kernel<<<dim3(splits, B * groups), kGNThreads, 0, st>>>(x, ge, splits, workspace);
-    gn_finish_kernel<<<ceil_div(B * C, 256), 256, 0, st>>>(workspace, splits, B, C, groups, (double)ge, eps, gamma, beta,
+    gn_finish_kernel<<<B * groups, 64, 0, st>>>(workspace, splits, B, C, groups, (double)ge, eps, gamma, beta,
                                                           scale, shift);
     return launch_status();
 }
@@ -157,7 +164,7 @@ extern "C" int sige_hip_group_norm_affine_nhwc_f32(const float *x, int B, int C,
     const int HW = H * W, splits = gn_nhwc_splits(HW);
     hipStream_t st = as_stream(stream);
     gn_partial_nhwc_kernel<<<dim3(splits, B), kGNThreads, 0, st>>>(x, C, HW, groups, splits, workspace);
-    gn_finish_kernel<<<ceil_div(B * C, 256), 256, 0, st>>>(workspace, splits, B, C, groups, (double)(C / groups) * HW, eps,
+    gn_finish_kernel<<<B * groups, 64, 0, st>>>(workspace, splits, B, C, groups, (double)(C / groups) * HW, eps,
                                                           gamma, beta, scale, shift);
     return launch_status();
 }

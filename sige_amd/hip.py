@@ -84,6 +84,8 @@ _SIGNATURES = {
         _c_int, [_c_vp] * 4 + [_c_int] * 12 + [_c_vp, _c_vp, _c_int, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]),
     "sige_hip_group_norm_affine_nhwc_workspace": (_c_sz, [_c_int] * 5),
     "sige_hip_group_norm_affine_nhwc_f32": (_c_int, [_c_vp] + [_c_int] * 5 + [ctypes.c_float] + [_c_vp] * 6),
+    "sige_hip_conv3x3_small_cout_nhwc_f32": (
+        _c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp, _c_int, _c_vp, _c_vp]),
     "sige_hip_attention_nhwc_f32": (_c_int, [_c_vp, _c_int, _c_int, _c_int, ctypes.c_float, _c_vp, _c_vp, _c_vp]),
 }
 
@@ -708,4 +710,23 @@ def attention_cl(qkv: torch.Tensor, scale: float):
     if status == UNSUPPORTED:
         return None
     _check(status, "attention_cl")
+    return out
+
+
+def conv3x3_small_cout_cl(x, weight, bias, scale=None, shift=None, activationName="identity"):
+    """conv(act(scale*x + shift)) for a 3x3 / padding-1 conv with <= 4 output channels on a full
+    channels-last tensor (the U-Net's norm_out -> swish -> conv_out tail); None if unsupported."""
+    x = _req_cl(x, "x")
+    B, C, H, W = x.shape
+    w = _req(weight.detach(), torch.float32, "weight")
+    Cout = w.shape[0]
+    if tuple(w.shape[1:]) != (C, 3, 3):
+        return None
+    (sa, s_keep), (ta, t_keep) = _cvec(scale, "scale"), _cvec(shift, "shift")
+    out = _empty_cl((B, Cout, H, W), x.device)
+    status = lib().sige_hip_conv3x3_small_cout_nhwc_f32(x.data_ptr(), B, C, H, W, *sa, *ta, _act(activationName),
+                                                        w.data_ptr(), _bias_ptr(bias), Cout, out.data_ptr(), _stream(x))
+    if status == UNSUPPORTED:
+        return None
+    _check(status, "conv3x3_small_cout_cl")
     return out

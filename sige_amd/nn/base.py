@@ -160,9 +160,11 @@ class SIGEConv2d(nn.Conv2d, SIGEModule):
                 if cl:
                     out = hip.gather_conv_cl(spec["x"], spec.get("x2"), spec["block"], spec["idx"], spec["scale"],
                                              spec["shift"], spec["act"], *common)
-                else:
+                elif spec.get("x2") is None:
                     out = hip.gather_conv(spec["x"], spec["block"], spec["idx"], spec["scale"], spec["shift"],
                                           spec["act"], *common)
+                else:
+                    out = None  # (the two-tensor input exists in the channels-last kernels only)
             else:
                 f = hip.scatter_gather_conv_cl if cl else hip.scatter_gather_conv
                 out = f(spec["x"], spec["y"], spec["block"], spec["idx"], spec["map"], spec["scale"], spec["shift"],

@@ -94,8 +94,33 @@ class DeferredTiles(torch.Tensor):
         return func(*tree_map(real, args), **tree_map(real, kwargs or {}))
 
 
+class LazyCat(DeferredTiles):
+    """`torch.cat([a, b], dim=1)` that has not run.  The up path of a U-Net concatenates the
+    running activation with a skip tensor and hands the result to a block whose first ops are
+    Gathers (sige_fused_unet.py:416): the fused gather -> conv kernels read the two tensors
+    through two base pointers instead (conv_mfma.hpp), so the 2 x full-tensor copy of the cat
+    never happens.  Any other consumer materialises the cat."""
+
+    @staticmethod
+    def __new__(cls, a: torch.Tensor, b: torch.Tensor):
+        shape = (a.shape[0], a.shape[1] + b.shape[1], a.shape[2], a.shape[3])
+        t = DeferredTiles.__new__(cls, shape, a.dtype, a.device, lambda: torch.cat([a, b], dim=1), dict(kind="cat"))
+        t.parts = (a, b)
+        return t
+
+
+def lazy_cat(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """cat([a, b], dim=1), deferred when both are GPU tensors of one layout (else eager)."""
+    from .. import hip
+
+    if (fusion_enabled() and a.is_cuda and b.is_cuda and a.dtype == b.dtype == torch.float32 and a.dim() == 4
+            and a.shape[0] == b.shape[0] and a.shape[2:] == b.shape[2:] and hip.is_cl(a) == hip.is_cl(b)):
+        return LazyCat(a, b)
+    return torch.cat([a, b], dim=1)
+
+
 def resolve(x: torch.Tensor) -> torch.Tensor:
-    """The real tensor behind `x` (materialising a pending DeferredTiles)."""
+    """The real tensor behind `x` (materialising a pending DeferredTiles / LazyCat)."""
     return x.materialize() if isinstance(x, DeferredTiles) else x
 
 

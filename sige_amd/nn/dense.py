@@ -71,6 +71,11 @@ def fused_conv2d(conv: nn.Conv2d, x: torch.Tensor, scale: Optional[torch.Tensor]
             Ho, Wo = (H + 1 - 3) // 2 + 1, (W + 1 - 3) // 2 + 1
         else:
             Ho, Wo = H, W
+        if (hip.is_cl(x) and conv.out_channels <= 4 and tuple(conv.kernel_size) == (3, 3) and conv.stride[0] == 1
+                and x2 is None and residual is None):
+            out = hip.conv3x3_small_cout_cl(x, conv.weight, conv.bias, scale, shift, activation_name)
+            if out is not None:
+                return out
         idx = hip.all_tiles(H, W, out_tile, conv.stride, offset, x.device)
         if hip.is_cl(x) and hip.cl_supported(x.shape[1], 0 if x2 is None else x2.shape[1], conv.out_channels):
             out = hip.gather_conv_cl(x, x2, block, idx, scale, shift, activation_name, _packed(conv, block), conv.bias,

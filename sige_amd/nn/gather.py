@@ -64,10 +64,20 @@ class Gather(SIGEModule):
         self.check_dtype(x, scale, shift)
         self.check_dim(x, scale, shift)
         if self.mode == "sparse":
+            x2 = None
+            if isinstance(x, deferred.LazyCat) and x.spec is not None:
+                # a pending cat: keep the two tensors apart if the fused conv can read them in place
+                a, b = x.parts
+                from .. import hip
+
+                if (hip.cat_fusable(a.shape[0], a.shape[1], self.kernel_size) and a.shape[1] % 4 == 0 and b.shape[1] % 4 == 0
+                        and deferred.defer_ok(a, scale, shift, self.activation_first, self.sparse_update, self.activation_name)
+                        and hip.is_cl(a) and hip.is_cl(b)):
+                    x, x2 = a, b
             fn = self.native(self.runtime, x)
             x = deferred.resolve(x)
             # channels-last activations stay channels-last (16-byte coalesced tile gathers)
-            cl = deferred.channels_last_ok(x, scale, shift, self.activation_first)
+            cl = x2 is not None or deferred.channels_last_ok(x, scale, shift, self.activation_first)
             if not cl:
                 x = x.contiguous()
             idx = self.indices_on(x.device)
@@ -77,18 +87,20 @@ class Gather(SIGEModule):
             act, first = self.activation_name, self.activation_first
 
             def run():
+                xx = x if x2 is None else torch.cat([x, x2], dim=1)
                 if cl:
                     from .. import hip
 
-                    return hip.gather_cl(x, bh, bw, idx, scale, shift, act)
-                return fn(x, bh, bw, idx, scale, shift, act, first)
+                    return hip.gather_cl(xx, bh, bw, idx, scale, shift, act)
+                return fn(xx, bh, bw, idx, scale, shift, act, first)
 
             if deferred.defer_ok(x, scale, shift, first, self.sparse_update, act):
                 # not computed yet: a SIGEConv2d consumer fuses it into its prologue,
                 # any other consumer materialises it through the gather kernel
+                channels = x.shape[1] + (0 if x2 is None else x2.shape[1])
                 return deferred.DeferredTiles(
-                    (x.shape[0] * idx.shape[0], x.shape[1], bh, bw), x.dtype, x.device, run,
-                    dict(kind="gather", x=x, block=(bh, bw), idx=idx, scale=scale, shift=shift, act=act, cl=cl))
+                    (x.shape[0] * idx.shape[0], channels, bh, bw), x.dtype, x.device, run,
+                    dict(kind="gather", x=x, x2=x2, block=(bh, bw), idx=idx, scale=scale, shift=shift, act=act, cl=cl))
             return run()
         if self.mode == "full":
             self.input_res = x.shape[2:]

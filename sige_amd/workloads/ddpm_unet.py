@@ -26,6 +26,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from ..nn import Gather, Scatter, ScatterGather, ScatterWithBlockResidual, SIGEConv2d, SIGEModel, SIGEModule
+from ..nn.deferred import lazy_cat
 from ..nn.dense import fused_conv2d, group_norm_affine
 
 
@@ -112,6 +113,8 @@ class ResBlock(SIGEModule):
         if self.mode in ("sparse", "profile"):
             if pair and not self.sparse_main and self.mode == "sparse":
                 return self._sparse_dense(pair[0], pair[1])
+            if pair and self.mode == "sparse" and self.cin != self.cout:
+                return self._sparse(lazy_cat(pair[0], pair[1]))  # consumed by the block's two Gathers only
             return self._sparse(torch.cat(pair, dim=1) if pair else x)
         raise NotImplementedError("Unknown mode [%s]!!!" % self.mode)
 

@@ -197,3 +197,52 @@ def test_ddpm_unet_channels_last_equals_nchw(inplace):
     for a, b in zip(outs["nchw"], outs["nhwc"]):
         torch.testing.assert_close(a, b, rtol=0, atol=1e-4)
     assert (outs["nhwc"][0] - outs["nhwc"][1]).abs().max() > 1e-3  # the two edits really differ
+
+
+@pytest.mark.parametrize("B,C,H,W,cout,act", [(1, 128, 256, 256, 3, "swish"), (2, 36, 19, 45, 4, "identity"), (1, 64, 8, 8, 1, "swish")])
+def test_conv3x3_small_cout_cl(hip, B, C, H, W, cout, act):
+    torch.manual_seed(C + H)
+    x = torch.randn(B, C, H, W, device=DEV)
+    w = torch.randn(cout, C, 3, 3, device=DEV) / (3 * C ** 0.5)
+    bias = torch.randn(cout, device=DEV)
+    sc, sh = torch.randn(B, C, 1, 1, device=DEV), torch.randn(B, C, 1, 1, device=DEV)
+    got = hip.conv3x3_small_cout_cl(_cl(x), w, bias, sc, sh, act)
+    assert got is not None
+    h = x.double() * sc.double() + sh.double()
+    if act == "swish":
+        h = torch.nn.functional.silu(h)
+    want = torch.nn.functional.conv2d(h, w.double(), bias.double(), 1, 1).float()
+    torch.testing.assert_close(got.contiguous(), want, rtol=0, atol=1e-4)
+    plain = hip.conv3x3_small_cout_cl(_cl(x), w, None)
+    torch.testing.assert_close(plain.contiguous(), torch.nn.functional.conv2d(x.double(), w.double(), None, 1, 1).float(), rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("c1,c2,k", [(128, 64, 3), (256, 128, 1), (100, 28, 3)])
+def test_lazy_cat_feeds_fused_gather(hip, c1, c2, k):
+    """A deferred torch.cat consumed by Gather -> SIGEConv2d (two-pointer kernel input, or the
+    materialising fallback when the split is not on a chunk boundary) equals the eager cat."""
+    from sige_amd.nn import Gather, SIGEConv2d, deferred
+    from sige_amd.utils import dilate_mask
+
+    torch.manual_seed(c1 + c2)
+    res = 64
+    conv = SIGEConv2d(c1 + c2, 96, k, 1, k // 2).to(DEV).eval()
+    gather = Gather(conv, 6 if k == 3 else 4, activation_name="swish" if k == 3 else "identity").to(DEV)
+    a, b = _cl(torch.randn(1, c1, res, res, device=DEV)), _cl(torch.randn(1, c2, res, res, device=DEV))
+    scale = torch.randn(1, c1 + c2, 1, 1, device=DEV) if k == 3 else None
+    shift = torch.randn(1, c1 + c2, 1, 1, device=DEV) if k == 3 else None
+    mask = torch.zeros(res, res, dtype=torch.bool, device=DEV)
+    mask[20:33, 10:40] = True
+    with torch.no_grad():
+        for m in (gather, conv):
+            m.set_mode("full")
+        conv(gather(torch.cat([a, b], 1)))
+        gather.set_mask({(res, res): dilate_mask(mask, 2)}, {}, 1)
+        for m in (gather, conv):
+            m.set_mode("sparse")
+        lazy = deferred.lazy_cat(a, b)
+        assert isinstance(lazy, deferred.LazyCat)
+        got = conv(gather(lazy, scale, shift))
+        want = conv(gather(torch.cat([a, b], 1), scale, shift))
+    torch.testing.assert_close(got.contiguous(), want.contiguous(), rtol=0, atol=1e-5)
+    assert lazy.spec is not None or (c1 % 32) != 0  # the cat never ran when the split sits on a chunk boundary

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--ratio", type=float, default=0.012)
     ap.add_argument("--replays", type=int, default=50)
     ap.add_argument("--mode", default="sparse", choices=["sparse", "dense", "eager"])
+    ap.add_argument("--layout", default="nhwc", choices=["nhwc", "nchw"])
     a = ap.parse_args()
     dev = torch.device("cuda")
     torch.backends.cudnn.benchmark = True
@@ -36,6 +37,10 @@ def main():
     x0 = torch.randn(1, 3, 256, 256, generator=gen).to(dev)
     noise = torch.randn(1, 3, 256, 256, generator=gen).to(dev)
     t = torch.zeros(1, device=dev)
+    if a.layout == "nhwc":
+        model = model.to(memory_format=torch.channels_last)
+        x0, noise = x0.contiguous(memory_format=torch.channels_last), noise.contiguous(memory_format=torch.channels_last)
+        model.set_scatter_inplace(True)
     mask = bench.square_mask(a.ratio).to(dev)
     x1 = x0 + noise * mask
     with torch.no_grad():
