@@ -164,6 +164,9 @@ int sige_hip_block_conv_direct_f32(const float *x, int T, int Cin, int R, int S,
  * mt pixels x (nb*mt) output channels, mt in {16, 32}, nb in {1, 2}; (0, 0) restores the
  * per-launch choice.  Results do not depend on it beyond fp32 summation order. */
 int sige_hip_block_conv_force_tile(int mt, int nb);
+/* Tuning knob: waves per workgroup of the channels-last stride-1 kernels: 4, 8 (two waves per SIMD),
+ * or 0 = per launch (8 when the grid has fewer than 384 workgroups). */
+int sige_hip_block_conv_force_waves(int waves);
 
 /* ---- fused gather -> conv and scatter_gather -> conv ------------------------
  * The same MFMA conv with the producer of its input tiles fused into the
@@ -231,7 +234,18 @@ int sige_hip_gather_conv_nhwc_f32(const float *x, const float *x2, int B, int C1
                                   const float *packed, const float *bias, int Cout, int kH, int kW,
                                   int strideH, int strideW,
                                   int to_full, int offsetH, int offsetW, const float *residual, int Ho, int Wo,
+                                  float *workspace, size_t workspace_floats,
+                                  const float *out_scale, const float *out_shift, int out_activation,
                                   float *out, void *stream);
+/* `out_scale` / `out_shift` ([Cout], optional): epilogue out = act(out_scale * (conv + bias + residual) + out_shift)
+ * -- the CONSUMER's cached GroupNorm affine + SiLU applied by the producer, once per element; the consumer then
+ * gathers with no affine (e.g. conv1 -> conv2 of a ResBlock, sige_fused_unet.py:112-125).                     */
+/* `workspace` (optional, NULL = none): room for up to 8 copies of the output.  When the conv has
+ * too few tiles to cover the chip with ANY block shape (the 8x8 layers: 64 pixels, K up to 9216),
+ * the channel chunks are split across workgroups that write partial sums there, and a second
+ * launch adds them in a fixed order with bias / residual (deterministic; no atomics).
+ * sige_hip_conv_ksplit_hint: how many copies such a call would use (1 = no split). */
+int sige_hip_conv_ksplit_hint(int T, int Cin, int Cout, int kH, int kW, int strideH, int strideW);
 int sige_hip_scatter_gather_conv_nhwc_f32(const float *x, const float *y, int B, int Cin, int H, int W,
                                           int Rx, int Sx, int bH, int bW,
                                           const int32_t *active_indices, int N, const int32_t *scatter_map,

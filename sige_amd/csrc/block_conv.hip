@@ -17,7 +17,7 @@ template <int KK, int MT>
 __global__ void pack_weights_kernel(const float *__restrict__ w, int Cout, int Cin, float *__restrict__ packed,
                                     long total) {
     constexpr int NL = 64 / MT, CW = (KK == 1 ? 16 : 4) * NL, CC = 4 * CW, L = (CW / NL) * KK, F = L / 4;
-    const int nchunks = (Cin + CC - 1) / CC;
+    const int nchunks = ((Cin + CC - 1) / CC + 1) & ~1;  // padded to even: the 8-wave kernels read chunk PAIRS
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long r = i;
         const int e = r % 4; r /= 4;
@@ -36,7 +36,7 @@ __global__ void pack_weights_kernel(const float *__restrict__ w, int Cout, int C
 
 static size_t packed_floats(int Cout, int Cin, int KK, int MT) {
     const int NL = 64 / MT, CW = (KK == 1 ? 16 : 4) * NL, CC = 4 * CW, F = (CW / NL) * KK / 4;
-    return (size_t)ceil_div(Cout, MT) * ceil_div(Cin, CC) * 4 * F * 64 * 4;
+    return (size_t)ceil_div(Cout, MT) * ((ceil_div(Cin, CC) + 1) & ~1) * 4 * F * 64 * 4;  // chunk count padded to even
 }
 
 // ---- any-shape direct kernel (groups, odd tiles): one lane per output -------
@@ -72,12 +72,12 @@ static int mfma_kind(int kH, int kW, int R, int S, int strH, int strW, int group
 }
 
 // specialisations defined in the per-geometry translation units
-#define SIGE_CONV_DECLARE(G, NB, LAY)                                                                    \
-    template <> void launch_conv_geo<G, NB, SRC_TILES, DST_TILES, LAY>(ConvArgs, int, hipStream_t);          \
-    template <> void launch_conv_geo<G, NB, SRC_GATHER, DST_TILES, LAY>(ConvArgs, int, hipStream_t);         \
-    template <> void launch_conv_geo<G, NB, SRC_GATHER, DST_NCHW, LAY>(ConvArgs, int, hipStream_t);          \
-    template <> void launch_conv_geo<G, NB, SRC_SCATTER_GATHER, DST_TILES, LAY>(ConvArgs, int, hipStream_t);
-#define SIGE_CONV_DECLARE_LAYOUTS(G, NB) SIGE_CONV_DECLARE(G, NB, LAYOUT_NCHW) SIGE_CONV_DECLARE(G, NB, LAYOUT_NHWC)
+#define SIGE_CONV_DECLARE(G, NB, LAY, W)                                                                 \
+    template <> void launch_conv_geo<G, NB, SRC_TILES, DST_TILES, LAY, W>(ConvArgs, int, hipStream_t);          \
+    template <> void launch_conv_geo<G, NB, SRC_GATHER, DST_TILES, LAY, W>(ConvArgs, int, hipStream_t);         \
+    template <> void launch_conv_geo<G, NB, SRC_GATHER, DST_NCHW, LAY, W>(ConvArgs, int, hipStream_t);          \
+    template <> void launch_conv_geo<G, NB, SRC_SCATTER_GATHER, DST_TILES, LAY, W>(ConvArgs, int, hipStream_t);
+#define SIGE_CONV_DECLARE_LAYOUTS(G, NB) SIGE_CONV_DECLARE(G, NB, LAYOUT_NCHW, 4) SIGE_CONV_DECLARE(G, NB, LAYOUT_NHWC, 4)
 using K31_16 = ConvGeo<3, 1, 6, 16>;
 using K31_32 = ConvGeo<3, 1, 6, 32>;
 using K11_16 = ConvGeo<1, 1, 4, 16>;
@@ -94,6 +94,57 @@ SIGE_CONV_DECLARE_LAYOUTS(K11_32, 1)
 SIGE_CONV_DECLARE_LAYOUTS(K11_32, 2)
 SIGE_CONV_DECLARE_LAYOUTS(K32_16, 1)  // stride 2: NB = 1 only (conv_k3s2*.hip)
 SIGE_CONV_DECLARE_LAYOUTS(K32_32, 1)
+// 8-wave workgroups: channels-last, stride 1 (conv_k3s1_nhwc_w8.hip, conv_k1_nhwc_w8.hip)
+SIGE_CONV_DECLARE(K31_16, 1, LAYOUT_NHWC, 8)
+SIGE_CONV_DECLARE(K31_16, 2, LAYOUT_NHWC, 8)
+SIGE_CONV_DECLARE(K31_32, 1, LAYOUT_NHWC, 8)
+SIGE_CONV_DECLARE(K31_32, 2, LAYOUT_NHWC, 8)
+SIGE_CONV_DECLARE(K11_16, 1, LAYOUT_NHWC, 8)
+SIGE_CONV_DECLARE(K11_16, 2, LAYOUT_NHWC, 8)
+SIGE_CONV_DECLARE(K11_32, 1, LAYOUT_NHWC, 8)
+SIGE_CONV_DECLARE(K11_32, 2, LAYOUT_NHWC, 8)
+
+// ---- cross-workgroup K split: deterministic second pass ------------------------
+// out[i] = sum_s ws[s][i] + bias[channel(i)] + residual[i]   (channels-last: channel = i mod C)
+__global__ __launch_bounds__(256) void splitk_reduce_nhwc_kernel(const float *__restrict__ ws, int S, size_t stride, size_t n4, int C,
+                                                                const float *__restrict__ bias, const float *__restrict__ residual,
+                                                                const float *__restrict__ oscale, const float *__restrict__ oshift, int oact,
+                                                                float *__restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 v = *reinterpret_cast<const float4 *>(ws + 4 * i);
+        for (int s = 1; s < S; ++s) {
+            const float4 p = *reinterpret_cast<const float4 *>(ws + s * stride + 4 * i);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        if (bias) {
+            const float4 b = *reinterpret_cast<const float4 *>(bias + (4 * i) % C);
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        if (residual) {
+            const float4 r = *reinterpret_cast<const float4 *>(residual + 4 * i);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        if (oscale) {
+            const float4 os = *reinterpret_cast<const float4 *>(oscale + (4 * i) % C), oh = *reinterpret_cast<const float4 *>(oshift + (4 * i) % C);
+            v.x = os.x * v.x; v.y = os.y * v.y; v.z = os.z * v.z; v.w = os.w * v.w;
+            v.x = oh.x + v.x; v.y = oh.y + v.y; v.z = oh.z + v.z; v.w = oh.w + v.w;
+            if (oact == SIGE_HIP_ACT_SWISH) { v.x = swish(v.x); v.y = swish(v.y); v.z = swish(v.z); v.w = swish(v.w); }
+        }
+        *reinterpret_cast<float4 *>(out + 4 * i) = v;
+    }
+}
+
+// K split factor for a conv whose smallest-tile grid (16 pixels x 16 channels per workgroup) cannot
+// cover the chip: every wave then runs K/4 MFMA steps back to back however few tiles there are
+// (the 8x8 layers of the U-Net: 64 pixels, K = 4608..9216), so the chunks are shared out.
+static int ksplit_for(long blocks, int nchunks, int cap) {
+    if (cap <= 1 || blocks >= 224) return 1;
+    int s = (int)((224 + blocks - 1) / blocks);
+    s = s < nchunks / 2 ? s : nchunks / 2;  // >= 2 chunks per split (the software pipeline's depth)
+    s = s < 8 ? s : 8;
+    s = s < cap ? s : cap;
+    return s < 1 ? 1 : s;
+}
 
 // Output block of a workgroup: the largest of (MT x NB*MT) in
 //   32x64, 32x32, 16x32, 16x16   (pixels x output channels)
@@ -101,7 +152,7 @@ SIGE_CONV_DECLARE_LAYOUTS(K32_32, 1)
 // matrix pipe is saturated by one wave per SIMD, so a grid below ~1 workgroup per
 // CU leaves matrix cores idle while a larger block only saves operand traffic).
 // sige_hip_block_conv_force_tile(mt, nb) overrides the choice (benchmarking).
-static int g_force_mt = 0, g_force_nb = 0;
+static int g_force_mt = 0, g_force_nb = 0, g_force_waves = 0;
 __device__ int32_t g_zero_idx[2] = {0, 0};
 
 template <int KH, int STR, int R, int SRC, int DST, int LAY>
@@ -121,6 +172,16 @@ static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
     const long kFill = 224;
     int mt = 0, nb = 1;
     if (g_force_mt) { mt = g_force_mt == 32 ? 32 : 16; nb = (g_force_nb == 2 && kHasNB2) ? 2 : 1; if (!usable(mt)) mt = 0; }
+    const int cap = (LAY == LAYOUT_NHWC && a.ws) ? a.ksplit_max : 1;
+    if (!mt && cap > 1 && usable(16) && blocks(G16::TPB, 16, 1) < kFill) {
+        // too few tiles for any block shape: split K across workgroups, largest block that then fills the chip
+        const int nc32 = ceil_div(a.Cin, G32::CC), nc16 = ceil_div(a.Cin, G16::CC);
+        auto filled = [&](int tpb, int m, int n, int nc) { long b = blocks(tpb, m, n); return b * ksplit_for(b, nc, cap); };
+        if (usable(32) && kHasNB2 && filled(G32::TPB, 32, 2, nc32) >= kFill) { mt = 32; nb = 2; }
+        else if (usable(32) && filled(G32::TPB, 32, 1, nc32) >= kFill) { mt = 32; nb = 1; }
+        else if (kHasNB2 && filled(G16::TPB, 16, 2, nc16) >= kFill) { mt = 16; nb = 2; }
+        else { mt = 16; nb = 1; }
+    }
     if (!mt) {
         if (usable(32) && kHasNB2 && blocks(G32::TPB, 32, 2) >= kFill) { mt = 32; nb = 2; }
         else if (usable(32) && blocks(G32::TPB, 32, 1) >= kFill) { mt = 32; nb = 1; }
@@ -132,17 +193,51 @@ static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
     const int tpb = mt == 32 ? G32::TPB : G16::TPB;
     a.mbk = ceil_div(a.T, tpb);
     a.ngk = ceil_div(a.Cout, mt * nb);
-    a.nchunks = ceil_div(a.Cin, mt == 32 ? G32::CC : G16::CC);
+    const int cc4 = mt == 32 ? G32::CC : G16::CC;
+    const int nchunks4 = (ceil_div(a.Cin, cc4) + 1) & ~1;  // as packed (padded to even)
+    a.nblk = nchunks4 * 4;
+    // 8-wave workgroups (two waves per SIMD) when the grid cannot give every CU two 4-wave workgroups
+    constexpr bool kHasW8 = LAY == LAYOUT_NHWC && STR == 1;
+    int waves = 4;
+    if (kHasW8 && g_force_waves != 4 && (g_force_waves == 8 || (long)a.mbk * a.ngk < 160)) {
+        const bool cat_ok = !(SRC == SRC_GATHER && a.Csplit != a.Cin && a.Csplit % (2 * cc4));
+        if (cat_ok && a.Cin > cc4) waves = 8;
+    }
+    a.nchunks = waves == 8 ? nchunks4 / 2 : ceil_div(a.Cin, cc4);
     // which operand should stay XCD-local: weights (dense layers) or input tiles (many active tiles)
     const double wbytes = (double)a.Cout * a.Cin * KH * KH, abytes = (double)a.T * a.Cin * R * R;
     a.ng_fast = wbytes > abytes;
     if (mt == 16) a.packed += packed_floats(a.Cout, a.Cin, KH * KH, 32);  // the MT=16 layout follows the MT=32 one
-    if constexpr (kHasNB2) {
-        if (mt == 32 && nb == 2) { launch_conv_geo<G32, 2, SRC, DST, LAY>(a, mode, st); return SIGE_HIP_OK; }
-        if (nb == 2) { launch_conv_geo<G16, 2, SRC, DST, LAY>(a, mode, st); return SIGE_HIP_OK; }
+    // K split (channels-last launches that came with a workspace)
+    a.ksplit = ksplit_for((long)a.mbk * a.ngk, a.nchunks, cap);
+    a.chunks_per_split = ceil_div(a.nchunks, a.ksplit);
+    a.ksplit = ceil_div(a.nchunks, a.chunks_per_split);
+    float *final_out = a.out;
+    if (a.ksplit > 1) a.out = a.ws;
+    bool done = false;
+    if constexpr (kHasW8) {
+        if (waves == 8) {
+            if (mt == 32 && nb == 2) launch_conv_geo<G32, 2, SRC, DST, LAY, 8>(a, mode, st);
+            else if (mt == 32) launch_conv_geo<G32, 1, SRC, DST, LAY, 8>(a, mode, st);
+            else if (nb == 2) launch_conv_geo<G16, 2, SRC, DST, LAY, 8>(a, mode, st);
+            else launch_conv_geo<G16, 1, SRC, DST, LAY, 8>(a, mode, st);
+            done = true;
+        }
     }
-    if (mt == 32) launch_conv_geo<G32, 1, SRC, DST, LAY>(a, mode, st);
-    else launch_conv_geo<G16, 1, SRC, DST, LAY>(a, mode, st);
+    if constexpr (kHasNB2) {
+        if (!done && mt == 32 && nb == 2) { launch_conv_geo<G32, 2, SRC, DST, LAY, 4>(a, mode, st); done = true; }
+        else if (!done && nb == 2) { launch_conv_geo<G16, 2, SRC, DST, LAY, 4>(a, mode, st); done = true; }
+    }
+    if (!done) {
+        if (mt == 32) launch_conv_geo<G32, 1, SRC, DST, LAY, 4>(a, mode, st);
+        else launch_conv_geo<G16, 1, SRC, DST, LAY, 4>(a, mode, st);
+    }
+    if (a.ksplit > 1) {
+        const size_t n4 = a.split_stride / 4;
+        const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+        splitk_reduce_nhwc_kernel<<<grid, 256, 0, st>>>(a.ws, a.ksplit, a.split_stride, n4, a.Cout, a.bias, a.residual,
+                                                       a.oscale, a.oshift, a.oact, final_out);
+    }
     return SIGE_HIP_OK;
 }
 
@@ -181,6 +276,12 @@ extern "C" int sige_hip_block_conv_force_tile(int mt, int nb) {
     if (nb < 0 || nb > 2) return SIGE_HIP_EINVAL;
     g_force_mt = mt;
     g_force_nb = nb;
+    return SIGE_HIP_OK;
+}
+
+extern "C" int sige_hip_block_conv_force_waves(int waves) {
+    if (waves != 0 && waves != 4 && waves != 8) return SIGE_HIP_EINVAL;
+    g_force_waves = waves;
     return SIGE_HIP_OK;
 }
 
@@ -326,6 +427,14 @@ static bool nhwc_ok(int Cin, int C1, int Cout, const void *p0, const void *p1, c
     return Cin % 4 == 0 && C1 % 4 == 0 && Cout % 4 == 0 && al(p0) && al(p1) && al(p2) && al(p3);
 }
 
+extern "C" int sige_hip_conv_ksplit_hint(int T, int Cin, int Cout, int kH, int kW, int strideH, int strideW) {
+    if (T <= 0 || Cin <= 0 || Cout <= 0) return 1;
+    const int px = (kH == 3 && strideH == 2) ? 4 : 16;  // output pixels per tile
+    const long blocks16 = (long)ceil_div(T, 16 / px) * ceil_div(Cout, 16);
+    if (blocks16 >= 224) return 1;
+    return 8;  // (the launch decides the actual factor, at most 8)
+}
+
 extern "C" int sige_hip_block_conv_nhwc_f32(const float *x, int T, int Cin, int R, int S,
                                             const float *packed, const float *bias, int Cout, int kH, int kW,
                                             int strideH, int strideW, float *out, void *stream) {
@@ -348,6 +457,8 @@ extern "C" int sige_hip_gather_conv_nhwc_f32(const float *x, const float *x2, in
                                              const float *packed, const float *bias, int Cout, int kH, int kW,
                                              int strideH, int strideW,
                                              int to_full, int offsetH, int offsetW, const float *residual, int Ho, int Wo,
+                                             float *workspace, size_t workspace_floats,
+                                             const float *out_scale, const float *out_shift, int out_activation,
                                              float *out, void *stream) {
     const int Cin = C1 + C2;
     if (B < 0 || C1 <= 0 || C2 < 0 || Cout <= 0 || H <= 0 || W <= 0 || N < 0) return SIGE_HIP_EINVAL;
@@ -366,6 +477,19 @@ extern "C" int sige_hip_gather_conv_nhwc_f32(const float *x, const float *x2, in
     a.scale = scale; a.shift = shift;
     const int mode = staging_mode(scale, scaleB, scaleC, shift, shiftB, shiftC, activation, B, Cin, &a.aff_sb, &a.aff_sc);
     if (mode < 0) return SIGE_HIP_EUNSUPPORTED;
+    if ((out_scale == nullptr) != (out_shift == nullptr)) return SIGE_HIP_EINVAL;
+    if (out_activation != SIGE_HIP_ACT_IDENTITY && out_activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(out_scale) | reinterpret_cast<uintptr_t>(out_shift)) & 15) return SIGE_HIP_EUNSUPPORTED;
+    a.oscale = out_scale; a.oshift = out_shift; a.oact = out_activation;
+    {   // optional K split: `workspace` holds whole copies of the output
+        const int Ro = (bH - kH) / strideH + 1, So = (bW - kW) / strideW + 1;
+        a.split_stride = to_full ? (size_t)B * Ho * Wo * Cout : (size_t)B * N * Ro * So * Cout;
+        a.ws = workspace;
+        a.ksplit_max = (workspace && a.split_stride && !(reinterpret_cast<uintptr_t>(workspace) & 15))
+                           ? (int)(workspace_floats / a.split_stride < 8 ? workspace_floats / a.split_stride : 8) : 1;
+        // (the second pass reads whole output copies: every pixel must be written by some tile)
+        if (to_full && (long)N * Ro * So < (long)Ho * Wo) a.ksplit_max = 1;
+    }
     if (to_full) {
         a.residual = residual; a.Ho = Ho; a.Wo = Wo; a.offH = offsetH; a.offW = offsetW; a.strH = strideH; a.strW = strideW;
         return launch_conv<SRC_GATHER, DST_NCHW, LAYOUT_NHWC>(a, mode, kH, kW, bH, bW, strideH, strideW, as_stream(stream));

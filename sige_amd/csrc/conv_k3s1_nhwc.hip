@@ -3,8 +3,8 @@
 namespace sige {
 using G16 = ConvGeo<3, 1, 6, 16>;
 using G32 = ConvGeo<3, 1, 6, 32>;
-SIGE_CONV_INSTANTIATE(G16, 1, LAYOUT_NHWC)
-SIGE_CONV_INSTANTIATE(G32, 1, LAYOUT_NHWC)
-SIGE_CONV_INSTANTIATE(G16, 2, LAYOUT_NHWC)
-SIGE_CONV_INSTANTIATE(G32, 2, LAYOUT_NHWC)
+SIGE_CONV_INSTANTIATE(G16, 1, LAYOUT_NHWC, 4)
+SIGE_CONV_INSTANTIATE(G32, 1, LAYOUT_NHWC, 4)
+SIGE_CONV_INSTANTIATE(G16, 2, LAYOUT_NHWC, 4)
+SIGE_CONV_INSTANTIATE(G32, 2, LAYOUT_NHWC, 4)
 }  // namespace sige

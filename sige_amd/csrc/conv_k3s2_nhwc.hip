@@ -3,7 +3,7 @@
 namespace sige {
 using G16 = ConvGeo<3, 2, 5, 16>;
 using G32 = ConvGeo<3, 2, 5, 32>;
-SIGE_CONV_INSTANTIATE(G16, 1, LAYOUT_NHWC)
-SIGE_CONV_INSTANTIATE(G32, 1, LAYOUT_NHWC)
+SIGE_CONV_INSTANTIATE(G16, 1, LAYOUT_NHWC, 4)
+SIGE_CONV_INSTANTIATE(G32, 1, LAYOUT_NHWC, 4)
 // (25 staging slots per lane in NCHW: only the single-accumulator forms)
 }  // namespace sige

@@ -80,7 +80,6 @@ struct ConvGeo {
     static constexpr int RED = MT_ + 4;                // padded pixel stride of the reduction buffer
     static_assert(L % 4 == 0, "wave slice must be a whole number of float4 weight loads");
     static_assert(MT_ % PX == 0 && TPB >= 1, "tile pixels must divide the M block");
-    static_assert(BUF % 256 == 0, "every lane owns the same number of staging slots");
 };
 
 __host__ __device__ constexpr int cmax(int a, int b) { return a > b ? a : b; }
@@ -103,7 +102,8 @@ struct ConvArgs {
     const float *packed;
     const float *bias;
     float *out;
-    int T, Cin, Cout, nchunks;
+    int T, Cin, Cout, nchunks;  // nchunks: channel chunks of THIS launch (W * CW channels each)
+    int nblk;                   // (chunk, wave) blocks per output-channel group in `packed`
     int B, N, H, W;
     int RxSx, Sx;
     const float *scale, *shift;  // per-(batch, channel) affine of the gather modes (same broadcast shape)
@@ -118,6 +118,17 @@ struct ConvArgs {
     // grid decomposition: blockIdx.x -> (mb, ng); ng_fast = consecutive workgroups (= consecutive
     // XCDs) take different output-channel blocks, so each XCD's L2 streams 1/8 of the weights
     int mbk, ngk, ng_fast;
+    // cross-workgroup K split: grid.y = ksplit workgroups share one output block, `out` is a workspace of
+    // ksplit copies of the output (split_stride floats apart)
+    int ksplit, chunks_per_split;
+    size_t split_stride;
+    // optional epilogue: out = act(oscale[co] * (conv + bias + residual) + oshift[co]) -- the NEXT layer's cached
+    // GroupNorm affine + SiLU applied once per output element by the producer, so that the consumer stages raw
+    // values (no VALU work between its MFMAs, and none repeated per output-channel block)
+    const float *oscale, *oshift;
+    int oact;
+    float *ws;       // host side: workspace for the partial outputs (nullptr / ksplit_max <= 1: no K split)
+    int ksplit_max;  // host side: how many output copies `ws` holds
 };
 
 // SiLU for the fused staging path: v_exp_f32 + v_rcp_f32 (each <= 1 ulp) instead of
@@ -170,20 +181,31 @@ __device__ __forceinline__ float4 buf_f32x4(rsrc_t r, unsigned byte_off, int sof
 // fully coalesced loads -- 25x fewer address-processing cycles per byte.
 enum { LAYOUT_NCHW = 0, LAYOUT_NHWC = 1 };
 
-template <typename G, int NB, int SRC, int MODE, int DST, int LAYOUT = LAYOUT_NCHW>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+// W = waves per workgroup (4 or 8).  All W waves split K: a channel chunk is W * CW channels.
+// W = 8 (512 lanes) puts TWO waves on every SIMD of the CU running the workgroup: measured
+// (tools/conv_floor.py) the K loop sustains ~88 % of the f32 MFMA rate with two waves per SIMD
+// against ~50-65 % with one, because one wave's waits are covered by the other's MFMAs -- the
+// form for grids that cannot give every CU two workgroups.  The packed weight order
+// [ng][chunk][wave][f][lane] read with chunk' = chunk / 2, wave' = 4 * (chunk % 2) + wave is
+// exactly the 8-wave order, so both forms share one packed tensor (chunk count padded to even).
+template <typename G, int NB, int SRC, int MODE, int DST, int LAYOUT = LAYOUT_NCHW, int W = 4>
+__global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
     using M = Mfma<G::MT>;
+    constexpr int NT = 64 * W;                   // lanes per workgroup
+    constexpr int CCk = W * G::CW;               // channels per LDS chunk
+    constexpr int TILEF = CCk * G::RS;           // floats of one staged tile (NCHW stage)
+    constexpr int BUFk = G::TPB * TILEF;
     constexpr bool NHWC = LAYOUT == LAYOUT_NHWC;
     constexpr bool VEC = NHWC || SRC == SRC_TILES;            // staging slots are float4 units
     constexpr int NACC = (G::MT == 16 && NB == 1) ? 2 : 1;   // 16x16x4: 40-cycle dependent latency vs 32-cycle issue
     constexpr bool AFF = MODE != MODE_RAW;
     // LDS stage of one channel chunk: NCHW [tile][channel][R][S]; NHWC [tile][R][S][LDC] (LDC = CC + 4 pad)
-    constexpr int LDC = G::CC + 4;
-    constexpr int STAGE = NHWC ? G::TPB * G::RS * LDC : G::BUF;
-    constexpr int TROW = G::CC + 4;                            // table row: CC channels + 4 zeros
+    constexpr int LDC = CCk + 4;
+    constexpr int STAGE = NHWC ? G::TPB * G::RS * LDC : BUFk;
+    constexpr int TROW = CCk + 4;                            // table row: CC channels + 4 zeros
     constexpr int TABF = AFF ? 2 * TROW : 0;                   // scale row | shift row
     constexpr int RP = G::MT + 4;                              // padded row of the reduction buffer
-    constexpr int LDS_FLOATS = cmax(2 * STAGE + 2 * TABF, 4 * NB * G::MT * RP);
+    constexpr int LDS_FLOATS = cmax(2 * STAGE + 2 * TABF, W * NB * G::MT * RP);
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
     float *const tab = smem + 2 * STAGE;
 
@@ -196,7 +218,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     else { mb = blockIdx.x % a.mbk; ng = blockIdx.x / a.mbk; }
     const int Cin = a.Cin;
     const int HW = a.H * a.W;
-    const int last = a.nchunks - 1;
+    // cross-workgroup K split (deep-K, small-M layers): blockIdx.y owns chunks [first, last]
+    const int split = blockIdx.y;
+    const int first = split * a.chunks_per_split;
+    const int last = min(a.nchunks, first + a.chunks_per_split) - 1;
 
     // ---- staging slots ------------------------------------------------------
     // One slot = one LDS unit (a float, or a float4 when VEC) this lane fills for every chunk.
@@ -204,8 +229,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     //   TILES           s_off  into the tile slab
     //   GATHER          s_off  into x, s_off2 into x2 (NHWC only: the two have different pitches)
     //   SCATTER_GATHER  s_off  into the conv-1 tiles, s_off2 into the cached tensor y (one of them kOOB)
-    constexpr int UNITS = VEC ? (NHWC ? G::TPB * G::RS * G::CC / 4 : G::BUF / 4) : G::BUF;
-    constexpr int NS = (UNITS + 255) / 256;
+    constexpr int UNITS = VEC ? (NHWC ? G::TPB * G::RS * CCk / 4 : BUFk / 4) : BUFk;
+    constexpr int NS = (UNITS + NT - 1) / NT;
     constexpr bool TWO = SRC == SRC_SCATTER_GATHER || (NHWC && SRC == SRC_GATHER);
     float st_z[2][VEC ? 1 : NS], st_z2[2][(!VEC && TWO) ? NS : 1];
     float4 st_q[2][VEC ? NS : 1], st_q2[2][(VEC && SRC == SRC_SCATTER_GATHER) ? NS : 1];
@@ -214,26 +239,28 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     int s_dst[NS];             // LDS float index of the unit inside a stage
     int s_cl[VEC ? NS : 1];    // first channel of the unit inside the chunk (partial last chunk test)
 
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        const int v = tid + 256 * i;
+    // (static_for, not `#pragma unroll`: a loop the unroller gives up on would index the slot arrays
+    //  dynamically and push them to scratch memory -- every scratch load then drains vmcnt to 0)
+    static_for<0, NS>([&](auto i_tag) {
+        constexpr int i = decltype(i_tag)::value;
+        const int v = tid + NT * i;
         int t_l, c_l, p;  // tile in block, channel in chunk, pixel in tile
         if (NHWC) {
-            constexpr int UPT = G::RS * G::CC / 4, UPP = G::CC / 4;  // units per tile / per pixel
+            constexpr int UPT = G::RS * CCk / 4, UPP = CCk / 4;  // units per tile / per pixel
             t_l = v / UPT;
             p = (v - t_l * UPT) / UPP;
             c_l = ((v - t_l * UPT) - p * UPP) * 4;
             s_dst[i] = (t_l * G::RS + p) * LDC + c_l;
         } else if (VEC) {
-            constexpr int U4 = G::TILE_FLOATS / 4;
+            constexpr int U4 = TILEF / 4;
             t_l = v / U4;
             const int e = (v - t_l * U4) * 4;
             c_l = e / G::RS; p = e - c_l * G::RS;  // (a float4 may straddle channels: c_l = its first)
             s_dst[i] = 4 * v;
         } else {
-            t_l = v / G::TILE_FLOATS;
-            c_l = (v - t_l * G::TILE_FLOATS) / G::RS;
-            p = (v - t_l * G::TILE_FLOATS) - c_l * G::RS;
+            t_l = v / TILEF;
+            c_l = (v - t_l * TILEF) / G::RS;
+            p = (v - t_l * TILEF) - c_l * G::RS;
             s_dst[i] = v;
         }
         if (VEC) s_cl[i] = c_l;
@@ -241,7 +268,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         unsigned off = kOOB, off2 = kOOB;
         if (v < UNITS && t < a.T) {
             if (SRC == SRC_TILES) {
-                off = NHWC ? (unsigned)((t * G::RS + p) * Cin + c_l) * 4u : (unsigned)(t * Cin * G::RS + (v % (G::TILE_FLOATS / 4)) * 4) * 4u;
+                off = NHWC ? (unsigned)((t * G::RS + p) * Cin + c_l) * 4u : (unsigned)(t * Cin * G::RS + (v % (TILEF / 4)) * 4) * 4u;
             } else {
                 const int b = t / a.N;
                 const int n = t - b * a.N;
@@ -270,15 +297,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             }
         }
         s_off[i] = off;
-        if (TWO) s_off2[i] = off2;
-        if (AFF) s_tab[i] = (off != kOOB || off2 != kOOB) ? c_l : G::CC;
-    }
+        // GATHER / NHWC keeps the x2-side offset as a DELTA to the x side (added when a chunk lives in x2):
+        // a select between two array elements would make the compiler keep both arrays in scratch memory
+        if (TWO) s_off2[i] = (SRC == SRC_GATHER) ? (off == kOOB ? 0u : off2 - off) : off2;
+        if (AFF) s_tab[i] = (off != kOOB || off2 != kOOB) ? c_l : CCk;
+    });
 
     // descriptors of the staging sources, advanced to channel chunk `chunk` with scalar arithmetic
     rsrc_t r_a, r_a2;
     bool use2 = false;  // NHWC GATHER: this chunk's channels live in x2
     auto set_chunk = [&](int chunk) {
-        const int c0 = chunk * G::CC;
+        const int c0 = chunk * CCk;
         const long cstep = NHWC ? 1 : HW;  // elements between consecutive channels of a full tensor
         if (SRC == SRC_TILES) {
             r_a = make_rsrc(a.x, (long)c0 * (NHWC ? 1 : G::RS), (long)a.T * Cin * G::RS);
@@ -295,9 +324,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     // float4 units: a partial last chunk must not read past the source's channels
     // (NCHW tile slab: the next tile; NHWC: the next pixel)
     auto vec_off = [&](unsigned off, int i, int chunk, int csrc, int cbase) -> unsigned {
-        const int left = csrc - (chunk * G::CC - cbase);  // channels of this source from the chunk start on
+        const int left = csrc - (chunk * CCk - cbase);  // channels of this source from the chunk start on
         if (NHWC) return s_cl[i] < left ? off : kOOB;
-        return (int)((tid + 256 * i) % (G::TILE_FLOATS / 4)) * 4 < left * G::RS ? off : kOOB;
+        return (int)((tid + NT * i) % (TILEF / 4)) * 4 < left * G::RS ? off : kOOB;
     };
     auto slot_load = [&](int set, int i, int chunk) {
         if (!VEC) {
@@ -306,8 +335,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         } else if (SRC == SRC_TILES) {
             st_q[set][i] = buf_f32x4(r_a, vec_off(s_off[i], i, chunk, Cin, 0), 0);
         } else if (SRC == SRC_GATHER) {
-            const unsigned o = use2 ? vec_off(s_off2[i], i, chunk, Cin - a.Csplit, a.Csplit) : vec_off(s_off[i], i, chunk, a.Csplit, 0);
-            st_q[set][i] = buf_f32x4(r_a, o, 0);
+            const unsigned o = s_off[i] + (use2 ? s_off2[i] : 0u);
+            st_q[set][i] = buf_f32x4(r_a, vec_off(o, i, chunk, use2 ? Cin - a.Csplit : a.Csplit, use2 ? a.Csplit : 0), 0);
         } else {
             st_q[set][i] = buf_f32x4(r_a, vec_off(s_off[i], i, chunk, Cin, 0), 0);
             st_q2[set][i] = buf_f32x4(r_a2, vec_off(s_off2[i], i, chunk, Cin, 0), 0);
@@ -323,7 +352,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         return z;
     };
     auto slot_store = [&](int set, int i, float *buf, const float *tb) {
-        if (256 * (i + 1) > UNITS && tid >= UNITS - 256 * i) return;  // (only the last slot of a ragged split)
+        if (NT * (i + 1) > UNITS && tid >= UNITS - NT * i) return;  // (only the last slot of a ragged split)
         if (!VEC) {
             float z = st_z[set][i];
             if (SRC == SRC_SCATTER_GATHER) z += st_z2[set][i];  // exactly one of the two is data, the other an exact 0
@@ -346,11 +375,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         }
     };
     // (scale, shift) of channel chunk `chunk` for table entry (tid mod CC); entries past Cin are 0
-    const int trow = tid % G::CC;
+    const int trow = tid % CCk;
     float t_sc, t_sh;
     auto tab_load = [&](int chunk) {
         if (AFF) {
-            const int c = chunk * G::CC + trow;
+            const int c = chunk * CCk + trow;
             const int cc = c < Cin ? c : 0;
             const int b0 = (mb * G::TPB) / a.N;  // (a per-batch affine needs one batch per M block: host side)
             const float sc = a.scale[b0 * a.aff_sb + cc * a.aff_sc], sh = a.shift[b0 * a.aff_sb + cc * a.aff_sc];
@@ -362,13 +391,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         if (AFF) {
             tb[trow] = t_sc;
             tb[TROW + trow] = t_sh;
-            if (tid < 4) { tb[G::CC + tid] = 0.f; tb[TROW + G::CC + tid] = 0.f; }
+            if (tid < 4) { tb[CCk + tid] = 0.f; tb[TROW + CCk + tid] = 0.f; }
         }
     };
 
     // ---- B: F float4 per lane per chunk and N sub-block, contiguous per (ng, chunk, wave) ----
     const int ngtot = (a.Cout + G::MT - 1) / G::MT;
-    const long packed_floats_total = (long)ngtot * a.nchunks * 4 * G::F * 64 * 4;
+    const long packed_floats_total = (long)ngtot * a.nblk * G::F * 64 * 4;  // nblk = (4-wave chunks, padded to even) * 4
     int gsel[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) gsel[nb] = min(ng * NB + nb, ngtot - 1);  // past-the-end sub-blocks re-read the last one; stores are masked
@@ -376,7 +405,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     auto set_b_chunk = [&](int chunk) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
-            r_b[nb] = make_rsrc(a.packed, (((long)gsel[nb] * a.nchunks + chunk) * 4 + wave) * G::F * 64 * 4, packed_floats_total);
+            r_b[nb] = make_rsrc(a.packed, ((long)gsel[nb] * a.nblk + chunk * W + wave) * G::F * 64 * 4, packed_floats_total);
     };
     float4 bset[2][NB][G::F];
     auto b_load = [&](float4 &dst, int nb, int f) { dst = buf_f32x4(r_b[nb], lane * 16, f * 1024); };
@@ -393,7 +422,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     const int tl = j / G::PX, px = j % G::PX;
     const int oy = px / G::RO, ox = px % G::RO;
     const int a_base = NHWC ? (tl * G::RS + oy * G::S * G::R + ox * G::S) * LDC + wave * G::CW + kq
-                            : tl * G::TILE_FLOATS + (wave * G::CW + kq) * G::RS + oy * G::S * G::R + ox * G::S;
+                            : tl * TILEF + (wave * G::CW + kq) * G::RS + oy * G::S * G::R + ox * G::S;
     auto a_off = [](int u) {
         const int q = u / G::KK, tap = u % G::KK, pix = (tap / G::K) * G::R + (tap % G::K);
         return NHWC ? pix * LDC + q * G::NL : q * G::NL * G::RS + pix;
@@ -401,35 +430,33 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 
     // ---- prologue: chunks 0 / 1 -> register sets 0 / 1, B sets 0 / 1, tables 0 / 1;
     //      chunk 0 -> LDS[0]; register set 0 re-issued as chunk 2 ----
-    set_chunk(0);
-    set_b_chunk(0);
-#pragma unroll
-    for (int i = 0; i < NS; ++i) slot_load(0, i, 0);
+    set_chunk(first);
+    set_b_chunk(first);
+    static_for<0, NS>([&](auto i_tag) { slot_load(0, decltype(i_tag)::value, first); });
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int f = 0; f < G::F; ++f) b_load(bset[0][nb][f], nb, f);
-    set_chunk(min(1, last));
-    set_b_chunk(min(1, last));
-#pragma unroll
-    for (int i = 0; i < NS; ++i) slot_load(1, i, min(1, last));
+    set_chunk(min(first + 1, last));
+    set_b_chunk(min(first + 1, last));
+    static_for<0, NS>([&](auto i_tag) { slot_load(1, decltype(i_tag)::value, min(first + 1, last)); });
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int f = 0; f < G::F; ++f) b_load(bset[1][nb][f], nb, f);
     if (AFF) {
-        tab_load(0);
+        tab_load(first);
         tab_store(tab);
-        tab_load(min(1, last));
+        tab_load(min(first + 1, last));
         tab_store(tab + TABF);
         __syncthreads();
     }
-    set_chunk(min(2, last));
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
+    set_chunk(min(first + 2, last));
+    static_for<0, NS>([&](auto i_tag) {
+        constexpr int i = decltype(i_tag)::value;
         slot_store(0, i, smem, tab);
-        slot_load(0, i, min(2, last));
-    }
+        slot_load(0, i, min(first + 2, last));
+    });
     __syncthreads();
 
     // one chunk: MFMAs on LDS[PAR] with B set PAR; register set PAR^1 (chunk+1) -> LDS[PAR^1],
@@ -473,9 +500,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         __syncthreads();
     };
 
-    for (int chunk = 0; chunk < a.nchunks; chunk += 2) {
+    for (int chunk = first; chunk <= last; chunk += 2) {
         body(std::integral_constant<int, 0>{}, chunk);
-        if (chunk + 1 < a.nchunks) body(std::integral_constant<int, 1>{}, chunk + 1);
+        if (chunk + 1 <= last) body(std::integral_constant<int, 1>{}, chunk + 1);
     }
 
     // ---- K-split reduction across the 4 waves, bias, store -----------------
@@ -512,38 +539,52 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 
     constexpr int UNITS_NB = G::MT * G::MT / 4;         // float4 units per N sub-block
     constexpr int OUT_UNITS = NB * UNITS_NB;
+    // K split: every split writes its partial sums (no bias / residual) to its own copy of the output
+    // in the workspace; splitk_reduce_kernel adds them up in a fixed order (deterministic) with the epilogue
+    float *const outp = a.out + (size_t)split * a.split_stride;
+    const float *const biasp = a.ksplit > 1 ? nullptr : a.bias;
+    const float *const resp = a.ksplit > 1 ? nullptr : a.residual;
     if (NHWC) {
         // one float4 = 4 consecutive output channels of one pixel per lane and step
 #pragma unroll
-        for (int o = tid; o < OUT_UNITS; o += 256) {
+        for (int o = tid; o < OUT_UNITS; o += NT) {
             const int nb = o / UNITS_NB, o1 = o - nb * UNITS_NB;
             const int n4 = o1 % (G::MT / 4), m = o1 / (G::MT / 4);
             const float *r0 = red + (nb * G::MT + m) * RP + 4 * n4;
             float4 s = *reinterpret_cast<const float4 *>(r0);
 #pragma unroll
-            for (int w = 1; w < 4; ++w) {
+            for (int w = 1; w < W; ++w) {
                 const float4 v = *reinterpret_cast<const float4 *>(r0 + w * NB * G::MT * RP);
                 s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             }
             const int t_l = m / G::PX, pxo = m % G::PX;
             const int t = mb * G::TPB + t_l, co = (ng * NB + nb) * G::MT + 4 * n4;
             if (t < a.T && co < a.Cout) {  // (Cout % 4 == 0: host side)
-                if (a.bias) {
-                    const float4 bb = *reinterpret_cast<const float4 *>(a.bias + co);
+                if (biasp) {
+                    const float4 bb = *reinterpret_cast<const float4 *>(biasp + co);
                     s.x += bb.x; s.y += bb.y; s.z += bb.z; s.w += bb.w;
                 }
+                auto post = [&](float4 v) -> float4 {
+                    if (a.oscale && a.ksplit <= 1) {
+                        const float4 os = *reinterpret_cast<const float4 *>(a.oscale + co), oh = *reinterpret_cast<const float4 *>(a.oshift + co);
+                        v.x = os.x * v.x; v.y = os.y * v.y; v.z = os.z * v.z; v.w = os.w * v.w;
+                        v.x = oh.x + v.x; v.y = oh.y + v.y; v.z = oh.z + v.z; v.w = oh.w + v.w;
+                        if (a.oact == SIGE_HIP_ACT_SWISH) { v.x = swish(v.x); v.y = swish(v.y); v.z = swish(v.z); v.w = swish(v.w); }
+                    }
+                    return v;
+                };
                 if (DST == DST_TILES) {
-                    *reinterpret_cast<float4 *>(a.out + ((size_t)t * G::PX + pxo) * a.Cout + co) = s;
+                    *reinterpret_cast<float4 *>(outp + ((size_t)t * G::PX + pxo) * a.Cout + co) = post(s);
                 } else {
                     const int b = t / a.N, n = t - b * a.N;
                     const int h = (a.offH + a.idx[2 * n]) / a.strH + pxo / G::RO, w = (a.offW + a.idx[2 * n + 1]) / a.strW + pxo % G::RO;
                     if (h >= 0 && h < a.Ho && w >= 0 && w < a.Wo) {
                         const size_t q = (((size_t)b * a.Ho + h) * a.Wo + w) * a.Cout + co;
-                        if (a.residual) {
-                            const float4 rr = *reinterpret_cast<const float4 *>(a.residual + q);
+                        if (resp) {
+                            const float4 rr = *reinterpret_cast<const float4 *>(resp + q);
                             s.x += rr.x; s.y += rr.y; s.z += rr.z; s.w += rr.w;
                         }
-                        *reinterpret_cast<float4 *>(a.out + q) = s;
+                        *reinterpret_cast<float4 *>(outp + q) = post(s);
                     }
                 }
             }
@@ -553,7 +594,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     // NCHW: one float4 (4 consecutive pixels of one tile and one output channel) per lane and step
     constexpr int P4 = G::PX / 4;                       // float4 per (tile, channel)
 #pragma unroll
-    for (int o = tid; o < OUT_UNITS; o += 256) {
+    for (int o = tid; o < OUT_UNITS; o += NT) {
         const int nb = o / UNITS_NB, o1 = o - nb * UNITS_NB;
         const int p4 = o1 % P4;
         const int co_l = (o1 / P4) % G::MT;
@@ -562,16 +603,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         const float *r0 = red + (nb * G::MT + co_l) * RP + rrow;
         float4 s = *reinterpret_cast<const float4 *>(r0);
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
+        for (int w = 1; w < W; ++w) {
             const float4 v = *reinterpret_cast<const float4 *>(r0 + w * NB * G::MT * RP);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
         const int t = mb * G::TPB + t_l, co = (ng * NB + nb) * G::MT + co_l;
         if (t < a.T && co < a.Cout) {
-            const float bb = a.bias ? a.bias[co] : 0.0f;
+            const float bb = biasp ? biasp[co] : 0.0f;
             s.x += bb; s.y += bb; s.z += bb; s.w += bb;
             if (DST == DST_TILES) {
-                *reinterpret_cast<float4 *>(a.out + ((size_t)t * a.Cout + co) * G::PX + p4 * 4) = s;
+                *reinterpret_cast<float4 *>(outp + ((size_t)t * a.Cout + co) * G::PX + p4 * 4) = s;
             } else {
                 const int b = t / a.N, n = t - b * a.N;
                 const int h0 = (a.offH + a.idx[2 * n]) / a.strH, w0 = (a.offW + a.idx[2 * n + 1]) / a.strW;
@@ -584,16 +625,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                         const size_t q = plane + (size_t)h * a.Wo + w0;
                         if (w0 >= 0 && w0 + 3 < a.Wo && ((q & 3) == 0)) {
                             float4 ov = s;
-                            if (a.residual) {
-                                const float4 rr = *reinterpret_cast<const float4 *>(a.residual + q);
+                            if (resp) {
+                                const float4 rr = *reinterpret_cast<const float4 *>(resp + q);
                                 ov.x += rr.x; ov.y += rr.y; ov.z += rr.z; ov.w += rr.w;
                             }
-                            *reinterpret_cast<float4 *>(a.out + q) = ov;
+                            *reinterpret_cast<float4 *>(outp + q) = ov;
                         } else {
 #pragma unroll
                             for (int i = 0; i < 4; ++i)
                                 if (w0 + i >= 0 && w0 + i < a.Wo)
-                                    a.out[q + i] = sv[i] + (a.residual ? a.residual[q + i] : 0.0f);
+                                    outp[q + i] = sv[i] + (resp ? resp[q + i] : 0.0f);
                         }
                     }
                 } else {
@@ -603,7 +644,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                         const int h = h0 + pp / G::RO, w = w0 + pp % G::RO;
                         if (h >= 0 && h < a.Ho && w >= 0 && w < a.Wo) {
                             const size_t q = plane + (size_t)h * a.Wo + w;
-                            a.out[q] = sv[i] + (a.residual ? a.residual[q] : 0.0f);
+                            outp[q] = sv[i] + (resp ? resp[q] : 0.0f);
                         }
                     }
                 }
@@ -613,25 +654,25 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 }
 
 // ---- launch ------------------------------------------------------------------
-template <typename G, int NB, int SRC, int DST, int LAYOUT>
+template <typename G, int NB, int SRC, int DST, int LAYOUT, int W>
 void launch_conv_geo(ConvArgs a, int mode, hipStream_t st);
 
 // mode: MODE_* (host side maps (scale, shift, activation) onto it)
-#define SIGE_CONV_LAUNCH3(G, NB, SRC, DST, LAY)                                                           \
-    template <> void launch_conv_geo<G, NB, SRC, DST, LAY>(ConvArgs a, int mode, hipStream_t st) {        \
-        const int grid = a.mbk * a.ngk;                                                                   \
-        if (mode == MODE_AFFINE_SWISH) conv_mfma_kernel<G, NB, SRC, MODE_AFFINE_SWISH, DST, LAY><<<grid, 256, 0, st>>>(a); \
-        else if (mode == MODE_AFFINE) conv_mfma_kernel<G, NB, SRC, MODE_AFFINE, DST, LAY><<<grid, 256, 0, st>>>(a);        \
-        else conv_mfma_kernel<G, NB, SRC, MODE_RAW, DST, LAY><<<grid, 256, 0, st>>>(a);                   \
+#define SIGE_CONV_LAUNCH3(G, NB, SRC, DST, LAY, W)                                                        \
+    template <> void launch_conv_geo<G, NB, SRC, DST, LAY, W>(ConvArgs a, int mode, hipStream_t st) {     \
+        const dim3 grid(a.mbk * a.ngk, a.ksplit);                                                         \
+        if (mode == MODE_AFFINE_SWISH) conv_mfma_kernel<G, NB, SRC, MODE_AFFINE_SWISH, DST, LAY, W><<<grid, 64 * W, 0, st>>>(a); \
+        else if (mode == MODE_AFFINE) conv_mfma_kernel<G, NB, SRC, MODE_AFFINE, DST, LAY, W><<<grid, 64 * W, 0, st>>>(a);        \
+        else conv_mfma_kernel<G, NB, SRC, MODE_RAW, DST, LAY, W><<<grid, 64 * W, 0, st>>>(a);             \
     }
 
 // explicit-instantiation helper used by the per-geometry translation units
-#define SIGE_CONV_INSTANTIATE(G, NB, LAY)                                                                 \
-    template <> void launch_conv_geo<G, NB, SRC_TILES, DST_TILES, LAY>(ConvArgs a, int, hipStream_t st) { \
-        conv_mfma_kernel<G, NB, SRC_TILES, MODE_RAW, DST_TILES, LAY><<<a.mbk * a.ngk, 256, 0, st>>>(a);   \
+#define SIGE_CONV_INSTANTIATE(G, NB, LAY, W)                                                              \
+    template <> void launch_conv_geo<G, NB, SRC_TILES, DST_TILES, LAY, W>(ConvArgs a, int, hipStream_t st) { \
+        conv_mfma_kernel<G, NB, SRC_TILES, MODE_RAW, DST_TILES, LAY, W><<<dim3(a.mbk * a.ngk, a.ksplit), 64 * W, 0, st>>>(a); \
     }                                                                                                     \
-    SIGE_CONV_LAUNCH3(G, NB, SRC_GATHER, DST_TILES, LAY)                                                  \
-    SIGE_CONV_LAUNCH3(G, NB, SRC_GATHER, DST_NCHW, LAY)                                                   \
-    SIGE_CONV_LAUNCH3(G, NB, SRC_SCATTER_GATHER, DST_TILES, LAY)
+    SIGE_CONV_LAUNCH3(G, NB, SRC_GATHER, DST_TILES, LAY, W)                                               \
+    SIGE_CONV_LAUNCH3(G, NB, SRC_GATHER, DST_NCHW, LAY, W)                                                \
+    SIGE_CONV_LAUNCH3(G, NB, SRC_SCATTER_GATHER, DST_TILES, LAY, W)
 
 }  // namespace sige

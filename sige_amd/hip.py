@@ -63,6 +63,7 @@ _SIGNATURES = {
     "sige_hip_group_norm_affine_f32": (_c_int, [_c_vp] + [_c_int] * 5 + [ctypes.c_float] + [_c_vp] * 6),
     "sige_hip_block_conv_direct_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp] + [_c_int] * 6 + [_c_vp, _c_vp]),
     "sige_hip_block_conv_force_tile": (_c_int, [_c_int, _c_int]),
+    "sige_hip_block_conv_force_waves": (_c_int, [_c_int]),
     "sige_hip_attention_workspace": (_c_sz, [_c_int] * 3),
     "sige_hip_attention_f32": (_c_int, [_c_vp, _c_int, _c_int, _c_int, ctypes.c_float, _c_vp, _c_vp, _c_vp]),
     "sige_hip_copy_f32": (_c_int, [_c_vp, _c_vp, _c_sz, _c_vp]),
@@ -70,7 +71,8 @@ _SIGNATURES = {
     "sige_hip_block_conv_nhwc_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp, _c_vp]),
     "sige_hip_gather_conv_nhwc_f32": (
         _c_int, [_c_vp, _c_vp] + [_c_int] * 7 + [_c_vp, _c_int] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
-        + [_c_int] * 5 + [_c_int, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_vp, _c_vp]),
+        + [_c_int] * 5 + [_c_int, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_vp, _c_sz, _c_vp, _c_vp, _c_int, _c_vp, _c_vp]),
+    "sige_hip_conv_ksplit_hint": (_c_int, [_c_int] * 7),
     "sige_hip_scatter_gather_conv_nhwc_f32": (
         _c_int, [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
         + [_c_int] * 5 + [_c_vp, _c_vp]),
@@ -308,6 +310,11 @@ def conv_pack_weights(weight: torch.Tensor, R: int, S: int, stride: Tuple[int, i
 def conv_force_tile(mt: int = 0, nb: int = 0):
     """Benchmark knob: pin the MFMA conv's output block (0, 0 = automatic)."""
     _check(lib().sige_hip_block_conv_force_tile(mt, nb), "conv_force_tile")
+
+
+def conv_force_waves(waves: int = 0):
+    """Benchmark knob: 4 or 8 waves per workgroup for the channels-last stride-1 convs (0 = automatic)."""
+    _check(lib().sige_hip_block_conv_force_waves(waves), "conv_force_waves")
 
 
 def block_conv(x, packed, bias, Cout: int, kernel: Tuple[int, int], stride: Tuple[int, int]):
@@ -555,7 +562,7 @@ def block_conv_cl(x, packed, bias, Cout: int, kernel: Tuple[int, int], stride: T
 
 def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, activationName: str,
                    packed, bias, Cout: int, kernel: Tuple[int, int], stride: Tuple[int, int],
-                   full: Optional[dict] = None):
+                   full: Optional[dict] = None, out_affine: Optional[tuple] = None):
     """Channels-last gather -> conv.  `full` = dict(offset=(oh, ow), out_res=(Ho, Wo), residual=tensor|None)
     writes the output tiles straight into a [B,Cout,Ho,Wo] tensor (dense layers).  None if unsupported."""
     x = _req_cl(x, "x")
@@ -580,6 +587,22 @@ def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, a
             if tuple(r.shape) != tuple(out.shape):
                 raise RuntimeError("gather_conv_cl: residual %s != output %s" % (tuple(r.shape), tuple(out.shape)))
         fargs = (1, full["offset"][0], full["offset"][1], None if r is None else r.data_ptr(), Ho, Wo)
+    # deep-K convs over a handful of tiles: workspace for the cross-workgroup K split
+    ws, ws_n = None, 0
+    ks = lib().sige_hip_conv_ksplit_hint(B * N, C1 + C2, Cout, kernel[0], kernel[1], stride[0], stride[1])
+    if ks > 1 and os.environ.get("SIGE_AMD_KSPLIT", "1") != "0":
+        ws_n = ks * out.numel()
+        ws = torch.empty(ws_n, dtype=torch.float32, device=x.device)
+    fargs = fargs + (None if ws is None else ws.data_ptr(), ws_n)
+    # epilogue affine + activation of the consumer: (scale [*,Cout,1,1], shift, activation name)
+    if out_affine is not None:
+        os_, oh_, oact = out_affine
+        os_, oh_ = _req(os_.reshape(-1), torch.float32, "out_scale", 1), _req(oh_.reshape(-1), torch.float32, "out_shift", 1)
+        if os_.numel() != Cout or oh_.numel() != Cout:
+            raise RuntimeError("gather_conv_cl: out_affine must have one entry per output channel")
+        fargs = fargs + (os_.data_ptr(), oh_.data_ptr(), _act(oact))
+    else:
+        fargs = fargs + (None, None, 0)
     status = lib().sige_hip_gather_conv_nhwc_f32(
         x.data_ptr(), None if x2 is None else x2.data_ptr(), B, C1, C2, H, W, block[0], block[1], idx.data_ptr(), N,
         *sa, *ta, _act(activationName), packed.data_ptr(), _bias_ptr(bias), Cout, kernel[0], kernel[1],

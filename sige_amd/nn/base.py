@@ -144,8 +144,24 @@ class SIGEConv2d(nn.Conv2d, SIGEModule):
             self._packed_key = key
         return self._packed
 
-    def _block_conv(self, x: torch.Tensor) -> torch.Tensor:
+    def _block_conv(self, x: torch.Tensor, out_affine=None) -> torch.Tensor:
         from .. import hip
+
+        if out_affine is not None:
+            # the consumer's affine + activation: in the fused channels-last kernel's epilogue, else as torch ops
+            spec = x.spec if isinstance(x, deferred.DeferredTiles) else None
+            packed = self._packed_weights(x) if self.groups == 1 and tuple(self.dilation) == (1, 1) else None
+            if (packed is not None and spec is not None and spec["kind"] == "gather" and spec.get("cl", False)
+                    and self.out_channels % 4 == 0):
+                out = hip.gather_conv_cl(spec["x"], spec.get("x2"), spec["block"], spec["idx"], spec["scale"], spec["shift"],
+                                         spec["act"], packed, self.bias, self.out_channels, self.kernel_size, self.stride,
+                                         out_affine=out_affine)
+                if out is not None:
+                    return out
+            out = self._block_conv(x)
+            os_, oh_, oact = out_affine
+            out = out * os_.reshape(1, -1, 1, 1) + oh_.reshape(1, -1, 1, 1)
+            return F.silu(out) if oact == "swish" else out
 
         if tuple(self.dilation) != (1, 1):  # no dilated kernel in libsige_hip: torch's conv
             return F.conv2d(deferred.resolve(x), self.weight, self.bias, self.stride, (0, 0), self.dilation,
@@ -180,14 +196,20 @@ class SIGEConv2d(nn.Conv2d, SIGEModule):
             return hip.block_conv(x, packed, self.bias, self.out_channels, self.kernel_size, self.stride)
         return hip.block_conv_direct(x, self.weight, self.bias, self.stride, self.groups)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, out_affine=None) -> torch.Tensor:
+        """`out_affine` (sparse mode only, not in the reference): (scale, shift, activation) applied to the
+        output tiles -- the consumer's cached GroupNorm affine + SiLU, fused into the kernel's epilogue."""
         if self.mode == "full":
             output = super(SIGEConv2d, self).forward(x)
         elif self.mode == "sparse":
             if x.is_cuda and x.dtype == torch.float32 and _conv_backend() == "hip":
-                output = self._block_conv(x)
+                output = self._block_conv(x, out_affine)
             else:
                 output = F.conv2d(x, self.weight, self.bias, self.stride, (0, 0), self.dilation, self.groups)
+                if out_affine is not None:
+                    os_, oh_, oact = out_affine
+                    output = output * os_.reshape(1, -1, 1, 1) + oh_.reshape(1, -1, 1, 1)
+                    output = F.silu(output) if oact == "swish" else output
         elif self.mode == "profile":
             output = F.conv2d(x, self.weight, self.bias, self.stride, (0, 0), self.dilation, self.groups)
         else:

@@ -55,9 +55,19 @@ def _act(x, name):
 def fused_conv2d(conv: nn.Conv2d, x: torch.Tensor, scale: Optional[torch.Tensor] = None,
                  shift: Optional[torch.Tensor] = None, activation_name: str = "identity",
                  x2: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-                 pad_bottom_right: bool = False) -> torch.Tensor:
+                 pad_bottom_right: bool = False, out_affine: Optional[tuple] = None) -> torch.Tensor:
     """conv(act(cat(x, x2) * scale + shift)) + residual.  scale/shift: [1|B, C, 1, 1].
-    `pad_bottom_right`: the DDPM downsample's (0,1,0,1) zero padding (stride-2 convs)."""
+    `pad_bottom_right`: the DDPM downsample's (0,1,0,1) zero padding (stride-2 convs).
+    `out_affine` = (scale, shift, activation) of the CONSUMER, applied to the result in the kernel's
+    epilogue (one launch, once per element): act(out * scale + shift)."""
+    out = _fused_conv2d(conv, x, scale, shift, activation_name, x2, residual, pad_bottom_right, out_affine)
+    if isinstance(out, tuple):  # (tensor, epilogue still to apply)
+        out, (os_, oh_, oact) = out
+        out = _act(out * os_.reshape(1, -1, 1, 1) + oh_.reshape(1, -1, 1, 1), oact)
+    return out
+
+
+def _fused_conv2d(conv, x, scale, shift, activation_name, x2, residual, pad_bottom_right, out_affine):
     if x.is_cuda and x.dtype == torch.float32 and fusable(conv):
         from .. import hip
 
@@ -72,7 +82,7 @@ def fused_conv2d(conv: nn.Conv2d, x: torch.Tensor, scale: Optional[torch.Tensor]
         else:
             Ho, Wo = H, W
         if (hip.is_cl(x) and conv.out_channels <= 4 and tuple(conv.kernel_size) == (3, 3) and conv.stride[0] == 1
-                and x2 is None and residual is None):
+                and x2 is None and residual is None and out_affine is None):
             out = hip.conv3x3_small_cout_cl(x, conv.weight, conv.bias, scale, shift, activation_name)
             if out is not None:
                 return out
@@ -80,13 +90,14 @@ def fused_conv2d(conv: nn.Conv2d, x: torch.Tensor, scale: Optional[torch.Tensor]
         if hip.is_cl(x) and hip.cl_supported(x.shape[1], 0 if x2 is None else x2.shape[1], conv.out_channels):
             out = hip.gather_conv_cl(x, x2, block, idx, scale, shift, activation_name, _packed(conv, block), conv.bias,
                                      conv.out_channels, conv.kernel_size, conv.stride,
-                                     full=dict(offset=offset, out_res=(Ho, Wo), residual=residual))
+                                     full=dict(offset=offset, out_res=(Ho, Wo), residual=residual), out_affine=out_affine)
             if out is not None:
                 return out
-        return hip.gather_conv_nchw(x.contiguous(), None if x2 is None else x2.contiguous(), block, idx,
+        out = hip.gather_conv_nchw(x.contiguous(), None if x2 is None else x2.contiguous(), block, idx,
                                     scale, shift, activation_name, _packed(conv, block), conv.bias,
                                     conv.out_channels, conv.kernel_size, conv.stride, offset, (Ho, Wo),
                                     None if residual is None else residual.contiguous())
+        return out if out_affine is None else (out, out_affine)
     h = x if x2 is None else torch.cat([x, x2], dim=1)
     if scale is not None:
         h = h * scale
@@ -96,7 +107,8 @@ def fused_conv2d(conv: nn.Conv2d, x: torch.Tensor, scale: Optional[torch.Tensor]
     if pad_bottom_right:
         h = F.pad(h, (0, 1, 0, 1))
     h = conv(h)
-    return h if residual is None else h + residual
+    h = h if residual is None else h + residual
+    return h if out_affine is None else (h, out_affine)
 
 
 def group_norm_affine(x: torch.Tensor, norm: nn.GroupNorm) -> Tuple[torch.Tensor, torch.Tensor]:

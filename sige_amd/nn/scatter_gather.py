@@ -29,10 +29,12 @@ class ScatterGather(SIGEModule):
         self.scatter_map = None
         self.output_res = None
         self.original_outputs = {}
+        self.activated_outputs = {}  # see cache_activated()
         self._maps: Dict = {}
 
     def clear_cache(self):
         self.original_outputs = {}
+        self.activated_outputs = {}  # see cache_activated()
 
     def _build_map(self, idx: torch.Tensor) -> torch.Tensor:
         g: Gather = self.gather.module
@@ -54,12 +56,45 @@ class ScatterGather(SIGEModule):
                 self._maps[device] = m
         return m if m.is_contiguous() else m.contiguous()
 
+    def cache_activated(self, scale: torch.Tensor, shift: torch.Tensor):
+        """(not in the reference) After a full-mode forward: also keep act(scale * cached + shift).  A sparse
+        forward may then be handed tiles that the producing conv already activated (SIGEConv2d `out_affine`)
+        with `preactivated=True`: both sources of the scatter-gather are final values and the conv stages them
+        raw -- the affine + SiLU is computed once per element instead of once per output-channel block."""
+        from .utils import activation as act_fn
+
+        y = self.original_outputs[self.cache_id]
+        self.activated_outputs[self.cache_id] = deferred.keep_layout(act_fn(y * scale + shift, self.activation_name))
+
     def forward(
-        self, x: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None
+        self, x: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
+        preactivated: bool = False
     ) -> torch.Tensor:
         self.check_dtype(x, scale, shift)
         self.check_dim(x, scale, shift)
         g: Gather = self.gather.module
+        if self.mode == "sparse" and preactivated:
+            assert scale is None and shift is None and not self.sparse_update
+            cached = self.activated_outputs[self.cache_id]
+            x = deferred.resolve(x)
+            cl = deferred.channels_last_ok(cached)
+            x = x.contiguous(memory_format=torch.channels_last) if cl else x.contiguous()
+            idx, smap = g.indices_on(x.device), self._map_on(x.device)
+            bh, bw = g.block_size
+
+            def run_pre():
+                if cl:
+                    from .. import hip
+
+                    return hip.scatter_gather_cl(x, cached, bh, bw, idx, smap, None, None, "identity")
+                return self.native(self.runtime, x)(x, cached.contiguous(), bh, bw, idx, smap, None, None, "identity", False)
+
+            if deferred.defer_ok(x, None, None, False, False, "identity"):
+                return deferred.DeferredTiles(
+                    (cached.shape[0] * idx.shape[0], x.shape[1], bh, bw), x.dtype, x.device, run_pre,
+                    dict(kind="scatter_gather", x=x, y=cached, block=(bh, bw), idx=idx, map=smap, scale=None, shift=None,
+                         act="identity", cl=cl))
+            return run_pre()
         if self.mode == "sparse":
             cached = self.original_outputs[self.cache_id]
             fn = self.native(self.runtime, x)

@@ -28,7 +28,7 @@ def cache_slots(model: torch.nn.Module) -> List[Tuple[dict, object, object]]:
     (identical on every rank that built the same model)."""
     slots = []
     for m in model.modules():
-        for attr in ("original_outputs", "original_residuals"):
+        for attr in ("original_outputs", "original_residuals", "activated_outputs"):
             d = getattr(m, attr, None)
             if isinstance(d, dict):
                 slots.extend((d, k, None) for k in sorted(d))

@@ -49,6 +49,9 @@ class DDPMConfig:
     # pass normalises every channel with channel 0's statistics.  True reproduces
     # that (bit-for-bit model-level parity tests); False is the intended math.
     reference_attn_quirk: bool = False
+    # conv1's epilogue applies the cached affine-2 + SiLU (and the ScatterGather cache keeps an activated copy),
+    # so conv2 stages raw values: the activation is computed once per element, not once per output-channel block
+    preactivate: bool = True
 
 
 def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
@@ -100,6 +103,7 @@ class ResBlock(SIGEModule):
             self.scatter = Scatter(self.main_gather)
         self.affine = {}  # cache_id -> (scale1, shift1, scale2, shift2) as [1,C,1,1]
         self.plain = False
+        self.preactivate = cfg.preactivate
 
     def clear_cache(self):
         self.affine = {}
@@ -146,12 +150,18 @@ class ResBlock(SIGEModule):
         s2, t2 = norm_affine(h + _as4(te), self.norm2)
         t2 = t2 + te * s2  # fold the timestep-embedding add into the cached shift
         self.affine[self.cache_id] = tuple(_as4(v).contiguous() for v in (s1, t1, s2, t2))
+        if self.sparse_main and self.preactivate:
+            self.scatter_gather.cache_activated(_as4(s2), _as4(t2))
         h = self.conv2(F.silu(h * _as4(s2) + _as4(t2)))
         return self.scatter(h, skip) if self.sparse_main else h + skip
 
     def _sparse(self, x):
         s1, t1, s2, t2 = self.affine[self.cache_id]
         skip = self._shortcut(x)
+        if self.sparse_main and self.preactivate and self.mode == "sparse":
+            h = self.conv1(self.main_gather(x, s1, t1), out_affine=(s2, t2, "swish"))
+            h = self.conv2(self.scatter_gather(h, preactivated=True))
+            return self.scatter(h, skip)
         if self.sparse_main:
             h = self.conv1(self.main_gather(x, s1, t1))
             h = self.conv2(self.scatter_gather(h, s2, t2))
@@ -165,6 +175,9 @@ class ResBlock(SIGEModule):
             skip = x if x2 is None else torch.cat([x, x2], dim=1)
         else:
             skip = fused_conv2d(self.nin_shortcut, x, x2=x2)
+        if self.preactivate:
+            h = fused_conv2d(self.conv1, x, s1, t1, "swish", x2=x2, out_affine=(s2, t2, "swish"))
+            return fused_conv2d(self.conv2, h, residual=skip)
         h = fused_conv2d(self.conv1, x, s1, t1, "swish", x2=x2)
         return fused_conv2d(self.conv2, h, s2, t2, "swish", residual=skip)
 

@@ -87,10 +87,12 @@ def test_scatter_cl_full_and_in_place(hip, B, C, res):
     assert torch.equal(out.contiguous(), want)
 
 
+@pytest.mark.parametrize("waves", [4, 8])
 @pytest.mark.parametrize("mt,nb", [(0, 0), (16, 1), (16, 2), (32, 1), (32, 2)])
 @pytest.mark.parametrize("cin,c2,cout,k,stride,blk,off", [(128, 0, 128, 3, 1, 6, 1), (64, 40, 200, 3, 1, 6, 1), (96, 0, 64, 1, 1, 4, 0),
-                                                          (256, 44, 40, 1, 1, 4, 0), (64, 0, 72, 3, 2, 5, 0), (68, 0, 24, 3, 1, 6, 1)])
-def test_conv_cl_vs_nchw(hip, mt, nb, cin, c2, cout, k, stride, blk, off):
+                                                          (256, 44, 40, 1, 1, 4, 0), (64, 0, 72, 3, 2, 5, 0), (68, 0, 24, 3, 1, 6, 1),
+                                                          (128, 64, 64, 3, 1, 6, 1), (512, 256, 48, 1, 1, 4, 0)])
+def test_conv_cl_vs_nchw(hip, waves, mt, nb, cin, c2, cout, k, stride, blk, off):
     from sige_amd.utils import reduce_mask
 
     torch.manual_seed(cin + cout + mt + nb)
@@ -104,6 +106,7 @@ def test_conv_cl_vs_nchw(hip, mt, nb, cin, c2, cout, k, stride, blk, off):
     packed = hip.conv_pack_weights(w, blk, blk, (stride, stride))
     conv = lambda t: torch.nn.functional.conv2d(t.double(), w.double(), bias.double(), stride).float()  # noqa: E731
     hip.conv_force_tile(mt, nb)
+    hip.conv_force_waves(waves)
     try:
         for act, sc, sh in (("swish", scale, shift), ("identity", scale, shift), ("identity", None, None)):
             tiles = hip.gather(x, blk, blk, idx, sc, sh, act, False)
@@ -136,6 +139,7 @@ def test_conv_cl_vs_nchw(hip, mt, nb, cin, c2, cout, k, stride, blk, off):
                 torch.testing.assert_close(got.contiguous(), conv(sg), rtol=0, atol=1e-4)
     finally:
         hip.conv_force_tile(0, 0)
+        hip.conv_force_waves(0)
 
 
 @pytest.mark.parametrize("shape,groups", [((1, 128, 256, 256), 32), ((2, 64, 17, 23), 16), ((1, 512, 8, 8), 32)])
@@ -246,3 +250,52 @@ def test_lazy_cat_feeds_fused_gather(hip, c1, c2, k):
         want = conv(gather(torch.cat([a, b], 1), scale, shift))
     torch.testing.assert_close(got.contiguous(), want.contiguous(), rtol=0, atol=1e-5)
     assert lazy.spec is not None or (c1 % 32) != 0  # the cat never ran when the split sits on a chunk boundary
+
+
+@pytest.mark.parametrize("res,c1,c2,cout,k,stride", [(8, 512, 0, 512, 3, 1), (8, 512, 512, 512, 3, 1), (8, 512, 256, 512, 1, 1),
+                                                     (16, 512, 0, 512, 3, 1), (32, 256, 256, 256, 3, 1), (16, 256, 0, 256, 3, 2),
+                                                     (8, 64, 0, 48, 3, 1)])
+def test_dense_fused_conv_cl(hip, res, c1, c2, cout, k, stride):
+    """Dense layers, channels-last: conv(swish(cat(x,x2)*s+t)) + residual == torch, including the
+    8x8 layers that take the cross-workgroup K split (workspace + deterministic second pass)."""
+    from torch import nn
+
+    from sige_amd.nn.dense import fused_conv2d
+
+    torch.manual_seed(res + c1 + k)
+    conv = nn.Conv2d(c1 + c2, cout, k, stride, 0 if stride == 2 else k // 2).to(DEV)
+    x = _cl(torch.randn(1, c1, res, res, device=DEV))
+    x2 = _cl(torch.randn(1, c2, res, res, device=DEV)) if c2 else None
+    s, t = torch.randn(1, c1 + c2, 1, 1, device=DEV), torch.randn(1, c1 + c2, 1, 1, device=DEV)
+    ro = res if stride == 1 else res // 2
+    residual = _cl(torch.randn(1, cout, ro, ro, device=DEV))
+    with torch.no_grad():
+        got = fused_conv2d(conv, x, s, t, "swish", x2=x2, residual=residual, pad_bottom_right=stride == 2)
+        assert hip.is_cl(got) or got.shape[2] == 1
+        h = x if x2 is None else torch.cat([x, x2], 1)
+        h = torch.nn.functional.silu(h * s + t)
+        if stride == 2:
+            h = torch.nn.functional.pad(h, (0, 1, 0, 1))
+        want = torch.nn.functional.conv2d(h.double(), conv.weight.double(), conv.bias.double(), stride,
+                                          conv.padding).float() + residual
+        torch.testing.assert_close(got.contiguous(), want.contiguous(), rtol=0, atol=2e-4)
+        again = fused_conv2d(conv, x, s, t, "swish", x2=x2, residual=residual, pad_bottom_right=stride == 2)
+        assert torch.equal(again, got)  # the K split is deterministic
+
+
+@pytest.mark.parametrize("res,cin,cout", [(16, 128, 96), (8, 512, 256)])
+def test_epilogue_affine_activation(hip, res, cin, cout):
+    """out_affine: the consumer's affine + SiLU in the producer's epilogue (also through the K split)."""
+    from torch import nn
+
+    from sige_amd.nn.dense import fused_conv2d
+
+    torch.manual_seed(res + cin)
+    conv = nn.Conv2d(cin, cout, 3, 1, 1).to(DEV)
+    x = _cl(torch.randn(1, cin, res, res, device=DEV))
+    residual = _cl(torch.randn(1, cout, res, res, device=DEV))
+    os_, oh_ = torch.randn(1, cout, 1, 1, device=DEV), torch.randn(1, cout, 1, 1, device=DEV)
+    with torch.no_grad():
+        got = fused_conv2d(conv, x, residual=residual, out_affine=(os_, oh_, "swish"))
+        want = torch.nn.functional.silu((conv(x.contiguous()) + residual) * os_ + oh_)
+    torch.testing.assert_close(got.contiguous(), want.contiguous(), rtol=0, atol=2e-4)

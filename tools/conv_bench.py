@@ -81,15 +81,19 @@ def sparse_case(name, T, cin, cout, k, stride, R, res, dev, nsets=4):
     return run, check, flop
 
 
+CL = False
+
+
 def dense_case(name, res, c1, c2, cout, k, stride, dev, nsets=4):
     conv = torch.nn.Conv2d(c1 + c2, cout, k, stride, 0 if stride == 2 else k // 2).to(dev)
     from sige_amd.nn.dense import fused_conv2d
 
-    xs = [torch.randn(1, c1, res, res, device=dev) for _ in range(nsets)]
-    x2s = [torch.randn(1, c2, res, res, device=dev) for _ in range(nsets)] if c2 else [None] * nsets
+    fmt = torch.channels_last if CL else torch.contiguous_format
+    xs = [torch.randn(1, c1, res, res, device=dev).contiguous(memory_format=fmt) for _ in range(nsets)]
+    x2s = [torch.randn(1, c2, res, res, device=dev).contiguous(memory_format=fmt) for _ in range(nsets)] if c2 else [None] * nsets
     s, t = torch.randn(1, c1 + c2, 1, 1, device=dev), torch.randn(1, c1 + c2, 1, 1, device=dev)
     ro = res if stride == 1 else res // 2
-    residual = torch.randn(1, cout, ro, ro, device=dev)
+    residual = torch.randn(1, cout, ro, ro, device=dev).contiguous(memory_format=fmt)
 
     def run(i):
         with torch.no_grad():
@@ -103,7 +107,7 @@ def dense_case(name, res, c1, c2, cout, k, stride, dev, nsets=4):
             if stride == 2:
                 h = F.pad(h, (0, 1, 0, 1))
             want = F.conv2d(h.double(), conv.weight.double(), conv.bias.double(), stride, conv.padding).float() + residual
-            return (got - want).abs().max().item()
+            return (got.contiguous() - want).abs().max().item()
 
     flop = 2.0 * ro * ro * cout * (c1 + c2) * k * k
     return run, check, flop
@@ -136,7 +140,10 @@ def main():
     ap.add_argument("--sparse", action="store_true")
     ap.add_argument("--tiles", default="auto,16x1,16x2,32x1,32x2")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--cl", action="store_true", help="dense cases in channels-last")
     a = ap.parse_args()
+    global CL
+    CL = a.cl
     if not a.dense and not a.sparse:
         a.dense = a.sparse = True
     dev = torch.device("cuda")
