@@ -149,6 +149,17 @@ def a_numel(t):
     return t.numel()
 
 
+def pmc_traffic(family):
+    """HBM-side bytes per launch of a kernel family from the committed rocprofv3 PMC pass (bench.py cannot
+    run the profiler on itself); None if the file or the family is missing."""
+    try:
+        with open(os.path.join(REPO, "profiles", "r1g_pmc_traffic.json")) as f:
+            fam = json.load(f)["families"][family]
+        return int(fam["traffic_MB_per_launch"] * 1e6)
+    except Exception:
+        return None
+
+
 def shape_key(name, a):
     parts = [name]
     for v in a:
@@ -456,13 +467,16 @@ def main():
                 result["roofline"] = {
                     "kernel": dom, "bound": "mfma" if is_mfma else "hbm",
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s" if is_mfma else "GB/s",
-                    "frac": round(achieved / peak, 4), "traffic": None,
+                    "frac": round(achieved / peak, 4), "traffic": pmc_traffic(dom),
                     "launches_per_forward": launches, "avg_launch_us": round(tot_us / launches, 2),
                     "work_per_launch": round(tot_work / launches / (1e9 if is_mfma else 1e6), 4),
                     "work_unit": "GFLOP" if is_mfma else "MB",
                     "note": "algorithmic work of all %d launches of this kernel in one forward / their summed "
                             "duration (hipGraph of back-to-back launches, HIP events on the launch stream, "
-                            "rotating input sets); traffic: see profiles/ (PMC pass)" % launches}
+                            "rotating input sets); traffic = bytes per launch from the committed PMC pass "
+                            "profiles/r1g_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs, "
+                            "FETCH_SIZE doubled per the gfx950 correction; L2-miss traffic incl. Infinity-Cache hits)"
+                            % launches}
                 # secondary: the HBM-bound copy-through scatter at its largest shape
                 sc = [c for c in per_cfg.values() if c["family"].startswith("scatter")]
                 if sc:

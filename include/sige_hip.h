@@ -236,10 +236,13 @@ int sige_hip_gather_conv_nhwc_f32(const float *x, const float *x2, int B, int C1
                                   int to_full, int offsetH, int offsetW, const float *residual, int Ho, int Wo,
                                   float *workspace, size_t workspace_floats,
                                   const float *out_scale, const float *out_shift, int out_activation,
+                                  int upsample2x,
                                   float *out, void *stream);
 /* `out_scale` / `out_shift` ([Cout], optional): epilogue out = act(out_scale * (conv + bias + residual) + out_shift)
  * -- the CONSUMER's cached GroupNorm affine + SiLU applied by the producer, once per element; the consumer then
- * gathers with no affine (e.g. conv1 -> conv2 of a ResBlock, sige_fused_unet.py:112-125).                     */
+ * gathers with no affine (e.g. conv1 -> conv2 of a ResBlock, sige_fused_unet.py:112-125).
+ * `upsample2x` = 1: x / x2 are [B,H/2,W/2,C] and the gather reads pixel (h/2, w/2): the x2 nearest-neighbour
+ * upsampling in front of the U-Net's Upsample conv (sige_fused_unet.py: F.interpolate) fused into the gather. */
 /* `workspace` (optional, NULL = none): room for up to 8 copies of the output.  When the conv has
  * too few tiles to cover the chip with ANY block shape (the 8x8 layers: 64 pixels, K up to 9216),
  * the channel chunks are split across workgroups that write partial sums there, and a second

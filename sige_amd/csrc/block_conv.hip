@@ -138,6 +138,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_nhwc_kernel(const float *__
 // cover the chip: every wave then runs K/4 MFMA steps back to back however few tiles there are
 // (the 8x8 layers of the U-Net: 64 pixels, K = 4608..9216), so the chunks are shared out.
 static int ksplit_for(long blocks, int nchunks, int cap) {
+    // (the second pass costs ~4.7 us per launch; measured on the DDPM-256 dense remainder the split still
+    //  wins 140 us per forward: 923 vs 1064 us over its 58 conv launches)
     if (cap <= 1 || blocks >= 224) return 1;
     int s = (int)((224 + blocks - 1) / blocks);
     s = s < nchunks / 2 ? s : nchunks / 2;  // >= 2 chunks per split (the software pipeline's depth)
@@ -459,8 +461,10 @@ extern "C" int sige_hip_gather_conv_nhwc_f32(const float *x, const float *x2, in
                                              int to_full, int offsetH, int offsetW, const float *residual, int Ho, int Wo,
                                              float *workspace, size_t workspace_floats,
                                              const float *out_scale, const float *out_shift, int out_activation,
+                                             int upsample2x,
                                              float *out, void *stream) {
     const int Cin = C1 + C2;
+    if (upsample2x && ((H | W) & 1)) return SIGE_HIP_EINVAL;  // (H, W) = the upsampled size
     if (B < 0 || C1 <= 0 || C2 < 0 || Cout <= 0 || H <= 0 || W <= 0 || N < 0) return SIGE_HIP_EINVAL;
     if (to_full && (Ho <= 0 || Wo <= 0)) return SIGE_HIP_EINVAL;
     if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
@@ -481,6 +485,7 @@ extern "C" int sige_hip_gather_conv_nhwc_f32(const float *x, const float *x2, in
     if (out_activation != SIGE_HIP_ACT_IDENTITY && out_activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(out_scale) | reinterpret_cast<uintptr_t>(out_shift)) & 15) return SIGE_HIP_EUNSUPPORTED;
     a.oscale = out_scale; a.oshift = out_shift; a.oact = out_activation;
+    a.up = upsample2x ? 1 : 0;
     {   // optional K split: `workspace` holds whole copies of the output
         const int Ro = (bH - kH) / strideH + 1, So = (bW - kW) / strideW + 1;
         a.split_stride = to_full ? (size_t)B * Ho * Wo * Cout : (size_t)B * N * Ro * So * Cout;

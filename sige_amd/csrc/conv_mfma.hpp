@@ -127,6 +127,7 @@ struct ConvArgs {
     // values (no VALU work between its MFMAs, and none repeated per output-channel block)
     const float *oscale, *oshift;
     int oact;
+    int up;          // GATHER: 1 = gather from the half-resolution tensor as if it were nearest-upsampled x2
     float *ws;       // host side: workspace for the partial outputs (nullptr / ksplit_max <= 1: no K split)
     int ksplit_max;  // host side: how many output copies `ws` holds
 };
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
     if (a.ng_fast) { ng = blockIdx.x % a.ngk; mb = blockIdx.x / a.ngk; }
     else { mb = blockIdx.x % a.mbk; ng = blockIdx.x / a.mbk; }
     const int Cin = a.Cin;
-    const int HW = a.H * a.W;
+    const int HW = (SRC == SRC_GATHER) ? (a.H >> a.up) * (a.W >> a.up) : a.H * a.W;  // pixels of the SOURCE tensor
     // cross-workgroup K split (deep-K, small-M layers): blockIdx.y owns chunks [first, last]
     const int split = blockIdx.y;
     const int first = split * a.chunks_per_split;
@@ -274,7 +275,9 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
                 const int n = t - b * a.N;
                 const int h = a.idx[2 * n] + p / G::R, w = a.idx[2 * n + 1] + p % G::R;
                 if (h >= 0 && h < a.H && w >= 0 && w < a.W) {
-                    const int hw = h * a.W + w;
+                    // GATHER with a.up = 1: the source tensor is the HALF-resolution one and (H, W) its x2
+                    // nearest-neighbour upsampling, which therefore never has to exist (F.interpolate fused)
+                    const int hw = (SRC == SRC_GATHER) ? (h >> a.up) * (a.W >> a.up) + (w >> a.up) : h * a.W + w;
                     if (SRC == SRC_GATHER) {
                         if (NHWC) {
                             off = (unsigned)((b * HW + hw) * a.Csplit + c_l) * 4u;

@@ -7,10 +7,16 @@
 // poor fit for the matrix cores (3 of 16 output columns used); it is bandwidth-bound
 // (33.5 MB in, 0.8 MB out).  Here: channels-last input, one workgroup per 8x32 pixel
 // tile, the activated (halo-extended) tile of a 32-channel chunk staged once in LDS,
-// every lane accumulates its pixel's COUT outputs with 16-byte LDS reads; weights in LDS.
+// every lane accumulates its pixel's COUT outputs with 16-byte LDS reads; the weights
+// are read with scalar loads (wave-uniform addresses) and enter the FMAs as SGPR operands.
 #include "common.hpp"
 
 namespace sige {
+
+__device__ __forceinline__ float silu_fast(float z) {
+    const float e = __builtin_amdgcn_exp2f(z * -1.44269504088896341f);
+    return z * __builtin_amdgcn_rcpf(1.0f + e);
+}
 
 constexpr int kTH = 8, kTW = 32, kCC = 32;  // tile rows / cols, channels per chunk
 constexpr int kPH = kTH + 2, kPW = kTW + 2;
@@ -22,7 +28,6 @@ __global__ __launch_bounds__(256) void conv_out_nhwc_kernel(const float *__restr
                                                            const float *__restrict__ w,  // [COUT, C, 3, 3]
                                                            const float *__restrict__ bias, float *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) float tile[kPH * kPW * kLDC];
-    __shared__ __attribute__((aligned(16))) float wl[COUT * 9 * kCC];  // [co][tap][c]
     const int tid = threadIdx.x;
     const int tx = tid % kTW, ty = tid / kTW;
     const int tilesW = (W + kTW - 1) / kTW, tilesH = (H + kTH - 1) / kTH;
@@ -48,26 +53,31 @@ __global__ __launch_bounds__(256) void conv_out_nhwc_kernel(const float *__restr
                     v.x = s4.x * v.x; v.y = s4.y * v.y; v.z = s4.z * v.z; v.w = s4.w * v.w;
                     v.x = t4.x + v.x; v.y = t4.y + v.y; v.z = t4.z + v.z; v.w = t4.w + v.w;
                 }
-                v.x = activate<ACT>(v.x); v.y = activate<ACT>(v.y); v.z = activate<ACT>(v.z); v.w = activate<ACT>(v.w);
+                if (ACT == SIGE_HIP_ACT_SWISH) {  // v_exp_f32 / v_rcp_f32 form (<= 1e-6 relative), as in the fused conv staging
+                    v.x = silu_fast(v.x); v.y = silu_fast(v.y); v.z = silu_fast(v.z); v.w = silu_fast(v.w);
+                }
             }
             *reinterpret_cast<float4 *>(tile + p * kLDC + c4) = v;
         }
-        for (int u = tid; u < COUT * 9 * kCC; u += 256) {
-            const int c = u % kCC, tap = (u / kCC) % 9, co = u / (kCC * 9);
-            wl[u] = (c0 + c < C) ? w[((size_t)co * C + c0 + c) * 9 + tap] : 0.f;
-        }
         __syncthreads();
+        // weights straight from global memory with wave-uniform addresses: scalar loads into SGPRs, so
+        // the only LDS traffic is the activations (LDS-bandwidth was the first version's limit: 61 us)
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const float *tp = tile + ((ty + tap / 3) * kPW + tx + tap % 3) * kLDC;
+        for (int c4 = 0; c4 < kCC; c4 += 4) {
+            if (c0 + c4 >= C) break;  // uniform
+            float4 a[9];
 #pragma unroll
-            for (int c4 = 0; c4 < kCC; c4 += 4) {
-                const float4 a = *reinterpret_cast<const float4 *>(tp + c4);
+            for (int tap = 0; tap < 9; ++tap)
+                a[tap] = *reinterpret_cast<const float4 *>(tile + ((ty + tap / 3) * kPW + tx + tap % 3) * kLDC + c4);
 #pragma unroll
-                for (int co = 0; co < COUT; ++co) {
-                    const float4 q = *reinterpret_cast<const float4 *>(wl + (co * 9 + tap) * kCC + c4);
-                    acc[co] = fmaf(a.x, q.x, acc[co]); acc[co] = fmaf(a.y, q.y, acc[co]);
-                    acc[co] = fmaf(a.z, q.z, acc[co]); acc[co] = fmaf(a.w, q.w, acc[co]);
+            for (int co = 0; co < COUT; ++co) {
+                const float *wp = w + ((size_t)co * C + c0 + c4) * 9;  // [4 channels][9 taps], contiguous
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    acc[co] = fmaf(a[tap].x, wp[tap], acc[co]);
+                    acc[co] = fmaf(a[tap].y, wp[9 + tap], acc[co]);
+                    acc[co] = fmaf(a[tap].z, wp[18 + tap], acc[co]);
+                    acc[co] = fmaf(a[tap].w, wp[27 + tap], acc[co]);
                 }
             }
         }

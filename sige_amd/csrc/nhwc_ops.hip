@@ -234,10 +234,22 @@ __global__ __launch_bounds__(kT) void attn_apply_nhwc_kernel(const float *__rest
     const float *vb = qkv + (size_t)b * HW * 3 * C + 2 * C + (cok ? c : 0);
     const float *pa = P + n * PS + kq;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < HW; j += 8) {
-        const float b0 = vb[(size_t)(j + kq) * 3 * C], b1 = vb[(size_t)(j + 4 + kq) * 3 * C];
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[j], b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[j + 4], b1, acc1, 0, 0, 0);
+    // 16 keys per step, the next step's v values in flight while this step's MFMAs run (HW % 16 == 0)
+    const size_t rs = (size_t)3 * C;
+    float bn[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bn[u] = vb[(size_t)(4 * u + kq) * rs];
+    for (int j = 0; j < HW; j += 16) {
+        float bc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bc[u] = bn[u];
+        const int jn = j + 16 < HW ? j + 16 : j;  // (last step re-reads its own rows)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bn[u] = vb[(size_t)(jn + 4 * u + kq) * rs];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[j], bc[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[j + 4], bc[1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[j + 8], bc[2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[j + 12], bc[3], acc1, 0, 0, 0);
     }
     // D[row = query 4*kq + r][col = channel n]
     if (cok) {

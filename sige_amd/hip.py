@@ -71,7 +71,7 @@ _SIGNATURES = {
     "sige_hip_block_conv_nhwc_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp, _c_vp]),
     "sige_hip_gather_conv_nhwc_f32": (
         _c_int, [_c_vp, _c_vp] + [_c_int] * 7 + [_c_vp, _c_int] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
-        + [_c_int] * 5 + [_c_int, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_vp, _c_sz, _c_vp, _c_vp, _c_int, _c_vp, _c_vp]),
+        + [_c_int] * 5 + [_c_int, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_vp, _c_sz, _c_vp, _c_vp, _c_int, _c_int, _c_vp, _c_vp]),
     "sige_hip_conv_ksplit_hint": (_c_int, [_c_int] * 7),
     "sige_hip_scatter_gather_conv_nhwc_f32": (
         _c_int, [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
@@ -562,11 +562,13 @@ def block_conv_cl(x, packed, bias, Cout: int, kernel: Tuple[int, int], stride: T
 
 def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, activationName: str,
                    packed, bias, Cout: int, kernel: Tuple[int, int], stride: Tuple[int, int],
-                   full: Optional[dict] = None, out_affine: Optional[tuple] = None):
+                   full: Optional[dict] = None, out_affine: Optional[tuple] = None, upsample2x: bool = False):
     """Channels-last gather -> conv.  `full` = dict(offset=(oh, ow), out_res=(Ho, Wo), residual=tensor|None)
     writes the output tiles straight into a [B,Cout,Ho,Wo] tensor (dense layers).  None if unsupported."""
     x = _req_cl(x, "x")
     B, C1, H, W = x.shape
+    if upsample2x:  # `x` is the half-resolution tensor; the tiles index its x2 nearest upsampling
+        H, W = 2 * H, 2 * W
     C2 = 0
     if x2 is not None:
         x2 = _req_cl(x2, "x2")
@@ -603,6 +605,7 @@ def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, a
         fargs = fargs + (os_.data_ptr(), oh_.data_ptr(), _act(oact))
     else:
         fargs = fargs + (None, None, 0)
+    fargs = fargs + (int(bool(upsample2x)),)
     status = lib().sige_hip_gather_conv_nhwc_f32(
         x.data_ptr(), None if x2 is None else x2.data_ptr(), B, C1, C2, H, W, block[0], block[1], idx.data_ptr(), N,
         *sa, *ta, _act(activationName), packed.data_ptr(), _bias_ptr(bias), Cout, kernel[0], kernel[1],

@@ -155,7 +155,7 @@ class SIGEConv2d(nn.Conv2d, SIGEModule):
                     and self.out_channels % 4 == 0):
                 out = hip.gather_conv_cl(spec["x"], spec.get("x2"), spec["block"], spec["idx"], spec["scale"], spec["shift"],
                                          spec["act"], packed, self.bias, self.out_channels, self.kernel_size, self.stride,
-                                         out_affine=out_affine)
+                                         out_affine=out_affine, upsample2x=spec.get("up", False))
                 if out is not None:
                     return out
             out = self._block_conv(x)
@@ -175,8 +175,8 @@ class SIGEConv2d(nn.Conv2d, SIGEModule):
             if spec["kind"] == "gather":
                 if cl:
                     out = hip.gather_conv_cl(spec["x"], spec.get("x2"), spec["block"], spec["idx"], spec["scale"],
-                                             spec["shift"], spec["act"], *common)
-                elif spec.get("x2") is None:
+                                             spec["shift"], spec["act"], *common, upsample2x=spec.get("up", False))
+                elif spec.get("x2") is None and not spec.get("up", False):
                     out = hip.gather_conv(spec["x"], spec["block"], spec["idx"], spec["scale"], spec["shift"],
                                           spec["act"], *common)
                 else:

@@ -59,10 +59,22 @@ class Gather(SIGEModule):
         self._tables: Dict = {}
 
     def forward(
-        self, x: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None
+        self, x: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
+        upsample2x: bool = False
     ) -> torch.Tensor:
+        """`upsample2x` (sparse mode, not in the reference): `x` is the HALF-resolution tensor and the tiles are
+        taken from its x2 nearest-neighbour upsampling -- which a fused gather -> conv never materialises
+        (the `F.interpolate` in front of the U-Net's upsampling convs)."""
         self.check_dtype(x, scale, shift)
         self.check_dim(x, scale, shift)
+        if upsample2x and self.mode != "sparse":
+            x = torch.nn.functional.interpolate(x, scale_factor=2.0, mode="nearest")
+        if self.mode == "sparse" and upsample2x:
+            x = deferred.resolve(x)
+            if not (deferred.channels_last_ok(x, scale, shift, self.activation_first)
+                    and deferred.defer_ok(x, scale, shift, self.activation_first, self.sparse_update, self.activation_name)):
+                x = torch.nn.functional.interpolate(x, scale_factor=2.0, mode="nearest")
+                upsample2x = False
         if self.mode == "sparse":
             x2 = None
             if isinstance(x, deferred.LazyCat) and x.spec is not None:
@@ -88,6 +100,8 @@ class Gather(SIGEModule):
 
             def run():
                 xx = x if x2 is None else torch.cat([x, x2], dim=1)
+                if upsample2x:
+                    xx = torch.nn.functional.interpolate(xx, scale_factor=2.0, mode="nearest")
                 if cl:
                     from .. import hip
 
@@ -100,7 +114,8 @@ class Gather(SIGEModule):
                 channels = x.shape[1] + (0 if x2 is None else x2.shape[1])
                 return deferred.DeferredTiles(
                     (x.shape[0] * idx.shape[0], channels, bh, bw), x.dtype, x.device, run,
-                    dict(kind="gather", x=x, x2=x2, block=(bh, bw), idx=idx, scale=scale, shift=shift, act=act, cl=cl))
+                    dict(kind="gather", x=x, x2=x2, block=(bh, bw), idx=idx, scale=scale, shift=shift, act=act, cl=cl,
+                         up=upsample2x))
             return run()
         if self.mode == "full":
             self.input_res = x.shape[2:]

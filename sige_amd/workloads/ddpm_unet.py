@@ -263,6 +263,9 @@ class Upsample(SIGEModule):
         self.plain = False
 
     def forward(self, x):
+        if self.mode == "sparse":
+            # the upsampled tensor only feeds the gather: read the half-resolution one at (h/2, w/2) instead
+            return self.scatter(self.conv(self.gather(x, upsample2x=True)))
         x = F.interpolate(x, scale_factor=2.0, mode="nearest")
         if self.plain and self.mode == "full":
             return self.conv(x)

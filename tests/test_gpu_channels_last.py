@@ -299,3 +299,20 @@ def test_epilogue_affine_activation(hip, res, cin, cout):
         got = fused_conv2d(conv, x, residual=residual, out_affine=(os_, oh_, "swish"))
         want = torch.nn.functional.silu((conv(x.contiguous()) + residual) * os_ + oh_)
     torch.testing.assert_close(got.contiguous(), want.contiguous(), rtol=0, atol=2e-4)
+
+
+def test_gather_conv_cl_fused_upsample(hip):
+    """upsample2x: gathering (h/2, w/2) of the half-resolution tensor == gathering its nearest x2 upsampling."""
+    from sige_amd.utils import reduce_mask
+
+    torch.manual_seed(5)
+    C, cout, lo = 64, 48, 24
+    x = torch.randn(1, C, lo, lo, device=DEV)
+    up = torch.nn.functional.interpolate(x, scale_factor=2.0, mode="nearest")
+    w = torch.randn(cout, C, 3, 3, device=DEV) / (3 * C ** 0.5)
+    bias = torch.randn(cout, device=DEV)
+    idx = reduce_mask(_mask(2 * lo), 6, 4, 1)
+    packed = hip.conv_pack_weights(w, 6, 6, (1, 1))
+    want = hip.gather_conv_cl(_cl(up), None, (6, 6), idx, None, None, "identity", packed, bias, cout, (3, 3), (1, 1))
+    got = hip.gather_conv_cl(_cl(x), None, (6, 6), idx, None, None, "identity", packed, bias, cout, (3, 3), (1, 1), upsample2x=True)
+    assert torch.equal(got, want)
