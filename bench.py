@@ -48,7 +48,7 @@ TRACED = ("gather", "scatter_gather", "scatter_fused", "scatter_with_block_resid
           "block_conv_direct", "gather_conv", "scatter_gather_conv", "gather_conv_nchw",
           # channels-last forms (the layout the benchmark runs in)
           "gather_cl", "scatter_gather_cl", "scatter_cl", "scatter_with_block_residual_cl", "block_conv_cl",
-          "gather_conv_cl", "scatter_gather_conv_cl")
+          "gather_conv_cl", "scatter_gather_conv_cl", "scatter_gather_conv_scatter_cl")
 
 
 class Tracer:
@@ -94,12 +94,22 @@ def op_cost(name, a, k=None):
     if name in ("gather_conv_cl", "gather_conv_nchw"):
         x, x2, block, idx = a[0], a[1], a[2], a[3]
         cout, kernel, stride = a[9], a[10], a[11]
-        dense = (k.get("full") is not None) if name == "gather_conv_cl" else True
         T, cin = x.shape[0] * idx.shape[0], x.shape[1] + (0 if x2 is None else x2.shape[1])
         ro, so = (block[0] - kernel[0]) // stride[0] + 1, (block[1] - kernel[1]) // stride[1] + 1
+        dense = True
+        if name == "gather_conv_cl":
+            full = k.get("full")
+            # dense layer = every output pixel covered by a tile; a sparse tile list written into a full tensor is
+            # the conv -> Scatter fusion of a SIGE layer
+            dense = full is not None and idx.shape[0] * ro * so >= full["out_res"][0] * full["out_res"][1]
         return ("dense_conv_mfma" if dense else "block_conv_mfma"), 0, 2 * T * ro * so * cout * cin * kernel[0] * kernel[1]
     if name == "scatter_gather_conv_cl":
         name = "scatter_gather_conv"
+    if name == "scatter_gather_conv_scatter_cl":
+        y, block, idx, cout, kernel = a[1], a[2], a[3], a[10], a[11]
+        T, cin = y.shape[0] * idx.shape[0], y.shape[1]
+        ro, so = block[0] - kernel[0] + 1, block[1] - kernel[1] + 1
+        return "block_conv_mfma", 0, 2 * T * ro * so * cout * cin * kernel[0] * kernel[1]
     if name == "gather":
         x, bH, bW, idx = a[0], a[1], a[2], a[3]
         B, C = x.shape[:2]

@@ -258,6 +258,21 @@ int sige_hip_scatter_gather_conv_nhwc_f32(const float *x, const float *y, int B,
                                           const float *packed, const float *bias, int Cout, int kH, int kW,
                                           int strideH, int strideW, float *out, void *stream);
 
+/* conv2 -> Scatter / ScatterWithBlockResidual fused (in-place scatter mode): the scatter_gather-fed 3x3 conv writes
+ * out[b, (offset+idx)/1 + r, ..., :] = conv + bias + residual  straight into `out` [B,H,W,Cout], a buffer that already
+ * equals the cached tensor outside this mask's tiles.  x1 != NULL: block residual -- `residual` is the cached shortcut
+ * tensor y1 and out += x1 - y1 wherever a shortcut tile (table1 over R1 x S1 cells, tiles x1 [B*N1,R1,S1,Cout]) covers
+ * the pixel (scatter.cpp:41-68).  The shortcut tiles must lie inside the main tiles (true for index lists that
+ * reduce_mask derives from one mask: a 4x4 block hit by the mask is inside an active 6x6 window). */
+int sige_hip_scatter_gather_conv_scatter_nhwc_f32(
+        const float *x, const float *y, int B, int Cin, int H, int W, int Rx, int Sx, int bH, int bW,
+        const int32_t *active_indices, int N, const int32_t *scatter_map,
+        const float *scale, int scaleB, int scaleC, const float *shift, int shiftB, int shiftC, int activation,
+        const float *packed, const float *bias, int Cout, int kH, int kW,
+        int offsetH, int offsetW, const float *residual,
+        const float *x1, const int32_t *table1, int gH1, int gW1, int N1, int R1, int S1,
+        float *out, void *stream);
+
 /* ---- channels-last forms of gather / scatter_gather / scatter ------------------
  * (materialising forms: the tiles are written to HBM; the fused convs above do not
  * need them).  scale / shift: [1|B, C].  Results are bit-identical to the NCHW

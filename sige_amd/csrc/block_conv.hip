@@ -94,6 +94,13 @@ SIGE_CONV_DECLARE_LAYOUTS(K11_32, 1)
 SIGE_CONV_DECLARE_LAYOUTS(K11_32, 2)
 SIGE_CONV_DECLARE_LAYOUTS(K32_16, 1)  // stride 2: NB = 1 only (conv_k3s2*.hip)
 SIGE_CONV_DECLARE_LAYOUTS(K32_32, 1)
+// scatter_gather -> conv -> scatter in one launch (channels-last 3x3): conv_k3s1_nhwc*.hip
+#define SIGE_CONV_DECLARE_SG_FULL(G, NB, W) \
+    template <> void launch_conv_geo<G, NB, SRC_SCATTER_GATHER, DST_NCHW, LAYOUT_NHWC, W>(ConvArgs, int, hipStream_t);
+SIGE_CONV_DECLARE_SG_FULL(K31_16, 1, 4) SIGE_CONV_DECLARE_SG_FULL(K31_16, 2, 4)
+SIGE_CONV_DECLARE_SG_FULL(K31_32, 1, 4) SIGE_CONV_DECLARE_SG_FULL(K31_32, 2, 4)
+SIGE_CONV_DECLARE_SG_FULL(K31_16, 1, 8) SIGE_CONV_DECLARE_SG_FULL(K31_16, 2, 8)
+SIGE_CONV_DECLARE_SG_FULL(K31_32, 1, 8) SIGE_CONV_DECLARE_SG_FULL(K31_32, 2, 8)
 // 8-wave workgroups: channels-last, stride 1 (conv_k3s1_nhwc_w8.hip, conv_k1_nhwc_w8.hip)
 SIGE_CONV_DECLARE(K31_16, 1, LAYOUT_NHWC, 8)
 SIGE_CONV_DECLARE(K31_16, 2, LAYOUT_NHWC, 8)
@@ -524,6 +531,39 @@ extern "C" int sige_hip_scatter_gather_conv_nhwc_f32(const float *x, const float
     const int mode = staging_mode(scale, scaleB, scaleC, shift, shiftB, shiftC, activation, B, Cin, &a.aff_sb, &a.aff_sc);
     if (mode < 0) return SIGE_HIP_EUNSUPPORTED;
     return launch_conv<SRC_SCATTER_GATHER, DST_TILES, LAYOUT_NHWC>(a, mode, kH, kW, bH, bW, strideH, strideW, as_stream(stream));
+}
+
+// scatter_gather -> conv -> Scatter / ScatterWithBlockResidual in ONE launch: the conv's output tiles go straight
+// into `out` [B,H,W,Cout], a buffer that already holds the cached tensor outside this mask's tiles (in-place scatter).
+extern "C" int sige_hip_scatter_gather_conv_scatter_nhwc_f32(
+        const float *x, const float *y, int B, int Cin, int H, int W, int Rx, int Sx, int bH, int bW,
+        const int32_t *active_indices, int N, const int32_t *scatter_map,
+        const float *scale, int scaleB, int scaleC, const float *shift, int shiftB, int shiftC, int activation,
+        const float *packed, const float *bias, int Cout, int kH, int kW,
+        int offsetH, int offsetW, const float *residual,
+        const float *x1, const int32_t *table1, int gH1, int gW1, int N1, int R1, int S1,
+        float *out, void *stream) {
+    if (B < 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || N < 0 || Rx <= 0 || Sx <= 0) return SIGE_HIP_EINVAL;
+    if (kH != 3 || kW != 3 || bH != 6 || bW != 6) return SIGE_HIP_EUNSUPPORTED;  // the stride-1 3x3 geometry of a ResBlock's conv2
+    if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
+    if ((long)B * Cin * H * W >= (1L << 29) || (long)B * N * Cin * Rx * Sx >= (1L << 29)) return SIGE_HIP_EUNSUPPORTED;
+    if ((long)B * N == 0) return SIGE_HIP_OK;
+    if (!x || !y || !packed || !out || !active_indices || !scatter_map) return SIGE_HIP_EINVAL;
+    if (x1 && (!residual || !table1 || R1 <= 0 || S1 <= 0 || gH1 < (H + R1 - 1) / R1 || gW1 < (W + S1 - 1) / S1)) return SIGE_HIP_EINVAL;
+    if (!nhwc_ok(Cin, Cin, Cout, x, y, out, bias) || (reinterpret_cast<uintptr_t>(packed) & 15) ||
+        (reinterpret_cast<uintptr_t>(residual) & 15) || (reinterpret_cast<uintptr_t>(x1) & 15))
+        return SIGE_HIP_EUNSUPPORTED;
+    ConvArgs a{};
+    a.x = x; a.y = y; a.idx = active_indices; a.map = scatter_map; a.packed = packed; a.bias = bias; a.out = out;
+    a.T = B * N; a.Cin = Cin; a.Cout = Cout; a.B = B; a.N = N; a.H = H; a.W = W;
+    a.RxSx = Rx * Sx; a.Sx = Sx;
+    a.scale = scale; a.shift = shift;
+    const int mode = staging_mode(scale, scaleB, scaleC, shift, shiftB, shiftC, activation, B, Cin, &a.aff_sb, &a.aff_sc);
+    if (mode < 0) return SIGE_HIP_EUNSUPPORTED;
+    a.residual = residual; a.Ho = H; a.Wo = W; a.offH = offsetH; a.offW = offsetW; a.strH = 1; a.strW = 1;
+    a.x1 = x1; a.table1 = table1; a.gW1 = gW1; a.N1 = N1; a.R1 = R1 > 0 ? R1 : 1; a.S1 = S1 > 0 ? S1 : 1;
+    return launch_kind<3, 1, 6, SRC_SCATTER_GATHER, DST_NCHW, LAYOUT_NHWC>(a, mode, as_stream(stream)) != SIGE_HIP_OK
+               ? SIGE_HIP_EUNSUPPORTED : launch_status();
 }
 
 extern "C" int sige_hip_block_conv_direct_f32(const float *x, int T, int Cin, int R, int S,

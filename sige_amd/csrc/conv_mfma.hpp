@@ -127,6 +127,11 @@ struct ConvArgs {
     // values (no VALU work between its MFMAs, and none repeated per output-channel block)
     const float *oscale, *oshift;
     int oact;
+    // DST full, block residual (ScatterWithBlockResidual fused into the epilogue, scatter.cpp:41-68): `residual` is the
+    // cached shortcut tensor y1; where a shortcut tile covers the pixel, out += x1 - y1 (x1 tiles [B*N1,R1,S1,Cout])
+    const float *x1;
+    const int32_t *table1;
+    int gW1, N1, R1, S1;
     int up;          // GATHER: 1 = gather from the half-resolution tensor as if it were nearest-upsampled x2
     float *ws;       // host side: workspace for the partial outputs (nullptr / ksplit_max <= 1: no K split)
     int ksplit_max;  // host side: how many output copies `ws` holds
@@ -586,6 +591,14 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
                         if (resp) {
                             const float4 rr = *reinterpret_cast<const float4 *>(resp + q);
                             s.x += rr.x; s.y += rr.y; s.z += rr.z; s.w += rr.w;
+                            if (a.x1) {
+                                const int t1 = a.table1[(h / a.R1) * a.gW1 + w / a.S1];
+                                if (t1 >= 0) {
+                                    const float4 xv = *reinterpret_cast<const float4 *>(
+                                        a.x1 + ((((size_t)b * a.N1 + t1) * a.R1 + h % a.R1) * a.S1 + w % a.S1) * a.Cout + co);
+                                    s.x += xv.x - rr.x; s.y += xv.y - rr.y; s.z += xv.z - rr.z; s.w += xv.w - rr.w;
+                                }
+                            }
                         }
                         *reinterpret_cast<float4 *>(outp + q) = post(s);
                     }
@@ -677,5 +690,8 @@ void launch_conv_geo(ConvArgs a, int mode, hipStream_t st);
     SIGE_CONV_LAUNCH3(G, NB, SRC_GATHER, DST_TILES, LAY, W)                                               \
     SIGE_CONV_LAUNCH3(G, NB, SRC_GATHER, DST_NCHW, LAY, W)                                                \
     SIGE_CONV_LAUNCH3(G, NB, SRC_SCATTER_GATHER, DST_TILES, LAY, W)
+
+// scatter_gather source written straight into a full tensor (conv2 -> Scatter fused): channels-last 3x3 only
+#define SIGE_CONV_INSTANTIATE_SG_FULL(G, NB, LAY, W) SIGE_CONV_LAUNCH3(G, NB, SRC_SCATTER_GATHER, DST_NCHW, LAY, W)
 
 }  // namespace sige

@@ -76,6 +76,9 @@ _SIGNATURES = {
     "sige_hip_scatter_gather_conv_nhwc_f32": (
         _c_int, [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
         + [_c_int] * 5 + [_c_vp, _c_vp]),
+    "sige_hip_scatter_gather_conv_scatter_nhwc_f32": (
+        _c_int, [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
+        + [_c_int] * 3 + [_c_int, _c_int, _c_vp] + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp, _c_vp]),
     "sige_hip_gather_nhwc_f32": (
         _c_int, [_c_vp] + [_c_int] * 6 + [_c_vp, _c_int] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]),
     "sige_hip_scatter_gather_nhwc_f32": (
@@ -562,7 +565,8 @@ def block_conv_cl(x, packed, bias, Cout: int, kernel: Tuple[int, int], stride: T
 
 def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, activationName: str,
                    packed, bias, Cout: int, kernel: Tuple[int, int], stride: Tuple[int, int],
-                   full: Optional[dict] = None, out_affine: Optional[tuple] = None, upsample2x: bool = False):
+                   full: Optional[dict] = None, out_affine: Optional[tuple] = None, upsample2x: bool = False,
+                   out: Optional[torch.Tensor] = None):
     """Channels-last gather -> conv.  `full` = dict(offset=(oh, ow), out_res=(Ho, Wo), residual=tensor|None)
     writes the output tiles straight into a [B,Cout,Ho,Wo] tensor (dense layers).  None if unsupported."""
     x = _req_cl(x, "x")
@@ -582,7 +586,10 @@ def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, a
         fargs = (0, 0, 0, None, 0, 0)
     else:
         Ho, Wo = full["out_res"]
-        out = _empty_cl((B, Cout, Ho, Wo), x.device)
+        if out is None:
+            out = _empty_cl((B, Cout, Ho, Wo), x.device)
+        elif tuple(out.shape) != (B, Cout, Ho, Wo) or not out.is_contiguous(memory_format=CL):
+            raise RuntimeError("gather_conv_cl: `out` must be a channels-last [B,Cout,Ho,Wo] tensor")
         r = full.get("residual")
         if r is not None:
             r = _req_cl(r, "residual")
@@ -633,6 +640,38 @@ def scatter_gather_conv_cl(x, y, block: Tuple[int, int], activeIndices, scatterM
     if status == UNSUPPORTED:
         return None
     _check(status, "scatter_gather_conv_cl")
+    return out
+
+
+def scatter_gather_conv_scatter_cl(x, y, block, activeIndices, scatterMap, scale, shift, activationName: str,
+                                   packed, bias, Cout: int, kernel, offset, out: torch.Tensor, residual=None,
+                                   x1=None, table1=None):
+    """scatter_gather -> 3x3 conv -> Scatter (residual = a full tensor) or ScatterWithBlockResidual (residual = the
+    cached shortcut tensor, x1 = the shortcut conv's tiles, table1 = their tile table) in one launch, written into
+    `out` (a persistent buffer that already equals the cache outside this mask's tiles).  None if unsupported."""
+    x, y = _req_cl(x, "x"), _req_cl(y, "y")
+    idx = _req(activeIndices, torch.int32, "activeIndices", 2)
+    smap = _req(scatterMap, torch.int32, "scatterMap", 3)
+    (sa, s_keep), (ta, t_keep) = _cvec(scale, "scale"), _cvec(shift, "shift")
+    B, C, H, W = y.shape
+    if tuple(out.shape) != (B, Cout, H, W) or not out.is_contiguous(memory_format=CL):
+        raise RuntimeError("scatter_gather_conv_scatter_cl: `out` must be a channels-last [B,Cout,H,W] tensor")
+    r = None if residual is None else _req_cl(residual, "residual")
+    if r is not None and tuple(r.shape) != tuple(out.shape):
+        raise RuntimeError("scatter_gather_conv_scatter_cl: residual must be full size")
+    if x1 is not None:
+        x1 = _req_cl(x1, "x1")
+        t1 = _req(table1, torch.int32, "table1", 2)
+        bargs = (x1.data_ptr(), t1.data_ptr(), t1.shape[0], t1.shape[1], x1.shape[0] // B, x1.shape[2], x1.shape[3])
+    else:
+        bargs = (None, None, 0, 0, 0, 0, 0)
+    status = lib().sige_hip_scatter_gather_conv_scatter_nhwc_f32(
+        x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3], block[0], block[1], idx.data_ptr(), idx.shape[0],
+        smap.data_ptr(), *sa, *ta, _act(activationName), packed.data_ptr(), _bias_ptr(bias), Cout, kernel[0], kernel[1],
+        offset[0], offset[1], None if r is None else r.data_ptr(), *bargs, out.data_ptr(), _stream(y))
+    if status == UNSUPPORTED:
+        return None
+    _check(status, "scatter_gather_conv_scatter_cl")
     return out
 
 

@@ -79,6 +79,20 @@ class Scatter(SIGEModule):
         self.original_outputs = {}
         self._out_bufs.clear()
 
+    def forward_fused(self, conv, tiles: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """(not in the reference) `self(conv(tiles), residual)` in ONE launch when the in-place mode is on and `tiles`
+        are pending (deferred) channels-last tiles: the conv's epilogue writes into this module's persistent output.
+        Falls back to the two-module form otherwise; values are identical."""
+        if self.mode == "sparse" and self.inplace and not self.sparse_update:
+            g: Gather = self.gather.module
+            cached = self.original_outputs[self.cache_id]
+            if _cl_ok(cached, residual) and isinstance(tiles, deferred.DeferredTiles) and tiles.spec is not None:
+                out = self._out_bufs.get(self.cache_id, cached, g.timestamp)
+                done = _fused_conv_into(conv, tiles, out, g, residual=residual)
+                if done is not None:
+                    return done
+        return self.forward(conv(tiles), residual)
+
     def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         self.check_dtype(x, residual)
         self.check_dim(x, residual)
@@ -121,6 +135,33 @@ class Scatter(SIGEModule):
         raise NotImplementedError("Unknown mode: [%s]!!!" % self.mode)
 
 
+def _fused_conv_into(conv, tiles, out, g: Gather, residual=None, x1=None, table1=None):
+    """Run `conv` on the pending (deferred) tiles with its output written straight into `out` at the tile positions of
+    gather `g`.  Returns `out`, or None when the combination has no fused kernel."""
+    from .. import hip
+
+    spec = tiles.spec if isinstance(tiles, deferred.DeferredTiles) else None
+    if spec is None or not spec.get("cl", False) or conv.groups != 1 or tuple(conv.dilation) != (1, 1):
+        return None
+    if conv.out_channels % 4 or tuple(conv.stride) != tuple(g.model_stride):
+        return None
+    packed = conv._packed_weights(tiles)
+    if packed is None:
+        return None
+    if spec["kind"] == "gather":
+        if x1 is not None:
+            return None
+        return hip.gather_conv_cl(spec["x"], spec.get("x2"), spec["block"], spec["idx"], spec["scale"], spec["shift"], spec["act"],
+                                  packed, conv.bias, conv.out_channels, conv.kernel_size, conv.stride,
+                                  full=dict(offset=g.offset, out_res=tuple(out.shape[2:]), residual=residual),
+                                  upsample2x=spec.get("up", False), out=out)
+    if tuple(conv.kernel_size) != (3, 3) or tuple(conv.stride) != (1, 1):
+        return None
+    return hip.scatter_gather_conv_scatter_cl(spec["x"], spec["y"], spec["block"], spec["idx"], spec["map"], spec["scale"],
+                                              spec["shift"], spec["act"], packed, conv.bias, conv.out_channels,
+                                              conv.kernel_size, g.offset, out, residual=residual, x1=x1, table1=table1)
+
+
 class ScatterWithBlockResidual(SIGEModule):
     """scatter(main tiles, residual = cached shortcut) + `x1 - y1` correction on the
     shortcut branch's own tiles (sige/nn/scatter.py:66-136)."""
@@ -142,6 +183,23 @@ class ScatterWithBlockResidual(SIGEModule):
         self.original_outputs = {}
         self.original_residuals = {}
         self._out_bufs.clear()
+
+    def forward_fused(self, conv, tiles: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
+        """(not in the reference) `self(conv(tiles), residual)` in ONE launch (see Scatter.forward_fused): `residual` are
+        the shortcut conv's tiles; the block-residual correction runs in the conv's epilogue."""
+        if self.mode == "sparse" and self.inplace and not self.sparse_update:
+            mg: Gather = self.main_gather.module
+            sg: Gather = self.shortcut_gather.module
+            y0 = self.original_outputs[self.cache_id]
+            y1 = self.original_residuals[self.cache_id]
+            if (_cl_ok(y0, y1) and hip_is_cl(y1) and isinstance(tiles, deferred.DeferredTiles) and tiles.spec is not None
+                    and sg.active_indices.size(0) <= mg.active_indices.size(0)):
+                out = self._out_bufs.get(self.cache_id, y0, (mg.timestamp, sg.timestamp))
+                x1 = deferred.resolve(residual)
+                done = _fused_conv_into(conv, tiles, out, mg, residual=y1, x1=x1, table1=sg.tile_table(y0.shape[2:], y0.device))
+                if done is not None:
+                    return done
+        return self.forward(conv(tiles), residual)
 
     def forward(self, x: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
         self.check_dtype(x, residual)

@@ -160,12 +160,12 @@ class ResBlock(SIGEModule):
         skip = self._shortcut(x)
         if self.sparse_main and self.preactivate and self.mode == "sparse":
             h = self.conv1(self.main_gather(x, s1, t1), out_affine=(s2, t2, "swish"))
-            h = self.conv2(self.scatter_gather(h, preactivated=True))
-            return self.scatter(h, skip)
+            return self.scatter.forward_fused(self.conv2, self.scatter_gather(h, preactivated=True), skip)
         if self.sparse_main:
             h = self.conv1(self.main_gather(x, s1, t1))
-            h = self.conv2(self.scatter_gather(h, s2, t2))
-            return self.scatter(h, skip)
+            if self.mode == "sparse":
+                return self.scatter.forward_fused(self.conv2, self.scatter_gather(h, s2, t2), skip)
+            return self.scatter(self.conv2(self.scatter_gather(h, s2, t2)), skip)
         return self._sparse_dense(x, None)
 
     def _sparse_dense(self, x, x2):
@@ -265,7 +265,7 @@ class Upsample(SIGEModule):
     def forward(self, x):
         if self.mode == "sparse":
             # the upsampled tensor only feeds the gather: read the half-resolution one at (h/2, w/2) instead
-            return self.scatter(self.conv(self.gather(x, upsample2x=True)))
+            return self.scatter.forward_fused(self.conv, self.gather(x, upsample2x=True))
         x = F.interpolate(x, scale_factor=2.0, mode="nearest")
         if self.plain and self.mode == "full":
             return self.conv(x)
@@ -293,6 +293,8 @@ class Downsample(SIGEModule):
         x = self.gather(x)
         if self.mode == "full":
             x = F.pad(x, (0, 1, 0, 1))
+        if self.mode == "sparse":
+            return self.scatter.forward_fused(self.conv, x)
         return self.scatter(self.conv(x))
 
 

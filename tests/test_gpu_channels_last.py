@@ -316,3 +316,70 @@ def test_gather_conv_cl_fused_upsample(hip):
     want = hip.gather_conv_cl(_cl(up), None, (6, 6), idx, None, None, "identity", packed, bias, cout, (3, 3), (1, 1))
     got = hip.gather_conv_cl(_cl(x), None, (6, 6), idx, None, None, "identity", packed, bias, cout, (3, 3), (1, 1), upsample2x=True)
     assert torch.equal(got, want)
+
+
+def test_conv_scatter_fusion_in_modules(hip):
+    """Scatter.forward_fused / ScatterWithBlockResidual.forward_fused (the conv's epilogue writes the persistent
+    output) equal the two-module form, for a ResBlock with and without a shortcut conv."""
+    from sige_amd.nn import Gather, Scatter, ScatterGather, ScatterWithBlockResidual, SIGEConv2d, SIGEModel, SIGEModule
+    from sige_amd.utils import dilate_mask
+
+    class Block(SIGEModule):
+        def __init__(self, cin, cout):
+            super().__init__()
+            self.conv1, self.conv2 = SIGEConv2d(cin, cout, 3, 1, 1), SIGEConv2d(cout, cout, 3, 1, 1)
+            self.main_gather = Gather(self.conv1, 6, activation_name="swish")
+            self.scatter_gather = ScatterGather(self.main_gather, activation_name="swish")
+            self.nin = None
+            if cin != cout:
+                self.nin = SIGEConv2d(cin, cout, 1, 1, 0)
+                self.shortcut_gather = Gather(self.nin, 4)
+                self.scatter = ScatterWithBlockResidual(self.main_gather, self.shortcut_gather)
+            else:
+                self.scatter = Scatter(self.main_gather)
+            self.fuse = False
+
+        def forward(self, x):
+            sc = x if self.nin is None else self.nin(self.shortcut_gather(x))
+            if self.mode == "full":
+                h = torch.nn.functional.silu(self.main_gather(x) * self.s1 + self.t1)
+                h = torch.nn.functional.silu(self.scatter_gather(self.conv1(h)) * self.s2 + self.t2)
+                return self.scatter(self.conv2(h), sc)
+            h = self.conv1(self.main_gather(x, self.s1, self.t1))
+            tiles = self.scatter_gather(h, self.s2, self.t2)
+            if self.fuse:
+                return self.scatter.forward_fused(self.conv2, tiles, sc)
+            return self.scatter(self.conv2(tiles), sc)
+
+    class Net(SIGEModel):
+        def __init__(self, cin, cout):
+            super().__init__()
+            self.block = Block(cin, cout)
+
+        def forward(self, x):
+            return self.block(x)
+
+    torch.manual_seed(11)
+    for cin, cout in ((64, 64), (64, 128)):
+        net = Net(cin, cout).to(DEV).eval().to(memory_format=CL)
+        blk = net.block
+        blk.s1, blk.t1 = torch.randn(1, cin, 1, 1, device=DEV), torch.randn(1, cin, 1, 1, device=DEV)
+        blk.s2, blk.t2 = torch.randn(1, cout, 1, 1, device=DEV), torch.randn(1, cout, 1, 1, device=DEV)
+        orig = _cl(torch.randn(1, cin, 64, 64, device=DEV))
+        mask = torch.zeros(64, 64, dtype=torch.bool, device=DEV)
+        mask[20:31, 12:40] = True
+        mask[0, 0] = True
+        edits = [_cl(orig + torch.randn_like(orig) * mask) for _ in range(2)]
+        with torch.no_grad():
+            net.set_mode("full")
+            net(orig)
+            net.set_mode("sparse")
+            net.set_masks({(64, 64): dilate_mask(dilate_mask(mask, (2, 0)), (0, 2))})
+            want = [net(e).contiguous().clone() for e in edits]
+            net.set_scatter_inplace(True)
+            blk.fuse = True
+            got = [net(e).contiguous().clone() for e in edits]
+            again = net(edits[0]).contiguous()
+        for g, w in zip(got, want):
+            torch.testing.assert_close(g, w, rtol=0, atol=1e-5)
+        torch.testing.assert_close(again, want[0], rtol=0, atol=1e-5)
