@@ -52,6 +52,10 @@ class DDPMConfig:
     # conv1's epilogue applies the cached affine-2 + SiLU (and the ScatterGather cache keeps an activated copy),
     # so conv2 stages raw values: the activation is computed once per element, not once per output-channel block
     preactivate: bool = True
+    # run the shortcut branch of a ResBlock (1x1 conv on the block input) on a second stream (it is independent of
+    # conv1 -> conv2).  Measured on MI355X / ROCm 7.2: the cross-stream graph edges cost more than the overlap gains
+    # (2.05 ms vs 1.82 ms per forward), so it is off by default.
+    overlap_shortcut: bool = False
 
 
 def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
@@ -104,9 +108,31 @@ class ResBlock(SIGEModule):
         self.affine = {}  # cache_id -> (scale1, shift1, scale2, shift2) as [1,C,1,1]
         self.plain = False
         self.preactivate = cfg.preactivate
+        self.overlap = cfg.overlap_shortcut
+        self._side = None
 
     def clear_cache(self):
         self.affine = {}
+
+    def _shortcut_async(self, fn, x_ready: torch.Tensor):
+        """Run `fn()` (the shortcut branch) on a side stream forked from the current one; returns (result, join).
+        `join()` must be called on the current stream before the result is consumed.  hipGraph capture records the
+        fork / join as graph edges, so the two branches run concurrently in a replay."""
+        if not (self.overlap and x_ready.is_cuda and self.mode == "sparse"):
+            return fn(), (lambda: None)
+        cur = torch.cuda.current_stream(x_ready.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=x_ready.device)
+        side = self._side
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            out = fn()
+
+        def join():
+            cur.wait_stream(side)
+            out.record_stream(cur)  # (allocated on the side stream, consumed on the current one)
+
+        return out, join
 
     def forward(self, x, temb: Optional[torch.Tensor]) -> torch.Tensor:
         """`x` may be a pair (h, skip): the up path's torch.cat, which the dense
@@ -157,10 +183,15 @@ class ResBlock(SIGEModule):
 
     def _sparse(self, x):
         s1, t1, s2, t2 = self.affine[self.cache_id]
-        skip = self._shortcut(x)
         if self.sparse_main and self.preactivate and self.mode == "sparse":
+            first = x.parts[0] if hasattr(x, "parts") else x
+            skip, join = (self._shortcut_async(lambda: self._shortcut(x), first) if self.cin != self.cout
+                          else (x, lambda: None))
             h = self.conv1(self.main_gather(x, s1, t1), out_affine=(s2, t2, "swish"))
-            return self.scatter.forward_fused(self.conv2, self.scatter_gather(h, preactivated=True), skip)
+            tiles = self.scatter_gather(h, preactivated=True)
+            join()
+            return self.scatter.forward_fused(self.conv2, tiles, skip)
+        skip = self._shortcut(x)
         if self.sparse_main:
             h = self.conv1(self.main_gather(x, s1, t1))
             if self.mode == "sparse":
@@ -171,13 +202,16 @@ class ResBlock(SIGEModule):
     def _sparse_dense(self, x, x2):
         """Dense block on the cached affine: 2-3 fused launches (shortcut 1x1, conv1, conv2+skip)."""
         s1, t1, s2, t2 = self.affine[self.cache_id]
+        join = lambda: None  # noqa: E731
         if self.cin == self.cout:
             skip = x if x2 is None else torch.cat([x, x2], dim=1)
         else:
-            skip = fused_conv2d(self.nin_shortcut, x, x2=x2)
+            skip, join = self._shortcut_async(lambda: fused_conv2d(self.nin_shortcut, x, x2=x2), x)
         if self.preactivate:
             h = fused_conv2d(self.conv1, x, s1, t1, "swish", x2=x2, out_affine=(s2, t2, "swish"))
+            join()
             return fused_conv2d(self.conv2, h, residual=skip)
+        join()
         h = fused_conv2d(self.conv1, x, s1, t1, "swish", x2=x2)
         return fused_conv2d(self.conv2, h, s2, t2, "swish", residual=skip)
 
