@@ -54,3 +54,27 @@ def test_unchanged_reference_model_with_deferred_tiles(reference_run):
     ours = _run("ours-refmodel", state, str(d / "ours_deferred.npz"), extra=("--deferred",))
     np.testing.assert_allclose(ours["full"], ref["full"], rtol=0, atol=1e-5)
     np.testing.assert_allclose(ours["sparse"], ref["sparse"], rtol=0, atol=1e-4)
+
+
+def _run_model(stack, model, state, out, extra=()):
+    cmd = [sys.executable, os.path.join(HERE, "ref_runner_models.py"), "--stack", stack, "--model", model, "--state", state,
+           "--out", out, *extra]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=2400)
+    assert res.returncode == 0, res.stderr[-3000:]
+    return np.load(out)
+
+
+@pytest.mark.parametrize("model", ["gaugan", "sd"])
+def test_unchanged_gaugan_and_sd_models_run_on_sige_amd(tmp_path, model):
+    """BASELINE configs[2] / configs[3] as parity cases: the reference's unmodified GauGAN SPADE generator
+    (gaugan/models/spade_generators/sige_fused_spade_generator.py) and Stable-Diffusion U-Net
+    (stable-diffusion/ldm/modules/diffusionmodules/sige_openaimodel.py; SPADE modulation of tiles, sparse-query
+    attention, CFG batch 2) on top of sige_amd's module API give the reference stack's full and sparse outputs --
+    also with Gather / ScatterGather returning DeferredTiles (tiles post-processed by model code materialise)."""
+    state = str(tmp_path / "state.pt")
+    ref = _run_model("reference", model, state, str(tmp_path / "ref.npz"))
+    assert np.abs(ref["sparse"] - ref["full"]).max() > 1e-2
+    for extra in ((), ("--deferred",)):
+        ours = _run_model("ours", model, state, str(tmp_path / "ours.npz"), extra)
+        np.testing.assert_allclose(ours["full"], ref["full"], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(ours["sparse"], ref["sparse"], rtol=0, atol=1e-4)
