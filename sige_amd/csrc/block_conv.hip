@@ -118,11 +118,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_nhwc_kernel(const float *__
                                                                 const float *__restrict__ oscale, const float *__restrict__ oshift, int oact,
                                                                 float *__restrict__ out) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        float4 v = *reinterpret_cast<const float4 *>(ws + 4 * i);
-        for (int s = 1; s < S; ++s) {
-            const float4 p = *reinterpret_cast<const float4 *>(ws + s * stride + 4 * i);
-            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
-        }
+        // all (<= 8) partials in flight at once, added in split order
+        float4 p[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) p[s] = *reinterpret_cast<const float4 *>(ws + (size_t)(s < S ? s : S - 1) * stride + 4 * i);
+        float4 v = p[0];
+#pragma unroll
+        for (int s = 1; s < 8; ++s)
+            if (s < S) { v.x += p[s].x; v.y += p[s].y; v.z += p[s].z; v.w += p[s].w; }
         if (bias) {
             const float4 b = *reinterpret_cast<const float4 *>(bias + (4 * i) % C);
             v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;

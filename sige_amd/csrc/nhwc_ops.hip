@@ -234,22 +234,21 @@ __global__ __launch_bounds__(kT) void attn_apply_nhwc_kernel(const float *__rest
     const float *vb = qkv + (size_t)b * HW * 3 * C + 2 * C + (cok ? c : 0);
     const float *pa = P + n * PS + kq;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    // 16 keys per step, the next step's v values in flight while this step's MFMAs run (HW % 16 == 0)
+    // 256 keys per block: all 64 value loads of the block are issued before the first MFMA needs one (a loop that
+    // loads one step ahead pays the memory latency every step: 16 x ~0.6 us for 256 tokens)
     const size_t rs = (size_t)3 * C;
-    float bn[4];
+    for (int j0 = 0; j0 < HW; j0 += 256) {
+        const int nk = min(256, HW - j0) / 4;  // k-steps in this block (HW % 16 == 0)
+        float bv[64];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) bn[u] = vb[(size_t)(4 * u + kq) * rs];
-    for (int j = 0; j < HW; j += 16) {
-        float bc[4];
+        for (int u = 0; u < 64; ++u) bv[u] = vb[(size_t)(j0 + 4 * min(u, nk - 1) + kq) * rs];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) bc[u] = bn[u];
-        const int jn = j + 16 < HW ? j + 16 : j;  // (last step re-reads its own rows)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) bn[u] = vb[(size_t)(jn + 4 * u + kq) * rs];
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[j], bc[0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[j + 4], bc[1], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[j + 8], bc[2], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[j + 12], bc[3], acc1, 0, 0, 0);
+        for (int u = 0; u < 64; ++u) {
+            const float av = pa[j0 + 4 * min(u, nk - 1)];
+            const float bb = u < nk ? bv[u] : 0.f;  // (steps past the block contribute exact zeros)
+            if (u & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bb, acc1, 0, 0, 0);
+            else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bb, acc0, 0, 0, 0);
+        }
     }
     // D[row = query 4*kq + r][col = channel n]
     if (cok) {
