@@ -163,7 +163,7 @@ def pmc_traffic(family):
     """HBM-side bytes per launch of a kernel family from the committed rocprofv3 PMC pass (bench.py cannot
     run the profiler on itself); None if the file or the family is missing."""
     try:
-        with open(os.path.join(REPO, "profiles", "r1g_pmc_traffic.json")) as f:
+        with open(os.path.join(REPO, "profiles", "r1k_pmc_traffic.json")) as f:
             fam = json.load(f)["families"][family]
         return int(fam["traffic_MB_per_launch"] * 1e6)
     except Exception:
@@ -484,7 +484,7 @@ def main():
                     "note": "algorithmic work of all %d launches of this kernel in one forward / their summed "
                             "duration (hipGraph of back-to-back launches, HIP events on the launch stream, "
                             "rotating input sets); traffic = bytes per launch from the committed PMC pass "
-                            "profiles/r1g_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs, "
+                            "profiles/r1k_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs, "
                             "FETCH_SIZE doubled per the gfx950 correction; L2-miss traffic incl. Infinity-Cache hits)"
                             % launches}
                 # secondary: the HBM-bound copy-through scatter (reference semantics: a fresh full tensor per call,

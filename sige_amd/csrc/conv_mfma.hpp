@@ -229,6 +229,34 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
     const int first = split * a.chunks_per_split;
     const int last = min(a.nchunks, first + a.chunks_per_split) - 1;
 
+    // ---- B: F float4 per lane per chunk and N sub-block, contiguous per (ng, chunk, wave) ----
+    const int ngtot = (a.Cout + G::MT - 1) / G::MT;
+    const long packed_floats_total = (long)ngtot * a.nblk * G::F * 64 * 4;  // nblk = (4-wave chunks, padded to even) * 4
+    int gsel[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) gsel[nb] = min(ng * NB + nb, ngtot - 1);  // past-the-end sub-blocks re-read the last one; stores are masked
+    rsrc_t r_b[NB];
+    auto set_b_chunk = [&](int chunk) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            r_b[nb] = make_rsrc(a.packed, ((long)gsel[nb] * a.nblk + chunk * W + wave) * G::F * 64 * 4, packed_floats_total);
+    };
+    float4 bset[2][NB][G::F];
+    auto b_load = [&](float4 &dst, int nb, int f) { dst = buf_f32x4(r_b[nb], lane * 16, f * 1024); };
+
+    // The weight loads of the first two chunks do not depend on the index list: issue them before the slot
+    // set-up (whose idx -> offset -> activation chain is two dependent memory round trips) so that they overlap.
+    set_b_chunk(first);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int f = 0; f < G::F; ++f) b_load(bset[0][nb][f], nb, f);
+    set_b_chunk(min(first + 1, last));
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int f = 0; f < G::F; ++f) b_load(bset[1][nb][f], nb, f);
+
     // ---- staging slots ------------------------------------------------------
     // One slot = one LDS unit (a float, or a float4 when VEC) this lane fills for every chunk.
     // s_off / s_off2: byte offsets at channel chunk 0 into the source window (kOOB = zero fill):
@@ -403,21 +431,6 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
         }
     };
 
-    // ---- B: F float4 per lane per chunk and N sub-block, contiguous per (ng, chunk, wave) ----
-    const int ngtot = (a.Cout + G::MT - 1) / G::MT;
-    const long packed_floats_total = (long)ngtot * a.nblk * G::F * 64 * 4;  // nblk = (4-wave chunks, padded to even) * 4
-    int gsel[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) gsel[nb] = min(ng * NB + nb, ngtot - 1);  // past-the-end sub-blocks re-read the last one; stores are masked
-    rsrc_t r_b[NB];
-    auto set_b_chunk = [&](int chunk) {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-            r_b[nb] = make_rsrc(a.packed, ((long)gsel[nb] * a.nblk + chunk * W + wave) * G::F * 64 * 4, packed_floats_total);
-    };
-    float4 bset[2][NB][G::F];
-    auto b_load = [&](float4 &dst, int nb, int f) { dst = buf_f32x4(r_b[nb], lane * 16, f * 1024); };
-
     typename M::acc_t acc[NB][NACC];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -439,19 +452,9 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
     // ---- prologue: chunks 0 / 1 -> register sets 0 / 1, B sets 0 / 1, tables 0 / 1;
     //      chunk 0 -> LDS[0]; register set 0 re-issued as chunk 2 ----
     set_chunk(first);
-    set_b_chunk(first);
     static_for<0, NS>([&](auto i_tag) { slot_load(0, decltype(i_tag)::value, first); });
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int f = 0; f < G::F; ++f) b_load(bset[0][nb][f], nb, f);
     set_chunk(min(first + 1, last));
-    set_b_chunk(min(first + 1, last));
     static_for<0, NS>([&](auto i_tag) { slot_load(1, decltype(i_tag)::value, min(first + 1, last)); });
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int f = 0; f < G::F; ++f) b_load(bset[1][nb][f], nb, f);
     if (AFF) {
         tab_load(first);
         tab_store(tab);

@@ -52,6 +52,9 @@ def graph_time(fn, nsets, reps=20, iters=10):
     return a.elapsed_time(b) * 1e3 / (iters * reps)
 
 
+CL = False
+
+
 def sparse_case(name, T, cin, cout, k, stride, R, res, dev, nsets=4):
     """Gather-fused conv over T active tiles of a [1,cin,res,res] activation."""
     block, out_tile, offset = GEO[(k, stride)]
@@ -63,25 +66,26 @@ def sparse_case(name, T, cin, cout, k, stride, R, res, dev, nsets=4):
     idx = torch.tensor([[min(r, n_side - 1) * pitch - offset[0], min(c, n_side - 1) * pitch - offset[1]] for r, c in coords],
                        dtype=torch.int32, device=dev)
     xs = [torch.randn(1, cin, res, res, device=dev) for _ in range(nsets)]
+    if CL:
+        xs = [x.contiguous(memory_format=torch.channels_last) for x in xs]
     wgt = torch.randn(cout, cin, k, k, device=dev) / (k * cin ** 0.5)
     bias = torch.randn(cout, device=dev)
     scale, shift = torch.randn(1, cin, 1, 1, device=dev), torch.randn(1, cin, 1, 1, device=dev)
     packed = hip.conv_pack_weights(wgt, block[0], block[1], (stride, stride))
 
     def run(i):
+        if CL:
+            return hip.gather_conv_cl(xs[i], None, block, idx, scale, shift, "swish", packed, bias, cout, (k, k), (stride, stride))
         return hip.gather_conv(xs[i], block, idx, scale, shift, "swish", packed, bias, cout, (k, k), (stride, stride))
 
     def check():
-        got = run(0)
-        tiles = hip.gather(xs[0], block[0], block[1], idx, scale, shift, "swish", False)
+        got = run(0).contiguous()
+        tiles = hip.gather(xs[0].contiguous(), block[0], block[1], idx, scale, shift, "swish", False)
         want = F.conv2d(tiles.double(), wgt.double(), bias.double(), stride).float()
         return (got - want).abs().max().item()
 
     flop = 2.0 * T * out_tile[0] * out_tile[1] * cout * cin * k * k
     return run, check, flop
-
-
-CL = False
 
 
 def dense_case(name, res, c1, c2, cout, k, stride, dev, nsets=4):
