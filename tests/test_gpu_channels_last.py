@@ -383,3 +383,24 @@ def test_conv_scatter_fusion_in_modules(hip):
         for g, w in zip(got, want):
             torch.testing.assert_close(g, w, rtol=0, atol=1e-5)
         torch.testing.assert_close(again, want[0], rtol=0, atol=1e-5)
+
+
+def test_empty_mask_sparse_forward_is_the_cached_result():
+    """N = 0 active tiles (the reference demo short-circuits this case, diffusion_demo/runner.py:146-147): every
+    fused / in-place kernel must be a no-op and the sparse forward must return the original image's output."""
+    from sige_amd.utils import downsample_mask
+    from sige_amd.workloads.ddpm_unet import DDPMConfig, DDPMSparseUNet
+
+    torch.manual_seed(0)
+    model = DDPMSparseUNet(DDPMConfig(ch=32)).to(DEV).eval().to(memory_format=CL)
+    model.set_scatter_inplace(True)
+    x0 = _cl(torch.randn(1, 3, 256, 256, device=DEV))
+    t = torch.zeros(1, device=DEV)
+    with torch.no_grad():
+        model.set_mode("full")
+        full = model(x0, t)
+        model.set_masks(downsample_mask(torch.zeros(256, 256, dtype=torch.bool, device=DEV), 8))
+        model.set_mode("sparse")
+        sparse = model(x0, t)
+    # (the dense remainder and the output norm are recomputed, so equality is to rounding, not bit-wise)
+    torch.testing.assert_close(sparse.contiguous(), full.contiguous(), rtol=0, atol=2e-4)

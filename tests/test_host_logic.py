@@ -363,3 +363,49 @@ def test_forced_deferral_matches_eager(cpu_oracle_backend, monkeypatch):
         assert not isinstance(blk.main_gather(edited, full_scale, None), deferred.DeferredTiles)
         net.set_sparse_update(True)
         assert not isinstance(blk.main_gather(edited, blk.s1, blk.t1), deferred.DeferredTiles)
+
+
+def test_mi355x_first_options_reduce_to_the_reference_form(cpu_oracle_backend):
+    """The options that are not in the reference -- producer-side activation (`out_affine` +
+    `cache_activated` / `preactivated`), conv -> scatter fusion (`forward_fused`), deferred `lazy_cat`,
+    `upsample2x` gathers -- must give the plain module chain's values when no fused kernel applies
+    (here: CPU tensors on the oracle backend)."""
+    from sige_amd.nn import deferred
+
+    torch.manual_seed(3)
+    net = ResNet(8, 8).eval()
+    blk = net.block
+    blk.s1, blk.t1, blk.s2, blk.t2 = (torch.randn(1, 8, 1, 1) for _ in range(4))
+    orig = torch.randn(1, 8, 32, 32)
+    mask = torch.zeros(32, 32, dtype=torch.bool)
+    mask[9:15, 5:19] = True
+    edited = orig + torch.randn_like(orig) * mask
+    with torch.no_grad():
+        net.set_mode("full")
+        net(orig)
+        blk.scatter_gather.cache_activated(blk.s2, blk.t2)
+        net.set_mode("sparse")
+        net.set_masks({(32, 32): dilate_mask(dilate_mask(mask, (2, 0)), (0, 2))})
+        want = net(edited)
+        # the same block with every option on
+        net.set_scatter_inplace(True)
+        sc = blk.nin(blk.shortcut_gather(edited))
+        h = blk.conv1(blk.main_gather(edited, blk.s1, blk.t1), out_affine=(blk.s2, blk.t2, "swish"))
+        got = blk.scatter.forward_fused(blk.conv2, blk.scatter_gather(h, preactivated=True), sc)
+        torch.testing.assert_close(got, want, rtol=0, atol=1e-5)
+        # lazy cat: eager on CPU, and the Gather accepts either
+        a, b = edited[:, :5], edited[:, 5:]
+        cat = deferred.lazy_cat(a, b)
+        assert not isinstance(cat, deferred.LazyCat) and torch.equal(cat, edited)
+        # upsample2x gather == gather of the nearest-upsampled tensor
+        conv = SIGEConv2d(8, 4, 3, 1, 1).eval()
+        g = Gather(conv, 6)
+        lo = torch.randn(1, 8, 16, 16)
+        up = torch.nn.functional.interpolate(lo, scale_factor=2.0, mode="nearest")
+        for m in (g, conv):
+            m.set_mode("full")
+        conv(g(up))
+        g.set_mask({(32, 32): mask}, {}, 1)
+        for m in (g, conv):
+            m.set_mode("sparse")
+        torch.testing.assert_close(conv(g(lo, upsample2x=True)), conv(g(up)), rtol=0, atol=0)
