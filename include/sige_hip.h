@@ -10,7 +10,9 @@
  *
  * Conventions
  *   - plain C: device pointers + sizes, no torch types.  All tensors are dense,
- *     contiguous, NCHW, fp32 (the reference is fp32-only: sige/nn/base.py:15);
+ *     contiguous, fp32 (the reference is fp32-only: sige/nn/base.py:15), NCHW like the
+ *     reference's -- except in the entry points named *_nhwc_*, which take the same
+ *     tensors channels-last ([B,H,W,C], tiles [T,R,S,C]; same arithmetic);
  *     index tensors are int32 [N,2] = (h, w) tile origins in the INPUT
  *     coordinates of the paired conv (sige/utils.py:30-37).
  *   - the CALLER allocates outputs (the reference's wrappers call torch::empty /
