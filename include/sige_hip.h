@@ -318,6 +318,18 @@ int sige_hip_conv3x3_small_cout_nhwc_f32(const float *x, int B, int C, int H, in
                                          const float *shift, int shiftB, int shiftC, int activation,
                                          const float *weight, const float *bias, int Cout,
                                          float *out, void *stream);
+/* benchmarking / tests: 1 = always the scalar-weight kernel; 0 (default) = the tap-GEMM MFMA kernel
+ * where it applies (C = 64 / 128, Cout <= 3). */
+int sige_hip_conv3x3_small_cout_force_scalar(int on);
+
+/* ---- 3x3 / padding-1 conv with <= 3 input channels and Cout = 32 / 64 / 128 over a full image
+ * (the U-Net's conv_in, sige_fused_unet.py:395: a plain nn.Conv2d in every mode):
+ * out [B,H,W,Cout] (channels-last) = conv(x) + bias; x is addressed through its element strides
+ * (NCHW or channels-last), weight [Cout,Cin,3,3]. */
+int sige_hip_conv3x3_small_cin_nhwc_f32(const float *x, int64_t strideB, int64_t strideC, int64_t strideH, int64_t strideW,
+                                        int B, int Cin, int H, int W,
+                                        const float *weight, const float *bias, int Cout,
+                                        float *out, void *stream);
 
 /* per-group mean / rstd of a [B,C,H,W] tensor -> per-channel (scale, shift) with
  * GroupNorm(x) == x*scale + shift  (scale = gamma*rstd, shift = beta - mean*scale):

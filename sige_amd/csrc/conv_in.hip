@@ -1,0 +1,106 @@
+// Input convolution of the U-Net: a 3x3 / padding-1 conv from a handful of input channels
+// (3 for DDPM's conv_in) to Cout = 32..128 over the FULL-resolution image, which the
+// reference runs densely in sparse mode too (sige_fused_unet.py:395, a plain nn.Conv2d).
+//
+// With K = 9*Cin = 27 the layer is one thin GEMM per pixel block: M = 32 pixels, N = Cout,
+// K = 27 (padded to 28 = 14 steps of the 32x32x2 f32 MFMA).  It is bound by the 33.5 MB of
+// channels-last output (0.8 MB in), so the kernel is arranged around the stores: in the
+// 32x32 accumulator layout the 32 lanes of a half-wave hold 32 consecutive output channels
+// of one pixel = one 128-byte segment per pixel and store instruction.
+// Lane (kq, j) owns pixel j of the block and the K indices 2s + kq; the weights
+// (Cout/32 x 14 registers) and the bias stay in registers for all blocks of the wave.
+// The input is addressed through element strides (NCHW or channels-last alike).
+#include "common.hpp"
+
+namespace sige {
+
+typedef float floatx16_in __attribute__((ext_vector_type(16)));
+
+constexpr int kInBPW = 2;  // pixel blocks per wave
+
+template <int CIN, int NBK>
+__global__ __launch_bounds__(256) void conv_in_gemm_kernel(const float *__restrict__ x, long sb, long sc, long sh, long sw,
+                                                          int B, int H, int W, const float *__restrict__ w,  // [Cout, CIN, 3, 3]
+                                                          const float *__restrict__ bias, float *__restrict__ out, long npix) {
+    constexpr int K = 9 * CIN, KS = (K + 1) / 2, COUT = 32 * NBK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kq = lane >> 5;
+    const long blk0 = ((long)blockIdx.x * 4 + wave) * kInBPW;
+
+    // A operand of both blocks first (the longest dependency chain), then the weights
+    float a[kInBPW][KS];
+#pragma unroll
+    for (int i = 0; i < kInBPW; ++i) {
+        const long p = (blk0 + i) * 32 + j;
+        const bool live = p < npix;
+        const int b = (int)(p / ((long)H * W));
+        const int rem = (int)(p - (long)b * H * W);
+        const int h = rem / W, ww = rem - h * W;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            // k = 2s + kq = ci*9 + tap  (the weight's own [ci][ky][kx] order)
+            const int k = 2 * s + kq;
+            const int ci = kq ? (2 * s + 1) / 9 : (2 * s) / 9;
+            const int tap = kq ? (2 * s + 1) % 9 : (2 * s) % 9;
+            const int ih = h + tap / 3 - 1, iw = ww + tap % 3 - 1;
+            const bool ok = live && k < K && ih >= 0 && ih < H && iw >= 0 && iw < W;
+            a[i][s] = ok ? x[b * sb + ci * sc + ih * sh + iw * sw] : 0.f;
+        }
+    }
+    float breg[NBK][KS], biasr[NBK];
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) {
+        const int n = nb * 32 + j;
+        biasr[nb] = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) breg[nb][s] = (2 * s + kq < K) ? w[(size_t)n * K + 2 * s + kq] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < kInBPW; ++i) {
+        const long pb = (blk0 + i) * 32;
+        if (pb >= npix) break;  // wave-uniform
+        floatx16_in acc[NBK];
+#pragma unroll
+        for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = biasr[nb];
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int nb = 0; nb < NBK; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], breg[nb][s], acc[nb], 0, 0, 0);
+        // reg r of lane (kq, j): pixel row m = (r & 3) + 8 * (r >> 2) + 4 * kq, output channel nb*32 + j
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long p = pb + (r & 3) + 8 * (r >> 2) + 4 * kq;
+            if (p < npix) {
+#pragma unroll
+                for (int nb = 0; nb < NBK; ++nb) out[p * COUT + nb * 32 + j] = acc[nb][r];
+            }
+        }
+    }
+}
+
+}  // namespace sige
+
+using namespace sige;
+
+extern "C" int sige_hip_conv3x3_small_cin_nhwc_f32(const float *x, int64_t strideB, int64_t strideC, int64_t strideH, int64_t strideW,
+                                                   int B, int Cin, int H, int W,
+                                                   const float *weight, const float *bias, int Cout,
+                                                   float *out, void *stream) {
+    if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return SIGE_HIP_EINVAL;
+    if (!x || !weight || !out) return SIGE_HIP_EINVAL;
+    if (Cin > 3 || !(Cout == 32 || Cout == 64 || Cout == 128)) return SIGE_HIP_EUNSUPPORTED;
+    const long npix = (long)B * H * W;
+    if (npix * Cout >= (1L << 40)) return SIGE_HIP_EUNSUPPORTED;
+    const long nblk = (npix + 31) / 32, grid = (nblk + 4 * kInBPW - 1) / (4 * kInBPW);
+    if (grid > 0x7fffffffL) return SIGE_HIP_EUNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+#define SIGE_CI(CI, NBK) \
+    conv_in_gemm_kernel<CI, NBK><<<(int)grid, 256, 0, st>>>(x, strideB, strideC, strideH, strideW, B, H, W, weight, bias, out, npix);
+#define SIGE_CI_N(CI)                                                                         \
+    if (Cout == 32) { SIGE_CI(CI, 1) } else if (Cout == 64) { SIGE_CI(CI, 2) } else { SIGE_CI(CI, 4) }
+    if (Cin == 1) { SIGE_CI_N(1) } else if (Cin == 2) { SIGE_CI_N(2) } else { SIGE_CI_N(3) }
+#undef SIGE_CI_N
+#undef SIGE_CI
+    return launch_status();
+}

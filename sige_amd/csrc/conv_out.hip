@@ -104,9 +104,123 @@ __global__ __launch_bounds__(256) void conv_out_nhwc_kernel(const float *__restr
     }
 }
 
+
+// ---- tap-GEMM form (C = 64 / 128, COUT <= 3): the matrix cores after all ------------------------------
+// Taking the 9 taps as extra output COLUMNS instead of extra K makes the layer a plain GEMM,
+//     P[p][tap*COUT + co] = sum_ch act(x[p][ch]) * w[co][ch][tap]      M = pixels, N = 9*COUT <= 32, K = C
+// followed by a 9-term shifted sum   out[y][x][co] = bias[co] + sum_tap P[(y+dy, x+dx)][tap*COUT + co].
+// 27 of the 32 columns of a 32x32x2 f32 MFMA do useful work (3 of 16 in the implicit-GEMM form), every
+// activation is computed once per workgroup, and the only VALU work left is the affine + SiLU itself.
+// One workgroup = a 16x16 output tile: its (16+2)^2 = 324 input pixels are 11 M-blocks of 32 shared out over
+// 4 waves; lane (kq, j) owns pixel j of the block and channels [kq*C/2, (kq+1)*C/2) -- the weights of those
+// channels stay in C/2 registers for the whole kernel, the pixel's channels arrive as 16-byte loads that are
+// issued one block ahead.  P lives in LDS (38 KB); out-of-image taps are skipped by the summing lane, which is
+// the zero padding of the activated tensor.
+constexpr int kGT = 16, kGP = kGT + 2, kGPix = kGP * kGP, kGBlocks = (kGPix + 31) / 32;
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+template <int CIN, int COUT, int ACT>
+__global__ __launch_bounds__(256) void conv_out_gemm_kernel(const float *__restrict__ x, int B, int H, int W,
+                                                           const float *__restrict__ scale, const float *__restrict__ shift, int aff_sb,
+                                                           const float *__restrict__ w,  // [COUT, CIN, 3, 3]
+                                                           const float *__restrict__ bias, float *__restrict__ out) {
+    constexpr int KS = CIN / 2;  // MFMA steps (K = 2 each: one channel of either half)
+    constexpr int NV = KS / 4;   // 16-byte loads per lane and block
+    constexpr int NP = 9 * COUT;
+    __shared__ float P[kGBlocks * 32 * NP];
+    __shared__ __attribute__((aligned(16))) float s_sc[CIN], s_sh[CIN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kq = lane >> 5;
+    const int tilesW = (W + kGT - 1) / kGT, tilesH = (H + kGT - 1) / kGT;
+    const int b = blockIdx.x / (tilesW * tilesH);
+    const int tr = blockIdx.x % (tilesW * tilesH);
+    const int h0 = (tr / tilesW) * kGT, w0 = (tr % tilesW) * kGT;
+
+    auto pixel = [&](int blk) -> const float4 * {
+        // (clamped: slots past the tile and pixels outside the image read a valid address; nobody sums them)
+        const int p = min(blk * 32 + j, kGPix - 1);
+        const int h = min(max(h0 + p / kGP - 1, 0), H - 1), ww = min(max(w0 + p % kGP - 1, 0), W - 1);
+        return reinterpret_cast<const float4 *>(x + (((size_t)b * H + h) * W + ww) * CIN + kq * KS);
+    };
+    float4 raw[NV];
+    {
+        const float4 *src = pixel(wave);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) raw[i] = src[i];
+    }
+    // B operand: column j = tap*COUT + co of the channels of this lane's half
+    float breg[KS];
+    {
+        const int co = j % COUT, tap = j / COUT;
+        const float *wp = w + ((size_t)co * CIN + kq * KS) * 9 + tap;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) breg[s] = j < NP ? wp[s * 9] : 0.f;
+    }
+    for (int c = tid; c < CIN; c += 256) {
+        s_sc[c] = scale ? scale[b * aff_sb + c] : 1.f;
+        s_sh[c] = shift ? shift[b * aff_sb + c] : 0.f;
+    }
+    __syncthreads();
+
+    for (int blk = wave; blk < kGBlocks; blk += 4) {
+        float a[KS];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float4 s4 = *reinterpret_cast<const float4 *>(s_sc + kq * KS + 4 * i);
+            const float4 t4 = *reinterpret_cast<const float4 *>(s_sh + kq * KS + 4 * i);
+            float4 v = raw[i];
+            v.x = s4.x * v.x; v.y = s4.y * v.y; v.z = s4.z * v.z; v.w = s4.w * v.w;
+            v.x = t4.x + v.x; v.y = t4.y + v.y; v.z = t4.z + v.z; v.w = t4.w + v.w;
+            if (ACT == SIGE_HIP_ACT_SWISH) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); v.z = silu_fast(v.z); v.w = silu_fast(v.w); }
+            a[4 * i] = v.x; a[4 * i + 1] = v.y; a[4 * i + 2] = v.z; a[4 * i + 3] = v.w;
+        }
+        if (blk + 4 < kGBlocks) {  // (wave-uniform) next block's pixel while this one is in the matrix pipe
+            const float4 *src = pixel(blk + 4);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) raw[i] = src[i];
+        }
+        floatx16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], breg[s], acc, 0, 0, 0);
+        // reg r of lane (kq, j): pixel row m = (r & 3) + 8 * (r >> 2) + 4 * kq, column j
+        if (j < NP) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) P[(blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq) * NP + j] = acc[r];
+        }
+    }
+    __syncthreads();
+
+    const int oy = tid / kGT, ox = tid % kGT;
+    const int h = h0 + oy, ww = w0 + ox;
+    if (h < H && ww < W) {
+        float o[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) o[co] = bias ? bias[co] : 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ih = h + tap / 3 - 1, iw = ww + tap % 3 - 1;
+            if (ih >= 0 && ih < H && iw >= 0 && iw < W) {
+                const float *pp = P + ((oy + tap / 3) * kGP + ox + tap % 3) * NP + tap * COUT;
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) o[co] += pp[co];
+            }
+        }
+        float *op = out + (((size_t)b * H + h) * W + ww) * COUT;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) op[co] = o[co];
+    }
+}
+
 }  // namespace sige
 
 using namespace sige;
+
+static int g_force_scalar = 0;
+
+// benchmarking / tests: 1 = always the scalar-weight kernel, 0 = the tap-GEMM kernel where it applies
+extern "C" int sige_hip_conv3x3_small_cout_force_scalar(int on) {
+    g_force_scalar = on ? 1 : 0;
+    return SIGE_HIP_OK;
+}
 
 extern "C" int sige_hip_conv3x3_small_cout_nhwc_f32(const float *x, int B, int C, int H, int W,
                                                     const float *scale, int scaleB, int scaleC,
@@ -127,6 +241,19 @@ extern "C" int sige_hip_conv3x3_small_cout_nhwc_f32(const float *x, int B, int C
     const long blocks = (long)B * ((H + kTH - 1) / kTH) * ((W + kTW - 1) / kTW);
     if (blocks > 0x7fffffffL) return SIGE_HIP_EUNSUPPORTED;
     hipStream_t st = as_stream(stream);
+    if (Cout <= 3 && (C == 128 || C == 64) && !g_force_scalar) {
+        const long tiles = (long)B * ((H + kGT - 1) / kGT) * ((W + kGT - 1) / kGT);
+        if (tiles > 0x7fffffffL) return SIGE_HIP_EUNSUPPORTED;
+#define SIGE_CG(CI, N)                                                                                                 \
+    if (activation == SIGE_HIP_ACT_SWISH)                                                                             \
+        conv_out_gemm_kernel<CI, N, SIGE_HIP_ACT_SWISH><<<(int)tiles, 256, 0, st>>>(x, B, H, W, scale, shift, aff_sb, weight, bias, out); \
+    else                                                                                                              \
+        conv_out_gemm_kernel<CI, N, SIGE_HIP_ACT_IDENTITY><<<(int)tiles, 256, 0, st>>>(x, B, H, W, scale, shift, aff_sb, weight, bias, out);
+        if (C == 128) { if (Cout == 1) { SIGE_CG(128, 1) } else if (Cout == 2) { SIGE_CG(128, 2) } else { SIGE_CG(128, 3) } }
+        else { if (Cout == 1) { SIGE_CG(64, 1) } else if (Cout == 2) { SIGE_CG(64, 2) } else { SIGE_CG(64, 3) } }
+#undef SIGE_CG
+        return launch_status();
+    }
 #define SIGE_CO(N)                                                                                                    \
     if (activation == SIGE_HIP_ACT_SWISH)                                                                             \
         conv_out_nhwc_kernel<N, SIGE_HIP_ACT_SWISH><<<(int)blocks, 256, 0, st>>>(x, B, C, H, W, scale, shift, aff_sb, weight, bias, out); \

@@ -59,7 +59,16 @@ __global__ __launch_bounds__(64) void gn_finish_kernel(const float *__restrict__
     const int lane = threadIdx.x;
     double s = 0.0, ss = 0.0;
     const float *p = ws + ((size_t)bg * splits) * 2;
-    for (int k = lane; k < splits; k += 64) { s += p[2 * k]; ss += p[2 * k + 1]; }
+    for (int k0 = lane; k0 < splits; k0 += 64 * 8) {  // 8 partials in flight per lane, added in split order
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 64 * u;
+            v[u] = k < splits ? *reinterpret_cast<const float2 *>(p + 2 * k) : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s += v[u].x; ss += v[u].y; }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
     const double mean = s / group_elems;
@@ -97,10 +106,21 @@ __global__ __launch_bounds__(kGNThreads) void gn_partial_nhwc_kernel(const float
     const int lo = sp * per, hi = min(HW, lo + per);
     float s = 0.f, ss = 0.f;
     const float *xb = x + (size_t)b * HW * C;
-    for (int p = lo + pl; p < hi; p += ppb) {
-        const float4 v = *reinterpret_cast<const float4 *>(xb + (size_t)p * C + cq * 4);
-        s += (v.x + v.y) + (v.z + v.w);
-        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    // 8 loads in flight per lane (a rolled loop pays the memory latency once per iteration: the [1,128,256,256]
+    // output norm took 19 us as 32 dependent round trips per lane; the host sizes a slice to one round)
+    constexpr int U = 8;
+    for (int p0 = lo + pl; p0 < hi; p0 += ppb * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = p0 + u * ppb;
+            v[u] = p < hi ? *reinterpret_cast<const float4 *>(xb + (size_t)p * C + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+            ss += (v[u].x * v[u].x + v[u].y * v[u].y) + (v[u].z * v[u].z + v[u].w * v[u].w);
+        }
     }
     // combine the lanes of one group: channels per group cg = C / groups; quads per group = cg / 4 (cg % 4 == 0: host side)
     __shared__ float sh[2][kGNThreads];
@@ -144,8 +164,8 @@ extern "C" int sige_hip_group_norm_affine_f32(const float *x, int B, int C, int 
 
 // ---- channels-last form: x [B,H,W,C] ----
 static int gn_nhwc_splits(int HW) {
-    int s = (HW + 255) / 256;  // ~256 pixels per workgroup
-    return s < 1 ? 1 : (s > 256 ? 256 : s);
+    int s = (HW + 63) / 64;  // 64 pixels per workgroup = one round of 8 loads per lane at C = 128
+    return s < 1 ? 1 : (s > 1024 ? 1024 : s);
 }
 
 extern "C" size_t sige_hip_group_norm_affine_nhwc_workspace(int B, int C, int H, int W, int groups) {

@@ -176,12 +176,23 @@ __global__ __launch_bounds__(kT) void attn_scores_nhwc_kernel(const float *__res
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     // each 16-byte load feeds 4 MFMA k-steps; the k order (kq*4 + e within a block of 16 channels)
     // is the same for A and B, which is all the contraction needs
-    for (int s = 0; s < cw; s += 16) {
-        const float4 a4 = ld4(qa + s), b4 = ld4(kb + s);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc1, 0, 0, 0);
+    // (8 steps = 16 loads in flight per lane: a loop that loads as it goes pays the memory latency every step)
+    for (int s0 = 0; s0 < cw; s0 += 128) {
+        float4 a4[8], b4[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int s = s0 + 16 * u;
+            const bool ok = s < cw;  // (steps past the end contribute exact zeros)
+            a4[u] = ok ? ld4(qa + s) : make_float4(0.f, 0.f, 0.f, 0.f);
+            b4[u] = ok ? ld4(kb + s) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u].x, b4[u].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u].y, b4[u].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u].z, b4[u].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u].w, b4[u].w, acc1, 0, 0, 0);
+        }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][4 * kq + r][n] = acc0[r] + acc1[r];
@@ -200,48 +211,88 @@ __global__ __launch_bounds__(kT) void attn_apply_nhwc_kernel(const float *__rest
     const int b = blockIdx.z;
     const int i0 = blockIdx.y * 16, c0 = blockIdx.x * 64;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    {
-        const int row = tid >> 4, l16 = tid & 15;
-        const float *srow = S + ((size_t)b * HW + i0 + row) * HW;
-        float m = -INFINITY;
-        for (int j = l16 * 4; j < HW; j += 64) {
-            const float4 t = ld4(srow + j);
-            st4(P + row * PS + j, t);
-            m = fmaxf(fmaxf(m, fmaxf(t.x, t.y)), fmaxf(t.z, t.w));
-        }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
-        float sum = 0.f;
-        for (int j = l16 * 4; j < HW; j += 64) {
-            float4 t = ld4(P + row * PS + j);
-            t.x = expf(t.x - m); t.y = expf(t.y - m); t.z = expf(t.z - m); t.w = expf(t.w - m);
-            sum += (t.x + t.y) + (t.z + t.w);
-            st4(P + row * PS + j, t);
-        }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
-        const float inv = 1.0f / sum;
-        for (int j = l16 * 4; j < HW; j += 64) {
-            float4 t = ld4(P + row * PS + j);
-            t.x *= inv; t.y *= inv; t.z *= inv; t.w *= inv;
-            st4(P + row * PS + j, t);
-        }
-    }
-    __syncthreads();
     const int kq = lane >> 4, n = lane & 15;
     const int c = c0 + wave * 16 + n;
     const bool cok = c < C;
     const float *vb = qkv + (size_t)b * HW * 3 * C + 2 * C + (cok ? c : 0);
-    const float *pa = P + n * PS + kq;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    // 256 keys per block: all 64 value loads of the block are issued before the first MFMA needs one (a loop that
-    // loads one step ahead pays the memory latency every step: 16 x ~0.6 us for 256 tokens)
     const size_t rs = (size_t)3 * C;
-    for (int j0 = 0; j0 < HW; j0 += 256) {
+    // 256 keys per block: all 64 value loads of a block are issued before the first MFMA needs one (a loop that
+    // loads one step ahead pays the memory latency every step: 16 x ~0.6 us for 256 tokens); the first block's
+    // are issued before the softmax, which does not depend on them
+    float bv[64];
+    auto load_values = [&](int j0) {
         const int nk = min(256, HW - j0) / 4;  // k-steps in this block (HW % 16 == 0)
-        float bv[64];
 #pragma unroll
         for (int u = 0; u < 64; ++u) bv[u] = vb[(size_t)(j0 + 4 * min(u, nk - 1) + kq) * rs];
+    };
+    load_values(0);
+    {
+        const int row = tid >> 4, l16 = tid & 15;
+        const float *srow = S + ((size_t)b * HW + i0 + row) * HW;
+        if (HW <= 256) {
+            // the whole score row of this lane group in registers: 4 loads in flight, one pass
+            float4 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = l16 * 4 + 64 * u;
+                t[u] = j < HW ? ld4(srow + j) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            }
+            float m = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) m = fmaxf(fmaxf(m, fmaxf(t[u].x, t[u].y)), fmaxf(t[u].z, t[u].w));
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
+            float sum = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (l16 * 4 + 64 * u < HW) {
+                    t[u].x = expf(t[u].x - m); t[u].y = expf(t[u].y - m); t[u].z = expf(t[u].z - m); t[u].w = expf(t[u].w - m);
+                    sum += (t[u].x + t[u].y) + (t[u].z + t[u].w);
+                }
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = l16 * 4 + 64 * u;
+                if (j < HW) {
+                    t[u].x *= inv; t[u].y *= inv; t[u].z *= inv; t[u].w *= inv;
+                    st4(P + row * PS + j, t[u]);
+                }
+            }
+        } else {
+            float m = -INFINITY;
+            for (int j = l16 * 4; j < HW; j += 64) {
+                const float4 t = ld4(srow + j);
+                st4(P + row * PS + j, t);
+                m = fmaxf(fmaxf(m, fmaxf(t.x, t.y)), fmaxf(t.z, t.w));
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
+            float sum = 0.f;
+            for (int j = l16 * 4; j < HW; j += 64) {
+                float4 t = ld4(P + row * PS + j);
+                t.x = expf(t.x - m); t.y = expf(t.y - m); t.z = expf(t.z - m); t.w = expf(t.w - m);
+                sum += (t.x + t.y) + (t.z + t.w);
+                st4(P + row * PS + j, t);
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
+            const float inv = 1.0f / sum;
+            for (int j = l16 * 4; j < HW; j += 64) {
+                float4 t = ld4(P + row * PS + j);
+                t.x *= inv; t.y *= inv; t.z *= inv; t.w *= inv;
+                st4(P + row * PS + j, t);
+            }
+        }
+    }
+    __syncthreads();
+    const float *pa = P + n * PS + kq;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int j0 = 0; j0 < HW; j0 += 256) {
+        const int nk = min(256, HW - j0) / 4;
+        if (j0 > 0) load_values(j0);
 #pragma unroll
         for (int u = 0; u < 64; ++u) {
             const float av = pa[j0 + 4 * min(u, nk - 1)];

@@ -91,6 +91,9 @@ _SIGNATURES = {
     "sige_hip_group_norm_affine_nhwc_f32": (_c_int, [_c_vp] + [_c_int] * 5 + [ctypes.c_float] + [_c_vp] * 6),
     "sige_hip_conv3x3_small_cout_nhwc_f32": (
         _c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp, _c_int, _c_vp, _c_vp]),
+    "sige_hip_conv3x3_small_cout_force_scalar": (_c_int, [_c_int]),
+    "sige_hip_conv3x3_small_cin_nhwc_f32": (
+        _c_int, [_c_vp] + [ctypes.c_int64] * 4 + [_c_int] * 4 + [_c_vp, _c_vp, _c_int, _c_vp, _c_vp]),
     "sige_hip_attention_nhwc_f32": (_c_int, [_c_vp, _c_int, _c_int, _c_int, ctypes.c_float, _c_vp, _c_vp, _c_vp]),
 }
 
@@ -599,6 +602,8 @@ def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, a
     # deep-K convs over a handful of tiles: workspace for the cross-workgroup K split
     ws, ws_n = None, 0
     ks = lib().sige_hip_conv_ksplit_hint(B * N, C1 + C2, Cout, kernel[0], kernel[1], stride[0], stride[1])
+    if full is not None and N * ((block[0] - kernel[0]) // stride[0] + 1) * ((block[1] - kernel[1]) // stride[1] + 1) < Ho * Wo:
+        ks = 1  # tiles written into a larger tensor: the second pass would need whole output copies
     if ks > 1 and os.environ.get("SIGE_AMD_KSPLIT", "1") != "0":
         ws_n = ks * out.numel()
         ws = torch.empty(ws_n, dtype=torch.float32, device=x.device)
@@ -794,4 +799,29 @@ def conv3x3_small_cout_cl(x, weight, bias, scale=None, shift=None, activationNam
     if status == UNSUPPORTED:
         return None
     _check(status, "conv3x3_small_cout_cl")
+    return out
+
+
+def conv3x3_small_cout_force_scalar(on: bool):
+    """Benchmarking / tests: route conv3x3_small_cout_cl through the scalar-weight kernel only."""
+    _check(lib().sige_hip_conv3x3_small_cout_force_scalar(int(bool(on))), "conv3x3_small_cout_force_scalar")
+
+
+def conv3x3_small_cin_cl(x, weight, bias):
+    """conv(x) + bias for a 3x3 / padding-1 conv with <= 3 input channels and 32 / 64 / 128 output channels
+    over a full image (the U-Net's conv_in); x in any dense layout, result channels-last.  None if unsupported."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+        raise ValueError("x must be a 4-D fp32 GPU tensor")
+    B, C, H, W = x.shape
+    w = _req(weight.detach(), torch.float32, "weight")
+    Cout = w.shape[0]
+    if tuple(w.shape[1:]) != (C, 3, 3) or C > 3 or Cout not in (32, 64, 128):
+        return None
+    out = _empty_cl((B, Cout, H, W), x.device)
+    sb, sc, sh, sw = x.stride()
+    status = lib().sige_hip_conv3x3_small_cin_nhwc_f32(x.data_ptr(), sb, sc, sh, sw, B, C, H, W, w.data_ptr(), _bias_ptr(bias),
+                                                       Cout, out.data_ptr(), _stream(x))
+    if status == UNSUPPORTED:
+        return None
+    _check(status, "conv3x3_small_cin_cl")
     return out

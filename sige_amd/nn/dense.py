@@ -39,6 +39,19 @@ def _packed(conv: nn.Conv2d, block):
     return conv._sige_packed
 
 
+def _plain_weight(conv: nn.Conv2d) -> torch.Tensor:
+    """conv.weight in the dense [Cout,Cin,kH,kW] order the kernels index (a channels-last model holds it
+    permuted); converted once per weight version, not once per forward."""
+    w = conv.weight
+    if w.is_contiguous():
+        return w
+    key = (w.data_ptr(), w._version, tuple(w.shape), w.device)
+    if getattr(conv, "_sige_plain_key", None) != key:
+        conv._sige_plain = w.detach().contiguous()
+        conv._sige_plain_key = key
+    return conv._sige_plain
+
+
 def fusable(conv: nn.Conv2d) -> bool:
     geo = (tuple(conv.kernel_size), tuple(conv.stride), tuple(conv.padding))
     return geo in _GEOMETRY and conv.groups == 1 and tuple(conv.dilation) == (1, 1)
@@ -83,7 +96,7 @@ def _fused_conv2d(conv, x, scale, shift, activation_name, x2, residual, pad_bott
             Ho, Wo = H, W
         if (hip.is_cl(x) and conv.out_channels <= 4 and tuple(conv.kernel_size) == (3, 3) and conv.stride[0] == 1
                 and x2 is None and residual is None and out_affine is None):
-            out = hip.conv3x3_small_cout_cl(x, conv.weight, conv.bias, scale, shift, activation_name)
+            out = hip.conv3x3_small_cout_cl(x, _plain_weight(conv), conv.bias, scale, shift, activation_name)
             if out is not None:
                 return out
         idx = hip.all_tiles(H, W, out_tile, conv.stride, offset, x.device)
@@ -109,6 +122,22 @@ def _fused_conv2d(conv, x, scale, shift, activation_name, x2, residual, pad_bott
     h = conv(h)
     h = h if residual is None else h + residual
     return h if out_affine is None else (h, out_affine)
+
+
+def input_conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
+    """`conv(x)` for the network's first layer (3x3 / padding 1, <= 3 input channels, e.g. DDPM's conv_in,
+    sige_fused_unet.py:395).  On a channels-last GPU image: one thin-GEMM launch writing the channels-last
+    result directly (libsige_hip.so); anything else is the plain `conv(x)`."""
+    if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] <= 3 and conv.groups == 1
+            and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1)
+            and tuple(conv.dilation) == (1, 1) and conv.padding_mode == "zeros"
+            and x.is_contiguous(memory_format=torch.channels_last) and (x.shape[1] == 1 or not x.is_contiguous())):
+        from .. import hip
+
+        out = hip.conv3x3_small_cin_cl(x, _plain_weight(conv), conv.bias)
+        if out is not None:
+            return out
+    return conv(x)
 
 
 def group_norm_affine(x: torch.Tensor, norm: nn.GroupNorm) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -27,7 +27,7 @@ from torch.nn import functional as F
 
 from ..nn import Gather, Scatter, ScatterGather, ScatterWithBlockResidual, SIGEConv2d, SIGEModel, SIGEModule
 from ..nn.deferred import lazy_cat
-from ..nn.dense import fused_conv2d, group_norm_affine
+from ..nn.dense import fused_conv2d, group_norm_affine, input_conv2d
 
 
 @dataclass
@@ -414,7 +414,7 @@ class DDPMSparseUNet(SIGEModel):
         temb = self._temb(t)
         nxt = (lambda: temb.pop(0)) if temb is not None else (lambda: None)
 
-        h0 = self.conv_in(x)
+        h0 = input_conv2d(self.conv_in, x) if self.mode == "sparse" else self.conv_in(x)
         if x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous():
             h0 = h0.contiguous(memory_format=torch.channels_last)  # (MIOpen may hand back NCHW for 3 input channels)
         hs = [h0]

@@ -203,7 +203,8 @@ def test_ddpm_unet_channels_last_equals_nchw(inplace):
     assert (outs["nhwc"][0] - outs["nhwc"][1]).abs().max() > 1e-3  # the two edits really differ
 
 
-@pytest.mark.parametrize("B,C,H,W,cout,act", [(1, 128, 256, 256, 3, "swish"), (2, 36, 19, 45, 4, "identity"), (1, 64, 8, 8, 1, "swish")])
+@pytest.mark.parametrize("B,C,H,W,cout,act", [(1, 128, 256, 256, 3, "swish"), (2, 36, 19, 45, 4, "identity"), (1, 64, 8, 8, 1, "swish"),
+                                              (2, 128, 37, 21, 3, "swish"), (1, 64, 33, 16, 2, "identity"), (3, 128, 16, 50, 1, "swish")])
 def test_conv3x3_small_cout_cl(hip, B, C, H, W, cout, act):
     torch.manual_seed(C + H)
     x = torch.randn(B, C, H, W, device=DEV)
@@ -219,6 +220,46 @@ def test_conv3x3_small_cout_cl(hip, B, C, H, W, cout, act):
     torch.testing.assert_close(got.contiguous(), want, rtol=0, atol=1e-4)
     plain = hip.conv3x3_small_cout_cl(_cl(x), w, None)
     torch.testing.assert_close(plain.contiguous(), torch.nn.functional.conv2d(x.double(), w.double(), None, 1, 1).float(), rtol=0, atol=1e-4)
+    # the tap-GEMM (MFMA) kernel and the scalar-weight kernel are two evaluations of the same sums
+    hip.conv3x3_small_cout_force_scalar(True)
+    try:
+        scalar = hip.conv3x3_small_cout_cl(_cl(x), w, bias, sc, sh, act)
+    finally:
+        hip.conv3x3_small_cout_force_scalar(False)
+    torch.testing.assert_close(scalar.contiguous(), want, rtol=0, atol=1e-4)
+    torch.testing.assert_close(scalar, got, rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,C,H,W,cout", [(1, 3, 256, 256, 128), (2, 3, 19, 45, 64), (1, 1, 8, 8, 32), (2, 2, 33, 16, 128), (1, 3, 5, 7, 128)])
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_conv3x3_small_cin_cl(hip, B, C, H, W, cout, layout):
+    """The U-Net's first layer as one thin-GEMM launch: any input layout in, channels-last out."""
+    torch.manual_seed(C + H + cout)
+    x = torch.randn(B, C, H, W, device=DEV)
+    w = torch.randn(cout, C, 3, 3, device=DEV) / (3 * C ** 0.5)
+    bias = torch.randn(cout, device=DEV)
+    xin = _cl(x) if layout == "nhwc" else x
+    got = hip.conv3x3_small_cin_cl(xin, w, bias)
+    assert got is not None and got.is_contiguous(memory_format=torch.channels_last)
+    want = torch.nn.functional.conv2d(x.double(), w.double(), bias.double(), 1, 1).float()
+    torch.testing.assert_close(got.contiguous(), want, rtol=0, atol=1e-5)
+    nobias = hip.conv3x3_small_cin_cl(xin, w, None)
+    torch.testing.assert_close(nobias.contiguous(), torch.nn.functional.conv2d(x.double(), w.double(), None, 1, 1).float(), rtol=0, atol=1e-5)
+    assert hip.conv3x3_small_cin_cl(xin, torch.randn(48, C, 3, 3, device=DEV), None) is None  # unsupported width -> caller's plain conv
+
+
+def test_input_conv2d_matches_the_plain_conv(hip):
+    from sige_amd.nn.dense import input_conv2d
+
+    torch.manual_seed(3)
+    conv = torch.nn.Conv2d(3, 128, 3, 1, 1).to(DEV).to(memory_format=torch.channels_last)
+    x = torch.randn(1, 3, 64, 48, device=DEV)
+    with torch.no_grad():
+        want = conv(x)
+        got = input_conv2d(conv, _cl(x))
+        assert got.is_contiguous(memory_format=torch.channels_last)
+        torch.testing.assert_close(got, want, rtol=0, atol=1e-5)
+        torch.testing.assert_close(input_conv2d(conv, x), want, rtol=0, atol=0)  # NCHW input: the plain conv itself
 
 
 @pytest.mark.parametrize("c1,c2,k", [(128, 64, 3), (256, 128, 1), (100, 28, 3)])
