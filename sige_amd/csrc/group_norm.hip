@@ -106,9 +106,9 @@ __global__ __launch_bounds__(kGNThreads) void gn_partial_nhwc_kernel(const float
     const int lo = sp * per, hi = min(HW, lo + per);
     float s = 0.f, ss = 0.f;
     const float *xb = x + (size_t)b * HW * C;
-    // 8 loads in flight per lane (a rolled loop pays the memory latency once per iteration: the [1,128,256,256]
+    // 16 loads in flight per lane (a rolled loop pays the memory latency once per iteration: the [1,128,256,256]
     // output norm took 19 us as 32 dependent round trips per lane; the host sizes a slice to one round)
-    constexpr int U = 8;
+    constexpr int U = 16;
     for (int p0 = lo + pl; p0 < hi; p0 += ppb * U) {
         float4 v[U];
 #pragma unroll
@@ -164,8 +164,8 @@ extern "C" int sige_hip_group_norm_affine_f32(const float *x, int B, int C, int 
 
 // ---- channels-last form: x [B,H,W,C] ----
 static int gn_nhwc_splits(int HW) {
-    int s = (HW + 63) / 64;  // 64 pixels per workgroup = one round of 8 loads per lane at C = 128
-    return s < 1 ? 1 : (s > 1024 ? 1024 : s);
+    int s = (HW + 127) / 128;  // 128 pixels per workgroup = one round of 16 loads per lane at C = 128
+    return s < 1 ? 1 : (s > 512 ? 512 : s);
 }
 
 extern "C" size_t sige_hip_group_norm_affine_nhwc_workspace(int B, int C, int H, int W, int groups) {

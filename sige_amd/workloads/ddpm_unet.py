@@ -191,13 +191,13 @@ class ResBlock(SIGEModule):
             tiles = self.scatter_gather(h, preactivated=True)
             join()
             return self.scatter.forward_fused(self.conv2, tiles, skip)
+        if not self.sparse_main:
+            return self._sparse_dense(x, None)
         skip = self._shortcut(x)
-        if self.sparse_main:
-            h = self.conv1(self.main_gather(x, s1, t1))
-            if self.mode == "sparse":
-                return self.scatter.forward_fused(self.conv2, self.scatter_gather(h, s2, t2), skip)
-            return self.scatter(self.conv2(self.scatter_gather(h, s2, t2)), skip)
-        return self._sparse_dense(x, None)
+        h = self.conv1(self.main_gather(x, s1, t1))
+        if self.mode == "sparse":
+            return self.scatter.forward_fused(self.conv2, self.scatter_gather(h, s2, t2), skip)
+        return self.scatter(self.conv2(self.scatter_gather(h, s2, t2)), skip)
 
     def _sparse_dense(self, x, x2):
         """Dense block on the cached affine: 2-3 fused launches (shortcut 1x1, conv1, conv2+skip)."""
