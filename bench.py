@@ -528,7 +528,7 @@ def main():
 
         # ---- edit-ratio sweep (rank 0 only, short) -----------------------------------
         sweep = []
-        if rank == 0 and args.sweep:
+        if rank == 0 and args.sweep and world == 1:  # (at N > 1 the other ranks would idle in the final barrier)
             for r in [float(v) for v in args.sweep.split(",")]:
                 xs = prepare(r)
                 model(xs, t)
