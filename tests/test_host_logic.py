@@ -409,3 +409,27 @@ def test_mi355x_first_options_reduce_to_the_reference_form(cpu_oracle_backend):
         for m in (g, conv):
             m.set_mode("sparse")
         torch.testing.assert_close(conv(g(lo, upsample2x=True)), conv(g(up)), rtol=0, atol=0)
+
+
+def test_input_conv2d_and_plain_weight_off_gpu():
+    """The first-layer helper is the plain conv anywhere but on a channels-last GPU image; a channels-last
+    model's permuted weight is converted once per weight version."""
+    from torch import nn
+
+    from sige_amd.nn.dense import _plain_weight, input_conv2d
+
+    torch.manual_seed(0)
+    conv = nn.Conv2d(3, 8, 3, 1, 1)
+    x = torch.randn(1, 3, 12, 10)
+    with torch.no_grad():
+        assert torch.equal(input_conv2d(conv, x), conv(x))
+        xcl = x.contiguous(memory_format=torch.channels_last)
+        assert torch.equal(input_conv2d(conv, xcl), conv(xcl))
+    assert _plain_weight(conv) is conv.weight  # already dense: no copy
+    conv = conv.to(memory_format=torch.channels_last)
+    w1 = _plain_weight(conv)
+    assert w1.is_contiguous() and torch.equal(w1, conv.weight) and _plain_weight(conv) is w1
+    with torch.no_grad():
+        conv.weight.mul_(2.0)
+    w2 = _plain_weight(conv)
+    assert w2 is not w1 and torch.equal(w2, conv.weight)
