@@ -244,18 +244,21 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
     float4 bset[2][NB][G::F];
     auto b_load = [&](float4 &dst, int nb, int f) { dst = buf_f32x4(r_b[nb], lane * 16, f * 1024); };
 
-    // The weight loads of the first two chunks do not depend on the index list: issue them before the slot
-    // set-up (whose idx -> offset -> activation chain is two dependent memory round trips) so that they overlap.
-    set_b_chunk(first);
+    // The weight loads of the first two chunks do not depend on the index list; they are issued right behind the
+    // (tiny) index / table loads below, so that everything the prologue needs is in flight in one round trip.
+    auto b_prologue = [&]() {
+        set_b_chunk(first);
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int f = 0; f < G::F; ++f) b_load(bset[0][nb][f], nb, f);
-    set_b_chunk(min(first + 1, last));
+            for (int f = 0; f < G::F; ++f) b_load(bset[0][nb][f], nb, f);
+        set_b_chunk(min(first + 1, last));
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int f = 0; f < G::F; ++f) b_load(bset[1][nb][f], nb, f);
+            for (int f = 0; f < G::F; ++f) b_load(bset[1][nb][f], nb, f);
+    };
+    if (!NHWC) b_prologue();
 
     // ---- staging slots ------------------------------------------------------
     // One slot = one LDS unit (a float, or a float4 when VEC) this lane fills for every chunk.
@@ -273,6 +276,96 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
     int s_dst[NS];             // LDS float index of the unit inside a stage
     int s_cl[VEC ? NS : 1];    // first channel of the unit inside the chunk (partial last chunk test)
 
+    // (scale, shift) of channel chunk `chunk` for table entry (tid mod CC); entries past Cin are 0
+    const int trow = tid % CCk;
+    const int tab_b0 = AFF ? ((mb * G::TPB) / a.N) * a.aff_sb : 0;  // (a per-batch affine needs one batch per M block: host side)
+    auto tab_fetch = [&](int chunk, float &sc, float &sh) {
+        const int c = chunk * CCk + trow;
+        const int cc = c < Cin ? c : 0;
+        const float vs = a.scale[tab_b0 + cc * a.aff_sc], vh = a.shift[tab_b0 + cc * a.aff_sc];
+        sc = c < Cin ? vs : 0.f;
+        sh = c < Cin ? vh : 0.f;
+    };
+    float t_sc = 0.f, t_sh = 0.f, t_sc1 = 0.f, t_sh1 = 0.f;
+
+    if constexpr (NHWC) {
+        // Channels-last: the slot set-up in load-batched, branch-free form.  Written slot by slot (index load ->
+        // bounds test -> offset, as in the NCHW branch below) every slot costs a dependent memory round trip behind the
+        // weight loads -- 3 to 6 of them before the first activation load can be issued (measured in the ISA:
+        // global_load / s_waitcnt vmcnt(0) per slot).  Here: (1) pure arithmetic, (2) ALL tile origins, then the
+        // affine table entries, then the weights of two chunks in flight together, (3) offsets with selects;
+        // SCATTER_GATHER adds one more batched round trip for the scatter-map entries.
+        constexpr int UPT = G::RS * CCk / 4, UPP = CCk / 4;  // units per tile / per pixel
+        int z_t[NS], z_p[NS], z_c[NS], z_h[NS], z_w[NS], z_b[NS];
+        bool z_live[NS];
+        static_for<0, NS>([&](auto i_tag) {
+            constexpr int i = decltype(i_tag)::value;
+            const int v = tid + NT * i;
+            const int t_l = v / UPT;
+            const int p = (v - t_l * UPT) / UPP;
+            const int c_l = ((v - t_l * UPT) - p * UPP) * 4;
+            s_dst[i] = (t_l * G::RS + p) * LDC + c_l;
+            s_cl[i] = c_l;
+            z_c[i] = c_l; z_p[i] = p;
+            z_t[i] = mb * G::TPB + t_l;
+            z_live[i] = v < UNITS && z_t[i] < a.T;
+        });
+        if (SRC != SRC_TILES) {
+            static_for<0, NS>([&](auto i_tag) {
+                constexpr int i = decltype(i_tag)::value;
+                const int tt = min(z_t[i], a.T - 1);  // (clamped: always a valid address; dead slots are masked below)
+                const int b = tt / a.N, n = tt - b * a.N;
+                const int2 o = *reinterpret_cast<const int2 *>(a.idx + 2 * n);
+                z_b[i] = b; z_h[i] = o.x + z_p[i] / G::R; z_w[i] = o.y + z_p[i] % G::R;
+            });
+        }
+        if (AFF) {
+            tab_fetch(first, t_sc, t_sh);
+            tab_fetch(min(first + 1, last), t_sc1, t_sh1);
+        }
+        b_prologue();
+        int z_hw[NS], z_m0[NS], z_m1[NS], z_m2[NS];
+        static_for<0, NS>([&](auto i_tag) {
+            constexpr int i = decltype(i_tag)::value;
+            unsigned off = kOOB, off2 = kOOB;
+            const int t = z_t[i], c_l = z_c[i];
+            if (SRC == SRC_TILES) {
+                off = z_live[i] ? (unsigned)((t * G::RS + z_p[i]) * Cin + c_l) * 4u : kOOB;
+            } else {
+                const int h = z_h[i], w = z_w[i], b = z_b[i];
+                const bool in = z_live[i] && h >= 0 && h < a.H && w >= 0 && w < a.W;
+                z_live[i] = in;
+                const int hw = (SRC == SRC_GATHER) ? (h >> a.up) * (a.W >> a.up) + (w >> a.up) : h * a.W + w;
+                if (SRC == SRC_GATHER) {
+                    off = in ? (unsigned)((b * HW + hw) * a.Csplit + c_l) * 4u : kOOB;
+                    off2 = in ? (unsigned)(hw * (Cin - a.Csplit) + c_l) * 4u : kOOB;  // (x2: B == 1, host side)
+                } else {
+                    const int hwc = in ? hw : 0;
+                    z_hw[i] = hwc;
+                    const int32_t *m = a.map + 3 * (size_t)hwc;
+                    z_m0[i] = m[0]; z_m1[i] = m[1]; z_m2[i] = m[2];
+                }
+            }
+            if (SRC != SRC_SCATTER_GATHER) {
+                s_off[i] = off;
+                if (TWO) s_off2[i] = (off == kOOB ? 0u : off2 - off);
+                if (AFF) s_tab[i] = (off != kOOB || off2 != kOOB) ? c_l : CCk;
+            }
+        });
+        if (SRC == SRC_SCATTER_GATHER) {
+            static_for<0, NS>([&](auto i_tag) {
+                constexpr int i = decltype(i_tag)::value;
+                const int blk = z_m0[i], c_l = z_c[i], b = z_b[i];
+                const bool in = z_live[i];
+                const unsigned off = (in && blk >= 0)
+                    ? (unsigned)(((b * a.N + blk) * a.RxSx + z_m1[i] * a.Sx + z_m2[i]) * Cin + c_l) * 4u : kOOB;
+                const unsigned off2 = (in && blk < 0) ? (unsigned)((b * HW + z_hw[i]) * Cin + c_l) * 4u : kOOB;
+                s_off[i] = off;
+                s_off2[i] = off2;
+                if (AFF) s_tab[i] = in ? c_l : CCk;
+            });
+        }
+    } else {
     // (static_for, not `#pragma unroll`: a loop the unroller gives up on would index the slot arrays
     //  dynamically and push them to scratch memory -- every scratch load then drains vmcnt to 0)
     static_for<0, NS>([&](auto i_tag) {
@@ -338,6 +431,7 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
         if (TWO) s_off2[i] = (SRC == SRC_GATHER) ? (off == kOOB ? 0u : off2 - off) : off2;
         if (AFF) s_tab[i] = (off != kOOB || off2 != kOOB) ? c_l : CCk;
     });
+    }
 
     // descriptors of the staging sources, advanced to channel chunk `chunk` with scalar arithmetic
     rsrc_t r_a, r_a2;
@@ -410,25 +504,16 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
             *reinterpret_cast<float4 *>(buf + s_dst[i]) = q;
         }
     };
-    // (scale, shift) of channel chunk `chunk` for table entry (tid mod CC); entries past Cin are 0
-    const int trow = tid % CCk;
-    float t_sc, t_sh;
     auto tab_load = [&](int chunk) {
-        if (AFF) {
-            const int c = chunk * CCk + trow;
-            const int cc = c < Cin ? c : 0;
-            const int b0 = (mb * G::TPB) / a.N;  // (a per-batch affine needs one batch per M block: host side)
-            const float sc = a.scale[b0 * a.aff_sb + cc * a.aff_sc], sh = a.shift[b0 * a.aff_sb + cc * a.aff_sc];
-            t_sc = c < Cin ? sc : 0.f;
-            t_sh = c < Cin ? sh : 0.f;
-        }
+        if (AFF) tab_fetch(chunk, t_sc, t_sh);
+    };
+    auto tab_put = [&](float *tb, float sc, float sh) {
+        tb[trow] = sc;
+        tb[TROW + trow] = sh;
+        if (tid < 4) { tb[CCk + tid] = 0.f; tb[TROW + CCk + tid] = 0.f; }
     };
     auto tab_store = [&](float *tb) {
-        if (AFF) {
-            tb[trow] = t_sc;
-            tb[TROW + trow] = t_sh;
-            if (tid < 4) { tb[CCk + tid] = 0.f; tb[TROW + CCk + tid] = 0.f; }
-        }
+        if (AFF) tab_put(tb, t_sc, t_sh);
     };
 
     typename M::acc_t acc[NB][NACC];
@@ -456,10 +541,12 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
     set_chunk(min(first + 1, last));
     static_for<0, NS>([&](auto i_tag) { slot_load(1, decltype(i_tag)::value, min(first + 1, last)); });
     if (AFF) {
-        tab_load(first);
-        tab_store(tab);
-        tab_load(min(first + 1, last));
-        tab_store(tab + TABF);
+        if (!NHWC) {  // (channels-last: both entries are already in flight, see the slot set-up)
+            tab_fetch(first, t_sc, t_sh);
+            tab_fetch(min(first + 1, last), t_sc1, t_sh1);
+        }
+        tab_put(tab, t_sc, t_sh);
+        tab_put(tab + TABF, t_sc1, t_sh1);
         __syncthreads();
     }
     set_chunk(min(first + 2, last));
