@@ -288,6 +288,23 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
     };
     float t_sc = 0.f, t_sh = 0.f, t_sc1 = 0.f, t_sh1 = 0.f;
 
+    // Output units of the epilogue (one float4 = 4 consecutive output channels of one pixel per lane and step).
+    // Channels-last, full-tensor destination: where each of this lane's (at most EU) units goes, its bias and its
+    // residual are fetched HERE, with the prologue's loads -- left to the epilogue, tile origin -> address -> residual
+    // -> store are two more dependent memory round trips at the end of every launch.
+    constexpr int UNITS_NB = G::MT * G::MT / 4;         // float4 units per N sub-block
+    constexpr int OUT_UNITS = NB * UNITS_NB;
+    constexpr int EU = (OUT_UNITS + NT - 1) / NT;
+    // (4-wave workgroups only: with 8 waves the register budget per lane is 256 and the loop needs it)
+    constexpr bool EPRE = NHWC && DST != DST_TILES && W == 4;
+    int e_h[EPRE ? EU : 1], e_w[EPRE ? EU : 1];          // tile origin, then the unit's output pixel
+    size_t e_q[EPRE ? EU : 1];                            // element offset of the unit in the output tensor
+    bool e_in[EPRE ? EU : 1];                             // the unit exists and its pixel is inside the output
+    float4 e_res[EPRE ? EU : 1];
+    constexpr bool EPV = NHWC && W == 4;                  // per-channel epilogue vectors (bias, out_affine) fetched up front
+    float4 e_bias[EPV ? EU : 1], e_os[EPV ? EU : 1], e_oh[EPV ? EU : 1];
+    const bool e_first_pass = a.ksplit <= 1;              // (K split: partial sums only, bias / residual in the second pass)
+
     if constexpr (NHWC) {
         // Channels-last: the slot set-up in load-batched, branch-free form.  Written slot by slot (index load ->
         // bounds test -> offset, as in the NCHW branch below) every slot costs a dependent memory round trip behind the
@@ -319,6 +336,33 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
                 z_b[i] = b; z_h[i] = o.x + z_p[i] / G::R; z_w[i] = o.y + z_p[i] % G::R;
             });
         }
+        if constexpr (EPRE) {
+            static_for<0, EU>([&](auto k_tag) {
+                constexpr int k = decltype(k_tag)::value;
+                const int o = tid + k * NT;
+                const int nb = o / UNITS_NB, o1 = o - nb * UNITS_NB;
+                const int m = o1 / (G::MT / 4);
+                const int tt = min(mb * G::TPB + m / G::PX, a.T - 1);
+                const int n = tt - (tt / a.N) * a.N;
+                const int2 og = *reinterpret_cast<const int2 *>(a.idx + 2 * n);
+                e_h[k] = og.x; e_w[k] = og.y;
+            });
+        }
+        if constexpr (EPV) static_for<0, EU>([&](auto k_tag) {  // bias / out_affine entries of this lane's output channels
+            constexpr int k = decltype(k_tag)::value;
+            const int o = tid + k * NT;
+            const int nb = o / UNITS_NB, o1 = o - nb * UNITS_NB;
+            const int co = (ng * NB + nb) * G::MT + 4 * (o1 % (G::MT / 4));
+            const int cs = (o < OUT_UNITS && co < a.Cout) ? co : 0;  // (dead units: a valid address, never used)
+            e_bias[k] = e_os[k] = e_oh[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e_first_pass) {
+                if (a.bias) e_bias[k] = *reinterpret_cast<const float4 *>(a.bias + cs);
+                if (a.oscale) {
+                    e_os[k] = *reinterpret_cast<const float4 *>(a.oscale + cs);
+                    e_oh[k] = *reinterpret_cast<const float4 *>(a.oshift + cs);
+                }
+            }
+        });
         if (AFF) {
             tab_fetch(first, t_sc, t_sh);
             tab_fetch(min(first + 1, last), t_sc1, t_sh1);
@@ -352,7 +396,7 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
                 if (AFF) s_tab[i] = (off != kOOB || off2 != kOOB) ? c_l : CCk;
             }
         });
-        if (SRC == SRC_SCATTER_GATHER) {
+        if constexpr (SRC == SRC_SCATTER_GATHER) {
             static_for<0, NS>([&](auto i_tag) {
                 constexpr int i = decltype(i_tag)::value;
                 const int blk = z_m0[i], c_l = z_c[i], b = z_b[i];
@@ -363,6 +407,23 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
                 s_off[i] = off;
                 s_off2[i] = off2;
                 if (AFF) s_tab[i] = in ? c_l : CCk;
+            });
+        }
+        if constexpr (EPRE) {
+            static_for<0, EU>([&](auto k_tag) {
+                constexpr int k = decltype(k_tag)::value;
+                const int o = tid + k * NT;
+                const int nb = o / UNITS_NB, o1 = o - nb * UNITS_NB;
+                const int n4 = o1 % (G::MT / 4), m = o1 / (G::MT / 4);
+                const int pxo = m % G::PX;
+                const int t = mb * G::TPB + m / G::PX, co = (ng * NB + nb) * G::MT + 4 * n4;
+                const int b = min(t, a.T - 1) / a.N;
+                const int h = (a.offH + e_h[k]) / a.strH + pxo / G::RO, w = (a.offW + e_w[k]) / a.strW + pxo % G::RO;
+                const bool in = o < OUT_UNITS && t < a.T && co < a.Cout && h >= 0 && h < a.Ho && w >= 0 && w < a.Wo;
+                e_h[k] = h; e_w[k] = w; e_in[k] = in;
+                e_q[k] = in ? (((size_t)b * a.Ho + h) * a.Wo + w) * a.Cout + co : 0;  // (dead units: a valid address, never stored)
+                e_res[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e_first_pass && a.residual) e_res[k] = *reinterpret_cast<const float4 *>(a.residual + e_q[k]);
             });
         }
     } else {
@@ -635,8 +696,6 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
     }
     __syncthreads();
 
-    constexpr int UNITS_NB = G::MT * G::MT / 4;         // float4 units per N sub-block
-    constexpr int OUT_UNITS = NB * UNITS_NB;
     // K split: every split writes its partial sums (no bias / residual) to its own copy of the output
     // in the workspace; splitk_reduce_kernel adds them up in a fixed order (deterministic) with the epilogue
     float *const outp = a.out + (size_t)split * a.split_stride;
@@ -644,8 +703,10 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
     const float *const resp = a.ksplit > 1 ? nullptr : a.residual;
     if (NHWC) {
         // one float4 = 4 consecutive output channels of one pixel per lane and step
-#pragma unroll
-        for (int o = tid; o < OUT_UNITS; o += NT) {
+        static_for<0, EU>([&](auto k_tag) {
+            constexpr int k = decltype(k_tag)::value;
+            const int o = tid + k * NT;
+            if (EU * NT > OUT_UNITS && o >= OUT_UNITS) return;
             const int nb = o / UNITS_NB, o1 = o - nb * UNITS_NB;
             const int n4 = o1 % (G::MT / 4), m = o1 / (G::MT / 4);
             const float *r0 = red + (nb * G::MT + m) * RP + 4 * n4;
@@ -659,29 +720,45 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
             const int t = mb * G::TPB + t_l, co = (ng * NB + nb) * G::MT + 4 * n4;
             if (t < a.T && co < a.Cout) {  // (Cout % 4 == 0: host side)
                 if (biasp) {
-                    const float4 bb = *reinterpret_cast<const float4 *>(biasp + co);
+                    float4 bb;
+                    if constexpr (EPV) bb = e_bias[k];
+                    else bb = *reinterpret_cast<const float4 *>(biasp + co);
                     s.x += bb.x; s.y += bb.y; s.z += bb.z; s.w += bb.w;
                 }
                 auto post = [&](float4 v) -> float4 {
                     if (a.oscale && a.ksplit <= 1) {
-                        const float4 os = *reinterpret_cast<const float4 *>(a.oscale + co), oh = *reinterpret_cast<const float4 *>(a.oshift + co);
+                        float4 os, oh;
+                        if constexpr (EPV) { os = e_os[k]; oh = e_oh[k]; }
+                        else { os = *reinterpret_cast<const float4 *>(a.oscale + co); oh = *reinterpret_cast<const float4 *>(a.oshift + co); }
                         v.x = os.x * v.x; v.y = os.y * v.y; v.z = os.z * v.z; v.w = os.w * v.w;
                         v.x = oh.x + v.x; v.y = oh.y + v.y; v.z = oh.z + v.z; v.w = oh.w + v.w;
                         if (a.oact == SIGE_HIP_ACT_SWISH) { v.x = swish(v.x); v.y = swish(v.y); v.z = swish(v.z); v.w = swish(v.w); }
                     }
                     return v;
                 };
-                if (DST == DST_TILES) {
+                if constexpr (DST == DST_TILES) {
                     *reinterpret_cast<float4 *>(outp + ((size_t)t * G::PX + pxo) * a.Cout + co) = post(s);
                 } else {
-                    const int b = t / a.N, n = t - b * a.N;
-                    const int h = (a.offH + a.idx[2 * n]) / a.strH + pxo / G::RO, w = (a.offW + a.idx[2 * n + 1]) / a.strW + pxo % G::RO;
-                    if (h >= 0 && h < a.Ho && w >= 0 && w < a.Wo) {
-                        const size_t q = (((size_t)b * a.Ho + h) * a.Wo + w) * a.Cout + co;
+                    // (4 waves: pixel, address, bias and residual were fetched with the prologue's loads)
+                    bool inside;
+                    int h, w;
+                    size_t q;
+                    float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if constexpr (EPRE) {
+                        inside = e_in[k]; h = e_h[k]; w = e_w[k]; q = e_q[k]; rr = e_res[k];
+                    } else {
+                        const int bq = t / a.N, n = t - bq * a.N;
+                        h = (a.offH + a.idx[2 * n]) / a.strH + pxo / G::RO;
+                        w = (a.offW + a.idx[2 * n + 1]) / a.strW + pxo % G::RO;
+                        inside = h >= 0 && h < a.Ho && w >= 0 && w < a.Wo;
+                        q = inside ? (((size_t)bq * a.Ho + h) * a.Wo + w) * a.Cout + co : 0;
+                        if (inside && resp) rr = *reinterpret_cast<const float4 *>(resp + q);
+                    }
+                    if (inside) {
                         if (resp) {
-                            const float4 rr = *reinterpret_cast<const float4 *>(resp + q);
                             s.x += rr.x; s.y += rr.y; s.z += rr.z; s.w += rr.w;
                             if (a.x1) {
+                                const int b = t / a.N;
                                 const int t1 = a.table1[(h / a.R1) * a.gW1 + w / a.S1];
                                 if (t1 >= 0) {
                                     const float4 xv = *reinterpret_cast<const float4 *>(
@@ -694,7 +771,7 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
                     }
                 }
             }
-        }
+        });
         return;
     }
     // NCHW: one float4 (4 consecutive pixels of one tile and one output channel) per lane and step
