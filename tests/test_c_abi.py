@@ -68,3 +68,43 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 src = open(os.path.join(root, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "libsige_oracle" not in src, f
+
+
+def _prototypes():
+    """{name: (return class, [parameter classes])} parsed from include/sige_hip.h."""
+    text = open(os.path.join(REPO, "include", "sige_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+
+    def cls(decl: str) -> str:
+        decl = decl.strip()
+        if "*" in decl:
+            return "char*" if re.match(r"(const\s+)?char\b", decl) else "ptr"
+        for key, name in (("size_t", "size"), ("int64_t", "i64"), ("double", "f64"), ("float", "f32"), ("int", "int")):
+            if re.search(r"\b%s\b" % key, decl):
+                return name
+        raise AssertionError("unclassified parameter: %r" % decl)
+
+    out = {}
+    for ret, name, params in re.findall(r"([A-Za-z_][A-Za-z0-9_ ]*?[ *]+)(sige_hip_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
+        params = params.strip()
+        plist = [] if params in ("", "void") else [cls(p) for p in params.split(",")]
+        out[name] = (cls(ret), plist)
+    return out
+
+
+def test_python_binding_matches_the_header_parameter_by_parameter():
+    """A ctypes signature that disagrees with the header only shows on the GPU (as garbage arguments): compare
+    the class of every parameter and of the return value of every bound entry point with its prototype."""
+    from sige_amd import hip
+
+    names = {ctypes.c_void_p: "ptr", ctypes.c_int: "int", ctypes.c_size_t: "size", ctypes.c_int64: "i64",
+             ctypes.c_float: "f32", ctypes.c_double: "f64", ctypes.c_char_p: "char*"}
+    protos = _prototypes()
+    assert sorted(protos) == _declared()
+    for name, (res, args) in hip._SIGNATURES.items():
+        want_res, want_args = protos[name]
+        got_args = [names[a] for a in args]
+        assert got_args == want_args, (name, [(i, g, w) for i, (g, w) in enumerate(zip(got_args, want_args)) if g != w],
+                                       len(got_args), len(want_args))
+        assert names[res] == want_res, name
