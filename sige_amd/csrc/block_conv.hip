@@ -118,6 +118,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_nhwc_kernel(const float *__
                                                                 const float *__restrict__ oscale, const float *__restrict__ oshift, int oact,
                                                                 float *__restrict__ out) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        // everything this element needs is requested before the first value is used: bias, residual and the
+        // out-affine entries do not depend on the partial sums (loaded after them, each was one more memory round trip)
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c = (int)((4 * i) % C);
+        float4 b = zero, r = zero, os = zero, oh = zero;
+        if (bias) b = *reinterpret_cast<const float4 *>(bias + c);
+        if (residual) r = *reinterpret_cast<const float4 *>(residual + 4 * i);
+        if (oscale) {
+            os = *reinterpret_cast<const float4 *>(oscale + c);
+            oh = *reinterpret_cast<const float4 *>(oshift + c);
+        }
         // all (<= 8) partials in flight at once, added in split order
         float4 p[8];
 #pragma unroll
@@ -126,16 +137,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_nhwc_kernel(const float *__
 #pragma unroll
         for (int s = 1; s < 8; ++s)
             if (s < S) { v.x += p[s].x; v.y += p[s].y; v.z += p[s].z; v.w += p[s].w; }
-        if (bias) {
-            const float4 b = *reinterpret_cast<const float4 *>(bias + (4 * i) % C);
-            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-        }
-        if (residual) {
-            const float4 r = *reinterpret_cast<const float4 *>(residual + 4 * i);
-            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-        }
+        if (bias) { v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+        if (residual) { v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
         if (oscale) {
-            const float4 os = *reinterpret_cast<const float4 *>(oscale + (4 * i) % C), oh = *reinterpret_cast<const float4 *>(oshift + (4 * i) % C);
             v.x = os.x * v.x; v.y = os.y * v.y; v.z = os.z * v.z; v.w = os.w * v.w;
             v.x = oh.x + v.x; v.y = oh.y + v.y; v.z = oh.z + v.z; v.w = oh.w + v.w;
             if (oact == SIGE_HIP_ACT_SWISH) { v.x = swish(v.x); v.y = swish(v.y); v.z = swish(v.z); v.w = swish(v.w); }

@@ -62,12 +62,11 @@ __global__ __launch_bounds__(64) void gn_finish_kernel(const float *__restrict__
     for (int k0 = lane; k0 < splits; k0 += 64 * 8) {  // 8 partials in flight per lane, added in split order
         float2 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int k = k0 + 64 * u;
-            v[u] = k < splits ? *reinterpret_cast<const float2 *>(p + 2 * k) : make_float2(0.f, 0.f);
-        }
+        for (int u = 0; u < 8; ++u)  // (clamped address, not a conditional load: a branch per load would serialise them)
+            v[u] = *reinterpret_cast<const float2 *>(p + 2 * min(k0 + 64 * u, splits - 1));
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { s += v[u].x; ss += v[u].y; }
+        for (int u = 0; u < 8; ++u)
+            if (k0 + 64 * u < splits) { s += v[u].x; ss += v[u].y; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
