@@ -15,7 +15,7 @@ the forward (halos come from the local cache).  So:
 
 `torch.distributed` backend "nccl" is RCCL on ROCm; "gloo" works for CPU tests.
 """
-from typing import Iterable, List, Sequence, Tuple
+from typing import List, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
