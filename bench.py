@@ -8,17 +8,21 @@ random-init weights.  Workload at N=1: BASELINE.json configs[1] -- one sparse
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" = one sparse U-Net forward per GPU (each rank edits its own region of
-the shared original image; one process per GPU, RCCL).  The activation cache of
-the original image is computed by rank 0 and RCCL-broadcast to the other ranks
-in one flat buffer BEFORE the timed region (once per original image; its time is
-reported as `cache_broadcast_ms`).  The timed region replays a hipGraph of the
-sparse forward K times, bracketed by barrier + synchronize, max over ranks.
+`python bench.py --gpus N` launches its own N ranks (torch.distributed.run, one process per GPU, RCCL);
+under a torchrun environment it joins it.
 
-One JSON line on rank 0, with `roofline` (dominant hot-path kernel, measured with
-HIP events on the launch stream, rotating buffers) and `cpu_baseline` (the
-reference's own sige/cpu backend -- oracle/_ref -- under the same U-Net on the
-host cores; falls back to the C restatement, kind "port", if _ref is absent).
+A "step" = one sparse U-Net forward per GPU (each rank edits its own region of the shared original image).
+N = 1: the timed region is K hipGraph replays of that forward.  N > 1: the timed region is one JOB -- the
+activation cache of the original image, computed by rank 0, is distributed to the other ranks as one flat buffer
+(one RCCL collective; what a rank derives from the cache is rebuilt locally) and every rank then runs K sparse
+forwards -- so `value` counts the distribution inside the job; the steady-state rate (cache already resident)
+and the cache-per-step rate are reported next to it (`multi_gpu`).  Barrier + synchronize on both sides, max over ranks.
+
+One JSON line on rank 0, with `roofline` (dominant hot-path kernel, HIP events on the launch stream, rotating
+buffers), `roofline_gather` / `roofline_scatter_gather` / `roofline_hbm` + the `data_movement` table (the HBM-bound
+kernels, standalone), `parity_max_abs` (the benchmarked artefact's outputs against the reference's CPU path on the
+same weights / inputs / masks, per edit ratio) and `cpu_baseline` (the reference's own sige/cpu backend --
+oracle/_ref -- under the same U-Net on the host cores; the C restatement, kind "port", if _ref is absent).
 """
 import argparse
 import json
@@ -159,17 +163,6 @@ def a_numel(t):
     return t.numel()
 
 
-def pmc_traffic(family):
-    """HBM-side bytes per launch of a kernel family from the committed rocprofv3 PMC pass (bench.py cannot
-    run the profiler on itself); None if the file or the family is missing."""
-    try:
-        with open(os.path.join(REPO, "profiles", "r1k_pmc_traffic.json")) as f:
-            fam = json.load(f)["families"][family]
-        return int(fam["traffic_MB_per_launch"] * 1e6)
-    except Exception:
-        return None
-
-
 def shape_key(name, a):
     parts = [name]
     for v in a:
@@ -201,6 +194,75 @@ def time_graph_of(fn, reps, iters=5):
         s.synchronize()
     torch.cuda.current_stream().wait_stream(s)
     return a.elapsed_time(b) * 1e3 / (reps * iters)  # us per launch
+
+
+def data_movement_rooflines(hip, dev):
+    """HBM roofline of the data-movement kernels that replace sige/cuda/gather_kernel.cu:7-67, scatter_gather_kernel.cu:8-67 and
+    scatter_kernel.cu:8-44, standalone (the forward fuses most of them away), NCHW and channels-last, at a bandwidth-bound size
+    (15 % edit, C = 256, B = 2, 256 x 256) and at the headline's launch-bound size (1.2 %, C = 128, B = 1).  Algorithmic bytes =
+    SURVEY.md 8(d), reference out-of-place semantics; the in-place scatter is listed under its own name with the
+    cache-preserving minimum.  HIP events on the launch stream, rotating buffer sets larger than the 256 MiB Infinity Cache."""
+    from sige_amd.utils import reduce_mask
+
+    rows = []
+    for ratio, B, C in ((0.15, 2, 256), (0.012, 1, 128)):
+        mask = square_mask(ratio).to(dev)
+        idx6 = reduce_mask(mask, 6, 4, 1)
+        n6 = idx6.shape[0]
+        smap = hip.get_scatter_map(256, 256, 6, 6, 3, 3, 1, 1, 1, 1, idx6)
+        table = hip.tile_table(idx6, (1, 1), (1, 1), (4, 4), (256, 256))
+        full_bytes = 4 * B * C * 256 * 256
+        nsets = max(3, min(8, int(1.2e9 // (2 * full_bytes)) + 1))
+        for layout in ("nhwc", "nchw"):
+            fmt = torch.channels_last if layout == "nhwc" else torch.contiguous_format
+            ys = [torch.randn(B, C, 256, 256, device=dev).contiguous(memory_format=fmt) for _ in range(nsets)]
+            rs = [torch.randn(B, C, 256, 256, device=dev).contiguous(memory_format=fmt) for _ in range(nsets)]
+            t4 = [torch.randn(B * n6, C, 4, 4, device=dev).contiguous(memory_format=fmt) for _ in range(nsets)]
+            sc, sh = torch.randn(1, C, 1, 1, device=dev), torch.randn(1, C, 1, 1, device=dev)
+            e = 4
+            gbytes = 2 * e * B * n6 * C * 36
+            tile_bytes = e * B * n6 * C * 16
+            cl = layout == "nhwc"
+            ops = {
+                "gather (6x6, affine + SiLU)": (gbytes, (lambda i: hip.gather_cl(ys[i], 6, 6, idx6, sc, sh, "swish")) if cl else
+                                                (lambda i: hip.gather(ys[i], 6, 6, idx6, sc, sh, "swish", False))),
+                "gather (6x6, raw)": (gbytes, (lambda i: hip.gather_cl(ys[i], 6, 6, idx6)) if cl else
+                                      (lambda i: hip.gather(ys[i], 6, 6, idx6))),
+                "scatter_gather (4x4 -> 6x6, affine + SiLU)": (gbytes + 12 * n6 * 36,
+                                                               (lambda i: hip.scatter_gather_cl(t4[i], ys[i], 6, 6, idx6, smap, sc, sh, "swish")) if cl else
+                                                               (lambda i: hip.scatter_gather(t4[i], ys[i], 6, 6, idx6, smap, sc, sh, "swish", False))),
+                "scatter (out-of-place, + full residual)": (2 * full_bytes + 3 * tile_bytes,
+                                                            (lambda i: hip.scatter_cl(t4[i], ys[i], (1, 1), (1, 1), idx6, table, rs[i])) if cl else
+                                                            (lambda i: hip.scatter_fused(t4[i], ys[i], table, n6, rs[i]))),
+            }
+            if cl:
+                ops["scatter (in-place persistent output, + full residual)"] = (
+                    3 * tile_bytes, lambda i: hip.scatter_cl(t4[i], ys[i], (1, 1), (1, 1), idx6, table, rs[i], out=ys[(i + 1) % nsets]))
+            for name, (nbytes, f) in ops.items():
+                it = [0]
+
+                def rot():
+                    f(it[0] % nsets)
+                    it[0] += 1
+
+                us = time_graph_of(rot, reps=nsets * 2)
+                gbs = nbytes / us / 1e3
+                rows.append({"op": name, "layout": layout, "edit_ratio": ratio, "B": B, "C": C, "active_tiles": int(n6),
+                             "alg_MB": round(nbytes / 1e6, 2), "us": round(us, 2), "GBps": round(gbs, 1),
+                             "frac_of_hbm_peak": round(gbs / PEAK_HBM_GBS, 4),
+                             "regime": "bandwidth-bound" if nbytes / 6.3e6 > 10.0 else "launch-bound (< 10 us of traffic at the measured copy ceiling)"})
+            del ys, rs, t4
+    pick = lambda op, lay, r: next(x for x in rows if x["op"].startswith(op) and x["layout"] == lay and x["edit_ratio"] == r)  # noqa: E731
+    g = pick("gather (6x6, affine", "nhwc", 0.15)
+    sg = pick("scatter_gather", "nhwc", 0.15)
+    so = pick("scatter (out-of-place", "nhwc", 0.15)
+
+    def roof(x):
+        return {"kernel": x["op"], "layout": x["layout"], "shape": "[%d,%d,256,256], %d active tiles (%.0f %% edit)"
+                % (x["B"], x["C"], x["active_tiles"], x["edit_ratio"] * 100), "bound": "hbm", "alg_MB": x["alg_MB"], "us": x["us"],
+                "achieved": x["GBps"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": x["frac_of_hbm_peak"]}
+
+    return {"data_movement": rows, "roofline_gather": roof(g), "roofline_scatter_gather": roof(sg), "roofline_hbm": roof(so)}
 
 
 def capture(model, x, t):
@@ -248,11 +310,29 @@ def eager_ms(model, x, t, steps):
     return (time.perf_counter() - t0) * 1e3 / steps
 
 
+# ------------------------------------------------------ inputs shared by both legs --
+def make_inputs():
+    """The original image and the edit noise, on the CPU (both legs start from exactly these)."""
+    gen = torch.Generator(device="cpu").manual_seed(1)
+    x0 = torch.randn(1, 3, 256, 256, generator=gen)
+    noise = torch.randn(1, 3, 256, 256, generator=gen)
+    return x0, noise
+
+
+def edit_mask(ratio, rank=0):
+    """Each rank edits its own region of the shared original."""
+    return square_mask(ratio, top=100 - 6 * rank, left=90 + 6 * rank)
+
+
 # ---------------------------------------------------------------- cpu baseline --
-def cpu_baseline(cfg_ratio, seconds):
-    """The same U-Net + masks on the host cores, native ops from oracle/_ref (the
-    reference's own compiled sige/cpu backend) or, if that is absent, from the C
-    restatement.  Bounded to ~`seconds` of sparse forwards."""
+def cpu_reference(ratios, headline_ratio, seconds):
+    """The same U-Net, weights, original image, noise and masks as the GPU run (rank 0's edit) on the host cores, native
+    ops from oracle/_ref (the reference's own compiled sige/cpu backend) or, if that is absent, from the C restatement;
+    the tile convs are the reference's own F.conv2d call.  Returns (cpu_baseline dict, {ratio: sparse output}).
+    Timing protocol: 5 warm-up + up to 20 timed sparse forwards at the headline ratio, bounded by
+    `seconds`; `value` is quoted on the MEDIAN."""
+    import statistics
+
     from oracle import build_ref, oracle
     from sige_amd import runtime
     from sige_amd.utils import dilate_mask, downsample_mask
@@ -274,35 +354,93 @@ def cpu_baseline(cfg_ratio, seconds):
     torch.set_num_threads(cores)
     oracle.set_num_threads(cores)
     os.environ["OMP_NUM_THREADS"] = str(cores)
-    runtime.register_backend("cpu", ref if ref is not None else oracle)
+    runtime.register_backend("cpu", oracle.as_backend(ref) if ref is not None else oracle)
+    outs, times = {}, []
     try:
         torch.manual_seed(0)
         model = DDPMSparseUNet(DDPMConfig()).eval()
-        x0 = torch.randn(1, 3, 256, 256)
-        mask = square_mask(cfg_ratio)
-        x1 = x0 + torch.randn(1, 3, 256, 256) * mask
+        x0, noise = make_inputs()
         t = torch.zeros(1)
         with torch.no_grad():
             model.set_mode("full")
             model(x0, t)
-            model.set_masks(downsample_mask(dilate_mask(mask, 5), 8))
-            model.set_mode("sparse")
-            model(x1, t)  # warm-up
-            n, t0 = 0, time.perf_counter()
-            while True:
-                model(x1, t)
-                n += 1
-                dt = time.perf_counter() - t0
-                if dt >= seconds or n >= 200:
-                    break
+            for r in ratios:
+                mask = edit_mask(r)
+                model.set_masks(downsample_mask(dilate_mask(mask, 5), 8))
+                model.set_mode("sparse")
+                outs[r] = model(x0 + noise * mask, t)
+            if seconds > 0:
+                mask = edit_mask(headline_ratio)
+                x1 = x0 + noise * mask
+                model.set_masks(downsample_mask(dilate_mask(mask, 5), 8))
+                t_begin = time.perf_counter()
+                for i in range(25):
+                    t0 = time.perf_counter()
+                    model(x1, t)
+                    if i >= 5:
+                        times.append(time.perf_counter() - t0)
+                    if time.perf_counter() - t_begin > seconds and len(times) >= 3:
+                        break
     finally:
         runtime.unregister_backend("cpu")
-    return {"value": round(n / dt, 3), "unit": "forward/s", "ms_per_forward": round(dt / n * 1e3, 2), "cores": cores,
-            "kind": kind,
-            "sample": "%d sparse DDPM-256 U-Net forwards at %.1f%% edit (same model/masks as the GPU run, "
-                      "native ops = %s, convs = torch CPU)" % (n, cfg_ratio * 100,
-                                                             "oracle/_ref (reference sige/cpu)" if ref is not None
-                                                             else "oracle C restatement")}
+    base = None
+    if times:
+        med = statistics.median(times)
+        base = {"value": round(1.0 / med, 3), "unit": "forward/s", "ms_per_forward": round(med * 1e3, 2),
+                "ms_per_forward_mean": round(sum(times) / len(times) * 1e3, 2), "statistic": "median", "cores": cores,
+                "kind": kind,
+                "sample": "%d timed sparse DDPM-256 U-Net forwards at %.1f%% edit after 5 warm-ups (same weights, original "
+                          "image, noise and masks as the GPU run; native ops = %s, tile convs = torch CPU F.conv2d as in "
+                          "sige/nn/base.py:88-89)" % (len(times), headline_ratio * 100,
+                                                     "oracle/_ref (reference sige/cpu)" if ref is not None
+                                                     else "oracle C restatement")}
+    return base, outs
+
+
+# ---------------------------------------------------------------- launching --
+def self_launch(args):
+    """`python bench.py --gpus N` without a torchrun environment: re-exec under torch.distributed.run, one rank per GPU."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    n_vis = torch.cuda.device_count()
+    if n_vis < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (args.gpus, n_vis))
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
+def source_hash():
+    from sige_amd import build
+
+    return build.source_hash()
+
+
+def pmc_traffic(family):
+    """HBM-side bytes per launch of a kernel family from the committed rocprofv3 PMC pass -- bench.py cannot run the
+    profiler on itself -- but ONLY if that pass was taken on exactly these kernel sources (hash of sige_amd/csrc +
+    include/, recorded by tools/pmc_traffic.py); otherwise (None, why)."""
+    path = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except Exception:
+        return None, "no profiles/pmc_traffic.json"
+    if d.get("source_hash") != source_hash():
+        return None, "profiles/pmc_traffic.json was measured on different kernel sources (stale): not reported"
+    fam = d.get("families", {}).get(family)
+    if fam is None:
+        return None, "family %s not in profiles/pmc_traffic.json" % family
+    return int(fam["traffic_MB_per_launch"] * 1e6), d.get("provenance", "profiles/pmc_traffic.json")
 
 
 # ------------------------------------------------------------------------ main --
@@ -313,26 +451,31 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--ratio", type=float, default=0.012, help="edit ratio of the headline workload")
     ap.add_argument("--sweep", default="0.012,0.05,0.15", help="edit ratios for the sweep section ('' = skip)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline timing (0 = skip the CPU leg)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layout", default="nhwc", choices=["nhwc", "nchw"],
                     help="memory format of the activations: nhwc = torch.channels_last (default), nchw = the reference's")
     ap.add_argument("--no-inplace-scatter", action="store_true",
                     help="Scatter modules return a fresh full tensor per call (reference semantics) instead of "
                          "updating a persistent output buffer")
+    ap.add_argument("--distribute", default="auto", choices=["auto", "broadcast", "scatter_allgather"],
+                    help="N > 1: collective that distributes the original image's cache")
     args = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path; see DESIGN.md)")
+    self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU path; see DESIGN.md)")
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d "
+                         "(or plain `python bench.py --gpus %d`, which does that itself)" % (args.gpus, world, args.gpus, args.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
 
     from sige_amd import hip, parallel
     from sige_amd.utils import dilate_mask, downsample_mask
@@ -344,59 +487,82 @@ def main():
     torch.manual_seed(0)
     model = DDPMSparseUNet(DDPMConfig()).to(dev).eval()  # random init: no checkpoints offline
     n_params = sum(p.numel() for p in model.parameters())
-    gen = torch.Generator(device="cpu").manual_seed(1)
-    x0 = torch.randn(1, 3, 256, 256, generator=gen).to(dev)
-    noise = torch.randn(1, 3, 256, 256, generator=gen).to(dev)
+    x0_cpu, noise_cpu = make_inputs()
+    x0, noise = x0_cpu.to(dev), noise_cpu.to(dev)
     if args.layout == "nhwc":
         model = model.to(memory_format=torch.channels_last)
         x0, noise = x0.contiguous(memory_format=torch.channels_last), noise.contiguous(memory_format=torch.channels_last)
-    model.set_scatter_inplace(args.layout == "nhwc" and not args.no_inplace_scatter)
+    inplace = args.layout == "nhwc" and not args.no_inplace_scatter
+    model.set_scatter_inplace(inplace)
     t = torch.zeros(1, device=dev)
 
     def edited(ratio):
-        # each rank edits its own region of the shared original
-        m = square_mask(ratio, top=100 - 6 * rank, left=90 + 6 * rank).to(dev)
+        m = edit_mask(ratio, rank).to(dev)
         return m, x0 + noise * m
 
     result = {}
+    gpu_out = {}  # edit ratio -> sparse output of the benchmarked artefact (rank 0), for the parity check
     with torch.no_grad():
-        # ---- dense baseline: the stock U-Net forward on the same GPU ------------
-        model.set_mode("full")
-        model.set_plain_dense(True)
-        mask, x1 = edited(args.ratio)
-        gd, _ = capture(model, x1, t)
-        dense_ms = timed_replays(gd, max(10, args.steps // 10), 3, 1) * 1e3 / max(10, args.steps // 10)
-        del gd
-        dense_by_layout = {args.layout: round(dense_ms, 3)}
-        if args.layout == "nhwc":
-            # the stock model in the reference's own layout too; the baseline is the faster of the two
-            model.to(memory_format=torch.contiguous_format)
-            gd, _ = capture(model, x1.contiguous(), t)
-            d2 = timed_replays(gd, max(10, args.steps // 10), 3, 1) * 1e3 / max(10, args.steps // 10)
+        # ---- dense baseline: the stock U-Net forward on the same GPU (rank 0) ------
+        dense_ms = None
+        if rank == 0:
+            model.set_mode("full")
+            model.set_plain_dense(True)
+            mask, x1 = edited(args.ratio)
+            kd = max(10, args.steps // 10)
+            gd, _ = capture(model, x1, t)
+            dense_ms = timed_replays(gd, kd, 3, 1) * 1e3 / kd
             del gd
-            model.to(memory_format=torch.channels_last)
-            dense_by_layout["nchw"] = round(d2, 3)
-            dense_ms = min(dense_ms, d2)
-        result["dense_forward_ms_by_layout"] = dense_by_layout
-        model.set_plain_dense(False)
+            dense_by_layout = {args.layout: round(dense_ms, 3)}
+            if args.layout == "nhwc":
+                # the stock model in the reference's own layout too; the baseline is the faster of the two
+                model.to(memory_format=torch.contiguous_format)
+                gd, _ = capture(model, x1.contiguous(), t)
+                d2 = timed_replays(gd, kd, 3, 1) * 1e3 / kd
+                del gd
+                model.to(memory_format=torch.channels_last)
+                dense_by_layout["nchw"] = round(d2, 3)
+                dense_ms = min(dense_ms, d2)
+            result["dense_forward_ms_by_layout"] = dense_by_layout
+            model.set_plain_dense(False)
 
-        # ---- cache of the original image: rank 0 computes, RCCL broadcast --------
-        model(x0, t)  # every rank runs it once so shapes / cache slots exist
-        flat = parallel.pack_caches(model)  # every cache tensor is now a view of `flat`
+        # ---- cache of the original image: rank 0 computes it, one collective distributes it ----
+        model.set_mode("full")
+        model(x0 if rank == 0 else torch.zeros_like(x0), t)  # ranks > 0 only need the cache SLOTS (shapes) here
+        flat = parallel.pack_caches(model)  # every ORIGINAL cache tensor is now a view of `flat`
         n_cached = len(parallel.cache_slots(model))
         torch.cuda.synchronize()
-        bcast_ms = 0.0
+        dist_info = {}
+        distribute = None
         if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            parallel.broadcast_cache(flat, src=0)
-            torch.cuda.synchronize()
-            bcast_ms = (time.perf_counter() - t0) * 1e3
-            t0 = time.perf_counter()
-            parallel.broadcast_cache(flat, src=0)  # second = steady-state (communicator warm)
-            torch.cuda.synchronize()
-            bcast_ms = min(bcast_ms, (time.perf_counter() - t0) * 1e3)
+            methods = ["broadcast", "scatter_allgather"] if args.distribute == "auto" else [args.distribute]
+            best = None
+            for meth in methods:
+                try:
+                    ms = []
+                    for _ in range(2):  # first = communicator set-up, second = steady state
+                        dist.barrier()
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        parallel.distribute_cache(flat, src=0, method=meth)
+                        torch.cuda.synchronize()
+                        ms.append((time.perf_counter() - t0) * 1e3)
+                    v = parallel.max_over_ranks(min(ms), device=dev)
+                    dist_info[meth + "_ms"] = round(v, 3)
+                    if best is None or v < best[0]:
+                        best = (v, meth)
+                except Exception as e:  # a collective this RCCL build cannot run: keep the other
+                    dist_info[meth + "_error"] = repr(e)[:200]
+            if best is None:
+                raise SystemExit("no cache distribution method worked: %r" % dist_info)
+            distribute = best[1]
+            parallel.refresh_derived(model)
+            # every rank now holds rank 0's cache: compare checksums
+            chk = flat.double().sum().reshape(1)
+            lo, hi = chk.clone(), chk.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            dist_info["cache_identical_on_all_ranks"] = bool(lo.item() == hi.item())
 
         def prepare(ratio):
             m, xe = edited(ratio)
@@ -408,13 +574,47 @@ def main():
         x1 = prepare(args.ratio)
         model(x1, t)  # packs weights, builds tile tables
         tracer.log = []
+        n0 = hip.launch_count()
         model(x1, t)
+        launches_per_forward = hip.launch_count() - n0  # kernels libsige_hip.so launched for one sparse forward
         trace, tracer.log = tracer.log, None
         e_ms = eager_ms(model, x1, t, 20)
         g, out = capture(model, x1, t)
-        dt = timed_replays(g, args.steps, args.warmup, world)
+        for _ in range(args.warmup):
+            g.replay()
+
+        # timed region.  N = 1: K graph replays.  N > 1: ONE job = the original image's cache distributed from rank 0
+        # (one collective + the local refresh of what is derived from it) followed by K sparse forwards per rank.
+        def timed_job(with_distribution):
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            t_d = 0.0
+            if with_distribution:
+                parallel.distribute_cache(flat, src=0, method=distribute)
+                parallel.refresh_derived(model)  # in place: the captured graph's buffers keep their addresses
+                torch.cuda.synchronize()
+                t_d = time.perf_counter() - t0
+            for _ in range(args.steps):
+                g.replay()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            dt_ = time.perf_counter() - t0
+            return parallel.max_over_ranks(dt_, device=dev), parallel.max_over_ranks(t_d, device=dev)
+
+        dt_steady, _ = timed_job(False)
+        if world > 1:
+            dt, dist_s = timed_job(True)
+        else:
+            dt, dist_s = dt_steady, 0.0
         ms_per_step = dt * 1e3 / args.steps
+        ms_steady = dt_steady * 1e3 / args.steps
+        g.replay()
+        torch.cuda.synchronize()
         assert torch.isfinite(out).all()
+        gpu_out[args.ratio] = out.float().cpu()
 
         if rank == 0:
             # ---- per-kernel accounting of the hot path (warm, in-situ tensors) ----
@@ -445,7 +645,8 @@ def main():
             conv = [f for n, f in fam.items() if n.startswith("block_conv")]  # the active-block (SIGE) convs
             conv_tflops = sum(f["flops"] for f in conv) / max(1e-9, sum(f["us"] for f in conv)) / 1e6
             hot_us = sum(f["us"] for f in fam.values())
-            result.update(kernels=kernels, hot_path_us=round(hot_us, 1), block_conv_tflops=round(conv_tflops, 2))
+            result.update(kernels=kernels, hot_path_us=round(hot_us, 1), block_conv_tflops=round(conv_tflops, 2),
+                          launches_per_forward=launches_per_forward)
 
             # ---- roofline of the dominant hot-path kernel family ---------------------
             if not args.no_roofline:
@@ -474,57 +675,33 @@ def main():
                 is_mfma = fam[dom]["flops"] > 0
                 achieved = tot_work / tot_us / (1e6 if is_mfma else 1e3)
                 peak = PEAK_F32_MFMA_TFS if is_mfma else PEAK_HBM_GBS
+                traffic, traffic_note = pmc_traffic(dom)
                 result["roofline"] = {
                     "kernel": dom, "bound": "mfma" if is_mfma else "hbm",
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s" if is_mfma else "GB/s",
-                    "frac": round(achieved / peak, 4), "traffic": pmc_traffic(dom),
+                    "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_note,
                     "launches_per_forward": launches, "avg_launch_us": round(tot_us / launches, 2),
                     "work_per_launch": round(tot_work / launches / (1e9 if is_mfma else 1e6), 4),
                     "work_unit": "GFLOP" if is_mfma else "MB",
-                    "note": "algorithmic work of all %d launches of this kernel in one forward / their summed "
+                    "note": "algorithmic work of all %d launches of this kernel family in one forward / their summed "
                             "duration (hipGraph of back-to-back launches, HIP events on the launch stream, "
-                            "rotating input sets); traffic = bytes per launch from the committed PMC pass "
-                            "profiles/r1k_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs, "
-                            "FETCH_SIZE doubled per the gfx950 correction; L2-miss traffic incl. Infinity-Cache hits)"
-                            % launches}
-                # secondary: the HBM-bound copy-through scatter (reference semantics: a fresh full tensor per call,
-                # sige/cpu/scatter.cpp:83) at its largest shape in this model.  The forward itself no longer launches
-                # it (conv -> scatter is fused into the conv's epilogue over a persistent output), so it is measured
-                # standalone on the module's own cache, index list and tile table, with rotating buffers.
-                from sige_amd.nn import Scatter as _Scatter
+                            "rotating input sets); traffic = fabric-side bytes per launch from a rocprofv3 PMC pass "
+                            "(FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, separate runs; Infinity-Cache hits "
+                            "included), printed only when that pass was taken on these exact kernel sources" % launches}
+                result.update(data_movement_rooflines(hip, dev))
+        del trace
 
-                cands = [m for m in model.modules() if isinstance(m, _Scatter) and m.original_outputs]
-                if cands:
-                    m = max(cands, key=lambda m: next(iter(m.original_outputs.values())).numel())
-                    gm = m.gather.module
-                    y = next(iter(m.original_outputs.values()))
-                    idx = gm.indices_on(dev)
-                    table = gm.tile_table(y.shape[2:], dev)
-                    nsets = 6
-                    fmt = torch.channels_last if hip.is_cl(y) else torch.contiguous_format
-                    ys = [torch.randn_like(y) for _ in range(nsets)]
-                    rs = [torch.randn_like(y) for _ in range(nsets)]
-                    xs = [torch.randn(y.shape[0] * idx.shape[0], y.shape[1], *gm.out_tile, device=dev).contiguous(memory_format=fmt)
-                          for _ in range(nsets)]
-                    it = [0]
-
-                    def rot2():
-                        i = it[0] % nsets
-                        if hip.is_cl(y):
-                            hip.scatter_cl(xs[i], ys[i], gm.offset, gm.model_stride, idx, table, rs[i])
-                        else:
-                            hip.scatter_fused(xs[i], ys[i], table, idx.shape[0], rs[i])
-                        it[0] += 1
-
-                    us = time_graph_of(rot2, reps=nsets * 2)
-                    nbytes = 2 * 4 * y.numel() + 4 * xs[0].numel() * 3
-                    result["roofline_hbm"] = {"kernel": "scatter (out-of-place, one pass, + residual)", "shape": str(tuple(y.shape)),
-                                              "layout": "nhwc" if hip.is_cl(y) else "nchw", "active_tiles": int(idx.shape[0]),
-                                              "alg_MB": round(nbytes / 1e6, 1), "us": round(us, 2),
-                                              "achieved": round(nbytes / us / 1e3, 1), "peak": PEAK_HBM_GBS,
-                                              "unit": "GB/s", "frac": round(nbytes / us / 1e3 / PEAK_HBM_GBS, 4)}
-                    del ys, rs, xs
-        del g, trace
+        # ---- the same forward with the reference's out-of-place Scatter semantics (a fresh tensor per call) ----
+        if rank == 0 and inplace:
+            model.set_scatter_inplace(False)
+            model(x1, t)
+            g2, out2 = capture(model, x1, t)
+            k2 = max(20, args.steps // 4)
+            result["forward_ms_out_of_place"] = round(timed_replays(g2, k2, 5, 1) * 1e3 / k2, 4)
+            result["out_of_place_equals_in_place"] = bool(torch.equal(out2, out))
+            del g2, out2
+            model.set_scatter_inplace(True)
+        del g
 
         # ---- edit-ratio sweep (rank 0 only, short) -----------------------------------
         sweep = []
@@ -535,22 +712,28 @@ def main():
                 tracer.log = []
                 model(xs, t)
                 tr, tracer.log = tracer.log, None
-                flops = sum(op_cost(n, a, k)[2] for n, a, k, o in tr if op_cost(n, a, k)[0] != "dense_conv_mfma")
-                gs, _ = capture(model, xs, t)
+                costs = [op_cost(n, a, k) for n, a, k, o in tr]
+                flops = sum(c[2] for c in costs if c[0] != "dense_conv_mfma")
+                gs, outs = capture(model, xs, t)
                 k = max(20, args.steps // 4)
                 ms = timed_replays(gs, k, 5, 1) * 1e3 / k
+                gpu_out[r] = outs.float().cpu()
                 n256 = max([a[3].shape[0] for n, a, kk, o in tr if n in ("gather", "gather_cl", "gather_conv_cl") and a[0].shape[2] == 256]
                            + [a[2].shape[0] for n, a, kk, o in tr if n == "gather_conv" and a[0].shape[2] == 256] + [0])
                 sweep.append({"edit_ratio": r, "forward_ms": round(ms, 3), "speedup_vs_dense": round(dense_ms / ms, 2),
                               "active_tiles_256": n256, "block_conv_GFLOP": round(flops / 1e9, 2)})
-                del gs, tr
+                del gs, tr, outs
 
     if world > 1:
         dist.barrier()
     if rank == 0:
         cpu = None
-        if args.cpu_seconds > 0 and world == 1:
-            cpu = cpu_baseline(args.ratio, args.cpu_seconds)
+        parity = None
+        if args.cpu_seconds > 0:
+            # the benchmarked artefact (this layout, in-place buffers, hipGraph replay) against the reference's CPU path on
+            # the SAME weights / image / noise / masks: max |gpu - cpu| per edit ratio, outside every timed region
+            cpu, cpu_out = cpu_reference(sorted(gpu_out), args.ratio, args.cpu_seconds if world == 1 else 0.0)
+            parity = {("%g" % r): round(float((gpu_out[r] - cpu_out[r]).abs().max()), 7) for r in sorted(gpu_out)}
         line = {
             "metric": "DDPM-256 U-Net sparse (SIGE) forwards/s",
             "value": round(world * args.steps / dt, 2),
@@ -560,24 +743,44 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "DDPM 256x256 church U-Net (ch128, mult 1-1-2-2-4-4, %.1fM params, random init), "
-                                   "%.1f%% square edit, one edited image per GPU, hipGraph replay, %s activations%s"
+                                   "%.1f%% square edit, one edited image per GPU, hipGraph replay, %s activations%s%s"
                                    % (n_params / 1e6, args.ratio * 100, args.layout.upper(),
-                                      ", in-place scatter buffers" if (args.layout == "nhwc" and not args.no_inplace_scatter) else ""),
+                                      ", in-place scatter buffers" if inplace else "",
+                                      "; the timed job = distribute the original image's cache from rank 0 (%s) + %d sparse "
+                                      "forwards per rank" % (distribute, args.steps) if world > 1 else ""),
                        "edit_ratio": args.ratio, "batch_per_gpu": 1, "resolution": 256,
                        "parallelism": "dp%d" % world},
-            "forward_ms": round(ms_per_step, 4),
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "devices": [torch.cuda.get_device_name(i) for i in range(min(world, torch.cuda.device_count()))],
+            "forward_ms": round(ms_steady, 4),
             "forward_ms_eager": round(e_ms, 3),
             "dense_forward_ms": round(dense_ms, 3),
-            "speedup_vs_dense": round(dense_ms / ms_per_step, 2),
+            "speedup_vs_dense": round(dense_ms / ms_steady, 2),
             "cache_bytes": int(flat.numel() * 4), "cached_tensors": n_cached,
-            "cache_broadcast_ms": round(bcast_ms, 3),
             "sweep": sweep,
         }
+        if world > 1:
+            step_s = dt_steady / args.steps
+            line["multi_gpu"] = dict(
+                dist_info, method=distribute,
+                cache_distribution_ms=round(dist_s * 1e3, 3),
+                value_cache_distribution_inside_job=round(world * args.steps / dt, 2),
+                value_steady_state_cache_resident=round(world * args.steps / dt_steady, 2),
+                value_cache_refreshed_every_step=round(world / (dist_s + step_s), 2),
+                note="`value` counts ONE cache distribution (collective + local refresh of derived buffers) inside the timed "
+                     "job of %d steps; steady_state = the same replays with the cache already resident; every_step = a fresh "
+                     "cache per step (SDEdit-style), computed from the two measured times" % args.steps)
         line.update(result)
+        if parity is not None:
+            line["parity_max_abs"] = parity
+            line["parity_tolerance"] = 1e-3
+            line["parity_ok"] = bool(max(parity.values()) <= 1e-3)
+            line["parity_against"] = "oracle/_ref (reference sige/cpu) + torch CPU convs, same weights / inputs / masks"
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -56,6 +56,9 @@ int sige_hip_version(void);
 const char *sige_hip_error_string(int status);
 /* name of device 0's gcnArchName ("gfx950...") or NULL if no device. */
 const char *sige_hip_device_arch(void);
+/* number of GPU kernels this library has launched in the process so far (all entry
+ * points, all streams): measurement aid -- launches per forward in bench.py. */
+int64_t sige_hip_launch_count(void);
 
 /* ---- gather : replaces gather_cpu / gather_cuda -------------------------
  * (sige/cpu/gather.cpp:60-114, sige/cuda/gather_kernel.cu:69-124, gather.h:5-12)
@@ -127,6 +130,31 @@ int sige_hip_scatter_gather_f32(const float *x, const float *y, int B, int C, in
                                 const float *shift, int shiftB, int shiftC, int shiftH, int shiftW,
                                 int activation, int activation_first, float *out, void *stream);
 
+/* ---- mask pipeline : replaces sige.utils.compute_difference_mask / dilate_mask /
+ * downsample_mask (sige/utils.py:74-85, 40-71, 88-118) for masks that live on the GPU,
+ * without the reference's device -> host synchronisation per pyramid level
+ * (`min(threshold, level.max() - eps)`, utils.py:107).  All masks are bytes (0 / 1),
+ * row-major [H,W].
+ *   difference_mask  out[h,w] = any_c |a[c,h,w] - b[c,h,w]| > eps; a / b addressed through
+ *                    element strides (NCHW or channels-last; strideH must equal W*strideW)
+ *   dilate_mask      OR of the ORIGINAL mask shifted by 1..dilationH rows and 1..dilationW
+ *                    columns (a plus-shaped element, utils.py:57-61); out != mask
+ *   mask_pyramid     every level of downsample_mask in ONE launch: level 0 = mask, level k+1 =
+ *                    bilinear (align_corners=False) halving of the FLOAT level k; each level
+ *                    is thresholded at min(threshold, max(level) - eps) and dilated; levels
+ *                    are written back to back into `out` (sizes: sige_hip_mask_pyramid_levels,
+ *                    which mirrors the loop `h//=2; w//=2; stop when h<min_h and w<min_w`).
+ *                    scratch_floats >= (H/2)*(W/2) + (H/4)*(W/4) + (H*W+3)/4 + 8.          */
+int sige_hip_difference_mask_u8(const float *a, const float *b, int C, int H, int W,
+                                int64_t strideC, int64_t strideH, int64_t strideW, float eps,
+                                uint8_t *out, void *stream);
+int sige_hip_dilate_mask_u8(const uint8_t *mask, int H, int W, int dilationH, int dilationW,
+                            uint8_t *out, void *stream);
+int sige_hip_mask_pyramid_levels(int H, int W, int min_h, int min_w, int *hs, int *ws, int capacity);
+int sige_hip_mask_pyramid_u8(const uint8_t *mask, int H, int W, int min_h, int min_w,
+                             int dilationH, int dilationW, float threshold, float eps,
+                             float *scratch, size_t scratch_floats, uint8_t *out, void *stream);
+
 /* ---- reduce_mask : replaces sige.utils.reduce_mask ------------------------
  * (sige/utils.py:8-37: F.pad -> F.max_pool2d -> nonzero -> stride*i - pad).
  * mask: H*W bytes (non-zero = edited).  Writes up to `capacity` (h,w) pairs in
@@ -150,8 +178,9 @@ int sige_hip_reduce_mask_i32(const uint8_t *mask, int H, int W, int bH, int bW,
  *                                              has no MFMA path; use _direct)
  *   sige_hip_block_conv_pack_f32(w, ..., packed)
  *   sige_hip_block_conv_f32(x, ..., packed, bias, ..., out)
- * sige_hip_block_conv_direct_f32 is the any-shape (groups, odd tiles) vector
- * FMA kernel reading the original weight layout.                             */
+ * sige_hip_block_conv_direct_f32 is the any-shape (groups, odd tiles, dilation:
+ * Ro=(R-(kH-1)*dilationH-1)/strH+1) vector FMA kernel reading the original
+ * weight layout.                                                              */
 size_t sige_hip_block_conv_packed_size(int Cout, int Cin, int kH, int kW, int R, int S,
                                        int strideH, int strideW, int groups);
 int sige_hip_block_conv_pack_f32(const float *w, int Cout, int Cin, int kH, int kW,
@@ -161,7 +190,8 @@ int sige_hip_block_conv_f32(const float *x, int T, int Cin, int R, int S,
                             int strideH, int strideW, float *out, void *stream);
 int sige_hip_block_conv_direct_f32(const float *x, int T, int Cin, int R, int S,
                                    const float *w, const float *bias, int Cout, int kH, int kW,
-                                   int strideH, int strideW, int groups, float *out, void *stream);
+                                   int strideH, int strideW, int dilationH, int dilationW, int groups,
+                                   float *out, void *stream);
 /* Tuning knob (process-wide, not thread-safe): pin the MFMA kernel's output block to
  * mt pixels x (nb*mt) output channels, mt in {16, 32}, nb in {1, 2}; (0, 0) restores the
  * per-launch choice.  Results do not depend on it beyond fp32 summation order. */

@@ -171,6 +171,22 @@ def block_conv(x, weight, bias, stride, groups=1):
     return out
 
 
+def conv2d_tiles(x, weight, bias, stride, dilation, groups):
+    """The stacked-tile convolution exactly as the reference runs it: F.conv2d with padding 0
+    (sige/nn/base.py:88-89).  sige_amd's SIGEConv2d has no conv of its own off the GPU; a test that
+    registers this module as the "cpu" backend gets the reference's call through this hook."""
+    return torch.nn.functional.conv2d(x, weight, bias, stride, (0, 0), dilation, groups)
+
+
+def as_backend(native):
+    """A backend object for sige_amd.runtime.register_backend made of `native`'s five reference functions
+    (e.g. oracle/_ref, the reference's compiled sige/cpu) plus the conv2d_tiles hook above."""
+    import types
+
+    names = ("gather", "scatter", "scatter_with_block_residual", "scatter_gather", "get_scatter_map")
+    return types.SimpleNamespace(conv2d_tiles=conv2d_tiles, **{n: getattr(native, n) for n in names})
+
+
 def set_num_threads(n: int):
     """OpenMP thread count for the oracle's loops (libgomp is process-global)."""
     try:

@@ -6,8 +6,9 @@
  * cpu_baseline leg can check / time the HIP path against the reference's
  * algorithm.  Parity is PINNED: tests/test_oracle_golden.py checks every entry
  * point below against vectors produced by the reference's own sige/cpu
- * extension + sige.nn / sige.utils Python (tests/golden/make_golden.py) and
- * tests/test_oracle_vs_ref.py checks it live against oracle/_ref when built.
+ * extension + sige.nn / sige.utils Python (tests/golden/make_golden.py), and
+ * tests/test_oracle_golden.py::test_oracle_vs_compiled_reference checks it live
+ * against oracle/_ref (the reference's sige/cpu compiled here) when that is built.
  *
  * Each function names the reference file:line it restates (paths relative to
  * /root/reference).  Plain C99, scalar, single-threaded unless built with

@@ -13,11 +13,25 @@ REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIB_DIR, "libsige_hip.so")
-SOURCES = ["api.hip", "gather.hip", "scatter.hip", "reduce_mask.hip", "block_conv.hip", "conv_k3s1.hip", "conv_k1.hip",
+SOURCES = ["api.hip", "gather.hip", "scatter.hip", "reduce_mask.hip", "mask_pipeline.hip", "block_conv.hip", "conv_k3s1.hip", "conv_k1.hip",
            "conv_k3s2.hip", "conv_k3s1_nhwc.hip", "conv_k1_nhwc.hip", "conv_k3s2_nhwc.hip", "conv_k3s1_nhwc_w8.hip", "conv_k1_nhwc_w8.hip", "group_norm.hip", "attention.hip", "nhwc_ops.hip", "conv_out.hip", "conv_in.hip"]
 # -ffp-contract=off: the reference applies scale then shift as two separately
 # rounded fp32 ops (sige/cpu/gather.cpp:33-53); an fma would differ in the last bit.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
+
+
+def source_hash() -> str:
+    """sha256 over the kernel sources (csrc/*, include/sige_hip.h) and the compile flags: identifies the build a
+    committed profile was taken on (bench.py prints `roofline.traffic` only for a matching hash; the GPU box has no .git)."""
+    import hashlib
+
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".hpp", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(REPO, "include", "sige_hip.h"), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _hipcc() -> str:
@@ -35,20 +49,33 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _stale(obj: str, src: str, headers) -> bool:
+    if not os.path.isfile(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(d) > t for d in [src, *headers])
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
+    headers.append(os.path.join(REPO, "include", "sige_hip.h"))
     objs = []
     procs = []
     for src in SOURCES:
         obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+        objs.append(obj)
+        # only translation units whose source (or any header) changed are recompiled
+        hdrs = headers if src.startswith(("conv_k", "block_conv")) else [h for h in headers if not h.endswith("conv_mfma.hpp")]
+        if not force and not _stale(obj, os.path.join(CSRC, src), hdrs):
+            continue
         cmd = [_hipcc(), *FLAGS, "-I" + os.path.join(REPO, "include"), "-I" + CSRC, "-c",
                os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))
-        objs.append(obj)
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))

@@ -14,7 +14,9 @@ import sys
 import types
 
 
-def install(force: bool = True) -> None:
+def install(force: bool = False) -> None:
+    """Register this package as `sige`.  Refuses (RuntimeError) when a different `sige` package is already imported,
+    unless `force=True` (the foreign package's modules are then replaced for the rest of the process)."""
     import sige_amd
     from sige_amd import nn, utils
     from sige_amd.nn import base, gather, scatter, scatter_gather
@@ -52,6 +54,8 @@ def install(force: bool = True) -> None:
 
 
 def uninstall() -> None:
+    """Remove the alias again (only if the installed `sige` is ours: a foreign package is left alone)."""
+    if not getattr(sys.modules.get("sige"), "__sige_amd__", False):
+        return
     for name in [n for n in sys.modules if n == "sige" or n.startswith("sige.")]:
-        if getattr(sys.modules.get("sige"), "__sige_amd__", False) or name != "sige":
-            sys.modules.pop(name, None)
+        sys.modules.pop(name, None)

@@ -1,7 +1,14 @@
 // Version / error / device queries of libsige_hip.so.
 #include "common.hpp"
 
+#include <atomic>
+
+static std::atomic<long> g_launches{0};
+void sige::note_launches(int kernels) { g_launches.fetch_add(kernels, std::memory_order_relaxed); }
+
 extern "C" int sige_hip_version(void) { return SIGE_HIP_VERSION; }
+
+extern "C" int64_t sige_hip_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
 
 extern "C" const char *sige_hip_error_string(int status) {
     switch (status) {

@@ -161,5 +161,5 @@ extern "C" int sige_hip_attention_f32(const float *qkv, int B, int C, int HW, fl
         }
     }
     attn_apply_kernel<<<dim3(ceil_div(C, kAttnCh), HW / 16, B), 256, lds, st>>>(qkv, workspace, C, HW, out);
-    return launch_status();
+    return launch_status(2);
 }

@@ -43,7 +43,7 @@ static size_t packed_floats(int Cout, int Cin, int KK, int MT) {
 __global__ void block_conv_direct_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                          const float *__restrict__ bias, float *__restrict__ out,
                                          int T, int Cin, int R, int S, int Cout, int kH, int kW,
-                                         int strH, int strW, int groups, int Ro, int So, long total) {
+                                         int strH, int strW, int dilH, int dilW, int groups, int Ro, int So, long total) {
     const int cig = Cin / groups, cog = Cout / groups;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long r = i;
@@ -57,7 +57,7 @@ __global__ void block_conv_direct_kernel(const float *__restrict__ x, const floa
             const float *xp = x + (((size_t)t * Cin + g * cig + ci) * R + oy * strH) * S + ox * strW;
             const float *wq = w + ((size_t)co * cig + ci) * kH * kW;
             for (int ky = 0; ky < kH; ++ky)
-                for (int kx = 0; kx < kW; ++kx) acc = fmaf(xp[ky * S + kx], wq[ky * kW + kx], acc);
+                for (int kx = 0; kx < kW; ++kx) acc = fmaf(xp[ky * dilH * S + kx * dilW], wq[ky * kW + kx], acc);
         }
         out[i] = acc;
     }
@@ -253,6 +253,7 @@ static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
         const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
         splitk_reduce_nhwc_kernel<<<grid, 256, 0, st>>>(a.ws, a.ksplit, a.split_stride, n4, a.Cout, a.bias, a.residual,
                                                        a.oscale, a.oshift, a.oact, final_out);
+        note_launches(1);
     }
     return SIGE_HIP_OK;
 }
@@ -323,7 +324,7 @@ extern "C" int sige_hip_block_conv_pack_f32(const float *w, int Cout, int Cin, i
         pack_weights_kernel<1, 32><<<blocks(n32), 256, 0, st>>>(w, Cout, Cin, packed, n32);
         pack_weights_kernel<1, 16><<<blocks(n16), 256, 0, st>>>(w, Cout, Cin, packed + n32, n16);
     }
-    return launch_status();
+    return launch_status(2);
 }
 
 extern "C" int sige_hip_block_conv_f32(const float *x, int T, int Cin, int R, int S,
@@ -575,16 +576,19 @@ extern "C" int sige_hip_scatter_gather_conv_scatter_nhwc_f32(
 
 extern "C" int sige_hip_block_conv_direct_f32(const float *x, int T, int Cin, int R, int S,
                                               const float *w, const float *bias, int Cout, int kH, int kW,
-                                              int strideH, int strideW, int groups, float *out, void *stream) {
-    if (T < 0 || Cin <= 0 || Cout <= 0 || kH <= 0 || kW <= 0 || strideH <= 0 || strideW <= 0 || groups <= 0)
+                                              int strideH, int strideW, int dilationH, int dilationW, int groups,
+                                              float *out, void *stream) {
+    if (T < 0 || Cin <= 0 || Cout <= 0 || kH <= 0 || kW <= 0 || strideH <= 0 || strideW <= 0 || groups <= 0 ||
+        dilationH <= 0 || dilationW <= 0)
         return SIGE_HIP_EINVAL;
-    if (Cin % groups || Cout % groups || R < kH || S < kW) return SIGE_HIP_EINVAL;
+    const int eH = (kH - 1) * dilationH + 1, eW = (kW - 1) * dilationW + 1;  // extent of the dilated kernel
+    if (Cin % groups || Cout % groups || R < eH || S < eW) return SIGE_HIP_EINVAL;
     if (T == 0) return SIGE_HIP_OK;
     if (!x || !w || !out) return SIGE_HIP_EINVAL;
-    const int Ro = (R - kH) / strideH + 1, So = (S - kW) / strideW + 1;
+    const int Ro = (R - eH) / strideH + 1, So = (S - eW) / strideW + 1;
     const long total = (long)T * Cout * Ro * So;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     block_conv_direct_kernel<<<blocks, 256, 0, as_stream(stream)>>>(x, w, bias, out, T, Cin, R, S, Cout, kH, kW,
-                                                                   strideH, strideW, groups, Ro, So, total);
+                                                                   strideH, strideW, dilationH, dilationW, groups, Ro, So, total);
     return launch_status();
 }

@@ -63,7 +63,11 @@ __device__ __forceinline__ float affine_act(float z, const Bcast4 &scale, const 
     return z;
 }
 
-inline int launch_status() {
+// (api.hip) every entry point reports how many kernels it launched: sige_hip_launch_count()
+void note_launches(int kernels);
+
+inline int launch_status(int kernels = 1) {
+    note_launches(kernels);
     return hipGetLastError() == hipSuccess ? SIGE_HIP_OK : SIGE_HIP_ELAUNCH;
 }
 

@@ -158,7 +158,7 @@ extern "C" int sige_hip_group_norm_affine_f32(const float *x, int B, int C, int 
     gn_partial_kernel<<<dim3(splits, B * groups), kGNThreads, 0, st>>>(x, ge, splits, workspace);
     gn_finish_kernel<<<B * groups, 64, 0, st>>>(workspace, splits, B, C, groups, (double)ge, eps, gamma, beta,
                                                           scale, shift);
-    return launch_status();
+    return launch_status(2);
 }
 
 // ---- channels-last form: x [B,H,W,C] ----
@@ -185,6 +185,6 @@ extern "C" int sige_hip_group_norm_affine_nhwc_f32(const float *x, int B, int C,
     gn_partial_nhwc_kernel<<<dim3(splits, B), kGNThreads, 0, st>>>(x, C, HW, groups, splits, workspace);
     gn_finish_kernel<<<B * groups, 64, 0, st>>>(workspace, splits, B, C, groups, (double)(C / groups) * HW, eps,
                                                           gamma, beta, scale, shift);
-    return launch_status();
+    return launch_status(2);
 }
 

@@ -437,5 +437,5 @@ extern "C" int sige_hip_attention_nhwc_f32(const float *qkv, int B, int C, int H
     hipStream_t st = as_stream(stream);
     attn_scores_nhwc_kernel<<<dim3(HW / 16, HW / 16, B), kT, 0, st>>>(qkv, C, HW, scale, workspace);
     attn_apply_nhwc_kernel<<<dim3(ceil_div(C, 64), HW / 16, B), kT, lds, st>>>(qkv, workspace, C, HW, out);
-    return launch_status();
+    return launch_status(2);
 }

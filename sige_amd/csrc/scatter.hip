@@ -290,7 +290,7 @@ extern "C" int sige_hip_scatter_f32(const float *x, const float *y, int B, int C
     a.offH = offsetH; a.offW = offsetW; a.strH = strideH; a.strW = strideW;
     a.res = make_bcast(residual, resB, resC, resH, resW);
     launch_tiles<0>(a, st);
-    return launch_status();
+    return launch_status(2);
 }
 
 extern "C" int sige_hip_scatter_with_block_residual_f32(
@@ -319,7 +319,7 @@ extern "C" int sige_hip_scatter_with_block_residual_f32(
     c.B = B; c.C = C; c.H = H; c.W = W; c.N = N1; c.R = R1; c.S = S1;
     c.offH = 0; c.offW = 0; c.strH = 1; c.strW = 1;
     launch_tiles<1>(c, st);
-    return launch_status();
+    return launch_status(3);
 }
 
 extern "C" int sige_hip_tile_table_i32(const int32_t *active_indices, int N, int offsetH, int offsetW,

@@ -2,4 +2,4 @@
 PYTHONPATH and `import sige` / `from sige.nn import Gather` resolve to sige_amd."""
 import sige_amd.compat as _compat
 
-_compat.install()
+_compat.install(force=True)  # (this stub IS the `sige` being imported)

@@ -35,6 +35,7 @@ _SIGNATURES = {
     "sige_hip_version": (_c_int, []),
     "sige_hip_error_string": (ctypes.c_char_p, [_c_int]),
     "sige_hip_device_arch": (ctypes.c_char_p, []),
+    "sige_hip_launch_count": (ctypes.c_int64, []),
     "sige_hip_gather_f32": (_c_int, [_c_vp] + [_c_int] * 6 + [_c_vp, _c_int] + _BC + _BC + [_c_int, _c_int, _c_vp, _c_vp]),
     "sige_hip_scatter_f32": (_c_int, [_c_vp, _c_vp] + [_c_int] * 10 + [_c_vp, _c_int] + _BC + [_c_vp, _c_vp]),
     "sige_hip_scatter_with_block_residual_f32": (
@@ -46,6 +47,10 @@ _SIGNATURES = {
     "sige_hip_scatter_map_i32": (_c_int, [_c_int] * 10 + [_c_vp, _c_int, _c_vp, _c_vp]),
     "sige_hip_scatter_gather_f32": (
         _c_int, [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + _BC + _BC + [_c_int, _c_int, _c_vp, _c_vp]),
+    "sige_hip_difference_mask_u8": (_c_int, [_c_vp, _c_vp] + [_c_int] * 3 + [ctypes.c_int64] * 3 + [ctypes.c_float, _c_vp, _c_vp]),
+    "sige_hip_dilate_mask_u8": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp]),
+    "sige_hip_mask_pyramid_levels": (_c_int, [_c_int] * 4 + [_c_vp, _c_vp, _c_int]),
+    "sige_hip_mask_pyramid_u8": (_c_int, [_c_vp] + [_c_int] * 6 + [ctypes.c_float] * 2 + [_c_vp, _c_sz, _c_vp, _c_vp]),
     "sige_hip_reduce_mask_capacity": (_c_int, [_c_int] * 6),
     "sige_hip_reduce_mask_i32": (_c_int, [_c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp, _c_vp]),
     "sige_hip_block_conv_packed_size": (_c_sz, [_c_int] * 9),
@@ -61,7 +66,7 @@ _SIGNATURES = {
         + [_c_int] * 7 + [_c_vp, _c_int, _c_int, _c_vp, _c_vp]),
     "sige_hip_group_norm_affine_workspace": (_c_sz, [_c_int] * 5),
     "sige_hip_group_norm_affine_f32": (_c_int, [_c_vp] + [_c_int] * 5 + [ctypes.c_float] + [_c_vp] * 6),
-    "sige_hip_block_conv_direct_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp] + [_c_int] * 6 + [_c_vp, _c_vp]),
+    "sige_hip_block_conv_direct_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_vp]),
     "sige_hip_block_conv_force_tile": (_c_int, [_c_int, _c_int]),
     "sige_hip_block_conv_force_waves": (_c_int, [_c_int]),
     "sige_hip_attention_workspace": (_c_sz, [_c_int] * 3),
@@ -100,6 +105,36 @@ _SIGNATURES = {
 EXPORTS = tuple(_SIGNATURES)  # every symbol include/sige_hip.h declares
 
 
+class _Guarded:
+    """A C entry point that launches on the device of the tensor whose stream was just taken.
+
+    The C ABI receives raw pointers and a stream handle and launches on HIP's *current* device
+    (the reference's sige/cuda wrappers have no device guard either).  Every
+    binding below evaluates `_stream(t)` as its last argument; that records `t`'s device, and
+    the call is wrapped in `torch.cuda.device(...)` when it is not the current one -- a model on
+    cuda:1 in a process whose current device is cuda:0 launches on cuda:1."""
+
+    __slots__ = ("fn",)
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __call__(self, *args):
+        global _pending_device
+        dev, _pending_device = _pending_device, None
+        if dev is not None and dev != torch.cuda.current_device():
+            with torch.cuda.device(dev):
+                return self.fn(*args)
+        return self.fn(*args)
+
+
+class _Lib:
+    pass
+
+
+_pending_device = None
+
+
 def lib():
     """Load libsige_hip.so (once).  Raises if it has not been built."""
     global _lib
@@ -109,11 +144,19 @@ def lib():
                 "sige_amd: %s not found -- the HIP extension is not built "
                 "(run `python -m sige_amd.build`); there is no CPU fallback." % LIB_PATH)
         handle = ctypes.CDLL(LIB_PATH)
+        table = _Lib()
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
-        _lib = handle
+            setattr(table, name, _Guarded(fn) if (args and args[-1] is _c_vp and res is _c_int) else fn)
+        table.handle = handle
+        _lib = table
     return _lib
+
+
+def launch_count() -> int:
+    """Kernel launches libsige_hip.so has issued in this process so far (bench.py: launches per forward)."""
+    return int(lib().sige_hip_launch_count())
 
 
 def available() -> bool:
@@ -121,6 +164,7 @@ def available() -> bool:
 
 
 UNSUPPORTED = -2  # SIGE_HIP_EUNSUPPORTED
+KSPLIT = True     # tools/conv_floor.py sets this to False to time the convs without the cross-workgroup K split
 
 
 def _check(status: int, what: str):
@@ -129,6 +173,9 @@ def _check(status: int, what: str):
 
 
 def _stream(t: torch.Tensor) -> int:
+    """Stream handle for a launch on `t`'s device (and note that device for the guard, see _Guarded)."""
+    global _pending_device
+    _pending_device = t.device.index
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
@@ -295,6 +342,93 @@ def reduce_mask(mask: torch.Tensor, block_size, stride, padding) -> torch.Tensor
     return buf[:n].clone()
 
 
+def reduce_mask_batch(requests) -> list:
+    """`reduce_mask` for many (mask [H,W], block, stride, padding) requests with ONE device -> host read for all
+    their counts (SIGEModel.set_masks: one request per distinct tile geometry and resolution of the network)."""
+    if not requests:
+        return []
+    dev = requests[0][0].device
+    counts = torch.empty(len(requests), dtype=torch.int32, device=dev)
+    bufs = []
+    for i, (mask, block, stride, padding) in enumerate(requests):
+        if mask.dim() != 2 or not mask.is_cuda or mask.device != dev:
+            raise RuntimeError("sige_amd.hip.reduce_mask_batch: expected 2-D masks on one GPU")
+        m = mask if mask.dtype in (torch.bool, torch.uint8) else (mask != 0)
+        m = m.contiguous()
+        H, W = m.shape
+        cap = lib().sige_hip_reduce_mask_capacity(H, W, stride[0], stride[1], padding[0], padding[1])
+        buf = torch.empty((max(cap, 1), 2), dtype=torch.int32, device=dev)
+        _check(lib().sige_hip_reduce_mask_i32(m.data_ptr(), H, W, block[0], block[1], stride[0], stride[1],
+                                              padding[0], padding[1], buf.data_ptr(), cap,
+                                              counts.data_ptr() + 4 * i, _stream(m)), "reduce_mask")
+        bufs.append((buf, m))
+    ns = counts.cpu().tolist()  # the one synchronisation of the mask -> index pipeline
+    return [buf[:n].clone() for (buf, _), n in zip(bufs, ns)]
+
+
+def difference_mask(tensor1: torch.Tensor, tensor2: torch.Tensor, eps: float) -> torch.Tensor:
+    """Device form of sige.utils.compute_difference_mask (sige/utils.py:74-85): bool [H,W]."""
+    if tensor1.shape != tensor2.shape:
+        raise RuntimeError("difference_mask: shapes differ")
+    a, b = tensor1, tensor2
+    if a.dim() == 4:
+        assert a.shape[0] == 1
+        a, b = a[0], b[0]
+    if a.dim() == 2:
+        a, b = a[None], b[None]
+    if a.dim() != 3:
+        raise NotImplementedError("Unknown mask dimension [%d]!!!" % tensor1.dim())
+    if not (a.is_cuda and b.is_cuda and a.dtype == b.dtype == torch.float32):
+        raise NotImplementedError("difference_mask: fp32 GPU tensors")
+    if a.stride() != b.stride() or a.stride(1) != a.shape[2] * a.stride(2):  # (NCHW and channels-last both pass as they are)
+        a, b = a.contiguous(), b.contiguous()
+    C, H, W = a.shape
+    out = torch.empty((H, W), dtype=torch.uint8, device=a.device)
+    _check(lib().sige_hip_difference_mask_u8(a.data_ptr(), b.data_ptr(), C, H, W, a.stride(0), a.stride(1), a.stride(2),
+                                             float(eps), out.data_ptr(), _stream(a)), "difference_mask")
+    return out.view(torch.bool)
+
+
+def _mask_u8(mask: torch.Tensor) -> torch.Tensor:
+    if mask.dim() != 2 or not mask.is_cuda:
+        raise RuntimeError("sige_amd.hip: expected a 2-D GPU mask")
+    m = mask if mask.dtype in (torch.bool, torch.uint8) else (mask != 0)
+    m = m.contiguous()
+    return m.view(torch.uint8) if m.dtype == torch.bool else m
+
+
+def dilate_mask(mask: torch.Tensor, dilation: Tuple[int, int]) -> torch.Tensor:
+    """Device form of sige.utils.dilate_mask for a 2-D mask (sige/utils.py:57-61): a new bool [H,W]."""
+    m = _mask_u8(mask)
+    H, W = m.shape
+    out = torch.empty_like(m)
+    _check(lib().sige_hip_dilate_mask_u8(m.data_ptr(), H, W, max(0, dilation[0]), max(0, dilation[1]), out.data_ptr(),
+                                         _stream(m)), "dilate_mask")
+    return out.view(torch.bool)
+
+
+def mask_pyramid(mask: torch.Tensor, min_res: Tuple[int, int], dilation: Tuple[int, int], threshold: float, eps: float):
+    """Device form of sige.utils.downsample_mask (sige/utils.py:88-118): {(h, w): bool [h,w]} -- ONE launch for all
+    levels, no host synchronisation (the reference synchronises once per level for `level.max()`)."""
+    m = _mask_u8(mask)
+    H, W = m.shape
+    n = lib().sige_hip_mask_pyramid_levels(H, W, min_res[0], min_res[1], None, None, 0)
+    hs, ws = (ctypes.c_int * n)(), (ctypes.c_int * n)()
+    lib().sige_hip_mask_pyramid_levels(H, W, min_res[0], min_res[1], hs, ws, n)
+    sizes = [(int(hs[i]), int(ws[i])) for i in range(n)]
+    out = torch.empty(sum(h * w for h, w in sizes), dtype=torch.uint8, device=m.device)
+    n_scratch = (H // 2) * (W // 2) + (H // 4) * (W // 4) + (H * W + 3) // 4 + 8
+    scratch = torch.empty(n_scratch, dtype=torch.float32, device=m.device)
+    _check(lib().sige_hip_mask_pyramid_u8(m.data_ptr(), H, W, min_res[0], min_res[1], max(0, dilation[0]), max(0, dilation[1]),
+                                          float(threshold), float(eps), scratch.data_ptr(), n_scratch, out.data_ptr(),
+                                          _stream(m)), "mask_pyramid")
+    pyramid, off = {}, 0
+    for h, w in sizes:
+        pyramid[(h, w)] = out[off:off + h * w].view(h, w).view(torch.bool)
+        off += h * w
+    return pyramid
+
+
 def conv_packed_size(Cout, Cin, kH, kW, R, S, strH, strW, groups=1) -> int:
     return int(lib().sige_hip_block_conv_packed_size(Cout, Cin, kH, kW, R, S, strH, strW, groups))
 
@@ -328,7 +462,8 @@ def block_conv(x, packed, bias, Cout: int, kernel: Tuple[int, int], stride: Tupl
     T, Cin, R, S = x.shape
     Ro, So = (R - kernel[0]) // stride[0] + 1, (S - kernel[1]) // stride[1] + 1
     out = torch.empty((T, Cout, Ro, So), dtype=torch.float32, device=x.device)
-    b = None if bias is None else _req(bias.detach(), torch.float32, "bias", 1).data_ptr()
+    bias_keep = _vec(bias, "bias")
+    b = _p(bias_keep)
     _check(lib().sige_hip_block_conv_f32(x.data_ptr(), T, Cin, R, S, packed.data_ptr(), b, Cout, kernel[0], kernel[1],
                                          stride[0], stride[1], out.data_ptr(), _stream(x)), "block_conv")
     return out
@@ -355,7 +490,8 @@ def gather_conv(x, block: Tuple[int, int], activeIndices, scale, shift, activati
     N = idx.shape[0]
     Ro, So = (block[0] - kernel[0]) // stride[0] + 1, (block[1] - kernel[1]) // stride[1] + 1
     out = torch.empty((B * N, Cout, Ro, So), dtype=torch.float32, device=x.device)
-    b = None if bias is None else _req(bias.detach(), torch.float32, "bias", 1).data_ptr()
+    bias_keep = _vec(bias, "bias")
+    b = _p(bias_keep)
     status = lib().sige_hip_gather_conv_f32(x.data_ptr(), B, C, H, W, block[0], block[1], idx.data_ptr(), N, *sa, *ta,
                                             _act(activationName), packed.data_ptr(), b, Cout, kernel[0], kernel[1],
                                             stride[0], stride[1], out.data_ptr(), _stream(x))
@@ -377,7 +513,8 @@ def scatter_gather_conv(x, y, block: Tuple[int, int], activeIndices, scatterMap,
     N = idx.shape[0]
     Ro, So = (block[0] - kernel[0]) // stride[0] + 1, (block[1] - kernel[1]) // stride[1] + 1
     out = torch.empty((B * N, Cout, Ro, So), dtype=torch.float32, device=y.device)
-    b = None if bias is None else _req(bias.detach(), torch.float32, "bias", 1).data_ptr()
+    bias_keep = _vec(bias, "bias")
+    b = _p(bias_keep)
     status = lib().sige_hip_scatter_gather_conv_f32(
         x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3], block[0], block[1], idx.data_ptr(), N,
         smap.data_ptr(), *sa, *ta, _act(activationName), packed.data_ptr(), b, Cout, kernel[0], kernel[1],
@@ -445,7 +582,8 @@ def gather_conv_nchw(x, x2, block: Tuple[int, int], activeIndices, scale, shift,
         if tuple(residual.shape) != tuple(out.shape):
             raise RuntimeError("gather_conv_nchw: residual %s != output %s" % (tuple(residual.shape), tuple(out.shape)))
         r = residual.data_ptr()
-    b = None if bias is None else _req(bias.detach(), torch.float32, "bias", 1).data_ptr()
+    bias_keep = _vec(bias, "bias")
+    b = _p(bias_keep)
     _check(lib().sige_hip_gather_conv_nchw_f32(
         x.data_ptr(), None if x2 is None else x2.data_ptr(), B, C1, C2, H, W, block[0], block[1], idx.data_ptr(),
         idx.shape[0], *sa, *ta, _act(activationName), packed.data_ptr(), b, Cout, kernel[0], kernel[1],
@@ -462,8 +600,10 @@ def group_norm_affine(x, groups: int, eps: float, gamma=None, beta=None):
         raise RuntimeError("group_norm_affine: channels %d not divisible by groups %d" % (C, groups))
     buf = torch.empty(n + 2 * B * C, dtype=torch.float32, device=x.device)
     scale, shift = buf[n:n + B * C].view(B, C, 1, 1), buf[n + B * C:].view(B, C, 1, 1)
-    ga = None if gamma is None else _req(gamma.detach(), torch.float32, "gamma", 1).data_ptr()
-    be = None if beta is None else _req(beta.detach(), torch.float32, "beta", 1).data_ptr()
+    gamma_keep = _vec(gamma, "gamma")
+    ga = _p(gamma_keep)
+    beta_keep = _vec(beta, "beta")
+    be = _p(beta_keep)
     _check(lib().sige_hip_group_norm_affine_f32(x.data_ptr(), B, C, H, W, groups, eps, ga, be, buf.data_ptr(),
                                                 scale.data_ptr(), shift.data_ptr(), _stream(x)), "group_norm_affine")
     return scale, shift
@@ -487,16 +627,19 @@ def attention(qkv: torch.Tensor, scale: float) -> torch.Tensor:
     return out
 
 
-def block_conv_direct(x, weight, bias, stride: Tuple[int, int], groups: int = 1):
+def block_conv_direct(x, weight, bias, stride: Tuple[int, int], groups: int = 1, dilation: Tuple[int, int] = (1, 1)):
     x = _req(x, torch.float32, "x")
     w = _req(weight.detach(), torch.float32, "weight")
     T, Cin, R, S = x.shape
     Cout, _, kH, kW = w.shape
-    Ro, So = (R - kH) // stride[0] + 1, (S - kW) // stride[1] + 1
+    Ro = (R - (kH - 1) * dilation[0] - 1) // stride[0] + 1
+    So = (S - (kW - 1) * dilation[1] - 1) // stride[1] + 1
     out = torch.empty((T, Cout, Ro, So), dtype=torch.float32, device=x.device)
-    b = None if bias is None else _req(bias.detach(), torch.float32, "bias", 1).data_ptr()
+    bias_keep = _vec(bias, "bias")
+    b = _p(bias_keep)
     _check(lib().sige_hip_block_conv_direct_f32(x.data_ptr(), T, Cin, R, S, w.data_ptr(), b, Cout, kH, kW,
-                                                stride[0], stride[1], groups, out.data_ptr(), _stream(x)),
+                                                stride[0], stride[1], dilation[0], dilation[1], groups, out.data_ptr(),
+                                                _stream(x)),
            "block_conv_direct")
     return out
 
@@ -549,16 +692,24 @@ def _cvec(t: Optional[torch.Tensor], name: str):
     return (t.data_ptr(), t.shape[0], t.shape[1]), t
 
 
-def _bias_ptr(bias):
-    return None if bias is None else _req(bias.detach(), torch.float32, "bias", 1).data_ptr()
+def _vec(t: Optional[torch.Tensor], name: str) -> Optional[torch.Tensor]:
+    """An optional 1-D fp32 vector (bias, gamma, ...) made contiguous.  The caller keeps the returned tensor
+    alive until after the launch: `.contiguous()` of a strided view is a temporary whose memory the caching
+    allocator may hand out again before the kernel has read it."""
+    return None if t is None else _req(t.detach(), torch.float32, name, 1)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
 
 
 def block_conv_cl(x, packed, bias, Cout: int, kernel: Tuple[int, int], stride: Tuple[int, int]):
+    bias_keep = _vec(bias, "bias")
     x = _req_cl(x, "x")
     T, Cin, R, S = x.shape
     Ro, So = (R - kernel[0]) // stride[0] + 1, (S - kernel[1]) // stride[1] + 1
     out = _empty_cl((T, Cout, Ro, So), x.device)
-    status = lib().sige_hip_block_conv_nhwc_f32(x.data_ptr(), T, Cin, R, S, packed.data_ptr(), _bias_ptr(bias), Cout,
+    status = lib().sige_hip_block_conv_nhwc_f32(x.data_ptr(), T, Cin, R, S, packed.data_ptr(), _p(bias_keep), Cout,
                                                 kernel[0], kernel[1], stride[0], stride[1], out.data_ptr(), _stream(x))
     if status == UNSUPPORTED:
         return None
@@ -572,6 +723,7 @@ def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, a
                    out: Optional[torch.Tensor] = None):
     """Channels-last gather -> conv.  `full` = dict(offset=(oh, ow), out_res=(Ho, Wo), residual=tensor|None)
     writes the output tiles straight into a [B,Cout,Ho,Wo] tensor (dense layers).  None if unsupported."""
+    bias_keep = _vec(bias, "bias")
     x = _req_cl(x, "x")
     B, C1, H, W = x.shape
     if upsample2x:  # `x` is the half-resolution tensor; the tiles index its x2 nearest upsampling
@@ -604,7 +756,7 @@ def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, a
     ks = lib().sige_hip_conv_ksplit_hint(B * N, C1 + C2, Cout, kernel[0], kernel[1], stride[0], stride[1])
     if full is not None and N * ((block[0] - kernel[0]) // stride[0] + 1) * ((block[1] - kernel[1]) // stride[1] + 1) < Ho * Wo:
         ks = 1  # tiles written into a larger tensor: the second pass would need whole output copies
-    if ks > 1 and os.environ.get("SIGE_AMD_KSPLIT", "1") != "0":
+    if ks > 1 and KSPLIT:
         ws_n = ks * out.numel()
         ws = torch.empty(ws_n, dtype=torch.float32, device=x.device)
     fargs = fargs + (None if ws is None else ws.data_ptr(), ws_n)
@@ -620,7 +772,7 @@ def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, a
     fargs = fargs + (int(bool(upsample2x)),)
     status = lib().sige_hip_gather_conv_nhwc_f32(
         x.data_ptr(), None if x2 is None else x2.data_ptr(), B, C1, C2, H, W, block[0], block[1], idx.data_ptr(), N,
-        *sa, *ta, _act(activationName), packed.data_ptr(), _bias_ptr(bias), Cout, kernel[0], kernel[1],
+        *sa, *ta, _act(activationName), packed.data_ptr(), _p(bias_keep), Cout, kernel[0], kernel[1],
         stride[0], stride[1], *fargs, out.data_ptr(), _stream(x))
     if status == UNSUPPORTED:
         return None
@@ -630,6 +782,7 @@ def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, a
 
 def scatter_gather_conv_cl(x, y, block: Tuple[int, int], activeIndices, scatterMap, scale, shift, activationName: str,
                            packed, bias, Cout: int, kernel: Tuple[int, int], stride: Tuple[int, int]):
+    bias_keep = _vec(bias, "bias")
     x, y = _req_cl(x, "x"), _req_cl(y, "y")
     idx = _req(activeIndices, torch.int32, "activeIndices", 2)
     smap = _req(scatterMap, torch.int32, "scatterMap", 3)
@@ -640,7 +793,7 @@ def scatter_gather_conv_cl(x, y, block: Tuple[int, int], activeIndices, scatterM
     out = _empty_cl((B * N, Cout, Ro, So), y.device)
     status = lib().sige_hip_scatter_gather_conv_nhwc_f32(
         x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3], block[0], block[1], idx.data_ptr(), N,
-        smap.data_ptr(), *sa, *ta, _act(activationName), packed.data_ptr(), _bias_ptr(bias), Cout, kernel[0], kernel[1],
+        smap.data_ptr(), *sa, *ta, _act(activationName), packed.data_ptr(), _p(bias_keep), Cout, kernel[0], kernel[1],
         stride[0], stride[1], out.data_ptr(), _stream(y))
     if status == UNSUPPORTED:
         return None
@@ -654,6 +807,7 @@ def scatter_gather_conv_scatter_cl(x, y, block, activeIndices, scatterMap, scale
     """scatter_gather -> 3x3 conv -> Scatter (residual = a full tensor) or ScatterWithBlockResidual (residual = the
     cached shortcut tensor, x1 = the shortcut conv's tiles, table1 = their tile table) in one launch, written into
     `out` (a persistent buffer that already equals the cache outside this mask's tiles).  None if unsupported."""
+    bias_keep = _vec(bias, "bias")
     x, y = _req_cl(x, "x"), _req_cl(y, "y")
     idx = _req(activeIndices, torch.int32, "activeIndices", 2)
     smap = _req(scatterMap, torch.int32, "scatterMap", 3)
@@ -672,7 +826,7 @@ def scatter_gather_conv_scatter_cl(x, y, block, activeIndices, scatterMap, scale
         bargs = (None, None, 0, 0, 0, 0, 0)
     status = lib().sige_hip_scatter_gather_conv_scatter_nhwc_f32(
         x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3], block[0], block[1], idx.data_ptr(), idx.shape[0],
-        smap.data_ptr(), *sa, *ta, _act(activationName), packed.data_ptr(), _bias_ptr(bias), Cout, kernel[0], kernel[1],
+        smap.data_ptr(), *sa, *ta, _act(activationName), packed.data_ptr(), _p(bias_keep), Cout, kernel[0], kernel[1],
         offset[0], offset[1], None if r is None else r.data_ptr(), *bargs, out.data_ptr(), _stream(y))
     if status == UNSUPPORTED:
         return None
@@ -758,8 +912,10 @@ def group_norm_affine_cl(x, groups: int, eps: float, gamma=None, beta=None):
         return None
     buf = torch.empty(n + 2 * B * C, dtype=torch.float32, device=x.device)
     scale, shift = buf[n:n + B * C].view(B, C, 1, 1), buf[n + B * C:].view(B, C, 1, 1)
-    ga = None if gamma is None else _req(gamma.detach(), torch.float32, "gamma", 1).data_ptr()
-    be = None if beta is None else _req(beta.detach(), torch.float32, "beta", 1).data_ptr()
+    gamma_keep = _vec(gamma, "gamma")
+    ga = _p(gamma_keep)
+    beta_keep = _vec(beta, "beta")
+    be = _p(beta_keep)
     status = lib().sige_hip_group_norm_affine_nhwc_f32(x.data_ptr(), B, C, H, W, groups, eps, ga, be, buf.data_ptr(),
                                                        scale.data_ptr(), shift.data_ptr(), _stream(x))
     if status == UNSUPPORTED:
@@ -792,10 +948,11 @@ def conv3x3_small_cout_cl(x, weight, bias, scale=None, shift=None, activationNam
     Cout = w.shape[0]
     if tuple(w.shape[1:]) != (C, 3, 3):
         return None
+    bias_keep = _vec(bias, "bias")
     (sa, s_keep), (ta, t_keep) = _cvec(scale, "scale"), _cvec(shift, "shift")
     out = _empty_cl((B, Cout, H, W), x.device)
     status = lib().sige_hip_conv3x3_small_cout_nhwc_f32(x.data_ptr(), B, C, H, W, *sa, *ta, _act(activationName),
-                                                        w.data_ptr(), _bias_ptr(bias), Cout, out.data_ptr(), _stream(x))
+                                                        w.data_ptr(), _p(bias_keep), Cout, out.data_ptr(), _stream(x))
     if status == UNSUPPORTED:
         return None
     _check(status, "conv3x3_small_cout_cl")
@@ -812,6 +969,7 @@ def conv3x3_small_cin_cl(x, weight, bias):
     over a full image (the U-Net's conv_in); x in any dense layout, result channels-last.  None if unsupported."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
         raise ValueError("x must be a 4-D fp32 GPU tensor")
+    bias_keep = _vec(bias, "bias")
     B, C, H, W = x.shape
     w = _req(weight.detach(), torch.float32, "weight")
     Cout = w.shape[0]
@@ -819,7 +977,7 @@ def conv3x3_small_cin_cl(x, weight, bias):
         return None
     out = _empty_cl((B, Cout, H, W), x.device)
     sb, sc, sh, sw = x.stride()
-    status = lib().sige_hip_conv3x3_small_cin_nhwc_f32(x.data_ptr(), sb, sc, sh, sw, B, C, H, W, w.data_ptr(), _bias_ptr(bias),
+    status = lib().sige_hip_conv3x3_small_cin_nhwc_f32(x.data_ptr(), sb, sc, sh, sw, B, C, H, W, w.data_ptr(), _p(bias_keep),
                                                        Cout, out.data_ptr(), _stream(x))
     if status == UNSUPPORTED:
         return None

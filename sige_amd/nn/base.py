@@ -12,7 +12,6 @@ What differs underneath: native functions come from the backend registry
 SIGEConv2d's sparse mode runs the MFMA stacked-block convolution of
 libsige_hip.so instead of F.conv2d.
 """
-import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -113,19 +112,16 @@ class SIGEModuleWrapper:
         self.module = module
 
 
-def _conv_backend() -> str:
-    return os.environ.get("SIGE_AMD_CONV", "hip")
-
-
 class SIGEConv2d(nn.Conv2d, SIGEModule):
     """nn.Conv2d whose `sparse`/`profile` modes convolve pre-padded stacked tiles
     with padding 0 (sige/nn/base.py:80-92).
 
-    On GPU tensors the sparse mode runs libsige_hip.so's stacked-block conv:
+    The sparse mode runs libsige_hip.so's stacked-block conv on fp32 GPU tensors:
     the MFMA implicit GEMM for the tile geometries SIGE produces (3x3/s1 on 6x6,
     1x1 on 4x4, 3x3/s2 on 5x5), the direct vector kernel for any other
-    groups/size, both fp32.  `SIGE_AMD_CONV=torch` selects F.conv2d (MIOpen)
-    instead, for A/B measurements.
+    groups / size / dilation.  There is no other path in the product: tiles on a
+    device without a registered native backend raise (tests register the CPU oracle,
+    whose `conv2d_tiles` is the reference's own F.conv2d call, sige/nn/base.py:88-89).
     """
 
     def __init__(self, *args, **kwargs):
@@ -133,6 +129,7 @@ class SIGEConv2d(nn.Conv2d, SIGEModule):
         SIGEModule.__init__(self, call_super=False)
         self._packed = None
         self._packed_key = None
+        self._tiles_runtime = self.load_runtime("conv2d_tiles", {})
 
     def _packed_weights(self, x: torch.Tensor):
         from .. import hip
@@ -163,10 +160,8 @@ class SIGEConv2d(nn.Conv2d, SIGEModule):
             out = out * os_.reshape(1, -1, 1, 1) + oh_.reshape(1, -1, 1, 1)
             return F.silu(out) if oact == "swish" else out
 
-        if tuple(self.dilation) != (1, 1):  # no dilated kernel in libsige_hip: torch's conv
-            return F.conv2d(deferred.resolve(x), self.weight, self.bias, self.stride, (0, 0), self.dilation,
-                            self.groups)
-        packed = self._packed_weights(x) if self.groups == 1 else None
+        plain = tuple(self.dilation) == (1, 1)
+        packed = self._packed_weights(x) if (self.groups == 1 and plain) else None
         spec = x.spec if isinstance(x, deferred.DeferredTiles) else None
         if packed is not None and spec is not None:
             # the producer of the tiles has not run: fuse it into the conv's prologue
@@ -194,7 +189,7 @@ class SIGEConv2d(nn.Conv2d, SIGEModule):
                 if out is not None:
                     return out
             return hip.block_conv(x, packed, self.bias, self.out_channels, self.kernel_size, self.stride)
-        return hip.block_conv_direct(x, self.weight, self.bias, self.stride, self.groups)
+        return hip.block_conv_direct(x, self.weight, self.bias, self.stride, self.groups, self.dilation)
 
     def forward(self, x: torch.Tensor, out_affine=None) -> torch.Tensor:
         """`out_affine` (sparse mode only, not in the reference): (scale, shift, activation) applied to the
@@ -202,10 +197,13 @@ class SIGEConv2d(nn.Conv2d, SIGEModule):
         if self.mode == "full":
             output = super(SIGEConv2d, self).forward(x)
         elif self.mode == "sparse":
-            if x.is_cuda and x.dtype == torch.float32 and _conv_backend() == "hip":
+            self.check_dtype(x)
+            if x.is_cuda:
                 output = self._block_conv(x, out_affine)
             else:
-                output = F.conv2d(x, self.weight, self.bias, self.stride, (0, 0), self.dilation, self.groups)
+                # no product path off the GPU: whatever backend a test registered for this device type, or a loud error
+                conv = self.native(self._tiles_runtime, x)
+                output = conv(deferred.resolve(x), self.weight, self.bias, self.stride, self.dilation, self.groups)
                 if out_affine is not None:
                     os_, oh_, oact = out_affine
                     output = output * os_.reshape(1, -1, 1, 1) + oh_.reshape(1, -1, 1, 1)
@@ -230,8 +228,30 @@ class SIGEModel(nn.Module):
     def set_masks(self, masks: Dict[Tuple[int, int], torch.Tensor]):
         self.timestamp += 1
         cache = {}  # shared by all modules: one reduce_mask / scatter_map per distinct geometry
+        self._prebuild_indices(masks, cache)
         for module in self._sige_modules():
             module.set_mask(masks, cache, self.timestamp)
+
+    def _prebuild_indices(self, masks, cache):
+        """GPU masks: the active-index lists of every distinct (resolution, tile geometry) of the network in one batch --
+        all compaction kernels are launched back to back and their counts are read with ONE device -> host copy, instead
+        of one `torch.nonzero`-style synchronisation per geometry (sige/utils.py:30 via sige/nn/gather.py:101-107)."""
+        from .gather import Gather
+
+        keys, reqs = [], []
+        for m in self._sige_modules():
+            if isinstance(m, Gather) and m.input_res is not None and not m.verbose:
+                res = tuple(m.input_res)
+                mask = masks.get(res)
+                key = m.index_key(res)
+                if mask is not None and mask.is_cuda and mask.dim() == 2 and key not in cache and key not in keys:
+                    keys.append(key)
+                    reqs.append((mask, m.block_size, m.block_stride, m.offset))
+        if reqs:
+            from .. import hip
+
+            for key, idx in zip(keys, hip.reduce_mask_batch(reqs)):
+                cache[key] = idx
 
     def set_mode(self, mode: str):
         self.mode = mode

@@ -16,17 +16,17 @@ its values.
     code that post-processes tiles (GauGAN's SPADE modulation, SD attention)
     keeps working unchanged.
 """
-import os
 from typing import Callable, Optional
 
 import torch
 from torch.utils._pytree import tree_map
 
 FORCE_ON_CPU = False  # tests: exercise the mechanism without a GPU
+FUSION = True         # tests / tools set this to False to run Gather and the conv as two kernels (A/B of the fusion)
 
 
 def fusion_enabled() -> bool:
-    return os.environ.get("SIGE_AMD_FUSE", "1") != "0"
+    return FUSION
 
 
 _METADATA = None

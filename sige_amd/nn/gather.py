@@ -63,18 +63,17 @@ class Gather(SIGEModule):
         upsample2x: bool = False
     ) -> torch.Tensor:
         """`upsample2x` (sparse mode, not in the reference): `x` is the HALF-resolution tensor and the tiles are
-        taken from its x2 nearest-neighbour upsampling -- which a fused gather -> conv never materialises
-        (the `F.interpolate` in front of the U-Net's upsampling convs)."""
+        taken from its x2 nearest-neighbour upsampling -- which the fused gather -> conv kernel never materialises
+        (the `F.interpolate` in front of the U-Net's upsampling convs).  Only valid where `fuses_upsample(x)` holds;
+        anywhere else the MODEL upsamples, as the reference's does (sige_fused_unet.py:222-227), and calls the
+        gather without the flag."""
         self.check_dtype(x, scale, shift)
         self.check_dim(x, scale, shift)
-        if upsample2x and self.mode != "sparse":
-            x = torch.nn.functional.interpolate(x, scale_factor=2.0, mode="nearest")
-        if self.mode == "sparse" and upsample2x:
+        if upsample2x:
             x = deferred.resolve(x)
-            if not (deferred.channels_last_ok(x, scale, shift, self.activation_first)
-                    and deferred.defer_ok(x, scale, shift, self.activation_first, self.sparse_update, self.activation_name)):
-                x = torch.nn.functional.interpolate(x, scale_factor=2.0, mode="nearest")
-                upsample2x = False
+            if not self.fuses_upsample(x, scale, shift):
+                raise ValueError("Gather(upsample2x=True) needs the fused channels-last gather -> conv path "
+                                 "(sparse mode, channels-last fp32 GPU tensor, per-channel affine); upsample in the model instead")
         if self.mode == "sparse":
             x2 = None
             if isinstance(x, deferred.LazyCat) and x.spec is not None:
@@ -143,11 +142,23 @@ class Gather(SIGEModule):
         assert self.input_res is not None
         res = tuple(self.input_res)
         self.mask = masks[res]
-        key = ("active_indices", *res, *self.block_size, *self.block_stride, *self.offset)
+        key = self.index_key(res)
         if key not in cache:
             cache[key] = reduce_mask(self.mask, self.block_size, self.block_stride, self.offset, verbose=self.verbose)
         self.active_indices = cache[key]
-        self._tables = cache.setdefault(("tile_tables", *key[1:]), {})
+        # (tile tables also depend on the conv's stride and output tile, which the index key does not contain)
+        self._tables = cache.setdefault(("tile_tables", *key[1:], *self.model_stride, *self.out_tile), {})
+
+    def fuses_upsample(self, x: torch.Tensor, scale=None, shift=None) -> bool:
+        """Can `forward(x, upsample2x=True)` be used for this input (see there)?"""
+        return (self.mode == "sparse" and not isinstance(x, deferred.LazyCat)
+                and deferred.channels_last_ok(deferred.resolve(x), scale, shift, self.activation_first)
+                and deferred.defer_ok(deferred.resolve(x), scale, shift, self.activation_first, self.sparse_update,
+                                      self.activation_name))
+
+    def index_key(self, res) -> tuple:
+        """Key of this gather's index list in the cache shared by SIGEModel.set_masks."""
+        return ("active_indices", *res, *self.block_size, *self.block_stride, *self.offset)
 
     def indices_on(self, device: torch.device) -> torch.Tensor:
         """active_indices on `device` (the reference requires mask and activations

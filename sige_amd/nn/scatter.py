@@ -47,18 +47,40 @@ class _OutputBuffers:
     module keeps, per cache id, one buffer that already equals the cached tensor outside the
     current mask's tiles; a forward then writes the covered pixels only.  The buffer is rebuilt
     (one copy) whenever the cache or the mask changes.  The caller must not modify the returned
-    tensor in place, and it is only valid until the module's next forward."""
+    tensor in place, and it is only valid until the module's next forward.
+
+    "The cache changed" is an explicit per-cache-id generation counter, bumped by whoever writes the
+    cache (a full-mode forward, `sparse_update`, `parallel.pack_caches` / `broadcast_cache`) --
+    not the tensor's address or version: the caching allocator recycles addresses, a fresh tensor
+    starts at version 0 and a collective may write a buffer without touching its version."""
 
     def __init__(self):
         self.bufs = {}
+        self.gen = {}
 
     def get(self, cache_id, cached: torch.Tensor, stamp):
         entry = self.bufs.get(cache_id)
-        key = (stamp, cached.data_ptr(), cached._version, tuple(cached.shape))
+        key = (stamp, self.gen.get(cache_id, 0), tuple(cached.shape), cached.stride())
         if entry is None or entry[0] != key:
             entry = (key, cached.clone(memory_format=torch.preserve_format))
             self.bufs[cache_id] = entry
         return entry[1]
+
+    def invalidate(self, cache_id=None):
+        """The cached tensor of `cache_id` (None: of every id) was replaced or rewritten."""
+        for k in ([cache_id] if cache_id is not None else set(self.bufs) | set(self.gen)):
+            self.gen[k] = self.gen.get(k, 0) + 1
+            self.bufs.pop(k, None)
+
+    def refresh(self, caches: dict):
+        """The cached tensors were rewritten IN PLACE (same tensors, new values -- e.g. a collective into the packed
+        cache): re-copy them into the existing buffers, whose addresses a captured hipGraph may hold."""
+        for cid, (key, buf) in list(self.bufs.items()):
+            cached = caches.get(cid)
+            if cached is not None and tuple(cached.shape) == tuple(buf.shape) and cached.stride() == buf.stride():
+                buf.copy_(cached)
+            else:
+                self.bufs.pop(cid)
 
     def clear(self):
         self.bufs = {}
@@ -78,6 +100,10 @@ class Scatter(SIGEModule):
     def clear_cache(self):
         self.original_outputs = {}
         self._out_bufs.clear()
+
+    def refresh_outputs(self):
+        """(sige_amd.parallel) the cache tensors were rewritten in place: persistent outputs follow, addresses kept."""
+        self._out_bufs.refresh(self.original_outputs)
 
     def forward_fused(self, conv, tiles: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         """(not in the reference) `self(conv(tiles), residual)` in ONE launch when the in-place mode is on and `tiles`
@@ -119,11 +145,13 @@ class Scatter(SIGEModule):
                             None if residual is None else residual.contiguous())
             if self.sparse_update:
                 cached.copy_(output)
+                self._out_bufs.invalidate(self.cache_id)
             return output
         if self.mode == "full":
             output = x if residual is None else x + residual
             self.output_res = output.shape[2:]
             self.original_outputs[self.cache_id] = deferred.keep_layout(output)
+            self._out_bufs.invalidate(self.cache_id)
             return output
         if self.mode == "profile":
             c = x.shape[1]
@@ -184,6 +212,10 @@ class ScatterWithBlockResidual(SIGEModule):
         self.original_residuals = {}
         self._out_bufs.clear()
 
+    def refresh_outputs(self):
+        """(sige_amd.parallel) the cache tensors were rewritten in place: persistent outputs follow, addresses kept."""
+        self._out_bufs.refresh(self.original_outputs)
+
     def forward_fused(self, conv, tiles: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
         """(not in the reference) `self(conv(tiles), residual)` in ONE launch (see Scatter.forward_fused): `residual` are
         the shortcut conv's tiles; the block-residual correction runs in the conv's epilogue."""
@@ -235,6 +267,7 @@ class ScatterWithBlockResidual(SIGEModule):
                 if self.scatter_runtime is None:
                     self.scatter_runtime = self.load_runtime("scatter", {})
                 y0.copy_(output)
+                self._out_bufs.invalidate(self.cache_id)
                 if _fused_ok(x):
                     from .. import hip
 
@@ -253,6 +286,7 @@ class ScatterWithBlockResidual(SIGEModule):
             self.original_residuals[self.cache_id] = (
                 residual.contiguous(memory_format=torch.channels_last) if cl and not residual.is_contiguous()
                 else deferred.keep_layout(residual))
+            self._out_bufs.invalidate(self.cache_id)
             return output
         if self.mode == "profile":
             c = x.shape[1]

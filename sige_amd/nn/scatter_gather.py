@@ -64,7 +64,12 @@ class ScatterGather(SIGEModule):
         from .utils import activation as act_fn
 
         y = self.original_outputs[self.cache_id]
-        self.activated_outputs[self.cache_id] = deferred.keep_layout(act_fn(y * scale + shift, self.activation_name))
+        new = deferred.keep_layout(act_fn(y * scale + shift, self.activation_name))
+        old = self.activated_outputs.get(self.cache_id)
+        if old is not None and old.shape == new.shape and old.stride() == new.stride() and old.device == new.device:
+            old.copy_(new)  # same address: a captured hipGraph that reads the activated copy stays valid
+        else:
+            self.activated_outputs[self.cache_id] = new
 
     def forward(
         self, x: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,

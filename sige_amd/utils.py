@@ -69,6 +69,11 @@ def dilate_mask(mask: Union[torch.Tensor, np.ndarray], dilation: IntPair) -> Uni
     d = _pair(dilation)
     if d[0] <= 0 and d[1] <= 0:
         return mask
+    if isinstance(mask, torch.Tensor) and mask.is_cuda and mask.dim() == 2 and mask.dtype in (torch.bool, torch.uint8):
+        from . import hip
+
+        out = hip.dilate_mask(mask, d)  # one kernel instead of 4 * d slice ops
+        return out if mask.dtype == torch.bool else out.view(torch.uint8)
     out = mask.clone() if isinstance(mask, torch.Tensor) else np.array(mask, copy=True)
     nd = out.ndim if isinstance(out, np.ndarray) else out.dim()
     if nd not in (2, 3):
@@ -92,6 +97,13 @@ def dilate_mask(mask: Union[torch.Tensor, np.ndarray], dilation: IntPair) -> Uni
 
 def compute_difference_mask(tensor1: torch.Tensor, tensor2: torch.Tensor, eps: float = 2e-2) -> torch.Tensor:
     """|a-b| > eps, reduced with `any` over channels -> [H,W] bool (sige/utils.py:74-85)."""
+    if (tensor1.is_cuda and tensor2.is_cuda and tensor1.dtype == tensor2.dtype == torch.float32
+            and tensor1.shape == tensor2.shape and tensor1.dim() in (2, 3, 4)):
+        from . import hip
+
+        if tensor1.dim() == 4:
+            assert tensor1.shape[0] == 1
+        return hip.difference_mask(tensor1, tensor2, eps)
     mask = torch.abs(tensor1 - tensor2) > eps
     if mask.dim() == 2:
         return mask
@@ -116,6 +128,11 @@ def downsample_mask(
     assert mask.dim() == 2
     H, W = mask.shape
     min_h, min_w = _pair(min_res)
+    if mask.is_cuda and mask.dtype in (torch.bool, torch.uint8):
+        from . import hip
+
+        # the whole pyramid in one launch; the loop below synchronises with the host once per level (level.max())
+        return hip.mask_pyramid(mask, (min_h, min_w), _pair(dilation), threshold, eps)
     level = mask.reshape(1, 1, H, W).float()
     h, w = H, W
     pyramid = {}

@@ -114,6 +114,15 @@ class ResBlock(SIGEModule):
     def clear_cache(self):
         self.affine = {}
 
+    def rebuild_derived_caches(self):
+        """(sige_amd.parallel) the cache tensors were rewritten in place: recompute the activated ScatterGather copy."""
+        if self.sparse_main and self.preactivate:
+            for cid, (_, _, s2, t2) in self.affine.items():
+                if cid in self.scatter_gather.original_outputs:
+                    keep, self.scatter_gather.cache_id = self.scatter_gather.cache_id, cid
+                    self.scatter_gather.cache_activated(s2, t2)
+                    self.scatter_gather.cache_id = keep
+
     def _shortcut_async(self, fn, x_ready: torch.Tensor):
         """Run `fn()` (the shortcut branch) on a side stream forked from the current one; returns (result, join).
         `join()` must be called on the current stream before the result is consumed.  hipGraph capture records the
@@ -297,10 +306,12 @@ class Upsample(SIGEModule):
         self.plain = False
 
     def forward(self, x):
-        if self.mode == "sparse":
+        if self.mode == "sparse" and self.gather.fuses_upsample(x):
             # the upsampled tensor only feeds the gather: read the half-resolution one at (h/2, w/2) instead
             return self.scatter.forward_fused(self.conv, self.gather(x, upsample2x=True))
         x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+        if self.mode == "sparse":
+            return self.scatter.forward_fused(self.conv, self.gather(x))
         if self.plain and self.mode == "full":
             return self.conv(x)
         return self.scatter(self.conv(self.gather(x)))

@@ -274,10 +274,8 @@ def test_conv_every_output_block_shape(hip, mt, nb, cin, c2, cout, k, stride, bl
 
 def test_deferred_fusion_in_modules():
     """Module level: with fusion on, Gather returns DeferredTiles and the ResBlock
-    output equals the unfused run (SIGE_AMD_FUSE=0) to 1e-5 (the fused staging path's
+    output equals the unfused run (deferred.FUSION = False) to 1e-5 (the fused staging path's
     SiLU uses v_exp_f32 / v_rcp_f32)."""
-    import os
-
     from sige_amd.nn import deferred
     from sige_amd.utils import dilate_mask
     from tests.test_host_logic import ResNet
@@ -299,12 +297,12 @@ def test_deferred_fusion_in_modules():
         net.set_masks({(64, 64): dilate_mask(dilate_mask(mask, (2, 0)), (0, 2))})
         assert isinstance(blk.main_gather(edited, blk.s1, blk.t1), deferred.DeferredTiles)
         fused = net(edited)
-        os.environ["SIGE_AMD_FUSE"] = "0"
+        deferred.FUSION = False
         try:
             assert not isinstance(blk.main_gather(edited, blk.s1, blk.t1), deferred.DeferredTiles)
             unfused = net(edited)
         finally:
-            del os.environ["SIGE_AMD_FUSE"]
+            deferred.FUSION = True
     torch.testing.assert_close(fused, unfused, rtol=0, atol=1e-5)
     torch.testing.assert_close(fused, dense, rtol=0, atol=util.CONV_ATOL)
 

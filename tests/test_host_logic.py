@@ -368,8 +368,8 @@ def test_forced_deferral_matches_eager(cpu_oracle_backend, monkeypatch):
 def test_mi355x_first_options_reduce_to_the_reference_form(cpu_oracle_backend):
     """The options that are not in the reference -- producer-side activation (`out_affine` +
     `cache_activated` / `preactivated`), conv -> scatter fusion (`forward_fused`), deferred `lazy_cat`,
-    `upsample2x` gathers -- must give the plain module chain's values when no fused kernel applies
-    (here: CPU tensors on the oracle backend)."""
+    -- must give the plain module chain's values when no fused kernel applies (here: CPU tensors on the
+    oracle backend); the `upsample2x` gather flag is refused there."""
     from sige_amd.nn import deferred
 
     torch.manual_seed(3)
@@ -408,7 +408,10 @@ def test_mi355x_first_options_reduce_to_the_reference_form(cpu_oracle_backend):
         g.set_mask({(32, 32): mask}, {}, 1)
         for m in (g, conv):
             m.set_mode("sparse")
-        torch.testing.assert_close(conv(g(lo, upsample2x=True)), conv(g(up)), rtol=0, atol=0)
+        # off the fused GPU path the flag is refused (the model upsamples itself, as the reference's does)
+        assert not g.fuses_upsample(lo)
+        with pytest.raises(ValueError, match="upsample in the model"):
+            g(lo, upsample2x=True)
 
 
 def test_input_conv2d_and_plain_weight_off_gpu():

@@ -48,7 +48,7 @@ def _sparse(net, mask, x):
     return net(x)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, method="broadcast"):
     sys.path.insert(0, REPO)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -63,18 +63,29 @@ def _worker(rank, world, port, out_dir):
         # rank 0 holds the true original; the others only need the cache SLOTS (shapes)
         net(orig if rank == 0 else torch.zeros_like(orig))
         flat = parallel.pack_caches(net)
-        parallel.broadcast_cache(flat, src=0)
+        if method == "broadcast":
+            parallel.broadcast_cache(flat, src=0, model=net)
+        else:
+            parallel.distribute_cache(flat, src=0, method=method)
+            parallel.refresh_derived(net)
         mine = parallel.shard(list(range(len(edits))))
         outs = {i: _sparse(net, *edits[i]) for i in mine}
-    torch.save({"outs": outs, "flat_sum": float(flat.double().sum())}, os.path.join(out_dir, "rank%d.pt" % rank))
+    slowest = parallel.max_over_ranks(0.25 * (rank + 1))
+    torch.save({"outs": outs, "flat_sum": float(flat.double().sum()), "slowest": slowest, "numel": flat.numel()},
+               os.path.join(out_dir, "rank%d.pt" % rank))
     dist.destroy_process_group()
 
 
-def test_cache_broadcast_and_sharded_edits(tmp_path):
+@pytest.mark.parametrize("method", ["broadcast", "scatter_allgather"])
+def test_cache_broadcast_and_sharded_edits(tmp_path, method):
+    """The multi-rank path of bench.py (pack -> one collective -> local refresh -> sharded edits -> max over ranks),
+    both distribution methods, on gloo."""
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), method), nprocs=world, join=True)
     res = [torch.load(tmp_path / ("rank%d.pt" % r)) for r in range(world)]
-    assert res[0]["flat_sum"] == res[1]["flat_sum"]  # identical caches after the broadcast
+    assert res[0]["flat_sum"] == res[1]["flat_sum"]  # identical caches after the collective
+    assert res[0]["slowest"] == res[1]["slowest"] == 0.5  # MAX over ranks
+    assert res[0]["numel"] % (64 * 48) == 0  # padded: 2 / 4 / 8 ranks get equal, aligned chunks
     assert sorted(res[0]["outs"]) == [0, 2] and sorted(res[1]["outs"]) == [1, 3]
 
     # single-process ground truth

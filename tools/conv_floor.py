@@ -23,7 +23,7 @@ for T, res in ((4, 8), (16, 16), (64, 32)):
                     mt, nb = [int(v) for v in tile[:-2].split("x")]
                     hip.conv_force_tile(mt, nb)
                     hip.conv_force_waves(int(tile[-1]))
-                    os.environ["SIGE_AMD_KSPLIT"] = "0"
+                    hip.KSPLIT = False
                     fn = lambda i: hip.gather_conv_cl(xs[i], None, (6, 6), idx, sc, sh, "swish" if mode == "swish" else "identity",
                                                       packs[i], bias, cout, (3, 3), (1, 1))
                     us = graph_time(fn, 4)
