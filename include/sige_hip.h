@@ -192,6 +192,53 @@ int sige_hip_block_conv_direct_f32(const float *x, int T, int Cin, int R, int S,
                                    const float *w, const float *bias, int Cout, int kH, int kW,
                                    int strideH, int strideW, int dilationH, int dilationW, int groups,
                                    float *out, void *stream);
+/* ---- f16 compute ("_f16c"): the same stacked-block convs on the fp16 matrix cores ---------
+ * (v_mfma_f32_32x32x16_f16 / v_mfma_f32_16x16x32_f16, 16x the rate of the f32-input forms).
+ * Tensors stay fp32 in HBM (x, y, residual, out, bias, scale / shift): the staging path
+ * finishes a value in fp32 (cached GroupNorm affine + SiLU), rounds it to fp16 (RNE) into LDS;
+ * weights are packed as fp16 by sige_hip_block_conv_pack_f16c (same fp32 weight tensor in);
+ * products are exact and accumulate in fp32.  Not in the reference, which is fp32-only
+ * (sige/nn/base.py:15,55-63): BASELINE.json configs[4]; parity vs the fp32 oracle is quoted at
+ * 2e-2 abs.  Channels-last entry points only; geometries: 3x3/s1 on 6x6 and
+ * 1x1 on 4x4 (packed_size_f16c returns 0 for the stride-2 geometry: pack that conv for fp32).
+ * `packed` sizes are in 4-byte units as for the fp32 forms; arguments as the _f32 functions
+ * of the same name (declared further down).                                              */
+size_t sige_hip_block_conv_packed_size_f16c(int Cout, int Cin, int kH, int kW, int R, int S,
+                                            int strideH, int strideW, int groups);
+int sige_hip_block_conv_pack_f16c(const float *w, int Cout, int Cin, int kH, int kW,
+                                  float *packed, void *stream);
+int sige_hip_block_conv_nhwc_f16c(const float *x, int T, int Cin, int R, int S,
+                                  const float *packed, const float *bias, int Cout, int kH, int kW,
+                                  int strideH, int strideW, float *out, void *stream);
+int sige_hip_gather_conv_nhwc_f16c(const float *x, const float *x2, int B, int C1, int C2, int H, int W,
+                                   int bH, int bW, const int32_t *active_indices, int N,
+                                   const float *scale, int scaleB, int scaleC,
+                                   const float *shift, int shiftB, int shiftC,
+                                   int activation,
+                                   const float *packed, const float *bias, int Cout, int kH, int kW,
+                                   int strideH, int strideW,
+                                   int to_full, int offsetH, int offsetW, const float *residual, int Ho, int Wo,
+                                   float *workspace, size_t workspace_floats,
+                                   const float *out_scale, const float *out_shift, int out_activation,
+                                   int upsample2x,
+                                   float *out, void *stream);
+int sige_hip_scatter_gather_conv_nhwc_f16c(const float *x, const float *y, int B, int Cin, int H, int W,
+                                           int Rx, int Sx, int bH, int bW,
+                                           const int32_t *active_indices, int N, const int32_t *scatter_map,
+                                           const float *scale, int scaleB, int scaleC,
+                                           const float *shift, int shiftB, int shiftC,
+                                           int activation,
+                                           const float *packed, const float *bias, int Cout, int kH, int kW,
+                                           int strideH, int strideW, float *out, void *stream);
+int sige_hip_scatter_gather_conv_scatter_nhwc_f16c(
+        const float *x, const float *y, int B, int Cin, int H, int W, int Rx, int Sx, int bH, int bW,
+        const int32_t *active_indices, int N, const int32_t *scatter_map,
+        const float *scale, int scaleB, int scaleC, const float *shift, int shiftB, int shiftC, int activation,
+        const float *packed, const float *bias, int Cout, int kH, int kW,
+        int offsetH, int offsetW, const float *residual,
+        const float *x1, const int32_t *table1, int gH1, int gW1, int N1, int R1, int S1,
+        float *out, void *stream);
+
 /* Tuning knob (process-wide, not thread-safe): pin the MFMA kernel's output block to
  * mt pixels x (nb*mt) output channels, mt in {16, 32}, nb in {1, 2}; (0, 0) restores the
  * per-launch choice.  Results do not depend on it beyond fp32 summation order. */

@@ -34,6 +34,35 @@ __global__ void pack_weights_kernel(const float *__restrict__ w, int Cout, int C
     }
 }
 
+// fp16 packing for the f16-compute kernels (ConvGeoH): 8 halves per lane and k-step,
+//   packed[ng][chunk][wave][u][kq][j][e] = half(w[co = MT*ng + j][ci][tap]),  u = slab * KK + tap,
+//   ci = chunk*CC + wave*CW + slab*SLAB + 8*kq + e
+template <int KK, int MT>
+__global__ void pack_weights_h_kernel(const float *__restrict__ w, int Cout, int Cin, _Float16 *__restrict__ packed, long total) {
+    using G = ConvGeoH<(KK == 1 ? 1 : 3), 1, (KK == 1 ? 4 : 6), MT>;  // (stride / tile edge do not enter the layout)
+    const int nchunks = ((Cin + G::CC - 1) / G::CC + 1) & ~1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i;
+        const int e = r % 8; r /= 8;
+        const int j = r % MT; r /= MT;
+        const int kq = r % G::NL; r /= G::NL;
+        const int u = r % G::L; r /= G::L;
+        const int wave = r % 4; r /= 4;
+        const int chunk = r % nchunks; r /= nchunks;
+        const int ng = (int)r;
+        const int slab = u / KK, tap = u % KK;
+        const int ci = chunk * G::CC + wave * G::CW + slab * G::SLAB + 8 * kq + e;
+        const int co = MT * ng + j;
+        packed[i] = (_Float16)((ci < Cin && co < Cout) ? w[((size_t)co * Cin + ci) * KK + tap] : 0.0f);
+    }
+}
+
+// size of the packed f16 weights of one tile shape, in 4-byte units (the Python side allocates fp32 storage)
+static size_t packed_units_h(int Cout, int Cin, int KK, int MT) {
+    const int NL = 64 / MT, CW = (KK == 1 ? 2 : 1) * NL * 8, CC = 4 * CW, L = (KK == 1 ? 2 : 1) * KK;
+    return (size_t)ceil_div(Cout, MT) * ((ceil_div(Cin, CC) + 1) & ~1) * 4 * L * 64 * 4;
+}
+
 static size_t packed_floats(int Cout, int Cin, int KK, int MT) {
     const int NL = 64 / MT, CW = (KK == 1 ? 16 : 4) * NL, CC = 4 * CW, F = (CW / NL) * KK / 4;
     return (size_t)ceil_div(Cout, MT) * ((ceil_div(Cin, CC) + 1) & ~1) * 4 * F * 64 * 4;  // chunk count padded to even
@@ -111,6 +140,20 @@ SIGE_CONV_DECLARE(K11_16, 2, LAYOUT_NHWC, 8)
 SIGE_CONV_DECLARE(K11_32, 1, LAYOUT_NHWC, 8)
 SIGE_CONV_DECLARE(K11_32, 2, LAYOUT_NHWC, 8)
 
+// f16-compute forms (ConvGeoH; channels-last, 4 waves): conv_k*_nhwc_h.hip
+using H31_16 = ConvGeoH<3, 1, 6, 16>;
+using H31_32 = ConvGeoH<3, 1, 6, 32>;
+using H11_16 = ConvGeoH<1, 1, 4, 16>;
+using H11_32 = ConvGeoH<1, 1, 4, 32>;
+SIGE_CONV_DECLARE(H31_16, 1, LAYOUT_NHWC, 4) SIGE_CONV_DECLARE(H31_16, 2, LAYOUT_NHWC, 4)
+SIGE_CONV_DECLARE(H31_32, 1, LAYOUT_NHWC, 4) SIGE_CONV_DECLARE(H31_32, 2, LAYOUT_NHWC, 4)
+SIGE_CONV_DECLARE(H11_16, 1, LAYOUT_NHWC, 4) SIGE_CONV_DECLARE(H11_16, 2, LAYOUT_NHWC, 4)
+SIGE_CONV_DECLARE(H11_32, 1, LAYOUT_NHWC, 4) SIGE_CONV_DECLARE(H11_32, 2, LAYOUT_NHWC, 4)
+// (no f16-compute form of the stride-2 geometry: 4 tiles x 25 pixels x 128 channels per chunk = 13 staging slots per
+//  lane do not fit the register file; those few convs -- the U-Net's downsamplers -- stay on the fp32 matrix path)
+SIGE_CONV_DECLARE_SG_FULL(H31_16, 1, 4) SIGE_CONV_DECLARE_SG_FULL(H31_16, 2, 4)
+SIGE_CONV_DECLARE_SG_FULL(H31_32, 1, 4) SIGE_CONV_DECLARE_SG_FULL(H31_32, 2, 4)
+
 // ---- cross-workgroup K split: deterministic second pass ------------------------
 // out[i] = sum_s ws[s][i] + bias[channel(i)] + residual[i]   (channels-last: channel = i mod C)
 __global__ __launch_bounds__(256) void splitk_reduce_nhwc_kernel(const float *__restrict__ ws, int S, size_t stride, size_t n4, int C,
@@ -171,10 +214,10 @@ static int ksplit_for(long blocks, int nchunks, int cap) {
 static int g_force_mt = 0, g_force_nb = 0, g_force_waves = 0;
 __device__ int32_t g_zero_idx[2] = {0, 0};
 
-template <int KH, int STR, int R, int SRC, int DST, int LAY>
+template <int KH, int STR, int R, int SRC, int DST, int LAY, int PREC = 0>
 static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
-    using G32 = ConvGeo<KH, STR, R, 32>;
-    using G16 = ConvGeo<KH, STR, R, 16>;
+    using G32 = std::conditional_t<PREC == 1, ConvGeoH<KH, STR, R, 32>, ConvGeo<KH, STR, R, 32>>;
+    using G16 = std::conditional_t<PREC == 1, ConvGeoH<KH, STR, R, 16>, ConvGeo<KH, STR, R, 16>>;
     constexpr bool kHasNB2 = STR == 1;
     auto blocks = [&](int tpb, int mt, int nb) { return (long)ceil_div(a.T, tpb) * ceil_div(a.Cout, mt * nb); };
     // constraints of the staging path (conv_mfma.hpp): a fused torch.cat must split on a chunk
@@ -213,7 +256,7 @@ static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
     const int nchunks4 = (ceil_div(a.Cin, cc4) + 1) & ~1;  // as packed (padded to even)
     a.nblk = nchunks4 * 4;
     // 8-wave workgroups (two waves per SIMD) when the grid cannot give every CU two 4-wave workgroups
-    constexpr bool kHasW8 = LAY == LAYOUT_NHWC && STR == 1;
+    constexpr bool kHasW8 = LAY == LAYOUT_NHWC && STR == 1 && PREC == 0;
     int waves = 4;
     if (kHasW8 && g_force_waves != 4 && (g_force_waves == 8 || (long)a.mbk * a.ngk < 160)) {
         const bool cat_ok = !(SRC == SRC_GATHER && a.Csplit != a.Cin && a.Csplit % (2 * cc4));
@@ -223,7 +266,8 @@ static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
     // which operand should stay XCD-local: weights (dense layers) or input tiles (many active tiles)
     const double wbytes = (double)a.Cout * a.Cin * KH * KH, abytes = (double)a.T * a.Cin * R * R;
     a.ng_fast = wbytes > abytes;
-    if (mt == 16) a.packed += packed_floats(a.Cout, a.Cin, KH * KH, 32);  // the MT=16 layout follows the MT=32 one
+    if (mt == 16)  // the MT=16 layout follows the MT=32 one
+        a.packed += PREC == 1 ? packed_units_h(a.Cout, a.Cin, KH * KH, 32) : packed_floats(a.Cout, a.Cin, KH * KH, 32);
     // K split (channels-last launches that came with a workspace)
     a.ksplit = ksplit_for((long)a.mbk * a.ngk, a.nchunks, cap);
     a.chunks_per_split = ceil_div(a.nchunks, a.ksplit);
@@ -258,13 +302,16 @@ static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
     return SIGE_HIP_OK;
 }
 
-template <int SRC, int DST = DST_TILES, int LAY = LAYOUT_NCHW>
+template <int SRC, int DST = DST_TILES, int LAY = LAYOUT_NCHW, int PREC = 0>
 static int launch_conv(const ConvArgs &a, int mode, int kH, int kW, int R, int S, int strH, int strW, hipStream_t st) {
     int rc;
     switch (mfma_kind(kH, kW, R, S, strH, strW, 1)) {
-        case 1: rc = launch_kind<3, 1, 6, SRC, DST, LAY>(a, mode, st); break;
-        case 2: rc = launch_kind<1, 1, 4, SRC, DST, LAY>(a, mode, st); break;
-        case 3: rc = launch_kind<3, 2, 5, SRC, DST, LAY>(a, mode, st); break;
+        case 1: rc = launch_kind<3, 1, 6, SRC, DST, LAY, PREC>(a, mode, st); break;
+        case 2: rc = launch_kind<1, 1, 4, SRC, DST, LAY, PREC>(a, mode, st); break;
+        case 3:
+            if constexpr (PREC == 1) return SIGE_HIP_EUNSUPPORTED;  // (see the f16-compute declarations above)
+            else rc = launch_kind<3, 2, 5, SRC, DST, LAY, PREC>(a, mode, st);
+            break;
         default: return SIGE_HIP_EUNSUPPORTED;
     }
     return rc != SIGE_HIP_OK ? rc : launch_status();
@@ -323,6 +370,33 @@ extern "C" int sige_hip_block_conv_pack_f32(const float *w, int Cout, int Cin, i
     } else {
         pack_weights_kernel<1, 32><<<blocks(n32), 256, 0, st>>>(w, Cout, Cin, packed, n32);
         pack_weights_kernel<1, 16><<<blocks(n16), 256, 0, st>>>(w, Cout, Cin, packed + n32, n16);
+    }
+    return launch_status(2);
+}
+
+extern "C" size_t sige_hip_block_conv_packed_size_f16c(int Cout, int Cin, int kH, int kW, int R, int S,
+                                                       int strideH, int strideW, int groups) {
+    if (Cout <= 0 || Cin <= 0) return 0;
+    const int kind = mfma_kind(kH, kW, R, S, strideH, strideW, groups);
+    if (kind != 1 && kind != 2) return 0;  // stride-1 3x3 on 6x6 and 1x1 on 4x4 (the stride-2 geometry stays fp32)
+    return packed_units_h(Cout, Cin, kH * kW, 32) + packed_units_h(Cout, Cin, kH * kW, 16);
+}
+
+extern "C" int sige_hip_block_conv_pack_f16c(const float *w, int Cout, int Cin, int kH, int kW,
+                                             float *packed, void *stream) {
+    if (!w || !packed || Cout <= 0 || Cin <= 0) return SIGE_HIP_EINVAL;
+    if (kH != kW || (kH != 1 && kH != 3)) return SIGE_HIP_EUNSUPPORTED;
+    const int KK = kH * kW;
+    hipStream_t st = as_stream(stream);
+    const long n32 = 2 * (long)packed_units_h(Cout, Cin, KK, 32), n16 = 2 * (long)packed_units_h(Cout, Cin, KK, 16);  // halves
+    auto blocks = [](long n) { return (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096); };
+    _Float16 *ph = reinterpret_cast<_Float16 *>(packed);
+    if (KK == 9) {
+        pack_weights_h_kernel<9, 32><<<blocks(n32), 256, 0, st>>>(w, Cout, Cin, ph, n32);
+        pack_weights_h_kernel<9, 16><<<blocks(n16), 256, 0, st>>>(w, Cout, Cin, ph + n32, n16);
+    } else {
+        pack_weights_h_kernel<1, 32><<<blocks(n32), 256, 0, st>>>(w, Cout, Cin, ph, n32);
+        pack_weights_h_kernel<1, 16><<<blocks(n16), 256, 0, st>>>(w, Cout, Cin, ph + n32, n16);
     }
     return launch_status(2);
 }
@@ -452,9 +526,10 @@ extern "C" int sige_hip_conv_ksplit_hint(int T, int Cin, int Cout, int kH, int k
     return 8;  // (the launch decides the actual factor, at most 8)
 }
 
-extern "C" int sige_hip_block_conv_nhwc_f32(const float *x, int T, int Cin, int R, int S,
-                                            const float *packed, const float *bias, int Cout, int kH, int kW,
-                                            int strideH, int strideW, float *out, void *stream) {
+template <int PREC>
+static int block_conv_nhwc_impl(const float *x, int T, int Cin, int R, int S,
+                                const float *packed, const float *bias, int Cout, int kH, int kW,
+                                int strideH, int strideW, float *out, void *stream) {
     if (T < 0 || Cin <= 0 || Cout <= 0) return SIGE_HIP_EINVAL;
     if (T == 0) return SIGE_HIP_OK;
     if (!x || !packed || !out) return SIGE_HIP_EINVAL;
@@ -463,10 +538,23 @@ extern "C" int sige_hip_block_conv_nhwc_f32(const float *x, int T, int Cin, int 
     ConvArgs a{};
     a.x = x; a.packed = packed; a.bias = bias; a.out = out;
     a.T = T; a.Cin = Cin; a.Cout = Cout;
-    return launch_conv<SRC_TILES, DST_TILES, LAYOUT_NHWC>(a, 0, kH, kW, R, S, strideH, strideW, as_stream(stream));
+    return launch_conv<SRC_TILES, DST_TILES, LAYOUT_NHWC, PREC>(a, 0, kH, kW, R, S, strideH, strideW, as_stream(stream));
 }
 
-extern "C" int sige_hip_gather_conv_nhwc_f32(const float *x, const float *x2, int B, int C1, int C2, int H, int W,
+extern "C" int sige_hip_block_conv_nhwc_f32(const float *x, int T, int Cin, int R, int S,
+                                            const float *packed, const float *bias, int Cout, int kH, int kW,
+                                            int strideH, int strideW, float *out, void *stream) {
+    return block_conv_nhwc_impl<0>(x, T, Cin, R, S, packed, bias, Cout, kH, kW, strideH, strideW, out, stream);
+}
+
+extern "C" int sige_hip_block_conv_nhwc_f16c(const float *x, int T, int Cin, int R, int S,
+                                             const float *packed, const float *bias, int Cout, int kH, int kW,
+                                             int strideH, int strideW, float *out, void *stream) {
+    return block_conv_nhwc_impl<1>(x, T, Cin, R, S, packed, bias, Cout, kH, kW, strideH, strideW, out, stream);
+}
+
+template <int PREC>
+static int gather_conv_nhwc_impl(const float *x, const float *x2, int B, int C1, int C2, int H, int W,
                                              int bH, int bW, const int32_t *active_indices, int N,
                                              const float *scale, int scaleB, int scaleC,
                                              const float *shift, int shiftB, int shiftC,
@@ -512,12 +600,45 @@ extern "C" int sige_hip_gather_conv_nhwc_f32(const float *x, const float *x2, in
     }
     if (to_full) {
         a.residual = residual; a.Ho = Ho; a.Wo = Wo; a.offH = offsetH; a.offW = offsetW; a.strH = strideH; a.strW = strideW;
-        return launch_conv<SRC_GATHER, DST_NCHW, LAYOUT_NHWC>(a, mode, kH, kW, bH, bW, strideH, strideW, as_stream(stream));
+        return launch_conv<SRC_GATHER, DST_NCHW, LAYOUT_NHWC, PREC>(a, mode, kH, kW, bH, bW, strideH, strideW, as_stream(stream));
     }
-    return launch_conv<SRC_GATHER, DST_TILES, LAYOUT_NHWC>(a, mode, kH, kW, bH, bW, strideH, strideW, as_stream(stream));
+    return launch_conv<SRC_GATHER, DST_TILES, LAYOUT_NHWC, PREC>(a, mode, kH, kW, bH, bW, strideH, strideW, as_stream(stream));
 }
 
-extern "C" int sige_hip_scatter_gather_conv_nhwc_f32(const float *x, const float *y, int B, int Cin, int H, int W,
+#define SIGE_GATHER_CONV_ARGS x, x2, B, C1, C2, H, W, bH, bW, active_indices, N, scale, scaleB, scaleC, shift, shiftB, shiftC, \
+    activation, packed, bias, Cout, kH, kW, strideH, strideW, to_full, offsetH, offsetW, residual, Ho, Wo, workspace,          \
+    workspace_floats, out_scale, out_shift, out_activation, upsample2x, out, stream
+extern "C" int sige_hip_gather_conv_nhwc_f32(const float *x, const float *x2, int B, int C1, int C2, int H, int W,
+                                             int bH, int bW, const int32_t *active_indices, int N,
+                                             const float *scale, int scaleB, int scaleC,
+                                             const float *shift, int shiftB, int shiftC,
+                                             int activation,
+                                             const float *packed, const float *bias, int Cout, int kH, int kW,
+                                             int strideH, int strideW,
+                                             int to_full, int offsetH, int offsetW, const float *residual, int Ho, int Wo,
+                                             float *workspace, size_t workspace_floats,
+                                             const float *out_scale, const float *out_shift, int out_activation,
+                                             int upsample2x,
+                                             float *out, void *stream) {
+    return gather_conv_nhwc_impl<0>(SIGE_GATHER_CONV_ARGS);
+}
+extern "C" int sige_hip_gather_conv_nhwc_f16c(const float *x, const float *x2, int B, int C1, int C2, int H, int W,
+                                             int bH, int bW, const int32_t *active_indices, int N,
+                                             const float *scale, int scaleB, int scaleC,
+                                             const float *shift, int shiftB, int shiftC,
+                                             int activation,
+                                             const float *packed, const float *bias, int Cout, int kH, int kW,
+                                             int strideH, int strideW,
+                                             int to_full, int offsetH, int offsetW, const float *residual, int Ho, int Wo,
+                                             float *workspace, size_t workspace_floats,
+                                             const float *out_scale, const float *out_shift, int out_activation,
+                                             int upsample2x,
+                                             float *out, void *stream) {
+    return gather_conv_nhwc_impl<1>(SIGE_GATHER_CONV_ARGS);
+}
+
+template <int PREC>
+static int scatter_gather_conv_nhwc_impl(const float *x, const float *y, int B, int Cin, int H, int W,
                                                      int Rx, int Sx, int bH, int bW,
                                                      const int32_t *active_indices, int N, const int32_t *scatter_map,
                                                      const float *scale, int scaleB, int scaleC,
@@ -538,12 +659,36 @@ extern "C" int sige_hip_scatter_gather_conv_nhwc_f32(const float *x, const float
     a.scale = scale; a.shift = shift;
     const int mode = staging_mode(scale, scaleB, scaleC, shift, shiftB, shiftC, activation, B, Cin, &a.aff_sb, &a.aff_sc);
     if (mode < 0) return SIGE_HIP_EUNSUPPORTED;
-    return launch_conv<SRC_SCATTER_GATHER, DST_TILES, LAYOUT_NHWC>(a, mode, kH, kW, bH, bW, strideH, strideW, as_stream(stream));
+    return launch_conv<SRC_SCATTER_GATHER, DST_TILES, LAYOUT_NHWC, PREC>(a, mode, kH, kW, bH, bW, strideH, strideW, as_stream(stream));
+}
+
+#define SIGE_SG_CONV_ARGS x, y, B, Cin, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB, \
+    shiftC, activation, packed, bias, Cout, kH, kW, strideH, strideW, out, stream
+extern "C" int sige_hip_scatter_gather_conv_nhwc_f32(const float *x, const float *y, int B, int Cin, int H, int W,
+                                                     int Rx, int Sx, int bH, int bW,
+                                                     const int32_t *active_indices, int N, const int32_t *scatter_map,
+                                                     const float *scale, int scaleB, int scaleC,
+                                                     const float *shift, int shiftB, int shiftC,
+                                                     int activation,
+                                                     const float *packed, const float *bias, int Cout, int kH, int kW,
+                                                     int strideH, int strideW, float *out, void *stream) {
+    return scatter_gather_conv_nhwc_impl<0>(SIGE_SG_CONV_ARGS);
+}
+extern "C" int sige_hip_scatter_gather_conv_nhwc_f16c(const float *x, const float *y, int B, int Cin, int H, int W,
+                                                     int Rx, int Sx, int bH, int bW,
+                                                     const int32_t *active_indices, int N, const int32_t *scatter_map,
+                                                     const float *scale, int scaleB, int scaleC,
+                                                     const float *shift, int shiftB, int shiftC,
+                                                     int activation,
+                                                     const float *packed, const float *bias, int Cout, int kH, int kW,
+                                                     int strideH, int strideW, float *out, void *stream) {
+    return scatter_gather_conv_nhwc_impl<1>(SIGE_SG_CONV_ARGS);
 }
 
 // scatter_gather -> conv -> Scatter / ScatterWithBlockResidual in ONE launch: the conv's output tiles go straight
 // into `out` [B,H,W,Cout], a buffer that already holds the cached tensor outside this mask's tiles (in-place scatter).
-extern "C" int sige_hip_scatter_gather_conv_scatter_nhwc_f32(
+template <int PREC>
+static int scatter_gather_conv_scatter_nhwc_impl(
         const float *x, const float *y, int B, int Cin, int H, int W, int Rx, int Sx, int bH, int bW,
         const int32_t *active_indices, int N, const int32_t *scatter_map,
         const float *scale, int scaleB, int scaleC, const float *shift, int shiftB, int shiftC, int activation,
@@ -570,8 +715,31 @@ extern "C" int sige_hip_scatter_gather_conv_scatter_nhwc_f32(
     if (mode < 0) return SIGE_HIP_EUNSUPPORTED;
     a.residual = residual; a.Ho = H; a.Wo = W; a.offH = offsetH; a.offW = offsetW; a.strH = 1; a.strW = 1;
     a.x1 = x1; a.table1 = table1; a.gW1 = gW1; a.N1 = N1; a.R1 = R1 > 0 ? R1 : 1; a.S1 = S1 > 0 ? S1 : 1;
-    return launch_kind<3, 1, 6, SRC_SCATTER_GATHER, DST_NCHW, LAYOUT_NHWC>(a, mode, as_stream(stream)) != SIGE_HIP_OK
+    return launch_kind<3, 1, 6, SRC_SCATTER_GATHER, DST_NCHW, LAYOUT_NHWC, PREC>(a, mode, as_stream(stream)) != SIGE_HIP_OK
                ? SIGE_HIP_EUNSUPPORTED : launch_status();
+}
+
+#define SIGE_SGS_CONV_ARGS x, y, B, Cin, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB, \
+    shiftC, activation, packed, bias, Cout, kH, kW, offsetH, offsetW, residual, x1, table1, gH1, gW1, N1, R1, S1, out, stream
+extern "C" int sige_hip_scatter_gather_conv_scatter_nhwc_f32(
+        const float *x, const float *y, int B, int Cin, int H, int W, int Rx, int Sx, int bH, int bW,
+        const int32_t *active_indices, int N, const int32_t *scatter_map,
+        const float *scale, int scaleB, int scaleC, const float *shift, int shiftB, int shiftC, int activation,
+        const float *packed, const float *bias, int Cout, int kH, int kW,
+        int offsetH, int offsetW, const float *residual,
+        const float *x1, const int32_t *table1, int gH1, int gW1, int N1, int R1, int S1,
+        float *out, void *stream) {
+    return scatter_gather_conv_scatter_nhwc_impl<0>(SIGE_SGS_CONV_ARGS);
+}
+extern "C" int sige_hip_scatter_gather_conv_scatter_nhwc_f16c(
+        const float *x, const float *y, int B, int Cin, int H, int W, int Rx, int Sx, int bH, int bW,
+        const int32_t *active_indices, int N, const int32_t *scatter_map,
+        const float *scale, int scaleB, int scaleC, const float *shift, int shiftB, int shiftC, int activation,
+        const float *packed, const float *bias, int Cout, int kH, int kW,
+        int offsetH, int offsetW, const float *residual,
+        const float *x1, const int32_t *table1, int gH1, int gW1, int N1, int R1, int S1,
+        float *out, void *stream) {
+    return scatter_gather_conv_scatter_nhwc_impl<1>(SIGE_SGS_CONV_ARGS);
 }
 
 extern "C" int sige_hip_block_conv_direct_f32(const float *x, int T, int Cin, int R, int S,

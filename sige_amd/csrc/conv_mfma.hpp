@@ -42,6 +42,8 @@ namespace sige {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 enum { SRC_TILES = 0, SRC_GATHER = 1, SRC_SCATTER_GATHER = 2 };
 enum { DST_TILES = 0, DST_NCHW = 1 };  // DST_NCHW = "into a full tensor" (in the launch's layout)
@@ -62,8 +64,27 @@ template <> struct Mfma<16> {
     }
 };
 
+// fp16 operands (8 k-values per lane and instruction), fp32 accumulation: v_mfma_f32_32x32x16_f16 / 16x16x32_f16,
+// 16x the rate of the f32-input forms above
+template <int MT_> struct MfmaH;
+template <> struct MfmaH<32> {
+    using acc_t = f32x16;
+    static constexpr int REGS = 16;
+    __device__ static __forceinline__ acc_t op(f16x8 a, f16x8 b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct MfmaH<16> {
+    using acc_t = f32x4;
+    static constexpr int REGS = 4;
+    __device__ static __forceinline__ acc_t op(f16x8 a, f16x8 b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+
 template <int KH, int STR, int R_, int MT_>
 struct ConvGeo {
+    static constexpr bool F16 = false;
     static constexpr int K = KH, S = STR, R = R_, MT = MT_;
     static constexpr int KK = KH * KH;
     static constexpr int RS = R_ * R_;
@@ -79,6 +100,33 @@ struct ConvGeo {
     static constexpr int BUF = TPB * TILE_FLOATS;      // floats per LDS stage, laid out [tile][channel][R][S]
     static constexpr int RED = MT_ + 4;                // padded pixel stride of the reduction buffer
     static_assert(L % 4 == 0, "wave slice must be a whole number of float4 weight loads");
+    static_assert(MT_ % PX == 0 && TPB >= 1, "tile pixels must divide the M block");
+};
+
+// The same tile geometry computed on the fp16 matrix cores ("f16 compute"): tensors stay fp32 in HBM; the staging path
+// finishes a value in fp32 (cached GroupNorm affine + SiLU), rounds it to fp16 (RNE) into LDS, the weights are packed
+// as fp16, products are exact in fp32 and accumulate in fp32.  One MFMA contracts SLAB = 8 * NL channels at ONE tap:
+// an A operand is 8 consecutive channels of a pixel = one ds_read_b128 of the channels-last stage.
+template <int KH, int STR, int R_, int MT_>
+struct ConvGeoH {
+    static constexpr bool F16 = true;
+    static constexpr int K = KH, S = STR, R = R_, MT = MT_;
+    static constexpr int KK = KH * KH;
+    static constexpr int RS = R_ * R_;
+    static constexpr int RO = (R_ - KH) / STR + 1;
+    static constexpr int PX = RO * RO;
+    static constexpr int NL = 64 / MT_;                // lane groups of an MFMA (2 or 4)
+    static constexpr int KP = 8;                       // k values (channels) per lane and MFMA
+    static constexpr int SLAB = NL * KP;               // channels one MFMA contracts (16 or 32)
+    static constexpr int NSLAB = KK == 1 ? 2 : 1;      // slabs per wave per chunk
+    static constexpr int TPB = MT_ / PX;
+    static constexpr int CW = NSLAB * SLAB;            // channels per wave per chunk
+    static constexpr int CC = 4 * CW;                  // channels per LDS chunk (4 waves)
+    static constexpr int L = NSLAB * KK;               // MFMAs per wave per chunk (9 or 2)
+    static constexpr int F = L;                        // 16-byte weight loads per lane per chunk and N sub-block
+    static constexpr int TILE_FLOATS = CC * RS;
+    static constexpr int BUF = TPB * TILE_FLOATS;
+    static constexpr int RED = MT_ + 4;
     static_assert(MT_ % PX == 0 && TPB >= 1, "tile pixels must divide the M block");
 };
 
@@ -196,18 +244,21 @@ enum { LAYOUT_NCHW = 0, LAYOUT_NHWC = 1 };
 // exactly the 8-wave order, so both forms share one packed tensor (chunk count padded to even).
 template <typename G, int NB, int SRC, int MODE, int DST, int LAYOUT = LAYOUT_NCHW, int W = 4>
 __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
-    using M = Mfma<G::MT>;
+    constexpr bool F16 = G::F16;                 // fp16 operands in LDS / registers (ConvGeoH)
+    using M = std::conditional_t<F16, MfmaH<G::MT>, Mfma<G::MT>>;
+    static_assert(!F16 || LAYOUT == LAYOUT_NHWC, "the f16-compute kernels are channels-last");
     constexpr int NT = 64 * W;                   // lanes per workgroup
     constexpr int CCk = W * G::CW;               // channels per LDS chunk
     constexpr int TILEF = CCk * G::RS;           // floats of one staged tile (NCHW stage)
     constexpr int BUFk = G::TPB * TILEF;
     constexpr bool NHWC = LAYOUT == LAYOUT_NHWC;
     constexpr bool VEC = NHWC || SRC == SRC_TILES;            // staging slots are float4 units
-    constexpr int NACC = (G::MT == 16 && NB == 1) ? 2 : 1;   // 16x16x4: 40-cycle dependent latency vs 32-cycle issue
+    constexpr int NACC = ((G::MT == 16 && NB == 1) || (F16 && NB == 1)) ? 2 : 1;   // 16x16x4: 40-cycle dependent latency vs 32-cycle issue
     constexpr bool AFF = MODE != MODE_RAW;
     // LDS stage of one channel chunk: NCHW [tile][channel][R][S]; NHWC [tile][R][S][LDC] (LDC = CC + 4 pad)
-    constexpr int LDC = CCk + 4;
-    constexpr int STAGE = NHWC ? G::TPB * G::RS * LDC : BUFk;
+    //   (f16 compute: the stage holds HALVES, row = CC + 8 halves; STAGE stays in floats)
+    constexpr int LDC = F16 ? CCk + 8 : CCk + 4;
+    constexpr int STAGE = NHWC ? (F16 ? G::TPB * G::RS * LDC / 2 : G::TPB * G::RS * LDC) : BUFk;
     constexpr int TROW = CCk + 4;                            // table row: CC channels + 4 zeros
     constexpr int TABF = AFF ? 2 * TROW : 0;                   // scale row | shift row
     constexpr int RP = G::MT + 4;                              // padded row of the reduction buffer
@@ -562,7 +613,12 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
                 q.x = finish(q.x, sc.x, sh.x); q.y = finish(q.y, sc.y, sh.y);
                 q.z = finish(q.z, sc.z, sh.z); q.w = finish(q.w, sc.w, sh.w);
             }
-            *reinterpret_cast<float4 *>(buf + s_dst[i]) = q;
+            if constexpr (F16) {
+                const f16x4 h = {(_Float16)q.x, (_Float16)q.y, (_Float16)q.z, (_Float16)q.w};  // RNE
+                *reinterpret_cast<f16x4 *>(reinterpret_cast<_Float16 *>(buf) + s_dst[i]) = h;
+            } else {
+                *reinterpret_cast<float4 *>(buf + s_dst[i]) = q;
+            }
         }
     };
     auto tab_load = [&](int chunk) {
@@ -588,10 +644,13 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
     // A: this lane's output pixel = row j of the M block; k-step u = (channel group q, tap)
     const int tl = j / G::PX, px = j % G::PX;
     const int oy = px / G::RO, ox = px % G::RO;
-    const int a_base = NHWC ? (tl * G::RS + oy * G::S * G::R + ox * G::S) * LDC + wave * G::CW + kq
+    //   (f16 compute: k-step u = (slab, tap); the lane's operand = 8 consecutive channels, offsets in halves)
+    const int a_base = F16 ? (tl * G::RS + oy * G::S * G::R + ox * G::S) * LDC + wave * G::CW + kq * 8
+                     : NHWC ? (tl * G::RS + oy * G::S * G::R + ox * G::S) * LDC + wave * G::CW + kq
                             : tl * TILEF + (wave * G::CW + kq) * G::RS + oy * G::S * G::R + ox * G::S;
     auto a_off = [](int u) {
         const int q = u / G::KK, tap = u % G::KK, pix = (tap / G::K) * G::R + (tap % G::K);
+        if (F16) return pix * LDC + q * (G::NL * 8);
         return NHWC ? pix * LDC + q * G::NL : q * G::NL * G::RS + pix;
     };
 
@@ -628,6 +687,34 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
         set_chunk(c3);
         set_b_chunk(c2);
         tab_load(c2);
+        if constexpr (F16) {
+            // one 16-byte A operand (8 channels of the lane's pixel at one tap) and one 16-byte B register per k-step
+            const _Float16 *ah = reinterpret_cast<const _Float16 *>(smem + PAR * STAGE) + a_base;
+            f16x8 avh[G::L];
+#pragma unroll
+            for (int u = 0; u < G::L; ++u) avh[u] = *reinterpret_cast<const f16x8 *>(ah + a_off(u));
+            static_for<0, G::L>([&](auto u_tag) {
+                constexpr int u = decltype(u_tag)::value;
+                static_for<0, NB>([&](auto nb_tag) {
+                    constexpr int nb = decltype(nb_tag)::value;
+                    const float4 bq = bset[PAR][nb][u];
+                    const f32x4 braw = {bq.x, bq.y, bq.z, bq.w};
+                    acc[nb][u % NACC] = M::op(avh[u], __builtin_bit_cast(f16x8, braw), acc[nb][u % NACC]);
+                });
+                static_for<(u * NS) / G::L, ((u + 1) * NS) / G::L>([&](auto i_tag) {
+                    constexpr int i = decltype(i_tag)::value;
+                    slot_store(PAR ^ 1, i, nxt, tab + (PAR ^ 1) * TABF);
+                    slot_load(PAR ^ 1, i, c3);
+                });
+                static_for<0, NB>([&](auto nb_tag) {
+                    constexpr int nb = decltype(nb_tag)::value;
+                    b_load(bset[PAR][nb][u], nb, u);
+                });
+            });
+            tab_store(tab + PAR * TABF);
+            __syncthreads();
+            return;
+        } else {
         // all A values of the chunk up front: LDS reads overlap with the matrix pipe for free
         float av[G::L];
 #pragma unroll
@@ -657,6 +744,7 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
         });
         tab_store(tab + PAR * TABF);  // table of chunk+2 replaces the one this chunk's predecessor used
         __syncthreads();
+        }
     };
 
     for (int chunk = first; chunk <= last; chunk += 2) {

@@ -54,6 +54,8 @@ _SIGNATURES = {
     "sige_hip_reduce_mask_capacity": (_c_int, [_c_int] * 6),
     "sige_hip_reduce_mask_i32": (_c_int, [_c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp, _c_vp]),
     "sige_hip_block_conv_packed_size": (_c_sz, [_c_int] * 9),
+    "sige_hip_block_conv_packed_size_f16c": (_c_sz, [_c_int] * 9),
+    "sige_hip_block_conv_pack_f16c": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp]),
     "sige_hip_block_conv_pack_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp]),
     "sige_hip_block_conv_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp, _c_vp]),
     "sige_hip_gather_conv_f32": (
@@ -78,6 +80,16 @@ _SIGNATURES = {
         _c_int, [_c_vp, _c_vp] + [_c_int] * 7 + [_c_vp, _c_int] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
         + [_c_int] * 5 + [_c_int, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_vp, _c_sz, _c_vp, _c_vp, _c_int, _c_int, _c_vp, _c_vp]),
     "sige_hip_conv_ksplit_hint": (_c_int, [_c_int] * 7),
+    "sige_hip_block_conv_nhwc_f16c": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp, _c_vp]),
+    "sige_hip_gather_conv_nhwc_f16c": (
+        _c_int, [_c_vp, _c_vp] + [_c_int] * 7 + [_c_vp, _c_int] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
+        + [_c_int] * 5 + [_c_int, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_vp, _c_sz, _c_vp, _c_vp, _c_int, _c_int, _c_vp, _c_vp]),
+    "sige_hip_scatter_gather_conv_nhwc_f16c": (
+        _c_int, [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
+        + [_c_int] * 5 + [_c_vp, _c_vp]),
+    "sige_hip_scatter_gather_conv_scatter_nhwc_f16c": (
+        _c_int, [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
+        + [_c_int] * 3 + [_c_int, _c_int, _c_vp] + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp, _c_vp]),
     "sige_hip_scatter_gather_conv_nhwc_f32": (
         _c_int, [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
         + [_c_int] * 5 + [_c_vp, _c_vp]),
@@ -433,18 +445,39 @@ def conv_packed_size(Cout, Cin, kH, kW, R, S, strH, strW, groups=1) -> int:
     return int(lib().sige_hip_block_conv_packed_size(Cout, Cin, kH, kW, R, S, strH, strW, groups))
 
 
-def conv_pack_weights(weight: torch.Tensor, R: int, S: int, stride: Tuple[int, int]) -> Optional[torch.Tensor]:
-    """Re-lay a conv weight [Cout,Cin,k,k] for the MFMA block conv; None if the
-    shape has no MFMA path."""
+class PackedWeights(torch.Tensor):
+    """Opaque packed conv weights (fp32 storage); `.compute` says which matrix path they were laid out for."""
+    compute = "f32"
+
+
+def conv_pack_weights(weight: torch.Tensor, R: int, S: int, stride: Tuple[int, int], compute: str = "f32") -> Optional[torch.Tensor]:
+    """Re-lay a conv weight [Cout,Cin,k,k] for the MFMA block conv; None if the shape has no MFMA path.
+    compute = "f16": fp16 operands on the 16x faster fp16 matrix path, fp32 accumulation (activations stay fp32 in HBM;
+    BASELINE.json configs[4]).  Shapes without an f16 kernel (the stride-2 geometry) are packed for the fp32 path --
+    the returned tensor's `.compute` tells which."""
     w = _req(weight.detach(), torch.float32, "weight")
     Cout, Cin, kH, kW = w.shape
-    n = conv_packed_size(Cout, Cin, kH, kW, R, S, stride[0], stride[1], 1)
+    if compute not in ("f32", "f16"):
+        raise ValueError("compute must be 'f32' or 'f16'")
+    n = 0
+    if compute == "f16":
+        n = int(lib().sige_hip_block_conv_packed_size_f16c(Cout, Cin, kH, kW, R, S, stride[0], stride[1], 1))
+        if n == 0:
+            compute = "f32"
+    if compute == "f32":
+        n = conv_packed_size(Cout, Cin, kH, kW, R, S, stride[0], stride[1], 1)
     if n == 0:
         return None
-    packed = torch.empty((n,), dtype=torch.float32, device=w.device)
-    _check(lib().sige_hip_block_conv_pack_f32(w.data_ptr(), Cout, Cin, kH, kW, packed.data_ptr(), _stream(w)),
-           "conv_pack_weights")
+    packed = torch.empty((n,), dtype=torch.float32, device=w.device).as_subclass(PackedWeights)
+    packed.compute = compute
+    fn = lib().sige_hip_block_conv_pack_f16c if compute == "f16" else lib().sige_hip_block_conv_pack_f32
+    _check(fn(w.data_ptr(), Cout, Cin, kH, kW, packed.data_ptr(), _stream(w)), "conv_pack_weights")
     return packed
+
+
+def _conv_fn(name: str, packed):
+    """The fp32 or the f16-compute entry point, according to how `packed` was laid out."""
+    return getattr(lib(), name + ("_f16c" if getattr(packed, "compute", "f32") == "f16" else "_f32"))
 
 
 def conv_force_tile(mt: int = 0, nb: int = 0):
@@ -457,7 +490,13 @@ def conv_force_waves(waves: int = 0):
     _check(lib().sige_hip_block_conv_force_waves(waves), "conv_force_waves")
 
 
+def _f32_packed(packed):
+    if getattr(packed, "compute", "f32") != "f32":
+        raise NotImplementedError("the f16-compute kernels are channels-last: pack with compute='f32' for NCHW tensors")
+
+
 def block_conv(x, packed, bias, Cout: int, kernel: Tuple[int, int], stride: Tuple[int, int]):
+    _f32_packed(packed)
     x = _req(x, torch.float32, "x")
     T, Cin, R, S = x.shape
     Ro, So = (R - kernel[0]) // stride[0] + 1, (S - kernel[1]) // stride[1] + 1
@@ -483,6 +522,7 @@ def gather_conv(x, block: Tuple[int, int], activeIndices, scale, shift, activati
     """gather(x, ...) followed by the stacked-block conv, in one kernel.  Returns None when
     the fused kernel cannot express the call (SIGE_HIP_EUNSUPPORTED: e.g. a per-batch affine
     whose tiles-per-workgroup straddle images); the caller then runs gather + block_conv."""
+    _f32_packed(packed)
     x = _req(x, torch.float32, "x")
     idx = _req(activeIndices, torch.int32, "activeIndices", 2)
     (sa, s_keep), (ta, t_keep) = _bc(scale, "scale"), _bc(shift, "shift")
@@ -505,6 +545,7 @@ def scatter_gather_conv(x, y, block: Tuple[int, int], activeIndices, scatterMap,
                         packed, bias, Cout: int, kernel: Tuple[int, int], stride: Tuple[int, int]):
     """scatter_gather(x, y, ...) followed by the stacked-block conv, in one kernel (None if
     the fused kernel cannot express the call, see gather_conv)."""
+    _f32_packed(packed)
     x, y = _req(x, torch.float32, "x"), _req(y, torch.float32, "y")
     idx = _req(activeIndices, torch.int32, "activeIndices", 2)
     smap = _req(scatterMap, torch.int32, "scatterMap", 3)
@@ -557,6 +598,7 @@ def gather_conv_nchw(x, x2, block: Tuple[int, int], activeIndices, scale, shift,
     """conv(act(cat(x, x2) * scale + shift)) + residual over the listed tiles, written
     straight into a fresh [B,Cout,Ho,Wo] tensor (pixels no tile covers are NOT written:
     pass the all-tiles list for a dense layer)."""
+    _f32_packed(packed)
     x = _req(x, torch.float32, "x")
     B, C1, H, W = x.shape
     C2 = 0
@@ -709,7 +751,7 @@ def block_conv_cl(x, packed, bias, Cout: int, kernel: Tuple[int, int], stride: T
     T, Cin, R, S = x.shape
     Ro, So = (R - kernel[0]) // stride[0] + 1, (S - kernel[1]) // stride[1] + 1
     out = _empty_cl((T, Cout, Ro, So), x.device)
-    status = lib().sige_hip_block_conv_nhwc_f32(x.data_ptr(), T, Cin, R, S, packed.data_ptr(), _p(bias_keep), Cout,
+    status = _conv_fn("sige_hip_block_conv_nhwc", packed)(x.data_ptr(), T, Cin, R, S, packed.data_ptr(), _p(bias_keep), Cout,
                                                 kernel[0], kernel[1], stride[0], stride[1], out.data_ptr(), _stream(x))
     if status == UNSUPPORTED:
         return None
@@ -770,7 +812,7 @@ def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, a
     else:
         fargs = fargs + (None, None, 0)
     fargs = fargs + (int(bool(upsample2x)),)
-    status = lib().sige_hip_gather_conv_nhwc_f32(
+    status = _conv_fn("sige_hip_gather_conv_nhwc", packed)(
         x.data_ptr(), None if x2 is None else x2.data_ptr(), B, C1, C2, H, W, block[0], block[1], idx.data_ptr(), N,
         *sa, *ta, _act(activationName), packed.data_ptr(), _p(bias_keep), Cout, kernel[0], kernel[1],
         stride[0], stride[1], *fargs, out.data_ptr(), _stream(x))
@@ -791,7 +833,7 @@ def scatter_gather_conv_cl(x, y, block: Tuple[int, int], activeIndices, scatterM
     N = idx.shape[0]
     Ro, So = (block[0] - kernel[0]) // stride[0] + 1, (block[1] - kernel[1]) // stride[1] + 1
     out = _empty_cl((B * N, Cout, Ro, So), y.device)
-    status = lib().sige_hip_scatter_gather_conv_nhwc_f32(
+    status = _conv_fn("sige_hip_scatter_gather_conv_nhwc", packed)(
         x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3], block[0], block[1], idx.data_ptr(), N,
         smap.data_ptr(), *sa, *ta, _act(activationName), packed.data_ptr(), _p(bias_keep), Cout, kernel[0], kernel[1],
         stride[0], stride[1], out.data_ptr(), _stream(y))
@@ -824,7 +866,7 @@ def scatter_gather_conv_scatter_cl(x, y, block, activeIndices, scatterMap, scale
         bargs = (x1.data_ptr(), t1.data_ptr(), t1.shape[0], t1.shape[1], x1.shape[0] // B, x1.shape[2], x1.shape[3])
     else:
         bargs = (None, None, 0, 0, 0, 0, 0)
-    status = lib().sige_hip_scatter_gather_conv_scatter_nhwc_f32(
+    status = _conv_fn("sige_hip_scatter_gather_conv_scatter_nhwc", packed)(
         x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3], block[0], block[1], idx.data_ptr(), idx.shape[0],
         smap.data_ptr(), *sa, *ta, _act(activationName), packed.data_ptr(), _p(bias_keep), Cout, kernel[0], kernel[1],
         offset[0], offset[1], None if r is None else r.data_ptr(), *bargs, out.data_ptr(), _stream(y))

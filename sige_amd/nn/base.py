@@ -127,19 +127,25 @@ class SIGEConv2d(nn.Conv2d, SIGEModule):
     def __init__(self, *args, **kwargs):
         nn.Conv2d.__init__(self, *args, **kwargs)
         SIGEModule.__init__(self, call_super=False)
-        self._packed = None
-        self._packed_key = None
+        self._packed = {}
         self._tiles_runtime = self.load_runtime("conv2d_tiles", {})
+        # "f32": exact fp32 products (v_mfma_f32_*_f32); "f16": fp16 operands, fp32 accumulation on the 16x faster fp16
+        # matrix path (SIGEModel.set_compute_dtype; channels-last tiles only -- BASELINE.json configs[4])
+        self.compute_dtype = "f32"
 
-    def _packed_weights(self, x: torch.Tensor):
+    def _packed_weights(self, x: torch.Tensor, channels_last: bool = True):
+        """Packed weights for tiles shaped like `x`; laid out for the f16 matrix path when `compute_dtype` asks for it
+        and the consumer is a channels-last kernel."""
         from .. import hip
 
+        compute = self.compute_dtype if channels_last else "f32"
         w = self.weight
         key = (w.data_ptr(), w._version, tuple(w.shape), x.shape[2], x.shape[3], w.device)
-        if self._packed_key != key:
-            self._packed = hip.conv_pack_weights(w, x.shape[2], x.shape[3], self.stride)
-            self._packed_key = key
-        return self._packed
+        entry = self._packed.get(compute)
+        if entry is None or entry[0] != key:
+            entry = (key, hip.conv_pack_weights(w, x.shape[2], x.shape[3], self.stride, compute))
+            self._packed[compute] = entry
+        return entry[1]
 
     def _block_conv(self, x: torch.Tensor, out_affine=None) -> torch.Tensor:
         from .. import hip
@@ -161,12 +167,14 @@ class SIGEConv2d(nn.Conv2d, SIGEModule):
             return F.silu(out) if oact == "swish" else out
 
         plain = tuple(self.dilation) == (1, 1)
-        packed = self._packed_weights(x) if (self.groups == 1 and plain) else None
         spec = x.spec if isinstance(x, deferred.DeferredTiles) else None
-        if packed is not None and spec is not None:
+        mfma = self.groups == 1 and plain
+        if mfma and spec is not None:
             # the producer of the tiles has not run: fuse it into the conv's prologue
-            common = (packed, self.bias, self.out_channels, self.kernel_size, self.stride)
             cl = spec.get("cl", False) and self.out_channels % 4 == 0
+            packed = self._packed_weights(x, cl)
+        if mfma and spec is not None and packed is not None:
+            common = (packed, self.bias, self.out_channels, self.kernel_size, self.stride)
             if spec["kind"] == "gather":
                 if cl:
                     out = hip.gather_conv_cl(spec["x"], spec.get("x2"), spec["block"], spec["idx"], spec["scale"],
@@ -183,12 +191,16 @@ class SIGEConv2d(nn.Conv2d, SIGEModule):
             if out is not None:
                 return out  # (None: shape outside the fused kernel's limits -> two-kernel form below)
         x = deferred.resolve(x)
-        if packed is not None:
+        if mfma:
             if hip.is_cl(x) and x.shape[1] % 4 == 0 and self.out_channels % 4 == 0:
-                out = hip.block_conv_cl(x, packed, self.bias, self.out_channels, self.kernel_size, self.stride)
+                packed = self._packed_weights(x, True)
+                out = None if packed is None else hip.block_conv_cl(x, packed, self.bias, self.out_channels, self.kernel_size,
+                                                                    self.stride)
                 if out is not None:
                     return out
-            return hip.block_conv(x, packed, self.bias, self.out_channels, self.kernel_size, self.stride)
+            packed = self._packed_weights(x, False)
+            if packed is not None:
+                return hip.block_conv(x, packed, self.bias, self.out_channels, self.kernel_size, self.stride)
         return hip.block_conv_direct(x, self.weight, self.bias, self.stride, self.groups, self.dilation)
 
     def forward(self, x: torch.Tensor, out_affine=None) -> torch.Tensor:
@@ -269,6 +281,17 @@ class SIGEModel(nn.Module):
     def set_sparse_update(self, sparse_update: bool):
         for module in self._sige_modules():
             module.set_sparse_update(sparse_update)
+
+    def set_compute_dtype(self, dtype: str):
+        """MI355X-first option (not in the reference, which is fp32-only: sige/nn/base.py:15,55-63): "f16" runs every
+        tile conv (SIGEConv2d on channels-last tiles, and the dense layers routed through sige_amd.nn.dense.fused_conv2d)
+        with fp16 operands and fp32 accumulation on the fp16 matrix cores; activations and caches stay fp32.  "f32"
+        (default) = exact fp32 products."""
+        if dtype not in ("f32", "f16"):
+            raise ValueError("compute dtype must be 'f32' or 'f16'")
+        for module in self.modules():
+            if isinstance(module, nn.Conv2d):
+                module.compute_dtype = dtype
 
     def set_scatter_inplace(self, inplace: bool):
         """MI355X-first option (not in the reference): Scatter / ScatterWithBlockResidual modules whose

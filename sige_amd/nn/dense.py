@@ -28,14 +28,17 @@ _GEOMETRY = {
 }
 
 
-def _packed(conv: nn.Conv2d, block):
+def _packed(conv: nn.Conv2d, block, channels_last: bool = True):
     from .. import hip
 
     w = conv.weight
-    key = (w.data_ptr(), w._version, tuple(w.shape), block, w.device)
+    compute = getattr(conv, "compute_dtype", "f32") if channels_last else "f32"  # (SIGEModel.set_compute_dtype)
+    key = (w.data_ptr(), w._version, tuple(w.shape), block, w.device, compute)
     if getattr(conv, "_sige_packed_key", None) != key:
-        conv._sige_packed = hip.conv_pack_weights(w, block[0], block[1], conv.stride)
+        conv._sige_packed = hip.conv_pack_weights(w, block[0], block[1], conv.stride, compute)
         conv._sige_packed_key = key
+    if conv._sige_packed is None:
+        raise RuntimeError("fused_conv2d: no matrix-core kernel for this conv geometry")
     return conv._sige_packed
 
 
@@ -107,7 +110,7 @@ def _fused_conv2d(conv, x, scale, shift, activation_name, x2, residual, pad_bott
             if out is not None:
                 return out
         out = hip.gather_conv_nchw(x.contiguous(), None if x2 is None else x2.contiguous(), block, idx,
-                                    scale, shift, activation_name, _packed(conv, block), conv.bias,
+                                    scale, shift, activation_name, _packed(conv, block, False), conv.bias,
                                     conv.out_channels, conv.kernel_size, conv.stride, offset, (Ho, Wo),
                                     None if residual is None else residual.contiguous())
         return out if out_affine is None else (out, out_affine)

@@ -173,7 +173,7 @@ def _fused_conv_into(conv, tiles, out, g: Gather, residual=None, x1=None, table1
         return None
     if conv.out_channels % 4 or tuple(conv.stride) != tuple(g.model_stride):
         return None
-    packed = conv._packed_weights(tiles)
+    packed = conv._packed_weights(tiles, True)
     if packed is None:
         return None
     if spec["kind"] == "gather":

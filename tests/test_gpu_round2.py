@@ -170,32 +170,38 @@ def test_inplace_scatter_buffer_follows_the_cache(hip):
     imgs = [cl(torch.randn(1, 64, 64, 64, device=DEV)) for _ in range(3)]
     edit = lambda x: cl(x + torch.randn_like(x) * mask)  # noqa: E731
 
-    def sparse(inplace, orig, edited):
+    def sparse(inplace, edited):
         net.set_scatter_inplace(inplace)
-        net.set_mode("full")
-        net(orig)
         net.set_mode("sparse")
-        net.set_masks(masks)
         return net(edited).clone()
 
+    def diff(a, b):
+        return float((a - b).abs().max())
+
     with torch.no_grad():
-        for k in range(6):  # full(A) -> sparse -> full(B) -> sparse ... with the SAME masks: addresses get recycled
+        net.set_mode("full")
+        net(imgs[0])
+        net.set_masks(masks)  # ONCE: the masks (and their timestamp) never change below, only the caches do
+        for k in range(6):  # full(A) -> sparse -> full(B) -> sparse ...: cache addresses get recycled by the allocator
             orig = imgs[k % 3]
+            net.set_mode("full")
+            net(orig)
             e = edit(orig)
-            want = sparse(False, orig, e)
-            got = sparse(True, orig, e)
-            assert torch.equal(got, want), k
-        # in-place + the block-residual fallback branch (more shortcut tiles than main tiles cannot happen for masks
-        # derived from one mask; force the unfused path instead)
+            want = sparse(False, e)
+            got = sparse(True, e)
+            assert torch.equal(got, want), (k, diff(got, want))
+            assert torch.equal(sparse(True, e), want), k  # and again on the now existing buffer
+        # in-place + the unfused module chain (Gather and conv as two kernels)
         from sige_amd.nn import deferred
 
         deferred.FUSION = False
         try:
-            got = sparse(True, imgs[0], e)
-            want = sparse(False, imgs[0], e)
+            got = sparse(True, e)
+            want2 = sparse(False, e)
         finally:
             deferred.FUSION = True
-        assert torch.equal(got, want)
+        assert torch.equal(got, want2), diff(got, want2)
+        torch.testing.assert_close(want2, want, rtol=0, atol=1e-5)
 
 
 def test_sparse_update_with_inplace_buffers(hip):
@@ -250,3 +256,129 @@ def test_launch_counter(hip):
     n0 = hip.launch_count()
     hip.gather(x, 6, 6, idx)
     assert hip.launch_count() == n0 + 1
+
+
+# ---- f16 compute (BASELINE.json configs[4]): fp16 operands on the fp16 matrix cores, fp32 accumulation -------------
+F16_ATOL, F16_RTOL = 2e-2, 1e-2   # stated tolerance of the f16-compute path against the fp32 oracle
+
+
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("k,cin,cout,T,mt,nb", [(3, 128, 128, 124, 0, 0), (3, 256, 128, 40, 16, 1), (3, 64, 256, 7, 32, 1),
+                                                 (3, 192, 64, 33, 16, 2), (3, 128, 128, 70, 32, 2), (1, 256, 128, 56, 0, 0),
+                                                 (1, 128, 256, 9, 32, 1), (1, 384, 128, 30, 16, 2), (3, 36, 64, 5, 0, 0)])
+def test_f16_compute_block_conv_exact_products(hip, k, cin, cout, T, mt, nb):
+    """The f16-compute tile conv equals an fp64 conv of the fp16-ROUNDED operands to fp32 summation accuracy (products
+    of two fp16 values are exact in fp32), and the fp32 oracle within the stated f16 tolerance."""
+    torch.manual_seed(T + cin)
+    R = 6 if k == 3 else 4
+    x = _cl(torch.randn(T, cin, R, R, device=DEV))
+    w = torch.randn(cout, cin, k, k, device=DEV) / (k * cin ** 0.5)
+    b = torch.randn(cout, device=DEV)
+    packed = hip.conv_pack_weights(w, R, R, (1, 1), "f16")
+    assert packed.compute == "f16"
+    hip.conv_force_tile(mt, nb)
+    try:
+        got = hip.block_conv_cl(x, packed, b, cout, (k, k), (1, 1))
+    finally:
+        hip.conv_force_tile(0, 0)
+    assert got is not None and hip.is_cl(got)
+    xh, wh = x.half().double(), w.half().double()
+    want_h = torch.nn.functional.conv2d(xh, wh, b.double()).float()
+    torch.testing.assert_close(got, want_h, rtol=0, atol=2e-5)
+    want = oracle.block_conv(x.contiguous().cpu(), w.cpu(), b.cpu(), 1)
+    torch.testing.assert_close(got.cpu(), want, rtol=F16_RTOL, atol=F16_ATOL)
+
+
+def test_f16_compute_stride2_falls_back_to_fp32_packing(hip):
+    w = torch.randn(64, 64, 3, 3, device=DEV)
+    assert hip.conv_pack_weights(w, 5, 5, (2, 2), "f16").compute == "f32"
+
+
+@pytest.mark.parametrize("act", ["swish", "identity"])
+def test_f16_compute_fused_gather_and_scatter_gather(hip, act):
+    """gather -> conv and scatter_gather -> conv (-> scatter) with f16 compute against the same fused kernels in fp32."""
+    from sige_amd.utils import reduce_mask
+
+    torch.manual_seed(5)
+    C, Co, H = 128, 128, 64
+    mask = torch.zeros(H, H, dtype=torch.bool, device=DEV)
+    mask[20:41, 12:40] = True
+    mask[0, 0] = mask[63, 63] = True
+    idx = reduce_mask(mask, 6, 4, 1)
+    x, y = _cl(torch.randn(1, C, H, H, device=DEV)), _cl(torch.randn(1, C, H, H, device=DEV))
+    sc, sh = torch.randn(1, C, 1, 1, device=DEV) * 0.5 + 1, torch.randn(1, C, 1, 1, device=DEV) * 0.2
+    sc_, sh_ = (sc, sh) if act == "swish" else (None, None)
+    w = torch.randn(Co, C, 3, 3, device=DEV) / (3 * C ** 0.5)
+    b = torch.randn(Co, device=DEV)
+    p32, p16 = hip.conv_pack_weights(w, 6, 6, (1, 1)), hip.conv_pack_weights(w, 6, 6, (1, 1), "f16")
+    a32 = hip.gather_conv_cl(x, None, (6, 6), idx, sc_, sh_, act, p32, b, Co, (3, 3), (1, 1))
+    a16 = hip.gather_conv_cl(x, None, (6, 6), idx, sc_, sh_, act, p16, b, Co, (3, 3), (1, 1))
+    torch.testing.assert_close(a16, a32, rtol=F16_RTOL, atol=F16_ATOL)
+    assert (a16 - a32).abs().max() > 0  # really another arithmetic
+    # two-pointer input (fused torch.cat) + out_affine epilogue, written into a full tensor (a dense layer)
+    xa, xb = _cl(torch.randn(1, 64, 32, 32, device=DEV)), _cl(torch.randn(1, 64, 32, 32, device=DEV))
+    all_idx = hip.all_tiles(32, 32, (4, 4), (1, 1), (1, 1), DEV)
+    res = _cl(torch.randn(1, Co, 32, 32, device=DEV))
+    oa = (torch.randn(Co, device=DEV) * 0.3 + 1, torch.randn(Co, device=DEV) * 0.1, "swish")
+    kw = dict(full=dict(offset=(1, 1), out_res=(32, 32), residual=res), out_affine=oa)
+    d32 = hip.gather_conv_cl(xa, xb, (6, 6), all_idx, sc_, sh_, act, p32, b, Co, (3, 3), (1, 1), **kw)
+    d16 = hip.gather_conv_cl(xa, xb, (6, 6), all_idx, sc_, sh_, act, p16, b, Co, (3, 3), (1, 1), **kw)
+    torch.testing.assert_close(d16, d32, rtol=F16_RTOL, atol=F16_ATOL)
+    # scatter_gather -> conv, tiles and fused scatter
+    smap = hip.get_scatter_map(H, H, 6, 6, 3, 3, 1, 1, 1, 1, idx)
+    t4 = _cl(torch.randn(idx.shape[0], C, 4, 4, device=DEV))
+    s32 = hip.scatter_gather_conv_cl(t4, y, (6, 6), idx, smap, sc_, sh_, act, p32, b, Co, (3, 3), (1, 1))
+    s16 = hip.scatter_gather_conv_cl(t4, y, (6, 6), idx, smap, sc_, sh_, act, p16, b, Co, (3, 3), (1, 1))
+    torch.testing.assert_close(s16, s32, rtol=F16_RTOL, atol=F16_ATOL)
+    o32, o16 = y.clone(memory_format=torch.preserve_format), y.clone(memory_format=torch.preserve_format)
+    r = _cl(torch.randn(1, Co, H, H, device=DEV))
+    hip.scatter_gather_conv_scatter_cl(t4, y, (6, 6), idx, smap, sc_, sh_, act, p32, b, Co, (3, 3), (1, 1), o32, residual=r)
+    hip.scatter_gather_conv_scatter_cl(t4, y, (6, 6), idx, smap, sc_, sh_, act, p16, b, Co, (3, 3), (1, 1), o16, residual=r)
+    torch.testing.assert_close(o16, o32, rtol=F16_RTOL, atol=F16_ATOL)
+
+
+def test_f16_compute_ddpm_forward_vs_fp32_oracle(hip):
+    """BASELINE.json configs[4] at its own size: the DDPM-256 sparse forward (ch 128, channels-last, in-place buffers) with
+    f16-compute convs against the fp32 CPU oracle network; stated tolerance 2e-2 abs / 1e-2 rel."""
+    import bench
+    from sige_amd import runtime
+    from sige_amd.utils import dilate_mask, downsample_mask
+    from sige_amd.workloads.ddpm_unet import DDPMConfig, DDPMSparseUNet
+
+    torch.manual_seed(0)
+    model = DDPMSparseUNet(DDPMConfig()).eval()
+    x0, noise = bench.make_inputs()
+    mask = bench.edit_mask(0.05)
+    x1 = x0 + noise * mask
+    t = torch.zeros(1)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    oracle.set_num_threads(min(32, os.cpu_count() or 1))
+    runtime.register_backend("cpu", oracle)
+    try:
+        with torch.no_grad():
+            model.set_mode("full")
+            model(x0, t)
+            model.set_masks(downsample_mask(dilate_mask(mask, 5), 8))
+            model.set_mode("sparse")
+            sparse_c = model(x1, t)
+    finally:
+        runtime.unregister_backend("cpu")
+    model.clear_cache()
+    model = model.to(DEV).to(memory_format=torch.channels_last)
+    model.set_scatter_inplace(True)
+    cl = lambda a: a.to(DEV).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    with torch.no_grad():
+        model.set_mode("full")
+        model(cl(x0), t.to(DEV))
+        model.set_masks(downsample_mask(dilate_mask(mask.to(DEV), 5), 8))
+        model.set_mode("sparse")
+        f32 = model(cl(x1), t.to(DEV)).clone()
+        model.set_compute_dtype("f16")
+        f16 = model(cl(x1), t.to(DEV)).clone()
+        model.set_compute_dtype("f32")
+    torch.testing.assert_close(f32.cpu(), sparse_c, rtol=0, atol=util.CONV_ATOL)
+    torch.testing.assert_close(f16.cpu(), sparse_c, rtol=F16_RTOL, atol=F16_ATOL)
+    assert (f16 - f32).abs().max() > 1e-6
