@@ -192,6 +192,22 @@ int sige_hip_block_conv_direct_f32(const float *x, int T, int Cin, int R, int S,
                                    const float *w, const float *bias, int Cout, int kH, int kW,
                                    int strideH, int strideW, int dilationH, int dilationW, int groups,
                                    float *out, void *stream);
+/* ---- SPADE modulation of tiles (GauGAN; gaugan/models/sige_normalization.py:62-88) --------
+ * out[B*N,bH,bW,C] = leaky(normalized * (1 + gamma) + beta), channels-last, one pass:
+ *   normalized = scale*X + shift with X = x_full [B,H,W,C] at the tile's pixels (x_tiles == NULL:
+ *                Gather) or, through map_x, the conv tiles x_tiles [B*Nx,Rx,Sx,C] where one covers
+ *                the pixel and the cache x_full elsewhere (ScatterGather);
+ *   gamma|beta = gb_tiles [B*Ng,Rg,Sg,2C] / gb_full [B,H,W,2C] through map_g the same way.
+ * Pixels outside the image give 0 (as Gather / ScatterGather zero-fill both operands).  leaky != 0
+ * applies x > 0 ? x : slope*x.  Same fp32 operations, in the same order, as the module chain
+ * Gather | ScatterGather, ScatterGather, split, 1 + gamma, *, + beta, leaky_relu.            */
+int sige_hip_spade_modulate_nhwc_f32(
+        const float *x_full, const float *x_tiles, const int32_t *map_x, int Nx, int Rx, int Sx,
+        const float *scale, int scaleB, int scaleC, const float *shift, int shiftB, int shiftC,
+        const float *gb_tiles, const float *gb_full, const int32_t *map_g, int Ng, int Rg, int Sg,
+        int B, int C, int H, int W, int bH, int bW, const int32_t *active_indices, int N,
+        int leaky, float slope, float *out, void *stream);
+
 /* ---- f16 compute ("_f16c"): the same stacked-block convs on the fp16 matrix cores ---------
  * (v_mfma_f32_32x32x16_f16 / v_mfma_f32_16x16x32_f16, 16x the rate of the f32-input forms).
  * Tensors stay fp32 in HBM (x, y, residual, out, bias, scale / shift): the staging path

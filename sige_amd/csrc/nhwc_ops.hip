@@ -78,6 +78,68 @@ __global__ __launch_bounds__(kT) void scatter_gather_nhwc_kernel(const float *__
     }
 }
 
+// ---------------------------------------------------------- SPADE modulation ----
+// GauGAN's SPADE layer on tiles (gaugan/models/sige_normalization.py:62-88): out = normalized * (1 + gamma) + beta, where
+//   normalized = the conv's input tiles: Gather(x, scale, shift) or ScatterGather(conv tiles, cache, scale, shift) -- the
+//                param-free norm folded into the cached affine (sige_fused_spade_generator.py:151-167);
+//   gamma|beta = ScatterGather(mlp_gamma_beta's output tiles, its cache) re-tiled to the conv's input tiles (for the
+//                shortcut branch Scatter then Gather, which is the same lookup through the scatter map),
+// followed by the block's leaky ReLU (sige_fused_spade_generator.py:139,161,166).  The reference runs this as two
+// gather-type kernels, a split and four elementwise kernels over [N,2C,b,b]; here it is ONE pass that writes the conv's
+// input tile slab.  Same fp32 operations in the same order as that chain (scale, shift; 1 + gamma; product; + beta; leaky).
+struct SpadeArgs {
+    const float *x_full, *x_tiles;      // normalized source: full tensor (gather) or cache + conv tiles (scatter_gather)
+    const int32_t *map_x;
+    int Nx, Rx, Sx;
+    const float *scale, *shift;
+    int aff_sb;
+    const float *gb_tiles, *gb_full;    // gamma | beta on the channel axis (2C channels)
+    const int32_t *map_g;
+    int Ng, Rg, Sg;
+    const int32_t *idx;
+    int N, bH, bW, B, C, H, W;
+    float slope;
+    int leaky;
+    float *out;
+};
+
+__global__ __launch_bounds__(kT) void spade_modulate_nhwc_kernel(SpadeArgs a, long units) {
+    const int C4 = a.C / 4, RS = a.bH * a.bW, C2 = 2 * a.C;
+    for (long u = (long)blockIdx.x * kT + threadIdx.x; u < units; u += (long)gridDim.x * kT) {
+        const int c = (int)(u % C4) * 4;
+        const long tp = u / C4;
+        const int p = (int)(tp % RS);
+        const int t = (int)(tp / RS);
+        const int b = t / a.N, n = t - b * a.N;
+        const int h = a.idx[2 * n] + p / a.bW, w = a.idx[2 * n + 1] + p % a.bW;
+        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (h >= 0 && h < a.H && w >= 0 && w < a.W) {
+            const size_t pix = ((size_t)b * a.H + h) * a.W + w;
+            // everything this unit reads is addressed before the first value is used: the three loads go out together
+            const float *xs = a.x_full + pix * a.C + c;
+            if (a.x_tiles) {
+                const int32_t *m = a.map_x + 3 * ((size_t)h * a.W + w);
+                const int blk = m[0];
+                if (blk >= 0) xs = a.x_tiles + ((((size_t)b * a.Nx + blk) * a.Rx + m[1]) * a.Sx + m[2]) * a.C + c;
+            }
+            const int32_t *mg = a.map_g + 3 * ((size_t)h * a.W + w);
+            const int gblk = mg[0];
+            const float *gs = gblk >= 0 ? a.gb_tiles + ((((size_t)b * a.Ng + gblk) * a.Rg + mg[1]) * a.Sg + mg[2]) * C2 + c
+                                        : a.gb_full + pix * C2 + c;
+            const float4 xv = ld4(xs), gamma = ld4(gs), beta = ld4(gs + a.C);
+            const float4 nv = affine_act4<SIGE_HIP_ACT_IDENTITY>(xv, a.scale, a.shift, b * a.aff_sb, c);
+            float4 g1 = make_float4(1.0f + gamma.x, 1.0f + gamma.y, 1.0f + gamma.z, 1.0f + gamma.w);
+            z = make_float4(nv.x * g1.x, nv.y * g1.y, nv.z * g1.z, nv.w * g1.w);
+            z = make_float4(z.x + beta.x, z.y + beta.y, z.z + beta.z, z.w + beta.w);
+            if (a.leaky) {
+                z.x = z.x > 0.f ? z.x : z.x * a.slope; z.y = z.y > 0.f ? z.y : z.y * a.slope;
+                z.z = z.z > 0.f ? z.z : z.z * a.slope; z.w = z.w > 0.f ? z.w : z.w * a.slope;
+            }
+        }
+        st4(a.out + (size_t)u * 4, z);
+    }
+}
+
 // ------------------------------------------------------------------ scatter ----
 struct ScatterNhwcArgs {
     const float *x0, *y0, *x1, *y1, *res;  // main tiles, cached tensor, shortcut tiles, cached shortcut tensor, residual
@@ -367,6 +429,31 @@ extern "C" int sige_hip_scatter_gather_nhwc_f32(const float *x, const float *y, 
         scatter_gather_nhwc_kernel<SIGE_HIP_ACT_SWISH><<<grid_for(units), kT, 0, st>>>(x, y, B, C, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, shift, aff_sb, out, units);
     else
         scatter_gather_nhwc_kernel<SIGE_HIP_ACT_IDENTITY><<<grid_for(units), kT, 0, st>>>(x, y, B, C, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, shift, aff_sb, out, units);
+    return launch_status();
+}
+
+extern "C" int sige_hip_spade_modulate_nhwc_f32(
+        const float *x_full, const float *x_tiles, const int32_t *map_x, int Nx, int Rx, int Sx,
+        const float *scale, int scaleB, int scaleC, const float *shift, int shiftB, int shiftC,
+        const float *gb_tiles, const float *gb_full, const int32_t *map_g, int Ng, int Rg, int Sg,
+        int B, int C, int H, int W, int bH, int bW, const int32_t *active_indices, int N,
+        int leaky, float slope, float *out, void *stream) {
+    if (B < 0 || C <= 0 || H <= 0 || W <= 0 || bH <= 0 || bW <= 0 || N < 0 || Ng < 0 || Nx < 0) return SIGE_HIP_EINVAL;
+    if ((long)B * N == 0) return SIGE_HIP_OK;
+    if (!x_full || !gb_full || !map_g || !active_indices || !out) return SIGE_HIP_EINVAL;
+    if ((Ng > 0 && (!gb_tiles || Rg <= 0 || Sg <= 0)) || (x_tiles && (!map_x || Rx <= 0 || Sx <= 0))) return SIGE_HIP_EINVAL;
+    int aff_sb = 0;
+    if (C % 4 || !al16(x_full) || !al16(x_tiles) || !al16(gb_tiles) || !al16(gb_full) || !al16(out) ||
+        !affine_shape(scale, scaleB, scaleC, shift, shiftB, shiftC, B, C, &aff_sb))
+        return SIGE_HIP_EUNSUPPORTED;
+    SpadeArgs a{};
+    a.x_full = x_full; a.x_tiles = x_tiles; a.map_x = map_x; a.Nx = Nx; a.Rx = Rx; a.Sx = Sx;
+    a.scale = scale; a.shift = shift; a.aff_sb = aff_sb;
+    a.gb_tiles = gb_tiles; a.gb_full = gb_full; a.map_g = map_g; a.Ng = Ng; a.Rg = Rg; a.Sg = Sg;
+    a.idx = active_indices; a.N = N; a.bH = bH; a.bW = bW; a.B = B; a.C = C; a.H = H; a.W = W;
+    a.slope = slope; a.leaky = leaky; a.out = out;
+    const long units = (long)B * N * bH * bW * (C / 4);
+    spade_modulate_nhwc_kernel<<<grid_for(units), kT, 0, as_stream(stream)>>>(a, units);
     return launch_status();
 }
 

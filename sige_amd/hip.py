@@ -100,6 +100,9 @@ _SIGNATURES = {
         _c_int, [_c_vp] + [_c_int] * 6 + [_c_vp, _c_int] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]),
     "sige_hip_scatter_gather_nhwc_f32": (
         _c_int, [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]),
+    "sige_hip_spade_modulate_nhwc_f32": (
+        _c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int] + [_c_vp, _c_int, _c_int] * 2 + [_c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int]
+        + [_c_int] * 6 + [_c_vp, _c_int, _c_int, ctypes.c_float, _c_vp, _c_vp]),
     "sige_hip_scatter_nhwc_f32": (
         _c_int, [_c_vp, _c_vp] + [_c_int] * 10 + [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_int, _c_vp, _c_vp]),
     "sige_hip_scatter_with_block_residual_nhwc_f32": (
@@ -900,6 +903,35 @@ def scatter_gather_cl(x, y, bSizeH, bSizeW, activeIndices, scatterMap, scale=Non
     _check(lib().sige_hip_scatter_gather_nhwc_f32(x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3],
                                                   bSizeH, bSizeW, idx.data_ptr(), N, smap.data_ptr(), *sa, *ta,
                                                   _act(activationName), out.data_ptr(), _stream(y)), "scatter_gather_cl")
+    return out
+
+
+def spade_modulate_cl(x_full, x_tiles, map_x, scale, shift, gb_tiles, gb_full, map_g, activeIndices, block: Tuple[int, int],
+                      slope: Optional[float] = None):
+    """SPADE modulation of the tiles at `activeIndices` in one pass (include/sige_hip.h): leaky(n * (1 + gamma) + beta) with
+    n = scale * X + shift, X gathered from `x_full` (x_tiles None) or scatter-gathered from (x_tiles, x_full) through map_x;
+    gamma | beta scatter-gathered from (gb_tiles, gb_full) through map_g.  slope None = no activation.  -> [B*N,C,bH,bW]."""
+    x_full = _req_cl(x_full, "x_full")
+    gb_full = _req_cl(gb_full, "gb_full")
+    gb_tiles = _req_cl(gb_tiles, "gb_tiles")
+    idx = _req(activeIndices, torch.int32, "activeIndices", 2)
+    map_g = _req(map_g, torch.int32, "map_g", 3)
+    B, C, H, W = x_full.shape
+    if gb_full.shape[1] != 2 * C or gb_tiles.shape[1] != 2 * C or tuple(gb_full.shape[2:]) != (H, W):
+        raise RuntimeError("spade_modulate_cl: gamma|beta must have 2*C channels at the resolution of x")
+    xt = (None, None, 0, 0, 0)
+    if x_tiles is not None:
+        x_tiles = _req_cl(x_tiles, "x_tiles")
+        map_x = _req(map_x, torch.int32, "map_x", 3)
+        xt = (x_tiles.data_ptr(), map_x.data_ptr(), x_tiles.shape[0] // B, x_tiles.shape[2], x_tiles.shape[3])
+    (sa, s_keep), (ta, t_keep) = _cvec(scale, "scale"), _cvec(shift, "shift")
+    N = idx.shape[0]
+    out = _empty_cl((B * N, C, block[0], block[1]), x_full.device)
+    _check(lib().sige_hip_spade_modulate_nhwc_f32(
+        x_full.data_ptr(), xt[0], xt[1], xt[2], xt[3], xt[4], *sa, *ta,
+        gb_tiles.data_ptr(), gb_full.data_ptr(), map_g.data_ptr(), gb_tiles.shape[0] // B, gb_tiles.shape[2], gb_tiles.shape[3],
+        B, C, H, W, block[0], block[1], idx.data_ptr(), N, int(slope is not None), float(slope or 0.0), out.data_ptr(),
+        _stream(x_full)), "spade_modulate_cl")
     return out
 
 

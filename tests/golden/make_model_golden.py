@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/models.npz from the REAL reference's model classes (build container only: /root/reference).
+
+    python tests/golden/make_model_golden.py
+
+BASELINE.json configs[2] (GauGAN SPADE generator, 256x512, ~5 % edit) and configs[3] (Stable-Diffusion U-Net block stack,
+CFG batch 2, 15 % edit) run on the reference's own sige.nn + its compiled sige/cpu backend (oracle/_ref), with weights drawn
+by tests/golden/model_init.py::init_by_name (name-keyed: the GPU tests re-create exactly these weights in sige_amd's workload
+models).  Stored: every 4th pixel of the full and sparse outputs + sums over all values.  /root/reference does not exist on
+the GPU box, hence committed fixtures.
+"""
+import argparse
+import os
+import sys
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("SIGE_REFERENCE", "/root/reference")
+sys.path = [p for p in sys.path if os.path.abspath(p or ".") != REPO]
+sys.path.insert(0, REF)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+sys.path.append(REPO)
+from oracle import build_ref  # noqa: E402
+from tests.golden.model_init import gaugan_labels, init_by_name, summarize  # noqa: E402
+
+build_ref.build(REF, verbose=False)
+ref_cpu = build_ref.load()
+import sige  # noqa: E402
+
+assert os.path.abspath(sige.__file__).startswith(REF), sige.__file__
+sys.modules["sige.cpu"] = ref_cpu
+sige.cpu = ref_cpu
+from sige.utils import compute_difference_mask, dilate_mask, downsample_mask  # noqa: E402
+
+torch.set_num_threads(8)
+out = {}
+
+
+def put(prefix, t):
+    s = summarize(t)
+    out[prefix + "/sub"] = s["sub"]
+    out[prefix + "/sums"] = np.array([s["sum"], s["abs_sum"]], dtype=np.float64)
+    out[prefix + "/shape"] = np.array(s["shape"], dtype=np.int64)
+
+
+def gaugan():
+    sys.path.insert(1, os.path.join(REF, "gaugan"))
+    from models.spade_generators.sige_fused_spade_generator import SIGEFusedSPADEGenerator
+
+    opt = argparse.Namespace(ngf=64, semantic_nc=36, norm_G="spadesyncbatch3x3", num_upsampling_layers="more",
+                             main_block_size=6, shortcut_block_size=4, num_sparse_layers=5, crop_size=512, aspect_ratio=2,
+                             separable_conv_norm="instance")
+    model = SIGEFusedSPADEGenerator(opt).eval()
+    init_by_name(model)
+    x0, x1 = gaugan_labels()
+    with torch.no_grad():
+        model.set_mode("full")
+        full = model(x0)
+        diff = compute_difference_mask(x0, x1)
+        masks = downsample_mask(dilate_mask(diff, 1), (model.sh, model.sw), dilation=2)  # gaugan/test.py recipe
+        model.set_masks(masks)
+        model.set_mode("sparse")
+        sparse = model(x1)
+        model.set_mode("full")
+        dense_edit = model(x1)
+    put("gaugan/full", full)
+    put("gaugan/sparse", sparse)
+    out["gaugan/edit_ratio"] = np.array([float(diff.float().mean())])
+    print("gaugan: edit ratio %.3f, |sparse - full| max %.3f, |sparse - dense(edited)| max %.3f"
+          % (float(diff.float().mean()), float((sparse - full).abs().max()), float((sparse - dense_edit).abs().max())))
+    sys.path.pop(1)
+
+
+if __name__ == "__main__":
+    import warnings
+
+    warnings.simplefilter("ignore")
+    gaugan()
+    path = os.path.join(HERE, "models.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")

@@ -5,6 +5,8 @@ software stacks and dump the outputs (helper of tests/test_reference_models.py; 
   --stack reference   the reference's sige.nn + its compiled sige/cpu backend
   --stack ours        the same model file, but `sige` is sige_amd (compat.install) with the CPU oracle as backend
                       (--deferred: Gather / ScatterGather return DeferredTiles as they do on the GPU)
+  --stack ours-workload   sige_amd's own workload model (sige_amd/workloads/gaugan_spade.py, sd_unet.py) loading the
+                      reference model's state dict
 
   --model gaugan      gaugan/models/spade_generators/sige_fused_spade_generator.py   (BASELINE configs[2])
   --model sd          stable-diffusion/ldm/modules/diffusionmodules/sige_openaimodel.py (BASELINE configs[3])
@@ -23,7 +25,7 @@ REF = os.environ.get("SIGE_REFERENCE", "/root/reference")
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--stack", required=True, choices=["reference", "ours"])
+    ap.add_argument("--stack", required=True, choices=["reference", "ours", "ours-workload"])
     ap.add_argument("--model", required=True, choices=["gaugan", "sd"])
     ap.add_argument("--state", required=True)
     ap.add_argument("--out", required=True)
@@ -67,12 +69,17 @@ def main():
     warnings.simplefilter("ignore")
     rs = np.random.RandomState(3)
     if a.model == "gaugan":
-        from models.spade_generators.sige_fused_spade_generator import SIGEFusedSPADEGenerator
+        if a.stack == "ours-workload":
+            from sige_amd.workloads.gaugan_spade import SPADEConfig, SpadeGenerator
 
-        opt = argparse.Namespace(ngf=16, semantic_nc=36, norm_G="spadesyncbatch3x3", num_upsampling_layers="more",
-                                 main_block_size=6, shortcut_block_size=4, num_sparse_layers=5, crop_size=256,
-                                 aspect_ratio=2, separable_conv_norm="instance")
-        model = SIGEFusedSPADEGenerator(opt).eval()
+            model = SpadeGenerator(SPADEConfig(ngf=16, crop_size=256)).eval()
+        else:
+            from models.spade_generators.sige_fused_spade_generator import SIGEFusedSPADEGenerator
+
+            opt = argparse.Namespace(ngf=16, semantic_nc=36, norm_G="spadesyncbatch3x3", num_upsampling_layers="more",
+                                     main_block_size=6, shortcut_block_size=4, num_sparse_layers=5, crop_size=256,
+                                     aspect_ratio=2, separable_conv_norm="instance")
+            model = SIGEFusedSPADEGenerator(opt).eval()
         H, W = 128, 256
         lab0 = rs.randint(0, 36, size=(H, W))
         lab1 = lab0.copy()
@@ -113,6 +120,13 @@ def main():
         run = lambda x: model(x, ts, context=ctx)  # noqa: E731
 
     if a.stack == "reference":
+        # BatchNorm running statistics away from (0, 1): the cached affine then really matters
+        g = torch.Generator().manual_seed(7)
+        for name, buf in model.named_buffers():
+            if name.endswith("running_mean"):
+                buf.copy_(torch.randn(buf.shape, generator=g) * 0.3)
+            elif name.endswith("running_var"):
+                buf.copy_(torch.rand(buf.shape, generator=g) + 0.5)
         torch.save(model.state_dict(), a.state)
     else:
         res = model.load_state_dict(torch.load(a.state), strict=True)

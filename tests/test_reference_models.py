@@ -78,3 +78,14 @@ def test_unchanged_gaugan_and_sd_models_run_on_sige_amd(tmp_path, model):
         ours = _run_model("ours", model, state, str(tmp_path / "ours.npz"), extra)
         np.testing.assert_allclose(ours["full"], ref["full"], rtol=0, atol=1e-5)
         np.testing.assert_allclose(ours["sparse"], ref["sparse"], rtol=0, atol=1e-4)
+
+
+def test_gaugan_workload_equals_reference_model(tmp_path):
+    """sige_amd/workloads/gaugan_spade.py loads the reference generator's state dict and reproduces its full and sparse
+    outputs (module chain; and with deferred tiles, the form the GPU runs)."""
+    state = str(tmp_path / "state.pt")
+    ref = _run_model("reference", "gaugan", state, str(tmp_path / "ref.npz"))
+    for extra in ((), ("--deferred",)):
+        ours = _run_model("ours-workload", "gaugan", state, str(tmp_path / "ours.npz"), extra)
+        np.testing.assert_allclose(ours["full"], ref["full"], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(ours["sparse"], ref["sparse"], rtol=0, atol=1e-4)
