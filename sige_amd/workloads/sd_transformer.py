@@ -1,0 +1,200 @@
+"""Stable-Diffusion spatial transformer with sparse queries (BASELINE.json configs[3]) on sige_amd.nn.
+
+The block of stable-diffusion/ldm/modules/sige_attention.py (`SIGESpatialTransformer`): GroupNorm -> 1x1 proj_in ->
+[self-attention, cross-attention on the text context, GEGLU feed-forward] x depth -> 1x1 proj_out + residual, where in sparse
+mode only the tokens of the ACTIVE 4x4 tiles are queries, while keys / values of the self-attention cover every token of the
+(scattered) full feature map.  Parameter names follow the reference (`norm`, `proj_in`, `transformer_blocks.0.attn1.to_q`,
+`...ff.net.0.proj`, `...ff.net.2`, `proj_out`), so its state dict loads here (tests/test_reference_models.py).
+
+Tile <-> token glue.  The reference keeps everything NCHW and pays, per transformer, a full-tensor Scatter (clone + write)
+plus `b c h w -> b (h w) c` permute copies of the full tensor and of the tiles in both directions
+(sige_attention.py:151-176).  Channels-last makes all of that free: a channels-last [B,C,H,W] tensor IS the token matrix
+[B,HW,C], and channels-last tiles [B*N,C,4,4] ARE the query tokens [B,N*16,C] -- both directions are views.  The Scatter
+writes the tiles into a persistent full-size buffer (in-place form), and proj_in / proj_out are the fused gather -> conv and
+conv -> scatter kernels.
+
+Keys / values of the self-attention (MI355X-first option `sparse_kv`, same values): LayerNorm and the K / V projections are
+per-token maps, and the full feature map differs from the original image's only on the active tiles.  So the full pass caches
+K and V of every token, and a sparse pass projects ONLY the active tokens and scatters those rows into a persistent copy of
+the cached K / V (two Scatter launches per block) instead of re-projecting all HW tokens (sige_attention.py:78, attention.py:
+78-80).  The cross-attention's K / V depend on the text only and are cached as in the reference (sige_attention.py:35-42).
+"""
+from typing import Optional
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from ..nn import Gather, Scatter, SIGEConv2d, SIGEModule
+
+
+def _heads(t: torch.Tensor, h: int) -> torch.Tensor:
+    b, n, c = t.shape
+    return t.reshape(b, n, h, c // h).permute(0, 2, 1, 3).reshape(b * h, n, c // h)
+
+
+def _merge(t: torch.Tensor, h: int) -> torch.Tensor:
+    bh, n, d = t.shape
+    return t.reshape(bh // h, h, n, d).permute(0, 2, 1, 3).reshape(bh // h, n, h * d)
+
+
+class Attention(SIGEModule):
+    """softmax(q k^T / sqrt(d)) v with separate bias-free q / k / v projections and an output projection.
+    `cache_context=True`: the keys / values of a fixed context (the text embedding) are computed in full mode only."""
+
+    def __init__(self, query_dim: int, context_dim: Optional[int], heads: int, dim_head: int, cache_context: bool = False):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads, self.scale = heads, dim_head ** -0.5
+        self.to_q = nn.Linear(query_dim, inner, bias=False)
+        self.to_k = nn.Linear(context_dim or query_dim, inner, bias=False)
+        self.to_v = nn.Linear(context_dim or query_dim, inner, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner, query_dim), nn.Dropout(0.0))
+        self.cache_context = cache_context
+        self.cached_k = self.cached_v = None
+
+    def attend(self, q, k, v):
+        q, k, v = _heads(q, self.heads), _heads(k, self.heads), _heads(v, self.heads)
+        sim = torch.bmm(q, k.transpose(1, 2)) * self.scale
+        return self.to_out(_merge(torch.bmm(sim.softmax(dim=-1), v), self.heads))
+
+    def forward(self, x, context=None):
+        context = x if context is None else context
+        if self.cache_context and self.mode != "full":
+            k, v = self.cached_k, self.cached_v
+        else:
+            k, v = self.to_k(context), self.to_v(context)
+            if self.cache_context:
+                self.cached_k, self.cached_v = k, v
+        return self.attend(self.to_q(x), k, v)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+    def forward(self, x):
+        a, gate = self.proj(x).chunk(2, dim=-1)
+        return a * F.gelu(gate)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        self.net = nn.Sequential(GEGLU(dim, dim * mult), nn.Dropout(0.0), nn.Linear(dim * mult, dim))
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class TransformerBlock(SIGEModule):
+    def __init__(self, dim, heads, dim_head, context_dim):
+        super().__init__()
+        self.attn1 = Attention(dim, None, heads, dim_head)
+        self.ff = FeedForward(dim)
+        self.attn2 = Attention(dim, context_dim, heads, dim_head, cache_context=True)
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(dim), nn.LayerNorm(dim), nn.LayerNorm(dim)
+
+    def forward(self, x, full_x=None, context=None, kv_scatter=None):
+        """x: query tokens [B,n,C]; full_x: all tokens [B,HW,C] (None: x itself); kv_scatter: (scatter_k, scatter_v, hw)
+        -- Scatter modules of the enclosing transformer for the sparse K / V refresh, or None for the reference's form."""
+        a1 = self.attn1
+        xn = self.norm1(x)
+        if kv_scatter is not None and self.mode == "full":
+            ctx = xn if full_x is None else self.norm1(full_x)
+            k, v = a1.to_k(ctx), a1.to_v(ctx)
+            sk, sv, (hh, ww) = kv_scatter
+            as_map = lambda t: t.reshape(t.shape[0], hh, ww, t.shape[2]).permute(0, 3, 1, 2)  # noqa: E731  [B,C,H,W] channels-last view
+            sk(as_map(k)), sv(as_map(v))  # full mode: the Scatter modules remember K / V as their cached tensors
+            x = a1.attend(a1.to_q(xn), k, v) + x
+        elif kv_scatter is not None and self.mode == "sparse":
+            sk, sv, (hh, ww) = kv_scatter
+            b, n, c = xn.shape
+            as_tiles = lambda t: t.reshape(-1, 4, 4, t.shape[2]).permute(0, 3, 1, 2)  # noqa: E731  tokens -> [B*N,C,4,4] channels-last view
+            k = sk(as_tiles(a1.to_k(xn)))  # rows of the active tokens over the cached K of the original image
+            v = sv(as_tiles(a1.to_v(xn)))
+            as_tokens = lambda t: t.permute(0, 2, 3, 1).reshape(t.shape[0], hh * ww, t.shape[1])  # noqa: E731
+            x = a1.attend(a1.to_q(xn), as_tokens(k), as_tokens(v)) + x
+        else:
+            x = a1(xn, context=None if full_x is None else self.norm1(full_x)) + x
+        x = self.attn2(self.norm2(x), context=context) + x
+        return self.ff(self.norm3(x)) + x
+
+
+def group_norm_affine(x: torch.Tensor, norm: nn.GroupNorm):
+    """(normalised x, scale, shift) with per-sample per-channel scale / shift [B,C,1,1]: GroupNorm(x) == x*scale + shift
+    (the contract of the reference's my_group_norm, stable-diffusion/ldm/modules/diffusionmodules/sige_model.py:12-33)."""
+    b, c, h, w = x.shape
+    g = norm.num_groups
+    xg = x.reshape(b, g, -1)
+    var, mean = torch.var_mean(xg, dim=2, unbiased=False, keepdim=True)
+    std = torch.sqrt(var + norm.eps)
+    y = ((xg - mean) / std).reshape(b, c, h, w)
+    scale = (1 / std).reshape(b, g, 1, 1).repeat_interleave(c // g, dim=1)
+    shift = (-mean / std).reshape(b, g, 1, 1).repeat_interleave(c // g, dim=1)
+    if norm.affine:
+        wt, bs = norm.weight.view(1, -1, 1, 1), norm.bias.view(1, -1, 1, 1)
+        y = y * wt + bs
+        scale = scale * wt
+        shift = shift * wt + bs
+    return y, scale, shift
+
+
+class SpatialTransformer(SIGEModule):
+    def __init__(self, in_channels: int, n_heads: int, d_head: int, depth: int = 1, context_dim: Optional[int] = None,
+                 block_size: Optional[int] = 4, sparse_kv: bool = True):
+        super().__init__()
+        inner = n_heads * d_head
+        self.in_channels, self.inner = in_channels, inner
+        self.tiled = block_size is not None
+        self.sparse_kv = sparse_kv and self.tiled
+        Conv = SIGEConv2d if self.tiled else nn.Conv2d
+        self.norm = nn.GroupNorm(32, in_channels, eps=1e-6, affine=True)
+        self.proj_in = Conv(in_channels, inner, 1)
+        self.transformer_blocks = nn.ModuleList([TransformerBlock(inner, n_heads, d_head, context_dim) for _ in range(depth)])
+        self.proj_out = Conv(inner, in_channels, 1)
+        if self.tiled:
+            self.gather = Gather(self.proj_in, block_size)
+            self.scatter1 = Scatter(self.gather)
+            self.scatter2 = Scatter(self.gather)
+            if self.sparse_kv:
+                # K / V of the self-attention live on the token grid: the same 4x4 tiles, one Scatter pair per block
+                self.kv_scatters = nn.ModuleList([nn.ModuleList([Scatter(self.gather), Scatter(self.gather)]) for _ in range(depth)])
+        self.scale = self.shift = None
+
+    def forward(self, x: torch.Tensor, context=None) -> torch.Tensor:
+        b, c, h, w = x.shape
+        x_in = x
+        if self.mode == "full":
+            if self.tiled:
+                x = self.gather(x)
+            x, self.scale, self.shift = group_norm_affine(x, self.norm)
+        elif self.mode in ("sparse", "profile"):
+            x = self.gather(x, self.scale, self.shift) if self.tiled else x * self.scale + self.shift
+        else:
+            raise NotImplementedError("Unknown mode [%s]!!!" % self.mode)
+        x = self.proj_in(x)
+
+        def tokens(t):  # [B,C,H,W] -> [B,HW,C]; a view for channels-last tensors
+            return t.permute(0, 2, 3, 1).reshape(t.shape[0], t.shape[2] * t.shape[3], t.shape[1])
+
+        if self.tiled:
+            full_x = tokens(self.scatter1(x))
+            if self.mode == "full":
+                q = full_x
+            else:  # tiles [B*N,C,4,4] -> [B, N*16, C]
+                q = x.permute(0, 2, 3, 1).reshape(b, -1, x.shape[1])
+        else:
+            full_x, q = None, tokens(x)
+        for i, blk in enumerate(self.transformer_blocks):
+            kv = (self.kv_scatters[i][0], self.kv_scatters[i][1], (h, w)) if (self.sparse_kv and self.mode != "profile") else None
+            q = blk(q, full_x=full_x, context=context, kv_scatter=kv)
+        if self.tiled and self.mode != "full":
+            bs = self.gather.block_size
+            x = q.reshape(-1, bs[0], bs[1], q.shape[-1]).permute(0, 3, 1, 2)  # tokens -> tiles (channels-last view)
+        else:
+            x = q.reshape(b, h, w, q.shape[-1]).permute(0, 3, 1, 2)
+        if self.tiled:
+            return self.scatter2.forward_fused(self.proj_out, x, x_in) if self.mode == "sparse" else self.scatter2(self.proj_out(x), x_in)
+        return self.proj_out(x) + x_in

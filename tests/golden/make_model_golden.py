@@ -25,7 +25,7 @@ import torch  # noqa: E402
 
 sys.path.append(REPO)
 from oracle import build_ref  # noqa: E402
-from tests.golden.model_init import gaugan_labels, init_by_name, summarize  # noqa: E402
+from tests.golden.model_init import gaugan_labels, init_by_name, sd_transformer_inputs, summarize  # noqa: E402
 
 build_ref.build(REF, verbose=False)
 ref_cpu = build_ref.load()
@@ -40,8 +40,9 @@ torch.set_num_threads(8)
 out = {}
 
 
-def put(prefix, t):
-    s = summarize(t)
+def put(prefix, t, cstep=1):
+    s = summarize(t, cstep=cstep)
+    out[prefix + "/cstep"] = np.array([cstep], dtype=np.int64)
     out[prefix + "/sub"] = s["sub"]
     out[prefix + "/sums"] = np.array([s["sum"], s["abs_sum"]], dtype=np.float64)
     out[prefix + "/shape"] = np.array(s["shape"], dtype=np.int64)
@@ -75,11 +76,48 @@ def gaugan():
     sys.path.pop(1)
 
 
+def sd_transformer():
+    """stable-diffusion/ldm/modules/sige_attention.py::SIGESpatialTransformer at the SD v1 level-1 shape (320 channels, 8 heads,
+    context 768), 64 x 64 latent, CFG batch 2 with per-sample cached affine, 15 % edit (inpainting_runner.py:50-54 masks)."""
+    sys.path.insert(1, os.path.join(REF, "stable-diffusion"))
+    for name in ("omegaconf", "omegaconf.listconfig"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    from ldm.modules.sige_attention import SIGESpatialTransformer
+    from sige.nn import SIGEModel
+
+    class Wrap(SIGEModel):
+        def __init__(self, m):
+            super().__init__()
+            self.m = m
+
+        def forward(self, x, **kw):
+            return self.m(x, **kw)
+
+    model = Wrap(SIGESpatialTransformer(320, 8, 40, depth=1, context_dim=768, use_checkpoint=False, block_size=4)).eval()
+    init_by_name(model)
+    x0, noise, ctx, mask512 = sd_transformer_inputs()
+    masks = downsample_mask(mask512, min_res=8, dilation=1)
+    m64 = masks[(64, 64)]
+    x1 = x0 + noise * m64
+    with torch.no_grad():
+        model.set_mode("full")
+        full = model(x0, context=ctx)
+        model.set_masks(masks)
+        model.set_mode("sparse")
+        sparse = model(x1, context=ctx)
+    put("sdt/full", full, cstep=5)
+    put("sdt/sparse", sparse, cstep=5)
+    out["sdt/active_ratio"] = np.array([float(m64.float().mean())])
+    print("sd transformer: active ratio %.3f at 64x64, |sparse - full| max %.3f" % (float(m64.float().mean()), float((sparse - full).abs().max())))
+    sys.path.pop(1)
+
+
 if __name__ == "__main__":
     import warnings
 
     warnings.simplefilter("ignore")
     gaugan()
+    sd_transformer()
     path = os.path.join(HERE, "models.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -37,8 +37,23 @@ def gaugan_labels(H=256, W=512, nc=36, seed=3):
     return onehot(lab0), onehot(lab1)
 
 
-def summarize(t: torch.Tensor, step: int = 4):
-    """What a fixture keeps of a model output: every `step`-th pixel, plus sums that depend on every value."""
+def summarize(t: torch.Tensor, step: int = 4, cstep: int = 1):
+    """What a fixture keeps of a model output: every `step`-th pixel of every `cstep`-th channel, plus sums that depend on
+    every value."""
     t = t.detach().float().cpu()
-    return {"sub": t[..., ::step, ::step].contiguous().numpy(), "sum": float(t.double().sum()),
+    return {"sub": t[:, ::cstep, ::step, ::step].contiguous().numpy(), "sum": float(t.double().sum()),
             "abs_sum": float(t.double().abs().sum()), "shape": list(t.shape)}
+
+
+def sd_transformer_inputs(C=320, H=64, W=64, B=2, ctx_dim=768, seed=5):
+    """(original, edited, context, mask512) of the SD spatial-transformer fixture: CFG batch 2, a 15 % square edit of the
+    512 x 512 image seen at the 64 x 64 latent resolution."""
+    import numpy as np
+
+    rs = np.random.RandomState(seed)
+    x0 = torch.from_numpy(rs.standard_normal((B, C, H, W)).astype(np.float32))
+    noise = torch.from_numpy(rs.standard_normal((B, C, H, W)).astype(np.float32))
+    ctx = torch.from_numpy(rs.standard_normal((B, 77, ctx_dim)).astype(np.float32))
+    mask512 = torch.zeros(512, 512, dtype=torch.bool)
+    mask512[150:348, 120:318] = True  # 198^2 / 512^2 = 15 %
+    return x0, noise, ctx, mask512

@@ -26,7 +26,7 @@ REF = os.environ.get("SIGE_REFERENCE", "/root/reference")
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--stack", required=True, choices=["reference", "ours", "ours-workload"])
-    ap.add_argument("--model", required=True, choices=["gaugan", "sd"])
+    ap.add_argument("--model", required=True, choices=["gaugan", "sd", "sdt"])
     ap.add_argument("--state", required=True)
     ap.add_argument("--out", required=True)
     ap.add_argument("--deferred", action="store_true")
@@ -36,6 +36,11 @@ def main():
     if a.stack == "reference":
         sys.path.insert(0, REF)
     sys.path.insert(1, os.path.join(REF, "gaugan" if a.model == "gaugan" else "stable-diffusion"))
+    if a.model == "sdt" and a.stack != "ours-workload":
+        import types as _t
+
+        for name in ("omegaconf", "omegaconf.listconfig"):  # (imported by the package, unused by this module)
+            sys.modules.setdefault(name, _t.ModuleType(name))
     sys.path.append(REPO)
 
     import torch
@@ -89,6 +94,38 @@ def main():
         diff = compute_difference_mask(x0, x1)
         masks = downsample_mask(dilate_mask(diff, 1), (model.sh, model.sw), dilation=2)
         run = lambda x: model(x)  # noqa: E731
+    elif a.model == "sdt":
+        # one sparse-query spatial transformer (SD v1 level-1 shape, scaled down), CFG batch 2
+        if a.stack == "ours-workload":
+            from sige_amd.workloads.sd_transformer import SpatialTransformer
+
+            model = SpatialTransformer(64, 4, 16, depth=1, context_dim=96, block_size=4).eval()
+        else:
+            from ldm.modules.sige_attention import SIGESpatialTransformer
+
+            model = SIGESpatialTransformer(64, 4, 16, depth=1, context_dim=96, use_checkpoint=False, block_size=4).eval()
+        from sige.nn import SIGEModel
+
+        class Wrap(SIGEModel):  # (a SIGEModel drives set_masks / set_mode; the same wrapper on both stacks)
+            def __init__(self, m):
+                super().__init__()
+                self.m = m
+
+            def forward(self, x, **kw):
+                return self.m(x, **kw)
+
+        model = Wrap(model).eval()
+        g = torch.Generator().manual_seed(1)
+        for p_ in model.parameters():  # (proj_out is zero-initialised in the reference)
+            if p_.abs().max() == 0:
+                p_.data.copy_(torch.randn(p_.shape, generator=g) * 0.05)
+        x0 = torch.from_numpy(rs.standard_normal((2, 64, 32, 32)).astype(np.float32))
+        m = torch.zeros(32, 32, dtype=torch.bool)
+        m[9:21, 6:19] = True
+        x1 = x0 + torch.from_numpy(rs.standard_normal((2, 64, 32, 32)).astype(np.float32)) * m
+        masks = {(32, 32): m}
+        ctx = torch.from_numpy(rs.standard_normal((2, 77, 96)).astype(np.float32))
+        run = lambda x: model(x, context=ctx)  # noqa: E731
     else:
         oc = types.ModuleType("omegaconf")
         lc = types.ModuleType("omegaconf.listconfig")

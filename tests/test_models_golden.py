@@ -12,14 +12,14 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-from tests.golden.model_init import gaugan_labels, init_by_name, summarize  # noqa: E402
+from tests.golden.model_init import gaugan_labels, init_by_name, sd_transformer_inputs, summarize  # noqa: E402
 
 GOLDEN = np.load(os.path.join(REPO, "tests", "golden", "models.npz"))
 ATOL = 1e-3  # north_star: activations within 1e-3 fp32 on conv-containing paths
 
 
 def _check(prefix, t, atol=ATOL):
-    s = summarize(t)
+    s = summarize(t, cstep=int(GOLDEN[prefix + "/cstep"][0]))
     assert list(GOLDEN[prefix + "/shape"]) == s["shape"]
     np.testing.assert_allclose(s["sub"], GOLDEN[prefix + "/sub"], rtol=0, atol=atol)
     n = float(np.prod(s["shape"]))
@@ -114,3 +114,50 @@ def test_spade_modulate_kernel_equals_the_module_chain():
     want = chain(hip.gather_cl(x, 4, 4, idx4, sc, sh), hip.gather_cl(scattered, 4, 4, idx4), None)
     got = hip.spade_modulate_cl(x, None, None, sc, sh, gb_t, gb_full, smap, idx4, (4, 4), None)
     assert torch.equal(got, want)
+
+
+# ---- Stable Diffusion: the sparse-query spatial transformer (BASELINE.json configs[3]) -------------
+def _sd_transformer(device, channels_last, inplace, sparse_kv=True):
+    from sige_amd.nn import SIGEModel
+    from sige_amd.utils import downsample_mask
+    from sige_amd.workloads.sd_transformer import SpatialTransformer
+
+    class Wrap(SIGEModel):
+        def __init__(self, m):
+            super().__init__()
+            self.m = m
+
+        def forward(self, x, **kw):
+            return self.m(x, **kw)
+
+    model = Wrap(SpatialTransformer(320, 8, 40, depth=1, context_dim=768, block_size=4, sparse_kv=sparse_kv)).eval()
+    init_by_name(model)
+    x0, noise, ctx, mask512 = sd_transformer_inputs()
+    model, x0, noise, ctx, mask512 = model.to(device), x0.to(device), noise.to(device), ctx.to(device), mask512.to(device)
+    if channels_last:
+        model = model.to(memory_format=torch.channels_last)
+        x0, noise = x0.contiguous(memory_format=torch.channels_last), noise.contiguous(memory_format=torch.channels_last)
+    model.set_scatter_inplace(inplace)
+    masks = downsample_mask(mask512, min_res=8, dilation=1)  # stable-diffusion/runners/inpainting_runner.py:50-54
+    x1 = x0 + noise * masks[(64, 64)]
+    with torch.no_grad():
+        model.set_mode("full")
+        full = model(x0, context=ctx)
+        model.set_masks(masks)
+        model.set_mode("sparse")
+        sparse = model(x1, context=ctx)
+        again = model(x1, context=ctx)  # persistent buffers / cached K, V must survive a second step
+    assert torch.equal(sparse, again)
+    assert abs(float(masks[(64, 64)].float().mean()) - float(GOLDEN["sdt/active_ratio"][0])) < 1e-9
+    return full, sparse
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels_last,inplace,sparse_kv", [(False, False, False), (True, False, True), (True, True, True)])
+def test_sd_spatial_transformer_on_the_gpu_matches_the_reference_fixture(channels_last, inplace, sparse_kv):
+    """SD v1 level-1 transformer (320 ch, 8 heads, text context 768) at the 64 x 64 latent, CFG batch 2, 15 % edit: the
+    reference's NCHW form with permute copies and full K / V re-projection; channels-last (tile <-> token glue as views) with
+    K / V refreshed by two Scatters; the same with in-place persistent scatter outputs."""
+    full, sparse = _sd_transformer("cuda", channels_last, inplace, sparse_kv)
+    _check("sdt/full", full)
+    _check("sdt/sparse", sparse)

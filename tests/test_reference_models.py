@@ -89,3 +89,16 @@ def test_gaugan_workload_equals_reference_model(tmp_path):
         ours = _run_model("ours-workload", "gaugan", state, str(tmp_path / "ours.npz"), extra)
         np.testing.assert_allclose(ours["full"], ref["full"], rtol=0, atol=1e-5)
         np.testing.assert_allclose(ours["sparse"], ref["sparse"], rtol=0, atol=1e-4)
+
+
+def test_sd_spatial_transformer_workload_equals_reference_module(tmp_path):
+    """sige_amd/workloads/sd_transformer.py (sparse queries; K / V of the self-attention refreshed by two Scatters instead
+    of re-projected for all tokens) loads the reference SIGESpatialTransformer's state dict and reproduces its full and
+    sparse outputs, CFG batch 2 with a per-sample cached affine."""
+    state = str(tmp_path / "state.pt")
+    ref = _run_model("reference", "sdt", state, str(tmp_path / "ref.npz"))
+    assert np.abs(ref["sparse"] - ref["full"]).max() > 1e-2
+    for extra in ((), ("--deferred",)):
+        ours = _run_model("ours-workload", "sdt", state, str(tmp_path / "ours.npz"), extra)
+        np.testing.assert_allclose(ours["full"], ref["full"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(ours["sparse"], ref["sparse"], rtol=0, atol=1e-4)
