@@ -1,51 +1,68 @@
 #!/usr/bin/env python3
-"""Fabric-side bytes per launch per kernel family from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE)
-of `tools/profile_forward.py --mode eager --replays R`, reduced by tools/pmc_summary.py.
-Usage: pmc_traffic.py FETCH.csv WRITE.csv OUT.json [forwards_profiled=7]"""
+"""Fabric-side bytes per launch per kernel family from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs,
+--kernel-trace only) of `tools/profile_forward.py --mode eager --replays R --manifest M.json`.
+
+    pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv M.json OUT.json
+
+The SIGE (sparse) and the dense-remainder convs run the SAME kernel symbols, so a kernel name cannot tell them apart; the
+manifest is the family of every conv launch of one forward in launch order (written by the profiled script itself from
+bench.py's op accounting), and the rows of `conv_mfma_kernel` dispatches, sorted by dispatch id, are matched to it
+cyclically -- the same family definition as bench.py's `roofline` (block_conv_mfma = every conv over a SIGE tile list).
+FETCH_SIZE is in KB and reports 1/2 of wide coalesced reads on gfx950 (MI355X_MICROARCH.md): doubled.  WRITE_SIZE in KB,
+uncalibrated.  Infinity-Cache hits are included: an upper bound on HBM bytes.  The output records the hash of the kernel
+sources it was measured on; bench.py prints `roofline.traffic` only when that hash matches the sources it runs."""
+import collections
 import csv
 import json
-import re
 import sys
 
-f = list(csv.DictReader(open(sys.argv[1])))
-w = list(csv.DictReader(open(sys.argv[2])))
-FORWARDS = int(sys.argv[4]) if len(sys.argv) > 4 else 7  # 3 warm-up + 4 measured sparse forwards
 
-
-def fam(k):
-    m = re.search(r"conv_mfma_kernel<sige::ConvGeo<(\d), (\d), (\d), (\d+)>, (\d), (\d), (\d), (\d), (\d), (\d)>", k)
-    if m:  # template args: G, NB, SRC, MODE, DST, LAYOUT, W -- DST 0 = tiles; SRC 2 (scatter_gather) is always a SIGE layer
-        return "block_conv_mfma" if (m.group(8) == "0" or m.group(6) == "2") else "dense_or_fused_scatter_conv_mfma"
-    for n in ("scatter_tiles_nhwc", "conv_out_nhwc", "gn_partial_nhwc", "attn_apply_nhwc", "attn_scores_nhwc", "splitk_reduce"):
-        if n in k:
-            return n
-    return None
-
-
-agg = {}
-for rows, key in ((f, "FETCH_SIZE"), (w, "WRITE_SIZE")):
+def conv_rows(path, counter):
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    conv = [r for r in rows if "conv_mfma_kernel" in r["Kernel_Name"]]
+    other = collections.defaultdict(list)
     for r in rows:
-        fm = fam(r["kernel"])
-        if not fm:
-            continue
-        d = agg.setdefault(fm, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "n_FETCH_SIZE": 0, "n_WRITE_SIZE": 0})
-        d[key] += float(r[key]) * int(r["dispatches"])
-        d["n_" + key] += int(r["dispatches"])
-out = {}
-for k, d in agg.items():
-    n, nw = d["n_FETCH_SIZE"], max(1, d["n_WRITE_SIZE"])
-    rd, wr = 2 * d["FETCH_SIZE"] / n / 1e3, d["WRITE_SIZE"] / nw / 1e3
-    out[k] = {"dispatches_profiled": n, "launches_per_forward": round(n / FORWARDS, 1),
-              "FETCH_SIZE_KB_raw_per_launch": round(d["FETCH_SIZE"] / n, 1), "WRITE_SIZE_KB_raw_per_launch": round(d["WRITE_SIZE"] / nw, 1),
-              "hbm_read_MB_per_launch_corrected_x2": round(rd, 2), "hbm_write_MB_per_launch": round(wr, 2),
-              "traffic_MB_per_launch": round(rd + wr, 2)}
-meta = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python "
-                  "tools/profile_forward.py --mode eager --replays 4 (NHWC, in-place scatter, 1.2% edit)",
-        "correction": "FETCH_SIZE counted in KB and doubled (MI355X_MICROARCH.md: gfx950 reports 1/2 of wide coalesced reads); "
-                      "WRITE_SIZE in KB, uncalibrated",
-        "note": "L2-miss traffic towards the fabric: Infinity-Cache hits are included, so this is an upper bound on HBM bytes. "
-                "block_conv_mfma = the SIGE convs that write tiles or are fed by scatter_gather; gather-fed convs writing a full "
-                "tensor (dense remainder, and the conv -> scatter fused up/downsample convs) are counted together",
-        "families": out}
-json.dump(meta, open(sys.argv[3], "w"), indent=1)
-print(json.dumps(out, indent=1))
+        if "sige::" in r["Kernel_Name"] and "conv_mfma_kernel" not in r["Kernel_Name"] and "pack_weights" not in r["Kernel_Name"]:
+            other[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+    return conv, other
+
+
+def main():
+    fetch, write, manifest, out_path = sys.argv[1:5]
+    man = json.load(open(manifest))
+    seq = man["conv_families_in_launch_order"]
+    fam = collections.defaultdict(lambda: {"FETCH_SIZE": [], "WRITE_SIZE": []})
+    others = {}
+    for path, counter in ((fetch, "FETCH_SIZE"), (write, "WRITE_SIZE")):
+        conv, other = conv_rows(path, counter)
+        if len(conv) % len(seq):
+            raise SystemExit("%s: %d conv dispatches is not a multiple of the %d-launch manifest" % (path, len(conv), len(seq)))
+        for i, r in enumerate(conv):
+            fam[seq[i % len(seq)]][counter].append(float(r["Counter_Value"]))
+        for k, v in other.items():
+            others.setdefault(k, {})[counter] = sum(v) / len(v)
+    out = {}
+    for k, d in fam.items():
+        rd = 2 * sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]) / 1e3
+        wr = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"]) / 1e3
+        out[k] = {"dispatches_profiled": len(d["FETCH_SIZE"]), "launches_per_forward": seq.count(k),
+                  "hbm_read_MB_per_launch_corrected_x2": round(rd, 3), "hbm_write_MB_per_launch": round(wr, 3),
+                  "traffic_MB_per_launch": round(rd + wr, 3)}
+    for k, d in others.items():
+        out[k] = {"hbm_read_MB_per_launch_corrected_x2": round(2 * d.get("FETCH_SIZE", 0) / 1e3, 3),
+                  "hbm_write_MB_per_launch": round(d.get("WRITE_SIZE", 0) / 1e3, 3),
+                  "traffic_MB_per_launch": round((2 * d.get("FETCH_SIZE", 0) + d.get("WRITE_SIZE", 0)) / 1e3, 3)}
+    meta = {"source_hash": man["source_hash"],
+            "provenance": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python "
+                          "tools/profile_forward.py --mode eager --manifest ... (NHWC, in-place scatter, 1.2% edit); conv rows matched "
+                          "to bench.py's families by launch order",
+            "correction": "FETCH_SIZE in KB, doubled (gfx950 reports 1/2 of wide coalesced reads); WRITE_SIZE in KB, uncalibrated; "
+                          "Infinity-Cache hits included (upper bound on HBM bytes)",
+            "families": out}
+    json.dump(meta, open(out_path, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

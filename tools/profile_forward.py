@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--replays", type=int, default=50)
     ap.add_argument("--mode", default="sparse", choices=["sparse", "dense", "eager"])
     ap.add_argument("--layout", default="nhwc", choices=["nhwc", "nchw"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16"], help="arithmetic of the tile convs (bench.py --dtype)")
+    ap.add_argument("--manifest", default="", help="eager mode: write the kernel-family sequence of one forward's conv launches here")
     a = ap.parse_args()
     dev = torch.device("cuda")
     torch.backends.cudnn.benchmark = True
@@ -41,6 +43,7 @@ def main():
         model = model.to(memory_format=torch.channels_last)
         x0, noise = x0.contiguous(memory_format=torch.channels_last), noise.contiguous(memory_format=torch.channels_last)
         model.set_scatter_inplace(True)
+    model.set_compute_dtype(a.dtype)
     mask = bench.square_mask(a.ratio).to(dev)
     x1 = x0 + noise * mask
     with torch.no_grad():
@@ -52,6 +55,20 @@ def main():
             model.set_masks(downsample_mask(dilate_mask(mask, 5), 8))
             model.set_mode("sparse")
         if a.mode == "eager":
+            if a.manifest:
+                import json
+
+                from sige_amd import hip
+
+                tracer = bench.Tracer(hip)
+                model(x1, t)
+                tracer.log = []
+                model(x1, t)
+                seq = [bench.op_cost(n, args, kw)[0] for n, args, kw, _ in tracer.log]
+                tracer.log = None
+                json.dump({"conv_families_in_launch_order": [f for f in seq if f.endswith("conv_mfma")],
+                           "warmup_forwards": 5, "measured_forwards": a.replays, "source_hash": bench.source_hash()},
+                          open(a.manifest, "w"))
             for _ in range(3):
                 model(x1, t)
             torch.cuda.synchronize()
