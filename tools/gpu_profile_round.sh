@@ -19,6 +19,21 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/${TAG}_pmc_write" -o pmc -- $PF --mode eager --replays 4 > "$OUT/${TAG}_pmc_write.log" 2>&1
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d "$OUT/${TAG}_pmc_sq" -o pmc -- $PF --mode eager --replays 4 > "$OUT/${TAG}_pmc_sq.log" 2>&1
 cd "$ROOT"
-# keep what is small: stats + counter tables (the raw kernel traces of 50 replays are a few MB)
-find "$OUT" -name "*_agent_info.csv" -delete 2>/dev/null
-du -sh "$OUT"/${TAG}_* 2>/dev/null | tail -20
+# reduce on the box (gpurun copies at most 64 MiB back): per-replay kernel summaries, per-kernel counter means, the traffic
+# table; the raw traces / counter tables are dropped
+for DT in f32 f16; do
+  T=$(ls "$OUT/${TAG}_trace_$DT"/*kernel_trace.csv 2>/dev/null | head -1)
+  [ -n "$T" ] && python tools/trace_summary.py "$T" --replays 50 --out "$OUT/${TAG}_kerneltrace_sparse_fwd_1p2pct_$DT.csv" > "$OUT/${TAG}_trace_summary_$DT.txt" 2>&1
+  [ -n "$T" ] && python tools/trace_summary.py "$T" --replays 50 --by-grid --top 0 --out "$OUT/${TAG}_kerneltrace_by_grid_sparse_fwd_1p2pct_$DT.csv" > /dev/null 2>&1
+  S=$(ls "$OUT/${TAG}_trace_$DT"/*kernel_stats.csv 2>/dev/null | head -1)
+  [ -n "$S" ] && cp "$S" "$OUT/${TAG}_rocprofv3_kernel_stats_profile_forward_$DT.csv"
+  rm -rf "$OUT/${TAG}_trace_$DT"
+done
+F=$(ls "$OUT/${TAG}_pmc_fetch"/*counter_collection.csv | head -1); W=$(ls "$OUT/${TAG}_pmc_write"/*counter_collection.csv | head -1)
+Q=$(ls "$OUT/${TAG}_pmc_sq"/*counter_collection.csv | head -1)
+python tools/pmc_traffic.py "$F" "$W" "$OUT/${TAG}_manifest.json" "$OUT/${TAG}_pmc_traffic.json" > "$OUT/${TAG}_pmc_traffic.txt" 2>&1
+python tools/pmc_summary.py "$F" "$OUT/${TAG}_pmc_fetch_size_per_kernel.csv" sige::
+python tools/pmc_summary.py "$W" "$OUT/${TAG}_pmc_write_size_per_kernel.csv" sige::
+python tools/pmc_summary.py "$Q" "$OUT/${TAG}_pmc_sq_counters_per_kernel.csv" sige::
+rm -rf "$OUT/${TAG}_pmc_fetch" "$OUT/${TAG}_pmc_write" "$OUT/${TAG}_pmc_sq"
+du -sh "$OUT"/${TAG}_* 2>/dev/null | tail -30

@@ -11,7 +11,7 @@ from collections import defaultdict
 def short(name: str) -> str:
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"\s+", " ", name)
-    return name[:160]
+    return name[:190]
 
 
 def main():
@@ -21,12 +21,18 @@ def main():
     ap.add_argument("--gap-ms", type=float, default=200.0)
     ap.add_argument("--out", required=True)
     ap.add_argument("--top", type=int, default=40)
+    ap.add_argument("--by-grid", action="store_true", help="one row per (kernel, grid size): separates the layers that share a kernel")
     a = ap.parse_args()
     rows = []
     with open(a.trace) as f:
         rd = csv.DictReader(f)
         for r in rd:
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+            name = r["Kernel_Name"]
+            if a.by_grid:
+                gx, gy = r.get("Grid_Size_X", r.get("Grid_Size", "?")), r.get("Grid_Size_Y", "1")
+                wx = r.get("Workgroup_Size_X", "")
+                name = "%s  [grid %sx%s wg %s]" % (short(name)[:130], gx, gy, wx)
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
     rows.sort()
     cut = 0
     for i in range(1, len(rows)):
