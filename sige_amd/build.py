@@ -56,6 +56,30 @@ def _stale(obj: str, src: str, headers) -> bool:
     return any(os.path.getmtime(d) > t for d in [src, *headers])
 
 
+def build_probe(verbose: bool = True) -> str:
+    """The measurement build of tools/conv_phase_probe.py: the conv translation units with -DSIGE_CONV_PROBE (phase
+    timestamps inside the kernel) linked with the product's other objects into lib/libsige_hip_probe.so."""
+    build(verbose=verbose)
+    pdir = os.path.join(LIB_DIR, "probe")
+    os.makedirs(pdir, exist_ok=True)
+    objs, procs = [], []
+    for src in SOURCES:
+        if src.startswith(("conv_k", "block_conv")):
+            obj = os.path.join(pdir, src.replace(".hip", ".o"))
+            cmd = [_hipcc(), *FLAGS, "-DSIGE_CONV_PROBE", "-I" + os.path.join(REPO, "include"), "-I" + CSRC, "-c",
+                   os.path.join(CSRC, src), "-o", obj]
+            procs.append((cmd, subprocess.Popen(cmd)))
+        else:
+            obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+        objs.append(obj)
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    out = os.path.join(LIB_DIR, "libsige_hip_probe.so")
+    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out])
+    return out
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB
@@ -87,4 +111,4 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build_probe() if "--probe" in sys.argv else build(force="--force" in sys.argv))

@@ -214,6 +214,24 @@ static int ksplit_for(long blocks, int nchunks, int cap) {
 static int g_force_mt = 0, g_force_nb = 0, g_force_waves = 0;
 __device__ int32_t g_zero_idx[2] = {0, 0};
 
+#ifdef SIGE_CONV_PROBE
+static unsigned long long *g_probe_buf = nullptr;
+static unsigned long long *conv_probe_buffer() {
+    if (!g_probe_buf && hipMalloc(&g_probe_buf, 8 * 4096 * sizeof(unsigned long long)) != hipSuccess) g_probe_buf = nullptr;
+    return g_probe_buf;
+}
+// (measurement build only, not declared in include/sige_hip.h) copy the timestamps of the last conv launches to the host
+extern "C" int sige_hip_conv_probe_read(unsigned long long *host, int workgroups) {
+    if (!g_probe_buf || workgroups > 4096) return SIGE_HIP_EINVAL;
+    return hipMemcpy(host, g_probe_buf, (size_t)workgroups * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess
+               ? SIGE_HIP_OK : SIGE_HIP_ELAUNCH;
+}
+extern "C" int sige_hip_conv_probe_clear(void) {
+    if (!conv_probe_buffer()) return SIGE_HIP_ELAUNCH;
+    return hipMemset(g_probe_buf, 0, 8 * 4096 * sizeof(unsigned long long)) == hipSuccess ? SIGE_HIP_OK : SIGE_HIP_ELAUNCH;
+}
+#endif
+
 template <int KH, int STR, int R, int SRC, int DST, int LAY, int PREC = 0>
 static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
     using G32 = std::conditional_t<PREC == 1, ConvGeoH<KH, STR, R, 32>, ConvGeo<KH, STR, R, 32>>;
@@ -274,6 +292,9 @@ static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
     a.ksplit = ceil_div(a.nchunks, a.chunks_per_split);
     float *final_out = a.out;
     if (a.ksplit > 1) a.out = a.ws;
+#ifdef SIGE_CONV_PROBE
+    a.probe = conv_probe_buffer();
+#endif
     bool done = false;
     if constexpr (kHasW8) {
         if (waves == 8) {

@@ -183,7 +183,22 @@ struct ConvArgs {
     int up;          // GATHER: 1 = gather from the half-resolution tensor as if it were nearest-upsampled x2
     float *ws;       // host side: workspace for the partial outputs (nullptr / ksplit_max <= 1: no K split)
     int ksplit_max;  // host side: how many output copies `ws` holds
+#ifdef SIGE_CONV_PROBE
+    unsigned long long *probe;  // tools/conv_phase_probe.py build only: 8 timestamps per workgroup
+#endif
 };
+
+// Phase timestamps (s_memtime) of workgroup 0..4095, lane 0 -- compiled in only for the measurement build of
+// tools/conv_phase_probe.py (python -m sige_amd.build --probe); the product library contains none of this.
+#ifdef SIGE_CONV_PROBE
+#define SIGE_PROBE(k)                                                                                       \
+    do {                                                                                                    \
+        if (a.probe && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096)                            \
+            a.probe[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime();                                   \
+    } while (0)
+#else
+#define SIGE_PROBE(k)
+#endif
 
 // SiLU for the fused staging path: v_exp_f32 + v_rcp_f32 (each <= 1 ulp) instead of
 // expf + IEEE division; |relative error| ~1e-6 (the standalone gather keeps the
@@ -266,6 +281,7 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
     float *const tab = smem + 2 * STAGE;
 
+    SIGE_PROBE(0);  // entry
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -670,12 +686,15 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
         __syncthreads();
     }
     set_chunk(min(first + 2, last));
+    SIGE_PROBE(1);  // all prologue loads issued (index / map round trips done)
     static_for<0, NS>([&](auto i_tag) {
         constexpr int i = decltype(i_tag)::value;
         slot_store(0, i, smem, tab);
         slot_load(0, i, min(first + 2, last));
     });
+    SIGE_PROBE(2);  // first chunk's data arrived and is in LDS
     __syncthreads();
+    SIGE_PROBE(3);  // every wave's share is in LDS
 
     // one chunk: MFMAs on LDS[PAR] with B set PAR; register set PAR^1 (chunk+1) -> LDS[PAR^1],
     // re-issued as chunk+3; B set PAR re-issued as chunk+2.  Loads past the last chunk re-read it.
@@ -752,6 +771,7 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
         if (chunk + 1 <= last) body(std::integral_constant<int, 1>{}, chunk + 1);
     }
 
+    SIGE_PROBE(4);  // K loop done
     // ---- K-split reduction across the 4 waves, bias, store -----------------
     // MT=32: reg r of lane (kq, j): pixel row m = (r&3) + 8*(r>>2) + 4*kq ; MT=16: m = 4*kq + r ; column (cout) = j
     float *red = smem;  // safe: the loop ended with a barrier
@@ -860,6 +880,7 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
                 }
             }
         });
+        SIGE_PROBE(5);  // stores issued
         return;
     }
     // NCHW: one float4 (4 consecutive pixels of one tile and one output channel) per lane and step
