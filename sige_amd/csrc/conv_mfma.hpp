@@ -289,6 +289,7 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
     int mb, ng;
     if (a.ng_fast) { ng = blockIdx.x % a.ngk; mb = blockIdx.x / a.ngk; }
     else { mb = blockIdx.x % a.mbk; ng = blockIdx.x / a.mbk; }
+    SIGE_PROBE(6);  // first kernel arguments are in registers
     const int Cin = a.Cin;
     const int HW = (SRC == SRC_GATHER) ? (a.H >> a.up) * (a.W >> a.up) : a.H * a.W;  // pixels of the SOURCE tensor
     // cross-workgroup K split (deep-K, small-M layers): blockIdx.y owns chunks [first, last]
@@ -434,6 +435,7 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
             tab_fetch(first, t_sc, t_sh);
             tab_fetch(min(first + 1, last), t_sc1, t_sh1);
         }
+        SIGE_PROBE(7);  // slot arithmetic done, tile origins / bias / table entries requested
         b_prologue();
         int z_hw[NS], z_m0[NS], z_m1[NS], z_m2[NS];
         static_for<0, NS>([&](auto i_tag) {

@@ -53,14 +53,15 @@ def report(name, fn):
         print(json.dumps({"case": name, "error": "no stamps"}))
         return
     d = np.diff(st[:, :6], axis=1)
+    pre = {"0-6 first kernargs": int(np.median(st[:, 6] - st[:, 0])), "6-7 slot arithmetic + index requests": int(np.median(st[:, 7] - st[:, 6])),
+           "7-1 weight / index-dependent / data loads issued": int(np.median(st[:, 1] - st[:, 7]))}
     span = int(st[:, 5].max() - st[:, 0].min())
     tick_us = us / max(span, 1)  # upper bound on the tick length: the span is shorter than the launch
-    row = {"case": name, "workgroups": int(len(st)), "graph_launch_us": round(us, 2), "span_ticks": span,
+    row = {"case": name, "workgroups": int(len(st)), "graph_launch_us": round(us, 2),
            "median_ticks": {"0-1 idx/map trips": int(np.median(d[:, 0])), "1-2 data arrives -> LDS": int(np.median(d[:, 1])),
                             "2-3 barrier": int(np.median(d[:, 2])), "3-4 K loop": int(np.median(d[:, 3])),
                             "4-5 reduce + epilogue": int(np.median(d[:, 4])), "0-5 total": int(np.median(st[:, 5] - st[:, 0]))},
-           "dispatch_skew_ticks": int(st[:, 0].max() - st[:, 0].min()),
-           "us_per_tick_if_span_were_the_whole_launch": round(tick_us, 5)}
+           "prologue_split_ticks": pre}
     print(json.dumps(row), flush=True)
 
 
