@@ -431,6 +431,166 @@ def cpu_reference(ratios, headline_ratio, seconds):
     return base, outs
 
 
+# ------------------------------------------------- BASELINE configs[2] / [3] sections --
+def _replay_ms(fn, k=30, warm=5):
+    """ms per call of `fn()` replayed as a hipGraph."""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            out = fn()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            out = fn()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    ms = timed_replays(g, k, warm, 1) * 1e3 / k
+    return ms, out, g
+
+
+def gaugan_section(dev, cpu_parity=True):
+    """BASELINE.json configs[2]: GauGAN SPADE generator (ngf 64, 93 M parameters, random init), 256 x 512 label map
+    (crop 512, aspect 2 -- gaugan/test.py:53-54), ~5 % relabelled rectangle; fp32, channels-last."""
+    import numpy as np
+
+    from sige_amd import runtime
+    from sige_amd.utils import compute_difference_mask, dilate_mask, downsample_mask
+    from sige_amd.workloads.gaugan_spade import SPADEConfig, SpadeGenerator
+
+    def labels():
+        rs = np.random.RandomState(3)
+        coarse = rs.randint(0, 36, size=(32, 64))
+        lab0 = np.kron(coarse, np.ones((8, 8), dtype=np.int64))
+        lab1 = lab0.copy()
+        lab1[85:136, 128:256] = (lab0[85:136, 128:256] + 5) % 36
+        oh = lambda l: torch.nn.functional.one_hot(torch.from_numpy(l), 36).permute(2, 0, 1)[None].float().contiguous()  # noqa: E731
+        return oh(lab0), oh(lab1)
+
+    def build():
+        torch.manual_seed(0)
+        m = SpadeGenerator(SPADEConfig()).eval()
+        g = torch.Generator().manual_seed(7)
+        for n_, b_ in m.named_buffers():  # running statistics away from (0, 1): the cached affine matters
+            if n_.endswith("running_mean"):
+                b_.copy_(torch.randn(b_.shape, generator=g) * 0.3)
+            elif n_.endswith("running_var"):
+                b_.copy_(torch.rand(b_.shape, generator=g) + 0.5)
+        return m
+
+    x0c, x1c = labels()
+    cl = lambda t_: t_.to(dev).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    model = build().to(dev).to(memory_format=torch.channels_last)
+    model.set_scatter_inplace(True)
+    x0, x1 = cl(x0c), cl(x1c)
+    res = {}
+    with torch.no_grad():
+        model.set_mode("full")
+        dense_ms, _, gd = _replay_ms(lambda: model(x1))
+        del gd
+        model(x0)
+        diff = compute_difference_mask(x0, x1)
+        model.set_masks(downsample_mask(dilate_mask(diff, 1), (model.sh, model.sw), dilation=2))
+        model.set_mode("sparse")
+        outs = {}
+        for name, fused in (("fused_spade_modulation", True), ("module_chain", False)):
+            model.cfg.fused = fused
+            n0 = _hip().launch_count()
+            model(x1)
+            launches = _hip().launch_count() - n0
+            ms, out, g = _replay_ms(lambda: model(x1))
+            outs[name] = out.float().cpu()
+            res[name] = {"forward_ms": round(ms, 3), "speedup_vs_dense": round(dense_ms / ms, 2), "hip_kernel_launches": launches}
+            del g
+        model.cfg.fused = True
+    res["dense_forward_ms"] = round(dense_ms, 3)
+    res["edit_ratio"] = round(float(diff.float().mean()), 4)
+    res["fused_vs_chain_max_abs"] = round(float((outs["fused_spade_modulation"] - outs["module_chain"]).abs().max()), 8)
+    if cpu_parity:
+        from oracle import oracle
+
+        ref = None
+        try:
+            from oracle import build_ref
+
+            ref = build_ref.load()
+        except Exception:
+            ref = None
+        runtime.register_backend("cpu", oracle.as_backend(ref) if ref is not None else oracle)
+        try:
+            cm = build()
+            with torch.no_grad():
+                cm.set_mode("full")
+                cm(x0c)
+                d = compute_difference_mask(x0c, x1c)
+                cm.set_masks(downsample_mask(dilate_mask(d, 1), (cm.sh, cm.sw), dilation=2))
+                cm.set_mode("sparse")
+                want = cm(x1c)
+        finally:
+            runtime.unregister_backend("cpu")
+        res["parity_max_abs"] = round(float((outs["fused_spade_modulation"] - want).abs().max()), 7)
+        res["parity_against"] = "the same generator on the CPU, native ops = %s" % ("oracle/_ref (reference sige/cpu)" if ref is not None else "oracle C restatement")
+    res["workload"] = "GauGAN SPADE generator ngf 64 (%.1fM params, random init), one-hot label map [1,36,256,512], %.1f%% relabelled, fp32 NHWC, hipGraph replay" % (
+        sum(p_.numel() for p_ in model.parameters()) / 1e6, 100 * res["edit_ratio"])
+    return res
+
+
+def sd_transformer_section(dev):
+    """BASELINE.json configs[3], the part that is specific to Stable Diffusion: one sparse-query spatial transformer at the SD
+    v1 level-1 shape (320 channels, 8 heads, text context 768), 64 x 64 latent, CFG batch 2, 15 % edit."""
+    from sige_amd.nn import SIGEModel
+    from sige_amd.utils import downsample_mask
+    from sige_amd.workloads.sd_transformer import SpatialTransformer
+
+    class Wrap(SIGEModel):
+        def __init__(self, m):
+            super().__init__()
+            self.m = m
+
+        def forward(self, x, **kw):
+            return self.m(x, **kw)
+
+    res = {}
+    cl = lambda t_: t_.contiguous(memory_format=torch.channels_last)  # noqa: E731
+    gen = torch.Generator().manual_seed(5)
+    x0 = cl(torch.randn(2, 320, 64, 64, generator=gen).to(dev))
+    noise = cl(torch.randn(2, 320, 64, 64, generator=gen).to(dev))
+    ctx = torch.randn(2, 77, 768, generator=gen).to(dev)
+    mask512 = torch.zeros(512, 512, dtype=torch.bool, device=dev)
+    mask512[150:348, 120:318] = True
+    masks = downsample_mask(mask512, min_res=8, dilation=1)
+    x1 = cl(x0 + noise * masks[(64, 64)])
+    outs = {}
+    with torch.no_grad():
+        for name, kv in (("sparse_queries_kv_scattered", True), ("sparse_queries_kv_reprojected", False)):
+            torch.manual_seed(0)
+            model = Wrap(SpatialTransformer(320, 8, 40, depth=1, context_dim=768, block_size=4, sparse_kv=kv)).to(dev).eval()
+            for p_ in model.parameters():
+                if p_.dim() >= 2:
+                    p_.data.normal_(0, 1.0 / float(p_[0].numel()) ** 0.5)
+            model = model.to(memory_format=torch.channels_last)
+            model.set_scatter_inplace(True)
+            model.set_mode("full")
+            if "dense_forward_ms" not in res:
+                res["dense_forward_ms"] = round(_replay_ms(lambda: model(x1, context=ctx))[0], 3)
+            model(x0, context=ctx)
+            model.set_masks(masks)
+            model.set_mode("sparse")
+            ms, out, g = _replay_ms(lambda: model(x1, context=ctx))
+            outs[name] = out.float().cpu()
+            res[name] = {"forward_ms": round(ms, 3), "speedup_vs_dense": round(res["dense_forward_ms"] / ms, 2)}
+            del g, model
+    res["kv_scattered_vs_reprojected_max_abs"] = round(float((outs["sparse_queries_kv_scattered"] - outs["sparse_queries_kv_reprojected"]).abs().max()), 8)
+    res["active_token_ratio"] = round(float(masks[(64, 64)].float().mean()), 4)
+    res["workload"] = "SD v1 spatial transformer (320 ch, 8 heads x 40, context 768), latent [2,320,64,64] (CFG batch 2), fp32 NHWC, hipGraph replay"
+    return res
+
+
+def _hip():
+    from sige_amd import hip
+
+    return hip
+
+
 # ---------------------------------------------------------------- launching --
 def self_launch(args):
     """`python bench.py --gpus N` without a torchrun environment: re-exec under torch.distributed.run, one rank per GPU."""
@@ -497,6 +657,7 @@ def main():
                          "operands on the fp16 matrix cores, fp32 accumulation and storage (BASELINE configs[4])")
     ap.add_argument("--f16-sweep", default="0.01,0.02,0.05,0.1,0.2",
                     help="edit ratios of the f16-compute section a default (f32) run appends ('' = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the GauGAN (configs[2]) and SD transformer (configs[3]) sections")
     ap.add_argument("--distribute", default="auto", choices=["auto", "broadcast", "scatter_allgather"],
                     help="N > 1: collective that distributes the original image's cache")
     args = ap.parse_args()
@@ -779,6 +940,15 @@ def main():
                                         "the epilogue (warm in-situ tensors, hipGraph of back-to-back launches)"}}
             model.set_compute_dtype("f32")
 
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras and args.layout == "nhwc":
+        for key, fn in (("gaugan", lambda: gaugan_section(dev, cpu_parity=args.cpu_seconds > 0)), ("sd_transformer", lambda: sd_transformer_section(dev))):
+            try:
+                extras[key] = fn()
+            except Exception as e:  # the headline must not die with an auxiliary section
+                extras[key] = {"error": repr(e)[:300]}
+            torch.cuda.empty_cache()
+
     if world > 1:
         dist.barrier()
     if rank == 0:
@@ -841,6 +1011,7 @@ def main():
             line["parity_against"] = "oracle/_ref (reference sige/cpu) + torch CPU convs, same weights / inputs / masks"
         if f16 is not None:
             line["f16_compute"] = f16
+        line.update(extras)
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
