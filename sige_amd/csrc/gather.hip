@@ -102,6 +102,88 @@ __global__ __launch_bounds__(kGatherThreads) void gather_kernel(GatherArgs a) {
     }
 }
 
+// ---- plain gather, row form (the reference layout's fast path) ----------------------------------------------------
+// In NCHW a tile is C x TR rows of TS contiguous floats.  One lane = one (channel, row): the row comes in with ONE
+// 16-byte + one 8-byte (4-byte) load at its natural 4-byte alignment (gfx950 global loads need no more) and leaves with
+// two stores -- 3x fewer memory instructions than an element per load, which is what bounds a strided gather
+// (address processing, not HBM bytes: the rows of neighbouring tiles share their cache lines).  Consecutive lanes
+// write consecutive 4*TS-byte pieces of the [C][TR][TS] output slab: fully coalesced stores.
+// Rows that leave the image horizontally take the guarded per-element path; rows above / below are zero fill.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+
+template <int TR, int TS, int ACT, bool ACT_FIRST>
+__global__ __launch_bounds__(kGatherThreads) void gather_rows_kernel(GatherArgs a) {
+    static_assert(TS >= 4 && TS <= 6, "row forms for 4-, 5- and 6-wide tiles");
+    const int tile = blockIdx.x;  // b*N + n
+    const int b = tile / a.N, n = tile - b * a.N;
+    const int c0 = blockIdx.y * a.cchunk;
+    const int cc = min(a.cchunk, a.C - c0);
+    const int h0 = a.idx[2 * n], w0 = a.idx[2 * n + 1];
+    const size_t HW = (size_t)a.H * a.W;
+    const float *xb = a.x + (size_t)b * a.C * HW;
+    float *ob = a.out + ((size_t)tile * a.C + c0) * (TR * TS);
+    const bool inside_w = w0 >= 0 && w0 + TS <= a.W;
+    const bool plain = ACT == SIGE_HIP_ACT_IDENTITY && !a.scale.data && !a.shift.data;
+    const bool row_uniform = (a.scale.sh | a.scale.sw | a.shift.sh | a.shift.sw) == 0;  // (absent operands have zero strides)
+    for (int u = threadIdx.x; u < cc * TR; u += kGatherThreads) {
+        const int cl = u / TR, r = u - cl * TR;
+        const int c = c0 + cl, h = h0 + r;
+        float v[TS];
+#pragma unroll
+        for (int i = 0; i < TS; ++i) v[i] = 0.0f;
+        if (h >= 0 && h < a.H) {
+            const float *src = xb + (size_t)c * HW + (size_t)h * a.W + w0;
+            if (inside_w) {
+                const f4u q = *reinterpret_cast<const f4u *>(src);
+                v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+                if (TS == 6) { const f2u t = *reinterpret_cast<const f2u *>(src + 4); v[4] = t[0]; v[5] = t[1]; }
+                if (TS == 5) v[4] = src[4];
+                if (!plain && row_uniform) {
+                    // per-(batch, channel) affine: one scale / shift for the whole row (same two separately rounded ops)
+                    const float sv = a.scale.data ? bcast_load(a.scale, b, c, 0, 0) : 1.0f;
+                    const float tv = a.shift.data ? bcast_load(a.shift, b, c, 0, 0) : 0.0f;
+#pragma unroll
+                    for (int i = 0; i < TS; ++i) {
+                        float z = v[i];
+                        if (!ACT_FIRST) { if (a.scale.data) z = sv * z; if (a.shift.data) z = tv + z; }
+                        z = activate<ACT>(z);
+                        if (ACT_FIRST) { if (a.scale.data) z = sv * z; if (a.shift.data) z = tv + z; }
+                        v[i] = z;
+                    }
+                } else if (!plain) {
+#pragma unroll
+                    for (int i = 0; i < TS; ++i) v[i] = affine_act<ACT, ACT_FIRST>(v[i], a.scale, a.shift, b, c, h, w0 + i);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TS; ++i) {
+                    const int w = w0 + i;
+                    if (w >= 0 && w < a.W) {
+                        const float z = src[i];
+                        v[i] = plain ? z : affine_act<ACT, ACT_FIRST>(z, a.scale, a.shift, b, c, h, w);
+                    }
+                }
+            }
+        }
+        float *dst = ob + (size_t)u * TS;
+        *reinterpret_cast<f4u *>(dst) = f4u{v[0], v[1], v[2], v[3]};
+        if (TS == 6) *reinterpret_cast<f2u *>(dst + 4) = f2u{v[4], v[5]};
+        if (TS == 5) dst[4] = v[4];
+    }
+}
+
+template <int TR, int TS>
+static void launch_rows(const GatherArgs &a, int act, bool first, dim3 grid, hipStream_t st) {
+    dim3 blk(kGatherThreads);
+    if (act == SIGE_HIP_ACT_SWISH) {
+        if (first) gather_rows_kernel<TR, TS, SIGE_HIP_ACT_SWISH, true><<<grid, blk, 0, st>>>(a);
+        else gather_rows_kernel<TR, TS, SIGE_HIP_ACT_SWISH, false><<<grid, blk, 0, st>>>(a);
+    } else {
+        gather_rows_kernel<TR, TS, SIGE_HIP_ACT_IDENTITY, false><<<grid, blk, 0, st>>>(a);
+    }
+}
+
 template <int TR, int TS, bool MAPPED, int VEC>
 static void launch_act(const GatherArgs &a, int act, bool first, dim3 grid, hipStream_t st) {
     dim3 blk(kGatherThreads);
@@ -126,6 +208,17 @@ static int launch(GatherArgs a, int act, bool first, hipStream_t st) {
     if (cchunk < 4) cchunk = 4;
     a.cchunk = cchunk;
     dim3 grid(tiles, ceil_div(a.C, cchunk));
+    if (!MAPPED && a.bH == a.bW && a.bH >= 4 && a.bH <= 6) {
+        // row form: one lane per (channel, tile row); ~64 channels per workgroup, but >= ~512 workgroups when possible
+        int cch = 64;
+        while (cch > 8 && (long)tiles * ceil_div(a.C, cch) < 512) cch /= 2;
+        a.cchunk = cch;
+        dim3 rgrid(tiles, ceil_div(a.C, cch));
+        if (a.bH == 6) launch_rows<6, 6>(a, act, first, rgrid, st);
+        else if (a.bH == 5) launch_rows<5, 5>(a, act, first, rgrid, st);
+        else launch_rows<4, 4>(a, act, first, rgrid, st);
+        return launch_status();
+    }
     const bool vec4 = ((long)a.C * RS) % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
 #define SIGE_DISPATCH(TR, TS)                                                    \
     do {                                                                         \
