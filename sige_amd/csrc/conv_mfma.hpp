@@ -225,10 +225,16 @@ using rsrc_t = __amdgpu_buffer_rsrc_t;
 constexpr unsigned kOOB = 0x80000000u;  // a byte offset no descriptor contains (tensors are < 2 GiB: host side)
 
 __device__ __forceinline__ rsrc_t make_rsrc(const float *base, long elem_off, long total_elems) {
-    // window [elem_off, total_elems) of the tensor at `base`; empty past the end
-    long bytes = (total_elems - elem_off) * 4;
-    if (bytes < 0) bytes = 0;
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base) + elem_off, 0, (int)bytes, 0x00020000);
+    // window [elem_off, total_elems) of the tensor at `base`; empty past the end.
+    // Every caller passes wave-uniform values, but the arithmetic behind them contains 64-bit multiplies / compares and
+    // divisions by runtime values, which LLVM evaluates on the VECTOR unit; a descriptor assembled from VGPRs then costs a
+    // waterfall loop (4 v_readfirstlane + 2 v_cmp + exec juggling) in front of EVERY buffer load that uses it -- measured in
+    // the ISA of the K loop: 18 loops per 72 MFMAs.  Both words are 32-bit here (tensors are < 2 GiB: host side) and are
+    // pinned to scalar registers once per descriptor.
+    const int off = __builtin_amdgcn_readfirstlane((int)elem_off);
+    int bytes = __builtin_amdgcn_readfirstlane((int)((total_elems - elem_off) * 4));
+    bytes = bytes < 0 ? 0 : bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base) + off, 0, bytes, 0x00020000);
 }
 __device__ __forceinline__ float buf_f32(rsrc_t r, unsigned byte_off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
