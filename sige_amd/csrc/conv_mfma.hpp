@@ -302,19 +302,6 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
     const int split = blockIdx.y;
     const int first = split * a.chunks_per_split;
     const int last = min(a.nchunks, first + a.chunks_per_split) - 1;
-    // Chunk ORDER per workgroup.  Workgroups b, b + 8, b + 16, ... share an XCD (and its L2) and, with the grid orders
-    // below, the same slice of the packed weights: walking the channel chunks in the same order they all ask the same L2
-    // channel for the same lines at the same moment (measured with the in-kernel phase probe: 4600-5200 cycles per chunk
-    // against 2304 cycles of matrix work, at 0.6 TB/s per XCD).  Every workgroup therefore starts its walk at a different
-    // chunk and wraps around; P() maps the loop's logical chunk to the one actually staged.  The sum over chunks is the
-    // same set of terms in a rotated order (deterministic per workgroup).
-    const int nloc = last - first + 1;
-    const int rot = __builtin_amdgcn_readfirstlane(nloc > 1 ? (int)((blockIdx.x >> 3) % (unsigned)nloc) : 0);
-    auto P = [&](int c) {
-        int t = c - first + rot;
-        t = t >= nloc ? t - nloc : t;
-        return first + t;
-    };
 
     // ---- B: F float4 per lane per chunk and N sub-block, contiguous per (ng, chunk, wave) ----
     const int ngtot = (a.Cout + G::MT - 1) / G::MT;
@@ -323,8 +310,7 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) gsel[nb] = min(ng * NB + nb, ngtot - 1);  // past-the-end sub-blocks re-read the last one; stores are masked
     rsrc_t r_b[NB];
-    auto set_b_chunk = [&](int lchunk) {
-        const int chunk = P(lchunk);
+    auto set_b_chunk = [&](int chunk) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
             r_b[nb] = make_rsrc(a.packed, ((long)gsel[nb] * a.nblk + chunk * W + wave) * G::F * 64 * 4, packed_floats_total);
@@ -367,8 +353,8 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
     // (scale, shift) of channel chunk `chunk` for table entry (tid mod CC); entries past Cin are 0
     const int trow = tid % CCk;
     const int tab_b0 = AFF ? ((mb * G::TPB) / a.N) * a.aff_sb : 0;  // (a per-batch affine needs one batch per M block: host side)
-    auto tab_fetch = [&](int lchunk, float &sc, float &sh) {
-        const int c = P(lchunk) * CCk + trow;
+    auto tab_fetch = [&](int chunk, float &sc, float &sh) {
+        const int c = chunk * CCk + trow;
         const int cc = c < Cin ? c : 0;
         const float vs = a.scale[tab_b0 + cc * a.aff_sc], vh = a.shift[tab_b0 + cc * a.aff_sc];
         sc = c < Cin ? vs : 0.f;
@@ -586,8 +572,8 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
     // descriptors of the staging sources, advanced to channel chunk `chunk` with scalar arithmetic
     rsrc_t r_a, r_a2;
     bool use2 = false;  // NHWC GATHER: this chunk's channels live in x2
-    auto set_chunk = [&](int lchunk) {
-        const int c0 = P(lchunk) * CCk;
+    auto set_chunk = [&](int chunk) {
+        const int c0 = chunk * CCk;
         const long cstep = NHWC ? 1 : HW;  // elements between consecutive channels of a full tensor
         if (SRC == SRC_TILES) {
             r_a = make_rsrc(a.x, (long)c0 * (NHWC ? 1 : G::RS), (long)a.T * Cin * G::RS);
@@ -608,8 +594,7 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
         if (NHWC) return s_cl[i] < left ? off : kOOB;
         return (int)((tid + NT * i) % (TILEF / 4)) * 4 < left * G::RS ? off : kOOB;
     };
-    auto slot_load = [&](int set, int i, int lchunk) {
-        const int chunk = P(lchunk);
+    auto slot_load = [&](int set, int i, int chunk) {
         if (!VEC) {
             st_z[set][i] = buf_f32(r_a, s_off[i]);
             if (SRC == SRC_SCATTER_GATHER) st_z2[set][i] = buf_f32(r_a2, s_off2[i]);
