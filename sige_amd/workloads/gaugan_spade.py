@@ -50,6 +50,17 @@ def _cl_gpu(t: torch.Tensor) -> bool:
     return hip.is_cl(t)
 
 
+def _dense_conv(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
+    """A dense (non-tiled) conv of a sparse-mode forward: on channels-last GPU tensors one launch of the MFMA tile kernel with
+    every tile active (sige_amd.nn.dense.fused_conv2d), else the plain conv -- the blocks below `num_sparse_layers` are
+    recomputed densely in sparse mode exactly as in the reference (sige_fused_spade_generator.py:133-173)."""
+    from ..nn.dense import fusable, fused_conv2d
+
+    if _cl_gpu(x) and fusable(conv) and conv.out_channels % 4 == 0:
+        return fused_conv2d(conv, x)
+    return conv(x)
+
+
 class SpadeNorm(SIGEModule):
     """One SPADE layer: param-free BatchNorm (running statistics) modulated by gamma|beta = conv3x3(label features).
     `role`: "main" (tiles of a 3x3 conv: gamma|beta re-tiled by ScatterGather) or "shortcut" (tiles of the 1x1 shortcut
@@ -92,7 +103,8 @@ class SpadeNorm(SIGEModule):
             n = x
         else:
             raise NotImplementedError("Unknown mode [%s]!!!" % self.mode)
-        gamma, beta = torch.split(self._retile(self.mlp_gamma_beta(actv)), self.channels, dim=1)
+        gb = _dense_conv(self.mlp_gamma_beta, actv) if (not self.tiled and self.mode == "sparse") else self.mlp_gamma_beta(actv)
+        gamma, beta = torch.split(self._retile(gb), self.channels, dim=1)
         return n * (1 + gamma) + beta
 
     # -- fused sparse form ----------------------------------------------------------
@@ -178,12 +190,16 @@ class SpadeResBlock(SIGEModule):
 
     def _label_features(self, seg, res):
         """ReLU(conv3x3(label map at this resolution)), split into one part per SPADE layer of the block."""
-        seg = F.interpolate(seg, size=res, mode="nearest")
+        if tuple(seg.shape[2:]) != tuple(res):  # (nearest resize to the same size is the identity: skip the copy)
+            seg = F.interpolate(seg, size=res, mode="nearest")
         if self.tiled:
             seg = self.seg_gather(seg)
-        a = self.mlp_shared(seg)
+        if not self.tiled and self.mode == "sparse":
+            a = F.relu(_dense_conv(self.mlp_shared[0], seg))
+        else:
+            a = self.mlp_shared(seg)
         if self.tiled:
-            a = self.seg_scatter_gather(a)
+            a = deferred.resolve(self.seg_scatter_gather(a))  # (a split is not a conv: the tiles are needed as a tensor)
         parts = torch.split(a, self.nhidden, dim=1)
         if self.tiled and self.mode == "sparse" and _cl_gpu(a):
             # channel slices of channels-last tiles are strided: give every consumer conv its own dense channels-last slab
@@ -229,12 +245,12 @@ class SpadeResBlock(SIGEModule):
         if t is None:
             dx = self.main_gather(x, *self.norm_0.affine4()) if self.tiled else self.norm_0.param_free_norm(x)
             t = self._lrelu(self.norm_0(dx, a[0]))
-        dx = self.conv_0(t)
+        dx = self.conv_0(t) if self.tiled else _dense_conv(self.conv_0, t)
         t = self.norm_1.modulated_tiles(("scatter_gather", self.main_scatter_gather, dx), a[1], slope) if fused else None
         if t is None:
             dx = self.main_scatter_gather(dx, *self.norm_1.affine4()) if self.tiled else self.norm_1.param_free_norm(dx)
             t = self._lrelu(self.norm_1(dx, a[1]))
-        dx = self.conv_1(t)
+        dx = self.conv_1(t) if self.tiled else _dense_conv(self.conv_1, t)
         return self.scatter(dx, xs) if self.tiled else xs + dx
 
 
