@@ -66,7 +66,8 @@ def build_probe(verbose: bool = True) -> str:
     for src in SOURCES:
         if src.startswith(("conv_k", "block_conv")):
             obj = os.path.join(pdir, src.replace(".hip", ".o"))
-            cmd = [_hipcc(), *FLAGS, "-DSIGE_CONV_PROBE", "-I" + os.path.join(REPO, "include"), "-I" + CSRC, "-c",
+            cmd = [_hipcc(), *FLAGS, "-DSIGE_CONV_PROBE", *os.environ.get("SIGE_PROBE_DEFS", "").split(),
+                   "-I" + os.path.join(REPO, "include"), "-I" + CSRC, "-c",
                    os.path.join(CSRC, src), "-o", obj]
             procs.append((cmd, subprocess.Popen(cmd)))
         else:

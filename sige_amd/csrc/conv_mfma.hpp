@@ -274,7 +274,12 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
     constexpr int BUFk = G::TPB * TILEF;
     constexpr bool NHWC = LAYOUT == LAYOUT_NHWC;
     constexpr bool VEC = NHWC || SRC == SRC_TILES;            // staging slots are float4 units
-    constexpr int NACC = ((G::MT == 16 && NB == 1) || (F16 && NB == 1)) ? 2 : 1;   // 16x16x4: 40-cycle dependent latency vs 32-cycle issue
+#ifndef SIGE_CONV_NACC32
+#define SIGE_CONV_NACC32 2
+#endif
+    // accumulators per N sub-block that consecutive k-steps alternate between: a chain of MFMAs on ONE accumulator pays for
+    // every instruction issued between two of them (16x16x4: 40-cycle dependent latency vs 32-cycle issue)
+    constexpr int NACC = NB == 1 ? ((G::MT == 16 || F16) ? 2 : SIGE_CONV_NACC32) : 1;
     constexpr bool AFF = MODE != MODE_RAW;
     // LDS stage of one channel chunk: NCHW [tile][channel][R][S]; NHWC [tile][R][S][LDC] (LDC = CC + 4 pad)
     //   (f16 compute: the stage holds HALVES, row = CC + 8 halves; STAGE stays in floats)
