@@ -275,7 +275,7 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
     constexpr bool NHWC = LAYOUT == LAYOUT_NHWC;
     constexpr bool VEC = NHWC || SRC == SRC_TILES;            // staging slots are float4 units
 #ifndef SIGE_CONV_NACC32
-#define SIGE_CONV_NACC32 2
+#define SIGE_CONV_NACC32 1
 #endif
     // accumulators per N sub-block that consecutive k-steps alternate between: a chain of MFMAs on ONE accumulator pays for
     // every instruction issued between two of them (16x16x4: 40-cycle dependent latency vs 32-cycle issue)
