@@ -597,7 +597,7 @@ def self_launch(args):
     if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
         return
     n_vis = torch.cuda.device_count()
-    if n_vis < args.gpus:
+    if n_vis < args.gpus and not args.oversubscribe:
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (args.gpus, n_vis))
     import socket
 
@@ -658,6 +658,10 @@ def main():
     ap.add_argument("--f16-sweep", default="0.01,0.02,0.05,0.1,0.2",
                     help="edit ratios of the f16-compute section a default (f32) run appends ('' = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the GauGAN (configs[2]) and SD transformer (configs[3]) sections")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only to "
+                    "exercise the multi-rank code path without N GPUs)")
+    ap.add_argument("--oversubscribe", action="store_true", help="debugging: all ranks on GPU 0 (with --backend gloo): runs the "
+                    "multi-rank code path on a one-GPU box; the numbers mean nothing")
     ap.add_argument("--distribute", default="auto", choices=["auto", "broadcast", "scatter_allgather"],
                     help="N > 1: collective that distributes the original image's cache")
     args = ap.parse_args()
@@ -671,11 +675,16 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d "
                          "(or plain `python bench.py --gpus %d`, which does that itself)" % (args.gpus, world, args.gpus, args.gpus))
+    if args.oversubscribe:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from sige_amd import hip, parallel
     from sige_amd.utils import dilate_mask, downsample_mask
@@ -982,7 +991,7 @@ def main():
                                       "forwards per rank" % (distribute, args.steps) if world > 1 else ""),
                        "edit_ratio": args.ratio, "batch_per_gpu": 1, "resolution": 256,
                        "parallelism": "dp%d" % world},
-            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": args.backend if world > 1 else None,
             "devices": [torch.cuda.get_device_name(i) for i in range(min(world, torch.cuda.device_count()))],
             "forward_ms": round(ms_steady, 4),
             "forward_ms_eager": round(e_ms, 3),

@@ -139,11 +139,14 @@ def distribute_cache(flat: torch.Tensor, src: int = 0, method: str = "broadcast"
     rank = dist.get_rank(group)
     chunk = flat.numel() // world
     mine = flat[rank * chunk:(rank + 1) * chunk]
+    # scatter as point-to-point sends (rank `src` keeps its own chunk where it is: no self-send, no aliased buffers)
     if rank == src:
-        dist.scatter(mine, [flat[r * chunk:(r + 1) * chunk] for r in range(world)], src=src, group=group)
+        ops = [dist.P2POp(dist.isend, flat[r * chunk:(r + 1) * chunk], r, group) for r in range(world) if r != src]
     else:
-        dist.scatter(mine, None, src=src, group=group)
-    dist.all_gather_into_tensor(flat, mine, group=group)
+        ops = [dist.P2POp(dist.irecv, mine, src, group)]
+    for work in dist.batch_isend_irecv(ops):
+        work.wait()
+    dist.all_gather_into_tensor(flat, mine, group=group)  # in place: rank r's input is chunk r of the output
 
 
 def max_over_ranks(seconds: float, device=None, group=None) -> float:
