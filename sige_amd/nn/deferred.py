@@ -49,7 +49,15 @@ def _metadata_funcs():
 class DeferredTiles(torch.Tensor):
     @staticmethod
     def __new__(cls, shape, dtype, device, thunk: Callable[[], torch.Tensor], spec: dict):
-        t = torch.Tensor._make_wrapper_subclass(cls, tuple(shape), dtype=dtype, device=device, requires_grad=False)
+        shape = tuple(shape)
+        strides = None
+        if spec.get("cl", False) and len(shape) == 4 and shape[1] > 1 and shape[2] * shape[3] > 1:
+            # the tiles will come out channels-last: advertise exactly those strides (layout queries on the pending
+            # tensor -- is_contiguous(memory_format=...), stride() -- then agree with what materialisation yields)
+            n, c, h, w = shape
+            strides = (c * h * w, 1, w * c, c)
+        t = torch.Tensor._make_wrapper_subclass(cls, shape, strides=strides, dtype=dtype, device=device, requires_grad=False)
+        t._cl = strides is not None
         t._thunk = thunk
         t._spec = spec
         t._value = None
@@ -77,8 +85,8 @@ class DeferredTiles(torch.Tensor):
         if func in _metadata_funcs():
             with torch._C.DisableTorchFunctionSubclass():
                 return func(*args, **kwargs)
-        if func is torch.Tensor.contiguous and len(args) == 1 and not kwargs:
-            return args[0]  # dense NCHW by construction
+        if func is torch.Tensor.contiguous and len(args) == 1 and not kwargs and not getattr(args[0], "_cl", False):
+            return args[0]  # dense NCHW by construction (a channels-last one materialises and converts below)
 
         def real(a):
             return a.materialize() if isinstance(a, DeferredTiles) else a
@@ -104,7 +112,8 @@ class LazyCat(DeferredTiles):
     @staticmethod
     def __new__(cls, a: torch.Tensor, b: torch.Tensor):
         shape = (a.shape[0], a.shape[1] + b.shape[1], a.shape[2], a.shape[3])
-        t = DeferredTiles.__new__(cls, shape, a.dtype, a.device, lambda: torch.cat([a, b], dim=1), dict(kind="cat"))
+        cl = a.dim() == 4 and a.is_contiguous(memory_format=torch.channels_last) and not a.is_contiguous()
+        t = DeferredTiles.__new__(cls, shape, a.dtype, a.device, lambda: torch.cat([a, b], dim=1), dict(kind="cat", cl=cl))
         t.parts = (a, b)
         return t
 

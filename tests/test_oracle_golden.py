@@ -93,3 +93,38 @@ def test_example_indices():
     idx = oracle.reduce_mask(mask, 6, 4, 1)
     assert idx.shape[0] == 783       # SURVEY.md 3a [probe]: 783 active blocks of 4225
     assert np.array_equal(idx.numpy(), ex["c16_32/idx"])
+
+
+def test_oracle_vs_compiled_reference():
+    """Live check of the restatement against the reference's own sige/cpu, compiled from /root/reference into oracle/_ref
+    (skipped where neither the sources nor a prebuilt _ref exist): random shapes beyond the committed goldens."""
+    from oracle import build_ref
+
+    try:
+        ref = build_ref.load()
+    except Exception as e:  # no _ref here (e.g. a checkout without /root/reference)
+        pytest.skip("oracle/_ref not available: %r" % (e,))
+    rs = np.random.RandomState(11)
+    for trial in range(6):
+        B, C, H, W = int(rs.randint(1, 3)), int(rs.randint(1, 9)), int(rs.randint(9, 40)), int(rs.randint(9, 40))
+        mask = torch.from_numpy(rs.rand(H, W) < 0.08)
+        mask[0, 0] = True
+        idx = oracle.reduce_mask(mask, 6, 4, 1)
+        x = torch.from_numpy(rs.standard_normal((B, C, H, W)).astype(np.float32))
+        y = torch.from_numpy(rs.standard_normal((B, C, H, W)).astype(np.float32))
+        sc = torch.from_numpy(rs.standard_normal((1, C, 1, 1)).astype(np.float32))
+        sh = torch.from_numpy(rs.standard_normal((B, C, 1, 1)).astype(np.float32))
+        act = ("identity", "swish")[trial % 2]
+        a, b = oracle.gather(x, 6, 6, idx, sc, sh, act, False), ref.gather(x, 6, 6, idx, sc, sh, act, False)
+        (torch.testing.assert_close(a, b, rtol=util.SWISH_RTOL, atol=util.SWISH_ATOL) if act == "swish" else None)
+        assert act == "swish" or torch.equal(a, b)
+        tiles = torch.from_numpy(rs.standard_normal((B * idx.shape[0], C, 4, 4)).astype(np.float32))
+        assert torch.equal(oracle.scatter(tiles, y, 1, 1, 1, 1, idx, x), ref.scatter(tiles, y, 1, 1, 1, 1, idx, x))
+        m1, m2 = oracle.get_scatter_map(H, W, 6, 6, 3, 3, 1, 1, 1, 1, idx), ref.get_scatter_map(H, W, 6, 6, 3, 3, 1, 1, 1, 1, idx)
+        assert torch.equal(m1, m2)
+        a = oracle.scatter_gather(tiles, y, 6, 6, idx, m1, sc, sh, "identity", False)
+        assert torch.equal(a, ref.scatter_gather(tiles, y, 6, 6, idx, m1, sc, sh, "identity", False))
+        idx1 = oracle.reduce_mask(mask, 4, 4, 0)
+        x1 = torch.from_numpy(rs.standard_normal((B * idx1.shape[0], C, 4, 4)).astype(np.float32))
+        assert torch.equal(oracle.scatter_with_block_residual(tiles, y, x1, x, 1, 1, 1, 1, idx, idx1),
+                           ref.scatter_with_block_residual(tiles, y, x1, x, 1, 1, 1, 1, idx, idx1))
