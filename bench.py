@@ -591,6 +591,135 @@ def _hip():
     return hip
 
 
+def main_sd(args, world, rank, dev):
+    """--workload sd: BASELINE.json configs[3] -- the Stable Diffusion v1 U-Net (860 M parameters, random init) on a 64 x 64
+    latent with classifier-free-guidance batch 2, a 15 % square edit of the 512 x 512 image; N different edits of ONE original
+    image, one per GPU, the original's activation cache distributed from rank 0 (same job definition as the DDPM headline)."""
+    from sige_amd import hip, parallel
+    from sige_amd.utils import downsample_mask
+    from sige_amd.workloads.sd_unet import SDConfig, SDUNet
+
+    hip.lib()
+    torch.manual_seed(0)
+    model = SDUNet(SDConfig()).eval()
+    n_params = sum(p.numel() for p in model.parameters())
+    model = model.to(dev).to(memory_format=torch.channels_last)
+    model.set_scatter_inplace(True)
+    model.set_compute_dtype(args.dtype)
+    gen = torch.Generator().manual_seed(1)
+    cl = lambda t_: t_.to(dev).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    x0, noise = cl(torch.randn(2, 4, 64, 64, generator=gen)), cl(torch.randn(2, 4, 64, 64, generator=gen))
+    ctx = torch.randn(2, 77, 768, generator=gen).to(dev)
+    ts = torch.full((2,), 500.0, device=dev)
+    mask512 = torch.zeros(512, 512, dtype=torch.bool, device=dev)
+    mask512[150 - 8 * rank:348 - 8 * rank, 120 + 8 * rank:318 + 8 * rank] = True  # 15 %, every rank its own region
+    masks = downsample_mask(mask512, min_res=8, dilation=1)  # stable-diffusion/runners/inpainting_runner.py:50-54
+    x1 = cl(x0 + noise * masks[(64, 64)])
+    run = lambda x: model(x, ts, context=ctx)  # noqa: E731
+    res = {}
+    with torch.no_grad():
+        model.set_mode("full")
+        dense_ms = None
+        if rank == 0:
+            dense_ms, _, gd = _replay_ms(lambda: run(x1), k=10, warm=2)
+            del gd
+        run(x0 if rank == 0 else torch.zeros_like(x0))
+        flat = parallel.pack_caches(model)
+        n_cached = len(parallel.cache_slots(model))
+        method, dist_info = None, {}
+        if world > 1:
+            for meth in (["broadcast", "scatter_allgather"] if args.distribute == "auto" else [args.distribute]):
+                try:
+                    ms = []
+                    for _ in range(2):
+                        dist.barrier()
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        parallel.distribute_cache(flat, src=0, method=meth)
+                        torch.cuda.synchronize()
+                        ms.append((time.perf_counter() - t0) * 1e3)
+                    v = parallel.max_over_ranks(min(ms), device=dev)
+                    dist_info[meth + "_ms"] = round(v, 3)
+                    if method is None or v < dist_info[method + "_ms"]:
+                        method = meth
+                except Exception as e:
+                    dist_info[meth + "_error"] = repr(e)[:200]
+            parallel.refresh_derived(model)
+            chk = flat.double().sum().reshape(1)
+            lo, hi = chk.clone(), chk.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            dist_info["cache_identical_on_all_ranks"] = bool(lo.item() == hi.item())
+        model.set_masks(masks)
+        model.set_mode("sparse")
+        n0 = hip.launch_count()
+        run(x1)
+        launches = hip.launch_count() - n0
+        g, out = capture_fn(lambda: run(x1))
+        for _ in range(args.warmup):
+            g.replay()
+
+        def job(with_distribution):
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            t_d = 0.0
+            if with_distribution:
+                parallel.distribute_cache(flat, src=0, method=method)
+                parallel.refresh_derived(model)
+                torch.cuda.synchronize()
+                t_d = time.perf_counter() - t0
+            for _ in range(args.steps):
+                g.replay()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            return parallel.max_over_ranks(time.perf_counter() - t0, device=dev), parallel.max_over_ranks(t_d, device=dev)
+
+        dt_steady, _ = job(False)
+        dt, dist_s = job(True) if world > 1 else (dt_steady, 0.0)
+        assert torch.isfinite(out).all()
+    if rank == 0:
+        ms_steady = dt_steady * 1e3 / args.steps
+        line = {"metric": "Stable Diffusion v1 U-Net sparse (SIGE) forwards/s", "value": round(world * args.steps / dt, 2),
+                "unit": "forward/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(dt * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": args.dtype, "data": "synthetic",
+                "config": {"workload": "Stable Diffusion v1 U-Net (320 ch, mult 1-2-4-4, %.0fM params, random init), latent [2,4,64,64] "
+                                       "(CFG batch 2), text context [2,77,768], 15%% square edit of the 512x512 image, %d different edits of "
+                                       "one original image, one per GPU, hipGraph replay, NHWC, in-place scatter buffers%s"
+                                       % (n_params / 1e6, world, "; the timed job = distribute the original's cache from rank 0 (%s) + %d "
+                                          "sparse forwards per rank" % (method, args.steps) if world > 1 else ""),
+                           "edit_ratio": 0.15, "batch_per_gpu": 2, "parallelism": "dp%d" % world},
+                "forward_ms": round(ms_steady, 4), "dense_forward_ms": round(dense_ms, 3), "speedup_vs_dense": round(dense_ms / ms_steady, 2),
+                "hip_kernel_launches_per_forward": launches, "cache_bytes": int(flat.numel() * 4), "cached_tensors": n_cached,
+                "active_token_ratio_64": round(float(masks[(64, 64)].float().mean()), 4)}
+        if world > 1:
+            step_s = dt_steady / args.steps
+            line["multi_gpu"] = dict(dist_info, method=method, cache_distribution_ms=round(dist_s * 1e3, 3),
+                                     value_steady_state_cache_resident=round(world * args.steps / dt_steady, 2),
+                                     value_cache_refreshed_every_step=round(world / (dist_s + step_s), 2))
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def capture_fn(fn):
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            fn()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            out = fn()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    return g, out
+
+
 # ---------------------------------------------------------------- launching --
 def self_launch(args):
     """`python bench.py --gpus N` without a torchrun environment: re-exec under torch.distributed.run, one rank per GPU."""
@@ -658,6 +787,9 @@ def main():
     ap.add_argument("--f16-sweep", default="0.01,0.02,0.05,0.1,0.2",
                     help="edit ratios of the f16-compute section a default (f32) run appends ('' = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the GauGAN (configs[2]) and SD transformer (configs[3]) sections")
+    ap.add_argument("--workload", default="ddpm", choices=["ddpm", "sd"],
+                    help="ddpm = BASELINE configs[1] (the headline; what a plain `bench.py` measures); sd = configs[3], the Stable "
+                         "Diffusion v1 U-Net, N different edits of one original image one per GPU")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "exercise the multi-rank code path without N GPUs)")
     ap.add_argument("--oversubscribe", action="store_true", help="debugging: all ranks on GPU 0 (with --backend gloo): runs the "
@@ -685,6 +817,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+
+    if args.workload == "sd":
+        return main_sd(args, world, rank, dev)
 
     from sige_amd import hip, parallel
     from sige_amd.utils import dilate_mask, downsample_mask

@@ -25,40 +25,51 @@ _ALIGN = 64  # floats; keeps every view 256-byte aligned for 16-byte vector acce
 _PAD = 64 * 48  # floats: world sizes 1, 2, 3, 4, 6, 8, 12, 16 divide the padded buffer into 256-byte aligned chunks
 
 
-def cache_slots(model: torch.nn.Module, derived: bool = False) -> List[Tuple[dict, object, object]]:
-    """(dict, key, tuple-index-or-None) of every cached tensor, in module order
-    (identical on every rank that built the same model).  `derived=False` (default) lists only what
-    the full pass produced -- Scatter / ScatterGather / ScatterWithBlockResidual `original_*` and the
-    models' cached affines (38 tensors / 673 MB for DDPM-256); `derived=True` adds the
-    activated copies (`activated_outputs`), which every rank can recompute from those."""
+def cache_slots(model: torch.nn.Module, derived: bool = False) -> List[Tuple]:
+    """Where every cached tensor of `model` lives, in module order (identical on every rank that built the same model):
+    ("dict", d, key, tuple-index-or-None) or ("attr", module, name, tuple-index-or-None).
+    `derived=False` (default) lists only what the full pass produced -- Scatter / ScatterGather / ScatterWithBlockResidual
+    `original_*` (incl. the K / V caches of the SD transformer, which are Scatter modules), the models' cached affines
+    (`affine` dicts or tuples, `scale` / `shift`) and the cross-attention's `cached_k` / `cached_v` (38 big
+    tensors / 673 MB for DDPM-256); `derived=True` adds the activated copies (`activated_outputs`), which every rank can
+    recompute from those."""
     slots = []
     attrs = ("original_outputs", "original_residuals") + (("activated_outputs",) if derived else ())
     for m in model.modules():
         for attr in attrs:
             d = getattr(m, attr, None)
             if isinstance(d, dict):
-                slots.extend((d, k, None) for k in sorted(d))
+                slots.extend(("dict", d, k, None) for k in sorted(d))
         aff = getattr(m, "affine", None)  # workload models keep (scale, shift, ...) tuples here
         if isinstance(aff, dict):
             for k in sorted(aff):
                 if isinstance(aff[k], tuple):
-                    slots.extend((aff, k, i) for i in range(len(aff[k])))
+                    slots.extend(("dict", aff, k, i) for i in range(len(aff[k])))
+        elif isinstance(aff, tuple) and all(isinstance(t, torch.Tensor) for t in aff):
+            slots.extend(("attr", m, "affine", i) for i in range(len(aff)))
+        for name in ("scale", "shift", "cached_k", "cached_v"):
+            t = m.__dict__.get(name)  # (plain attributes only: not parameters / buffers / sub-modules)
+            if isinstance(t, torch.Tensor) and t.dtype == torch.float32:
+                slots.append(("attr", m, name, None))
     return slots
 
 
 def _get(slot):
-    d, k, i = slot
-    return d[k] if i is None else d[k][i]
+    kind, holder, k, i = slot
+    v = holder[k] if kind == "dict" else getattr(holder, k)
+    return v if i is None else v[i]
 
 
 def _set(slot, value):
-    d, k, i = slot
-    if i is None:
-        d[k] = value
+    kind, holder, k, i = slot
+    if i is not None:
+        cur = list(holder[k] if kind == "dict" else getattr(holder, k))
+        cur[i] = value
+        value = tuple(cur)
+    if kind == "dict":
+        holder[k] = value
     else:
-        lst = list(d[k])
-        lst[i] = value
-        d[k] = tuple(lst)
+        setattr(holder, k, value)
 
 
 def refresh_derived(model: torch.nn.Module) -> None:
@@ -97,7 +108,7 @@ def pack_caches(model: torch.nn.Module) -> torch.Tensor:
             b, c, h, w = t.shape
             view = flat[off:off + t.numel()].view(b, h, w, c).permute(0, 3, 1, 2)
         else:
-            view = flat[off:off + t.numel()].view(t.shape)
+            view = flat[off:off + t.numel()].view(t.shape)  # (a non-dense view -- e.g. an expanded affine -- is stored dense)
         view.copy_(t)
         _set(s, view)
         off += size

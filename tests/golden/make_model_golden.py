@@ -25,7 +25,7 @@ import torch  # noqa: E402
 
 sys.path.append(REPO)
 from oracle import build_ref  # noqa: E402
-from tests.golden.model_init import gaugan_labels, init_by_name, sd_transformer_inputs, summarize  # noqa: E402
+from tests.golden.model_init import gaugan_labels, init_by_name, sd_transformer_inputs, sd_unet_inputs, summarize  # noqa: E402
 
 build_ref.build(REF, verbose=False)
 ref_cpu = build_ref.load()
@@ -40,9 +40,9 @@ torch.set_num_threads(8)
 out = {}
 
 
-def put(prefix, t, cstep=1):
-    s = summarize(t, cstep=cstep)
-    out[prefix + "/cstep"] = np.array([cstep], dtype=np.int64)
+def put(prefix, t, cstep=1, step=4):
+    s = summarize(t, step=step, cstep=cstep)
+    out[prefix + "/cstep"] = np.array([cstep, step], dtype=np.int64)
     out[prefix + "/sub"] = s["sub"]
     out[prefix + "/sums"] = np.array([s["sum"], s["abs_sum"]], dtype=np.float64)
     out[prefix + "/shape"] = np.array(s["shape"], dtype=np.int64)
@@ -112,12 +112,48 @@ def sd_transformer():
     sys.path.pop(1)
 
 
+def sd_unet():
+    """stable-diffusion/ldm/modules/diffusionmodules/sige_openaimodel.py::SIGEUNetModel with SD v1's structure (2 res blocks per
+    level, channel mult 1-2-4-4, transformers at ds 1 / 2 / 4, 8 heads, context 768) at model_channels 128 (the full 320 is
+    860 M parameters: too slow for a CPU fixture), 64 x 64 latent, CFG batch 2, 15 % edit (inpainting_runner.py:50-54)."""
+    sys.path.insert(1, os.path.join(REF, "stable-diffusion"))
+    oc, lc = types.ModuleType("omegaconf"), types.ModuleType("omegaconf.listconfig")
+
+    class ListConfig(list):
+        pass
+
+    lc.ListConfig = ListConfig
+    oc.listconfig = lc
+    sys.modules["omegaconf"], sys.modules["omegaconf.listconfig"] = oc, lc
+    from ldm.modules.diffusionmodules.sige_openaimodel import SIGEUNetModel
+
+    model = SIGEUNetModel(image_size=32, in_channels=4, model_channels=128, out_channels=4, num_res_blocks=2,
+                          attention_resolutions=[4, 2, 1], channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True,
+                          transformer_depth=1, context_dim=768, use_checkpoint=False, legacy=False).eval()
+    init_by_name(model)
+    x0, noise, ctx, ts, mask512 = sd_unet_inputs()
+    masks = downsample_mask(mask512, min_res=8, dilation=1)
+    x1 = x0 + noise * masks[(64, 64)]
+    with torch.no_grad():
+        model.set_mode("full")
+        full = model(x0, ts, context=ctx)
+        model.set_masks(masks)
+        model.set_mode("sparse")
+        sparse = model(x1, ts, context=ctx)
+    put("sdunet/full", full, step=2)
+    put("sdunet/sparse", sparse, step=2)
+    print("sd unet (mc 128, %.1fM params): |sparse - full| max %.3f, |out| max %.2f"
+          % (sum(p.numel() for p in model.parameters()) / 1e6, float((sparse - full).abs().max()), float(sparse.abs().max())))
+    sys.path.pop(1)
+
+
 if __name__ == "__main__":
     import warnings
 
     warnings.simplefilter("ignore")
     gaugan()
     sd_transformer()
+    sd_unet()
     path = os.path.join(HERE, "models.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

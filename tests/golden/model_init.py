@@ -57,3 +57,17 @@ def sd_transformer_inputs(C=320, H=64, W=64, B=2, ctx_dim=768, seed=5):
     mask512 = torch.zeros(512, 512, dtype=torch.bool)
     mask512[150:348, 120:318] = True  # 198^2 / 512^2 = 15 %
     return x0, noise, ctx, mask512
+
+
+def sd_unet_inputs(B=2, ctx_dim=768, seed=9):
+    """(original latent, noise, context, timesteps, mask512) of the SD U-Net fixture: CFG batch 2, 64 x 64 latent, 15 % edit."""
+    import numpy as np
+
+    rs = np.random.RandomState(seed)
+    x0 = torch.from_numpy(rs.standard_normal((B, 4, 64, 64)).astype(np.float32))
+    noise = torch.from_numpy(rs.standard_normal((B, 4, 64, 64)).astype(np.float32))
+    ctx = torch.from_numpy(rs.standard_normal((B, 77, ctx_dim)).astype(np.float32))
+    ts = torch.full((B,), 500.0)
+    mask512 = torch.zeros(512, 512, dtype=torch.bool)
+    mask512[150:348, 120:318] = True
+    return x0, noise, ctx, ts, mask512

@@ -136,12 +136,17 @@ def main():
         lc.ListConfig = ListConfig
         oc.listconfig = lc
         sys.modules["omegaconf"], sys.modules["omegaconf.listconfig"] = oc, lc
-        from ldm.modules.diffusionmodules.sige_openaimodel import SIGEUNetModel
+        if a.stack == "ours-workload":
+            from sige_amd.workloads.sd_unet import SDConfig, SDUNet
 
-        model = SIGEUNetModel(image_size=32, in_channels=4, model_channels=64, out_channels=4, num_res_blocks=1,
-                              attention_resolutions=[4, 2, 1], channel_mult=[1, 2, 4, 4], num_heads=4,
-                              use_spatial_transformer=True, transformer_depth=1, context_dim=96, use_checkpoint=False,
-                              legacy=False).eval()
+            model = SDUNet(SDConfig(model_channels=64, num_res_blocks=1, num_heads=4, context_dim=96)).eval()
+        else:
+            from ldm.modules.diffusionmodules.sige_openaimodel import SIGEUNetModel
+
+            model = SIGEUNetModel(image_size=32, in_channels=4, model_channels=64, out_channels=4, num_res_blocks=1,
+                                  attention_resolutions=[4, 2, 1], channel_mult=[1, 2, 4, 4], num_heads=4,
+                                  use_spatial_transformer=True, transformer_depth=1, context_dim=96, use_checkpoint=False,
+                                  legacy=False).eval()
         g = torch.Generator().manual_seed(1)
         for p in model.parameters():  # zero_module()-initialised convs would make every output trivially equal
             if p.abs().max() == 0:

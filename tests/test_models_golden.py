@@ -12,14 +12,15 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-from tests.golden.model_init import gaugan_labels, init_by_name, sd_transformer_inputs, summarize  # noqa: E402
+from tests.golden.model_init import gaugan_labels, init_by_name, sd_transformer_inputs, sd_unet_inputs, summarize  # noqa: E402
 
 GOLDEN = np.load(os.path.join(REPO, "tests", "golden", "models.npz"))
 ATOL = 1e-3  # north_star: activations within 1e-3 fp32 on conv-containing paths
 
 
 def _check(prefix, t, atol=ATOL):
-    s = summarize(t, cstep=int(GOLDEN[prefix + "/cstep"][0]))
+    cs = GOLDEN[prefix + "/cstep"]
+    s = summarize(t, cstep=int(cs[0]), step=int(cs[1]) if len(cs) > 1 else 4)
     assert list(GOLDEN[prefix + "/shape"]) == s["shape"]
     np.testing.assert_allclose(s["sub"], GOLDEN[prefix + "/sub"], rtol=0, atol=atol)
     n = float(np.prod(s["shape"]))
@@ -161,3 +162,51 @@ def test_sd_spatial_transformer_on_the_gpu_matches_the_reference_fixture(channel
     full, sparse = _sd_transformer("cuda", channels_last, inplace, sparse_kv)
     _check("sdt/full", full)
     _check("sdt/sparse", sparse)
+
+
+# ---- Stable Diffusion: the whole U-Net (structure of SD v1 at model_channels 128) -----------------------------------------
+def _sd_unet(device, channels_last, inplace):
+    from sige_amd.utils import downsample_mask
+    from sige_amd.workloads.sd_unet import SDConfig, SDUNet
+
+    model = SDUNet(SDConfig(model_channels=128)).eval()
+    init_by_name(model)
+    x0, noise, ctx, ts, mask512 = (t.to(device) for t in sd_unet_inputs())
+    model = model.to(device)
+    if channels_last:
+        model = model.to(memory_format=torch.channels_last)
+        x0, noise = x0.contiguous(memory_format=torch.channels_last), noise.contiguous(memory_format=torch.channels_last)
+    model.set_scatter_inplace(inplace)
+    masks = downsample_mask(mask512, min_res=8, dilation=1)
+    x1 = x0 + noise * masks[(64, 64)]
+    with torch.no_grad():
+        model.set_mode("full")
+        full = model(x0, ts, context=ctx)
+        model.set_masks(masks)
+        model.set_mode("sparse")
+        sparse = model(x1, ts, context=ctx)
+    return full, sparse
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels_last,inplace", [(False, False), (True, True)])
+def test_sd_unet_on_the_gpu_matches_the_reference_fixture(channels_last, inplace):
+    """BASELINE.json configs[3] at model level: the SD v1 U-Net structure (137 M parameters at model_channels 128), CFG batch
+    2, 15 % edit, through the HIP kernels in the reference's layout and channels-last with in-place persistent outputs."""
+    full, sparse = _sd_unet("cuda", channels_last, inplace)
+    _check("sdunet/full", full)
+    _check("sdunet/sparse", sparse)
+
+
+def test_sd_unet_workload_on_the_oracle_backend_matches_the_reference_fixture():
+    from oracle import oracle
+    from sige_amd import runtime
+
+    torch.set_num_threads(8)
+    runtime.register_backend("cpu", oracle)
+    try:
+        full, sparse = _sd_unet("cpu", False, False)
+    finally:
+        runtime.unregister_backend("cpu")
+    _check("sdunet/full", full, 2e-5)
+    _check("sdunet/sparse", sparse, 1e-4)

@@ -102,3 +102,14 @@ def test_sd_spatial_transformer_workload_equals_reference_module(tmp_path):
         ours = _run_model("ours-workload", "sdt", state, str(tmp_path / "ours.npz"), extra)
         np.testing.assert_allclose(ours["full"], ref["full"], rtol=0, atol=2e-5)
         np.testing.assert_allclose(ours["sparse"], ref["sparse"], rtol=0, atol=1e-4)
+
+
+def test_sd_unet_workload_equals_reference_model(tmp_path):
+    """sige_amd/workloads/sd_unet.py loads the reference SIGEUNetModel's state dict and reproduces its full and sparse
+    outputs (CFG batch 2, per-sample cached affines, timestep embedding folded into the cached shift, deferred skip cat)."""
+    state = str(tmp_path / "state.pt")
+    ref = _run_model("reference", "sd", state, str(tmp_path / "ref.npz"))
+    for extra in ((), ("--deferred",)):
+        ours = _run_model("ours-workload", "sd", state, str(tmp_path / "ours.npz"), extra)
+        np.testing.assert_allclose(ours["full"], ref["full"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(ours["sparse"], ref["sparse"], rtol=0, atol=2e-4)
