@@ -1035,6 +1035,7 @@ def main():
                 tr, tracer.log = tracer.log, None
                 costs = [op_cost(n, a, k) for n, a, k, o in tr]
                 flops = sum(c[2] for c in costs if c[0] != "dense_conv_mfma")
+                _, _, kern_r, conv_tf_r, _ = kernel_families(tr)  # the metric: active-block conv TFLOP/s vs edit ratio
                 gs, outs = capture(model, xs, t)
                 k = max(20, args.steps // 4)
                 ms = timed_replays(gs, k, 5, 1) * 1e3 / k
@@ -1042,7 +1043,10 @@ def main():
                 n256 = max([a[3].shape[0] for n, a, kk, o in tr if n in ("gather", "gather_cl", "gather_conv_cl") and a[0].shape[2] == 256]
                            + [a[2].shape[0] for n, a, kk, o in tr if n == "gather_conv" and a[0].shape[2] == 256] + [0])
                 sweep.append({"edit_ratio": r, "forward_ms": round(ms, 3), "speedup_vs_dense": round(dense_ms / ms, 2),
-                              "active_tiles_256": n256, "block_conv_GFLOP": round(flops / 1e9, 2)})
+                              "active_tiles_256": n256, "block_conv_GFLOP": round(flops / 1e9, 2),
+                              "block_conv_TFLOPs": round(conv_tf_r, 2), "block_conv_frac_of_mfma_peak": round(conv_tf_r / mfma_peak, 4),
+                              "block_conv_us": kern_r.get("block_conv_mfma", {}).get("us_total"),
+                              "dense_remainder_us": kern_r.get("dense_conv_mfma", {}).get("us_total")})
                 del gs, tr, outs
 
         # ---- f16 compute (BASELINE.json configs[4]): the same forward with fp16 operands on the fp16 matrix cores ----
@@ -1054,11 +1058,17 @@ def main():
             for r in [float(v) for v in args.f16_sweep.split(",")]:
                 xs = prepare(r)
                 model(xs, t)
+                tracer.log = []
+                model(xs, t)
+                tr16, tracer.log = tracer.log, None
+                _, _, _, conv_tf_r, _ = kernel_families(tr16)
                 gs, outs = capture(model, xs, t)
                 k = max(20, args.steps // 4)
                 ms = timed_replays(gs, k, 5, 1) * 1e3 / k
                 gpu_out_f16[r] = outs.float().cpu()
-                rows.append({"edit_ratio": r, "forward_ms": round(ms, 3), "speedup_vs_dense_fp32": round(dense_ms / ms, 2)})
+                rows.append({"edit_ratio": r, "forward_ms": round(ms, 3), "speedup_vs_dense_fp32": round(dense_ms / ms, 2),
+                             "block_conv_TFLOPs": round(conv_tf_r, 2)})
+                del tr16
                 del gs, outs
             xs = prepare(args.ratio)
             model(xs, t)
