@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Profiling target: the standalone data-movement launches of bench.py's `data_movement` table (gather, scatter_gather, scatter
+out-of-place / in-place; NCHW and channels-last; 15 % / C 256 / B 2 and 1.2 % / C 128 / B 1), once more under rocprofv3 so that
+every row of that table has a profiler row next to it:
+
+    rocprofv3 --kernel-trace --output-format csv -d OUT -o dm -- python tools/profile_data_movement.py
+    python tools/trace_summary.py OUT/*kernel_trace.csv --replays 1 --by-grid --gap-ms 100 --out profiles/r2z_kerneltrace_data_movement.csv
+"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from sige_amd import hip  # noqa: E402
+
+hip.lib()
+dev = torch.device("cuda")
+torch.zeros(1, device=dev)
+torch.cuda.synchronize()
+time.sleep(0.3)
+res = bench.data_movement_rooflines(hip, dev)
+torch.cuda.synchronize()
+print(json.dumps(res["data_movement"]))
