@@ -283,7 +283,9 @@ static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
     a.nchunks = waves == 8 ? nchunks4 / 2 : ceil_div(a.Cin, cc4);
     // which operand should stay XCD-local: weights (dense layers) or input tiles (many active tiles)
     const double wbytes = (double)a.Cout * a.Cin * KH * KH, abytes = (double)a.T * a.Cin * R * R;
-    a.ng_fast = wbytes > abytes;
+    // (0: M blocks fastest -- small launches; 1: weights dominate; 2: activations dominate and there are enough M blocks
+    //  to give every XCD whole ones)
+    a.ng_fast = wbytes > abytes ? 1 : ((a.mbk >= 16 && a.ngk > 1) ? 2 : 0);
     if (mt == 16)  // the MT=16 layout follows the MT=32 one
         a.packed += PREC == 1 ? packed_units_h(a.Cout, a.Cin, KH * KH, 32) : packed_floats(a.Cout, a.Cin, KH * KH, 32);
     // K split (channels-last launches that came with a workspace)

@@ -163,7 +163,7 @@ struct ConvArgs {
     // ((off+idx)/stride), clipped, + residual[B,Cout,Ho,Wo] (dense layers: all tiles active)
     const float *residual;
     int Ho, Wo, offH, offW, strH, strW;
-    // grid decomposition: blockIdx.x -> (mb, ng); ng_fast = consecutive workgroups (= consecutive
+    // grid decomposition: blockIdx.x -> (mb, ng); ng_fast = 2: XCD-grouped by M block (see the kernel); ng_fast = 1: consecutive workgroups (= consecutive
     // XCDs) take different output-channel blocks, so each XCD's L2 streams 1/8 of the weights
     int mbk, ngk, ng_fast;
     // cross-workgroup K split: grid.y = ksplit workgroups share one output block, `out` is a workspace of
@@ -298,8 +298,16 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
     const int lane = tid & 63;
     const int kq = lane / G::MT, j = lane % G::MT;
     int mb, ng;
-    if (a.ng_fast) { ng = blockIdx.x % a.ngk; mb = blockIdx.x / a.ngk; }
-    else { mb = blockIdx.x % a.mbk; ng = blockIdx.x / a.mbk; }
+    if (a.ng_fast == 1) { ng = blockIdx.x % a.ngk; mb = blockIdx.x / a.ngk; }
+    else if (a.ng_fast == 2) {
+        // activation-dominant launches: all output-channel blocks of one M block on ONE XCD (workgroup b runs on XCD
+        // b % 8), so the M block's input tiles are fetched into one L2 instead of into up to ngk of them; the grid is
+        // padded to 8 * ceil(mbk / 8) * ngk and the surplus workgroups leave here (before any barrier)
+        const int jj = blockIdx.x >> 3;
+        mb = (blockIdx.x & 7) + 8 * (jj / a.ngk);
+        ng = jj % a.ngk;
+        if (mb >= a.mbk) return;
+    } else { mb = blockIdx.x % a.mbk; ng = blockIdx.x / a.mbk; }
     SIGE_PROBE(6);  // first kernel arguments are in registers
     const int Cin = a.Cin;
     const int HW = (SRC == SRC_GATHER) ? (a.H >> a.up) * (a.W >> a.up) : a.H * a.W;  // pixels of the SOURCE tensor
@@ -959,13 +967,15 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
 }
 
 // ---- launch ------------------------------------------------------------------
+inline int conv_grid_x(const ConvArgs &a) { return a.ng_fast == 2 ? 8 * ((a.mbk + 7) / 8) * a.ngk : a.mbk * a.ngk; }
+
 template <typename G, int NB, int SRC, int DST, int LAYOUT, int W>
 void launch_conv_geo(ConvArgs a, int mode, hipStream_t st);
 
 // mode: MODE_* (host side maps (scale, shift, activation) onto it)
 #define SIGE_CONV_LAUNCH3(G, NB, SRC, DST, LAY, W)                                                        \
     template <> void launch_conv_geo<G, NB, SRC, DST, LAY, W>(ConvArgs a, int mode, hipStream_t st) {     \
-        const dim3 grid(a.mbk * a.ngk, a.ksplit);                                                         \
+        const dim3 grid(conv_grid_x(a), a.ksplit);                                                        \
         if (mode == MODE_AFFINE_SWISH) conv_mfma_kernel<G, NB, SRC, MODE_AFFINE_SWISH, DST, LAY, W><<<grid, 64 * W, 0, st>>>(a); \
         else if (mode == MODE_AFFINE) conv_mfma_kernel<G, NB, SRC, MODE_AFFINE, DST, LAY, W><<<grid, 64 * W, 0, st>>>(a);        \
         else conv_mfma_kernel<G, NB, SRC, MODE_RAW, DST, LAY, W><<<grid, 64 * W, 0, st>>>(a);             \
@@ -974,7 +984,7 @@ void launch_conv_geo(ConvArgs a, int mode, hipStream_t st);
 // explicit-instantiation helper used by the per-geometry translation units
 #define SIGE_CONV_INSTANTIATE(G, NB, LAY, W)                                                              \
     template <> void launch_conv_geo<G, NB, SRC_TILES, DST_TILES, LAY, W>(ConvArgs a, int, hipStream_t st) { \
-        conv_mfma_kernel<G, NB, SRC_TILES, MODE_RAW, DST_TILES, LAY, W><<<dim3(a.mbk * a.ngk, a.ksplit), 64 * W, 0, st>>>(a); \
+        conv_mfma_kernel<G, NB, SRC_TILES, MODE_RAW, DST_TILES, LAY, W><<<dim3(conv_grid_x(a), a.ksplit), 64 * W, 0, st>>>(a); \
     }                                                                                                     \
     SIGE_CONV_LAUNCH3(G, NB, SRC_GATHER, DST_TILES, LAY, W)                                               \
     SIGE_CONV_LAUNCH3(G, NB, SRC_GATHER, DST_NCHW, LAY, W)                                                \
