@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SIGE_HIP_VERSION 100 /* 0.1.0 */
+#define SIGE_HIP_VERSION 200 /* 0.2.0: round 2 -- f16-compute convs, mask pipeline, SPADE modulation, launch counter */
 
 enum {
     SIGE_HIP_OK = 0,

@@ -10,6 +10,6 @@ SIGEConv2d / SIGEModel) behind the reference's own `sige.nn` module API.
 `sige`, so model files written against the reference (`from sige.nn import ...`)
 load unchanged.
 """
-__version__ = "0.1.0"
+__version__ = "0.2.0"
 
 from . import nn, utils  # noqa: E402,F401
