@@ -260,8 +260,21 @@ int sige_hip_scatter_gather_conv_scatter_nhwc_f16c(
  * per-launch choice.  Results do not depend on it beyond fp32 summation order. */
 int sige_hip_block_conv_force_tile(int mt, int nb);
 /* Tuning knob: waves per workgroup of the channels-last stride-1 kernels: 4, 8 (two waves per SIMD),
- * or 0 = per launch (8 when the grid has fewer than 384 workgroups). */
+ * or 0 = per launch (8 when the grid has fewer than 160 workgroups). */
 int sige_hip_block_conv_force_waves(int waves);
+/* Horizontal fusion of the two independent convs at the head of a residual block.  After pair_begin() the next
+ * channels-last fp32 1x1 gather -> conv launch with raw staging (the block's shortcut) is HELD: the call returns
+ * SIGE_HIP_OK without launching.  The next channels-last fp32 3x3/s1 gather -> conv launch with affine + SiLU staging on
+ * the same stream and with the same destination kind (the block's conv1) then runs both in ONE kernel (workgroups of
+ * both convs side by side; the 1x1's own ~5 us launch disappears).  Any other conv launch, and pair_end(), launch the held
+ * conv on its own first, so results never depend on whether a pair was formed.  Per host thread; the pointers of the
+ * held call must stay valid until it has been launched.  pairs_fused(): how many pairs this process has formed. */
+int sige_hip_conv_pair_begin(void);
+int sige_hip_conv_pair_end(void);
+int64_t sige_hip_conv_pairs_fused(void);
+/* Tuning knob: cross-workgroup K split of the channels-last launches that come with a workspace: 1..8 = at most this
+ * many splits whatever the grid size (clamped to the workspace and to >= 2 channel chunks per split), 0 = per launch. */
+int sige_hip_block_conv_force_ksplit(int ksplit);
 
 /* ---- fused gather -> conv and scatter_gather -> conv ------------------------
  * The same MFMA conv with the producer of its input tiles fused into the

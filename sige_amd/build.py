@@ -14,7 +14,8 @@ CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIB_DIR, "libsige_hip.so")
 SOURCES = ["api.hip", "gather.hip", "scatter.hip", "reduce_mask.hip", "mask_pipeline.hip", "block_conv.hip", "conv_k3s1.hip", "conv_k1.hip",
-           "conv_k3s2.hip", "conv_k3s1_nhwc.hip", "conv_k1_nhwc.hip", "conv_k3s2_nhwc.hip", "conv_k3s1_nhwc_w8.hip", "conv_k1_nhwc_w8.hip", "conv_k3s1_nhwc_h.hip", "conv_k1_nhwc_h.hip", "group_norm.hip", "attention.hip", "nhwc_ops.hip", "conv_out.hip", "conv_in.hip"]
+           "conv_k3s2.hip", "conv_k3s1_nhwc.hip", "conv_k1_nhwc.hip", "conv_k3s2_nhwc.hip", "conv_k3s1_nhwc_w8.hip", "conv_k1_nhwc_w8.hip", "conv_k3s1_nhwc_h.hip", "conv_k1_nhwc_h.hip",
+           "conv_pair_nhwc_t4.hip", "conv_pair_nhwc_t8.hip", "conv_pair_nhwc_f4.hip", "conv_pair_nhwc_f8.hip", "group_norm.hip", "attention.hip", "nhwc_ops.hip", "conv_out.hip", "conv_in.hip"]
 # -ffp-contract=off: the reference applies scale then shift as two separately
 # rounded fp32 ops (sige/cpu/gather.cpp:33-53); an fma would differ in the last bit.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
@@ -60,11 +61,13 @@ def build_probe(verbose: bool = True) -> str:
     """The measurement build of tools/conv_phase_probe.py: the conv translation units with -DSIGE_CONV_PROBE (phase
     timestamps inside the kernel) linked with the product's other objects into lib/libsige_hip_probe.so."""
     build(verbose=verbose)
-    pdir = os.path.join(LIB_DIR, "probe")
+    tag = os.environ.get("SIGE_PROBE_TAG", "")  # several measurement builds side by side (ablations): lib/libsige_hip_probe<tag>.so
+    only = os.environ.get("SIGE_PROBE_ONLY", "").split()  # restrict the -D build to these translation units
+    pdir = os.path.join(LIB_DIR, "probe" + tag)
     os.makedirs(pdir, exist_ok=True)
     objs, procs = [], []
     for src in SOURCES:
-        if src.startswith(("conv_k", "block_conv")):
+        if src.startswith(("conv_k", "conv_pair", "block_conv")) and (not only or src in only or src.startswith("block_conv")):
             obj = os.path.join(pdir, src.replace(".hip", ".o"))
             cmd = [_hipcc(), *FLAGS, "-DSIGE_CONV_PROBE", *os.environ.get("SIGE_PROBE_DEFS", "").split(),
                    "-I" + os.path.join(REPO, "include"), "-I" + CSRC, "-c",
@@ -76,7 +79,7 @@ def build_probe(verbose: bool = True) -> str:
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    out = os.path.join(LIB_DIR, "libsige_hip_probe.so")
+    out = os.path.join(LIB_DIR, "libsige_hip_probe%s.so" % tag)
     subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out])
     return out
 
@@ -93,7 +96,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
         objs.append(obj)
         # only translation units whose source (or any header) changed are recompiled
-        hdrs = headers if src.startswith(("conv_k", "block_conv")) else [h for h in headers if not h.endswith("conv_mfma.hpp")]
+        hdrs = headers if src.startswith(("conv_k", "conv_pair", "block_conv")) else [h for h in headers if not h.endswith("conv_mfma.hpp")]
         if not force and not _stale(obj, os.path.join(CSRC, src), hdrs):
             continue
         cmd = [_hipcc(), *FLAGS, "-I" + os.path.join(REPO, "include"), "-I" + CSRC, "-c",

@@ -194,11 +194,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_nhwc_kernel(const float *__
 // K split factor for a conv whose smallest-tile grid (16 pixels x 16 channels per workgroup) cannot
 // cover the chip: every wave then runs K/4 MFMA steps back to back however few tiles there are
 // (the 8x8 layers of the U-Net: 64 pixels, K = 4608..9216), so the chunks are shared out.
+static int g_force_ksplit = 0;  // sige_hip_block_conv_force_ksplit (benchmarking)
 static int ksplit_for(long blocks, int nchunks, int cap) {
     // (the second pass costs ~4.7 us per launch; measured on the DDPM-256 dense remainder the split still
     //  wins 140 us per forward: 923 vs 1064 us over its 58 conv launches)
-    if (cap <= 1 || blocks >= 224) return 1;
-    int s = (int)((224 + blocks - 1) / blocks);
+    if (cap <= 1 || (blocks >= 224 && !g_force_ksplit)) return 1;
+    int s = g_force_ksplit ? g_force_ksplit : (int)((224 + blocks - 1) / blocks);
     s = s < nchunks / 2 ? s : nchunks / 2;  // >= 2 chunks per split (the software pipeline's depth)
     s = s < 8 ? s : 8;
     s = s < cap ? s : cap;
@@ -232,24 +233,68 @@ extern "C" int sige_hip_conv_probe_clear(void) {
 }
 #endif
 
-template <int KH, int STR, int R, int SRC, int DST, int LAY, int PREC = 0>
-static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
+// ---- horizontal fusion: a residual block's 1x1 shortcut held back and launched WITH the block's conv1 ----
+// sige_hip_conv_pair_begin(): the next eligible 1x1 launch of this thread (channels-last gather -> conv, raw staging,
+// fp32) is recorded instead of launched; the next eligible 3x3 launch (gather + affine + SiLU -> conv, same stream and
+// destination kind) then runs both in one conv_pair_kernel launch.  Anything else -- another conv kind, or
+// sige_hip_conv_pair_end() -- launches the held conv on its own first, so results never depend on pairing.
+struct HeldConv {
+    bool active = false;
+    ConvArgs a;
+    int mode = 0, dst = 0;
+    hipStream_t st = nullptr;
+    int (*launch)(ConvArgs, int, hipStream_t) = nullptr;
+};
+static thread_local HeldConv g_held;
+static thread_local bool g_pairing = false;
+static long g_pairs_fused = 0;
+
+static int flush_held() {
+    if (!g_held.active) return SIGE_HIP_OK;
+    const HeldConv h = g_held;
+    g_held.active = false;
+    const bool p = g_pairing;
+    g_pairing = false;
+    const int rc = h.launch(h.a, h.mode, h.st);
+    note_launches(1);
+    g_pairing = p;
+    return rc;
+}
+
+template <typename GA, int NBA, typename GB, int DST, int W>
+void launch_conv_pair(ConvArgs a, ConvArgs b, hipStream_t st);
+#define SIGE_PAIR_DECLARE(DST, W)                                                                        \
+    template <> void launch_conv_pair<K31_16, 1, K11_16, DST, W>(ConvArgs, ConvArgs, hipStream_t);       \
+    template <> void launch_conv_pair<K31_16, 1, K11_32, DST, W>(ConvArgs, ConvArgs, hipStream_t);       \
+    template <> void launch_conv_pair<K31_16, 2, K11_16, DST, W>(ConvArgs, ConvArgs, hipStream_t);       \
+    template <> void launch_conv_pair<K31_16, 2, K11_32, DST, W>(ConvArgs, ConvArgs, hipStream_t);       \
+    template <> void launch_conv_pair<K31_32, 1, K11_16, DST, W>(ConvArgs, ConvArgs, hipStream_t);       \
+    template <> void launch_conv_pair<K31_32, 1, K11_32, DST, W>(ConvArgs, ConvArgs, hipStream_t);       \
+    template <> void launch_conv_pair<K31_32, 2, K11_16, DST, W>(ConvArgs, ConvArgs, hipStream_t);       \
+    template <> void launch_conv_pair<K31_32, 2, K11_32, DST, W>(ConvArgs, ConvArgs, hipStream_t);
+SIGE_PAIR_DECLARE(DST_TILES, 4) SIGE_PAIR_DECLARE(DST_TILES, 8) SIGE_PAIR_DECLARE(DST_NCHW, 4) SIGE_PAIR_DECLARE(DST_NCHW, 8)
+
+struct ConvPlan { int mt, nb, waves; };
+
+// Everything a launch decides on the host: output block, waves, grid order, K split.  `want_waves` != 0 / `nb1`: the
+// constraints of the second conv of a pair (same workgroup size as the first, NB = 1, no K split: cap = 1).
+template <int KH, int STR, int R, int SRC, int LAY, int PREC>
+static int plan_conv(ConvArgs &a, int cap, int want_waves, bool nb1, ConvPlan &p) {
     using G32 = std::conditional_t<PREC == 1, ConvGeoH<KH, STR, R, 32>, ConvGeo<KH, STR, R, 32>>;
     using G16 = std::conditional_t<PREC == 1, ConvGeoH<KH, STR, R, 16>, ConvGeo<KH, STR, R, 16>>;
-    constexpr bool kHasNB2 = STR == 1;
+    const bool kHasNB2 = STR == 1 && !nb1;
     auto blocks = [&](int tpb, int mt, int nb) { return (long)ceil_div(a.T, tpb) * ceil_div(a.Cout, mt * nb); };
     // constraints of the staging path (conv_mfma.hpp): a fused torch.cat must split on a chunk
     // boundary; a per-batch affine needs every M block inside one batch
     auto usable = [&](int mt) {
-        const int cc = mt == 32 ? G32::CC : G16::CC, tpb = mt == 32 ? G32::TPB : G16::TPB;
+        const int cc = (mt == 32 ? G32::CC : G16::CC) * (want_waves == 8 ? 2 : 1), tpb = mt == 32 ? G32::TPB : G16::TPB;
         if (SRC == SRC_GATHER && a.Csplit != a.Cin && a.Csplit % cc) return false;
         if (SRC != SRC_TILES && a.aff_sb != 0 && a.B > 1 && a.N % tpb) return false;
         return true;
     };
-    const long kFill = 224;
+    const long kFill = want_waves ? 64 : 224;  // (a pair's second conv shares the chip with the first)
     int mt = 0, nb = 1;
-    if (g_force_mt) { mt = g_force_mt == 32 ? 32 : 16; nb = (g_force_nb == 2 && kHasNB2) ? 2 : 1; if (!usable(mt)) mt = 0; }
-    const int cap = (LAY == LAYOUT_NHWC && a.ws) ? a.ksplit_max : 1;
+    if (g_force_mt && !want_waves) { mt = g_force_mt == 32 ? 32 : 16; nb = (g_force_nb == 2 && kHasNB2) ? 2 : 1; if (!usable(mt)) mt = 0; }
     if (!mt && cap > 1 && usable(16) && blocks(G16::TPB, 16, 1) < kFill) {
         // too few tiles for any block shape: split K across workgroups, largest block that then fills the chip
         const int nc32 = ceil_div(a.Cin, G32::CC), nc16 = ceil_div(a.Cin, G16::CC);
@@ -276,9 +321,12 @@ static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
     // 8-wave workgroups (two waves per SIMD) when the grid cannot give every CU two 4-wave workgroups
     constexpr bool kHasW8 = LAY == LAYOUT_NHWC && STR == 1 && PREC == 0;
     int waves = 4;
-    if (kHasW8 && g_force_waves != 4 && (g_force_waves == 8 || (long)a.mbk * a.ngk < 160)) {
-        const bool cat_ok = !(SRC == SRC_GATHER && a.Csplit != a.Cin && a.Csplit % (2 * cc4));
-        if (cat_ok && a.Cin > cc4) waves = 8;
+    const bool w8_ok = kHasW8 && !(SRC == SRC_GATHER && a.Csplit != a.Cin && a.Csplit % (2 * cc4)) && a.Cin > cc4;
+    if (want_waves) {
+        if (want_waves == 8 && !w8_ok) return SIGE_HIP_EUNSUPPORTED;
+        waves = want_waves;
+    } else if (g_force_waves != 4 && (g_force_waves == 8 || (long)a.mbk * a.ngk < 160) && w8_ok) {
+        waves = 8;
     }
     a.nchunks = waves == 8 ? nchunks4 / 2 : ceil_div(a.Cin, cc4);
     // which operand should stay XCD-local: weights (dense layers) or input tiles (many active tiles)
@@ -292,14 +340,79 @@ static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
     a.ksplit = ksplit_for((long)a.mbk * a.ngk, a.nchunks, cap);
     a.chunks_per_split = ceil_div(a.nchunks, a.ksplit);
     a.ksplit = ceil_div(a.nchunks, a.chunks_per_split);
-    float *final_out = a.out;
-    if (a.ksplit > 1) a.out = a.ws;
 #ifdef SIGE_CONV_PROBE
     a.probe = conv_probe_buffer();
 #endif
+    p.mt = mt; p.nb = nb; p.waves = waves;
+    return SIGE_HIP_OK;
+}
+
+// conv A (planned: pa) + the held 1x1 conv in one launch; false: no pair kernel for this combination
+template <int DST>
+static bool launch_pair(const ConvArgs &a, const ConvPlan &pa, ConvArgs b, hipStream_t st) {
+    ConvPlan pb;
+    if (plan_conv<1, 1, 4, SRC_GATHER, LAYOUT_NHWC, 0>(b, 1, pa.waves, true, pb) != SIGE_HIP_OK) return false;
+#define SIGE_PAIR_GO(GA, NBA, W)                                                                         \
+    do {                                                                                                 \
+        if (pb.mt == 32) launch_conv_pair<GA, NBA, K11_32, DST, W>(a, b, st);                            \
+        else launch_conv_pair<GA, NBA, K11_16, DST, W>(a, b, st);                                        \
+    } while (0)
+#define SIGE_PAIR_W(W)                                                                                   \
+    do {                                                                                                 \
+        if (pa.mt == 32 && pa.nb == 2) SIGE_PAIR_GO(K31_32, 2, W);                                       \
+        else if (pa.mt == 32) SIGE_PAIR_GO(K31_32, 1, W);                                                \
+        else if (pa.nb == 2) SIGE_PAIR_GO(K31_16, 2, W);                                                 \
+        else SIGE_PAIR_GO(K31_16, 1, W);                                                                 \
+    } while (0)
+    if (pa.waves == 8) SIGE_PAIR_W(8); else SIGE_PAIR_W(4);
+#undef SIGE_PAIR_W
+#undef SIGE_PAIR_GO
+    ++g_pairs_fused;
+    return true;
+}
+
+template <int KH, int STR, int R, int SRC, int DST, int LAY, int PREC = 0>
+static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
+    using G32 = std::conditional_t<PREC == 1, ConvGeoH<KH, STR, R, 32>, ConvGeo<KH, STR, R, 32>>;
+    using G16 = std::conditional_t<PREC == 1, ConvGeoH<KH, STR, R, 16>, ConvGeo<KH, STR, R, 16>>;
+    constexpr bool kHasNB2 = STR == 1;
+    constexpr bool kPairLayout = SRC == SRC_GATHER && LAY == LAYOUT_NHWC && PREC == 0 && STR == 1;
+    constexpr bool kPairFirst = kPairLayout && KH == 3, kPairSecond = kPairLayout && KH == 1;
+    const bool may_pair = kPairFirst && g_held.active && mode == MODE_AFFINE_SWISH && g_held.st == st && g_held.dst == DST;
+    if (g_held.active && !may_pair) {
+        const int rc = flush_held();
+        if (rc != SIGE_HIP_OK) return rc;
+    }
+    if (kPairSecond && g_pairing && !g_held.active && mode == MODE_RAW && !g_force_mt) {
+        g_held.active = true; g_held.a = a; g_held.mode = mode; g_held.dst = DST; g_held.st = st;
+        g_held.launch = &launch_kind<KH, STR, R, SRC, DST, LAY, PREC>;
+        note_launches(-1);  // (the caller counts one launch per call: this one happens later, or inside its partner's)
+        return SIGE_HIP_OK;
+    }
+    const int cap = (LAY == LAYOUT_NHWC && a.ws) ? a.ksplit_max : 1;
+    ConvPlan p;
+    const int prc = plan_conv<KH, STR, R, SRC, LAY, PREC>(a, cap, 0, false, p);
+    if (prc != SIGE_HIP_OK) {
+        const int rc = flush_held();
+        return rc != SIGE_HIP_OK ? rc : prc;
+    }
+    const int mt = p.mt, nb = p.nb, waves = p.waves;
+    float *final_out = a.out;
+    if (a.ksplit > 1) a.out = a.ws;
     bool done = false;
+    if constexpr (kPairFirst) {
+        if (may_pair) {
+            done = launch_pair<DST>(a, p, g_held.a, st);
+            if (done) g_held.active = false;
+            else {
+                const int rc = flush_held();
+                if (rc != SIGE_HIP_OK) return rc;
+            }
+        }
+    }
+    constexpr bool kHasW8 = LAY == LAYOUT_NHWC && STR == 1 && PREC == 0;
     if constexpr (kHasW8) {
-        if (waves == 8) {
+        if (!done && waves == 8) {
             if (mt == 32 && nb == 2) launch_conv_geo<G32, 2, SRC, DST, LAY, 8>(a, mode, st);
             else if (mt == 32) launch_conv_geo<G32, 1, SRC, DST, LAY, 8>(a, mode, st);
             else if (nb == 2) launch_conv_geo<G16, 2, SRC, DST, LAY, 8>(a, mode, st);
@@ -363,6 +476,26 @@ extern "C" int sige_hip_block_conv_force_tile(int mt, int nb) {
     if (nb < 0 || nb > 2) return SIGE_HIP_EINVAL;
     g_force_mt = mt;
     g_force_nb = nb;
+    return SIGE_HIP_OK;
+}
+
+extern "C" int sige_hip_conv_pair_begin(void) {
+    const int rc = flush_held();
+    g_pairing = true;
+    return rc != SIGE_HIP_OK ? rc : SIGE_HIP_OK;
+}
+
+extern "C" int sige_hip_conv_pair_end(void) {
+    g_pairing = false;
+    const int rc = flush_held();
+    return rc != SIGE_HIP_OK ? rc : launch_status(0);
+}
+
+extern "C" int64_t sige_hip_conv_pairs_fused(void) { return (int64_t)g_pairs_fused; }
+
+extern "C" int sige_hip_block_conv_force_ksplit(int ksplit) {
+    if (ksplit < 0 || ksplit > 8) return SIGE_HIP_EINVAL;
+    g_force_ksplit = ksplit;
     return SIGE_HIP_OK;
 }
 
@@ -545,7 +678,7 @@ extern "C" int sige_hip_conv_ksplit_hint(int T, int Cin, int Cout, int kH, int k
     if (T <= 0 || Cin <= 0 || Cout <= 0) return 1;
     const int px = (kH == 3 && strideH == 2) ? 4 : 16;  // output pixels per tile
     const long blocks16 = (long)ceil_div(T, 16 / px) * ceil_div(Cout, 16);
-    if (blocks16 >= 224) return 1;
+    if (blocks16 >= 224 && !g_force_ksplit) return 1;
     return 8;  // (the launch decides the actual factor, at most 8)
 }
 

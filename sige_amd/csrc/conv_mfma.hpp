@@ -199,6 +199,13 @@ struct ConvArgs {
 #else
 #define SIGE_PROBE(k)
 #endif
+// Ablations for the probe build (timing experiments only, results are WRONG): a bit mask of what the K loop leaves out.
+//   1 weight loads | 2 activation (slot) loads | 4 slot finish + LDS store | 8 the per-chunk barrier | 16 the A operand LDS reads
+#if defined(SIGE_CONV_PROBE) && defined(SIGE_ABL)
+#define SIGE_ABL_HAS(bit) (((SIGE_ABL) & (bit)) != 0)
+#else
+#define SIGE_ABL_HAS(bit) false
+#endif
 
 // SiLU for the fused staging path: v_exp_f32 + v_rcp_f32 (each <= 1 ulp) instead of
 // expf + IEEE division; |relative error| ~1e-6 (the standalone gather keeps the
@@ -263,8 +270,21 @@ enum { LAYOUT_NCHW = 0, LAYOUT_NHWC = 1 };
 // form for grids that cannot give every CU two workgroups.  The packed weight order
 // [ng][chunk][wave][f][lane] read with chunk' = chunk / 2, wave' = 4 * (chunk % 2) + wave is
 // exactly the 8-wave order, so both forms share one packed tensor (chunk count padded to even).
-template <typename G, int NB, int SRC, int MODE, int DST, int LAYOUT = LAYOUT_NCHW, int W = 4>
-__global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
+// LDS floats of one workgroup (the kernels below declare the array; the body only receives the pointer, so that two
+// bodies sharing a launch -- conv_pair_kernel -- share one allocation)
+template <typename G, int NB, int MODE, int LAYOUT, int W>
+__host__ __device__ constexpr int conv_lds_floats() {
+    constexpr int CCk = W * G::CW;
+    constexpr bool NHWC = LAYOUT == LAYOUT_NHWC;
+    constexpr int LDC = G::F16 ? CCk + 8 : CCk + 4;
+    constexpr int STAGE = NHWC ? (G::F16 ? G::TPB * G::RS * LDC / 2 : G::TPB * G::RS * LDC) : G::TPB * CCk * G::RS;
+    constexpr int TABF = MODE != MODE_RAW ? 2 * (CCk + 4) : 0;
+    return cmax(2 * STAGE + 2 * TABF, W * NB * G::MT * (G::MT + 4));
+}
+
+// The whole launch of one workgroup (bx, by) = what blockIdx would be in a launch of its own.
+template <typename G, int NB, int SRC, int MODE, int DST, int LAYOUT, int W>
+__device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, const int by, float *const smem) {
     constexpr bool F16 = G::F16;                 // fp16 operands in LDS / registers (ConvGeoH)
     using M = std::conditional_t<F16, MfmaH<G::MT>, Mfma<G::MT>>;
     static_assert(!F16 || LAYOUT == LAYOUT_NHWC, "the f16-compute kernels are channels-last");
@@ -289,7 +309,7 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
     constexpr int TABF = AFF ? 2 * TROW : 0;                   // scale row | shift row
     constexpr int RP = G::MT + 4;                              // padded row of the reduction buffer
     constexpr int LDS_FLOATS = cmax(2 * STAGE + 2 * TABF, W * NB * G::MT * RP);
-    __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
+    static_assert(LDS_FLOATS == conv_lds_floats<G, NB, MODE, LAYOUT, W>(), "conv_lds_floats() out of step with the body");
     float *const tab = smem + 2 * STAGE;
 
     SIGE_PROBE(0);  // entry
@@ -298,21 +318,21 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
     const int lane = tid & 63;
     const int kq = lane / G::MT, j = lane % G::MT;
     int mb, ng;
-    if (a.ng_fast == 1) { ng = blockIdx.x % a.ngk; mb = blockIdx.x / a.ngk; }
+    if (a.ng_fast == 1) { ng = bx % a.ngk; mb = bx / a.ngk; }
     else if (a.ng_fast == 2) {
         // activation-dominant launches: all output-channel blocks of one M block on ONE XCD (workgroup b runs on XCD
         // b % 8), so the M block's input tiles are fetched into one L2 instead of into up to ngk of them; the grid is
         // padded to 8 * ceil(mbk / 8) * ngk and the surplus workgroups leave here (before any barrier)
-        const int jj = blockIdx.x >> 3;
-        mb = (blockIdx.x & 7) + 8 * (jj / a.ngk);
+        const int jj = bx >> 3;
+        mb = (bx & 7) + 8 * (jj / a.ngk);
         ng = jj % a.ngk;
         if (mb >= a.mbk) return;
-    } else { mb = blockIdx.x % a.mbk; ng = blockIdx.x / a.mbk; }
+    } else { mb = bx % a.mbk; ng = bx / a.mbk; }
     SIGE_PROBE(6);  // first kernel arguments are in registers
     const int Cin = a.Cin;
     const int HW = (SRC == SRC_GATHER) ? (a.H >> a.up) * (a.W >> a.up) : a.H * a.W;  // pixels of the SOURCE tensor
-    // cross-workgroup K split (deep-K, small-M layers): blockIdx.y owns chunks [first, last]
-    const int split = blockIdx.y;
+    // cross-workgroup K split (deep-K, small-M layers): by owns chunks [first, last]
+    const int split = by;
     const int first = split * a.chunks_per_split;
     const int last = min(a.nchunks, first + a.chunks_per_split) - 1;
 
@@ -758,7 +778,7 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
         // all A values of the chunk up front: LDS reads overlap with the matrix pipe for free
         float av[G::L];
 #pragma unroll
-        for (int u = 0; u < G::L; ++u) av[u] = as[a_off(u)];
+        for (int u = 0; u < G::L; ++u) av[u] = SIGE_ABL_HAS(16) ? __builtin_bit_cast(float, 0x3f800000 + u + lane) : as[a_off(u)];
         static_for<0, G::L / 4>([&](auto g_tag) {
             constexpr int g = decltype(g_tag)::value;
             static_for<0, 4>([&](auto e_tag) {
@@ -773,17 +793,17 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
                 // staging slots spread evenly over the k-steps
                 static_for<(u * NS) / G::L, ((u + 1) * NS) / G::L>([&](auto i_tag) {
                     constexpr int i = decltype(i_tag)::value;
-                    slot_store(PAR ^ 1, i, nxt, tab + (PAR ^ 1) * TABF);
-                    slot_load(PAR ^ 1, i, c3);
+                    if (!SIGE_ABL_HAS(4)) slot_store(PAR ^ 1, i, nxt, tab + (PAR ^ 1) * TABF);
+                    if (!SIGE_ABL_HAS(2)) slot_load(PAR ^ 1, i, c3);
                 });
             });
             static_for<0, NB>([&](auto nb_tag) {
                 constexpr int nb = decltype(nb_tag)::value;
-                b_load(bset[PAR][nb][g], nb, g);
+                if (!SIGE_ABL_HAS(1)) b_load(bset[PAR][nb][g], nb, g);
             });
         });
         tab_store(tab + PAR * TABF);  // table of chunk+2 replaces the one this chunk's predecessor used
-        __syncthreads();
+        if (!SIGE_ABL_HAS(8)) __syncthreads();
         }
     };
 
@@ -968,6 +988,37 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
 
 // ---- launch ------------------------------------------------------------------
 inline int conv_grid_x(const ConvArgs &a) { return a.ng_fast == 2 ? 8 * ((a.mbk + 7) / 8) * a.ngk : a.mbk * a.ngk; }
+
+template <typename G, int NB, int SRC, int MODE, int DST, int LAYOUT = LAYOUT_NCHW, int W = 4>
+__global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[conv_lds_floats<G, NB, MODE, LAYOUT, W>()];
+    conv_mfma_body<G, NB, SRC, MODE, DST, LAYOUT, W>(a, blockIdx.x, blockIdx.y, smem);
+}
+
+// Two independent convs of a residual block in ONE launch (horizontal fusion): workgroups [0, na) run conv A
+// (3x3, gather + cached affine + SiLU: the block's conv1), the rest conv B (the 1x1 shortcut on the same input).  Both are
+// a few microseconds of work dominated by their start-up, and B's ~5 us launch disappears behind A.  A may be K-split over
+// gridDim.y; B never is (its workgroups with blockIdx.y > 0 leave at once).
+template <typename GA, int NBA, typename GB, int DST, int W>
+__global__ __launch_bounds__(64 * W) void conv_pair_kernel(const ConvArgs a, const ConvArgs b, const int na) {
+    constexpr int LA = conv_lds_floats<GA, NBA, MODE_AFFINE_SWISH, LAYOUT_NHWC, W>();
+    constexpr int LB = conv_lds_floats<GB, 1, MODE_RAW, LAYOUT_NHWC, W>();
+    __shared__ __attribute__((aligned(16))) float smem[cmax(LA, LB)];
+    if ((int)blockIdx.x < na)
+        conv_mfma_body<GA, NBA, SRC_GATHER, MODE_AFFINE_SWISH, DST, LAYOUT_NHWC, W>(a, blockIdx.x, blockIdx.y, smem);
+    else if (blockIdx.y == 0)
+        conv_mfma_body<GB, 1, SRC_GATHER, MODE_RAW, DST, LAYOUT_NHWC, W>(b, blockIdx.x - na, 0, smem);
+}
+
+template <typename GA, int NBA, typename GB, int DST, int W>
+void launch_conv_pair(ConvArgs a, ConvArgs b, hipStream_t st);
+
+#define SIGE_CONV_PAIR_INSTANTIATE(GA, NBA, GB, DST, W)                                                   \
+    template <> void launch_conv_pair<GA, NBA, GB, DST, W>(ConvArgs a, ConvArgs b, hipStream_t st) {      \
+        const int na = conv_grid_x(a);                                                                    \
+        conv_pair_kernel<GA, NBA, GB, DST, W><<<dim3(na + conv_grid_x(b), a.ksplit), 64 * W, 0, st>>>(a, b, na); \
+    }
+
 
 template <typename G, int NB, int SRC, int DST, int LAYOUT, int W>
 void launch_conv_geo(ConvArgs a, int mode, hipStream_t st);

@@ -71,6 +71,10 @@ _SIGNATURES = {
     "sige_hip_block_conv_direct_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_vp]),
     "sige_hip_block_conv_force_tile": (_c_int, [_c_int, _c_int]),
     "sige_hip_block_conv_force_waves": (_c_int, [_c_int]),
+    "sige_hip_block_conv_force_ksplit": (_c_int, [_c_int]),
+    "sige_hip_conv_pair_begin": (_c_int, []),
+    "sige_hip_conv_pair_end": (_c_int, []),
+    "sige_hip_conv_pairs_fused": (ctypes.c_int64, []),
     "sige_hip_attention_workspace": (_c_sz, [_c_int] * 3),
     "sige_hip_attention_f32": (_c_int, [_c_vp, _c_int, _c_int, _c_int, ctypes.c_float, _c_vp, _c_vp, _c_vp]),
     "sige_hip_copy_f32": (_c_int, [_c_vp, _c_vp, _c_sz, _c_vp]),
@@ -493,6 +497,48 @@ def conv_force_waves(waves: int = 0):
     _check(lib().sige_hip_block_conv_force_waves(waves), "conv_force_waves")
 
 
+_PAIR_KEEP = None
+
+
+class conv_pair:
+    """`with hip.conv_pair():` around the shortcut conv and the conv1 of a residual block (in that order, nothing else):
+    the 1x1 is held back and launched inside the 3x3's kernel (sige_hip_conv_pair_begin / _end, include/sige_hip.h).
+    Results do not depend on it; whatever cannot be paired is launched on its own, at the latest when the block ends."""
+
+    def __init__(self, like: Optional[torch.Tensor] = None):
+        self.like = like  # (a tensor of the convs' device: the held conv may be launched when the block ends)
+
+    def _on_device(self):
+        global _pending_device
+        if self.like is not None:
+            _pending_device = self.like.device.index
+
+    def __enter__(self):
+        global _PAIR_KEEP
+        self._on_device()
+        _check(lib().sige_hip_conv_pair_begin(), "conv_pair_begin")
+        _PAIR_KEEP = []
+        return self
+
+    def __exit__(self, *exc):
+        global _PAIR_KEEP
+        try:
+            self._on_device()
+            _check(lib().sige_hip_conv_pair_end(), "conv_pair_end")
+        finally:
+            _PAIR_KEEP = None
+        return False
+
+
+def conv_pairs_fused() -> int:
+    return int(lib().sige_hip_conv_pairs_fused())
+
+
+def conv_force_ksplit(ksplit: int = 0):
+    """Benchmark knob: cross-workgroup K split of the channels-last launches with a workspace (0 = automatic)."""
+    _check(lib().sige_hip_block_conv_force_ksplit(ksplit), "conv_force_ksplit")
+
+
 def _f32_packed(packed):
     if getattr(packed, "compute", "f32") != "f32":
         raise NotImplementedError("the f16-compute kernels are channels-last: pack with compute='f32' for NCHW tensors")
@@ -822,6 +868,8 @@ def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, a
     if status == UNSUPPORTED:
         return None
     _check(status, "gather_conv_cl")
+    if _PAIR_KEEP is not None:  # (conv_pair(): a held launch reads these after this call has returned)
+        _PAIR_KEEP.append((x, x2, idx, s_keep, t_keep, packed, bias_keep, out, ws, out_affine, full))
     return out
 
 

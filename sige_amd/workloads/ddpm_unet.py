@@ -17,6 +17,7 @@ Sparse-mode contract (what SIGE caches):
     pass feeds them to Gather / ScatterGather as the fused affine + SiLU.
   * resolutions below `sparse_threshold` run dense convs on the cached affine.
 """
+import contextlib
 import math
 from dataclasses import dataclass
 from typing import Optional, Tuple
@@ -52,6 +53,8 @@ class DDPMConfig:
     # conv1's epilogue applies the cached affine-2 + SiLU (and the ScatterGather cache keeps an activated copy),
     # so conv2 stages raw values: the activation is computed once per element, not once per output-channel block
     preactivate: bool = True
+    # launch the shortcut 1x1 of a ResBlock inside the kernel of its conv1 (sige_amd.hip.conv_pair: horizontal fusion)
+    pair_shortcut: bool = True
     # run the shortcut branch of a ResBlock (1x1 conv on the block input) on a second stream (it is independent of
     # conv1 -> conv2).  Measured on MI355X / ROCm 7.2: the cross-stream graph edges cost more than the overlap gains
     # (2.05 ms vs 1.82 ms per forward), so it is off by default.
@@ -109,6 +112,7 @@ class ResBlock(SIGEModule):
         self.plain = False
         self.preactivate = cfg.preactivate
         self.overlap = cfg.overlap_shortcut
+        self.pair = cfg.pair_shortcut
         self._side = None
 
     def clear_cache(self):
@@ -142,6 +146,14 @@ class ResBlock(SIGEModule):
             out.record_stream(cur)  # (allocated on the side stream, consumed on the current one)
 
         return out, join
+
+    def _pairing(self, t: torch.Tensor):
+        """Context for [shortcut conv, conv1] of a sparse-mode block: on the GPU the two share one launch."""
+        if self.pair and self.cin != self.cout and t.is_cuda and self.mode == "sparse":
+            from .. import hip
+
+            return hip.conv_pair(t)
+        return contextlib.nullcontext()
 
     def forward(self, x, temb: Optional[torch.Tensor]) -> torch.Tensor:
         """`x` may be a pair (h, skip): the up path's torch.cat, which the dense
@@ -194,9 +206,10 @@ class ResBlock(SIGEModule):
         s1, t1, s2, t2 = self.affine[self.cache_id]
         if self.sparse_main and self.preactivate and self.mode == "sparse":
             first = x.parts[0] if hasattr(x, "parts") else x
-            skip, join = (self._shortcut_async(lambda: self._shortcut(x), first) if self.cin != self.cout
-                          else (x, lambda: None))
-            h = self.conv1(self.main_gather(x, s1, t1), out_affine=(s2, t2, "swish"))
+            with self._pairing(first):
+                skip, join = (self._shortcut_async(lambda: self._shortcut(x), first) if self.cin != self.cout
+                              else (x, lambda: None))
+                h = self.conv1(self.main_gather(x, s1, t1), out_affine=(s2, t2, "swish"))
             tiles = self.scatter_gather(h, preactivated=True)
             join()
             return self.scatter.forward_fused(self.conv2, tiles, skip)
@@ -212,14 +225,19 @@ class ResBlock(SIGEModule):
         """Dense block on the cached affine: 2-3 fused launches (shortcut 1x1, conv1, conv2+skip)."""
         s1, t1, s2, t2 = self.affine[self.cache_id]
         join = lambda: None  # noqa: E731
+        if self.preactivate:
+            with self._pairing(x):
+                if self.cin == self.cout:
+                    skip = x if x2 is None else torch.cat([x, x2], dim=1)
+                else:
+                    skip, join = self._shortcut_async(lambda: fused_conv2d(self.nin_shortcut, x, x2=x2), x)
+                h = fused_conv2d(self.conv1, x, s1, t1, "swish", x2=x2, out_affine=(s2, t2, "swish"))
+            join()
+            return fused_conv2d(self.conv2, h, residual=skip)
         if self.cin == self.cout:
             skip = x if x2 is None else torch.cat([x, x2], dim=1)
         else:
             skip, join = self._shortcut_async(lambda: fused_conv2d(self.nin_shortcut, x, x2=x2), x)
-        if self.preactivate:
-            h = fused_conv2d(self.conv1, x, s1, t1, "swish", x2=x2, out_affine=(s2, t2, "swish"))
-            join()
-            return fused_conv2d(self.conv2, h, residual=skip)
         join()
         h = fused_conv2d(self.conv1, x, s1, t1, "swish", x2=x2)
         return fused_conv2d(self.conv2, h, s2, t2, "swish", residual=skip)

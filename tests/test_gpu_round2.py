@@ -382,3 +382,114 @@ def test_f16_compute_ddpm_forward_vs_fp32_oracle(hip):
     torch.testing.assert_close(f32.cpu(), sparse_c, rtol=0, atol=util.CONV_ATOL)
     torch.testing.assert_close(f16.cpu(), sparse_c, rtol=F16_RTOL, atol=F16_ATOL)
     assert (f16 - f32).abs().max() > 1e-6
+
+
+# ---- horizontal fusion: a residual block's 1x1 shortcut launched inside the kernel of its conv1 ---------------------
+def _pair_case(hip, res, c1, c2, cout, T, full, seed=0):
+    """(run_shortcut, run_conv1) of a residual block at `res`: both gather from the same (optionally concatenated) input."""
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g).to(DEV)  # noqa: E731
+    cin = c1 + c2
+    x, x2 = _cl(r(1, c1, res, res)), (_cl(r(1, c2, res, res)) if c2 else None)
+    w3, b3, w1, b1 = r(cout, cin, 3, 3) / (3 * cin ** 0.5), r(cout), r(cout, cin, 1, 1) / cin ** 0.5, r(cout)
+    sc, sh, os_, oh_ = r(1, cin, 1, 1), r(1, cin, 1, 1), r(cout), r(cout)
+    p3, p1 = hip.conv_pack_weights(w3, 6, 6, (1, 1)), hip.conv_pack_weights(w1, 4, 4, (1, 1))
+    if full:
+        i6, i4 = hip.all_tiles(res, res, (4, 4), (1, 1), (1, 1), DEV), hip.all_tiles(res, res, (4, 4), (1, 1), (0, 0), DEV)
+        f6, f4 = dict(offset=(1, 1), out_res=(res, res), residual=None), dict(offset=(0, 0), out_res=(res, res), residual=None)
+    else:
+        n = res // 4
+        cells = torch.randperm(n * n, generator=g)[:T]
+        i4 = torch.stack([cells // n * 4, cells % n * 4], 1).int().to(DEV)
+        i6, f6, f4 = (i4 - 1).contiguous(), None, None
+    shortcut = lambda: hip.gather_conv_cl(x, x2, (4, 4), i4, None, None, "identity", p1, b1, cout, (1, 1), (1, 1), full=f4)  # noqa: E731
+    conv1 = lambda: hip.gather_conv_cl(x, x2, (6, 6), i6, sc, sh, "swish", p3, b3, cout, (3, 3), (1, 1), full=f6,  # noqa: E731
+                                       out_affine=(os_, oh_, "swish"))
+    return shortcut, conv1
+
+
+@pytest.mark.parametrize("res,c1,c2,cout,T,full", [
+    (64, 128, 0, 256, 18, False),    # SIGE block, few tiles
+    (256, 128, 128, 128, 106, False),  # SIGE up-path block: fused torch.cat, many tiles
+    (128, 256, 128, 128, 40, False),
+    (32, 256, 256, 256, 0, True),    # dense remainder at 32x32
+    (16, 512, 512, 512, 0, True),    # 16x16: 8-wave workgroups
+    (8, 512, 512, 512, 0, True),     # 8x8: conv1 is K-split across workgroups (second pass), the shortcut rides along
+    (16, 256, 0, 512, 0, True),
+])
+def test_conv_pair_equals_separate_launches(hip, res, c1, c2, cout, T, full):
+    """sige_hip_conv_pair_begin / _end: the pair kernel runs the same two workgroup programs, so conv1 is bit-identical
+    to its own launch; the shortcut may pick another output block inside a pair (fp32 summation order only)."""
+    shortcut, conv1 = _pair_case(hip, res, c1, c2, cout, T, full)
+    want_s, want_c = shortcut(), conv1()
+    n0, f0 = hip.launch_count(), hip.conv_pairs_fused()
+    with hip.conv_pair(want_s):
+        got_s = shortcut()
+        got_c = conv1()
+    torch.cuda.synchronize()
+    assert hip.conv_pairs_fused() == f0 + 1, "no pair kernel for this combination"
+    ksplit_pass = 1 if (full and res == 8) else 0
+    assert hip.launch_count() == n0 + 1 + ksplit_pass
+    assert torch.equal(got_c, want_c)
+    torch.testing.assert_close(got_s, want_s, rtol=1e-5, atol=1e-5)
+
+
+def test_conv_pair_leftovers_are_launched(hip):
+    """A held shortcut with no partner is launched when the block ends, or in front of the next launch that is not a
+    conv1 -- order and results as without pairing."""
+    shortcut, conv1 = _pair_case(hip, 64, 128, 0, 256, 18, False, seed=1)
+    want_s, want_c = shortcut(), conv1()
+    f0, n0 = hip.conv_pairs_fused(), hip.launch_count()
+    with hip.conv_pair(want_s):
+        got_s = shortcut()              # held ...
+    torch.cuda.synchronize()            # ... and launched by pair_end
+    assert torch.equal(got_s, want_s) and hip.launch_count() == n0 + 1
+    with hip.conv_pair(want_s):
+        got_c = conv1()                 # a conv1 with nothing held: a plain launch
+        got_s2 = shortcut()             # held, launched at the end
+    torch.cuda.synchronize()
+    assert torch.equal(got_c, want_c) and torch.equal(got_s2, want_s)
+    with hip.conv_pair(want_s):
+        a = shortcut()                  # held
+        b = shortcut()                  # not a partner: the first one goes out on its own, this one is held in turn
+        c = conv1()                     # pairs with the second
+    torch.cuda.synchronize()
+    assert torch.equal(a, want_s) and torch.equal(c, want_c)
+    torch.testing.assert_close(b, want_s, rtol=1e-5, atol=1e-5)
+    assert hip.conv_pairs_fused() == f0 + 1
+    assert hip.launch_count() == n0 + 1 + 2 + 2
+    # outside a `with` nothing is held
+    assert torch.equal(shortcut(), want_s)
+
+
+def test_ddpm_forward_paired_vs_unpaired(hip):
+    """The benchmark network with and without the shortcut pairing: same outputs (fp32 summation order of the 1x1s),
+    20 launches fewer."""
+    import bench
+    from sige_amd.utils import dilate_mask, downsample_mask
+    from sige_amd.workloads.ddpm_unet import DDPMConfig, DDPMSparseUNet, ResBlock
+
+    torch.manual_seed(0)
+    model = DDPMSparseUNet(DDPMConfig()).eval().to(DEV).to(memory_format=torch.channels_last)
+    model.set_scatter_inplace(True)
+    x0, noise = bench.make_inputs()
+    mask = bench.edit_mask(0.012)
+    x0, x1, t = _cl(x0.to(DEV)), _cl((x0 + noise * mask).to(DEV)), torch.zeros(1, device=DEV)
+    outs, launches = [], []
+    with torch.no_grad():
+        model.set_mode("full")
+        model(x0, t)
+        model.set_masks(downsample_mask(dilate_mask(mask.to(DEV), 5), 8))
+        model.set_mode("sparse")
+        for pair in (False, True):
+            for m in model.modules():
+                if isinstance(m, ResBlock):
+                    m.pair = pair
+            model(x1, t)
+            n0, f0 = hip.launch_count(), hip.conv_pairs_fused()
+            outs.append(model(x1, t).clone())
+            launches.append((hip.launch_count() - n0, hip.conv_pairs_fused() - f0))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(outs[1], outs[0], rtol=0, atol=1e-4)
+    assert launches[0][1] == 0 and launches[1][1] >= 15, launches
+    assert launches[1][0] == launches[0][0] - launches[1][1], launches

@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--dense", action="store_true")
     ap.add_argument("--sparse", action="store_true")
     ap.add_argument("--tiles", default="auto,16x1,16x2,32x1,32x2")
+    ap.add_argument("--waves", default="0", help="waves per workgroup to sweep, e.g. 0,4,8 (0 = automatic)")
+    ap.add_argument("--ksplit", default="0", help="forced K splits to sweep, e.g. 0,2,4 (0 = automatic)")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--cl", action="store_true", help="dense cases in channels-last")
     a = ap.parse_args()
@@ -181,12 +183,19 @@ def main():
             else:
                 mt, nb = tile.split("x")
                 hip.conv_force_tile(int(mt), int(nb))
-            err = check()
-            us = graph_time(run, 4, reps=a.reps)
-            rec = dict(kind=kind, layer=name, shape=desc, tile=tile, us=round(us, 2), GFLOP=round(flop / 1e9, 4),
-                       TFLOPs=round(flop / us / 1e6, 2), frac=round(flop / us / 1e6 / PEAK_TF, 3), max_err=float("%.2e" % err))
-            print(json.dumps(rec), flush=True)
+            for waves in [int(v) for v in a.waves.split(",")]:
+                for ks in [int(v) for v in a.ksplit.split(",")]:
+                    hip.conv_force_waves(waves)
+                    hip.conv_force_ksplit(ks)
+                    err = check()
+                    us = graph_time(run, 4, reps=a.reps)
+                    rec = dict(kind=kind, layer=name, shape=desc, tile=tile, waves=waves, ksplit=ks, us=round(us, 2),
+                               GFLOP=round(flop / 1e9, 4), TFLOPs=round(flop / us / 1e6, 2),
+                               frac=round(flop / us / 1e6 / PEAK_TF, 3), max_err=float("%.2e" % err))
+                    print(json.dumps(rec), flush=True)
         hip.conv_force_tile(0, 0)
+        hip.conv_force_waves(0)
+        hip.conv_force_ksplit(0)
 
 
 if __name__ == "__main__":

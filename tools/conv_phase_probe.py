@@ -17,7 +17,8 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
-os.environ["SIGE_HIP_LIB"] = os.path.join(REPO, "sige_amd", "lib", "libsige_hip_probe.so")
+os.environ.setdefault("SIGE_HIP_LIB", os.path.join(REPO, "sige_amd", "lib", "libsige_hip_probe.so"))
+CASES = os.environ.get("SIGE_PROBE_CASES", "")  # e.g. "f32:A,B,D": compute types and case letters to run (default: all)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -48,6 +49,11 @@ def probe(fn):
 
 
 def report(name, fn):
+    if CASES:
+        comp, letter = name.split()[0], name.split()[1]
+        want_c, _, want_l = CASES.partition(":")
+        if comp not in want_c.split("+") or (want_l and letter not in want_l.split(",")):
+            return
     st, us = probe(fn)
     if len(st) == 0:
         print(json.dumps({"case": name, "error": "no stamps"}))
@@ -57,7 +63,7 @@ def report(name, fn):
            "7-1 weight / index-dependent / data loads issued": int(np.median(st[:, 1] - st[:, 7]))}
     span = int(st[:, 5].max() - st[:, 0].min())
     tick_us = us / max(span, 1)  # upper bound on the tick length: the span is shorter than the launch
-    row = {"case": name, "workgroups": int(len(st)), "graph_launch_us": round(us, 2),
+    row = {"lib": os.path.basename(os.environ["SIGE_HIP_LIB"]), "case": name, "workgroups": int(len(st)), "graph_launch_us": round(us, 2),
            "median_ticks": {"0-1 idx/map trips": int(np.median(d[:, 0])), "1-2 data arrives -> LDS": int(np.median(d[:, 1])),
                             "2-3 barrier": int(np.median(d[:, 2])), "3-4 K loop": int(np.median(d[:, 3])),
                             "4-5 reduce + epilogue": int(np.median(d[:, 4])), "0-5 total": int(np.median(st[:, 5] - st[:, 0]))},
