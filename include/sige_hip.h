@@ -275,6 +275,10 @@ int64_t sige_hip_conv_pairs_fused(void);
 /* Tuning knob: cross-workgroup K split of the channels-last launches that come with a workspace: 1..8 = at most this
  * many splits whatever the grid size (clamped to the workspace and to >= 2 channel chunks per split), 0 = per launch. */
 int sige_hip_block_conv_force_ksplit(int ksplit);
+/* Tuning knob: how a K-split launch is finished.  0 (default): inside the launch -- the last workgroup to finish an output
+ * block adds the partial copies of that block up in split order and runs the epilogue (tickets in a library-owned,
+ * per-device buffer); 1: by a second launch over the whole output.  Both add in the same order: identical results. */
+int sige_hip_block_conv_force_ksplit_pass(int second_pass);
 
 /* ---- fused gather -> conv and scatter_gather -> conv ------------------------
  * The same MFMA conv with the producer of its input tiles fused into the

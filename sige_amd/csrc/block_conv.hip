@@ -6,6 +6,8 @@
 // see a batch of T tiny 6x6 images) after a separate gather kernel
 // (sige/cuda/gather_kernel.cu:7-67) or scatter_gather kernel
 // (scatter_gather_kernel.cu:8-67).
+#include <mutex>
+
 #include "conv_mfma.hpp"
 
 namespace sige {
@@ -274,6 +276,46 @@ void launch_conv_pair(ConvArgs a, ConvArgs b, hipStream_t st);
     template <> void launch_conv_pair<K31_32, 2, K11_32, DST, W>(ConvArgs, ConvArgs, hipStream_t);
 SIGE_PAIR_DECLARE(DST_TILES, 4) SIGE_PAIR_DECLARE(DST_TILES, 8) SIGE_PAIR_DECLARE(DST_NCHW, 4) SIGE_PAIR_DECLARE(DST_NCHW, 8)
 
+// Tickets of the in-kernel K-split finish (conv_mfma.hpp): one int per output block of a split launch, zero whenever no
+// such launch is running.  One buffer per device: a ring for eager launches (a slice is only live while its launch runs;
+// 2^20 tickets = hundreds of launches in flight before a wrap could meet a running one) and a bump-allocated region for
+// launches recorded into a hipGraph, whose slice is baked into the graph and must never be handed out again.  nullptr
+// (first use during a capture, region exhausted, allocation failure): the launch falls back to the second pass.
+constexpr size_t kTicketRing = size_t(1) << 20, kTicketGraph = size_t(3) << 20;
+struct TicketPool { int32_t *buf = nullptr; size_t ring_pos = 0, graph_pos = 0; bool failed = false; };
+static TicketPool g_tickets[32];
+static std::mutex g_tickets_mu;
+static bool g_inkernel_splitk = true;  // sige_hip_block_conv_force_ksplit_pass (benchmarking)
+
+static int32_t *split_tickets(hipStream_t st, long blocks) {
+    int dev = -1;
+    if (!g_inkernel_splitk || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32 || blocks > (long)kTicketRing) return nullptr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) return nullptr;
+    const bool capturing = cs != hipStreamCaptureStatusNone;
+    std::lock_guard<std::mutex> lock(g_tickets_mu);
+    TicketPool &t = g_tickets[dev];
+    if (!t.buf) {
+        if (capturing || t.failed) return nullptr;
+        const size_t bytes = (kTicketRing + kTicketGraph) * sizeof(int32_t);
+        if (hipMalloc(&t.buf, bytes) != hipSuccess || hipMemset(t.buf, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            t.buf = nullptr; t.failed = true;
+            (void)hipGetLastError();
+            return nullptr;
+        }
+    }
+    if (capturing) {
+        if (t.graph_pos + blocks > kTicketGraph) return nullptr;
+        int32_t *p = t.buf + kTicketRing + t.graph_pos;
+        t.graph_pos += blocks;
+        return p;
+    }
+    if (t.ring_pos + blocks > kTicketRing) t.ring_pos = 0;
+    int32_t *p = t.buf + t.ring_pos;
+    t.ring_pos += blocks;
+    return p;
+}
+
 struct ConvPlan { int mt, nb, waves; };
 
 // Everything a launch decides on the host: output block, waves, grid order, K split.  `want_waves` != 0 / `nb1`: the
@@ -398,7 +440,11 @@ static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
     }
     const int mt = p.mt, nb = p.nb, waves = p.waves;
     float *final_out = a.out;
-    if (a.ksplit > 1) a.out = a.ws;
+    if (a.ksplit > 1) {
+        a.out = a.ws;
+        a.fout = final_out;
+        a.counters = split_tickets(st, (long)a.mbk * a.ngk);
+    }
     bool done = false;
     if constexpr (kPairFirst) {
         if (may_pair) {
@@ -428,7 +474,7 @@ static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
         if (mt == 32) launch_conv_geo<G32, 1, SRC, DST, LAY, 4>(a, mode, st);
         else launch_conv_geo<G16, 1, SRC, DST, LAY, 4>(a, mode, st);
     }
-    if (a.ksplit > 1) {
+    if (a.ksplit > 1 && !a.counters) {
         const size_t n4 = a.split_stride / 4;
         const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
         splitk_reduce_nhwc_kernel<<<grid, 256, 0, st>>>(a.ws, a.ksplit, a.split_stride, n4, a.Cout, a.bias, a.residual,
@@ -492,6 +538,11 @@ extern "C" int sige_hip_conv_pair_end(void) {
 }
 
 extern "C" int64_t sige_hip_conv_pairs_fused(void) { return (int64_t)g_pairs_fused; }
+
+extern "C" int sige_hip_block_conv_force_ksplit_pass(int second_pass) {
+    g_inkernel_splitk = second_pass == 0;
+    return SIGE_HIP_OK;
+}
 
 extern "C" int sige_hip_block_conv_force_ksplit(int ksplit) {
     if (ksplit < 0 || ksplit > 8) return SIGE_HIP_EINVAL;

@@ -183,6 +183,9 @@ struct ConvArgs {
     int up;          // GATHER: 1 = gather from the half-resolution tensor as if it were nearest-upsampled x2
     float *ws;       // host side: workspace for the partial outputs (nullptr / ksplit_max <= 1: no K split)
     int ksplit_max;  // host side: how many output copies `ws` holds
+    // K split finished inside the launch: one ticket per output block (zero between launches), and the real destination
+    int32_t *counters;
+    float *fout;
 #ifdef SIGE_CONV_PROBE
     unsigned long long *probe;  // tools/conv_phase_probe.py build only: 8 timestamps per workgroup
 #endif
@@ -270,6 +273,23 @@ enum { LAYOUT_NCHW = 0, LAYOUT_NHWC = 1 };
 // form for grids that cannot give every CU two workgroups.  The packed weight order
 // [ng][chunk][wave][f][lane] read with chunk' = chunk / 2, wave' = 4 * (chunk % 2) + wave is
 // exactly the 8-wave order, so both forms share one packed tensor (chunk count padded to even).
+// 16 bytes to / from the device's coherence point (two relaxed agent-scope 8-byte atomics: visible to every XCD without
+// cache maintenance) -- the partial sums of the in-kernel K-split finish
+__device__ __forceinline__ void coherent_store(float *p, float4 v) {
+    unsigned long long *q = reinterpret_cast<unsigned long long *>(p);
+    const unsigned long long lo = (unsigned long long)__builtin_bit_cast(unsigned, v.x) | ((unsigned long long)__builtin_bit_cast(unsigned, v.y) << 32);
+    const unsigned long long hi = (unsigned long long)__builtin_bit_cast(unsigned, v.z) | ((unsigned long long)__builtin_bit_cast(unsigned, v.w) << 32);
+    __hip_atomic_store(q, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4 coherent_load(const float *p) {
+    unsigned long long *q = reinterpret_cast<unsigned long long *>(const_cast<float *>(p));
+    const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float4(__builtin_bit_cast(float, (unsigned)lo), __builtin_bit_cast(float, (unsigned)(lo >> 32)),
+                       __builtin_bit_cast(float, (unsigned)hi), __builtin_bit_cast(float, (unsigned)(hi >> 32)));
+}
+
 // LDS floats of one workgroup (the kernels below declare the array; the body only receives the pointer, so that two
 // bodies sharing a launch -- conv_pair_kernel -- share one allocation)
 template <typename G, int NB, int MODE, int LAYOUT, int W>
@@ -410,7 +430,9 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
     float4 e_res[EPRE ? EU : 1];
     constexpr bool EPV = NHWC && W == 4;                  // per-channel epilogue vectors (bias, out_affine) fetched up front
     float4 e_bias[EPV ? EU : 1], e_os[EPV ? EU : 1], e_oh[EPV ? EU : 1];
-    const bool e_first_pass = a.ksplit <= 1;              // (K split: partial sums only, bias / residual in the second pass)
+    // (K split with a second launch: partial sums only, bias / residual in the second pass; with in-kernel finish any
+    //  workgroup may turn out to be the one that runs the epilogue)
+    const bool e_first_pass = a.ksplit <= 1 || a.counters != nullptr;
 
     if constexpr (NHWC) {
         // Channels-last: the slot set-up in load-batched, branch-free form.  Written slot by slot (index load ->
@@ -845,17 +867,83 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
     }
     __syncthreads();
 
-    // K split: every split writes its partial sums (no bias / residual) to its own copy of the output
-    // in the workspace; splitk_reduce_kernel adds them up in a fixed order (deterministic) with the epilogue
+    // K split: every split writes its partial sums (no bias / residual) to its own copy of the output in the workspace.
+    //   a.counters == nullptr: splitk_reduce_nhwc_kernel (a second launch) adds them up with the epilogue;
+    //   a.counters != nullptr: the LAST workgroup to finish an output block (a ticket per block, device-scope release /
+    //   acquire around it) adds the copies of ITS block up in split order -- the same fixed order, so the result is the
+    //   same bits as the second pass gives -- and runs the epilogue into a.fout.  No second launch.
+    const bool split_k = a.ksplit > 1;
     float *const outp = a.out + (size_t)split * a.split_stride;
-    const float *const biasp = a.ksplit > 1 ? nullptr : a.bias;
-    const float *const resp = a.ksplit > 1 ? nullptr : a.residual;
     if (NHWC) {
         // one float4 = 4 consecutive output channels of one pixel per lane and step
+        struct Unit { bool ok; size_t addr; int co, b, h, w; float4 rr; };
+        auto locate = [&](auto k_tag, const bool want_res) -> Unit {
+            constexpr int k = decltype(k_tag)::value;
+            Unit u;
+            u.ok = false; u.addr = 0; u.co = 0; u.b = 0; u.h = 0; u.w = 0; u.rr = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int o = tid + k * NT;
+            if (EU * NT > OUT_UNITS && o >= OUT_UNITS) return u;
+            const int nb = o / UNITS_NB, o1 = o - nb * UNITS_NB;
+            const int n4 = o1 % (G::MT / 4), m = o1 / (G::MT / 4);
+            const int t_l = m / G::PX, pxo = m % G::PX;
+            const int t = mb * G::TPB + t_l;
+            u.co = (ng * NB + nb) * G::MT + 4 * n4;
+            if (!(t < a.T && u.co < a.Cout)) return u;  // (Cout % 4 == 0: host side)
+            u.b = t / a.N;
+            if constexpr (DST == DST_TILES) {
+                u.ok = true;
+                u.addr = ((size_t)t * G::PX + pxo) * a.Cout + u.co;
+            } else if constexpr (EPRE) {
+                // (4 waves: pixel, address and residual were fetched with the prologue's loads)
+                u.ok = e_in[k]; u.h = e_h[k]; u.w = e_w[k]; u.addr = e_q[k]; u.rr = e_res[k];
+            } else {
+                const int n = t - u.b * a.N;
+                u.h = (a.offH + a.idx[2 * n]) / a.strH + pxo / G::RO;
+                u.w = (a.offW + a.idx[2 * n + 1]) / a.strW + pxo % G::RO;
+                u.ok = u.h >= 0 && u.h < a.Ho && u.w >= 0 && u.w < a.Wo;
+                u.addr = u.ok ? (((size_t)u.b * a.Ho + u.h) * a.Wo + u.w) * a.Cout + u.co : 0;
+                if (u.ok && a.residual && want_res) u.rr = *reinterpret_cast<const float4 *>(a.residual + u.addr);
+            }
+            return u;
+        };
+        // bias, residual (block residual), the consumer's affine + activation, store: the epilogue proper
+        auto emit = [&](auto k_tag, const Unit &u, float4 s, float *dst) {
+            constexpr int k = decltype(k_tag)::value;
+            if (a.bias) {
+                float4 bb;
+                if constexpr (EPV) bb = e_bias[k];
+                else bb = *reinterpret_cast<const float4 *>(a.bias + u.co);
+                s.x += bb.x; s.y += bb.y; s.z += bb.z; s.w += bb.w;
+            }
+            if constexpr (DST != DST_TILES) {
+                if (a.residual) {
+                    const float4 rr = u.rr;
+                    s.x += rr.x; s.y += rr.y; s.z += rr.z; s.w += rr.w;
+                    if (a.x1) {
+                        const int t1 = a.table1[(u.h / a.R1) * a.gW1 + u.w / a.S1];
+                        if (t1 >= 0) {
+                            const float4 xv = *reinterpret_cast<const float4 *>(
+                                a.x1 + ((((size_t)u.b * a.N1 + t1) * a.R1 + u.h % a.R1) * a.S1 + u.w % a.S1) * a.Cout + u.co);
+                            s.x += xv.x - rr.x; s.y += xv.y - rr.y; s.z += xv.z - rr.z; s.w += xv.w - rr.w;
+                        }
+                    }
+                }
+            }
+            if (a.oscale) {
+                float4 os, oh;
+                if constexpr (EPV) { os = e_os[k]; oh = e_oh[k]; }
+                else { os = *reinterpret_cast<const float4 *>(a.oscale + u.co); oh = *reinterpret_cast<const float4 *>(a.oshift + u.co); }
+                s.x = os.x * s.x; s.y = os.y * s.y; s.z = os.z * s.z; s.w = os.w * s.w;
+                s.x = oh.x + s.x; s.y = oh.y + s.y; s.z = oh.z + s.z; s.w = oh.w + s.w;
+                if (a.oact == SIGE_HIP_ACT_SWISH) { s.x = swish(s.x); s.y = swish(s.y); s.z = swish(s.z); s.w = swish(s.w); }
+            }
+            *reinterpret_cast<float4 *>(dst + u.addr) = s;
+        };
         static_for<0, EU>([&](auto k_tag) {
             constexpr int k = decltype(k_tag)::value;
+            const Unit u = locate(k_tag, !split_k);
+            if (!u.ok) return;
             const int o = tid + k * NT;
-            if (EU * NT > OUT_UNITS && o >= OUT_UNITS) return;
             const int nb = o / UNITS_NB, o1 = o - nb * UNITS_NB;
             const int n4 = o1 % (G::MT / 4), m = o1 / (G::MT / 4);
             const float *r0 = red + (nb * G::MT + m) * RP + 4 * n4;
@@ -865,65 +953,43 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
                 const float4 v = *reinterpret_cast<const float4 *>(r0 + w * NB * G::MT * RP);
                 s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             }
-            const int t_l = m / G::PX, pxo = m % G::PX;
-            const int t = mb * G::TPB + t_l, co = (ng * NB + nb) * G::MT + 4 * n4;
-            if (t < a.T && co < a.Cout) {  // (Cout % 4 == 0: host side)
-                if (biasp) {
-                    float4 bb;
-                    if constexpr (EPV) bb = e_bias[k];
-                    else bb = *reinterpret_cast<const float4 *>(biasp + co);
-                    s.x += bb.x; s.y += bb.y; s.z += bb.z; s.w += bb.w;
-                }
-                auto post = [&](float4 v) -> float4 {
-                    if (a.oscale && a.ksplit <= 1) {
-                        float4 os, oh;
-                        if constexpr (EPV) { os = e_os[k]; oh = e_oh[k]; }
-                        else { os = *reinterpret_cast<const float4 *>(a.oscale + co); oh = *reinterpret_cast<const float4 *>(a.oshift + co); }
-                        v.x = os.x * v.x; v.y = os.y * v.y; v.z = os.z * v.z; v.w = os.w * v.w;
-                        v.x = oh.x + v.x; v.y = oh.y + v.y; v.z = oh.z + v.z; v.w = oh.w + v.w;
-                        if (a.oact == SIGE_HIP_ACT_SWISH) { v.x = swish(v.x); v.y = swish(v.y); v.z = swish(v.z); v.w = swish(v.w); }
-                    }
-                    return v;
-                };
-                if constexpr (DST == DST_TILES) {
-                    *reinterpret_cast<float4 *>(outp + ((size_t)t * G::PX + pxo) * a.Cout + co) = post(s);
-                } else {
-                    // (4 waves: pixel, address, bias and residual were fetched with the prologue's loads)
-                    bool inside;
-                    int h, w;
-                    size_t q;
-                    float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if constexpr (EPRE) {
-                        inside = e_in[k]; h = e_h[k]; w = e_w[k]; q = e_q[k]; rr = e_res[k];
-                    } else {
-                        const int bq = t / a.N, n = t - bq * a.N;
-                        h = (a.offH + a.idx[2 * n]) / a.strH + pxo / G::RO;
-                        w = (a.offW + a.idx[2 * n + 1]) / a.strW + pxo % G::RO;
-                        inside = h >= 0 && h < a.Ho && w >= 0 && w < a.Wo;
-                        q = inside ? (((size_t)bq * a.Ho + h) * a.Wo + w) * a.Cout + co : 0;
-                        if (inside && resp) rr = *reinterpret_cast<const float4 *>(resp + q);
-                    }
-                    if (inside) {
-                        if (resp) {
-                            s.x += rr.x; s.y += rr.y; s.z += rr.z; s.w += rr.w;
-                            if (a.x1) {
-                                const int b = t / a.N;
-                                const int t1 = a.table1[(h / a.R1) * a.gW1 + w / a.S1];
-                                if (t1 >= 0) {
-                                    const float4 xv = *reinterpret_cast<const float4 *>(
-                                        a.x1 + ((((size_t)b * a.N1 + t1) * a.R1 + h % a.R1) * a.S1 + w % a.S1) * a.Cout + co);
-                                    s.x += xv.x - rr.x; s.y += xv.y - rr.y; s.z += xv.z - rr.z; s.w += xv.w - rr.w;
-                                }
-                            }
-                        }
-                        *reinterpret_cast<float4 *>(outp + q) = post(s);
-                    }
-                }
-            }
+            if (!split_k) emit(k_tag, u, s, a.out);
+            else if (!a.counters) *reinterpret_cast<float4 *>(outp + u.addr) = s;
+            else coherent_store(outp + u.addr, s);
         });
+        if (split_k && a.counters) {
+            // The partial sums went out as device-coherent (relaxed, agent-scope atomic) stores: they are at the device's
+            // coherence point once they have completed (vmcnt 0) -- no L2 write-back / invalidate of the whole XCD, which a
+            // release / acquire fence would cost every workgroup (measured: +11 us per launch).  Then the block's ticket.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int32_t *const cnt = a.counters + mb * a.ngk + ng;
+            if (tid == 0) red[0] = __builtin_bit_cast(float, __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            __syncthreads();
+            const int ticket = __builtin_bit_cast(int, red[0]);
+            if (ticket == a.ksplit - 1) {
+                if (tid == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+                static_for<0, EU>([&](auto k_tag) {
+                    const Unit u = locate(k_tag, true);
+                    if (!u.ok) return;
+                    // all (<= 8) copies in flight at once, added in split order
+                    float4 pv[8];
+#pragma unroll
+                    for (int sidx = 0; sidx < 8; ++sidx)
+                        pv[sidx] = coherent_load(a.out + (size_t)(sidx < a.ksplit ? sidx : a.ksplit - 1) * a.split_stride + u.addr);
+                    float4 s = pv[0];
+#pragma unroll
+                    for (int sidx = 1; sidx < 8; ++sidx)
+                        if (sidx < a.ksplit) { s.x += pv[sidx].x; s.y += pv[sidx].y; s.z += pv[sidx].z; s.w += pv[sidx].w; }
+                    emit(k_tag, u, s, a.fout);
+                });
+            }
+        }
         SIGE_PROBE(5);  // stores issued
         return;
     }
+    const float *const biasp = split_k ? nullptr : a.bias;
+    const float *const resp = split_k ? nullptr : a.residual;
     // NCHW: one float4 (4 consecutive pixels of one tile and one output channel) per lane and step
     constexpr int P4 = G::PX / 4;                       // float4 per (tile, channel)
 #pragma unroll

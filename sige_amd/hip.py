@@ -72,6 +72,7 @@ _SIGNATURES = {
     "sige_hip_block_conv_force_tile": (_c_int, [_c_int, _c_int]),
     "sige_hip_block_conv_force_waves": (_c_int, [_c_int]),
     "sige_hip_block_conv_force_ksplit": (_c_int, [_c_int]),
+    "sige_hip_block_conv_force_ksplit_pass": (_c_int, [_c_int]),
     "sige_hip_conv_pair_begin": (_c_int, []),
     "sige_hip_conv_pair_end": (_c_int, []),
     "sige_hip_conv_pairs_fused": (ctypes.c_int64, []),
@@ -537,6 +538,11 @@ def conv_pairs_fused() -> int:
 def conv_force_ksplit(ksplit: int = 0):
     """Benchmark knob: cross-workgroup K split of the channels-last launches with a workspace (0 = automatic)."""
     _check(lib().sige_hip_block_conv_force_ksplit(ksplit), "conv_force_ksplit")
+
+
+def conv_force_ksplit_pass(second_pass: bool = False):
+    """Benchmark knob: finish K-split launches with a second launch (True) instead of inside the launch (default)."""
+    _check(lib().sige_hip_block_conv_force_ksplit_pass(int(bool(second_pass))), "conv_force_ksplit_pass")
 
 
 def _f32_packed(packed):

@@ -385,7 +385,7 @@ def test_f16_compute_ddpm_forward_vs_fp32_oracle(hip):
 
 
 # ---- horizontal fusion: a residual block's 1x1 shortcut launched inside the kernel of its conv1 ---------------------
-def _pair_case(hip, res, c1, c2, cout, T, full, seed=0):
+def _pair_case(hip, res, c1, c2, cout, T, full, seed=0, residual=False):
     """(run_shortcut, run_conv1) of a residual block at `res`: both gather from the same (optionally concatenated) input."""
     g = torch.Generator().manual_seed(seed)
     r = lambda *s: torch.randn(*s, generator=g).to(DEV)  # noqa: E731
@@ -396,7 +396,8 @@ def _pair_case(hip, res, c1, c2, cout, T, full, seed=0):
     p3, p1 = hip.conv_pack_weights(w3, 6, 6, (1, 1)), hip.conv_pack_weights(w1, 4, 4, (1, 1))
     if full:
         i6, i4 = hip.all_tiles(res, res, (4, 4), (1, 1), (1, 1), DEV), hip.all_tiles(res, res, (4, 4), (1, 1), (0, 0), DEV)
-        f6, f4 = dict(offset=(1, 1), out_res=(res, res), residual=None), dict(offset=(0, 0), out_res=(res, res), residual=None)
+        f6 = dict(offset=(1, 1), out_res=(res, res), residual=_cl(r(1, cout, res, res)) if residual else None)
+        f4 = dict(offset=(0, 0), out_res=(res, res), residual=None)
     else:
         n = res // 4
         cells = torch.randperm(n * n, generator=g)[:T]
@@ -428,8 +429,7 @@ def test_conv_pair_equals_separate_launches(hip, res, c1, c2, cout, T, full):
         got_c = conv1()
     torch.cuda.synchronize()
     assert hip.conv_pairs_fused() == f0 + 1, "no pair kernel for this combination"
-    ksplit_pass = 1 if (full and res == 8) else 0
-    assert hip.launch_count() == n0 + 1 + ksplit_pass
+    assert hip.launch_count() == n0 + 1  # (8x8: the K split of conv1 is finished inside the launch, too)
     assert torch.equal(got_c, want_c)
     torch.testing.assert_close(got_s, want_s, rtol=1e-5, atol=1e-5)
 
@@ -493,3 +493,41 @@ def test_ddpm_forward_paired_vs_unpaired(hip):
     torch.testing.assert_close(outs[1], outs[0], rtol=0, atol=1e-4)
     assert launches[0][1] == 0 and launches[1][1] >= 15, launches
     assert launches[1][0] == launches[0][0] - launches[1][1], launches
+
+
+@pytest.mark.parametrize("res,c1,c2,cout,residual", [(8, 512, 512, 512, False), (8, 512, 0, 512, True), (16, 512, 512, 512, True),
+                                                      (8, 512, 0, 256, True)])
+def test_ksplit_finished_inside_the_launch(hip, res, c1, c2, cout, residual):
+    """Cross-workgroup K split: the last workgroup of an output block adds the partial copies up in split order and runs the
+    epilogue -- bit-identical to the second-pass kernel, one launch instead of two; the tickets are back at zero afterwards
+    and no workgroup reads a stale partial sum (two different inputs alternate over the same workspace memory, eagerly and
+    in graph replays)."""
+    convs = [_pair_case(hip, res, c1, c2, cout, 0, True, seed=3 + i, residual=residual)[1] for i in range(2)]
+    try:
+        hip.conv_force_ksplit(4)
+        hip.conv_force_ksplit_pass(True)
+        n0 = hip.launch_count()
+        want = [c() for c in convs]
+        assert hip.launch_count() == n0 + 4
+        assert not torch.equal(want[0], want[1])
+        hip.conv_force_ksplit_pass(False)
+        n0 = hip.launch_count()
+        got = [convs[i % 2]() for i in range(60)]
+        assert hip.launch_count() == n0 + 60
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, want[i % 2]) for i, o in enumerate(got))
+        del got
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            convs[0]()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=s):
+                outs = [convs[i % 2]() for i in range(6)]
+        for _ in range(20):
+            g.replay()
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, want[i % 2]) for i, o in enumerate(outs))
+    finally:
+        hip.conv_force_ksplit(0)
+        hip.conv_force_ksplit_pass(False)
