@@ -89,6 +89,23 @@ def main():
         report("%s A' same, raw staging" % compute,
                lambda: hip.gather_conv_cl(x, None, (6, 6), idx, None, None, "identity", p, b, C, (3, 3), (1, 1),
                                           full=dict(offset=(1, 1), out_res=(32, 32), residual=res)))
+        # F: dense 16x16, fused cat 512 + 512 -> 512 (K = 9216): the deep-K layers of the up path, 4 and 8 waves per workgroup
+        Cf = 512
+        xf, xf2 = cl(torch.randn(1, Cf, 16, 16, device=dev)), cl(torch.randn(1, Cf, 16, 16, device=dev))
+        wf = torch.randn(Cf, 2 * Cf, 3, 3, device=dev) / 96
+        bf = torch.randn(Cf, device=dev)
+        scf, shf = torch.randn(1, 2 * Cf, 1, 1, device=dev), torch.randn(1, 2 * Cf, 1, 1, device=dev)
+        idxf = hip.all_tiles(16, 16, (4, 4), (1, 1), (1, 1), dev)
+        pf = hip.conv_pack_weights(wf, 6, 6, (1, 1), compute)
+        for waves in ((4, 8) if compute == "f32" else (4,)):
+            hip.conv_force_waves(waves)
+            report("%s F%d dense 16x16 cat 512+512->512 gather+swish -> full, %d waves" % (compute, waves, waves),
+                   lambda: hip.gather_conv_cl(xf, xf2, (6, 6), idxf, scf, shf, "swish", pf, bf, Cf, (3, 3), (1, 1),
+                                              full=dict(offset=(1, 1), out_res=(16, 16), residual=None)))
+            report("%s G%d same, raw staging, %d waves" % (compute, waves, waves),
+                   lambda: hip.gather_conv_cl(xf, xf2, (6, 6), idxf, None, None, "identity", pf, bf, Cf, (3, 3), (1, 1),
+                                              full=dict(offset=(1, 1), out_res=(16, 16), residual=None)))
+        hip.conv_force_waves(0)
         # B: SIGE 64x64 conv2: scatter_gather -> conv -> scatter with block residual
         m = torch.zeros(64, 64, dtype=torch.bool, device=dev)
         m[25:32, 22:29] = True

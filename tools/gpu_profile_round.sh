@@ -24,7 +24,7 @@ cd "$ROOT"
 for DT in f32 f16; do
   T=$(ls "$OUT/${TAG}_trace_$DT"/*kernel_trace.csv 2>/dev/null | head -1)
   [ -n "$T" ] && python tools/trace_summary.py "$T" --replays 50 --out "$OUT/${TAG}_kerneltrace_sparse_fwd_1p2pct_$DT.csv" > "$OUT/${TAG}_trace_summary_$DT.txt" 2>&1
-  [ -n "$T" ] && python tools/trace_summary.py "$T" --replays 50 --by-grid --top 0 --out "$OUT/${TAG}_kerneltrace_by_grid_sparse_fwd_1p2pct_$DT.csv" > /dev/null 2>&1
+  [ -n "$T" ] && python tools/trace_summary.py "$T" --replays 50 --by-grid --top 0 --out "$OUT/${TAG}_kerneltrace_by_grid_sparse_fwd_1p2pct_$DT.csv" --sequence "$OUT/${TAG}_kernel_sequence_sparse_fwd_1p2pct_$DT.csv" > /dev/null 2>&1
   S=$(ls "$OUT/${TAG}_trace_$DT"/*kernel_stats.csv 2>/dev/null | head -1)
   [ -n "$S" ] && cp "$S" "$OUT/${TAG}_rocprofv3_kernel_stats_profile_forward_$DT.csv"
   rm -rf "$OUT/${TAG}_trace_$DT"

@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--top", type=int, default=40)
     ap.add_argument("--by-grid", action="store_true", help="one row per (kernel, grid size): separates the layers that share a kernel")
+    ap.add_argument("--sequence", default=None, help="also write the replay as a SEQUENCE: one row per launch position "
+                    "(mean duration and mean gap to the previous kernel over the replays, kernel, grid)")
     a = ap.parse_args()
     rows = []
     with open(a.trace) as f:
@@ -54,6 +56,18 @@ def main():
         for name, (cnt, ns) in out:
             w.writerow([name, round(cnt / a.replays, 2), round(ns / cnt / 1e3, 2), round(ns / a.replays / 1e3, 2),
                         round(100.0 * ns / (busy * 1e6), 2)])
+    if a.sequence and len(burst) % a.replays == 0:
+        per = len(burst) // a.replays
+        with open(a.sequence, "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["# position in the replay, mean over %d replays" % a.replays])
+            w.writerow(["pos", "start_us", "dur_us", "gap_before_us", "kernel"])
+            for i in range(per):
+                d = [burst[r * per + i][1] - burst[r * per + i][0] for r in range(a.replays)]
+                g = [burst[r * per + i][0] - burst[r * per + i - 1][1] for r in range(a.replays) if r * per + i > 0]
+                st = [burst[r * per + i][0] - burst[r * per][0] for r in range(a.replays)]
+                w.writerow([i, round(sum(st) / len(st) / 1e3, 2), round(sum(d) / len(d) / 1e3, 2),
+                            round(sum(g) / max(len(g), 1) / 1e3, 2), short(burst[i][2])])
     print("wall %.3f ms/replay, kernel-busy %.3f ms/replay, %d kernels/replay" % (span / a.replays, busy / a.replays, len(burst) // a.replays))
     for name, (cnt, ns) in out[: a.top]:
         print("%7.1f us/replay %6.1f launches avg %8.2f us  %s" % (ns / a.replays / 1e3, cnt / a.replays, ns / cnt / 1e3, name[:110]))
