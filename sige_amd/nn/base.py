@@ -302,3 +302,18 @@ class SIGEModel(nn.Module):
         for module in self._sige_modules():
             if hasattr(module, "inplace"):
                 module.inplace = inplace
+
+
+def paired_convs(like, enabled: bool = True):
+    """Context for the two independent convs at the head of a residual block -- the 1x1 shortcut, then conv1 (3x3, cached
+    affine + SiLU), both gathering from the block's input: on the GPU (channels-last, fp32) they share ONE launch
+    (sige_amd.hip.conv_pair / sige_hip_conv_pair_begin: horizontal fusion); anywhere else, and whenever the pair cannot be
+    formed, each conv runs on its own.  Results do not depend on it.  `like`: a tensor (or deferred cat) on the convs' device."""
+    import contextlib
+
+    first = like.parts[0] if hasattr(like, "parts") else like
+    if enabled and isinstance(first, torch.Tensor) and first.is_cuda:
+        from .. import hip
+
+        return hip.conv_pair(first)
+    return contextlib.nullcontext()

@@ -17,7 +17,6 @@ Sparse-mode contract (what SIGE caches):
     pass feeds them to Gather / ScatterGather as the fused affine + SiLU.
   * resolutions below `sparse_threshold` run dense convs on the cached affine.
 """
-import contextlib
 import math
 from dataclasses import dataclass
 from typing import Optional, Tuple
@@ -26,7 +25,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
-from ..nn import Gather, Scatter, ScatterGather, ScatterWithBlockResidual, SIGEConv2d, SIGEModel, SIGEModule
+from ..nn import Gather, Scatter, ScatterGather, ScatterWithBlockResidual, SIGEConv2d, SIGEModel, SIGEModule, paired_convs
 from ..nn.deferred import lazy_cat
 from ..nn.dense import fused_conv2d, group_norm_affine, input_conv2d
 
@@ -149,11 +148,7 @@ class ResBlock(SIGEModule):
 
     def _pairing(self, t: torch.Tensor):
         """Context for [shortcut conv, conv1] of a sparse-mode block: on the GPU the two share one launch."""
-        if self.pair and self.cin != self.cout and t.is_cuda and self.mode == "sparse":
-            from .. import hip
-
-            return hip.conv_pair(t)
-        return contextlib.nullcontext()
+        return paired_convs(t, enabled=self.pair and self.cin != self.cout and self.mode == "sparse")
 
     def forward(self, x, temb: Optional[torch.Tensor]) -> torch.Tensor:
         """`x` may be a pair (h, skip): the up path's torch.cat, which the dense

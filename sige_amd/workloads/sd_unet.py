@@ -19,7 +19,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
-from ..nn import Gather, Scatter, ScatterGather, ScatterWithBlockResidual, SIGEConv2d, SIGEModel, SIGEModule
+from ..nn import Gather, Scatter, ScatterGather, ScatterWithBlockResidual, SIGEConv2d, SIGEModel, SIGEModule, paired_convs
 from ..nn.deferred import lazy_cat
 from .sd_transformer import SpatialTransformer, group_norm_affine
 
@@ -90,8 +90,9 @@ class ResBlock(SIGEModule):
             return self.scatter(self.out_layers[3](F.silu(h)), skip)
         if self.mode in ("sparse", "profile"):
             s1, t1, s2, t2 = self.affine
-            skip = x if self.cin == self.cout else self.skip_connection(self.shortcut_gather(x))
-            h = self.in_layers[2](self.main_gather(x, s1, t1))
+            with paired_convs(x, enabled=self.cin != self.cout and self.mode == "sparse"):  # the 1x1 rides in conv1's launch
+                skip = x if self.cin == self.cout else self.skip_connection(self.shortcut_gather(x))
+                h = self.in_layers[2](self.main_gather(x, s1, t1))
             tiles = self.scatter_gather(h, s2, t2)
             if self.mode == "sparse":
                 return self.scatter.forward_fused(self.out_layers[3], tiles, skip)

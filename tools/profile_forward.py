@@ -55,6 +55,11 @@ def main():
             model.set_masks(downsample_mask(dilate_mask(mask, 5), 8))
             model.set_mode("sparse")
         if a.mode == "eager":
+            # (the PMC attribution matches counter rows to conv CALLS by launch order: every call must be its own kernel, so the
+            #  shortcut / conv1 pairing -- the same two workgroup programs side by side in one launch -- is off for these passes)
+            for m in model.modules():
+                if hasattr(m, "pair"):
+                    m.pair = False
             if a.manifest:
                 import json
 
