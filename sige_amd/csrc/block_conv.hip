@@ -243,7 +243,7 @@ extern "C" int sige_hip_conv_probe_clear(void) {
 struct HeldConv {
     bool active = false;
     ConvArgs a;
-    int mode = 0, dst = 0;
+    int mode = 0, dst = 0, prec = 0;
     hipStream_t st = nullptr;
     int (*launch)(ConvArgs, int, hipStream_t) = nullptr;
 };
@@ -275,6 +275,16 @@ void launch_conv_pair(ConvArgs a, ConvArgs b, hipStream_t st);
     template <> void launch_conv_pair<K31_32, 2, K11_16, DST, W>(ConvArgs, ConvArgs, hipStream_t);       \
     template <> void launch_conv_pair<K31_32, 2, K11_32, DST, W>(ConvArgs, ConvArgs, hipStream_t);
 SIGE_PAIR_DECLARE(DST_TILES, 4) SIGE_PAIR_DECLARE(DST_TILES, 8) SIGE_PAIR_DECLARE(DST_NCHW, 4) SIGE_PAIR_DECLARE(DST_NCHW, 8)
+#define SIGE_PAIR_DECLARE_H(DST)                                                                         \
+    template <> void launch_conv_pair<H31_16, 1, H11_16, DST, 4>(ConvArgs, ConvArgs, hipStream_t);       \
+    template <> void launch_conv_pair<H31_16, 1, H11_32, DST, 4>(ConvArgs, ConvArgs, hipStream_t);       \
+    template <> void launch_conv_pair<H31_16, 2, H11_16, DST, 4>(ConvArgs, ConvArgs, hipStream_t);       \
+    template <> void launch_conv_pair<H31_16, 2, H11_32, DST, 4>(ConvArgs, ConvArgs, hipStream_t);       \
+    template <> void launch_conv_pair<H31_32, 1, H11_16, DST, 4>(ConvArgs, ConvArgs, hipStream_t);       \
+    template <> void launch_conv_pair<H31_32, 1, H11_32, DST, 4>(ConvArgs, ConvArgs, hipStream_t);       \
+    template <> void launch_conv_pair<H31_32, 2, H11_16, DST, 4>(ConvArgs, ConvArgs, hipStream_t);       \
+    template <> void launch_conv_pair<H31_32, 2, H11_32, DST, 4>(ConvArgs, ConvArgs, hipStream_t);
+SIGE_PAIR_DECLARE_H(DST_TILES) SIGE_PAIR_DECLARE_H(DST_NCHW)
 
 // Tickets of the in-kernel K-split finish (conv_mfma.hpp): one int per output block of a split launch, zero whenever no
 // such launch is running.  One buffer per device: a ring for eager launches (a slice is only live while its launch runs;
@@ -390,23 +400,32 @@ static int plan_conv(ConvArgs &a, int cap, int want_waves, bool nb1, ConvPlan &p
 }
 
 // conv A (planned: pa) + the held 1x1 conv in one launch; false: no pair kernel for this combination
-template <int DST>
+template <int DST, int PREC>
 static bool launch_pair(const ConvArgs &a, const ConvPlan &pa, ConvArgs b, hipStream_t st) {
+    using A16 = std::conditional_t<PREC == 1, H31_16, K31_16>;
+    using A32 = std::conditional_t<PREC == 1, H31_32, K31_32>;
+    using B16 = std::conditional_t<PREC == 1, H11_16, K11_16>;
+    using B32 = std::conditional_t<PREC == 1, H11_32, K11_32>;
     ConvPlan pb;
-    if (plan_conv<1, 1, 4, SRC_GATHER, LAYOUT_NHWC, 0>(b, 1, pa.waves, true, pb) != SIGE_HIP_OK) return false;
+    if (plan_conv<1, 1, 4, SRC_GATHER, LAYOUT_NHWC, PREC>(b, 1, pa.waves, true, pb) != SIGE_HIP_OK) return false;
 #define SIGE_PAIR_GO(GA, NBA, W)                                                                         \
     do {                                                                                                 \
-        if (pb.mt == 32) launch_conv_pair<GA, NBA, K11_32, DST, W>(a, b, st);                            \
-        else launch_conv_pair<GA, NBA, K11_16, DST, W>(a, b, st);                                        \
+        if (pb.mt == 32) launch_conv_pair<GA, NBA, B32, DST, W>(a, b, st);                               \
+        else launch_conv_pair<GA, NBA, B16, DST, W>(a, b, st);                                           \
     } while (0)
 #define SIGE_PAIR_W(W)                                                                                   \
     do {                                                                                                 \
-        if (pa.mt == 32 && pa.nb == 2) SIGE_PAIR_GO(K31_32, 2, W);                                       \
-        else if (pa.mt == 32) SIGE_PAIR_GO(K31_32, 1, W);                                                \
-        else if (pa.nb == 2) SIGE_PAIR_GO(K31_16, 2, W);                                                 \
-        else SIGE_PAIR_GO(K31_16, 1, W);                                                                 \
+        if (pa.mt == 32 && pa.nb == 2) SIGE_PAIR_GO(A32, 2, W);                                          \
+        else if (pa.mt == 32) SIGE_PAIR_GO(A32, 1, W);                                                   \
+        else if (pa.nb == 2) SIGE_PAIR_GO(A16, 2, W);                                                    \
+        else SIGE_PAIR_GO(A16, 1, W);                                                                    \
     } while (0)
-    if (pa.waves == 8) SIGE_PAIR_W(8); else SIGE_PAIR_W(4);
+    if constexpr (PREC == 0) {
+        if (pa.waves == 8) SIGE_PAIR_W(8); else SIGE_PAIR_W(4);
+    } else {
+        if (pa.waves != 4) return false;
+        SIGE_PAIR_W(4);
+    }
 #undef SIGE_PAIR_W
 #undef SIGE_PAIR_GO
     ++g_pairs_fused;
@@ -418,15 +437,15 @@ static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
     using G32 = std::conditional_t<PREC == 1, ConvGeoH<KH, STR, R, 32>, ConvGeo<KH, STR, R, 32>>;
     using G16 = std::conditional_t<PREC == 1, ConvGeoH<KH, STR, R, 16>, ConvGeo<KH, STR, R, 16>>;
     constexpr bool kHasNB2 = STR == 1;
-    constexpr bool kPairLayout = SRC == SRC_GATHER && LAY == LAYOUT_NHWC && PREC == 0 && STR == 1;
+    constexpr bool kPairLayout = SRC == SRC_GATHER && LAY == LAYOUT_NHWC && STR == 1;
     constexpr bool kPairFirst = kPairLayout && KH == 3, kPairSecond = kPairLayout && KH == 1;
-    const bool may_pair = kPairFirst && g_held.active && mode == MODE_AFFINE_SWISH && g_held.st == st && g_held.dst == DST;
+    const bool may_pair = kPairFirst && g_held.active && mode == MODE_AFFINE_SWISH && g_held.st == st && g_held.dst == DST && g_held.prec == PREC;
     if (g_held.active && !may_pair) {
         const int rc = flush_held();
         if (rc != SIGE_HIP_OK) return rc;
     }
     if (kPairSecond && g_pairing && !g_held.active && mode == MODE_RAW && !g_force_mt) {
-        g_held.active = true; g_held.a = a; g_held.mode = mode; g_held.dst = DST; g_held.st = st;
+        g_held.active = true; g_held.a = a; g_held.mode = mode; g_held.dst = DST; g_held.st = st; g_held.prec = PREC;
         g_held.launch = &launch_kind<KH, STR, R, SRC, DST, LAY, PREC>;
         note_launches(-1);  // (the caller counts one launch per call: this one happens later, or inside its partner's)
         return SIGE_HIP_OK;
@@ -448,7 +467,7 @@ static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
     bool done = false;
     if constexpr (kPairFirst) {
         if (may_pair) {
-            done = launch_pair<DST>(a, p, g_held.a, st);
+            done = launch_pair<DST, PREC>(a, p, g_held.a, st);
             if (done) g_held.active = false;
             else {
                 const int rc = flush_held();

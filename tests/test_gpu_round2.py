@@ -385,7 +385,7 @@ def test_f16_compute_ddpm_forward_vs_fp32_oracle(hip):
 
 
 # ---- horizontal fusion: a residual block's 1x1 shortcut launched inside the kernel of its conv1 ---------------------
-def _pair_case(hip, res, c1, c2, cout, T, full, seed=0, residual=False):
+def _pair_case(hip, res, c1, c2, cout, T, full, seed=0, residual=False, compute="f32"):
     """(run_shortcut, run_conv1) of a residual block at `res`: both gather from the same (optionally concatenated) input."""
     g = torch.Generator().manual_seed(seed)
     r = lambda *s: torch.randn(*s, generator=g).to(DEV)  # noqa: E731
@@ -393,7 +393,7 @@ def _pair_case(hip, res, c1, c2, cout, T, full, seed=0, residual=False):
     x, x2 = _cl(r(1, c1, res, res)), (_cl(r(1, c2, res, res)) if c2 else None)
     w3, b3, w1, b1 = r(cout, cin, 3, 3) / (3 * cin ** 0.5), r(cout), r(cout, cin, 1, 1) / cin ** 0.5, r(cout)
     sc, sh, os_, oh_ = r(1, cin, 1, 1), r(1, cin, 1, 1), r(cout), r(cout)
-    p3, p1 = hip.conv_pack_weights(w3, 6, 6, (1, 1)), hip.conv_pack_weights(w1, 4, 4, (1, 1))
+    p3, p1 = hip.conv_pack_weights(w3, 6, 6, (1, 1), compute), hip.conv_pack_weights(w1, 4, 4, (1, 1), compute)
     if full:
         i6, i4 = hip.all_tiles(res, res, (4, 4), (1, 1), (1, 1), DEV), hip.all_tiles(res, res, (4, 4), (1, 1), (0, 0), DEV)
         f6 = dict(offset=(1, 1), out_res=(res, res), residual=_cl(r(1, cout, res, res)) if residual else None)
@@ -430,6 +430,22 @@ def test_conv_pair_equals_separate_launches(hip, res, c1, c2, cout, T, full):
     torch.cuda.synchronize()
     assert hip.conv_pairs_fused() == f0 + 1, "no pair kernel for this combination"
     assert hip.launch_count() == n0 + 1  # (8x8: the K split of conv1 is finished inside the launch, too)
+    assert torch.equal(got_c, want_c)
+    torch.testing.assert_close(got_s, want_s, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("res,c1,c2,cout,T,full", [(64, 128, 0, 256, 18, False), (256, 128, 128, 128, 106, False),
+                                                   (32, 256, 256, 256, 0, True), (16, 512, 512, 512, 0, True)])
+def test_conv_pair_f16_compute(hip, res, c1, c2, cout, T, full):
+    """The same pairing for the f16-compute kernels (ConvGeoH)."""
+    shortcut, conv1 = _pair_case(hip, res, c1, c2, cout, T, full, compute="f16")
+    want_s, want_c = shortcut(), conv1()
+    n0, f0 = hip.launch_count(), hip.conv_pairs_fused()
+    with hip.conv_pair(want_s):
+        got_s = shortcut()
+        got_c = conv1()
+    torch.cuda.synchronize()
+    assert hip.conv_pairs_fused() == f0 + 1 and hip.launch_count() == n0 + 1
     assert torch.equal(got_c, want_c)
     torch.testing.assert_close(got_s, want_s, rtol=1e-5, atol=1e-5)
 
