@@ -454,8 +454,18 @@ def conv_packed_size(Cout, Cin, kH, kW, R, S, strH, strW, groups=1) -> int:
 
 
 class PackedWeights(torch.Tensor):
-    """Opaque packed conv weights (fp32 storage); `.compute` says which matrix path they were laid out for."""
+    """Opaque packed conv weights (fp32 storage); `.compute` says which matrix path they were laid out for (it follows
+    the tensor through clone / detach / to: a copy read with the wrong kernel family would run past its end)."""
     compute = "f32"
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        out = super().__torch_function__(func, types, args, kwargs or {})
+        if isinstance(out, PackedWeights):
+            src = next((a for a in args if isinstance(a, PackedWeights)), None)
+            if src is not None and src is not out:
+                out.compute = src.__dict__.get("compute", "f32")
+        return out
 
 
 def conv_pack_weights(weight: torch.Tensor, R: int, S: int, stride: Tuple[int, int], compute: str = "f32") -> Optional[torch.Tensor]:

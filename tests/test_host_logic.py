@@ -436,3 +436,15 @@ def test_input_conv2d_and_plain_weight_off_gpu():
         conv.weight.mul_(2.0)
     w2 = _plain_weight(conv)
     assert w2 is not w1 and torch.equal(w2, conv.weight)
+
+
+def test_packed_weights_keep_their_compute_tag():
+    """A copy of f16-packed weights must still be dispatched to the f16 kernels (bench.py clones the operands of the calls it
+    re-times; read as fp32-packed the buffer is half as long as the kernel expects)."""
+    from sige_amd.hip import PackedWeights
+
+    p = torch.zeros(8).as_subclass(PackedWeights)
+    p.compute = "f16"
+    for q in (p.clone(), p.detach(), p.contiguous(), p.to(torch.float32)):
+        assert isinstance(q, PackedWeights) and q.compute == "f16"
+    assert torch.zeros(8).as_subclass(PackedWeights).clone().compute == "f32"
