@@ -423,12 +423,12 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
     constexpr int OUT_UNITS = NB * UNITS_NB;
     constexpr int EU = (OUT_UNITS + NT - 1) / NT;
     // (4-wave workgroups only: with 8 waves the register budget per lane is 256 and the loop needs it)
-    constexpr bool EPRE = NHWC && DST != DST_TILES && W == 4;
+    constexpr bool EPRE = NHWC && DST != DST_TILES && (W == 4 || NB == 1);
     int e_h[EPRE ? EU : 1], e_w[EPRE ? EU : 1];          // tile origin, then the unit's output pixel
     size_t e_q[EPRE ? EU : 1];                            // element offset of the unit in the output tensor
     bool e_in[EPRE ? EU : 1];                             // the unit exists and its pixel is inside the output
     float4 e_res[EPRE ? EU : 1];
-    constexpr bool EPV = NHWC && W == 4;                  // per-channel epilogue vectors (bias, out_affine) fetched up front
+    constexpr bool EPV = NHWC && (W == 4 || NB == 1);                 // per-channel epilogue vectors (bias, out_affine) fetched up front
     float4 e_bias[EPV ? EU : 1], e_os[EPV ? EU : 1], e_oh[EPV ? EU : 1];
     // (K split with a second launch: partial sums only, bias / residual in the second pass; with in-kernel finish any
     //  workgroup may turn out to be the one that runs the epilogue)
