@@ -920,9 +920,10 @@ def main():
         x1 = prepare(args.ratio)
         model(x1, t)  # packs weights, builds tile tables
         tracer.log = []
-        n0 = hip.launch_count()
+        n0, p0 = hip.launch_count(), hip.conv_pairs_fused()
         model(x1, t)
         launches_per_forward = hip.launch_count() - n0  # kernels libsige_hip.so launched for one sparse forward
+        pairs_per_forward = hip.conv_pairs_fused() - p0  # (shortcut, conv1) pairs that shared a launch
         trace, tracer.log = tracer.log, None
         e_ms = eager_ms(model, x1, t, 20)
         g, out = capture(model, x1, t)
@@ -966,7 +967,8 @@ def main():
             # ---- per-kernel accounting of the hot path (warm, in-situ tensors) ----
             fam, per_cfg, kernels, conv_tflops, hot_us = kernel_families(trace)
             result.update(kernels=kernels, hot_path_us=round(hot_us, 1), block_conv_tflops=round(conv_tflops, 2),
-                          launches_per_forward=launches_per_forward)
+                          launches_per_forward=launches_per_forward, conv_pairs_per_forward=pairs_per_forward,
+                          launches_note="conv calls = launches + pairs; K-split convs finish inside their launch (no second pass)")
 
             # ---- roofline of the dominant hot-path kernel family ---------------------
             if not args.no_roofline:
