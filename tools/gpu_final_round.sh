@@ -1,0 +1,19 @@
+#!/bin/bash
+# Second GPU-box session of a round (after tools/gpu_profile_round.sh <tag> and `cp gpurun_out/<tag>_pmc_traffic.json
+# profiles/pmc_traffic.json`): the profiler rows behind bench.py's data_movement table, the default bench line, the f16
+# bench line, the multi-rank code path on one GPU (gloo, oversubscribed) and the SD U-Net workload.
+set -u
+TAG=${1:-r2}
+ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p "$OUT"; export TMPDIR=/tmp
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/${TAG}_dm" -o dm -- python $ROOT/tools/profile_data_movement.py > "$OUT/${TAG}_dm.log" 2>&1
+cd "$ROOT"
+T=$(ls "$OUT/${TAG}_dm"/*kernel_trace.csv 2>/dev/null | head -1)
+[ -n "$T" ] && python tools/trace_summary.py "$T" --replays 1 --by-grid --gap-ms 100 --top 0 --out "$OUT/${TAG}_kerneltrace_data_movement.csv" > /dev/null 2>&1
+rm -rf "$OUT/${TAG}_dm"
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2> "$OUT/${TAG}_bench.err" | tail -1 > "$OUT/${TAG}_bench.json"
+timeout 600 python bench.py --dtype f16 --no-extras --cpu-seconds 1 2> "$OUT/${TAG}_bench_f16.err" | tail -1 > "$OUT/${TAG}_bench_f16.json"
+timeout 600 python bench.py --gpus 2 --oversubscribe --backend gloo --steps 20 --warmup 5 --no-extras --cpu-seconds 1 2> "$OUT/${TAG}_bench_2ranks.err" | grep '^{"metric"' | tail -1 > "$OUT/${TAG}_bench_2ranks_gloo.json"
+timeout 600 python bench.py --workload sd --steps 20 --warmup 5 2> "$OUT/${TAG}_bench_sd.err" | tail -1 > "$OUT/${TAG}_bench_sd.json"
+wc -c "$OUT"/${TAG}_bench*.json
+tail -2 "$OUT"/${TAG}_bench*.err
