@@ -69,7 +69,9 @@ def build_probe(verbose: bool = True) -> str:
     for src in SOURCES:
         if src.startswith(("conv_k", "conv_pair", "block_conv")) and (not only or src in only or src.startswith("block_conv")):
             obj = os.path.join(pdir, src.replace(".hip", ".o"))
-            cmd = [_hipcc(), *FLAGS, "-DSIGE_CONV_PROBE", *os.environ.get("SIGE_PROBE_DEFS", "").split(),
+            # (SIGE_VARIANT_ONLY=1: an experimental variant of the product kernels -- the defines only, no phase stamps)
+            probe_def = [] if os.environ.get("SIGE_VARIANT_ONLY") else ["-DSIGE_CONV_PROBE"]
+            cmd = [_hipcc(), *FLAGS, *probe_def, *os.environ.get("SIGE_PROBE_DEFS", "").split(),
                    "-I" + os.path.join(REPO, "include"), "-I" + CSRC, "-c",
                    os.path.join(CSRC, src), "-o", obj]
             procs.append((cmd, subprocess.Popen(cmd)))
