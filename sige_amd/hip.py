@@ -17,6 +17,7 @@ RuntimeError is raised.  torch is used only for allocation and the stream.
 """
 import ctypes
 import os
+import threading
 from typing import Optional, Tuple
 
 import torch
@@ -508,13 +509,14 @@ def conv_force_waves(waves: int = 0):
     _check(lib().sige_hip_block_conv_force_waves(waves), "conv_force_waves")
 
 
-_PAIR_KEEP = None
+_pair_state = threading.local()  # .keep: operands of the launches of the open conv_pair() block; .depth: nesting
 
 
 class conv_pair:
     """`with hip.conv_pair():` around the shortcut conv and the conv1 of a residual block (in that order, nothing else):
     the 1x1 is held back and launched inside the 3x3's kernel (sige_hip_conv_pair_begin / _end, include/sige_hip.h).
-    Results do not depend on it; whatever cannot be paired is launched on its own, at the latest when the block ends."""
+    Results do not depend on it; whatever cannot be paired is launched on its own, at the latest when the block ends.
+    Per thread, like the C side; a nested block joins the outer one."""
 
     def __init__(self, like: Optional[torch.Tensor] = None):
         self.like = like  # (a tensor of the convs' device: the held conv may be launched when the block ends)
@@ -525,19 +527,22 @@ class conv_pair:
             _pending_device = self.like.device.index
 
     def __enter__(self):
-        global _PAIR_KEEP
-        self._on_device()
-        _check(lib().sige_hip_conv_pair_begin(), "conv_pair_begin")
-        _PAIR_KEEP = []
+        depth = getattr(_pair_state, "depth", 0)
+        if depth == 0:
+            self._on_device()
+            _check(lib().sige_hip_conv_pair_begin(), "conv_pair_begin")
+            _pair_state.keep = []
+        _pair_state.depth = depth + 1
         return self
 
     def __exit__(self, *exc):
-        global _PAIR_KEEP
-        try:
-            self._on_device()
-            _check(lib().sige_hip_conv_pair_end(), "conv_pair_end")
-        finally:
-            _PAIR_KEEP = None
+        _pair_state.depth -= 1
+        if _pair_state.depth == 0:
+            try:
+                self._on_device()
+                _check(lib().sige_hip_conv_pair_end(), "conv_pair_end")
+            finally:
+                _pair_state.keep = None
         return False
 
 
@@ -884,8 +889,9 @@ def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, a
     if status == UNSUPPORTED:
         return None
     _check(status, "gather_conv_cl")
-    if _PAIR_KEEP is not None:  # (conv_pair(): a held launch reads these after this call has returned)
-        _PAIR_KEEP.append((x, x2, idx, s_keep, t_keep, packed, bias_keep, out, ws, out_affine, full))
+    keep = getattr(_pair_state, "keep", None)
+    if keep is not None:  # (conv_pair(): a held launch reads these after this call has returned)
+        keep.append((x, x2, idx, s_keep, t_keep, packed, bias_keep, out, ws, out_affine, full))
     return out
 
 
