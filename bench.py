@@ -36,6 +36,10 @@ sys.path.insert(0, REPO)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+# hipGraph captures: "thread_local" -- another thread of the process (RCCL's watchdog at N > 1) calling into HIP while this
+# thread records must not invalidate the capture; the recording thread itself makes no capture-unsafe call either way.
+CAPTURE_MODE = "thread_local"
+
 PEAK_HBM_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md)
 PEAK_F32_MFMA_TFS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA_TFS = 2500.0  # v_mfma_f32_32x32x16_f16 dense peak (not the 2:1-sparsity figure)
@@ -182,7 +186,7 @@ def time_graph_of(fn, reps, iters=5):
     with torch.cuda.stream(s):
         fn()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=s):
+        with torch.cuda.graph(g, stream=s, capture_error_mode=CAPTURE_MODE):
             for _ in range(reps):
                 fn()
         g.replay()
@@ -306,7 +310,7 @@ def capture(model, x, t):
         for _ in range(2):
             model(x, t)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=s):
+        with torch.cuda.graph(g, stream=s, capture_error_mode=CAPTURE_MODE):
             out = model(x, t)
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
@@ -440,7 +444,7 @@ def _replay_ms(fn, k=30, warm=5):
         for _ in range(2):
             out = fn()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=s):
+        with torch.cuda.graph(g, stream=s, capture_error_mode=CAPTURE_MODE):
             out = fn()
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
@@ -713,7 +717,7 @@ def capture_fn(fn):
         for _ in range(2):
             fn()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=s):
+        with torch.cuda.graph(g, stream=s, capture_error_mode=CAPTURE_MODE):
             out = fn()
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
