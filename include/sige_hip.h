@@ -68,6 +68,9 @@ int sige_hip_gather_f32(const float *x, int B, int C, int H, int W, int bH, int 
                         const float *scale, int scaleB, int scaleC, int scaleH, int scaleW,
                         const float *shift, int shiftB, int shiftC, int shiftH, int shiftW,
                         int activation, int activation_first, float *out, void *stream);
+/* Tuning knob: 1 = the NCHW gather always uses the one-tile-per-workgroup row form; 0 (default) = groups of 8 consecutive
+ * tiles per workgroup when there are enough tiles (merged cache-line requests for horizontally adjacent tiles). */
+int sige_hip_gather_force_rows(int one_tile_rows);
 
 /* ---- scatter : replaces scatter_cpu / scatter_cuda ----------------------
  * (sige/cpu/scatter.cpp:70-109, sige/cuda/scatter_kernel.cu:76-117, scatter.h:5-11)

@@ -547,7 +547,7 @@ extern "C" int sige_hip_block_conv_force_tile(int mt, int nb) {
 extern "C" int sige_hip_conv_pair_begin(void) {
     const int rc = flush_held();
     g_pairing = true;
-    return rc != SIGE_HIP_OK ? rc : SIGE_HIP_OK;
+    return rc;
 }
 
 extern "C" int sige_hip_conv_pair_end(void) {

@@ -173,6 +173,98 @@ __global__ __launch_bounds__(kGatherThreads) void gather_rows_kernel(GatherArgs 
     }
 }
 
+// ---- plain gather, grouped row form (round 2) ----------------------------------------------------------------------
+// The row form above gives every lane its own cache line to read (rows of one tile are W floats apart, channels H*W):
+// 64 line requests per wave-wide load for 24 useful bytes each -- 0.30 of the HBM peak, bound by address processing.
+// Index lists come row-major sorted from reduce_mask, so CONSECUTIVE tiles are usually horizontal neighbours whose
+// windows overlap (stride 4, width 6).  Here one workgroup takes kGroup consecutive tiles x a channel chunk and maps its
+// lanes tile-fastest: the 8 lanes of one (channel, row) read 8 overlapping 24-byte windows out of the same two or three
+// cache lines, which the address unit merges -- 3x fewer line requests.  The rows go to LDS ([tile][channel][row], one
+// padded slab per tile) and leave as each tile's contiguous [C-chunk][TR][TS] slab with 16-byte stores.  Values and
+// rounding are those of the row form (the same affine / activation code).
+constexpr int kGroup = 8;
+
+template <int TR, int TS, int ACT, bool ACT_FIRST>
+__global__ __launch_bounds__(kGatherThreads) void gather_rows_grouped_kernel(GatherArgs a) {
+    static_assert(TS >= 4 && TS <= 6, "row forms for 4-, 5- and 6-wide tiles");
+    extern __shared__ __attribute__((aligned(16))) float g_lds[];
+    __shared__ int s_org[kGroup][2];
+    const int tiles = a.B * a.N;
+    const int tile0 = blockIdx.x * kGroup;
+    const int c0 = blockIdx.y * a.cchunk;
+    const int cc = min(a.cchunk, a.C - c0);
+    const int slab = cc * TR * TS;            // floats of one tile's output slab (contiguous in HBM)
+    const int slab_pad = slab + 4;            // LDS pitch per tile: the tile-fastest writers hit different banks
+    if (threadIdx.x < kGroup) {
+        const int t = min(tile0 + (int)threadIdx.x, tiles - 1);
+        const int n = t % a.N;
+        s_org[threadIdx.x][0] = a.idx[2 * n];
+        s_org[threadIdx.x][1] = a.idx[2 * n + 1];
+    }
+    __syncthreads();
+    const size_t HW = (size_t)a.H * a.W;
+    const bool plain = ACT == SIGE_HIP_ACT_IDENTITY && !a.scale.data && !a.shift.data;
+    const bool row_uniform = (a.scale.sh | a.scale.sw | a.shift.sh | a.shift.sw) == 0;  // (absent operands have zero strides)
+    for (int u = threadIdx.x; u < cc * TR * kGroup; u += kGatherThreads) {
+        const int g = u % kGroup, r = (u / kGroup) % TR, cl = u / (kGroup * TR);
+        const int tile = tile0 + g;
+        if (tile >= tiles) continue;
+        const int b = tile / a.N;
+        const int c = c0 + cl, h0 = s_org[g][0], w0 = s_org[g][1], h = h0 + r;
+        float v[TS];
+#pragma unroll
+        for (int i = 0; i < TS; ++i) v[i] = 0.0f;
+        if (h >= 0 && h < a.H) {
+            const float *src = a.x + ((size_t)b * a.C + c) * HW + (size_t)h * a.W + w0;
+            if (w0 >= 0 && w0 + TS <= a.W) {
+                const f4u q = *reinterpret_cast<const f4u *>(src);
+                v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+                if (TS == 6) { const f2u t = *reinterpret_cast<const f2u *>(src + 4); v[4] = t[0]; v[5] = t[1]; }
+                if (TS == 5) v[4] = src[4];
+                if (!plain && row_uniform) {
+                    const float sv = a.scale.data ? bcast_load(a.scale, b, c, 0, 0) : 1.0f;
+                    const float tv = a.shift.data ? bcast_load(a.shift, b, c, 0, 0) : 0.0f;
+#pragma unroll
+                    for (int i = 0; i < TS; ++i) {
+                        float z = v[i];
+                        if (!ACT_FIRST) { if (a.scale.data) z = sv * z; if (a.shift.data) z = tv + z; }
+                        z = activate<ACT>(z);
+                        if (ACT_FIRST) { if (a.scale.data) z = sv * z; if (a.shift.data) z = tv + z; }
+                        v[i] = z;
+                    }
+                } else if (!plain) {
+#pragma unroll
+                    for (int i = 0; i < TS; ++i) v[i] = affine_act<ACT, ACT_FIRST>(v[i], a.scale, a.shift, b, c, h, w0 + i);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TS; ++i) {
+                    const int w = w0 + i;
+                    if (w >= 0 && w < a.W) {
+                        const float z = src[i];
+                        v[i] = plain ? z : affine_act<ACT, ACT_FIRST>(z, a.scale, a.shift, b, c, h, w);
+                    }
+                }
+            }
+        }
+        float *d = g_lds + g * slab_pad + (cl * TR + r) * TS;
+#pragma unroll
+        for (int i = 0; i < TS; ++i) d[i] = v[i];
+    }
+    __syncthreads();
+    // every tile's slab: contiguous in HBM, 4-byte aligned in general (TS = 5), 16-byte pieces
+    const int q4 = slab / 4, rem = slab - 4 * q4;
+    for (int g = 0; g < kGroup; ++g) {
+        const int tile = tile0 + g;
+        if (tile >= tiles) break;  // uniform
+        float *ob = a.out + ((size_t)tile * a.C + c0) * (TR * TS);
+        const float *sl = g_lds + g * slab_pad;
+        for (int i = threadIdx.x; i < q4; i += kGatherThreads)
+            *reinterpret_cast<f4u *>(ob + 4 * i) = *reinterpret_cast<const f4u *>(sl + 4 * i);
+        if ((int)threadIdx.x < rem) ob[4 * q4 + threadIdx.x] = sl[4 * q4 + threadIdx.x];
+    }
+}
+
 template <int TR, int TS>
 static void launch_rows(const GatherArgs &a, int act, bool first, dim3 grid, hipStream_t st) {
     dim3 blk(kGatherThreads);
@@ -181,6 +273,18 @@ static void launch_rows(const GatherArgs &a, int act, bool first, dim3 grid, hip
         else gather_rows_kernel<TR, TS, SIGE_HIP_ACT_SWISH, false><<<grid, blk, 0, st>>>(a);
     } else {
         gather_rows_kernel<TR, TS, SIGE_HIP_ACT_IDENTITY, false><<<grid, blk, 0, st>>>(a);
+    }
+}
+
+template <int TR, int TS>
+static void launch_rows_grouped(const GatherArgs &a, int act, bool first, hipStream_t st) {
+    dim3 blk(kGatherThreads), grid(ceil_div(a.B * a.N, kGroup), ceil_div(a.C, a.cchunk));
+    const size_t lds = (size_t)kGroup * (a.cchunk * TR * TS + 4) * sizeof(float);
+    if (act == SIGE_HIP_ACT_SWISH) {
+        if (first) gather_rows_grouped_kernel<TR, TS, SIGE_HIP_ACT_SWISH, true><<<grid, blk, lds, st>>>(a);
+        else gather_rows_grouped_kernel<TR, TS, SIGE_HIP_ACT_SWISH, false><<<grid, blk, lds, st>>>(a);
+    } else {
+        gather_rows_grouped_kernel<TR, TS, SIGE_HIP_ACT_IDENTITY, false><<<grid, blk, lds, st>>>(a);
     }
 }
 
@@ -196,6 +300,8 @@ static void launch_act(const GatherArgs &a, int act, bool first, dim3 grid, hipS
     }
 }
 
+static bool g_gather_grouped = true;  // sige_hip_gather_force_rows (benchmarking): false = always the one-tile row form
+
 template <bool MAPPED>
 static int launch(GatherArgs a, int act, bool first, hipStream_t st) {
     const int RS = a.bH * a.bW;
@@ -209,6 +315,14 @@ static int launch(GatherArgs a, int act, bool first, hipStream_t st) {
     a.cchunk = cchunk;
     dim3 grid(tiles, ceil_div(a.C, cchunk));
     if (!MAPPED && a.bH == a.bW && a.bH >= 4 && a.bH <= 6) {
+        // enough tiles to fill the chip in groups of kGroup: the grouped row form (32 channels per workgroup = 37 KB of LDS)
+        if (g_gather_grouped && (long)ceil_div(tiles, kGroup) * ceil_div(a.C, 32) >= 512) {
+            a.cchunk = 32;
+            if (a.bH == 6) launch_rows_grouped<6, 6>(a, act, first, st);
+            else if (a.bH == 5) launch_rows_grouped<5, 5>(a, act, first, st);
+            else launch_rows_grouped<4, 4>(a, act, first, st);
+            return launch_status();
+        }
         // row form: one lane per (channel, tile row); ~64 channels per workgroup, but >= ~512 workgroups when possible
         int cch = 64;
         while (cch > 8 && (long)tiles * ceil_div(a.C, cch) < 512) cch /= 2;
@@ -236,6 +350,11 @@ static int launch(GatherArgs a, int act, bool first, hipStream_t st) {
 }  // namespace sige
 
 using namespace sige;
+
+extern "C" int sige_hip_gather_force_rows(int one_tile_rows) {
+    g_gather_grouped = one_tile_rows == 0;
+    return SIGE_HIP_OK;
+}
 
 extern "C" int sige_hip_gather_f32(const float *x, int B, int C, int H, int W, int bH, int bW,
                                    const int32_t *active_indices, int N,

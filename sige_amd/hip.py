@@ -73,6 +73,7 @@ _SIGNATURES = {
     "sige_hip_block_conv_force_tile": (_c_int, [_c_int, _c_int]),
     "sige_hip_block_conv_force_waves": (_c_int, [_c_int]),
     "sige_hip_block_conv_force_ksplit": (_c_int, [_c_int]),
+    "sige_hip_gather_force_rows": (_c_int, [_c_int]),
     "sige_hip_block_conv_force_ksplit_pass": (_c_int, [_c_int]),
     "sige_hip_conv_pair_begin": (_c_int, []),
     "sige_hip_conv_pair_end": (_c_int, []),
@@ -553,6 +554,11 @@ def conv_pairs_fused() -> int:
 def conv_force_ksplit(ksplit: int = 0):
     """Benchmark knob: cross-workgroup K split of the channels-last launches with a workspace (0 = automatic)."""
     _check(lib().sige_hip_block_conv_force_ksplit(ksplit), "conv_force_ksplit")
+
+
+def gather_force_rows(one_tile_rows: bool = False):
+    """Benchmark knob: the NCHW gather's one-tile row form always (True) instead of the grouped form where it applies."""
+    _check(lib().sige_hip_gather_force_rows(int(bool(one_tile_rows))), "gather_force_rows")
 
 
 def conv_force_ksplit_pass(second_pass: bool = False):

@@ -547,3 +547,31 @@ def test_ksplit_finished_inside_the_launch(hip, res, c1, c2, cout, residual):
     finally:
         hip.conv_force_ksplit(0)
         hip.conv_force_ksplit_pass(False)
+
+
+# ---- NCHW gather, grouped row form (8 consecutive tiles per workgroup) ----------------------------------------------
+@pytest.mark.parametrize("bsize,B,C,res,act,first", [(6, 1, 256, 128, "swish", False), (6, 2, 160, 96, "identity", False),
+                                                      (4, 1, 256, 128, "identity", False), (5, 1, 264, 128, "swish", True)])
+def test_grouped_nchw_gather_bit_exact(hip, bsize, B, C, res, act, first):
+    """Enough tiles for the grouped form (merged cache-line requests for neighbouring tiles): bit-identical to the one-tile
+    row form and to the oracle, including tiles over the image border, a ragged last group and a ragged channel chunk."""
+    g = torch.Generator().manual_seed(bsize * 100 + C)
+    stride = 4 if bsize != 5 else 4
+    n_side = res // stride
+    keep = torch.rand(n_side, n_side, generator=g) < 0.75          # most tiles active: long horizontal runs, some holes
+    cells = keep.nonzero()
+    idx = (cells * stride - 1).int().contiguous()                   # origins -1, 3, ...: first row / column start outside the image
+    x = torch.randn(B, C, res, res, generator=g)
+    scale, shift = (torch.randn(1, C, 1, 1, generator=g), torch.randn(1, C, 1, 1, generator=g)) if act == "swish" else (None, None)
+    d = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    try:
+        hip.gather_force_rows(True)
+        rows = hip.gather(d(x), bsize, bsize, d(idx), d(scale), d(shift), act, first)
+        hip.gather_force_rows(False)
+        grouped = hip.gather(d(x), bsize, bsize, d(idx), d(scale), d(shift), act, first)
+    finally:
+        hip.gather_force_rows(False)
+    torch.cuda.synchronize()
+    assert torch.equal(grouped, rows)
+    want = oracle.gather(x, bsize, bsize, idx, scale, shift, act, first)
+    torch.testing.assert_close(grouped.cpu(), want, rtol=1e-6, atol=1e-6)
