@@ -16,4 +16,4 @@ timeout 600 python bench.py --dtype f16 --no-extras --cpu-seconds 1 2> "$OUT/${T
 timeout 600 python bench.py --gpus 2 --oversubscribe --backend gloo --steps 20 --warmup 5 --no-extras --cpu-seconds 1 2> "$OUT/${TAG}_bench_2ranks.err" | grep '^{"metric"' | tail -1 > "$OUT/${TAG}_bench_2ranks_gloo.json"
 timeout 600 python bench.py --workload sd --steps 20 --warmup 5 2> "$OUT/${TAG}_bench_sd.err" | tail -1 > "$OUT/${TAG}_bench_sd.json"
 wc -c "$OUT"/${TAG}_bench*.json
-tail -2 "$OUT"/${TAG}_bench*.err
+for e in "$OUT"/${TAG}_bench*.err; do tail -n 2 "$e"; done
