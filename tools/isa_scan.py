@@ -10,7 +10,7 @@ sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, 'tools'))
 import isa_report as R
 out = []
 for tu in ["conv_k3s1_nhwc.hip", "conv_k1_nhwc.hip", "conv_k3s2_nhwc.hip", "conv_k3s1_nhwc_w8.hip", "conv_k1_nhwc_w8.hip",
-           "block_conv.hip", "nhwc_ops.hip", "group_norm.hip", "attention.hip", "conv_out.hip", "conv_in.hip", "gather.hip", "scatter.hip", "reduce_mask.hip"]:
+           "conv_pair_nhwc_t4.hip", "conv_pair_nhwc_f4.hip", "conv_pair_nhwc_f8.hip", "block_conv.hip", "mask_pipeline.hip", "nhwc_ops.hip", "group_norm.hip", "attention.hip", "conv_out.hip", "conv_in.hip", "gather.hip", "scatter.hip", "reduce_mask.hip"]:
     with tempfile.TemporaryDirectory() as d:
         asm = R.compile_to_asm(os.path.join(REPO, 'sige_amd', 'csrc', tu), d)
     res = R.resources(asm)
