@@ -144,7 +144,7 @@ class _Guarded:
     def __call__(self, *args):
         global _pending_device
         dev, _pending_device = _pending_device, None
-        if dev is not None and dev != torch.cuda.current_device():
+        if dev is not None and dev != (_raw_device() if _raw_device is not None else torch.cuda.current_device()):
             with torch.cuda.device(dev):
                 return self.fn(*args)
         return self.fn(*args)
@@ -194,10 +194,19 @@ def _check(status: int, what: str):
         raise RuntimeError("sige_amd.hip.%s failed: %s" % (what, lib().sige_hip_error_string(status).decode()))
 
 
+# (the raw-handle getters of torch._C are what torch.cuda.current_stream / current_device wrap; a sparse forward calls them
+#  ~120 times, and the Stream-object round trip was 5 % of its host time)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream(t: torch.Tensor) -> int:
     """Stream handle for a launch on `t`'s device (and note that device for the guard, see _Guarded)."""
     global _pending_device
-    _pending_device = t.device.index
+    idx = t.device.index
+    _pending_device = idx
+    if _raw_stream is not None and idx is not None:
+        return _raw_stream(idx)
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
@@ -814,7 +823,7 @@ def _vec(t: Optional[torch.Tensor], name: str) -> Optional[torch.Tensor]:
     """An optional 1-D fp32 vector (bias, gamma, ...) made contiguous.  The caller keeps the returned tensor
     alive until after the launch: `.contiguous()` of a strided view is a temporary whose memory the caching
     allocator may hand out again before the kernel has read it."""
-    return None if t is None else _req(t.detach(), torch.float32, name, 1)
+    return None if t is None else _req(t.detach() if t.requires_grad else t, torch.float32, name, 1)
 
 
 def _p(t: Optional[torch.Tensor]):
