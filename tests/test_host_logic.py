@@ -448,3 +448,18 @@ def test_packed_weights_keep_their_compute_tag():
     for q in (p.clone(), p.detach(), p.contiguous(), p.to(torch.float32)):
         assert isinstance(q, PackedWeights) and q.compute == "f16"
     assert torch.zeros(8).as_subclass(PackedWeights).clone().compute == "f32"
+
+
+def test_paired_convs_is_a_noop_off_the_gpu():
+    """sige_amd.nn.paired_convs: the horizontal fusion of [shortcut conv, conv1] exists on the GPU only; on CPU tensors
+    (and deferred cats of them) the context does nothing and never touches the native library."""
+    from sige_amd.nn import paired_convs
+    from sige_amd.nn.deferred import lazy_cat
+
+    x = torch.randn(1, 4, 8, 8)
+    with paired_convs(x) as ctx:
+        assert ctx is None
+    with paired_convs(lazy_cat(x, x), enabled=True) as ctx:
+        assert ctx is None
+    with paired_convs(x, enabled=False) as ctx:
+        assert ctx is None
