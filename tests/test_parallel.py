@@ -109,6 +109,17 @@ def test_cache_broadcast_and_sharded_edits(tmp_path, method):
         runtime.unregister_backend("cpu")
 
 
+def test_scatter_allgather_with_eight_ranks(tmp_path):
+    """The driver's 8-GPU shape of the cache distribution: rank 0 sends seven different chunks (point to point), then one
+    in-place all-gather -- chunk indexing and the padding of the packed buffer for a world size of 8."""
+    world = 8
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "scatter_allgather"), nprocs=world, join=True)
+    res = [torch.load(tmp_path / ("rank%d.pt" % r)) for r in range(world)]
+    assert len({r["flat_sum"] for r in res}) == 1 and res[0]["flat_sum"] != 0.0
+    assert res[0]["numel"] % world == 0 and {r["slowest"] for r in res} == {2.0}
+    assert [sorted(r["outs"]) for r in res] == [[0], [1], [2], [3], [], [], [], []]
+
+
 def test_pack_caches_keeps_results_and_aliases_buffer():
     from oracle import oracle
     from sige_amd import parallel, runtime
