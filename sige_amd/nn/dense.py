@@ -85,6 +85,11 @@ def fused_conv2d(conv: nn.Conv2d, x: torch.Tensor, scale: Optional[torch.Tensor]
     if isinstance(out, tuple):  # (tensor, epilogue still to apply)
         out, (os_, oh_, oact) = out
         out = _act(out * os_.reshape(1, -1, 1, 1) + oh_.reshape(1, -1, 1, 1), oact)
+    if not made and twins and out_affine is None:
+        from . import scatter
+
+        if scatter.EMULATE_TWINS:  # (tests only: see scatter.EMULATE_TWINS)
+            made = scatter.emulated_twins(out, twins)
     out._sige_twins = made
     return out
 

@@ -137,6 +137,16 @@ class _TwinBuffers:
         self.bufs = {}
 
 
+# Tests only (tests/test_host_logic.py): where a launch cannot write twins itself (no GPU: the CPU path goes through the
+# plain Scatter kernels), compute them from the finished output with torch -- the registration / invalidation logic of the
+# twins can then be exercised end to end on the oracle backend.  Never set in the product.
+EMULATE_TWINS = False
+
+
+def emulated_twins(out: torch.Tensor, regs: dict) -> dict:
+    return {k: torch.nn.functional.silu(out * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) for k, (sc, sh) in list(regs.items())[:2]}
+
+
 def tag_twins(out: torch.Tensor, twins: dict, producer=None) -> torch.Tensor:
     """Attach {consumer key: activated twin} (possibly empty: persistent outputs keep their Python object, a stale
     entry must not survive a launch that did not write it) and the producing module to an output tensor."""
@@ -211,7 +221,8 @@ class Scatter(SIGEModule):
                 cached.copy_(output)
                 self._out_bufs.invalidate(self.cache_id)
                 self.twins.invalidate(self.cache_id)
-            return tag_twins(output, {})  # (this launch wrote no twin: consumers activate for themselves)
+            # (this launch wrote no twin: consumers activate for themselves)
+            return tag_twins(output, emulated_twins(output, self.twins.regs) if EMULATE_TWINS else {})
         if self.mode == "full":
             output = x if residual is None else x + residual
             self.output_res = output.shape[2:]
@@ -350,7 +361,7 @@ class ScatterWithBlockResidual(SIGEModule):
                     fn = self.native(self.scatter_runtime, x)
                     y1.copy_(fn(residual.contiguous(), y1.contiguous(), sg.offset[0], sg.offset[1],
                                 sg.model_stride[0], sg.model_stride[1], sg.indices_on(x.device), None))
-            return tag_twins(output, {})  # (this launch wrote no twin)
+            return tag_twins(output, emulated_twins(output, self.twins.regs) if EMULATE_TWINS else {})  # (no twin written)
         if self.mode == "full":
             output = x + residual
             self.output_res = output.shape[2:]

@@ -180,7 +180,9 @@ class ResBlock(SIGEModule, _TwinProducer):
         """The activated twins of this block's conv1 inputs, one per part of the (possibly concatenated) input -- or None
         (then conv1 activates in its staging path, as without twins).  A missing twin is requested from the module that
         produced the part; it exists from the next forward on."""
-        if not (self.use_twins and self.preactivate and self.mode == "sparse" and parts[0].is_cuda):
+        from ..nn import scatter as _scatter
+
+        if not (self.use_twins and self.preactivate and self.mode == "sparse" and (parts[0].is_cuda or _scatter.EMULATE_TWINS)):
             return None
         if s1.shape[0] != 1:
             return None  # (per-sample affine: the epilogue's twin vectors are per channel)
