@@ -521,3 +521,34 @@ def test_conv1_twins_host_logic_on_the_oracle_backend():
     finally:
         scatter.EMULATE_TWINS = False
         runtime.unregister_backend("cpu")
+
+
+def test_twin_buffers_follow_cache_and_masks():
+    """scatter._TwinBuffers (the persistent activated twins of a Scatter module's in-place output): built from the cache,
+    rebuilt when the mask stamp or the cache generation changes, refreshed in place when the cache is rewritten in place,
+    at most two registrations."""
+    from sige_amd.nn.scatter import _TwinBuffers
+
+    tb = _TwinBuffers()
+    cache = torch.randn(1, 8, 4, 4).contiguous(memory_format=torch.channels_last)
+    sc, sh = torch.randn(8), torch.randn(8)
+    want = lambda c: torch.nn.functional.silu(c * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))  # noqa: E731
+    assert tb.register("a", sc, sh) and tb.register("b", sc * 2, sh) and not tb.register("c", sc, sh)
+    (ka, ba, _, _), (kb, bb, _, _) = tb.launch_args(0, cache, stamp=1)
+    assert (ka, kb) == ("a", "b")
+    torch.testing.assert_close(ba, want(cache))
+    assert tb.launch_args(0, cache, stamp=1)[0][1] is ba                      # same mask, same cache: the same buffer
+    ba.add_(1.0)                                                              # (a launch wrote tiles into it)
+    b2 = tb.launch_args(0, cache, stamp=2)[0][1]                              # new masks: rebuilt from the cache
+    assert b2 is not ba
+    torch.testing.assert_close(b2, want(cache))
+    tb.invalidate(0)                                                          # the cache was replaced (full pass)
+    cache2 = torch.randn_like(cache)
+    b3 = tb.launch_args(0, cache2, stamp=2)[0][1]
+    torch.testing.assert_close(b3, want(cache2))
+    cache2.mul_(0.5)                                                          # rewritten in place (a collective): same address
+    tb.refresh({0: cache2})
+    assert tb.launch_args(0, cache2, stamp=2)[0][1] is b3
+    torch.testing.assert_close(b3, want(cache2))
+    tb.unregister("a")
+    assert [k for k, *_ in tb.launch_args(0, cache2, stamp=2)] == ["b"] and tb.register("c", sc, sh)
