@@ -240,6 +240,8 @@ int sige_hip_gather_conv_nhwc_f16c(const float *x, const float *x2, int B, int C
                                    float *workspace, size_t workspace_floats,
                                    const float *out_scale, const float *out_shift, int out_activation,
                                    int upsample2x,
+                                   float *twin0, const float *twin0_scale, const float *twin0_shift,
+                                   float *twin1, const float *twin1_scale, const float *twin1_shift,
                                    float *out, void *stream);
 int sige_hip_scatter_gather_conv_nhwc_f16c(const float *x, const float *y, int B, int Cin, int H, int W,
                                            int Rx, int Sx, int bH, int bW,
@@ -256,6 +258,8 @@ int sige_hip_scatter_gather_conv_scatter_nhwc_f16c(
         const float *packed, const float *bias, int Cout, int kH, int kW,
         int offsetH, int offsetW, const float *residual,
         const float *x1, const int32_t *table1, int gH1, int gW1, int N1, int R1, int S1,
+        float *twin0, const float *twin0_scale, const float *twin0_shift,
+        float *twin1, const float *twin1_scale, const float *twin1_shift,
         float *out, void *stream);
 
 /* Tuning knob (process-wide, not thread-safe): pin the MFMA kernel's output block to
@@ -352,6 +356,8 @@ int sige_hip_gather_conv_nhwc_f32(const float *x, const float *x2, int B, int C1
                                   float *workspace, size_t workspace_floats,
                                   const float *out_scale, const float *out_shift, int out_activation,
                                   int upsample2x,
+                                  float *twin0, const float *twin0_scale, const float *twin0_shift,
+                                  float *twin1, const float *twin1_scale, const float *twin1_shift,
                                   float *out, void *stream);
 /* `out_scale` / `out_shift` ([Cout], optional): epilogue out = act(out_scale * (conv + bias + residual) + out_shift)
  * -- the CONSUMER's cached GroupNorm affine + SiLU applied by the producer, once per element; the consumer then
@@ -386,6 +392,8 @@ int sige_hip_scatter_gather_conv_scatter_nhwc_f32(
         const float *packed, const float *bias, int Cout, int kH, int kW,
         int offsetH, int offsetW, const float *residual,
         const float *x1, const int32_t *table1, int gH1, int gW1, int N1, int R1, int S1,
+        float *twin0, const float *twin0_scale, const float *twin0_shift,
+        float *twin1, const float *twin1_scale, const float *twin1_shift,
         float *out, void *stream);
 
 /* ---- channels-last forms of gather / scatter_gather / scatter ------------------

@@ -264,26 +264,26 @@ static int flush_held() {
 }
 
 template <typename GA, int NBA, typename GB, int DST, int W>
-void launch_conv_pair(ConvArgs a, ConvArgs b, hipStream_t st);
+void launch_conv_pair(ConvArgs a, ConvArgs b, int mode_a, hipStream_t st);
 #define SIGE_PAIR_DECLARE(DST, W)                                                                        \
-    template <> void launch_conv_pair<K31_16, 1, K11_16, DST, W>(ConvArgs, ConvArgs, hipStream_t);       \
-    template <> void launch_conv_pair<K31_16, 1, K11_32, DST, W>(ConvArgs, ConvArgs, hipStream_t);       \
-    template <> void launch_conv_pair<K31_16, 2, K11_16, DST, W>(ConvArgs, ConvArgs, hipStream_t);       \
-    template <> void launch_conv_pair<K31_16, 2, K11_32, DST, W>(ConvArgs, ConvArgs, hipStream_t);       \
-    template <> void launch_conv_pair<K31_32, 1, K11_16, DST, W>(ConvArgs, ConvArgs, hipStream_t);       \
-    template <> void launch_conv_pair<K31_32, 1, K11_32, DST, W>(ConvArgs, ConvArgs, hipStream_t);       \
-    template <> void launch_conv_pair<K31_32, 2, K11_16, DST, W>(ConvArgs, ConvArgs, hipStream_t);       \
-    template <> void launch_conv_pair<K31_32, 2, K11_32, DST, W>(ConvArgs, ConvArgs, hipStream_t);
+    template <> void launch_conv_pair<K31_16, 1, K11_16, DST, W>(ConvArgs, ConvArgs, int, hipStream_t);       \
+    template <> void launch_conv_pair<K31_16, 1, K11_32, DST, W>(ConvArgs, ConvArgs, int, hipStream_t);       \
+    template <> void launch_conv_pair<K31_16, 2, K11_16, DST, W>(ConvArgs, ConvArgs, int, hipStream_t);       \
+    template <> void launch_conv_pair<K31_16, 2, K11_32, DST, W>(ConvArgs, ConvArgs, int, hipStream_t);       \
+    template <> void launch_conv_pair<K31_32, 1, K11_16, DST, W>(ConvArgs, ConvArgs, int, hipStream_t);       \
+    template <> void launch_conv_pair<K31_32, 1, K11_32, DST, W>(ConvArgs, ConvArgs, int, hipStream_t);       \
+    template <> void launch_conv_pair<K31_32, 2, K11_16, DST, W>(ConvArgs, ConvArgs, int, hipStream_t);       \
+    template <> void launch_conv_pair<K31_32, 2, K11_32, DST, W>(ConvArgs, ConvArgs, int, hipStream_t);
 SIGE_PAIR_DECLARE(DST_TILES, 4) SIGE_PAIR_DECLARE(DST_TILES, 8) SIGE_PAIR_DECLARE(DST_NCHW, 4) SIGE_PAIR_DECLARE(DST_NCHW, 8)
 #define SIGE_PAIR_DECLARE_H(DST)                                                                         \
-    template <> void launch_conv_pair<H31_16, 1, H11_16, DST, 4>(ConvArgs, ConvArgs, hipStream_t);       \
-    template <> void launch_conv_pair<H31_16, 1, H11_32, DST, 4>(ConvArgs, ConvArgs, hipStream_t);       \
-    template <> void launch_conv_pair<H31_16, 2, H11_16, DST, 4>(ConvArgs, ConvArgs, hipStream_t);       \
-    template <> void launch_conv_pair<H31_16, 2, H11_32, DST, 4>(ConvArgs, ConvArgs, hipStream_t);       \
-    template <> void launch_conv_pair<H31_32, 1, H11_16, DST, 4>(ConvArgs, ConvArgs, hipStream_t);       \
-    template <> void launch_conv_pair<H31_32, 1, H11_32, DST, 4>(ConvArgs, ConvArgs, hipStream_t);       \
-    template <> void launch_conv_pair<H31_32, 2, H11_16, DST, 4>(ConvArgs, ConvArgs, hipStream_t);       \
-    template <> void launch_conv_pair<H31_32, 2, H11_32, DST, 4>(ConvArgs, ConvArgs, hipStream_t);
+    template <> void launch_conv_pair<H31_16, 1, H11_16, DST, 4>(ConvArgs, ConvArgs, int, hipStream_t);       \
+    template <> void launch_conv_pair<H31_16, 1, H11_32, DST, 4>(ConvArgs, ConvArgs, int, hipStream_t);       \
+    template <> void launch_conv_pair<H31_16, 2, H11_16, DST, 4>(ConvArgs, ConvArgs, int, hipStream_t);       \
+    template <> void launch_conv_pair<H31_16, 2, H11_32, DST, 4>(ConvArgs, ConvArgs, int, hipStream_t);       \
+    template <> void launch_conv_pair<H31_32, 1, H11_16, DST, 4>(ConvArgs, ConvArgs, int, hipStream_t);       \
+    template <> void launch_conv_pair<H31_32, 1, H11_32, DST, 4>(ConvArgs, ConvArgs, int, hipStream_t);       \
+    template <> void launch_conv_pair<H31_32, 2, H11_16, DST, 4>(ConvArgs, ConvArgs, int, hipStream_t);       \
+    template <> void launch_conv_pair<H31_32, 2, H11_32, DST, 4>(ConvArgs, ConvArgs, int, hipStream_t);
 SIGE_PAIR_DECLARE_H(DST_TILES) SIGE_PAIR_DECLARE_H(DST_NCHW)
 
 // Tickets of the in-kernel K-split finish (conv_mfma.hpp): one int per output block of a split launch, zero whenever no
@@ -401,7 +401,7 @@ static int plan_conv(ConvArgs &a, int cap, int want_waves, bool nb1, ConvPlan &p
 
 // conv A (planned: pa) + the held 1x1 conv in one launch; false: no pair kernel for this combination
 template <int DST, int PREC>
-static bool launch_pair(const ConvArgs &a, const ConvPlan &pa, ConvArgs b, hipStream_t st) {
+static bool launch_pair(const ConvArgs &a, const ConvPlan &pa, int mode_a, ConvArgs b, hipStream_t st) {
     using A16 = std::conditional_t<PREC == 1, H31_16, K31_16>;
     using A32 = std::conditional_t<PREC == 1, H31_32, K31_32>;
     using B16 = std::conditional_t<PREC == 1, H11_16, K11_16>;
@@ -410,8 +410,8 @@ static bool launch_pair(const ConvArgs &a, const ConvPlan &pa, ConvArgs b, hipSt
     if (plan_conv<1, 1, 4, SRC_GATHER, LAYOUT_NHWC, PREC>(b, 1, pa.waves, true, pb) != SIGE_HIP_OK) return false;
 #define SIGE_PAIR_GO(GA, NBA, W)                                                                         \
     do {                                                                                                 \
-        if (pb.mt == 32) launch_conv_pair<GA, NBA, B32, DST, W>(a, b, st);                               \
-        else launch_conv_pair<GA, NBA, B16, DST, W>(a, b, st);                                           \
+        if (pb.mt == 32) launch_conv_pair<GA, NBA, B32, DST, W>(a, b, mode_a, st);                       \
+        else launch_conv_pair<GA, NBA, B16, DST, W>(a, b, mode_a, st);                                   \
     } while (0)
 #define SIGE_PAIR_W(W)                                                                                   \
     do {                                                                                                 \
@@ -439,7 +439,7 @@ static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
     constexpr bool kHasNB2 = STR == 1;
     constexpr bool kPairLayout = SRC == SRC_GATHER && LAY == LAYOUT_NHWC && STR == 1;
     constexpr bool kPairFirst = kPairLayout && KH == 3, kPairSecond = kPairLayout && KH == 1;
-    const bool may_pair = kPairFirst && g_held.active && mode == MODE_AFFINE_SWISH && g_held.st == st && g_held.dst == DST && g_held.prec == PREC;
+    const bool may_pair = kPairFirst && g_held.active && (mode == MODE_AFFINE_SWISH || mode == MODE_RAW) && g_held.st == st && g_held.dst == DST && g_held.prec == PREC;
     if (g_held.active && !may_pair) {
         const int rc = flush_held();
         if (rc != SIGE_HIP_OK) return rc;
@@ -452,22 +452,32 @@ static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
     }
     const int cap = (LAY == LAYOUT_NHWC && a.ws) ? a.ksplit_max : 1;
     ConvPlan p;
+    const ConvArgs a0 = a;  // (as handed in: plan_conv rewrites the packed-weight pointer and the grid fields)
     const int prc = plan_conv<KH, STR, R, SRC, LAY, PREC>(a, cap, 0, false, p);
     if (prc != SIGE_HIP_OK) {
         const int rc = flush_held();
         return rc != SIGE_HIP_OK ? rc : prc;
     }
-    const int mt = p.mt, nb = p.nb, waves = p.waves;
     float *final_out = a.out;
+    if (a.ksplit > 1) {
+        a.counters = split_tickets(st, (long)a.mbk * a.ngk);
+        if (!a.counters && (a.twin0 || a.twin1)) {
+            // (the second-pass kernel does not write twins: without tickets such a launch runs unsplit)
+            const ConvArgs keep = a;
+            a = a0;
+            const int rc1 = plan_conv<KH, STR, R, SRC, LAY, PREC>(a, 1, 0, false, p);
+            if (rc1 != SIGE_HIP_OK) a = keep;
+        }
+    }
     if (a.ksplit > 1) {
         a.out = a.ws;
         a.fout = final_out;
-        a.counters = split_tickets(st, (long)a.mbk * a.ngk);
     }
+    const int mt = p.mt, nb = p.nb, waves = p.waves;
     bool done = false;
     if constexpr (kPairFirst) {
         if (may_pair) {
-            done = launch_pair<DST, PREC>(a, p, g_held.a, st);
+            done = launch_pair<DST, PREC>(a, p, mode, g_held.a, st);
             if (done) g_held.active = false;
             else {
                 const int rc = flush_held();
@@ -791,6 +801,8 @@ static int gather_conv_nhwc_impl(const float *x, const float *x2, int B, int C1,
                                              float *workspace, size_t workspace_floats,
                                              const float *out_scale, const float *out_shift, int out_activation,
                                              int upsample2x,
+                                             float *twin0, const float *twin0_scale, const float *twin0_shift,
+                                             float *twin1, const float *twin1_scale, const float *twin1_shift,
                                              float *out, void *stream) {
     const int Cin = C1 + C2;
     if (upsample2x && ((H | W) & 1)) return SIGE_HIP_EINVAL;  // (H, W) = the upsampled size
@@ -824,6 +836,13 @@ static int gather_conv_nhwc_impl(const float *x, const float *x2, int B, int C1,
         // (the second pass reads whole output copies: every pixel must be written by some tile)
         if (to_full && (long)N * Ro * So < (long)Ho * Wo) a.ksplit_max = 1;
     }
+    if ((twin0 || twin1) && !to_full) return SIGE_HIP_EINVAL;  // twins share the addressing of a full-tensor destination
+    if ((twin0 && (!twin0_scale || !twin0_shift)) || (twin1 && (!twin1_scale || !twin1_shift))) return SIGE_HIP_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(twin0) | reinterpret_cast<uintptr_t>(twin1) | reinterpret_cast<uintptr_t>(twin0_scale) |
+         reinterpret_cast<uintptr_t>(twin0_shift) | reinterpret_cast<uintptr_t>(twin1_scale) | reinterpret_cast<uintptr_t>(twin1_shift)) & 15)
+        return SIGE_HIP_EUNSUPPORTED;
+    a.twin0 = twin0; a.tscale0 = twin0_scale; a.tshift0 = twin0_shift;
+    a.twin1 = twin1; a.tscale1 = twin1_scale; a.tshift1 = twin1_shift;
     if (to_full) {
         a.residual = residual; a.Ho = Ho; a.Wo = Wo; a.offH = offsetH; a.offW = offsetW; a.strH = strideH; a.strW = strideW;
         return launch_conv<SRC_GATHER, DST_NCHW, LAYOUT_NHWC, PREC>(a, mode, kH, kW, bH, bW, strideH, strideW, as_stream(stream));
@@ -833,7 +852,8 @@ static int gather_conv_nhwc_impl(const float *x, const float *x2, int B, int C1,
 
 #define SIGE_GATHER_CONV_ARGS x, x2, B, C1, C2, H, W, bH, bW, active_indices, N, scale, scaleB, scaleC, shift, shiftB, shiftC, \
     activation, packed, bias, Cout, kH, kW, strideH, strideW, to_full, offsetH, offsetW, residual, Ho, Wo, workspace,          \
-    workspace_floats, out_scale, out_shift, out_activation, upsample2x, out, stream
+    workspace_floats, out_scale, out_shift, out_activation, upsample2x, twin0, twin0_scale, twin0_shift, twin1, twin1_scale, \
+    twin1_shift, out, stream
 extern "C" int sige_hip_gather_conv_nhwc_f32(const float *x, const float *x2, int B, int C1, int C2, int H, int W,
                                              int bH, int bW, const int32_t *active_indices, int N,
                                              const float *scale, int scaleB, int scaleC,
@@ -845,6 +865,8 @@ extern "C" int sige_hip_gather_conv_nhwc_f32(const float *x, const float *x2, in
                                              float *workspace, size_t workspace_floats,
                                              const float *out_scale, const float *out_shift, int out_activation,
                                              int upsample2x,
+                                             float *twin0, const float *twin0_scale, const float *twin0_shift,
+                                             float *twin1, const float *twin1_scale, const float *twin1_shift,
                                              float *out, void *stream) {
     return gather_conv_nhwc_impl<0>(SIGE_GATHER_CONV_ARGS);
 }
@@ -859,6 +881,8 @@ extern "C" int sige_hip_gather_conv_nhwc_f16c(const float *x, const float *x2, i
                                              float *workspace, size_t workspace_floats,
                                              const float *out_scale, const float *out_shift, int out_activation,
                                              int upsample2x,
+                                             float *twin0, const float *twin0_scale, const float *twin0_shift,
+                                             float *twin1, const float *twin1_scale, const float *twin1_shift,
                                              float *out, void *stream) {
     return gather_conv_nhwc_impl<1>(SIGE_GATHER_CONV_ARGS);
 }
@@ -921,6 +945,8 @@ static int scatter_gather_conv_scatter_nhwc_impl(
         const float *packed, const float *bias, int Cout, int kH, int kW,
         int offsetH, int offsetW, const float *residual,
         const float *x1, const int32_t *table1, int gH1, int gW1, int N1, int R1, int S1,
+        float *twin0, const float *twin0_scale, const float *twin0_shift,
+        float *twin1, const float *twin1_scale, const float *twin1_shift,
         float *out, void *stream) {
     if (B < 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || N < 0 || Rx <= 0 || Sx <= 0) return SIGE_HIP_EINVAL;
     if (kH != 3 || kW != 3 || bH != 6 || bW != 6) return SIGE_HIP_EUNSUPPORTED;  // the stride-1 3x3 geometry of a ResBlock's conv2
@@ -941,12 +967,19 @@ static int scatter_gather_conv_scatter_nhwc_impl(
     if (mode < 0) return SIGE_HIP_EUNSUPPORTED;
     a.residual = residual; a.Ho = H; a.Wo = W; a.offH = offsetH; a.offW = offsetW; a.strH = 1; a.strW = 1;
     a.x1 = x1; a.table1 = table1; a.gW1 = gW1; a.N1 = N1; a.R1 = R1 > 0 ? R1 : 1; a.S1 = S1 > 0 ? S1 : 1;
+    if ((twin0 && (!twin0_scale || !twin0_shift)) || (twin1 && (!twin1_scale || !twin1_shift))) return SIGE_HIP_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(twin0) | reinterpret_cast<uintptr_t>(twin1) | reinterpret_cast<uintptr_t>(twin0_scale) |
+         reinterpret_cast<uintptr_t>(twin0_shift) | reinterpret_cast<uintptr_t>(twin1_scale) | reinterpret_cast<uintptr_t>(twin1_shift)) & 15)
+        return SIGE_HIP_EUNSUPPORTED;
+    a.twin0 = twin0; a.tscale0 = twin0_scale; a.tshift0 = twin0_shift;
+    a.twin1 = twin1; a.tscale1 = twin1_scale; a.tshift1 = twin1_shift;
     return launch_kind<3, 1, 6, SRC_SCATTER_GATHER, DST_NCHW, LAYOUT_NHWC, PREC>(a, mode, as_stream(stream)) != SIGE_HIP_OK
                ? SIGE_HIP_EUNSUPPORTED : launch_status();
 }
 
 #define SIGE_SGS_CONV_ARGS x, y, B, Cin, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB, \
-    shiftC, activation, packed, bias, Cout, kH, kW, offsetH, offsetW, residual, x1, table1, gH1, gW1, N1, R1, S1, out, stream
+    shiftC, activation, packed, bias, Cout, kH, kW, offsetH, offsetW, residual, x1, table1, gH1, gW1, N1, R1, S1, twin0, twin0_scale, twin0_shift, twin1, \
+    twin1_scale, twin1_shift, out, stream
 extern "C" int sige_hip_scatter_gather_conv_scatter_nhwc_f32(
         const float *x, const float *y, int B, int Cin, int H, int W, int Rx, int Sx, int bH, int bW,
         const int32_t *active_indices, int N, const int32_t *scatter_map,
@@ -954,6 +987,8 @@ extern "C" int sige_hip_scatter_gather_conv_scatter_nhwc_f32(
         const float *packed, const float *bias, int Cout, int kH, int kW,
         int offsetH, int offsetW, const float *residual,
         const float *x1, const int32_t *table1, int gH1, int gW1, int N1, int R1, int S1,
+        float *twin0, const float *twin0_scale, const float *twin0_shift,
+        float *twin1, const float *twin1_scale, const float *twin1_shift,
         float *out, void *stream) {
     return scatter_gather_conv_scatter_nhwc_impl<0>(SIGE_SGS_CONV_ARGS);
 }
@@ -964,6 +999,8 @@ extern "C" int sige_hip_scatter_gather_conv_scatter_nhwc_f16c(
         const float *packed, const float *bias, int Cout, int kH, int kW,
         int offsetH, int offsetW, const float *residual,
         const float *x1, const int32_t *table1, int gH1, int gW1, int N1, int R1, int S1,
+        float *twin0, const float *twin0_scale, const float *twin0_shift,
+        float *twin1, const float *twin1_scale, const float *twin1_shift,
         float *out, void *stream) {
     return scatter_gather_conv_scatter_nhwc_impl<1>(SIGE_SGS_CONV_ARGS);
 }

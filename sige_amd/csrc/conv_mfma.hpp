@@ -186,6 +186,11 @@ struct ConvArgs {
     // K split finished inside the launch: one ticket per output block (zero between launches), and the real destination
     int32_t *counters;
     float *fout;
+    // DST full: up to two "twin" outputs of the same launch, twin_k[addr] = SiLU(tscale_k[co] * v + tshift_k[co]) with v the value
+    // the primary output receives before its own out-affine -- the activated input of a CONSUMER's conv1 (its cached GroupNorm
+    // affine + SiLU applied once by the producer instead of once per output-channel block by the consumer's staging path)
+    float *twin0, *twin1;
+    const float *tscale0, *tshift0, *tscale1, *tshift1;
 #ifdef SIGE_CONV_PROBE
     unsigned long long *probe;  // tools/conv_phase_probe.py build only: 8 timestamps per workgroup
 #endif
@@ -929,6 +934,18 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
                     }
                 }
             }
+            if constexpr (DST != DST_TILES) {
+                auto twin = [&](float *dst2, const float *ts, const float *tt) {
+                    const float4 sc = *reinterpret_cast<const float4 *>(ts + u.co), sh = *reinterpret_cast<const float4 *>(tt + u.co);
+                    float4 t;
+                    t.x = sc.x * s.x; t.y = sc.y * s.y; t.z = sc.z * s.z; t.w = sc.w * s.w;
+                    t.x = sh.x + t.x; t.y = sh.y + t.y; t.z = sh.z + t.z; t.w = sh.w + t.w;
+                    t.x = swish(t.x); t.y = swish(t.y); t.z = swish(t.z); t.w = swish(t.w);
+                    *reinterpret_cast<float4 *>(dst2 + u.addr) = t;
+                };
+                if (a.twin0) twin(a.twin0, a.tscale0, a.tshift0);
+                if (a.twin1) twin(a.twin1, a.tscale1, a.tshift1);
+            }
             if (a.oscale) {
                 float4 os, oh;
                 if constexpr (EPV) { os = e_os[k]; oh = e_oh[k]; }
@@ -1065,24 +1082,28 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
 // (3x3, gather + cached affine + SiLU: the block's conv1), the rest conv B (the 1x1 shortcut on the same input).  Both are
 // a few microseconds of work dominated by their start-up, and B's ~5 us launch disappears behind A.  A may be K-split over
 // gridDim.y; B never is (its workgroups with blockIdx.y > 0 leave at once).
-template <typename GA, int NBA, typename GB, int DST, int W>
+// MODEA: staging of conv A -- MODE_AFFINE_SWISH (the consumer activates its input), or MODE_RAW (its producers wrote an
+// activated twin: ConvArgs::twin0/1)
+template <typename GA, int NBA, typename GB, int DST, int W, int MODEA>
 __global__ __launch_bounds__(64 * W) void conv_pair_kernel(const ConvArgs a, const ConvArgs b, const int na) {
-    constexpr int LA = conv_lds_floats<GA, NBA, MODE_AFFINE_SWISH, LAYOUT_NHWC, W>();
+    constexpr int LA = conv_lds_floats<GA, NBA, MODEA, LAYOUT_NHWC, W>();
     constexpr int LB = conv_lds_floats<GB, 1, MODE_RAW, LAYOUT_NHWC, W>();
     __shared__ __attribute__((aligned(16))) float smem[cmax(LA, LB)];
     if ((int)blockIdx.x < na)
-        conv_mfma_body<GA, NBA, SRC_GATHER, MODE_AFFINE_SWISH, DST, LAYOUT_NHWC, W>(a, blockIdx.x, blockIdx.y, smem);
+        conv_mfma_body<GA, NBA, SRC_GATHER, MODEA, DST, LAYOUT_NHWC, W>(a, blockIdx.x, blockIdx.y, smem);
     else if (blockIdx.y == 0)
         conv_mfma_body<GB, 1, SRC_GATHER, MODE_RAW, DST, LAYOUT_NHWC, W>(b, blockIdx.x - na, 0, smem);
 }
 
 template <typename GA, int NBA, typename GB, int DST, int W>
-void launch_conv_pair(ConvArgs a, ConvArgs b, hipStream_t st);
+void launch_conv_pair(ConvArgs a, ConvArgs b, int mode_a, hipStream_t st);
 
 #define SIGE_CONV_PAIR_INSTANTIATE(GA, NBA, GB, DST, W)                                                   \
-    template <> void launch_conv_pair<GA, NBA, GB, DST, W>(ConvArgs a, ConvArgs b, hipStream_t st) {      \
+    template <> void launch_conv_pair<GA, NBA, GB, DST, W>(ConvArgs a, ConvArgs b, int mode_a, hipStream_t st) { \
         const int na = conv_grid_x(a);                                                                    \
-        conv_pair_kernel<GA, NBA, GB, DST, W><<<dim3(na + conv_grid_x(b), a.ksplit), 64 * W, 0, st>>>(a, b, na); \
+        const dim3 grid(na + conv_grid_x(b), a.ksplit);                                                   \
+        if (mode_a == MODE_RAW) conv_pair_kernel<GA, NBA, GB, DST, W, MODE_RAW><<<grid, 64 * W, 0, st>>>(a, b, na); \
+        else conv_pair_kernel<GA, NBA, GB, DST, W, MODE_AFFINE_SWISH><<<grid, 64 * W, 0, st>>>(a, b, na);  \
     }
 
 

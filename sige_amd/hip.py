@@ -85,24 +85,26 @@ _SIGNATURES = {
     "sige_hip_block_conv_nhwc_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp, _c_vp]),
     "sige_hip_gather_conv_nhwc_f32": (
         _c_int, [_c_vp, _c_vp] + [_c_int] * 7 + [_c_vp, _c_int] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
-        + [_c_int] * 5 + [_c_int, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_vp, _c_sz, _c_vp, _c_vp, _c_int, _c_int, _c_vp, _c_vp]),
+        + [_c_int] * 5 + [_c_int, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_vp, _c_sz, _c_vp, _c_vp, _c_int, _c_int] + [_c_vp] * 6
+        + [_c_vp, _c_vp]),
     "sige_hip_conv_ksplit_hint": (_c_int, [_c_int] * 7),
     "sige_hip_block_conv_nhwc_f16c": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp, _c_vp]),
     "sige_hip_gather_conv_nhwc_f16c": (
         _c_int, [_c_vp, _c_vp] + [_c_int] * 7 + [_c_vp, _c_int] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
-        + [_c_int] * 5 + [_c_int, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_vp, _c_sz, _c_vp, _c_vp, _c_int, _c_int, _c_vp, _c_vp]),
+        + [_c_int] * 5 + [_c_int, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_vp, _c_sz, _c_vp, _c_vp, _c_int, _c_int] + [_c_vp] * 6
+        + [_c_vp, _c_vp]),
     "sige_hip_scatter_gather_conv_nhwc_f16c": (
         _c_int, [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
         + [_c_int] * 5 + [_c_vp, _c_vp]),
     "sige_hip_scatter_gather_conv_scatter_nhwc_f16c": (
         _c_int, [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
-        + [_c_int] * 3 + [_c_int, _c_int, _c_vp] + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp, _c_vp]),
+        + [_c_int] * 3 + [_c_int, _c_int, _c_vp] + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp] * 6 + [_c_vp, _c_vp]),
     "sige_hip_scatter_gather_conv_nhwc_f32": (
         _c_int, [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
         + [_c_int] * 5 + [_c_vp, _c_vp]),
     "sige_hip_scatter_gather_conv_scatter_nhwc_f32": (
         _c_int, [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
-        + [_c_int] * 3 + [_c_int, _c_int, _c_vp] + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp, _c_vp]),
+        + [_c_int] * 3 + [_c_int, _c_int, _c_vp] + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp] * 6 + [_c_vp, _c_vp]),
     "sige_hip_gather_nhwc_f32": (
         _c_int, [_c_vp] + [_c_int] * 6 + [_c_vp, _c_int] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]),
     "sige_hip_scatter_gather_nhwc_f32": (
@@ -830,6 +832,28 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+def _twin_args(twins, like: torch.Tensor, Cout: int, name: str):
+    """The six twin pointers of a full-tensor conv launch (include/sige_hip.h) from `twins` = up to two (buffer, scale,
+    shift): buffer = channels-last tensor shaped like the launch's output, scale / shift = [Cout] (or [1,Cout,1,1]) fp32.
+    Returns (args, keep-alive list)."""
+    args, keep = [], []
+    for k in range(2):
+        if twins is not None and k < len(twins):
+            buf, sc, sh = twins[k]
+            if tuple(buf.shape) != tuple(like.shape) or not buf.is_contiguous(memory_format=CL) or buf.dtype != torch.float32:
+                raise RuntimeError("%s: twin %d must be a channels-last fp32 tensor shaped like the output" % (name, k))
+            sc, sh = _req(sc.reshape(-1), torch.float32, "twin_scale", 1), _req(sh.reshape(-1), torch.float32, "twin_shift", 1)
+            if sc.numel() != Cout or sh.numel() != Cout:
+                raise RuntimeError("%s: twin %d needs one scale / shift entry per output channel" % (name, k))
+            args += [buf.data_ptr(), sc.data_ptr(), sh.data_ptr()]
+            keep += [buf, sc, sh]
+        else:
+            args += [None, None, None]
+    if twins is not None and len(twins) > 2:
+        raise RuntimeError("%s: at most two twins per launch" % name)
+    return args, keep
+
+
 def block_conv_cl(x, packed, bias, Cout: int, kernel: Tuple[int, int], stride: Tuple[int, int]):
     bias_keep = _vec(bias, "bias")
     x = _req_cl(x, "x")
@@ -847,9 +871,11 @@ def block_conv_cl(x, packed, bias, Cout: int, kernel: Tuple[int, int], stride: T
 def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, activationName: str,
                    packed, bias, Cout: int, kernel: Tuple[int, int], stride: Tuple[int, int],
                    full: Optional[dict] = None, out_affine: Optional[tuple] = None, upsample2x: bool = False,
-                   out: Optional[torch.Tensor] = None):
+                   out: Optional[torch.Tensor] = None, twins=None):
     """Channels-last gather -> conv.  `full` = dict(offset=(oh, ow), out_res=(Ho, Wo), residual=tensor|None)
-    writes the output tiles straight into a [B,Cout,Ho,Wo] tensor (dense layers).  None if unsupported."""
+    writes the output tiles straight into a [B,Cout,Ho,Wo] tensor (dense layers).  `twins` (full only): up to two
+    (buffer, scale, shift): buffer = SiLU(scale * result + shift), the activated input of a consumer's conv1, written by
+    the same launch.  None if unsupported."""
     bias_keep = _vec(bias, "bias")
     x = _req_cl(x, "x")
     B, C1, H, W = x.shape
@@ -896,7 +922,10 @@ def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, a
         fargs = fargs + (os_.data_ptr(), oh_.data_ptr(), _act(oact))
     else:
         fargs = fargs + (None, None, 0)
-    fargs = fargs + (int(bool(upsample2x)),)
+    if twins and full is None:
+        raise RuntimeError("gather_conv_cl: twins need a full-tensor destination")
+    targs, twin_keep = _twin_args(twins if twins else None, out, Cout, "gather_conv_cl")
+    fargs = fargs + (int(bool(upsample2x)), *targs)
     status = _conv_fn("sige_hip_gather_conv_nhwc", packed)(
         x.data_ptr(), None if x2 is None else x2.data_ptr(), B, C1, C2, H, W, block[0], block[1], idx.data_ptr(), N,
         *sa, *ta, _act(activationName), packed.data_ptr(), _p(bias_keep), Cout, kernel[0], kernel[1],
@@ -906,7 +935,7 @@ def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, a
     _check(status, "gather_conv_cl")
     keep = getattr(_pair_state, "keep", None)
     if keep is not None:  # (conv_pair(): a held launch reads these after this call has returned)
-        keep.append((x, x2, idx, s_keep, t_keep, packed, bias_keep, out, ws, out_affine, full))
+        keep.append((x, x2, idx, s_keep, t_keep, packed, bias_keep, out, ws, out_affine, full, twin_keep))
     return out
 
 
@@ -933,7 +962,7 @@ def scatter_gather_conv_cl(x, y, block: Tuple[int, int], activeIndices, scatterM
 
 def scatter_gather_conv_scatter_cl(x, y, block, activeIndices, scatterMap, scale, shift, activationName: str,
                                    packed, bias, Cout: int, kernel, offset, out: torch.Tensor, residual=None,
-                                   x1=None, table1=None):
+                                   x1=None, table1=None, twins=None):
     """scatter_gather -> 3x3 conv -> Scatter (residual = a full tensor) or ScatterWithBlockResidual (residual = the
     cached shortcut tensor, x1 = the shortcut conv's tiles, table1 = their tile table) in one launch, written into
     `out` (a persistent buffer that already equals the cache outside this mask's tiles).  None if unsupported."""
@@ -954,10 +983,11 @@ def scatter_gather_conv_scatter_cl(x, y, block, activeIndices, scatterMap, scale
         bargs = (x1.data_ptr(), t1.data_ptr(), t1.shape[0], t1.shape[1], x1.shape[0] // B, x1.shape[2], x1.shape[3])
     else:
         bargs = (None, None, 0, 0, 0, 0, 0)
+    targs, twin_keep = _twin_args(twins if twins else None, out, Cout, "scatter_gather_conv_scatter_cl")
     status = _conv_fn("sige_hip_scatter_gather_conv_scatter_nhwc", packed)(
         x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3], block[0], block[1], idx.data_ptr(), idx.shape[0],
         smap.data_ptr(), *sa, *ta, _act(activationName), packed.data_ptr(), _p(bias_keep), Cout, kernel[0], kernel[1],
-        offset[0], offset[1], None if r is None else r.data_ptr(), *bargs, out.data_ptr(), _stream(y))
+        offset[0], offset[1], None if r is None else r.data_ptr(), *bargs, *targs, out.data_ptr(), _stream(y))
     if status == UNSUPPORTED:
         return None
     _check(status, "scatter_gather_conv_scatter_cl")

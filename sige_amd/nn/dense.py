@@ -71,19 +71,30 @@ def _act(x, name):
 def fused_conv2d(conv: nn.Conv2d, x: torch.Tensor, scale: Optional[torch.Tensor] = None,
                  shift: Optional[torch.Tensor] = None, activation_name: str = "identity",
                  x2: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-                 pad_bottom_right: bool = False, out_affine: Optional[tuple] = None) -> torch.Tensor:
+                 pad_bottom_right: bool = False, out_affine: Optional[tuple] = None,
+                 twins: Optional[dict] = None) -> torch.Tensor:
     """conv(act(cat(x, x2) * scale + shift)) + residual.  scale/shift: [1|B, C, 1, 1].
     `pad_bottom_right`: the DDPM downsample's (0,1,0,1) zero padding (stride-2 convs).
     `out_affine` = (scale, shift, activation) of the CONSUMER, applied to the result in the kernel's
-    epilogue (one launch, once per element): act(out * scale + shift)."""
-    out = _fused_conv2d(conv, x, scale, shift, activation_name, x2, residual, pad_bottom_right, out_affine)
+    epilogue (one launch, once per element): act(out * scale + shift).
+    `twins` = {key: (scale [Cout], shift [Cout])} (at most two): where the launch can, it also writes
+    SiLU(scale * result + shift) -- the activated input of a consumer's conv1 -- and returns them as
+    `out._sige_twins[key]` (scatter.tag_twins); a consumer that finds no entry activates for itself."""
+    made = {}
+    out = _fused_conv2d(conv, x, scale, shift, activation_name, x2, residual, pad_bottom_right, out_affine, twins, made)
     if isinstance(out, tuple):  # (tensor, epilogue still to apply)
         out, (os_, oh_, oact) = out
         out = _act(out * os_.reshape(1, -1, 1, 1) + oh_.reshape(1, -1, 1, 1), oact)
+    if not made and twins and out_affine is None:
+        from . import scatter
+
+        if scatter.EMULATE_TWINS:  # (tests only: see scatter.EMULATE_TWINS)
+            made = scatter.emulated_twins(out, twins)
+    out._sige_twins = made
     return out
 
 
-def _fused_conv2d(conv, x, scale, shift, activation_name, x2, residual, pad_bottom_right, out_affine):
+def _fused_conv2d(conv, x, scale, shift, activation_name, x2, residual, pad_bottom_right, out_affine, twins=None, made=None):
     if x.is_cuda and x.dtype == torch.float32 and fusable(conv):
         from .. import hip
 
@@ -104,10 +115,18 @@ def _fused_conv2d(conv, x, scale, shift, activation_name, x2, residual, pad_bott
                 return out
         idx = hip.all_tiles(H, W, out_tile, conv.stride, offset, x.device)
         if hip.is_cl(x) and hip.cl_supported(x.shape[1], 0 if x2 is None else x2.shape[1], conv.out_channels):
+            tw = []
+            if twins and out_affine is None:  # (a twin is a function of the RAW result: the primary output must be it)
+                for key, (sc, sh) in list(twins.items())[:2]:
+                    tw.append((key, torch.empty((B, conv.out_channels, Ho, Wo), dtype=torch.float32, device=x.device,
+                                                memory_format=torch.channels_last), sc, sh))
             out = hip.gather_conv_cl(x, x2, block, idx, scale, shift, activation_name, _packed(conv, block), conv.bias,
                                      conv.out_channels, conv.kernel_size, conv.stride,
-                                     full=dict(offset=offset, out_res=(Ho, Wo), residual=residual), out_affine=out_affine)
+                                     full=dict(offset=offset, out_res=(Ho, Wo), residual=residual), out_affine=out_affine,
+                                     twins=[(b, sc, sh) for _, b, sc, sh in tw] or None)
             if out is not None:
+                if made is not None:
+                    made.update({k: b for k, b, _, _ in tw})
                 return out
         out = hip.gather_conv_nchw(x.contiguous(), None if x2 is None else x2.contiguous(), block, idx,
                                     scale, shift, activation_name, _packed(conv, block, False), conv.bias,

@@ -60,9 +60,12 @@ class Gather(SIGEModule):
 
     def forward(
         self, x: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
-        upsample2x: bool = False
+        upsample2x: bool = False, preactivated: bool = False
     ) -> torch.Tensor:
-        """`upsample2x` (sparse mode, not in the reference): `x` is the HALF-resolution tensor and the tiles are
+        """`preactivated` (sparse mode, not in the reference): `x` already IS activation(scale * input + shift) -- an
+        activated twin its producer wrote (sige_amd.hip: twins) -- so the tiles are gathered raw whatever this module's
+        activation is.  Zero fill stays zero (gather.cpp:27-30: padding is never transformed; SiLU(0) = 0 anyway).
+        `upsample2x` (sparse mode, not in the reference): `x` is the HALF-resolution tensor and the tiles are
         taken from its x2 nearest-neighbour upsampling -- which the fused gather -> conv kernel never materialises
         (the `F.interpolate` in front of the U-Net's upsampling convs).  Only valid where `fuses_upsample(x)` holds;
         anywhere else the MODEL upsamples, as the reference's does (sige_fused_unet.py:222-227), and calls the
@@ -75,6 +78,11 @@ class Gather(SIGEModule):
                 raise ValueError("Gather(upsample2x=True) needs the fused channels-last gather -> conv path "
                                  "(sparse mode, channels-last fp32 GPU tensor, per-channel affine); upsample in the model instead")
         if self.mode == "sparse":
+            act_name = self.activation_name
+            if preactivated:
+                if scale is not None or shift is not None:
+                    raise ValueError("Gather(preactivated=True) takes no scale / shift: the input already carries them")
+                act_name = "identity"
             x2 = None
             if isinstance(x, deferred.LazyCat) and x.spec is not None:
                 # a pending cat: keep the two tensors apart if the fused conv can read them in place
@@ -82,7 +90,7 @@ class Gather(SIGEModule):
                 from .. import hip
 
                 if (hip.cat_fusable(a.shape[0], a.shape[1], self.kernel_size) and a.shape[1] % 4 == 0 and b.shape[1] % 4 == 0
-                        and deferred.defer_ok(a, scale, shift, self.activation_first, self.sparse_update, self.activation_name)
+                        and deferred.defer_ok(a, scale, shift, self.activation_first, self.sparse_update, act_name)
                         and hip.is_cl(a) and hip.is_cl(b)):
                     x, x2 = a, b
             fn = self.native(self.runtime, x)
@@ -95,7 +103,7 @@ class Gather(SIGEModule):
             scale = None if scale is None else scale.contiguous()
             shift = None if shift is None else shift.contiguous()
             bh, bw = self.block_size
-            act, first = self.activation_name, self.activation_first
+            act, first = act_name, self.activation_first
 
             def run():
                 xx = x if x2 is None else torch.cat([x, x2], dim=1)

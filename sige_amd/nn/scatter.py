@@ -58,11 +58,13 @@ class _OutputBuffers:
         self.bufs = {}
         self.gen = {}
 
-    def get(self, cache_id, cached: torch.Tensor, stamp):
+    def get(self, cache_id, cached: torch.Tensor, stamp, build=None):
+        """`build(cached)`: what a fresh buffer holds (default: a copy of the cache; an activated twin: its activation)."""
         entry = self.bufs.get(cache_id)
         key = (stamp, self.gen.get(cache_id, 0), tuple(cached.shape), cached.stride())
         if entry is None or entry[0] != key:
-            entry = (key, cached.clone(memory_format=torch.preserve_format))
+            buf = cached.clone(memory_format=torch.preserve_format) if build is None else build(cached)
+            entry = (key, buf, build)
             self.bufs[cache_id] = entry
         return entry[1]
 
@@ -75,15 +77,83 @@ class _OutputBuffers:
     def refresh(self, caches: dict):
         """The cached tensors were rewritten IN PLACE (same tensors, new values -- e.g. a collective into the packed
         cache): re-copy them into the existing buffers, whose addresses a captured hipGraph may hold."""
-        for cid, (key, buf) in list(self.bufs.items()):
+        for cid, (key, buf, build) in list(self.bufs.items()):
             cached = caches.get(cid)
             if cached is not None and tuple(cached.shape) == tuple(buf.shape) and cached.stride() == buf.stride():
-                buf.copy_(cached)
+                buf.copy_(cached if build is None else build(cached))
             else:
                 self.bufs.pop(cid)
 
     def clear(self):
         self.bufs = {}
+
+
+class _TwinBuffers:
+    """Activated twins of a Scatter module's persistent output (not in the reference).
+
+    A CONSUMER whose conv1 applies a cached GroupNorm affine + SiLU to this module's output can register (scale, shift)
+    under a key; the fused conv -> scatter launch then also writes SiLU(scale * value + shift) for every pixel it writes
+    into a second persistent buffer that equals SiLU(scale * cache + shift) elsewhere -- the consumer stages raw values
+    (the activation is computed once per element by the producer instead of once per output-channel block).  At most two
+    registrations (a skip tensor has two consumers); further ones are refused and those consumers keep activating."""
+
+    MAX = 2
+
+    def __init__(self):
+        self.regs = {}   # key -> (scale [C], shift [C])
+        self.bufs = {}   # key -> _OutputBuffers
+
+    def register(self, key, scale: torch.Tensor, shift: torch.Tensor) -> bool:
+        if key not in self.regs and len(self.regs) >= self.MAX:
+            return False
+        self.regs[key] = (scale, shift)
+        self.bufs.pop(key, None)
+        return True
+
+    def unregister(self, key):
+        self.regs.pop(key, None)
+        self.bufs.pop(key, None)
+
+    def launch_args(self, cache_id, cached: torch.Tensor, stamp):
+        """[(key, buffer, scale, shift)] for the fused launch; buffers are (re)built from the cache when stale."""
+        out = []
+        for key, (sc, sh) in self.regs.items():
+            def build(c, sc=sc, sh=sh):
+                return torch.nn.functional.silu(c * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).contiguous(
+                    memory_format=torch.channels_last)
+            buf = self.bufs.setdefault(key, _OutputBuffers()).get(cache_id, cached, stamp, build=build)
+            out.append((key, buf, sc, sh))
+        return out
+
+    def invalidate(self, cache_id=None):
+        for b in self.bufs.values():
+            b.invalidate(cache_id)
+
+    def refresh(self, caches: dict):
+        for b in self.bufs.values():
+            b.refresh(caches)
+
+    def clear(self):
+        self.bufs = {}
+
+
+# Tests only (tests/test_host_logic.py): where a launch cannot write twins itself (no GPU: the CPU path goes through the
+# plain Scatter kernels), compute them from the finished output with torch -- the registration / invalidation logic of the
+# twins can then be exercised end to end on the oracle backend.  Never set in the product.
+EMULATE_TWINS = False
+
+
+def emulated_twins(out: torch.Tensor, regs: dict) -> dict:
+    return {k: torch.nn.functional.silu(out * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) for k, (sc, sh) in list(regs.items())[:2]}
+
+
+def tag_twins(out: torch.Tensor, twins: dict, producer=None) -> torch.Tensor:
+    """Attach {consumer key: activated twin} (possibly empty: persistent outputs keep their Python object, a stale
+    entry must not survive a launch that did not write it) and the producing module to an output tensor."""
+    out._sige_twins = twins
+    if producer is not None:
+        out._sige_producer = producer
+    return out
 
 
 class Scatter(SIGEModule):
@@ -96,14 +166,17 @@ class Scatter(SIGEModule):
         self.original_outputs = {}
         self.inplace = False
         self._out_bufs = _OutputBuffers()
+        self.twins = _TwinBuffers()
 
     def clear_cache(self):
         self.original_outputs = {}
         self._out_bufs.clear()
+        self.twins.clear()
 
     def refresh_outputs(self):
         """(sige_amd.parallel) the cache tensors were rewritten in place: persistent outputs follow, addresses kept."""
         self._out_bufs.refresh(self.original_outputs)
+        self.twins.refresh(self.original_outputs)
 
     def forward_fused(self, conv, tiles: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         """(not in the reference) `self(conv(tiles), residual)` in ONE launch when the in-place mode is on and `tiles`
@@ -114,9 +187,10 @@ class Scatter(SIGEModule):
             cached = self.original_outputs[self.cache_id]
             if _cl_ok(cached, residual) and isinstance(tiles, deferred.DeferredTiles) and tiles.spec is not None:
                 out = self._out_bufs.get(self.cache_id, cached, g.timestamp)
-                done = _fused_conv_into(conv, tiles, out, g, residual=residual)
+                tw = self.twins.launch_args(self.cache_id, cached, g.timestamp)
+                done = _fused_conv_into(conv, tiles, out, g, residual=residual, twins=[(b, sc, sh) for _, b, sc, sh in tw])
                 if done is not None:
-                    return done
+                    return tag_twins(done, {k: b for k, b, _, _ in tw})
         return self.forward(conv(tiles), residual)
 
     def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -146,12 +220,15 @@ class Scatter(SIGEModule):
             if self.sparse_update:
                 cached.copy_(output)
                 self._out_bufs.invalidate(self.cache_id)
-            return output
+                self.twins.invalidate(self.cache_id)
+            # (this launch wrote no twin: consumers activate for themselves)
+            return tag_twins(output, emulated_twins(output, self.twins.regs) if EMULATE_TWINS else {})
         if self.mode == "full":
             output = x if residual is None else x + residual
             self.output_res = output.shape[2:]
             self.original_outputs[self.cache_id] = deferred.keep_layout(output)
             self._out_bufs.invalidate(self.cache_id)
+            self.twins.invalidate(self.cache_id)
             return output
         if self.mode == "profile":
             c = x.shape[1]
@@ -163,7 +240,7 @@ class Scatter(SIGEModule):
         raise NotImplementedError("Unknown mode: [%s]!!!" % self.mode)
 
 
-def _fused_conv_into(conv, tiles, out, g: Gather, residual=None, x1=None, table1=None):
+def _fused_conv_into(conv, tiles, out, g: Gather, residual=None, x1=None, table1=None, twins=None):
     """Run `conv` on the pending (deferred) tiles with its output written straight into `out` at the tile positions of
     gather `g`.  Returns `out`, or None when the combination has no fused kernel."""
     from .. import hip
@@ -182,12 +259,13 @@ def _fused_conv_into(conv, tiles, out, g: Gather, residual=None, x1=None, table1
         return hip.gather_conv_cl(spec["x"], spec.get("x2"), spec["block"], spec["idx"], spec["scale"], spec["shift"], spec["act"],
                                   packed, conv.bias, conv.out_channels, conv.kernel_size, conv.stride,
                                   full=dict(offset=g.offset, out_res=tuple(out.shape[2:]), residual=residual),
-                                  upsample2x=spec.get("up", False), out=out)
+                                  upsample2x=spec.get("up", False), out=out, twins=twins)
     if tuple(conv.kernel_size) != (3, 3) or tuple(conv.stride) != (1, 1):
         return None
     return hip.scatter_gather_conv_scatter_cl(spec["x"], spec["y"], spec["block"], spec["idx"], spec["map"], spec["scale"],
                                               spec["shift"], spec["act"], packed, conv.bias, conv.out_channels,
-                                              conv.kernel_size, g.offset, out, residual=residual, x1=x1, table1=table1)
+                                              conv.kernel_size, g.offset, out, residual=residual, x1=x1, table1=table1,
+                                              twins=twins)
 
 
 class ScatterWithBlockResidual(SIGEModule):
@@ -206,15 +284,18 @@ class ScatterWithBlockResidual(SIGEModule):
         self.original_residuals = {}
         self.inplace = False
         self._out_bufs = _OutputBuffers()
+        self.twins = _TwinBuffers()
 
     def clear_cache(self):
         self.original_outputs = {}
         self.original_residuals = {}
         self._out_bufs.clear()
+        self.twins.clear()
 
     def refresh_outputs(self):
         """(sige_amd.parallel) the cache tensors were rewritten in place: persistent outputs follow, addresses kept."""
         self._out_bufs.refresh(self.original_outputs)
+        self.twins.refresh(self.original_outputs)
 
     def forward_fused(self, conv, tiles: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
         """(not in the reference) `self(conv(tiles), residual)` in ONE launch (see Scatter.forward_fused): `residual` are
@@ -228,9 +309,11 @@ class ScatterWithBlockResidual(SIGEModule):
                     and sg.active_indices.size(0) <= mg.active_indices.size(0)):
                 out = self._out_bufs.get(self.cache_id, y0, (mg.timestamp, sg.timestamp))
                 x1 = deferred.resolve(residual)
-                done = _fused_conv_into(conv, tiles, out, mg, residual=y1, x1=x1, table1=sg.tile_table(y0.shape[2:], y0.device))
+                tw = self.twins.launch_args(self.cache_id, y0, (mg.timestamp, sg.timestamp))
+                done = _fused_conv_into(conv, tiles, out, mg, residual=y1, x1=x1, table1=sg.tile_table(y0.shape[2:], y0.device),
+                                        twins=[(b, sc, sh) for _, b, sc, sh in tw])
                 if done is not None:
-                    return done
+                    return tag_twins(done, {k: b for k, b, _, _ in tw})
         return self.forward(conv(tiles), residual)
 
     def forward(self, x: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
@@ -268,6 +351,7 @@ class ScatterWithBlockResidual(SIGEModule):
                     self.scatter_runtime = self.load_runtime("scatter", {})
                 y0.copy_(output)
                 self._out_bufs.invalidate(self.cache_id)
+                self.twins.invalidate(self.cache_id)
                 if _fused_ok(x):
                     from .. import hip
 
@@ -277,7 +361,7 @@ class ScatterWithBlockResidual(SIGEModule):
                     fn = self.native(self.scatter_runtime, x)
                     y1.copy_(fn(residual.contiguous(), y1.contiguous(), sg.offset[0], sg.offset[1],
                                 sg.model_stride[0], sg.model_stride[1], sg.indices_on(x.device), None))
-            return output
+            return tag_twins(output, emulated_twins(output, self.twins.regs) if EMULATE_TWINS else {})  # (no twin written)
         if self.mode == "full":
             output = x + residual
             self.output_res = output.shape[2:]
@@ -287,6 +371,7 @@ class ScatterWithBlockResidual(SIGEModule):
                 residual.contiguous(memory_format=torch.channels_last) if cl and not residual.is_contiguous()
                 else deferred.keep_layout(residual))
             self._out_bufs.invalidate(self.cache_id)
+            self.twins.invalidate(self.cache_id)
             return output
         if self.mode == "profile":
             c = x.shape[1]

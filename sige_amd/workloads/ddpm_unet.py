@@ -54,6 +54,13 @@ class DDPMConfig:
     preactivate: bool = True
     # launch the shortcut 1x1 of a ResBlock inside the kernel of its conv1 (sige_amd.hip.conv_pair: horizontal fusion)
     pair_shortcut: bool = True
+    # conv1 inputs activated by their PRODUCERS: every module whose output feeds a ResBlock's conv1 also writes
+    # SiLU(scale1 * out + shift1) (an "activated twin", sige_amd.nn.scatter._TwinBuffers / dense.fused_conv2d(twins=...)), so
+    # conv1 stages raw values -- the cached affine + SiLU is computed once per element instead of once per
+    # output-channel block (8-16 per layer).  Consumers register on their first sparse forward and activate for
+    # themselves until the twin exists.  (WIP: written without GPU time left in round 2 -- validate first:
+    # tests/test_gpu_round2.py::test_ddpm_forward_twins_vs_no_twins, then bench.py; measured upper bound -76 us / forward.)
+    conv1_twins: bool = True
     # run the shortcut branch of a ResBlock (1x1 conv on the block input) on a second stream (it is independent of
     # conv1 -> conv2).  Measured on MI355X / ROCm 7.2: the cross-stream graph edges cost more than the overlap gains
     # (2.05 ms vs 1.82 ms per forward), so it is off by default.
@@ -85,7 +92,44 @@ def _as4(v: torch.Tensor) -> torch.Tensor:
     return v.reshape(1, -1, 1, 1)
 
 
-class ResBlock(SIGEModule):
+class _TwinProducer:
+    """Mixin of the modules whose output is written by a full-tensor conv epilogue and can therefore carry activated twins
+    for the conv1 of a consumer (cfg.conv1_twins).  `_twin_scatter()`: the Scatter module that owns the persistent in-place
+    output (SIGE layers: persistent twins live next to it), or None (dense layers: a fresh twin per forward)."""
+
+    def _twin_scatter(self):
+        return None
+
+    def _twins_ok(self) -> bool:
+        return True
+
+    def register_twin(self, key, scale: torch.Tensor, shift: torch.Tensor) -> bool:
+        if not self._twins_ok():
+            return False
+        sct = self._twin_scatter()
+        if sct is not None:
+            return sct.twins.register(key, scale, shift)
+        regs = self.__dict__.setdefault("twin_regs", {})
+        if key not in regs and len(regs) >= 2:
+            return False
+        regs[key] = (scale, shift)
+        return True
+
+    def unregister_twin(self, key):
+        sct = self._twin_scatter()
+        if sct is not None:
+            sct.twins.unregister(key)
+        self.__dict__.setdefault("twin_regs", {}).pop(key, None)
+
+    def _produced(self, out: torch.Tensor) -> torch.Tensor:
+        """Mark `out` as this module's output of the current sparse forward (consumers find their producer through it)."""
+        out._sige_producer = self
+        if not hasattr(out, "_sige_twins"):
+            out._sige_twins = {}
+        return out
+
+
+class ResBlock(SIGEModule, _TwinProducer):
     def __init__(self, cfg: DDPMConfig, cin: int, cout: int, sparse: bool):
         super().__init__()
         self.cin, self.cout = cin, cout
@@ -112,10 +156,52 @@ class ResBlock(SIGEModule):
         self.preactivate = cfg.preactivate
         self.overlap = cfg.overlap_shortcut
         self.pair = cfg.pair_shortcut
+        self.use_twins = cfg.conv1_twins
+        self.twin_regs = {}     # as a producer (dense blocks): consumer key -> (scale, shift)
+        self._twin_links = {}   # as a consumer: key -> the producer it registered with
+        self._aff_gen = 0       # bumped when the cached affine is recomputed: old twins are for the old affine
         self._side = None
 
     def clear_cache(self):
         self.affine = {}
+        self._drop_twin_links()
+
+    # ---- activated twins (cfg.conv1_twins) ----
+    def _twin_scatter(self):
+        return self.scatter if self.sparse_main else None
+
+    def _drop_twin_links(self):
+        for key, prod in self._twin_links.items():
+            prod.unregister_twin(key)
+        self._twin_links = {}
+        self._aff_gen += 1
+
+    def _twin_inputs(self, parts, s1, t1):
+        """The activated twins of this block's conv1 inputs, one per part of the (possibly concatenated) input -- or None
+        (then conv1 activates in its staging path, as without twins).  A missing twin is requested from the module that
+        produced the part; it exists from the next forward on."""
+        from ..nn import scatter as _scatter
+
+        if not (self.use_twins and self.preactivate and self.mode == "sparse" and (parts[0].is_cuda or _scatter.EMULATE_TWINS)):
+            return None
+        if s1.shape[0] != 1:
+            return None  # (per-sample affine: the epilogue's twin vectors are per channel)
+        twins, off, complete = [], 0, True
+        for i, p in enumerate(parts):
+            c = p.shape[1]
+            key = (id(self), i, self._aff_gen)
+            t = getattr(p, "_sige_twins", {}).get(key)
+            if t is None:
+                complete = False
+                prod = getattr(p, "_sige_producer", None)
+                if prod is not None and key not in self._twin_links:
+                    sc = s1.reshape(-1)[off:off + c].contiguous()
+                    sh = t1.reshape(-1)[off:off + c].contiguous()
+                    if prod.register_twin(key, sc, sh):
+                        self._twin_links[key] = prod
+            twins.append(t)
+            off += c
+        return twins if complete else None
 
     def rebuild_derived_caches(self):
         """(sige_amd.parallel) the cache tensors were rewritten in place: recompute the activated ScatterGather copy."""
@@ -191,6 +277,7 @@ class ResBlock(SIGEModule):
         te = temb.reshape(-1)
         s2, t2 = norm_affine(h + _as4(te), self.norm2)
         t2 = t2 + te * s2  # fold the timestep-embedding add into the cached shift
+        self._drop_twin_links()  # (twins written for the previous affine are stale)
         self.affine[self.cache_id] = tuple(_as4(v).contiguous() for v in (s1, t1, s2, t2))
         if self.sparse_main and self.preactivate:
             self.scatter_gather.cache_activated(_as4(s2), _as4(t2))
@@ -200,14 +287,20 @@ class ResBlock(SIGEModule):
     def _sparse(self, x):
         s1, t1, s2, t2 = self.affine[self.cache_id]
         if self.sparse_main and self.preactivate and self.mode == "sparse":
-            first = x.parts[0] if hasattr(x, "parts") else x
+            parts = list(x.parts) if hasattr(x, "parts") else [x]
+            first = parts[0]
+            tw = self._twin_inputs(parts, s1, t1)
             with self._pairing(first):
                 skip, join = (self._shortcut_async(lambda: self._shortcut(x), first) if self.cin != self.cout
                               else (x, lambda: None))
-                h = self.conv1(self.main_gather(x, s1, t1), out_affine=(s2, t2, "swish"))
+                if tw is not None:  # the producers wrote SiLU(s1 * x + t1): conv1 stages raw values
+                    xa = tw[0] if len(tw) == 1 else lazy_cat(tw[0], tw[1])
+                    h = self.conv1(self.main_gather(xa, preactivated=True), out_affine=(s2, t2, "swish"))
+                else:
+                    h = self.conv1(self.main_gather(x, s1, t1), out_affine=(s2, t2, "swish"))
             tiles = self.scatter_gather(h, preactivated=True)
             join()
-            return self.scatter.forward_fused(self.conv2, tiles, skip)
+            return self._produced(self.scatter.forward_fused(self.conv2, tiles, skip))
         if not self.sparse_main:
             return self._sparse_dense(x, None)
         skip = self._shortcut(x)
@@ -221,14 +314,19 @@ class ResBlock(SIGEModule):
         s1, t1, s2, t2 = self.affine[self.cache_id]
         join = lambda: None  # noqa: E731
         if self.preactivate:
+            tw = self._twin_inputs([x] if x2 is None else [x, x2], s1, t1)
             with self._pairing(x):
                 if self.cin == self.cout:
                     skip = x if x2 is None else torch.cat([x, x2], dim=1)
                 else:
                     skip, join = self._shortcut_async(lambda: fused_conv2d(self.nin_shortcut, x, x2=x2), x)
-                h = fused_conv2d(self.conv1, x, s1, t1, "swish", x2=x2, out_affine=(s2, t2, "swish"))
+                if tw is not None:  # the producers wrote SiLU(s1 * x + t1): conv1 stages raw values
+                    h = fused_conv2d(self.conv1, tw[0], None, None, "identity", x2=(tw[1] if len(tw) > 1 else None),
+                                     out_affine=(s2, t2, "swish"))
+                else:
+                    h = fused_conv2d(self.conv1, x, s1, t1, "swish", x2=x2, out_affine=(s2, t2, "swish"))
             join()
-            return fused_conv2d(self.conv2, h, residual=skip)
+            return self._produced(fused_conv2d(self.conv2, h, residual=skip, twins=self.twin_regs))
         if self.cin == self.cout:
             skip = x if x2 is None else torch.cat([x, x2], dim=1)
         else:
@@ -238,10 +336,11 @@ class ResBlock(SIGEModule):
         return fused_conv2d(self.conv2, h, s2, t2, "swish", residual=skip)
 
 
-class AttnBlock(SIGEModule):
+class AttnBlock(SIGEModule, _TwinProducer):
     def __init__(self, cfg: DDPMConfig, ch: int, sparse: bool):
         super().__init__()
         self.ch = ch
+        self.twin_regs = {}
         self.quirk = cfg.reference_attn_quirk
         self.sparse = sparse and cfg.shortcut_block is not None
         Conv = SIGEConv2d if self.sparse else nn.Conv2d
@@ -303,13 +402,19 @@ class AttnBlock(SIGEModule):
         attn = torch.softmax(torch.bmm(q.transpose(1, 2), k) * (self.ch ** -0.5), dim=2)
         return torch.bmm(v, attn.transpose(1, 2)).reshape(b, self.ch, hh, ww)
 
+    def _twins_ok(self) -> bool:
+        return not self.sparse  # (the tiled form ends in a plain Scatter with a residual: not wired for twins)
+
     def _dense_sparse(self, x, s, t):
         qkv = fused_conv2d(self.qkv, x, s, t, "identity")
-        return fused_conv2d(self.proj_out, self._attention(qkv), residual=x)
+        return self._produced(fused_conv2d(self.proj_out, self._attention(qkv), residual=x, twins=self.twin_regs))
 
 
-class Upsample(SIGEModule):
+class Upsample(SIGEModule, _TwinProducer):
     """nearest x2 then a tiled 3x3 conv (always tiled, as in the reference)."""
+
+    def _twin_scatter(self):
+        return self.scatter
 
     def __init__(self, cfg: DDPMConfig, ch: int):
         super().__init__()
@@ -321,18 +426,21 @@ class Upsample(SIGEModule):
     def forward(self, x):
         if self.mode == "sparse" and self.gather.fuses_upsample(x):
             # the upsampled tensor only feeds the gather: read the half-resolution one at (h/2, w/2) instead
-            return self.scatter.forward_fused(self.conv, self.gather(x, upsample2x=True))
+            return self._produced(self.scatter.forward_fused(self.conv, self.gather(x, upsample2x=True)))
         x = F.interpolate(x, scale_factor=2.0, mode="nearest")
         if self.mode == "sparse":
-            return self.scatter.forward_fused(self.conv, self.gather(x))
+            return self._produced(self.scatter.forward_fused(self.conv, self.gather(x)))
         if self.plain and self.mode == "full":
             return self.conv(x)
         return self.scatter(self.conv(self.gather(x)))
 
 
-class Downsample(SIGEModule):
+class Downsample(SIGEModule, _TwinProducer):
     """3x3 stride-2 conv with (0,1,0,1) zero padding; tiled when `sparse` (the
     gather's zero fill past the bottom/right border IS the padding then)."""
+
+    def _twin_scatter(self):
+        return self.scatter if self.sparse else None
 
     def __init__(self, cfg: DDPMConfig, ch: int, sparse: bool):
         super().__init__()
@@ -345,14 +453,14 @@ class Downsample(SIGEModule):
 
     def forward(self, x):
         if not self.sparse and self.mode == "sparse":
-            return fused_conv2d(self.conv, x, pad_bottom_right=True)
+            return self._produced(fused_conv2d(self.conv, x, pad_bottom_right=True, twins=self.__dict__.get("twin_regs")))
         if not self.sparse or (self.plain and self.mode == "full"):
             return self.conv(F.pad(x, (0, 1, 0, 1)))
         x = self.gather(x)
         if self.mode == "full":
             x = F.pad(x, (0, 1, 0, 1))
         if self.mode == "sparse":
-            return self.scatter.forward_fused(self.conv, x)
+            return self._produced(self.scatter.forward_fused(self.conv, x))
         return self.scatter(self.conv(x))
 
 

@@ -463,3 +463,92 @@ def test_paired_convs_is_a_noop_off_the_gpu():
         assert ctx is None
     with paired_convs(x, enabled=False) as ctx:
         assert ctx is None
+
+
+def test_conv1_twins_host_logic_on_the_oracle_backend():
+    """Producer-side activation of the conv1 inputs (DDPMConfig.conv1_twins): registration on the first sparse forward,
+    persistent twins across mask changes, invalidation by a new full pass -- with the twins EMULATED in torch where the CPU
+    path cannot write them from a launch (scatter.EMULATE_TWINS), so that the whole state machine runs without a GPU.  The
+    network with twins must equal the network without to fp32 rounding in every situation."""
+    from oracle import oracle
+    from sige_amd import runtime
+    from sige_amd.nn import scatter
+    from sige_amd.utils import dilate_mask, downsample_mask
+    from sige_amd.workloads.ddpm_unet import DDPMConfig, DDPMSparseUNet, ResBlock
+
+    torch.manual_seed(0)
+    cfg = DDPMConfig(ch=32, ch_mult=(1, 2, 2, 4), num_res_blocks=2, attn_resolutions=(16,), resolution=64, sparse_threshold=32, groups=8)
+    model = DDPMSparseUNet(cfg).eval()
+    model.set_scatter_inplace(True)
+    blocks = [m for m in model.modules() if isinstance(m, ResBlock)]
+    g = torch.Generator().manual_seed(1)
+    x0, noise, t = torch.randn(1, 3, 64, 64, generator=g), torch.randn(1, 3, 64, 64, generator=g), torch.zeros(1)
+
+    def run(k, twins, original):
+        m = torch.zeros(64, 64, dtype=torch.bool)
+        m[10 + k:22 + k, 14:30 + k] = True
+        for b in blocks:
+            b.use_twins = twins
+            b._drop_twin_links()
+        model.set_masks(downsample_mask(dilate_mask(m, 5), 8))
+        model.set_mode("sparse")
+        for _ in range(3):  # (forward 1 registers, from forward 2 on the twins exist)
+            out = model(original + noise * m, t)
+        return out.clone()
+
+    runtime.register_backend("cpu", oracle)
+    scatter.EMULATE_TWINS = True
+    try:
+        with torch.no_grad():
+            model.set_mode("full")
+            model(x0, t)
+            first = None
+            for k in (0, 6, 3):
+                ref, got = run(k, False, x0), run(k, True, x0)
+                assert (ref - got).abs().max() < 1e-4
+                assert sum(1 for b in blocks if b._twin_links) >= 12
+                first = ref if first is None else first
+            x0b = x0.flip(-1).contiguous()
+            model.set_mode("full")
+            model(x0b, t)
+            ref, got = run(0, False, x0b), run(0, True, x0b)
+            assert (ref - got).abs().max() < 1e-4
+            assert (ref - first).abs().max() > 1e-2
+            # a consumer that keeps an OLD twin after the producer's cache changed would show up here: make one stale on purpose
+            stale = next(b for b in blocks if b._twin_links)
+            key, prod = next(iter(stale._twin_links.items()))
+            assert key[2] == stale._aff_gen  # (the link carries the generation of the affine it was made for)
+    finally:
+        scatter.EMULATE_TWINS = False
+        runtime.unregister_backend("cpu")
+
+
+def test_twin_buffers_follow_cache_and_masks():
+    """scatter._TwinBuffers (the persistent activated twins of a Scatter module's in-place output): built from the cache,
+    rebuilt when the mask stamp or the cache generation changes, refreshed in place when the cache is rewritten in place,
+    at most two registrations."""
+    from sige_amd.nn.scatter import _TwinBuffers
+
+    tb = _TwinBuffers()
+    cache = torch.randn(1, 8, 4, 4).contiguous(memory_format=torch.channels_last)
+    sc, sh = torch.randn(8), torch.randn(8)
+    want = lambda c: torch.nn.functional.silu(c * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))  # noqa: E731
+    assert tb.register("a", sc, sh) and tb.register("b", sc * 2, sh) and not tb.register("c", sc, sh)
+    (ka, ba, _, _), (kb, bb, _, _) = tb.launch_args(0, cache, stamp=1)
+    assert (ka, kb) == ("a", "b")
+    torch.testing.assert_close(ba, want(cache))
+    assert tb.launch_args(0, cache, stamp=1)[0][1] is ba                      # same mask, same cache: the same buffer
+    ba.add_(1.0)                                                              # (a launch wrote tiles into it)
+    b2 = tb.launch_args(0, cache, stamp=2)[0][1]                              # new masks: rebuilt from the cache
+    assert b2 is not ba
+    torch.testing.assert_close(b2, want(cache))
+    tb.invalidate(0)                                                          # the cache was replaced (full pass)
+    cache2 = torch.randn_like(cache)
+    b3 = tb.launch_args(0, cache2, stamp=2)[0][1]
+    torch.testing.assert_close(b3, want(cache2))
+    cache2.mul_(0.5)                                                          # rewritten in place (a collective): same address
+    tb.refresh({0: cache2})
+    assert tb.launch_args(0, cache2, stamp=2)[0][1] is b3
+    torch.testing.assert_close(b3, want(cache2))
+    tb.unregister("a")
+    assert [k for k, *_ in tb.launch_args(0, cache2, stamp=2)] == ["b"] and tb.register("c", sc, sh)
