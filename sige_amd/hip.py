@@ -144,8 +144,7 @@ class _Guarded:
         self.fn = fn
 
     def __call__(self, *args):
-        global _pending_device
-        dev, _pending_device = _pending_device, None
+        dev, _tls.pending_device = getattr(_tls, "pending_device", None), None
         if dev is not None and dev != (_raw_device() if _raw_device is not None else torch.cuda.current_device()):
             with torch.cuda.device(dev):
                 return self.fn(*args)
@@ -156,7 +155,9 @@ class _Lib:
     pass
 
 
-_pending_device = None
+# per thread (one thread per GPU in one process is a supported set-up): the device of the tensor whose stream the binding
+# being evaluated just took -- consumed by the _Guarded call that follows in the same thread
+_tls = threading.local()
 
 
 def lib():
@@ -204,9 +205,8 @@ _raw_device = getattr(torch._C, "_cuda_getDevice", None)
 
 def _stream(t: torch.Tensor) -> int:
     """Stream handle for a launch on `t`'s device (and note that device for the guard, see _Guarded)."""
-    global _pending_device
     idx = t.device.index
-    _pending_device = idx
+    _tls.pending_device = idx
     if _raw_stream is not None and idx is not None:
         return _raw_stream(idx)
     return torch.cuda.current_stream(t.device).cuda_stream
@@ -534,15 +534,21 @@ class conv_pair:
         self.like = like  # (a tensor of the convs' device: the held conv may be launched when the block ends)
 
     def _on_device(self):
-        global _pending_device
-        if self.like is not None:
-            _pending_device = self.like.device.index
+        """Device context for begin / end: both may launch a held conv (with another device's stream and pointers if
+        HIP's current device is not the convs'), and neither takes a stream argument the _Guarded wrapper could key on."""
+        import contextlib
+
+        if self.like is not None and self.like.is_cuda:
+            cur = _raw_device() if _raw_device is not None else torch.cuda.current_device()
+            if self.like.device.index != cur:
+                return torch.cuda.device(self.like.device)
+        return contextlib.nullcontext()
 
     def __enter__(self):
         depth = getattr(_pair_state, "depth", 0)
         if depth == 0:
-            self._on_device()
-            _check(lib().sige_hip_conv_pair_begin(), "conv_pair_begin")
+            with self._on_device():
+                _check(lib().sige_hip_conv_pair_begin(), "conv_pair_begin")
             _pair_state.keep = []
         _pair_state.depth = depth + 1
         return self
@@ -551,8 +557,8 @@ class conv_pair:
         _pair_state.depth -= 1
         if _pair_state.depth == 0:
             try:
-                self._on_device()
-                _check(lib().sige_hip_conv_pair_end(), "conv_pair_end")
+                with self._on_device():
+                    _check(lib().sige_hip_conv_pair_end(), "conv_pair_end")
             finally:
                 _pair_state.keep = None
         return False

@@ -112,8 +112,15 @@ class LazyCat(DeferredTiles):
     @staticmethod
     def __new__(cls, a: torch.Tensor, b: torch.Tensor):
         shape = (a.shape[0], a.shape[1] + b.shape[1], a.shape[2], a.shape[3])
-        cl = a.dim() == 4 and a.is_contiguous(memory_format=torch.channels_last) and not a.is_contiguous()
-        t = DeferredTiles.__new__(cls, shape, a.dtype, a.device, lambda: torch.cat([a, b], dim=1), dict(kind="cat", cl=cl))
+        def _cl(p):
+            return p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last) and not p.is_contiguous()
+
+        # channels-last strides are advertised only when BOTH parts are channels-last (torch.cat follows its inputs; a mixed
+        # pair materialises as plain NCHW), and the materialised tensor is forced into the advertised format
+        cl = _cl(a) and _cl(b)
+        fmt = torch.channels_last if cl else torch.contiguous_format
+        t = DeferredTiles.__new__(cls, shape, a.dtype, a.device,
+                                  lambda: torch.cat([a, b], dim=1).contiguous(memory_format=fmt), dict(kind="cat", cl=cl))
         t.parts = (a, b)
         return t
 

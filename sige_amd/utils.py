@@ -69,11 +69,12 @@ def dilate_mask(mask: Union[torch.Tensor, np.ndarray], dilation: IntPair) -> Uni
     d = _pair(dilation)
     if d[0] <= 0 and d[1] <= 0:
         return mask
-    if isinstance(mask, torch.Tensor) and mask.is_cuda and mask.dim() == 2 and mask.dtype in (torch.bool, torch.uint8):
+    if isinstance(mask, torch.Tensor) and mask.is_cuda and mask.dim() == 2 and mask.dtype == torch.bool:
+        # (bool only: the kernel reads "non-zero = set" and writes 0 / 1, while the slice-OR below keeps the VALUES of an
+        #  integer mask -- a 0 / 255 uint8 mask stays on the generic path so CPU and GPU agree)
         from . import hip
 
-        out = hip.dilate_mask(mask, d)  # one kernel instead of 4 * d slice ops
-        return out if mask.dtype == torch.bool else out.view(torch.uint8)
+        return hip.dilate_mask(mask, d)  # one kernel instead of 4 * d slice ops
     out = mask.clone() if isinstance(mask, torch.Tensor) else np.array(mask, copy=True)
     nd = out.ndim if isinstance(out, np.ndarray) else out.dim()
     if nd not in (2, 3):
@@ -128,10 +129,11 @@ def downsample_mask(
     assert mask.dim() == 2
     H, W = mask.shape
     min_h, min_w = _pair(min_res)
-    if mask.is_cuda and mask.dtype in (torch.bool, torch.uint8):
+    if mask.is_cuda and mask.dtype == torch.bool:
         from . import hip
 
-        # the whole pyramid in one launch; the loop below synchronises with the host once per level (level.max())
+        # the whole pyramid in one launch; the loop below synchronises with the host once per level (level.max()).
+        # bool only: the kernel's level 0 is 0.0 / 1.0; `mask.float()` of a 0 / 255 uint8 mask is not
         return hip.mask_pyramid(mask, (min_h, min_w), _pair(dilation), threshold, eps)
     level = mask.reshape(1, 1, H, W).float()
     h, w = H, W

@@ -65,9 +65,16 @@ def _worker(rank, world, port, out_dir, method="broadcast"):
         flat = parallel.pack_caches(net)
         if method == "broadcast":
             parallel.broadcast_cache(flat, src=0, model=net)
+        elif method.startswith("pipelined:"):
+            info = parallel.distribute_cache_pipelined(flat, net, src=0, method=method.split(":")[1], n_chunks=3)
+            assert info["chunks"] >= 2 and info["refreshed"] >= 1
+        elif method == "subgroup":
+            # a group that is NOT the default one and whose rank 0 is global rank 1: `src` is a rank of the group
+            grp = dist.new_group(ranks=[1, 0] if world == 2 else list(reversed(range(world))))
+            src_in_group = dist.get_group_rank(grp, 0)
+            parallel.distribute_cache(flat, src=src_in_group, method="scatter_allgather", group=grp, model=net)
         else:
-            parallel.distribute_cache(flat, src=0, method=method)
-            parallel.refresh_derived(net)
+            parallel.distribute_cache(flat, src=0, method=method, model=net)
         mine = parallel.shard(list(range(len(edits))))
         outs = {i: _sparse(net, *edits[i]) for i in mine}
     slowest = parallel.max_over_ranks(0.25 * (rank + 1))
@@ -76,7 +83,7 @@ def _worker(rank, world, port, out_dir, method="broadcast"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("method", ["broadcast", "scatter_allgather"])
+@pytest.mark.parametrize("method", ["broadcast", "scatter_allgather", "pipelined:broadcast", "pipelined:scatter_allgather", "subgroup"])
 def test_cache_broadcast_and_sharded_edits(tmp_path, method):
     """The multi-rank path of bench.py (pack -> one collective -> local refresh -> sharded edits -> max over ranks),
     both distribution methods, on gloo."""
