@@ -15,7 +15,7 @@ LIB_DIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIB_DIR, "libsige_hip.so")
 SOURCES = ["api.hip", "gather.hip", "scatter.hip", "reduce_mask.hip", "mask_pipeline.hip", "block_conv.hip", "conv_k3s1.hip", "conv_k1.hip",
            "conv_k3s2.hip", "conv_k3s1_nhwc.hip", "conv_k1_nhwc.hip", "conv_k3s2_nhwc.hip", "conv_k3s1_nhwc_w8.hip", "conv_k1_nhwc_w8.hip", "conv_k3s1_nhwc_h.hip", "conv_k1_nhwc_h.hip",
-           "conv_pair_nhwc_t4.hip", "conv_pair_nhwc_t8.hip", "conv_pair_nhwc_f4.hip", "conv_pair_nhwc_f8.hip", "conv_pair_nhwc_h_t4.hip", "conv_pair_nhwc_h_f4.hip", "group_norm.hip", "attention.hip", "nhwc_ops.hip", "conv_out.hip", "conv_in.hip"]
+           "conv_pair_nhwc_t4.hip", "conv_pair_nhwc_t8.hip", "conv_pair_nhwc_f4.hip", "conv_pair_nhwc_f8.hip", "conv_pair_nhwc_h_t4.hip", "conv_pair_nhwc_h_f4.hip", "conv_wide.hip", "conv_wide_k3.hip", "conv_wide_k1.hip", "group_norm.hip", "attention.hip", "nhwc_ops.hip", "conv_out.hip", "conv_in.hip"]
 # -ffp-contract=off: the reference applies scale then shift as two separately
 # rounded fp32 ops (sige/cpu/gather.cpp:33-53); an fma would differ in the last bit.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
@@ -98,7 +98,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
         objs.append(obj)
         # only translation units whose source (or any header) changed are recompiled
-        hdrs = headers if src.startswith(("conv_k", "conv_pair", "block_conv")) else [h for h in headers if not h.endswith("conv_mfma.hpp")]
+        hdrs = (headers if src.startswith("conv_wide") else [h for h in headers if not h.endswith("conv_wide.hpp")] if src.startswith(("conv_k", "conv_pair", "block_conv"))
+                else [h for h in headers if not h.endswith(("conv_mfma.hpp", "conv_wide.hpp"))])
         if not force and not _stale(obj, os.path.join(CSRC, src), hdrs):
             continue
         cmd = [_hipcc(), *FLAGS, "-I" + os.path.join(REPO, "include"), "-I" + CSRC, "-c",

@@ -297,7 +297,7 @@ static TicketPool g_tickets[32];
 static std::mutex g_tickets_mu;
 static bool g_inkernel_splitk = true;  // sige_hip_block_conv_force_ksplit_pass (benchmarking)
 
-static int32_t *split_tickets(hipStream_t st, long blocks) {
+int32_t *split_tickets(hipStream_t st, long blocks) {
     int dev = -1;
     if (!g_inkernel_splitk || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32 || blocks > (long)kTicketRing) return nullptr;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;

@@ -71,6 +71,10 @@ inline int launch_status(int kernels = 1) {
     return hipGetLastError() == hipSuccess ? SIGE_HIP_OK : SIGE_HIP_ELAUNCH;
 }
 
+// (block_conv.hip) tickets of the in-launch K-split finish: `blocks` zeroed ints that stay valid while the launch runs
+// (or, during a hipGraph capture, for the life of the graph); nullptr = unavailable, the caller must not split
+int32_t *split_tickets(hipStream_t st, long blocks);
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

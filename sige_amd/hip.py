@@ -124,6 +124,15 @@ _SIGNATURES = {
     "sige_hip_conv3x3_small_cin_nhwc_f32": (
         _c_int, [_c_vp] + [ctypes.c_int64] * 4 + [_c_int] * 4 + [_c_vp, _c_vp, _c_int, _c_vp, _c_vp]),
     "sige_hip_attention_nhwc_f32": (_c_int, [_c_vp, _c_int, _c_int, _c_int, ctypes.c_float, _c_vp, _c_vp, _c_vp]),
+    # dense layers on the fp16 matrix cores (conv_wide)
+    "sige_hip_wide_conv_supported": (_c_int, [_c_int] * 5),
+    "sige_hip_wide_conv_packed_size": (_c_sz, [_c_int] * 5),
+    "sige_hip_wide_conv_pack": (_c_int, [_c_vp] + [_c_int] * 6 + [_c_vp, _c_vp]),
+    "sige_hip_wide_conv_workspace": (_c_sz, [_c_int] * 8),
+    "sige_hip_wide_conv_force_ksplit": (_c_int, [_c_int]),
+    "sige_hip_wide_conv_nhwc": (
+        _c_int, [_c_vp, _c_vp] + [_c_int] * 6 + [_c_vp, _c_vp, _c_int, _c_int] + [_c_vp, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_int]
+        + [_c_vp, _c_vp, _c_vp, _c_int] + [_c_vp] * 6 + [_c_vp, _c_sz, _c_vp, _c_vp]),
 }
 
 EXPORTS = tuple(_SIGNATURES)  # every symbol include/sige_hip.h declares
@@ -470,6 +479,7 @@ class PackedWeights(torch.Tensor):
     """Opaque packed conv weights (fp32 storage); `.compute` says which matrix path they were laid out for (it follows
     the tensor through clone / detach / to: a copy read with the wrong kernel family would run past its end)."""
     compute = "f32"
+    wshift = 0  # wide packs (compute "f16w" / "f16x3w"): the weights were stored as w * 2^wshift
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
@@ -478,6 +488,7 @@ class PackedWeights(torch.Tensor):
             src = next((a for a in args if isinstance(a, PackedWeights)), None)
             if src is not None and src is not out:
                 out.compute = src.__dict__.get("compute", "f32")
+                out.wshift = src.__dict__.get("wshift", 0)
         return out
 
 
@@ -509,6 +520,109 @@ def conv_pack_weights(weight: torch.Tensor, R: int, S: int, stride: Tuple[int, i
 def _conv_fn(name: str, packed):
     """The fp32 or the f16-compute entry point, according to how `packed` was laid out."""
     return getattr(lib(), name + ("_f16c" if getattr(packed, "compute", "f32") == "f16" else "_f32"))
+
+
+# ---- dense layers on the fp16 matrix cores (csrc/conv_wide.hpp) ----
+COMPUTE_DTYPES = ("f32", "f16", "f16x3")
+
+
+def wide_conv_supported(C1: int, C2: int, Cout: int, kernel: Tuple[int, int]) -> bool:
+    return bool(lib().sige_hip_wide_conv_supported(C1, C2, Cout, kernel[0], kernel[1]))
+
+
+def wide_conv_pack_weights(weight: torch.Tensor, compute: str) -> Optional[torch.Tensor]:
+    """Weights [Cout,Cin,k,k] (k = 1 | 3) packed for the dense-layer conv on the fp16 matrix cores; compute "f16" (operands
+    rounded to fp16) or "f16x3" (operands split into fp16 hi + lo, three products: fp32-level results).  None: no kernel
+    for this shape.  For "f16x3" the weights are stored as w * 2^s with max |w| * 2^s in [2^13, 2^14) (one device -> host
+    read of max |w| at pack time), so that the lo parts are normal fp16 numbers."""
+    if compute not in ("f16", "f16x3"):
+        raise ValueError("compute must be 'f16' or 'f16x3'")
+    w = _req(weight.detach(), torch.float32, "weight")
+    Cout, Cin, kH, kW = w.shape
+    x3 = int(compute == "f16x3")
+    n = int(lib().sige_hip_wide_conv_packed_size(Cout, Cin, kH, kW, x3))
+    if n == 0:
+        return None
+    wshift = 0
+    if x3:
+        import math
+
+        m = float(w.abs().max())
+        if m > 0 and math.isfinite(m):
+            wshift = max(-40, min(40, 13 - math.frexp(m)[1] + 1))  # m = f * 2^e, f in [0.5, 1): m * 2^(14 - e) in [2^13, 2^14)
+    packed = torch.empty((n,), dtype=torch.float32, device=w.device).as_subclass(PackedWeights)
+    packed.compute = compute + "w"
+    packed.wshift = wshift
+    _check(lib().sige_hip_wide_conv_pack(w.data_ptr(), Cout, Cin, kH, kW, x3, wshift, packed.data_ptr(), _stream(w)),
+           "wide_conv_pack_weights")
+    return packed
+
+
+def wide_conv_force_ksplit(ksplit: int = 0):
+    """Benchmark knob: pin the cross-workgroup K split of the dense-layer conv (0 = automatic)."""
+    _check(lib().sige_hip_wide_conv_force_ksplit(ksplit), "wide_conv_force_ksplit")
+
+
+def wide_conv_cl(x, x2, scale, shift, activationName: str, packed, bias, Cout: int, kernel: Tuple[int, int],
+                 residual=None, out_affine: Optional[tuple] = None, twins=None, upsample2x: bool = False,
+                 out: Optional[torch.Tensor] = None):
+    """out_act(os * (conv(act(scale * cat(x, x2) + shift)) + bias + residual) + oh) over a whole channels-last tensor in one
+    launch on the fp16 matrix cores (include/sige_hip.h: sige_hip_wide_conv_nhwc).  3x3 / padding 1 or 1x1, stride 1.
+    `packed` from wide_conv_pack_weights.  None if the shape has no kernel."""
+    compute = getattr(packed, "compute", "f32")
+    if compute not in ("f16w", "f16x3w"):
+        raise NotImplementedError("wide_conv_cl: weights must be packed with wide_conv_pack_weights")
+    bias_keep = _vec(bias, "bias")
+    x = _req_cl(x, "x")
+    B, C1, H, W = x.shape
+    if upsample2x:
+        H, W = 2 * H, 2 * W
+    C2 = 0
+    if x2 is not None:
+        x2 = _req_cl(x2, "x2")
+        C2 = x2.shape[1]
+        if tuple(x2.shape[2:]) != tuple(x.shape[2:]) or x2.shape[0] != B:
+            raise RuntimeError("wide_conv_cl: x2 must match x in batch and resolution")
+    if not wide_conv_supported(C1, C2, Cout, kernel):
+        return None
+    (sa, s_keep), (ta, t_keep) = _cvec(scale, "scale"), _cvec(shift, "shift")
+    if (s_keep is None) != (t_keep is None):
+        return None
+    if s_keep is not None and (sa[1] != ta[1] or sa[2] != C1 + C2 or ta[2] != C1 + C2 or sa[1] not in (1, B)):
+        return None
+    if s_keep is None and activationName != "identity":
+        return None
+    if out is None:
+        out = _empty_cl((B, Cout, H, W), x.device)
+    elif tuple(out.shape) != (B, Cout, H, W) or not out.is_contiguous(memory_format=CL):
+        raise RuntimeError("wide_conv_cl: `out` must be a channels-last [B,Cout,H,W] tensor")
+    r = None
+    if residual is not None:
+        r = _req_cl(residual, "residual")
+        if tuple(r.shape) != tuple(out.shape):
+            raise RuntimeError("wide_conv_cl: residual %s != output %s" % (tuple(r.shape), tuple(out.shape)))
+    if out_affine is not None:
+        os_, oh_, oact = out_affine
+        os_, oh_ = _req(os_.reshape(-1), torch.float32, "out_scale", 1), _req(oh_.reshape(-1), torch.float32, "out_shift", 1)
+        if os_.numel() != Cout or oh_.numel() != Cout:
+            raise RuntimeError("wide_conv_cl: out_affine must have one entry per output channel")
+        oargs = (os_.data_ptr(), oh_.data_ptr(), _act(oact))
+    else:
+        os_ = oh_ = None
+        oargs = (None, None, 0)
+    targs, twin_keep = _twin_args(twins if twins else None, out, Cout, "wide_conv_cl")
+    ws, ws_n = None, int(lib().sige_hip_wide_conv_workspace(B, H, W, C1, C2, Cout, kernel[0], kernel[1])) if KSPLIT else 0
+    if ws_n:
+        ws = torch.empty(ws_n, dtype=torch.float32, device=x.device)
+    status = lib().sige_hip_wide_conv_nhwc(
+        x.data_ptr(), None if x2 is None else x2.data_ptr(), B, C1, C2, H, W, int(bool(upsample2x)),
+        sa[0], ta[0], sa[1] if s_keep is not None else 0, _act(activationName),
+        packed.data_ptr(), int(compute == "f16x3w"), int(getattr(packed, "wshift", 0)), _p(bias_keep), Cout, kernel[0], kernel[1],
+        None if r is None else r.data_ptr(), *oargs, *targs, None if ws is None else ws.data_ptr(), ws_n, out.data_ptr(), _stream(x))
+    if status == UNSUPPORTED:
+        return None
+    _check(status, "wide_conv_cl")
+    return out
 
 
 def conv_force_tile(mt: int = 0, nb: int = 0):

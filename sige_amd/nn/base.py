@@ -138,7 +138,9 @@ class SIGEConv2d(nn.Conv2d, SIGEModule):
         and the consumer is a channels-last kernel."""
         from .. import hip
 
-        compute = self.compute_dtype if channels_last else "f32"
+        from .dense import _tile_compute
+
+        compute = _tile_compute(self.compute_dtype) if channels_last else "f32"
         w = self.weight
         key = (w.data_ptr(), w._version, tuple(w.shape), x.shape[2], x.shape[3], w.device)
         entry = self._packed.get(compute)
@@ -207,7 +209,12 @@ class SIGEConv2d(nn.Conv2d, SIGEModule):
         """`out_affine` (sparse mode only, not in the reference): (scale, shift, activation) applied to the
         output tiles -- the consumer's cached GroupNorm affine + SiLU, fused into the kernel's epilogue."""
         if self.mode == "full":
-            output = super(SIGEConv2d, self).forward(x)
+            if x.is_cuda and self.compute_dtype != "f32":
+                from .dense import full_conv2d
+
+                output = full_conv2d(self, x)  # (one launch on the fp16 matrix cores where the shape has a kernel)
+            else:
+                output = super(SIGEConv2d, self).forward(x)
         elif self.mode == "sparse":
             self.check_dtype(x)
             if x.is_cuda:
@@ -282,16 +289,32 @@ class SIGEModel(nn.Module):
         for module in self._sige_modules():
             module.set_sparse_update(sparse_update)
 
-    def set_compute_dtype(self, dtype: str):
-        """MI355X-first option (not in the reference, which is fp32-only: sige/nn/base.py:15,55-63): "f16" runs every
-        tile conv (SIGEConv2d on channels-last tiles, and the dense layers routed through sige_amd.nn.dense.fused_conv2d)
-        with fp16 operands and fp32 accumulation on the fp16 matrix cores; activations and caches stay fp32.  "f32"
-        (default) = exact fp32 products."""
-        if dtype not in ("f32", "f16"):
-            raise ValueError("compute dtype must be 'f32' or 'f16'")
-        for module in self.modules():
+    def set_compute_dtype(self, dtype: str, keep=None):
+        """MI355X-first option (not in the reference, which is fp32-only: sige/nn/base.py:15,55-63).
+
+        "f32" (default): exact fp32 products (v_mfma_f32_*_f32).
+        "f16": fp16 operands, fp32 accumulation on the fp16 matrix cores (16x the f32-input rate) -- every tile conv
+               (SIGEConv2d on channels-last tiles) and every dense layer routed through sige_amd.nn.dense.fused_conv2d;
+               activations and caches stay fp32.  Stated tolerance: sige_amd.tolerance.F16_CRITERION.
+        "f16x3": the fp16 matrix cores with every fp32 operand SPLIT into an fp16 hi + lo pair (three products per term,
+               22-bit operands): fp32-level results (inside the fp32 path's 1e-3) -- dense layers and the full pass; tile
+               convs, which have no such kernel, run exact fp32.
+
+        `keep`: module-name prefixes of convs that stay at the higher precision when dtype is "f16" -- they run "f16x3".
+        None = the model's own default (`F16_KEEP`, from its per-layer error trace: tests/f16_error_trace.py); () = none."""
+        if dtype not in ("f32", "f16", "f16x3"):
+            raise ValueError("compute dtype must be 'f32', 'f16' or 'f16x3'")
+        if keep is None:
+            keep = tuple(getattr(self, "F16_KEEP", ())) if dtype == "f16" else ()
+        keep = tuple(keep)
+
+        def kept(name):
+            return any(name == k or name.startswith(k + ".") for k in keep)
+
+        self.compute_policy = {"dtype": dtype, "keep": keep}
+        for name, module in self.named_modules():
             if isinstance(module, nn.Conv2d):
-                module.compute_dtype = dtype
+                module.compute_dtype = "f16x3" if (dtype == "f16" and kept(name)) else dtype
 
     def set_scatter_inplace(self, inplace: bool):
         """MI355X-first option (not in the reference): Scatter / ScatterWithBlockResidual modules whose

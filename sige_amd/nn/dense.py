@@ -28,11 +28,84 @@ _GEOMETRY = {
 }
 
 
+def _tile_compute(compute: str) -> str:
+    """Arithmetic of the TILE kernels (conv_mfma.hpp) for a conv whose compute dtype is `compute`: they have exact-fp32 and
+    fp16-operand forms; "f16x3" (fp32-level results from split fp16 operands) exists in the dense-layer kernel only, so a
+    conv that asks for it runs exact fp32 there."""
+    return "f16" if compute == "f16" else "f32"
+
+
+def _wide_packed(conv: nn.Conv2d, compute: str):
+    """Weights of `conv` packed for the dense-layer kernel on the fp16 matrix cores (None: no kernel for the shape)."""
+    from .. import hip
+
+    w = conv.weight
+    key = (w.data_ptr(), w._version, tuple(w.shape), w.device)
+    cache = conv.__dict__.setdefault("_sige_wide", {})
+    entry = cache.get(compute)
+    if entry is None or entry[0] != key:
+        entry = (key, hip.wide_conv_pack_weights(_plain_weight(conv), compute))
+        cache[compute] = entry
+    return entry[1]
+
+
+def _wide_conv(conv: nn.Conv2d, x, x2, scale, shift, activation_name, residual, out_affine, twins, made, upsample2x=False):
+    """The conv as one launch of the dense-layer kernel (csrc/conv_wide.hpp) when the layer's compute dtype asks for the fp16
+    matrix cores ("f16" / "f16x3") and the shape has a kernel; None otherwise (the caller goes on to the tile kernels)."""
+    from .. import hip
+
+    compute = getattr(conv, "compute_dtype", "f32")
+    if compute not in ("f16", "f16x3") or not hip.is_cl(x) or (x2 is not None and not hip.is_cl(x2)):
+        return None
+    k = tuple(conv.kernel_size)
+    if (k not in ((1, 1), (3, 3)) or tuple(conv.stride) != (1, 1) or tuple(conv.padding) != (k[0] // 2, k[1] // 2)
+            or conv.groups != 1 or tuple(conv.dilation) != (1, 1) or getattr(conv, "padding_mode", "zeros") != "zeros"):
+        return None
+    C1, C2 = x.shape[1], 0 if x2 is None else x2.shape[1]
+    if not hip.wide_conv_supported(C1, C2, conv.out_channels, k):
+        if x2 is None or upsample2x or not hip.wide_conv_supported(C1 + C2, 0, conv.out_channels, k):
+            return None
+        x, x2, C1, C2 = torch.cat([x, x2], dim=1), None, C1 + C2, 0  # (a split that is not on a chunk boundary)
+    packed = _wide_packed(conv, compute)
+    if packed is None:
+        return None
+    B = x.shape[0]
+    H, W = (2 * x.shape[2], 2 * x.shape[3]) if upsample2x else (x.shape[2], x.shape[3])
+    tw = []
+    if twins and out_affine is None:
+        for key, (sc, sh) in list(twins.items())[:2]:
+            tw.append((key, torch.empty((B, conv.out_channels, H, W), dtype=torch.float32, device=x.device,
+                                        memory_format=torch.channels_last), sc, sh))
+    out = hip.wide_conv_cl(x, x2, scale, shift, activation_name, packed, conv.bias, conv.out_channels, k, residual=residual,
+                           out_affine=out_affine, twins=[(b, sc, sh) for _, b, sc, sh in tw] or None, upsample2x=upsample2x)
+    if out is not None and made is not None:
+        made.update({k_: b for k_, b, _, _ in tw})
+    return out
+
+
+def full_conv2d(conv: nn.Conv2d, x: torch.Tensor, scale=None, shift=None, activation_name: str = "identity") -> torch.Tensor:
+    """`conv(act(x * scale + shift))` of the FULL pass (the pass that produces the caches: sige/nn/base.py:85-86).  On a
+    channels-last GPU tensor and a conv whose compute dtype is "f16" / "f16x3" (SIGEModel.set_compute_dtype) it is one
+    launch of the dense-layer kernel with the affine + SiLU in its staging path; anywhere else exactly the torch
+    expression the reference runs (a SIGEConv2d in full mode is nn.Conv2d.forward)."""
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4:
+        out = _wide_conv(conv, x, None, scale, shift, activation_name, None, None, None, None)
+        if out is not None:
+            return out
+    h = x
+    if scale is not None:
+        h = h * scale
+    if shift is not None:
+        h = h + shift
+    h = _act(h, activation_name)
+    return nn.Conv2d.forward(conv, h)
+
+
 def _packed(conv: nn.Conv2d, block, channels_last: bool = True):
     from .. import hip
 
     w = conv.weight
-    compute = getattr(conv, "compute_dtype", "f32") if channels_last else "f32"  # (SIGEModel.set_compute_dtype)
+    compute = _tile_compute(getattr(conv, "compute_dtype", "f32")) if channels_last else "f32"  # (SIGEModel.set_compute_dtype)
     key = (w.data_ptr(), w._version, tuple(w.shape), block, w.device, compute)
     if getattr(conv, "_sige_packed_key", None) != key:
         conv._sige_packed = hip.conv_pack_weights(w, block[0], block[1], conv.stride, compute)
@@ -99,6 +172,10 @@ def _fused_conv2d(conv, x, scale, shift, activation_name, x2, residual, pad_bott
         from .. import hip
 
         block, out_tile, offset = _GEOMETRY[(tuple(conv.kernel_size), tuple(conv.stride), tuple(conv.padding))]
+        if not pad_bottom_right:
+            out = _wide_conv(conv, x, x2, scale, shift, activation_name, residual, out_affine, twins, made)
+            if out is not None:
+                return out
         if x2 is not None and not hip.cat_fusable(x.shape[0], x.shape[1], conv.kernel_size):
             x, x2 = torch.cat([x, x2], dim=1), None
         B, _, H, W = x.shape

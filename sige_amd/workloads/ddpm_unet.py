@@ -27,7 +27,7 @@ from torch.nn import functional as F
 
 from ..nn import Gather, Scatter, ScatterGather, ScatterWithBlockResidual, SIGEConv2d, SIGEModel, SIGEModule, paired_convs
 from ..nn.deferred import lazy_cat
-from ..nn.dense import fused_conv2d, group_norm_affine, input_conv2d
+from ..nn.dense import full_conv2d, fused_conv2d, group_norm_affine, input_conv2d
 
 
 @dataclass
@@ -75,10 +75,14 @@ def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
     return F.pad(emb, (0, 1)) if dim % 2 else emb
 
 
-def norm_affine(x: torch.Tensor, norm: nn.GroupNorm):
-    """Per-channel (scale, shift) with GroupNorm(x) == x * scale + shift, batch 1."""
+def norm_affine(x: torch.Tensor, norm: nn.GroupNorm, fast: bool = False):
+    """Per-channel (scale, shift) with GroupNorm(x) == x * scale + shift, batch 1.  `fast` (the full pass on the fp16 matrix
+    cores): the library's split reduction (fp64 combine) instead of torch's var_mean + five elementwise kernels."""
     n, c, h, w = x.shape
     assert n == 1, "SIGE caches one original image"
+    if fast and x.is_cuda:
+        sc, sh = group_norm_affine(x, norm)
+        return sc.reshape(-1), sh.reshape(-1)
     g = norm.num_groups
     var, mean = torch.var_mean(x.reshape(g, -1), dim=1, unbiased=False)
     inv = torch.rsqrt(var + norm.eps).repeat_interleave(c // g)
@@ -255,7 +259,7 @@ class ResBlock(SIGEModule, _TwinProducer):
             return x
         if self.sparse_shortcut:
             x = self.shortcut_gather(x)
-        return self.nin_shortcut(x)
+        return full_conv2d(self.nin_shortcut, x) if self.mode == "full" else self.nin_shortcut(x)
 
     def _plain(self, x, temb):
         """Dense forward with stock GroupNorm and no caching (the "original model"
@@ -268,20 +272,21 @@ class ResBlock(SIGEModule, _TwinProducer):
     def _full(self, x, temb):
         if self.plain:
             return self._plain(x, temb)
+        fast = getattr(self.conv1, "compute_dtype", "f32") != "f32"  # (the full pass on the fp16 matrix cores: dense.full_conv2d)
         skip = self._shortcut(x)
         h = self.main_gather(x) if self.sparse_main else x  # records the input resolution
-        s1, t1 = norm_affine(h, self.norm1)
-        h = self.conv1(F.silu(h * _as4(s1) + _as4(t1)))
+        s1, t1 = norm_affine(h, self.norm1, fast)
+        h = full_conv2d(self.conv1, h, _as4(s1), _as4(t1), "swish")  # conv1(silu(h * s1 + t1))
         if self.sparse_main:
             h = self.scatter_gather(h)
         te = temb.reshape(-1)
-        s2, t2 = norm_affine(h + _as4(te), self.norm2)
+        s2, t2 = norm_affine(h + _as4(te), self.norm2, fast)
         t2 = t2 + te * s2  # fold the timestep-embedding add into the cached shift
         self._drop_twin_links()  # (twins written for the previous affine are stale)
         self.affine[self.cache_id] = tuple(_as4(v).contiguous() for v in (s1, t1, s2, t2))
         if self.sparse_main and self.preactivate:
             self.scatter_gather.cache_activated(_as4(s2), _as4(t2))
-        h = self.conv2(F.silu(h * _as4(s2) + _as4(t2)))
+        h = full_conv2d(self.conv2, h, _as4(s2), _as4(t2), "swish")  # conv2(silu(h * s2 + t2))
         return self.scatter(h, skip) if self.sparse_main else h + skip
 
     def _sparse(self, x):
@@ -363,8 +368,11 @@ class AttnBlock(SIGEModule, _TwinProducer):
             h = self.norm(x)
         elif self.mode == "full":
             h = self.gather1(x) if self.sparse else x
-            s, t = norm_affine(h, self.norm)
+            s, t = norm_affine(h, self.norm, getattr(self.qkv, "compute_dtype", "f32") != "f32")
             self.affine[self.cache_id] = (_as4(s).contiguous(), _as4(t).contiguous())
+            if not self.sparse:  # dense block: qkv(h * s + t) in one launch where the conv's compute dtype allows, then the rest
+                qkv = full_conv2d(self.qkv, h, _as4(s), _as4(t), "identity")
+                return full_conv2d(self.proj_out, self._attention(qkv)) + x
             h = h * _as4(s) + _as4(t)
         else:
             s, t = self.affine[self.cache_id]
@@ -465,6 +473,13 @@ class Downsample(SIGEModule, _TwinProducer):
 
 
 class DDPMSparseUNet(SIGEModel):
+    # set_compute_dtype("f16"): the convs that stay at fp32-level precision (split fp16 operands, "f16x3") so that the f16
+    # path meets sige_amd.tolerance.F16_CRITERION at every edit ratio of BASELINE.json configs[4] (1 ... 20 %).  From the
+    # per-layer error trace (tests/f16_error_trace.py, profiles/r3a_f16_error_trace.json): fp16 rounding errors made on
+    # the down path and at the 16x16 / 8x8 levels are amplified by everything downstream; with them kept the worst
+    # element is at 0.34 of the allowed error at 20 % edit (2.5x over it with every conv in plain fp16).
+    F16_KEEP = ("down", "up.4", "up.5")
+
     def __init__(self, cfg: DDPMConfig = DDPMConfig()):
         super().__init__()
         self.cfg = cfg

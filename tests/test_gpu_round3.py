@@ -1,0 +1,348 @@
+"""Round 3, on the MI355X: the dense-layer conv on the fp16 matrix cores (csrc/conv_wide.hpp) -- fp16 operands and split
+fp16 operands ("f16x3": fp32-level results) -- against fp64 torch; the compute-dtype policy of BASELINE.json configs[4]
+over its whole edit-ratio sweep with the ONE stated criterion (sige_amd.tolerance); the full pass on those kernels;
+multi-step caches (cache_id > 0); a model on a non-current device."""
+import os
+
+import pytest
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from oracle import oracle
+from sige_amd import tolerance
+from tests import util
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from sige_amd import hip as h
+
+    h.lib()
+    return h
+
+
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def _ref64(x, x2, s, t, act, w, b, residual, oaff, up):
+    h = x if x2 is None else torch.cat([x, x2], 1)
+    if up:
+        h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+    h = h.double()
+    if s is not None:
+        h = h * s.double() + t.double()
+        if act == "swish":
+            h = F.silu(h)
+    out = F.conv2d(h, w.double(), None if b is None else b.double(), 1, w.shape[2] // 2)
+    if residual is not None:
+        out = out + residual.double()
+    raw = out
+    if oaff is not None:
+        out = out * oaff[0].double().view(1, -1, 1, 1) + oaff[1].double().view(1, -1, 1, 1)
+        if oaff[2] == "swish":
+            out = F.silu(out)
+    return out, raw
+
+
+WIDE_CASES = [
+    # k, C1, C2, Cout, H, W, B, affine, act, residual, out_affine, up
+    (3, 256, 0, 256, 32, 32, 1, True, "swish", True, False, False),     # 32x32 dense block conv (K split 2)
+    (3, 512, 256, 256, 32, 32, 1, True, "swish", False, True, False),   # fused cat, epilogue affine + SiLU
+    (3, 1024, 0, 512, 16, 16, 1, True, "swish", True, False, False),    # deep K, 4 pixel blocks (K split 16)
+    (3, 512, 512, 512, 8, 8, 1, False, "identity", True, False, False),  # one pixel block, raw staging, cat
+    (1, 768, 0, 256, 32, 32, 1, False, "identity", False, False, False),  # shortcut 1x1
+    (1, 512, 0, 1536, 16, 16, 1, True, "identity", False, False, False),  # attention qkv: affine without activation
+    (1, 256, 256, 512, 8, 8, 2, True, "swish", True, True, False),      # batch 2, per-batch affine
+    (3, 128, 0, 128, 40, 24, 1, True, "swish", True, False, False),     # ragged: 24 = 3 patches, 40 = 5; no K split
+    (3, 64, 0, 64, 12, 20, 2, False, "identity", False, False, False),  # H, W not multiples of 8 (masked stores)
+    (3, 128, 0, 64, 32, 32, 1, True, "swish", False, False, True),      # nearest x2 upsampling fused into the addressing
+    (3, 128, 0, 128, 128, 128, 1, True, "swish", False, False, False),  # a full-pass layer: 512 workgroups, no split
+]
+
+
+@pytest.mark.parametrize("compute", ["f16x3", "f16"])
+@pytest.mark.parametrize("k,c1,c2,cout,H,W,B,aff,act,res,oaff,up", WIDE_CASES)
+def test_wide_conv_vs_fp64(hip, compute, k, c1, c2, cout, H, W, B, aff, act, res, oaff, up):
+    """One launch of the dense-layer kernel against the same expression in fp64 torch.
+    f16x3: the result is fp32-level -- max |d| <= 2e-5 * (1 + max |ref|), three orders inside the 1e-3 of the fp32 path;
+    f16: exactly the fp64 conv of the fp16-ROUNDED operands (products of two fp16 values are exact in fp32) to fp32
+         summation accuracy, and the exact result within the stated f16 criterion."""
+    g = torch.Generator().manual_seed(1000 * k + c1 + cout + H)
+    r = lambda *s: torch.randn(*s, generator=g).to(DEV)  # noqa: E731
+    cin = c1 + c2
+    hs, ws = (H // 2, W // 2) if up else (H, W)
+    x, x2 = _cl(r(B, c1, hs, ws)), (_cl(r(B, c2, hs, ws)) if c2 else None)
+    w, b = r(cout, cin, k, k) / (k * cin ** 0.5), r(cout)
+    nb = B if (aff and B > 1) else 1
+    s, t = (r(nb, cin, 1, 1), r(nb, cin, 1, 1)) if aff else (None, None)
+    residual = _cl(r(B, cout, H, W)) if res else None
+    oa = (r(cout), r(cout), "swish") if oaff else None
+    packed = hip.wide_conv_pack_weights(w, compute)
+    assert packed is not None and packed.compute == compute + "w"
+    got = hip.wide_conv_cl(x, x2, s, t, act, packed, b, cout, (k, k), residual=residual, out_affine=oa, upsample2x=up)
+    assert got is not None and hip.is_cl(got) and tuple(got.shape) == (B, cout, H, W)
+    want, _ = _ref64(x, x2, s, t, act, w, b, residual, oa, up)
+    if compute == "f16x3":
+        err = float((got.double() - want).abs().max())
+        assert err <= 2e-5 * (1.0 + float(want.abs().max())), err
+    else:
+        assert tolerance.f16_check(got, want.float())["ok"]
+        # exact-product check: round the operands as the kernel does and convolve in fp64
+        h = x if x2 is None else torch.cat([x, x2], 1)
+        if up:
+            h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+        if s is not None:
+            h = h * s + t  # (two separately rounded fp32 ops, as in the kernel)
+            if act == "swish":
+                h = F.silu(h)
+        out = F.conv2d(h.half().double(), w.half().double(), b.double(), 1, k // 2)
+        if residual is not None:
+            out = out + residual.double()
+        if oa is not None:
+            out = F.silu(out * oa[0].double().view(1, -1, 1, 1) + oa[1].double().view(1, -1, 1, 1))
+        # (swish_fast in the staging path is <= 1e-6 relative; a value next to an fp16 rounding boundary may round the other way)
+        bad = (got.double() - out).abs() > 3e-4 * (1.0 + out.abs())
+        assert float(bad.double().mean()) < 1e-3
+
+
+def test_wide_conv_split_k_is_deterministic_and_equals_unsplit(hip):
+    """The in-launch K-split finish: same bits on every run (fixed summation order), fp32-close to the unsplit launch, and no
+    stale partial sum when two inputs alternate over the same workspace memory -- eagerly and in graph replays."""
+    g = torch.Generator().manual_seed(7)
+    r = lambda *s: torch.randn(*s, generator=g).to(DEV)  # noqa: E731
+    xa, xb = _cl(r(1, 1024, 16, 16)), _cl(r(1, 1024, 16, 16))
+    w, b = r(512, 1024, 3, 3) / 96, r(512)
+    packed = hip.wide_conv_pack_weights(w, "f16x3")
+    run = lambda x: hip.wide_conv_cl(x, None, None, None, "identity", packed, b, 512, (3, 3))  # noqa: E731
+    a1, b1, a2, b2 = run(xa).clone(), run(xb).clone(), run(xa).clone(), run(xb).clone()
+    assert torch.equal(a1, a2) and torch.equal(b1, b2) and not torch.equal(a1, b1)
+    hip.wide_conv_force_ksplit(1)
+    try:
+        a0 = run(xa).clone()
+    finally:
+        hip.wide_conv_force_ksplit(0)
+    torch.testing.assert_close(a1, a0, rtol=0, atol=2e-5)
+    for ks in (2, 5, 16):
+        hip.wide_conv_force_ksplit(ks)
+        try:
+            torch.testing.assert_close(run(xa), a0, rtol=0, atol=2e-5)
+        finally:
+            hip.wide_conv_force_ksplit(0)
+    xin = xa.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        run(xin)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=s):
+            out = run(xin)
+    torch.cuda.current_stream().wait_stream(s)
+    for i in range(6):
+        xin.copy_(xa if i % 2 == 0 else xb)
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, a1 if i % 2 == 0 else b1)
+
+
+def test_wide_conv_small_operands_keep_their_precision(hip):
+    """Split operands at small magnitudes: weights of 1e-4 (their lo parts would be fp16 subnormals without the power-of-two
+    pre-scaling at pack time) and activations around 1e-2 still give fp32-level results."""
+    g = torch.Generator().manual_seed(3)
+    r = lambda *s: torch.randn(*s, generator=g).to(DEV)  # noqa: E731
+    x = _cl(r(1, 256, 16, 16) * 1e-2)
+    w = r(64, 256, 3, 3) * 1e-4
+    packed = hip.wide_conv_pack_weights(w, "f16x3")
+    assert packed.wshift > 20
+    got = hip.wide_conv_cl(x, None, None, None, "identity", packed, None, 64, (3, 3))
+    want = F.conv2d(x.double(), w.double(), None, 1, 1)
+    rel = float((got.double() - want).abs().max() / want.abs().max())
+    assert rel < 2e-5, rel
+
+
+def test_wide_conv_twins_and_dense_module_routing(hip):
+    """fused_conv2d on a conv whose compute dtype is "f16x3" runs the dense-layer kernel (one launch), with twins."""
+    from sige_amd.nn.dense import fused_conv2d
+
+    torch.manual_seed(5)
+    conv = nn.Conv2d(768, 256, 3, 1, 1).to(DEV)
+    conv.compute_dtype = "f16x3"
+    x, x2 = _cl(torch.randn(1, 512, 32, 32, device=DEV)), _cl(torch.randn(1, 256, 32, 32, device=DEV))
+    s, t = torch.randn(1, 768, 1, 1, device=DEV), torch.randn(1, 768, 1, 1, device=DEV)
+    res = _cl(torch.randn(1, 256, 32, 32, device=DEV))
+    tw = {"a": (torch.randn(256, device=DEV), torch.randn(256, device=DEV))}
+    with torch.no_grad():
+        n0 = hip.launch_count()
+        got = fused_conv2d(conv, x, s, t, "swish", x2=x2, residual=res, twins=tw)
+        assert hip.launch_count() - n0 == 1
+        want = conv(F.silu(torch.cat([x, x2], 1) * s + t)) + res
+        torch.testing.assert_close(got, want, rtol=0, atol=2e-4)
+        twin = got._sige_twins["a"]
+        torch.testing.assert_close(twin, F.silu(want * tw["a"][0].view(1, -1, 1, 1) + tw["a"][1].view(1, -1, 1, 1)), rtol=0, atol=3e-4)
+
+
+# ---- the whole DDPM-256 U-Net under the three compute dtypes -------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def ddpm_reference():
+    """The fp32 reference: the DDPM-256 U-Net on the CPU oracle backend (sige/cpu restated + torch CPU convs), full pass
+    on the original, sparse outputs at the five edit ratios of BASELINE.json configs[4]."""
+    import bench
+    from sige_amd import runtime
+    from sige_amd.utils import dilate_mask, downsample_mask
+    from sige_amd.workloads.ddpm_unet import DDPMConfig, DDPMSparseUNet
+
+    torch.manual_seed(0)
+    model = DDPMSparseUNet(DDPMConfig()).eval()
+    x0, noise = bench.make_inputs()
+    t = torch.zeros(1)
+    n = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(n)
+    oracle.set_num_threads(n)
+    runtime.register_backend("cpu", oracle)
+    outs = {}
+    try:
+        with torch.no_grad():
+            model.set_mode("full")
+            full = model(x0, t)
+            for r in (0.01, 0.02, 0.05, 0.1, 0.2):
+                mask = bench.edit_mask(r)
+                model.set_masks(downsample_mask(dilate_mask(mask, 5), 8))
+                model.set_mode("sparse")
+                outs[r] = model(x0 + noise * mask, t).clone()
+    finally:
+        runtime.unregister_backend("cpu")
+    model.clear_cache()
+    return {"state": model.state_dict(), "x0": x0, "noise": noise, "full": full, "sparse": outs}
+
+
+@pytest.fixture(scope="module")
+def ddpm_gpu(ddpm_reference):
+    from sige_amd.workloads.ddpm_unet import DDPMConfig, DDPMSparseUNet
+
+    model = DDPMSparseUNet(DDPMConfig()).eval()
+    model.load_state_dict(ddpm_reference["state"])
+    model = model.to(DEV).to(memory_format=torch.channels_last)
+    model.set_scatter_inplace(True)
+    return model
+
+
+def _gpu_sparse(model, ref, ratio, full_dtype="f32"):
+    import bench
+    from sige_amd.utils import dilate_mask, downsample_mask
+
+    cl = lambda a: a.to(DEV).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    t = torch.zeros(1, device=DEV)
+    mask = bench.edit_mask(ratio)
+    with torch.no_grad():
+        model.set_masks(downsample_mask(dilate_mask(mask.to(DEV), 5), 8))
+        model.set_mode("sparse")
+        x1 = cl(ref["x0"] + ref["noise"] * mask)
+        model(x1, t)  # (consumers register their activated twins on the first forward)
+        return model(x1, t).clone()
+
+
+@pytest.mark.parametrize("ratio", [0.01, 0.02, 0.05, 0.1, 0.2])
+def test_f16_policy_ddpm_forward_whole_sweep(hip, ddpm_reference, ddpm_gpu, ratio):
+    """BASELINE.json configs[4] at its own size over its WHOLE sweep, ONE criterion (sige_amd.tolerance.F16_CRITERION):
+    set_compute_dtype("f16") = fp16 operands everywhere except the model's F16_KEEP convs, which run split fp16 operands."""
+    ref = ddpm_reference
+    model = ddpm_gpu
+    cl = lambda a: a.to(DEV).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    with torch.no_grad():
+        model.set_compute_dtype("f32")
+        model.set_mode("full")
+        model(cl(ref["x0"]), torch.zeros(1, device=DEV))  # the original's cache: the fp32 full pass
+        model.set_compute_dtype("f16")
+        assert model.compute_policy["keep"] == model.F16_KEEP
+        out = _gpu_sparse(model, ref, ratio)
+        model.set_compute_dtype("f32")
+    chk = tolerance.f16_check(out, ref["sparse"][ratio])
+    assert chk["ok"], chk
+
+
+@pytest.mark.parametrize("ratio", [0.01, 0.2])
+def test_f16x3_ddpm_forward_meets_the_fp32_tolerance(hip, ddpm_reference, ddpm_gpu, ratio):
+    """Split fp16 operands ("f16x3": dense remainder AND the cache-producing full pass on the fp16 matrix cores, tile convs
+    exact fp32) against the fp32 CPU reference with the FP32 path's tolerance, 1e-3 abs."""
+    ref = ddpm_reference
+    model = ddpm_gpu
+    cl = lambda a: a.to(DEV).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    with torch.no_grad():
+        model.set_compute_dtype("f16x3")
+        model.set_mode("full")
+        n0 = hip.launch_count()
+        full = model(cl(ref["x0"]), torch.zeros(1, device=DEV)).clone()
+        assert hip.launch_count() - n0 >= 60  # the full pass ran on the library's kernels, not on MIOpen
+        out = _gpu_sparse(model, ref, ratio)
+        model.set_compute_dtype("f32")
+    torch.testing.assert_close(full.cpu(), ref["full"], rtol=0, atol=util.CONV_ATOL)
+    torch.testing.assert_close(out.cpu(), ref["sparse"][ratio], rtol=0, atol=util.CONV_ATOL)
+
+
+def test_multi_step_caches_cache_id(hip, ddpm_reference, ddpm_gpu):
+    """One cache per denoising step (sige/nn/scatter.py:59-60, diffusion_demo/runner.py:134-164): two different
+    originals under cache_id 0 / 1, the same edit against each; every (cache_id, edit) pair equals the CPU reference."""
+    import bench
+    from sige_amd import runtime
+    from sige_amd.utils import dilate_mask, downsample_mask
+    from sige_amd.workloads.ddpm_unet import DDPMConfig, DDPMSparseUNet
+
+    ref = ddpm_reference
+    x0 = [ref["x0"], ref["x0"].flip(3) * 0.9]
+    mask = bench.edit_mask(0.05)
+    t = torch.zeros(1)
+    cpu = DDPMSparseUNet(DDPMConfig()).eval()
+    cpu.load_state_dict(ref["state"])
+    runtime.register_backend("cpu", oracle)
+    want = {}
+    try:
+        with torch.no_grad():
+            for cid in (0, 1):
+                cpu.set_cache_id(cid)
+                cpu.set_mode("full")
+                cpu(x0[cid], t)
+            cpu.set_masks(downsample_mask(dilate_mask(mask, 5), 8))
+            cpu.set_mode("sparse")
+            for cid in (1, 0, 1):
+                cpu.set_cache_id(cid)
+                want[cid] = cpu(x0[cid] + ref["noise"] * mask, t).clone()
+    finally:
+        runtime.unregister_backend("cpu")
+    model = ddpm_gpu
+    cl = lambda a: a.to(DEV).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    td = torch.zeros(1, device=DEV)
+    with torch.no_grad():
+        model.set_compute_dtype("f32")
+        for cid in (0, 1):
+            model.set_cache_id(cid)
+            model.set_mode("full")
+            model(cl(x0[cid]), td)
+        model.set_masks(downsample_mask(dilate_mask(mask.to(DEV), 5), 8))
+        model.set_mode("sparse")
+        for cid in (1, 0, 1, 0):
+            model.set_cache_id(cid)
+            got = model(cl(x0[cid] + ref["noise"] * mask), td)
+            torch.testing.assert_close(got.cpu(), want[cid], rtol=0, atol=util.CONV_ATOL)
+        model.set_cache_id(0)
+
+
+def test_model_on_a_non_current_device(hip):
+    """a paired / unpaired conv of a model that lives on a device other than HIP's current one launches on the
+    model's device (skipped on a one-GPU box)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    dev1 = torch.device("cuda", 1)
+    x = _cl(torch.randn(1, 64, 32, 32, device=dev1))
+    w = torch.randn(64, 64, 3, 3, device=dev1) / 24
+    idx = hip.all_tiles(32, 32, (4, 4), (1, 1), (1, 1), dev1)
+    p = hip.conv_pack_weights(w, 6, 6, (1, 1))
+    torch.cuda.set_device(0)
+    with hip.conv_pair(x):
+        out = hip.gather_conv_cl(x, None, (6, 6), idx, None, None, "identity", p, None, 64, (3, 3), (1, 1),
+                                 full=dict(offset=(1, 1), out_res=(32, 32), residual=None))
+    torch.cuda.synchronize(dev1)
+    torch.testing.assert_close(out, F.conv2d(x, w, None, 1, 1), rtol=0, atol=2e-4)
