@@ -57,7 +57,7 @@ TRACED = ("gather", "scatter_gather", "scatter_fused", "scatter_with_block_resid
           "block_conv_direct", "gather_conv", "scatter_gather_conv", "gather_conv_nchw",
           # channels-last forms (the layout the benchmark runs in)
           "gather_cl", "scatter_gather_cl", "scatter_cl", "scatter_with_block_residual_cl", "block_conv_cl",
-          "gather_conv_cl", "scatter_gather_conv_cl", "scatter_gather_conv_scatter_cl")
+          "gather_conv_cl", "scatter_gather_conv_cl", "scatter_gather_conv_scatter_cl", "wide_conv_cl")
 
 
 class Tracer:
@@ -112,6 +112,11 @@ def op_cost(name, a, k=None):
             # the conv -> Scatter fusion of a SIGE layer
             dense = full is not None and idx.shape[0] * ro * so >= full["out_res"][0] * full["out_res"][1]
         return ("dense_conv_mfma" if dense else "block_conv_mfma"), 0, 2 * T * ro * so * cout * cin * kernel[0] * kernel[1]
+    if name == "wide_conv_cl":  # dense layer on the fp16 matrix cores (conv_wide.hpp): algorithmic flops of the conv
+        x, x2, cout, kernel = a[0], a[1], a[7], a[8]
+        cin = x.shape[1] + (0 if x2 is None else x2.shape[1])
+        up = 4 if k.get("upsample2x") else 1
+        return "dense_conv_wide", 0, 2 * x.shape[0] * x.shape[2] * x.shape[3] * up * cout * cin * kernel[0] * kernel[1]
     if name == "scatter_gather_conv_cl":
         name = "scatter_gather_conv"
     if name == "scatter_gather_conv_scatter_cl":
@@ -426,7 +431,7 @@ def cpu_reference(ratios, headline_ratio, seconds):
         med = statistics.median(times)
         base = {"value": round(1.0 / med, 3), "unit": "forward/s", "ms_per_forward": round(med * 1e3, 2),
                 "ms_per_forward_mean": round(sum(times) / len(times) * 1e3, 2), "statistic": "median", "cores": cores,
-                "kind": kind,
+                "host_cpus": os.cpu_count(), "kind": kind,
                 "sample": "%d timed sparse DDPM-256 U-Net forwards at %.1f%% edit after 5 warm-ups (same weights, original "
                           "image, noise and masks as the GPU run; native ops = %s, tile convs = torch CPU F.conv2d as in "
                           "sige/nn/base.py:88-89)" % (len(times), headline_ratio * 100,
@@ -670,8 +675,10 @@ def main_sd(args, world, rank, dev):
             t0 = time.perf_counter()
             t_d = 0.0
             if with_distribution:
-                parallel.distribute_cache(flat, src=0, method=method)
-                parallel.refresh_derived(model)
+                if args.no_pipeline:
+                    parallel.distribute_cache(flat, src=0, method=method, model=model)
+                else:
+                    parallel.distribute_cache_pipelined(flat, model, src=0, method=method, n_chunks=args.chunks)
                 torch.cuda.synchronize()
                 t_d = time.perf_counter() - t0
             for _ in range(args.steps):
@@ -684,6 +691,50 @@ def main_sd(args, world, rank, dev):
         dt_steady, _ = job(False)
         dt, dist_s = job(True) if world > 1 else (dt_steady, 0.0)
         assert torch.isfinite(out).all()
+        g.replay()
+        torch.cuda.synchronize()
+        gpu_sparse = out.float().cpu()
+    parity = None
+    if rank == 0 and args.cpu_seconds > 0:
+        # configs[3] AT ITS OWN SIZE against the reference's CPU path: the same 860 M-parameter U-Net (same seed), latent,
+        # context and masks on the host cores, native ops from oracle/_ref (the reference's compiled sige/cpu) or the C
+        # restatement, convs = torch CPU; one full + one sparse forward, outside every timed region
+        from oracle import build_ref, oracle
+        from sige_amd import runtime
+
+        try:
+            ref = build_ref.load()
+        except Exception:
+            ref = None
+        n_thr = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("SIGE_CPU_THREADS", "32"))))
+        torch.set_num_threads(n_thr)
+        oracle.set_num_threads(n_thr)
+        runtime.register_backend("cpu", oracle.as_backend(ref) if ref is not None else oracle)
+        try:
+            torch.manual_seed(0)
+            cpu_model = SDUNet(SDConfig()).eval()
+            with torch.no_grad():
+                t0 = time.perf_counter()
+                cpu_model.set_mode("full")
+                cpu_model(x0.cpu().contiguous(), ts.cpu(), context=ctx.cpu())
+                cpu_model.set_masks(downsample_mask(mask512.cpu(), min_res=8, dilation=1))
+                cpu_model.set_mode("sparse")
+                t1 = time.perf_counter()
+                cpu_sparse = cpu_model(x1.cpu().contiguous(), ts.cpu(), context=ctx.cpu())
+                t2 = time.perf_counter()
+            err = float((gpu_sparse - cpu_sparse).abs().max())
+            tol = 1e-3 if args.dtype == "f32" else None
+            parity = {"parity_max_abs": round(err, 7), "parity_max_ref": round(float(cpu_sparse.abs().max()), 4),
+                      "parity_against": ("oracle/_ref (reference sige/cpu)" if ref is not None else "oracle C restatement")
+                                        + " + torch CPU convs, the same 860 M-parameter U-Net / latent / context / masks",
+                      "cpu_baseline": {"value": round(1.0 / (t2 - t1), 4), "unit": "forward/s", "ms_per_forward": round((t2 - t1) * 1e3, 1),
+                                       "cores": n_thr, "host_cpus": os.cpu_count(), "kind": "reference" if ref is not None else "port",
+                                       "sample": "ONE sparse SD U-Net forward (CFG batch 2) after one full forward (%.1f s)" % (t1 - t0)}}
+            if tol is not None:
+                parity.update(parity_tolerance=tol, parity_ok=bool(err <= tol))
+            del cpu_model
+        finally:
+            runtime.unregister_backend("cpu")
     if rank == 0:
         ms_steady = dt_steady * 1e3 / args.steps
         line = {"metric": "Stable Diffusion v1 U-Net sparse (SIGE) forwards/s", "value": round(world * args.steps / dt, 2),
@@ -704,17 +755,19 @@ def main_sd(args, world, rank, dev):
             line["multi_gpu"] = dict(dist_info, method=method, cache_distribution_ms=round(dist_s * 1e3, 3),
                                      value_steady_state_cache_resident=round(world * args.steps / dt_steady, 2),
                                      value_cache_refreshed_every_step=round(world / (dist_s + step_s), 2))
+        if parity is not None:
+            line.update(parity)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def capture_fn(fn):
+def capture_fn(fn, warm=2):
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
-        for _ in range(2):
+        for _ in range(warm):
             fn()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=s, capture_error_mode=CAPTURE_MODE):
@@ -790,6 +843,9 @@ def main():
                          "operands on the fp16 matrix cores, fp32 accumulation and storage (BASELINE configs[4])")
     ap.add_argument("--f16-sweep", default="0.01,0.02,0.05,0.1,0.2",
                     help="edit ratios of the f16-compute section a default (f32) run appends ('' = skip)")
+    ap.add_argument("--x3-sweep", default="0.012,0.05,0.15",
+                    help="edit ratios of the split-fp16-operand (f16x3) section a default (f32) run appends ('' = skip)")
+    ap.add_argument("--no-dynamic", action="store_true", help="skip the mask-change / multi-step section")
     ap.add_argument("--no-extras", action="store_true", help="skip the GauGAN (configs[2]) and SD transformer (configs[3]) sections")
     ap.add_argument("--workload", default="ddpm", choices=["ddpm", "sd"],
                     help="ddpm = BASELINE configs[1] (the headline; what a plain `bench.py` measures); sd = configs[3], the Stable "
@@ -800,6 +856,9 @@ def main():
                     "multi-rank code path on a one-GPU box; the numbers mean nothing")
     ap.add_argument("--distribute", default="auto", choices=["auto", "broadcast", "scatter_allgather"],
                     help="N > 1: collective that distributes the original image's cache")
+    ap.add_argument("--no-pipeline", action="store_true", help="N > 1: one collective over the whole cache, then the local refresh "
+                    "(default: chunks in module order, refresh of chunk k overlapped with the transfer of chunk k+1)")
+    ap.add_argument("--chunks", type=int, default=8, help="N > 1: chunks of the pipelined cache distribution")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -943,8 +1002,12 @@ def main():
             t0 = time.perf_counter()
             t_d = 0.0
             if with_distribution:
-                parallel.distribute_cache(flat, src=0, method=distribute)
-                parallel.refresh_derived(model)  # in place: the captured graph's buffers keep their addresses
+                # chunks in module order, issued asynchronously; what a rank derives from the cache is refreshed chunk by
+                # chunk while later chunks still move (in place: the captured graph's buffers keep their addresses)
+                if args.no_pipeline:
+                    parallel.distribute_cache(flat, src=0, method=distribute, model=model)
+                else:
+                    parallel.distribute_cache_pipelined(flat, model, src=0, method=distribute, n_chunks=args.chunks)
                 torch.cuda.synchronize()
                 t_d = time.perf_counter() - t0
             for _ in range(args.steps):
@@ -1087,9 +1150,12 @@ def main():
             ms16 = timed_replays(gs, k, 5, 1) * 1e3 / k
             gpu_out_f16[args.ratio] = outs.float().cpu()
             del gs, outs, tr
-            f16 = {"what": "tile convs with fp16 operands (v_mfma_f32_32x32x16_f16 / 16x16x32_f16), fp32 accumulation; activations, "
+            f16 = {"what": "convs with fp16 operands (v_mfma_f32_32x32x16_f16 / 16x16x32_f16), fp32 accumulation; activations, "
                            "caches and every other kernel fp32; GroupNorm affine + SiLU fused in fp32 before the down-convert; "
-                           "the 4 stride-2 downsample convs stay on the fp32 matrix path",
+                           "the convs named in `keep_higher_precision` (the model's F16_KEEP, from the per-layer error trace "
+                           "profiles/r3a_f16_error_trace.json) run split fp16 operands (f16x3: fp32-level) where the dense-layer "
+                           "kernel applies and exact fp32 elsewhere (tile convs, the 4 stride-2 downsample convs)",
+                   "keep_higher_precision": list(model.compute_policy["keep"]),
                    "forward_ms": round(ms16, 4), "edit_ratio": args.ratio, "speedup_vs_dense_fp32": round(dense_ms / ms16, 2),
                    "speedup_vs_f32_sparse": round(ms_steady / ms16, 2), "sweep": rows, "kernels": kern16,
                    "block_conv_tflops": round(conv_tf16, 2),
@@ -1099,6 +1165,119 @@ def main():
                                         "rest of its ~5 us is the kernel boundary, the index -> gather -> LDS prologue chain and "
                                         "the epilogue (warm in-situ tensors, hipGraph of back-to-back launches)"}}
             model.set_compute_dtype("f32")
+
+        # ---- split fp16 operands ("f16x3"): fp32-level results on the fp16 matrix cores -- dense remainder + the full pass ----
+        x3 = None
+        gpu_out_x3 = {}
+        if rank == 0 and world == 1 and args.dtype == "f32" and args.x3_sweep and args.layout == "nhwc":
+            model.set_compute_dtype("f16x3")
+            rows = []
+            kern_x3 = None
+            for r in [float(v) for v in args.x3_sweep.split(",")]:
+                xs = prepare(r)
+                model(xs, t)
+                model(xs, t)
+                n0 = hip.launch_count()
+                tracer.log = []
+                model(xs, t)
+                trx, tracer.log = tracer.log, None
+                nl = hip.launch_count() - n0
+                if kern_x3 is None:
+                    kern_x3 = kernel_families(trx)[2]
+                del trx
+                gs, outs = capture(model, xs, t)
+                k = max(20, args.steps // 4)
+                ms = timed_replays(gs, k, 5, 1) * 1e3 / k
+                gpu_out_x3[r] = outs.float().cpu()
+                rows.append({"edit_ratio": r, "forward_ms": round(ms, 4), "speedup_vs_dense_fp32": round(dense_ms / ms, 2), "launches": nl})
+                del gs, outs
+            # the cache-producing full pass (sige/nn/base.py:85-86; one per denoising step in the reference's sampler,
+            # diffusion/samplers/ddim_ddpm_sampler.py:60-66): stock torch / MIOpen in fp32 against the library's kernels
+            full = {}
+            for dt in ("f32", "f16x3"):
+                model.set_compute_dtype(dt)
+                model.set_mode("full")
+                gf, outf = capture(model, x0, t)
+                kf = max(10, args.steps // 10)
+                full[dt] = timed_replays(gf, kf, 3, 1) * 1e3 / kf
+                full[dt + "_out"] = outf.float().clone()
+                del gf, outf
+            full_delta = float((full.pop("f32_out") - full.pop("f16x3_out")).abs().max())
+            # restore the fp32 cache of the original for everything that follows
+            model.set_compute_dtype("f32")
+            model.set_mode("full")
+            model(x0, t)
+            flat = parallel.pack_caches(model)
+            base = rows[0]["forward_ms"] if rows else None
+            x3 = {"what": "every fp32 operand of a dense-layer conv split into fp16 hi + lo, products hi*hi + lo*hi + hi*lo on "
+                          "v_mfma_f32_32x32x16_f16, fp32 accumulation (22-bit operands; weights pre-scaled by a power of two): "
+                          "the dense remainder of the sparse pass (layers >= 1 GFLOP) and the cache-producing full pass; tile convs "
+                          "stay exact fp32",
+                  "forward_ms": base, "sweep": rows, "kernels": kern_x3,
+                  "full_pass_ms": {"torch_miopen_f32": round(full["f32"], 3), "library_f16x3": round(full["f16x3"], 3),
+                                   "speedup": round(full["f32"] / full["f16x3"], 2),
+                                   "max_abs_output_delta": round(full_delta, 7)},
+                  "step_ms_full_plus_sparse": {"f32": round(full["f32"] + ms_steady, 3),
+                                               "f16x3": round(full["f16x3"] + (base or ms_steady), 3),
+                                               "note": "one denoising step of the reference's sampler = full pass on the original + "
+                                                       "sparse pass on the edit (ddim_ddpm_sampler.py:60-73)"}}
+
+        # ---- a new edit arrives (mask change), and one cache per denoising step (cache_id) ----
+        dyn = None
+        if rank == 0 and world == 1 and not args.no_dynamic and args.layout == "nhwc":
+            import statistics
+
+            model.set_compute_dtype(args.dtype)
+            tms = {"set_masks": [], "first_forward_eager": [], "recapture": []}
+            for i in range(4):
+                m, xe = edited(0.012 + 0.004 * i)  # (a different mask every time: nothing is memoised)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                model.set_masks(downsample_mask(dilate_mask(m, 5), 8))
+                model.set_mode("sparse")
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                model(xe, t)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                gm, _ = capture_fn(lambda: model(xe, t), warm=0)  # (capture only: the eager forward above was the warm-up)
+                gm.replay()
+                torch.cuda.synchronize()
+                t3 = time.perf_counter()
+                del gm
+                tms["set_masks"].append((t1 - t0) * 1e3)
+                tms["first_forward_eager"].append((t2 - t1) * 1e3)
+                tms["recapture"].append((t3 - t2) * 1e3)
+            med = {k: round(statistics.median(v), 3) for k, v in tms.items()}
+            # K denoising steps with one cache per step (set_cache_id(k), sige/nn/scatter.py:59-60, diffusion_demo/runner.py:134-164)
+            K = 4
+            x1m = prepare(args.ratio)
+            graphs = []
+            for cid in range(K):
+                model.set_cache_id(cid)
+                model.set_mode("full")
+                model(x0 * (1.0 - 0.05 * cid), t)  # (a different "x_t" per step)
+                model.set_mode("sparse")
+                model(x1m, t)
+                graphs.append(capture(model, x1m, t)[0])
+            reps = max(5, args.steps // K)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                for g_ in graphs:
+                    g_.replay()
+            torch.cuda.synchronize()
+            per_step = (time.perf_counter() - t0) * 1e3 / (reps * K)
+            del graphs
+            model.set_cache_id(0)
+            dyn = {"mask_change_ms": round(med["set_masks"] + med["first_forward_eager"], 3), "mask_change_parts_ms": med,
+                   "mask_change_note": "new edit -> first sparse output: set_masks (device mask pyramid, every index list, ONE device->host "
+                                       "read) + the first eager forward (tile tables, scatter maps); `recapture` = capturing and "
+                                       "replaying a hipGraph for the new mask (what a multi-step loop on that mask then amortises)",
+                   "multi_step": {"steps": K, "caches": K, "sparse_ms_per_step_one_cache_per_step": round(per_step, 4),
+                                  "note": "K hipGraphs, one per cache_id, replayed round-robin: every step reads a DIFFERENT 673 MB "
+                                          "cache (no cross-step cache residency); parity of cache_id > 0 is a -m gpu test"}}
+            prepare(args.ratio)
 
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras and args.layout == "nhwc":
@@ -1117,14 +1296,22 @@ def main():
         if args.cpu_seconds > 0:
             # the benchmarked artefact (this layout, in-place buffers, hipGraph replay) against the reference's CPU path on
             # the SAME weights / image / noise / masks: max |gpu - cpu| per edit ratio, outside every timed region
-            ratios = sorted(set(gpu_out) | set(gpu_out_f16))
+            ratios = sorted(set(gpu_out) | set(gpu_out_f16) | set(gpu_out_x3))
             cpu, cpu_out = cpu_reference(ratios, args.ratio, args.cpu_seconds if world == 1 else 0.0)
             parity = {("%g" % r): round(float((gpu_out[r] - cpu_out[r]).abs().max()), 7) for r in sorted(gpu_out)}
             if f16 is not None:
-                f16["parity_max_abs_vs_fp32_reference"] = {("%g" % r): round(float((gpu_out_f16[r] - cpu_out[r]).abs().max()), 6)
-                                                           for r in sorted(gpu_out_f16)}
-                f16["parity_tolerance"] = "2e-2 abs (stated for the f16-compute path; the fp32 path's is 1e-3)"
-                f16["parity_ok"] = bool(max(f16["parity_max_abs_vs_fp32_reference"].values()) <= 2e-2)
+                from sige_amd import tolerance
+
+                chk = {("%g" % r): tolerance.f16_check(gpu_out_f16[r], cpu_out[r]) for r in sorted(gpu_out_f16)}
+                f16["parity_vs_fp32_reference"] = chk
+                f16["parity_max_abs_vs_fp32_reference"] = {k: v["max_abs"] for k, v in chk.items()}
+                f16["parity_tolerance"] = tolerance.F16_CRITERION + " (the same criterion in tests/test_gpu_round3.py)"
+                f16["parity_ok"] = bool(all(v["ok"] for v in chk.values()))
+            if x3 is not None:
+                x3["parity_max_abs_vs_fp32_reference"] = {("%g" % r): round(float((gpu_out_x3[r] - cpu_out[r]).abs().max()), 7)
+                                                          for r in sorted(gpu_out_x3)}
+                x3["parity_tolerance"] = 1e-3
+                x3["parity_ok"] = bool(max(x3["parity_max_abs_vs_fp32_reference"].values()) <= 1e-3)
         line = {
             "metric": "DDPM-256 U-Net sparse (SIGE) forwards/s",
             "value": round(world * args.steps / dt, 2),
@@ -1154,7 +1341,8 @@ def main():
         if world > 1:
             step_s = dt_steady / args.steps
             line["multi_gpu"] = dict(
-                dist_info, method=distribute,
+                dist_info, method=distribute, pipelined=not args.no_pipeline, chunks=None if args.no_pipeline else args.chunks,
+                rccl_ranks_seen=dist.get_world_size(),
                 cache_distribution_ms=round(dist_s * 1e3, 3),
                 value_cache_distribution_inside_job=round(world * args.steps / dt, 2),
                 value_steady_state_cache_resident=round(world * args.steps / dt_steady, 2),
@@ -1171,6 +1359,10 @@ def main():
             line["parity_against"] = "oracle/_ref (reference sige/cpu) + torch CPU convs, same weights / inputs / masks"
         if f16 is not None:
             line["f16_compute"] = f16
+        if x3 is not None:
+            line["f16x3_compute"] = x3
+        if dyn is not None:
+            line["dynamic"] = dyn
         line.update(extras)
         if cpu is not None:
             line["cpu_baseline"] = cpu

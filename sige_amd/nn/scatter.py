@@ -88,6 +88,18 @@ class _OutputBuffers:
         self.bufs = {}
 
 
+def twin_key_cache_id(key):
+    """Consumers key their registration (consumer id, input part, affine generation, cache id): the registered (scale,
+    shift) is the consumer's cached affine of THAT cache id (one cache per denoising step, sige/nn/scatter.py:59-60).  Keys of
+    any other shape apply to every cache id."""
+    return key[3] if isinstance(key, tuple) and len(key) >= 4 else None
+
+
+def twins_for(regs: dict, cache_id) -> dict:
+    """The registrations a launch under `cache_id` serves."""
+    return {k: v for k, v in regs.items() if twin_key_cache_id(k) in (None, cache_id)}
+
+
 class _TwinBuffers:
     """Activated twins of a Scatter module's persistent output (not in the reference).
 
@@ -104,7 +116,7 @@ class _TwinBuffers:
         self.bufs = {}   # key -> _OutputBuffers
 
     def register(self, key, scale: torch.Tensor, shift: torch.Tensor) -> bool:
-        if key not in self.regs and len(self.regs) >= self.MAX:
+        if key not in self.regs and len(twins_for(self.regs, twin_key_cache_id(key))) >= self.MAX:
             return False
         self.regs[key] = (scale, shift)
         self.bufs.pop(key, None)
@@ -117,7 +129,7 @@ class _TwinBuffers:
     def launch_args(self, cache_id, cached: torch.Tensor, stamp):
         """[(key, buffer, scale, shift)] for the fused launch; buffers are (re)built from the cache when stale."""
         out = []
-        for key, (sc, sh) in self.regs.items():
+        for key, (sc, sh) in twins_for(self.regs, cache_id).items():
             def build(c, sc=sc, sh=sh):
                 return torch.nn.functional.silu(c * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).contiguous(
                     memory_format=torch.channels_last)
@@ -222,7 +234,7 @@ class Scatter(SIGEModule):
                 self._out_bufs.invalidate(self.cache_id)
                 self.twins.invalidate(self.cache_id)
             # (this launch wrote no twin: consumers activate for themselves)
-            return tag_twins(output, emulated_twins(output, self.twins.regs) if EMULATE_TWINS else {})
+            return tag_twins(output, emulated_twins(output, twins_for(self.twins.regs, self.cache_id)) if EMULATE_TWINS else {})
         if self.mode == "full":
             output = x if residual is None else x + residual
             self.output_res = output.shape[2:]
@@ -361,7 +373,7 @@ class ScatterWithBlockResidual(SIGEModule):
                     fn = self.native(self.scatter_runtime, x)
                     y1.copy_(fn(residual.contiguous(), y1.contiguous(), sg.offset[0], sg.offset[1],
                                 sg.model_stride[0], sg.model_stride[1], sg.indices_on(x.device), None))
-            return tag_twins(output, emulated_twins(output, self.twins.regs) if EMULATE_TWINS else {})  # (no twin written)
+            return tag_twins(output, emulated_twins(output, twins_for(self.twins.regs, self.cache_id)) if EMULATE_TWINS else {})  # (no twin written)
         if self.mode == "full":
             output = x + residual
             self.output_res = output.shape[2:]

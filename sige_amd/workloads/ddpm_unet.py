@@ -113,8 +113,10 @@ class _TwinProducer:
         sct = self._twin_scatter()
         if sct is not None:
             return sct.twins.register(key, scale, shift)
+        from ..nn.scatter import twin_key_cache_id, twins_for
+
         regs = self.__dict__.setdefault("twin_regs", {})
-        if key not in regs and len(regs) >= 2:
+        if key not in regs and len(twins_for(regs, twin_key_cache_id(key))) >= 2:
             return False
         regs[key] = (scale, shift)
         return True
@@ -124,6 +126,12 @@ class _TwinProducer:
         if sct is not None:
             sct.twins.unregister(key)
         self.__dict__.setdefault("twin_regs", {}).pop(key, None)
+
+    def _my_twins(self) -> dict:
+        """(dense producers) the registrations this forward serves: those of the current cache id."""
+        from ..nn.scatter import twins_for
+
+        return twins_for(self.__dict__.get("twin_regs") or {}, getattr(self, "cache_id", 0))
 
     def _produced(self, out: torch.Tensor) -> torch.Tensor:
         """Mark `out` as this module's output of the current sparse forward (consumers find their producer through it)."""
@@ -193,7 +201,7 @@ class ResBlock(SIGEModule, _TwinProducer):
         twins, off, complete = [], 0, True
         for i, p in enumerate(parts):
             c = p.shape[1]
-            key = (id(self), i, self._aff_gen)
+            key = (id(self), i, self._aff_gen, self.cache_id)  # (the registered affine is this cache id's)
             t = getattr(p, "_sige_twins", {}).get(key)
             if t is None:
                 complete = False
@@ -331,7 +339,7 @@ class ResBlock(SIGEModule, _TwinProducer):
                 else:
                     h = fused_conv2d(self.conv1, x, s1, t1, "swish", x2=x2, out_affine=(s2, t2, "swish"))
             join()
-            return self._produced(fused_conv2d(self.conv2, h, residual=skip, twins=self.twin_regs))
+            return self._produced(fused_conv2d(self.conv2, h, residual=skip, twins=self._my_twins()))
         if self.cin == self.cout:
             skip = x if x2 is None else torch.cat([x, x2], dim=1)
         else:
@@ -415,7 +423,7 @@ class AttnBlock(SIGEModule, _TwinProducer):
 
     def _dense_sparse(self, x, s, t):
         qkv = fused_conv2d(self.qkv, x, s, t, "identity")
-        return self._produced(fused_conv2d(self.proj_out, self._attention(qkv), residual=x, twins=self.twin_regs))
+        return self._produced(fused_conv2d(self.proj_out, self._attention(qkv), residual=x, twins=self._my_twins()))
 
 
 class Upsample(SIGEModule, _TwinProducer):
@@ -461,7 +469,7 @@ class Downsample(SIGEModule, _TwinProducer):
 
     def forward(self, x):
         if not self.sparse and self.mode == "sparse":
-            return self._produced(fused_conv2d(self.conv, x, pad_bottom_right=True, twins=self.__dict__.get("twin_regs")))
+            return self._produced(fused_conv2d(self.conv, x, pad_bottom_right=True, twins=self._my_twins()))
         if not self.sparse or (self.plain and self.mode == "full"):
             return self.conv(F.pad(x, (0, 1, 0, 1)))
         x = self.gather(x)

@@ -178,7 +178,7 @@ def test_wide_conv_twins_and_dense_module_routing(hip):
     with torch.no_grad():
         n0 = hip.launch_count()
         got = fused_conv2d(conv, x, s, t, "swish", x2=x2, residual=res, twins=tw)
-        assert hip.launch_count() - n0 == 1
+        assert hip.launch_count() - n0 == 2  # (weight packing + ONE conv launch)
         want = conv(F.silu(torch.cat([x, x2], 1) * s + t)) + res
         torch.testing.assert_close(got, want, rtol=0, atol=2e-4)
         twin = got._sige_twins["a"]
@@ -346,3 +346,50 @@ def test_model_on_a_non_current_device(hip):
                                  full=dict(offset=(1, 1), out_res=(32, 32), residual=None))
     torch.cuda.synchronize(dev1)
     torch.testing.assert_close(out, F.conv2d(x, w, None, 1, 1), rtol=0, atol=2e-4)
+
+
+def test_sd_unet_at_its_own_size_vs_cpu_oracle(hip):
+    """BASELINE.json configs[3] AT ITS OWN SIZE (model_channels 320: the 860 M-parameter SD v1 U-Net, latent [2,4,64,64], text
+    context [2,77,768], 15 % edit): channels-last + in-place buffers on the GPU against the same network on the CPU oracle
+    backend, 1e-3.  (The committed fixture pins the structure at model_channels 128 to the reference's own model class;
+    this test carries that parity to the size the benchmark runs.)"""
+    from sige_amd import runtime
+    from sige_amd.utils import downsample_mask
+    from sige_amd.workloads.sd_unet import SDConfig, SDUNet
+    from tests.golden.model_init import init_by_name
+
+    model = SDUNet(SDConfig()).eval()
+    init_by_name(model)
+    g = torch.Generator().manual_seed(4)
+    x0, noise = torch.randn(2, 4, 64, 64, generator=g), torch.randn(2, 4, 64, 64, generator=g)
+    ctx, ts = torch.randn(2, 77, 768, generator=g), torch.full((2,), 500.0)
+    mask512 = torch.zeros(512, 512, dtype=torch.bool)
+    mask512[150:348, 120:318] = True
+    masks = downsample_mask(mask512, min_res=8, dilation=1)
+    x1 = x0 + noise * masks[(64, 64)]
+    n = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(n)
+    oracle.set_num_threads(n)
+    runtime.register_backend("cpu", oracle)
+    try:
+        with torch.no_grad():
+            model.set_mode("full")
+            full_c = model(x0, ts, context=ctx)
+            model.set_masks(masks)
+            model.set_mode("sparse")
+            sparse_c = model(x1, ts, context=ctx)
+    finally:
+        runtime.unregister_backend("cpu")
+    model.clear_cache()
+    model = model.to(DEV).to(memory_format=torch.channels_last)
+    model.set_scatter_inplace(True)
+    cl = lambda a: a.to(DEV).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    with torch.no_grad():
+        model.set_mode("full")
+        full_g = model(cl(x0), ts.to(DEV), context=ctx.to(DEV))
+        model.set_masks(downsample_mask(mask512.to(DEV), min_res=8, dilation=1))
+        model.set_mode("sparse")
+        sparse_g = model(cl(x1), ts.to(DEV), context=ctx.to(DEV))
+    assert float(sparse_c.abs().max()) > 1e-2 and float((sparse_c - full_c).abs().max()) > 1e-3
+    torch.testing.assert_close(full_g.cpu(), full_c, rtol=0, atol=util.CONV_ATOL)
+    torch.testing.assert_close(sparse_g.cpu(), sparse_c, rtol=0, atol=util.CONV_ATOL)

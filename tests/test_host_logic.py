@@ -518,6 +518,31 @@ def test_conv1_twins_host_logic_on_the_oracle_backend():
             stale = next(b for b in blocks if b._twin_links)
             key, prod = next(iter(stale._twin_links.items()))
             assert key[2] == stale._aff_gen  # (the link carries the generation of the affine it was made for)
+            # one cache per denoising step (cache_id, sige/nn/scatter.py:59-60): two originals under ids 0 / 1, forwards
+            # ALTERNATING between them -- a twin registered with cache 1's affine must never serve a forward under cache 0
+            # (found on the GPU in round 3: the registration key did not carry the cache id)
+            for cid, orig in ((0, x0), (1, x0b)):
+                model.set_cache_id(cid)
+                model.set_mode("full")
+                model(orig, t)
+            m = torch.zeros(64, 64, dtype=torch.bool)
+            m[12:30, 20:40] = True
+            model.set_masks(downsample_mask(dilate_mask(m, 5), 8))
+            model.set_mode("sparse")
+            want = {}
+            for b in blocks:
+                b.use_twins = False
+            for cid, orig in ((0, x0), (1, x0b)):
+                model.set_cache_id(cid)
+                want[cid] = model(orig + noise * m, t).clone()
+            for b in blocks:
+                b.use_twins = True
+            for cid in (1, 0, 1, 0, 0, 1):
+                model.set_cache_id(cid)
+                got = model((x0, x0b)[cid] + noise * m, t)
+                assert (got - want[cid]).abs().max() < 1e-4, cid
+            assert any(k[3] == 0 for b in blocks for k in b._twin_links) and any(k[3] == 1 for b in blocks for k in b._twin_links)
+            model.set_cache_id(0)
     finally:
         scatter.EMULATE_TWINS = False
         runtime.unregister_backend("cpu")

@@ -70,9 +70,11 @@ def main():
     ap.add_argument("--ksplit-sweep", action="store_true")
     args = ap.parse_args()
     from sige_amd import hip
+    from sige_amd.nn import dense
     from sige_amd.nn.dense import fused_conv2d
 
     hip.lib()
+    dense.WIDE_MIN_FLOP = 0.0  # (time the dense-layer kernel on every layer, also below the routing threshold)
     dev = "cuda"
     rows = []
     for name, k, c1, c2, cout, res, aff, resid in LAYERS:
