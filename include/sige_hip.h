@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SIGE_HIP_VERSION 300 /* 0.3.0: round 3 -- dense-layer convs on the fp16 matrix cores (fp16 / split-fp16 operands) */
+#define SIGE_HIP_VERSION 301 /* 0.3.0: round 3 -- dense-layer convs on the fp16 matrix cores (fp16 / split-fp16 operands) */
 
 enum {
     SIGE_HIP_OK = 0,
@@ -507,8 +507,9 @@ size_t sige_hip_wide_conv_packed_size(int Cout, int Cin, int kH, int kW, int x3)
 int sige_hip_wide_conv_pack(const float *w, int Cout, int Cin, int kH, int kW, int x3, int wshift,
                             float *packed, void *stream);
 size_t sige_hip_wide_conv_workspace(int B, int H, int W, int C1, int C2, int Cout, int kH, int kW);
-/* benchmarking: pin the K split (0 = automatic) */
+/* benchmarking: pin the K split (0 = automatic) / the width of a workgroup's output patch (8 | 16; 0 = automatic) */
 int sige_hip_wide_conv_force_ksplit(int ksplit);
+int sige_hip_wide_conv_force_patch(int width);
 int sige_hip_wide_conv_nhwc(const float *x, const float *x2, int B, int C1, int C2, int H, int W, int upsample2x,
                             const float *scale, const float *shift, int affineB, int activation,
                             const float *packed, int x3, int wshift, const float *bias, int Cout, int kH, int kW,

@@ -7,10 +7,10 @@
 
 namespace sige {
 
-template <> void launch_conv_wide<3, false>(const WideArgs &, bool, bool, hipStream_t);
-template <> void launch_conv_wide<3, true>(const WideArgs &, bool, bool, hipStream_t);
-template <> void launch_conv_wide<1, false>(const WideArgs &, bool, bool, hipStream_t);
-template <> void launch_conv_wide<1, true>(const WideArgs &, bool, bool, hipStream_t);
+#define SIGE_WIDE_DECLARE(KH, X3)                                                                   \
+    template <> void launch_conv_wide<KH, X3, 8>(const WideArgs &, bool, bool, hipStream_t);        \
+    template <> void launch_conv_wide<KH, X3, 16>(const WideArgs &, bool, bool, hipStream_t);
+SIGE_WIDE_DECLARE(3, false) SIGE_WIDE_DECLARE(3, true) SIGE_WIDE_DECLARE(1, false) SIGE_WIDE_DECLARE(1, true)
 
 // packed[ntile][wave][chunk][ks][tap][nt][plane][lane = (kq, j)][e] =
 //     plane(w[co = 64 ntile + 32 nt + j][ci = chunk*CC + wave*CW + 16 ks + 8 kq + e][tap] * 2^wshift)
@@ -42,7 +42,7 @@ __global__ void pack_wide_kernel(const float *__restrict__ w, int Cout, int Cin,
 template <typename G>
 static size_t wide_packed_bytes(int Cout, int Cin) {
     const size_t nchunks = (Cin + G::CC - 1) / G::CC, ntn = (Cout + 63) / 64;
-    return ntn * 4 * nchunks * G::STEPS * G::STEPB + (size_t)G::RB * G::STEPB;  // + padding for the prefetch past the last step
+    return ntn * 4 * nchunks * G::STEPS * G::STEPB + (size_t)kWidePadSteps * G::STEPB;  // + padding for the prefetch past the last step
 }
 
 static bool wide_shape_ok(int C1, int C2, int Cout, int kH, int kW) {
@@ -51,7 +51,11 @@ static bool wide_shape_ok(int C1, int C2, int Cout, int kH, int kW) {
     return C1 > 0 && C2 >= 0 && C1 % cc == 0 && C2 % cc == 0 && Cout > 0 && Cout % 64 == 0;
 }
 
-static int g_wide_force_ksplit = 0;
+static int g_wide_force_ksplit = 0, g_wide_force_patch = 0;
+
+// width of a workgroup's output patch: 8 x 16 pixels (one wave per SIMD, a chunk of weights in registers) wherever the map
+// is at least 16 wide; 8 x 8 for the 8 x 8 maps
+static int wide_patch(int W) { return g_wide_force_patch ? g_wide_force_patch : (W >= 16 ? 16 : 8); }
 
 // K split of a launch with `blocks` output blocks and `nchunks` channel chunks: enough workgroups for two per CU
 static int wide_ksplit(long blocks, int nchunks, size_t out_floats, size_t ws_floats) {
@@ -89,7 +93,7 @@ extern "C" int sige_hip_wide_conv_pack(const float *w, int Cout, int Cin, int kH
     _Float16 *ph = reinterpret_cast<_Float16 *>(packed);
     auto go = [&](auto g_tag) {
         using G = decltype(g_tag);
-        const long total = (long)((wide_packed_bytes<G>(Cout, Cin) - (size_t)G::RB * G::STEPB) / 2);
+        const long total = (long)((wide_packed_bytes<G>(Cout, Cin) - (size_t)kWidePadSteps * G::STEPB) / 2);
         const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
         pack_wide_kernel<G><<<grid, 256, 0, st>>>(w, Cout, Cin, wmul, ph, total);
     };
@@ -100,11 +104,17 @@ extern "C" int sige_hip_wide_conv_pack(const float *w, int Cout, int Cin, int kH
 
 extern "C" size_t sige_hip_wide_conv_workspace(int B, int H, int W, int C1, int C2, int Cout, int kH, int kW) {
     if (!wide_shape_ok(C1, C2, Cout, kH, kW) || B <= 0 || H <= 0 || W <= 0) return 0;
-    const long blocks = (long)B * ceil_div(H, 8) * ceil_div(W, 8) * (Cout / 64);
+    const long blocks = (long)B * ceil_div(H, 8) * ceil_div(W, wide_patch(W)) * (Cout / 64);
     const int cc = kH == 3 ? WideGeo<3, false>::CC : WideGeo<1, false>::CC;
     const size_t out_floats = (size_t)B * H * W * Cout;
-    const int s = wide_ksplit(blocks, (C1 + C2) / cc, out_floats, (size_t)-1);
+    const int s = wide_ksplit(blocks * (wide_patch(W) / 8), (C1 + C2) / cc, out_floats, (size_t)-1);
     return s > 1 ? (size_t)s * out_floats : 0;
+}
+
+extern "C" int sige_hip_wide_conv_force_patch(int width) {
+    if (width != 0 && width != 8 && width != 16) return SIGE_HIP_EINVAL;
+    g_wide_force_patch = width;
+    return SIGE_HIP_OK;
 }
 
 extern "C" int sige_hip_wide_conv_force_ksplit(int ksplit) {
@@ -145,13 +155,15 @@ extern "C" int sige_hip_wide_conv_nhwc(const float *x, const float *x2, int B, i
     a.wscale = ldexpf(1.0f, -wshift);
     a.B = B; a.H = H; a.W = W; a.C1 = C1; a.C2 = C2; a.Cout = Cout; a.up = upsample2x ? 1 : 0; a.act = activation;
     a.aff_sb = (scale && affineB > 1) ? C1 + C2 : 0;
-    a.th = ceil_div(H, 8); a.tw = ceil_div(W, 8); a.ntn = Cout / 64;
+    const int pwo = wide_patch(W);
+    a.th = ceil_div(H, 8); a.tw = ceil_div(W, pwo); a.ntn = Cout / 64;
     const int cc = kH == 3 ? WideGeo<3, false>::CC : WideGeo<1, false>::CC;
     a.nchunks = (C1 + C2) / cc; a.nchunks1 = C1 / cc;
     hipStream_t st = as_stream(stream);
     const long blocks = (long)B * a.th * a.tw * a.ntn;
     const size_t out_floats = (size_t)B * H * W * Cout;
-    a.ksplit = workspace ? wide_ksplit(blocks, a.nchunks, out_floats, workspace_floats) : 1;
+    // (an 8 x 16 workgroup is one per CU: the same fill target in units of 8 x 8 blocks)
+    a.ksplit = workspace ? wide_ksplit(blocks * (pwo / 8), a.nchunks, out_floats, workspace_floats) : 1;
     if (a.ksplit > 1) {
         a.counters = split_tickets(st, blocks);
         if (!a.counters) a.ksplit = 1;
@@ -160,7 +172,13 @@ extern "C" int sige_hip_wide_conv_nhwc(const float *x, const float *x2, int B, i
     a.ksplit = ceil_div(a.nchunks, a.chunks_per_split);
     if (a.ksplit > 1) { a.out = workspace; a.split_stride = out_floats; }
     const bool aff = scale != nullptr, cat = C2 > 0;
-    if (kH == 3) { if (x3) launch_conv_wide<3, true>(a, aff, cat, st); else launch_conv_wide<3, false>(a, aff, cat, st); }
-    else { if (x3) launch_conv_wide<1, true>(a, aff, cat, st); else launch_conv_wide<1, false>(a, aff, cat, st); }
+#define SIGE_WIDE_GO(KH, X3)                                                                        \
+    do {                                                                                            \
+        if (pwo == 16) launch_conv_wide<KH, X3, 16>(a, aff, cat, st);                               \
+        else launch_conv_wide<KH, X3, 8>(a, aff, cat, st);                                          \
+    } while (0)
+    if (kH == 3) { if (x3) SIGE_WIDE_GO(3, true); else SIGE_WIDE_GO(3, false); }
+    else { if (x3) SIGE_WIDE_GO(1, true); else SIGE_WIDE_GO(1, false); }
+#undef SIGE_WIDE_GO
     return launch_status(1);
 }

@@ -29,17 +29,27 @@
 
 namespace sige {
 
-template <int KH_, bool X3_>
+// PWO_: width of the output patch of a workgroup -- 8 (8 x 8 pixels, two waves per SIMD: small maps, many workgroups) or
+// 16 (8 x 16 pixels = four M tiles per wave, ONE wave per SIMD with the 512-register budget: every weight byte pulled from
+// L2 feeds twice the matrix work, and the weight ring holds a whole chunk -- a workgroup of the 8 x 8 form needs 4 KB of
+// weights per 384 cycles of MFMA and wave, 85 B/clk/CU with eight waves, about twice what a CU can pull from L2).
+template <int KH_, bool X3_, int PWO_ = 8>
 struct WideGeo {
     static constexpr int KH = KH_, KK = KH_ * KH_;
     static constexpr bool X3 = X3_;
+    static constexpr int PWO = PWO_;                   // output patch: 8 rows x PWO columns
+    static constexpr int MTN = PWO_ / 4;               // 32-pixel M tiles per wave (2 | 4)
+    static constexpr int RPT = 32 / PWO_;              // patch rows per M tile (4 | 2)
+    static constexpr int BM = 8 * PWO_;                // output pixels per workgroup
+    static constexpr int OCC = PWO_ == 16 ? 1 : 2;     // waves per SIMD the register budget is set for
     static constexpr int NP = X3_ ? 2 : 1;             // operand planes: hi | hi, lo
     static constexpr int KS = KH_ == 1 ? 2 : 1;        // 16-channel k-steps per tap and chunk (per wave)
     static constexpr int CW = 16 * KS;                 // channels per wave per chunk
     static constexpr int CC = 4 * CW;                  // channels per chunk (4 waves split K)
     static constexpr int STEPS = KS * KK;              // k-steps per chunk; one step = 2x2 tiles x (1 | 3) MFMAs
-    static constexpr int PW = KH_ == 3 ? 10 : 8;       // edge of the staged patch (8x8 outputs + halo)
-    static constexpr int NPX = PW * PW;                // staged pixels
+    static constexpr int PW = PWO_ + (KH_ == 3 ? 2 : 0);  // width of the staged patch (outputs + halo)
+    static constexpr int PH = 8 + (KH_ == 3 ? 2 : 0);  // its height
+    static constexpr int NPX = PW * PH;                // staged pixels
     static constexpr int QP = CW / 4;                  // float4 units per staged pixel (per wave)
     static constexpr int UNITS = NPX * QP;
     static constexpr int NS = (UNITS + 63) / 64;       // staging slots per lane
@@ -47,12 +57,15 @@ struct WideGeo {
     static constexpr int ROWB = KS * KSB + 16;         // LDS row of one staged pixel (padded against bank conflicts)
     static constexpr int ABUF = NPX * ROWB;            // bytes of one stage of one wave
     static constexpr int STEPB = 2 * NP * 1024;        // packed weight bytes per k-step of one wave: [nt][plane][lane][16 B]
-    static constexpr int RB = KH_ == 3 ? (X3_ ? 3 : 9) : 4;  // weight register ring, in k-steps (= prefetch distance)
+    // weight register ring, in k-steps (= prefetch distance): a whole chunk where the register budget allows
+    static constexpr int RB = KH_ == 3 ? (X3_ ? (PWO_ == 8 ? 3 : 6) : 9) : 4;
     static_assert((2 * STEPS) % RB == 0, "the ring position of a step must not depend on the chunk");
-    static constexpr int LDS_BYTES = cmax(4 * 2 * ABUF, 4 * 64 * 68 * 4);
+    static_assert(RB <= 9, "kWidePadSteps");
+    static constexpr int LDS_BYTES = cmax(4 * 2 * ABUF, 4 * BM * 68 * 4);
 };
 
 constexpr int kWideMaxSplit = 16;
+constexpr int kWidePadSteps = 9;   // k-steps of padding behind the packed weights (>= every geometry's RB: the prefetch runs past the last step)
 
 struct WideArgs {
     const float *x, *x2;        // [B,Hs,Ws,C1], [B,Hs,Ws,C2] channels-last (Hs = H >> up); channels of x2 follow those of x
@@ -66,7 +79,7 @@ struct WideArgs {
     size_t split_stride;
     float wscale;               // 2^-S: the weights were packed as w * 2^S
     int B, H, W, C1, C2, Cout, up, act, oact, aff_sb;
-    int th, tw;                 // 8x8 patches per image: rows, columns
+    int th, tw;                 // output patches (8 x PWO) per image: rows, columns
     int ntn;                    // 64-channel output blocks
     int nchunks, nchunks1;      // channel chunks in total / in x
     int ksplit, chunks_per_split;
@@ -79,7 +92,7 @@ __device__ __forceinline__ f16x8 buf_h8(rsrc_t r, unsigned byte_off, int soff) {
 
 // One workgroup of the launch.  AFF: the staging path applies scale * x + shift (and SiLU if a.act); CAT: channels from two tensors.
 template <typename G, bool AFF, bool CAT>
-__global__ __launch_bounds__(256, 2) void conv_wide_kernel(const WideArgs a) {
+__global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];
     constexpr bool X3 = G::X3;
     constexpr int NS = G::NS, STEPS = G::STEPS, RB = G::RB, NP = G::NP;
@@ -93,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void conv_wide_kernel(const WideArgs a) {
     const int last = min(a.nchunks, first + a.chunks_per_split) - 1;
     const int tpi = a.th * a.tw;
     const int b = mtile / tpi, tr = mtile - b * tpi;
-    const int ph0 = (tr / a.tw) * 8, pw0 = (tr % a.tw) * 8;
+    const int ph0 = (tr / a.tw) * 8, pw0 = (tr % a.tw) * G::PWO;
     const int Hs = a.H >> a.up, Ws = a.W >> a.up;
 
     // ---- staging slots: slot i of this lane = float4 unit v = lane + 64 i of the wave's patch [pixel][QP] ----
@@ -173,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv_wide_kernel(const WideArgs a) {
     const unsigned char *const bstream = reinterpret_cast<const unsigned char *>(a.packed) +
                                          ((long)(ntile * 4 + wave) * a.nchunks + first) * STEPS * G::STEPB;
     // (range: the rest of the packed tensor from here on; the allocation carries RB steps of padding for the prefetch past `last`)
-    const long left = (long)a.ntn * 4 * stream_bytes - ((long)(ntile * 4 + wave) * a.nchunks + first) * STEPS * G::STEPB + (long)RB * G::STEPB;
+    const long left = (long)a.ntn * 4 * stream_bytes - ((long)(ntile * 4 + wave) * a.nchunks + first) * STEPS * G::STEPB + (long)kWidePadSteps * G::STEPB;
     const rsrc_t r_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(bstream), 0,
                                                          __builtin_amdgcn_readfirstlane((int)(left > 0x7fffffffL ? 0x7fffffffL : left)), 0x00020000);
     f16x8 bring[RB][2][NP];
@@ -188,26 +201,24 @@ __global__ __launch_bounds__(256, 2) void conv_wide_kernel(const WideArgs a) {
 
     // ---- A operand of this lane: pixel i of M tile mt (rows 4 mt .. 4 mt + 3 of the patch), k-group kq ----
     const int i32 = lane & 31, kq = lane >> 5;
-    const int abase = ((i32 >> 3) * G::PW + (i32 & 7)) * G::ROWB + kq * 16;  // + mt * 4 * PW * ROWB
-    struct AOp { f16x8 hi[2], lo[2]; };
-    auto a_read = [&](auto s_tag, const unsigned char *buf) -> AOp {
+    const int abase = ((i32 / G::PWO) * G::PW + (i32 % G::PWO)) * G::ROWB + kq * 16;  // + mt * RPT * PW * ROWB
+    constexpr int MTN = G::MTN;
+    struct AHalf { f16x8 v[G::MTN]; };
+    // plane 0 = hi, 1 = lo (32 bytes further in the pixel's row)
+    auto a_read = [&](auto s_tag, const unsigned char *buf, int plane) -> AHalf {
         constexpr int s = decltype(s_tag)::value;
         constexpr int ks = s / G::KK, tap = s % G::KK;
         constexpr int off = ((tap / G::KH) * G::PW + tap % G::KH) * G::ROWB + ks * G::KSB;
-        AOp r;
+        AHalf r;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const unsigned char *p = buf + abase + mt * 4 * G::PW * G::ROWB + off;
-            r.hi[mt] = *reinterpret_cast<const f16x8 *>(p);
-            if constexpr (X3) r.lo[mt] = *reinterpret_cast<const f16x8 *>(p + 32);
-            else r.lo[mt] = r.hi[mt];
-        }
+        for (int mt = 0; mt < MTN; ++mt)
+            r.v[mt] = *reinterpret_cast<const f16x8 *>(buf + abase + mt * G::RPT * G::PW * G::ROWB + off + plane * 32);
         return r;
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MTN][2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MTN; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -222,7 +233,8 @@ __global__ __launch_bounds__(256, 2) void conv_wide_kernel(const WideArgs a) {
     static_for<0, NS>([&](auto i_tag) { a_store(i_tag, mybuf, sc_c, sh_c); });
     a_load(min(first + 1, last));
     __builtin_amdgcn_wave_barrier();
-    AOp a_cur = a_read(std::integral_constant<int, 0>{}, mybuf);
+    AHalf a_hi = a_read(std::integral_constant<int, 0>{}, mybuf, 0), a_lo = a_hi;
+    if constexpr (X3) a_lo = a_read(std::integral_constant<int, 0>{}, mybuf, 1);
 
     // one chunk: MFMAs on stage PAR; the registers holding chunk+1 are finished into stage PAR^1 and re-issued as chunk+2;
     // every ring position is re-issued RB steps ahead right after its MFMAs
@@ -238,25 +250,29 @@ __global__ __launch_bounds__(256, 2) void conv_wide_kernel(const WideArgs a) {
         static_for<0, STEPS>([&](auto s_tag) {
             constexpr int s = decltype(s_tag)::value;
             constexpr int slot = (PAR * STEPS + s) % RB;
-            AOp a_nxt;
-            if constexpr (s + 1 < STEPS) a_nxt = a_read(std::integral_constant<int, s + 1>{}, cur);
-            // hi*hi for the four tiles, then lo*hi, then hi*lo: consecutive MFMAs never share an accumulator
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur.hi[mt], bring[slot][nt][0], acc[mt][nt], 0, 0, 0);
+            // lo*hi first: the lo operands die after the first group and next step's lo takes their registers; then hi*hi and
+            // hi*lo.  Consecutive MFMAs never share an accumulator.
+            AHalf n_hi = a_hi, n_lo = a_lo;
+            if constexpr (s + 1 < STEPS) n_hi = a_read(std::integral_constant<int, s + 1>{}, cur, 0);
             if constexpr (X3) {
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < MTN; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur.lo[mt], bring[slot][nt][0], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo.v[mt], bring[slot][nt][0], acc[mt][nt], 0, 0, 0);
+                if constexpr (s + 1 < STEPS) n_lo = a_read(std::integral_constant<int, s + 1>{}, cur, 1);
+            }
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MTN; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi.v[mt], bring[slot][nt][0], acc[mt][nt], 0, 0, 0);
+            if constexpr (X3) {
+#pragma unroll
+                for (int mt = 0; mt < MTN; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur.hi[mt], bring[slot][nt][NP - 1], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi.v[mt], bring[slot][nt][NP - 1], acc[mt][nt], 0, 0, 0);
             }
             // staging slots of chunk+1 spread over the steps before the last one
             if constexpr (s < STEPS - 1 || STEPS == 1) {
@@ -276,9 +292,11 @@ __global__ __launch_bounds__(256, 2) void conv_wide_kernel(const WideArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (s + 1 == STEPS) {
                 __builtin_amdgcn_wave_barrier();  // (the stage was written by other lanes of this wave: LDS is in order per wave)
-                a_nxt = a_read(std::integral_constant<int, 0>{}, nxt);
+                n_hi = a_read(std::integral_constant<int, 0>{}, nxt, 0);
+                if constexpr (X3) n_lo = a_read(std::integral_constant<int, 0>{}, nxt, 1);
             }
-            a_cur = a_nxt;
+            a_hi = n_hi;
+            a_lo = n_lo;
         });
     };
     for (int chunk = first; chunk <= last; chunk += 2) {
@@ -291,9 +309,9 @@ __global__ __launch_bounds__(256, 2) void conv_wide_kernel(const WideArgs a) {
     constexpr int RP = 68;
     float *const red = reinterpret_cast<float *>(smem);
     {
-        float *r = red + wave * 64 * RP + i32;
+        float *r = red + wave * G::BM * RP + i32;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MTN; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -311,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void conv_wide_kernel(const WideArgs a) {
     auto locate = [&](int k) -> Unit {
         const int o = tid + 256 * k;
         const int n4 = o & 15, m = o >> 4;
-        const int h = ph0 + (m >> 3), w = pw0 + (m & 7);
+        const int h = ph0 + m / G::PWO, w = pw0 + m % G::PWO;
         Unit u;
         u.co = ntile * 64 + 4 * n4;
         u.ok = h < a.H && w < a.W && u.co < a.Cout;
@@ -346,15 +364,16 @@ __global__ __launch_bounds__(256, 2) void conv_wide_kernel(const WideArgs a) {
         }
         *reinterpret_cast<float4 *>((split_k ? a.fout : a.out) + u.addr) = s;
     };
+    constexpr int EU = G::BM * 16 / 256;  // float4 units per lane
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < EU; ++k) {
         const Unit u = locate(k);
         const int o = tid + 256 * k;
         const float *r0 = red + (o >> 4) * RP + 4 * (o & 15);
         float4 s = *reinterpret_cast<const float4 *>(r0);
 #pragma unroll
         for (int w = 1; w < 4; ++w) {
-            const float4 v = *reinterpret_cast<const float4 *>(r0 + w * 64 * RP);
+            const float4 v = *reinterpret_cast<const float4 *>(r0 + w * G::BM * RP);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
         if (!u.ok) continue;
@@ -372,30 +391,40 @@ __global__ __launch_bounds__(256, 2) void conv_wide_kernel(const WideArgs a) {
         const int ticket = __builtin_bit_cast(int, red[0]);
         if (ticket == a.ksplit - 1) {
             if (tid == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the copies of this lane's units (four units at a time), four splits in flight at a time, added in split order
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const Unit u = locate(k);
-                if (!u.ok) continue;
-                float4 pv[kWideMaxSplit];
+            for (int k0 = 0; k0 < EU; k0 += 4) {
+                Unit us[4];
+                float4 sum[4];
 #pragma unroll
-                for (int sidx = 0; sidx < kWideMaxSplit; ++sidx)
-                    pv[sidx] = coherent_load(a.out + (size_t)(sidx < a.ksplit ? sidx : a.ksplit - 1) * a.split_stride + u.addr);
-                float4 s = pv[0];
+                for (int k = 0; k < 4; ++k) { us[k] = locate(k0 + k); sum[k] = make_float4(0.f, 0.f, 0.f, 0.f); }
+                for (int s0 = 0; s0 < a.ksplit; s0 += 4) {
+                    float4 pv[4][4];
 #pragma unroll
-                for (int sidx = 1; sidx < kWideMaxSplit; ++sidx)
-                    if (sidx < a.ksplit) { s.x += pv[sidx].x; s.y += pv[sidx].y; s.z += pv[sidx].z; s.w += pv[sidx].w; }
-                emit(u, s);
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int d = 0; d < 4; ++d)
+                            pv[k][d] = coherent_load(a.out + (size_t)(s0 + d < a.ksplit ? s0 + d : a.ksplit - 1) * a.split_stride + us[k].addr);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int d = 0; d < 4; ++d)
+                            if (s0 + d < a.ksplit) { sum[k].x += pv[k][d].x; sum[k].y += pv[k][d].y; sum[k].z += pv[k][d].z; sum[k].w += pv[k][d].w; }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (us[k].ok) emit(us[k], sum[k]);
             }
         }
     }
 }
 
-template <int KH, bool X3>
+template <int KH, bool X3, int PWO>
 void launch_conv_wide(const WideArgs &a, bool aff, bool cat, hipStream_t st);
 
-#define SIGE_WIDE_INSTANTIATE(KH, X3)                                                                      \
-    template <> void launch_conv_wide<KH, X3>(const WideArgs &a, bool aff, bool cat, hipStream_t st) {     \
-        using G = WideGeo<KH, X3>;                                                                         \
+#define SIGE_WIDE_INSTANTIATE(KH, X3, PWO)                                                                 \
+    template <> void launch_conv_wide<KH, X3, PWO>(const WideArgs &a, bool aff, bool cat, hipStream_t st) { \
+        using G = WideGeo<KH, X3, PWO>;                                                                    \
         const dim3 grid(a.B * a.th * a.tw * a.ntn, a.ksplit);                                              \
         if (aff && cat) conv_wide_kernel<G, true, true><<<grid, 256, 0, st>>>(a);                          \
         else if (aff) conv_wide_kernel<G, true, false><<<grid, 256, 0, st>>>(a);                           \

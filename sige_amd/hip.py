@@ -130,6 +130,7 @@ _SIGNATURES = {
     "sige_hip_wide_conv_pack": (_c_int, [_c_vp] + [_c_int] * 6 + [_c_vp, _c_vp]),
     "sige_hip_wide_conv_workspace": (_c_sz, [_c_int] * 8),
     "sige_hip_wide_conv_force_ksplit": (_c_int, [_c_int]),
+    "sige_hip_wide_conv_force_patch": (_c_int, [_c_int]),
     "sige_hip_wide_conv_nhwc": (
         _c_int, [_c_vp, _c_vp] + [_c_int] * 6 + [_c_vp, _c_vp, _c_int, _c_int] + [_c_vp, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_int]
         + [_c_vp, _c_vp, _c_vp, _c_int] + [_c_vp] * 6 + [_c_vp, _c_sz, _c_vp, _c_vp]),
@@ -561,6 +562,11 @@ def wide_conv_pack_weights(weight: torch.Tensor, compute: str) -> Optional[torch
 def wide_conv_force_ksplit(ksplit: int = 0):
     """Benchmark knob: pin the cross-workgroup K split of the dense-layer conv (0 = automatic)."""
     _check(lib().sige_hip_wide_conv_force_ksplit(ksplit), "wide_conv_force_ksplit")
+
+
+def wide_conv_force_patch(width: int = 0):
+    """Benchmark knob: 8 x 8 or 8 x 16 output pixels per workgroup of the dense-layer conv (0 = automatic)."""
+    _check(lib().sige_hip_wide_conv_force_patch(width), "wide_conv_force_patch")
 
 
 def wide_conv_cl(x, x2, scale, shift, activationName: str, packed, bias, Cout: int, kernel: Tuple[int, int],
