@@ -1194,13 +1194,13 @@ def main():
             # the cache-producing full pass (sige/nn/base.py:85-86; one per denoising step in the reference's sampler,
             # diffusion/samplers/ddim_ddpm_sampler.py:60-66): stock torch / MIOpen in fp32 against the library's kernels
             full = {}
-            for dt in ("f32", "f16x3"):
-                model.set_compute_dtype(dt)
+            for cdt in ("f32", "f16x3"):
+                model.set_compute_dtype(cdt)
                 model.set_mode("full")
                 gf, outf = capture(model, x0, t)
                 kf = max(10, args.steps // 10)
-                full[dt] = timed_replays(gf, kf, 3, 1) * 1e3 / kf
-                full[dt + "_out"] = outf.float().clone()
+                full[cdt] = timed_replays(gf, kf, 3, 1) * 1e3 / kf
+                full[cdt + "_out"] = outf.float().clone()
                 del gf, outf
             full_delta = float((full.pop("f32_out") - full.pop("f16x3_out")).abs().max())
             # restore the fp32 cache of the original for everything that follows

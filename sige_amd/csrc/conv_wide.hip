@@ -53,9 +53,11 @@ static bool wide_shape_ok(int C1, int C2, int Cout, int kH, int kW) {
 
 static int g_wide_force_ksplit = 0, g_wide_force_patch = 0;
 
-// width of a workgroup's output patch: 8 x 16 pixels (one wave per SIMD, a chunk of weights in registers) wherever the map
-// is at least 16 wide; 8 x 8 for the 8 x 8 maps
-static int wide_patch(int W) { return g_wide_force_patch ? g_wide_force_patch : (W >= 16 ? 16 : 8); }
+// width of a workgroup's output patch.  8 x 8 pixels / two waves per SIMD everywhere: the 8 x 16 form (one wave per SIMD, the
+// 512-register budget, twice the matrix work per weight byte) measured SLOWER on every layer of the DDPM-256 U-Net (256^2
+// 128->128: 92 vs 73 us; 32^2 768->256: 34 vs 24 us -- profiles/r3b_wide_bench.jsonl): one in-order wave per SIMD hides
+// nothing.  It stays selectable for measurements (sige_hip_wide_conv_force_patch).
+static int wide_patch(int W) { (void)W; return g_wide_force_patch ? g_wide_force_patch : 8; }
 
 // K split of a launch with `blocks` output blocks and `nchunks` channel chunks: enough workgroups for two per CU
 static int wide_ksplit(long blocks, int nchunks, size_t out_floats, size_t ws_floats) {

@@ -35,10 +35,12 @@ def _tile_compute(compute: str) -> str:
     return "f16" if compute == "f16" else "f32"
 
 
-# Dense layers below this many flop stay on the tile kernels (conv_mfma.hpp).  Measured per layer on MI355X
-# (tools/wide_bench.py, profiles/r3b_wide_bench.jsonl): at >= 1.2 GFLOP the 64 x 64 blocks of conv_wide.hpp win (2.4 GFLOP:
-# 36 -> 24 us, 3.6 GFLOP: 51 -> 27 us, the 19 GFLOP layers of the full pass: 280 -> 75 us); below, the launch is its start-up.
-WIDE_MIN_FLOP = 1.0e9
+# Dense layers below this many flop stay on the tile kernels (conv_mfma.hpp), by kernel size.  Measured per layer on MI355X
+# (tools/wide_bench.py, profiles/r3b_wide_bench.jsonl; split fp16 operands vs the exact-fp32 tile kernel): every 3x3 dense
+# layer of the DDPM-256 U-Net is at least as fast on the 64 x 64 blocks of conv_wide.hpp (0.3 GFLOP: 15.8 vs 15.5 us; 1.2:
+# 16.6 vs 22.0; 3.6: 24.3 vs 51.4; the 19 GFLOP layers of the full pass: 73 vs 282), the 1x1 convs of the sparse pass
+# (<= 0.4 GFLOP: two k-steps per chunk, the launch is its start-up) are not (12.9 vs 7.5 us).
+WIDE_MIN_FLOP = {3: 0.25e9, 1: 2.0e9}
 
 
 def _wide_packed(conv: nn.Conv2d, compute: str):
@@ -69,7 +71,7 @@ def _wide_conv(conv: nn.Conv2d, x, x2, scale, shift, activation_name, residual, 
         return None
     C1, C2 = x.shape[1], 0 if x2 is None else x2.shape[1]
     pix = x.shape[0] * x.shape[2] * x.shape[3] * (4 if upsample2x else 1)
-    if 2.0 * pix * conv.out_channels * (C1 + C2) * k[0] * k[1] < WIDE_MIN_FLOP:
+    if 2.0 * pix * conv.out_channels * (C1 + C2) * k[0] * k[1] < WIDE_MIN_FLOP[k[0]]:
         return None  # (small layers are latency-bound: the tile kernels' 16 / 32-pixel blocks start up faster)
     if not hip.wide_conv_supported(C1, C2, conv.out_channels, k):
         if x2 is None or upsample2x or not hip.wide_conv_supported(C1 + C2, 0, conv.out_channels, k):

@@ -74,7 +74,7 @@ def main():
     from sige_amd.nn.dense import fused_conv2d
 
     hip.lib()
-    dense.WIDE_MIN_FLOP = 0.0  # (time the dense-layer kernel on every layer, also below the routing threshold)
+    dense.WIDE_MIN_FLOP = {1: 0.0, 3: 0.0}  # (time the dense-layer kernel on every layer, also below the routing threshold)
     dev = "cuda"
     rows = []
     for name, k, c1, c2, cout, res, aff, resid in LAYERS:
