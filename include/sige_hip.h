@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SIGE_HIP_VERSION 301 /* 0.3.0: round 3 -- dense-layer convs on the fp16 matrix cores (fp16 / split-fp16 operands) */
+#define SIGE_HIP_VERSION 302 /* 0.3.0: round 3 -- dense-layer convs on the fp16 matrix cores (fp16 / split-fp16 operands) */
 
 enum {
     SIGE_HIP_OK = 0,
@@ -480,6 +480,53 @@ int sige_hip_attention_f32(const float *qkv, int B, int C, int HW, float scale, 
 /* channels-last form: qkv [B,HW,3C] -> out [B,HW,C]; C % 64 == 0 */
 int sige_hip_attention_nhwc_f32(const float *qkv, int B, int C, int HW, float scale, float *workspace,
                                 float *out, void *stream);
+
+/* ---- split fp16 operands ("_f16x3"): fp32-level results from the fp16 matrix cores -------------------
+ * The same entry points once more: every fp32 operand (staged activation after the cached affine + SiLU, weight) is
+ * carried as an fp16 pair hi = fp16(v), lo = fp16(v - hi); hi*hi + lo*hi + hi*lo accumulate in fp32 (22-bit operands;
+ * the dropped lo*lo term is 2^-22 relative).  Results are inside the fp32 path's 1e-3 (measured ~1e-6 relative against an
+ * fp64 conv) at a third of the fp16 matrix rate = 5.3x the f32-input rate.  sige_hip_block_conv_pack_f16x3 scales the
+ * weights by a power of two chosen on the device (max |w| * 2^S in [2^13, 2^14): lo parts stay normal fp16 numbers) and
+ * stores 2^-S behind the packed data; no host synchronisation.  Geometries and arguments as the _f16c functions.  */
+size_t sige_hip_block_conv_packed_size_f16x3(int Cout, int Cin, int kH, int kW, int R, int S,
+                                            int strideH, int strideW, int groups);
+int sige_hip_block_conv_pack_f16x3(const float *w, int Cout, int Cin, int kH, int kW,
+                                  float *packed, void *stream);
+int sige_hip_block_conv_nhwc_f16x3(const float *x, int T, int Cin, int R, int S,
+                                  const float *packed, const float *bias, int Cout, int kH, int kW,
+                                  int strideH, int strideW, float *out, void *stream);
+int sige_hip_gather_conv_nhwc_f16x3(const float *x, const float *x2, int B, int C1, int C2, int H, int W,
+                                   int bH, int bW, const int32_t *active_indices, int N,
+                                   const float *scale, int scaleB, int scaleC,
+                                   const float *shift, int shiftB, int shiftC,
+                                   int activation,
+                                   const float *packed, const float *bias, int Cout, int kH, int kW,
+                                   int strideH, int strideW,
+                                   int to_full, int offsetH, int offsetW, const float *residual, int Ho, int Wo,
+                                   float *workspace, size_t workspace_floats,
+                                   const float *out_scale, const float *out_shift, int out_activation,
+                                   int upsample2x,
+                                   float *twin0, const float *twin0_scale, const float *twin0_shift,
+                                   float *twin1, const float *twin1_scale, const float *twin1_shift,
+                                   float *out, void *stream);
+int sige_hip_scatter_gather_conv_nhwc_f16x3(const float *x, const float *y, int B, int Cin, int H, int W,
+                                           int Rx, int Sx, int bH, int bW,
+                                           const int32_t *active_indices, int N, const int32_t *scatter_map,
+                                           const float *scale, int scaleB, int scaleC,
+                                           const float *shift, int shiftB, int shiftC,
+                                           int activation,
+                                           const float *packed, const float *bias, int Cout, int kH, int kW,
+                                           int strideH, int strideW, float *out, void *stream);
+int sige_hip_scatter_gather_conv_scatter_nhwc_f16x3(
+        const float *x, const float *y, int B, int Cin, int H, int W, int Rx, int Sx, int bH, int bW,
+        const int32_t *active_indices, int N, const int32_t *scatter_map,
+        const float *scale, int scaleB, int scaleC, const float *shift, int shiftB, int shiftC, int activation,
+        const float *packed, const float *bias, int Cout, int kH, int kW,
+        int offsetH, int offsetW, const float *residual,
+        const float *x1, const int32_t *table1, int gH1, int gW1, int N1, int R1, int S1,
+        float *twin0, const float *twin0_scale, const float *twin0_shift,
+        float *twin1, const float *twin1_scale, const float *twin1_shift,
+        float *out, void *stream);
 
 /* ---- dense layers on the fp16 matrix cores ("wide" conv: 8x8 pixels x 64 output channels per workgroup) -------
  * The layers a SIGE network runs DENSELY -- below `sparse_resolution_threshold` in the sparse pass

@@ -59,11 +59,65 @@ __global__ void pack_weights_h_kernel(const float *__restrict__ w, int Cout, int
     }
 }
 
+// split fp16 packing for ConvGeoX: two planes per k-step,
+//   packed[ng][chunk][wave][u][plane][kq][j][e],  plane 0 = hi = fp16(v), plane 1 = lo = fp16(v - hi),  v = w * 2^S
+// S is chosen ON THE DEVICE so that max |w| * 2^S lies in [2^13, 2^14) (the lo parts of all but the tiniest weights are then
+// normal fp16 numbers): wmax_bits_kernel reduces max |w| into header[0], every pack thread derives S from it, thread 0
+// writes header[1] = 2^-S, which the conv kernel multiplies back in (ConvArgs::wscale_ptr).  No host synchronisation.
+__global__ void wmax_bits_kernel(const float *__restrict__ w, long n, unsigned *__restrict__ header) {
+    float m = 0.0f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = fabsf(w[i]);
+        m = (v == v && v <= 3.0e38f) ? fmaxf(m, v) : m;  // (NaN / inf do not steer the scale)
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(header, __float_as_uint(m));  // (non-negative floats order like their bit patterns)
+}
+
+__device__ __forceinline__ int x3_shift(unsigned wmax_bits) {
+    const int e = (int)((wmax_bits >> 23) & 0xff);  // biased exponent of max |w|: max |w| in [2^(e-127), 2^(e-126))
+    if (e == 0) return 0;                             // all-zero (or subnormal) weights
+    const int s = 13 - (e - 127);
+    return s < -40 ? -40 : (s > 40 ? 40 : s);
+}
+
+template <int KK, int MT>
+__global__ void pack_weights_x_kernel(const float *__restrict__ w, int Cout, int Cin, _Float16 *__restrict__ packed, long total,
+                                      float *__restrict__ header) {
+    using G = ConvGeoH<(KK == 1 ? 1 : 3), 1, (KK == 1 ? 4 : 6), MT>;
+    const int nchunks = ((Cin + G::CC - 1) / G::CC + 1) & ~1;
+    const int S = x3_shift(__float_as_uint(header[0]));
+    const float wmul = ldexpf(1.0f, S);
+    if (blockIdx.x == 0 && threadIdx.x == 0) header[1] = ldexpf(1.0f, -S);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i;
+        const int e = r % 8; r /= 8;
+        const int j = r % MT; r /= MT;
+        const int kq = r % G::NL; r /= G::NL;
+        const int pl = r % 2; r /= 2;
+        const int u = r % G::L; r /= G::L;
+        const int wave = r % 4; r /= 4;
+        const int chunk = r % nchunks; r /= nchunks;
+        const int ng = (int)r;
+        const int slab = u / KK, tap = u % KK;
+        const int ci = chunk * G::CC + wave * G::CW + slab * G::SLAB + 8 * kq + e;
+        const int co = MT * ng + j;
+        float v = (ci < Cin && co < Cout) ? w[((size_t)co * Cin + ci) * KK + tap] * wmul : 0.0f;
+        v = fminf(fmaxf(v, -65504.0f), 65504.0f);
+        const _Float16 hi = (_Float16)v;
+        packed[i] = pl == 0 ? hi : (_Float16)(v - (float)hi);
+    }
+}
+
 // size of the packed f16 weights of one tile shape, in 4-byte units (the Python side allocates fp32 storage)
 static size_t packed_units_h(int Cout, int Cin, int KK, int MT) {
     const int NL = 64 / MT, CW = (KK == 1 ? 2 : 1) * NL * 8, CC = 4 * CW, L = (KK == 1 ? 2 : 1) * KK;
     return (size_t)ceil_div(Cout, MT) * ((ceil_div(Cin, CC) + 1) & ~1) * 4 * L * 64 * 4;
 }
+
+// split fp16: two planes; the two tile shapes are followed by a 16-unit header (max |w| bits, 2^-S)
+static size_t packed_units_x(int Cout, int Cin, int KK, int MT) { return 2 * packed_units_h(Cout, Cin, KK, MT); }
+constexpr size_t kX3Header = 16;
 
 static size_t packed_floats(int Cout, int Cin, int KK, int MT) {
     const int NL = 64 / MT, CW = (KK == 1 ? 16 : 4) * NL, CC = 4 * CW, F = (CW / NL) * KK / 4;
@@ -155,6 +209,15 @@ SIGE_CONV_DECLARE(H11_32, 1, LAYOUT_NHWC, 4) SIGE_CONV_DECLARE(H11_32, 2, LAYOUT
 //  lane do not fit the register file; those few convs -- the U-Net's downsamplers -- stay on the fp32 matrix path)
 SIGE_CONV_DECLARE_SG_FULL(H31_16, 1, 4) SIGE_CONV_DECLARE_SG_FULL(H31_16, 2, 4)
 SIGE_CONV_DECLARE_SG_FULL(H31_32, 1, 4) SIGE_CONV_DECLARE_SG_FULL(H31_32, 2, 4)
+
+// split-fp16-operand forms (ConvGeoX; channels-last, 4 waves, NB = 1): conv_k*_nhwc_x.hip
+using X31_16 = ConvGeoX<3, 1, 6, 16>;
+using X31_32 = ConvGeoX<3, 1, 6, 32>;
+using X11_16 = ConvGeoX<1, 1, 4, 16>;
+using X11_32 = ConvGeoX<1, 1, 4, 32>;
+SIGE_CONV_DECLARE(X31_16, 1, LAYOUT_NHWC, 4) SIGE_CONV_DECLARE(X31_32, 1, LAYOUT_NHWC, 4)
+SIGE_CONV_DECLARE(X11_16, 1, LAYOUT_NHWC, 4) SIGE_CONV_DECLARE(X11_32, 1, LAYOUT_NHWC, 4)
+SIGE_CONV_DECLARE_SG_FULL(X31_16, 1, 4) SIGE_CONV_DECLARE_SG_FULL(X31_32, 1, 4)
 
 // ---- cross-workgroup K split: deterministic second pass ------------------------
 // out[i] = sum_s ws[s][i] + bias[channel(i)] + residual[i]   (channels-last: channel = i mod C)
@@ -285,6 +348,12 @@ SIGE_PAIR_DECLARE(DST_TILES, 4) SIGE_PAIR_DECLARE(DST_TILES, 8) SIGE_PAIR_DECLAR
     template <> void launch_conv_pair<H31_32, 2, H11_16, DST, 4>(ConvArgs, ConvArgs, int, hipStream_t);       \
     template <> void launch_conv_pair<H31_32, 2, H11_32, DST, 4>(ConvArgs, ConvArgs, int, hipStream_t);
 SIGE_PAIR_DECLARE_H(DST_TILES) SIGE_PAIR_DECLARE_H(DST_NCHW)
+#define SIGE_PAIR_DECLARE_X(DST)                                                                         \
+    template <> void launch_conv_pair<X31_16, 1, X11_16, DST, 4>(ConvArgs, ConvArgs, int, hipStream_t);       \
+    template <> void launch_conv_pair<X31_16, 1, X11_32, DST, 4>(ConvArgs, ConvArgs, int, hipStream_t);       \
+    template <> void launch_conv_pair<X31_32, 1, X11_16, DST, 4>(ConvArgs, ConvArgs, int, hipStream_t);       \
+    template <> void launch_conv_pair<X31_32, 1, X11_32, DST, 4>(ConvArgs, ConvArgs, int, hipStream_t);
+SIGE_PAIR_DECLARE_X(DST_TILES) SIGE_PAIR_DECLARE_X(DST_NCHW)
 
 // Tickets of the in-kernel K-split finish (conv_mfma.hpp): one int per output block of a split launch, zero whenever no
 // such launch is running.  One buffer per device: a ring for eager launches (a slice is only live while its launch runs;
@@ -328,13 +397,17 @@ int32_t *split_tickets(hipStream_t st, long blocks) {
 
 struct ConvPlan { int mt, nb, waves; };
 
+// PREC: 0 exact fp32 (ConvGeo) | 1 fp16 operands (ConvGeoH) | 2 split fp16 operands (ConvGeoX)
+template <int PREC, int KH, int STR, int R, int MT>
+using GeoOf = std::conditional_t<PREC == 2, ConvGeoX<KH, STR, R, MT>, std::conditional_t<PREC == 1, ConvGeoH<KH, STR, R, MT>, ConvGeo<KH, STR, R, MT>>>;
+
 // Everything a launch decides on the host: output block, waves, grid order, K split.  `want_waves` != 0 / `nb1`: the
 // constraints of the second conv of a pair (same workgroup size as the first, NB = 1, no K split: cap = 1).
 template <int KH, int STR, int R, int SRC, int LAY, int PREC>
 static int plan_conv(ConvArgs &a, int cap, int want_waves, bool nb1, ConvPlan &p) {
-    using G32 = std::conditional_t<PREC == 1, ConvGeoH<KH, STR, R, 32>, ConvGeo<KH, STR, R, 32>>;
-    using G16 = std::conditional_t<PREC == 1, ConvGeoH<KH, STR, R, 16>, ConvGeo<KH, STR, R, 16>>;
-    const bool kHasNB2 = STR == 1 && !nb1;
+    using G32 = GeoOf<PREC, KH, STR, R, 32>;
+    using G16 = GeoOf<PREC, KH, STR, R, 16>;
+    const bool kHasNB2 = STR == 1 && !nb1 && PREC != 2;  // (split operands: the (hi, lo) weight registers of two sub-blocks do not fit)
     auto blocks = [&](int tpb, int mt, int nb) { return (long)ceil_div(a.T, tpb) * ceil_div(a.Cout, mt * nb); };
     // constraints of the staging path (conv_mfma.hpp): a fused torch.cat must split on a chunk
     // boundary; a per-batch affine needs every M block inside one batch
@@ -387,7 +460,8 @@ static int plan_conv(ConvArgs &a, int cap, int want_waves, bool nb1, ConvPlan &p
     //  to give every XCD whole ones)
     a.ng_fast = wbytes > abytes ? 1 : ((a.mbk >= 16 && a.ngk > 1) ? 2 : 0);
     if (mt == 16)  // the MT=16 layout follows the MT=32 one
-        a.packed += PREC == 1 ? packed_units_h(a.Cout, a.Cin, KH * KH, 32) : packed_floats(a.Cout, a.Cin, KH * KH, 32);
+        a.packed += PREC == 2 ? packed_units_x(a.Cout, a.Cin, KH * KH, 32)
+                              : (PREC == 1 ? packed_units_h(a.Cout, a.Cin, KH * KH, 32) : packed_floats(a.Cout, a.Cin, KH * KH, 32));
     // K split (channels-last launches that came with a workspace)
     a.ksplit = ksplit_for((long)a.mbk * a.ngk, a.nchunks, cap);
     a.chunks_per_split = ceil_div(a.nchunks, a.ksplit);
@@ -402,10 +476,10 @@ static int plan_conv(ConvArgs &a, int cap, int want_waves, bool nb1, ConvPlan &p
 // conv A (planned: pa) + the held 1x1 conv in one launch; false: no pair kernel for this combination
 template <int DST, int PREC>
 static bool launch_pair(const ConvArgs &a, const ConvPlan &pa, int mode_a, ConvArgs b, hipStream_t st) {
-    using A16 = std::conditional_t<PREC == 1, H31_16, K31_16>;
-    using A32 = std::conditional_t<PREC == 1, H31_32, K31_32>;
-    using B16 = std::conditional_t<PREC == 1, H11_16, K11_16>;
-    using B32 = std::conditional_t<PREC == 1, H11_32, K11_32>;
+    using A16 = GeoOf<PREC, 3, 1, 6, 16>;
+    using A32 = GeoOf<PREC, 3, 1, 6, 32>;
+    using B16 = GeoOf<PREC, 1, 1, 4, 16>;
+    using B32 = GeoOf<PREC, 1, 1, 4, 32>;
     ConvPlan pb;
     if (plan_conv<1, 1, 4, SRC_GATHER, LAYOUT_NHWC, PREC>(b, 1, pa.waves, true, pb) != SIGE_HIP_OK) return false;
 #define SIGE_PAIR_GO(GA, NBA, W)                                                                         \
@@ -422,9 +496,12 @@ static bool launch_pair(const ConvArgs &a, const ConvPlan &pa, int mode_a, ConvA
     } while (0)
     if constexpr (PREC == 0) {
         if (pa.waves == 8) SIGE_PAIR_W(8); else SIGE_PAIR_W(4);
-    } else {
+    } else if constexpr (PREC == 1) {
         if (pa.waves != 4) return false;
         SIGE_PAIR_W(4);
+    } else {
+        if (pa.waves != 4 || pa.nb != 1) return false;
+        if (pa.mt == 32) SIGE_PAIR_GO(A32, 1, 4); else SIGE_PAIR_GO(A16, 1, 4);
     }
 #undef SIGE_PAIR_W
 #undef SIGE_PAIR_GO
@@ -434,9 +511,11 @@ static bool launch_pair(const ConvArgs &a, const ConvPlan &pa, int mode_a, ConvA
 
 template <int KH, int STR, int R, int SRC, int DST, int LAY, int PREC = 0>
 static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
-    using G32 = std::conditional_t<PREC == 1, ConvGeoH<KH, STR, R, 32>, ConvGeo<KH, STR, R, 32>>;
-    using G16 = std::conditional_t<PREC == 1, ConvGeoH<KH, STR, R, 16>, ConvGeo<KH, STR, R, 16>>;
-    constexpr bool kHasNB2 = STR == 1;
+    using G32 = GeoOf<PREC, KH, STR, R, 32>;
+    using G16 = GeoOf<PREC, KH, STR, R, 16>;
+    constexpr bool kHasNB2 = STR == 1 && PREC != 2;
+    if constexpr (PREC == 2)  // 2^-S sits in the header behind the two packed tile shapes (pack_weights_x_kernel)
+        a.wscale_ptr = a.packed + packed_units_x(a.Cout, a.Cin, KH * KH, 32) + packed_units_x(a.Cout, a.Cin, KH * KH, 16) + 1;
     constexpr bool kPairLayout = SRC == SRC_GATHER && LAY == LAYOUT_NHWC && STR == 1;
     constexpr bool kPairFirst = kPairLayout && KH == 3, kPairSecond = kPairLayout && KH == 1;
     const bool may_pair = kPairFirst && g_held.active && (mode == MODE_AFFINE_SWISH || mode == MODE_RAW) && g_held.st == st && g_held.dst == DST && g_held.prec == PREC;
@@ -520,7 +599,7 @@ static int launch_conv(const ConvArgs &a, int mode, int kH, int kW, int R, int S
         case 1: rc = launch_kind<3, 1, 6, SRC, DST, LAY, PREC>(a, mode, st); break;
         case 2: rc = launch_kind<1, 1, 4, SRC, DST, LAY, PREC>(a, mode, st); break;
         case 3:
-            if constexpr (PREC == 1) return SIGE_HIP_EUNSUPPORTED;  // (see the f16-compute declarations above)
+            if constexpr (PREC != 0) return SIGE_HIP_EUNSUPPORTED;  // (see the f16-compute declarations above)
             else rc = launch_kind<3, 2, 5, SRC, DST, LAY, PREC>(a, mode, st);
             break;
         default: return SIGE_HIP_EUNSUPPORTED;
@@ -635,6 +714,38 @@ extern "C" int sige_hip_block_conv_pack_f16c(const float *w, int Cout, int Cin, 
         pack_weights_h_kernel<1, 16><<<blocks(n16), 256, 0, st>>>(w, Cout, Cin, ph + n32, n16);
     }
     return launch_status(2);
+}
+
+extern "C" size_t sige_hip_block_conv_packed_size_f16x3(int Cout, int Cin, int kH, int kW, int R, int S,
+                                                        int strideH, int strideW, int groups) {
+    if (Cout <= 0 || Cin <= 0) return 0;
+    const int kind = mfma_kind(kH, kW, R, S, strideH, strideW, groups);
+    if (kind != 1 && kind != 2) return 0;  // stride-1 3x3 on 6x6 and 1x1 on 4x4 (the stride-2 geometry stays fp32)
+    return packed_units_x(Cout, Cin, kH * kW, 32) + packed_units_x(Cout, Cin, kH * kW, 16) + kX3Header;
+}
+
+extern "C" int sige_hip_block_conv_pack_f16x3(const float *w, int Cout, int Cin, int kH, int kW,
+                                              float *packed, void *stream) {
+    if (!w || !packed || Cout <= 0 || Cin <= 0) return SIGE_HIP_EINVAL;
+    if (kH != kW || (kH != 1 && kH != 3)) return SIGE_HIP_EUNSUPPORTED;
+    const int KK = kH * kW;
+    hipStream_t st = as_stream(stream);
+    const size_t u32 = packed_units_x(Cout, Cin, KK, 32), u16 = packed_units_x(Cout, Cin, KK, 16);
+    const long n32 = 2 * (long)u32, n16 = 2 * (long)u16;  // halves
+    float *header = packed + u32 + u16;
+    if (hipMemsetAsync(header, 0, kX3Header * sizeof(float), st) != hipSuccess) return SIGE_HIP_ELAUNCH;
+    const long nw = (long)Cout * Cin * KK;
+    wmax_bits_kernel<<<(int)((nw + 255) / 256 < 1024 ? (nw + 255) / 256 : 1024), 256, 0, st>>>(w, nw, reinterpret_cast<unsigned *>(header));
+    auto blocks = [](long n) { return (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096); };
+    _Float16 *ph = reinterpret_cast<_Float16 *>(packed);
+    if (KK == 9) {
+        pack_weights_x_kernel<9, 32><<<blocks(n32), 256, 0, st>>>(w, Cout, Cin, ph, n32, header);
+        pack_weights_x_kernel<9, 16><<<blocks(n16), 256, 0, st>>>(w, Cout, Cin, ph + n32, n16, header);
+    } else {
+        pack_weights_x_kernel<1, 32><<<blocks(n32), 256, 0, st>>>(w, Cout, Cin, ph, n32, header);
+        pack_weights_x_kernel<1, 16><<<blocks(n16), 256, 0, st>>>(w, Cout, Cin, ph + n32, n16, header);
+    }
+    return launch_status(3);
 }
 
 extern "C" int sige_hip_block_conv_f32(const float *x, int T, int Cin, int R, int S,
@@ -789,6 +900,12 @@ extern "C" int sige_hip_block_conv_nhwc_f16c(const float *x, int T, int Cin, int
     return block_conv_nhwc_impl<1>(x, T, Cin, R, S, packed, bias, Cout, kH, kW, strideH, strideW, out, stream);
 }
 
+extern "C" int sige_hip_block_conv_nhwc_f16x3(const float *x, int T, int Cin, int R, int S,
+                                              const float *packed, const float *bias, int Cout, int kH, int kW,
+                                              int strideH, int strideW, float *out, void *stream) {
+    return block_conv_nhwc_impl<2>(x, T, Cin, R, S, packed, bias, Cout, kH, kW, strideH, strideW, out, stream);
+}
+
 template <int PREC>
 static int gather_conv_nhwc_impl(const float *x, const float *x2, int B, int C1, int C2, int H, int W,
                                              int bH, int bW, const int32_t *active_indices, int N,
@@ -886,6 +1003,22 @@ extern "C" int sige_hip_gather_conv_nhwc_f16c(const float *x, const float *x2, i
                                              float *out, void *stream) {
     return gather_conv_nhwc_impl<1>(SIGE_GATHER_CONV_ARGS);
 }
+extern "C" int sige_hip_gather_conv_nhwc_f16x3(const float *x, const float *x2, int B, int C1, int C2, int H, int W,
+                                             int bH, int bW, const int32_t *active_indices, int N,
+                                             const float *scale, int scaleB, int scaleC,
+                                             const float *shift, int shiftB, int shiftC,
+                                             int activation,
+                                             const float *packed, const float *bias, int Cout, int kH, int kW,
+                                             int strideH, int strideW,
+                                             int to_full, int offsetH, int offsetW, const float *residual, int Ho, int Wo,
+                                             float *workspace, size_t workspace_floats,
+                                             const float *out_scale, const float *out_shift, int out_activation,
+                                             int upsample2x,
+                                             float *twin0, const float *twin0_scale, const float *twin0_shift,
+                                             float *twin1, const float *twin1_scale, const float *twin1_shift,
+                                             float *out, void *stream) {
+    return gather_conv_nhwc_impl<2>(SIGE_GATHER_CONV_ARGS);
+}
 
 template <int PREC>
 static int scatter_gather_conv_nhwc_impl(const float *x, const float *y, int B, int Cin, int H, int W,
@@ -933,6 +1066,16 @@ extern "C" int sige_hip_scatter_gather_conv_nhwc_f16c(const float *x, const floa
                                                      const float *packed, const float *bias, int Cout, int kH, int kW,
                                                      int strideH, int strideW, float *out, void *stream) {
     return scatter_gather_conv_nhwc_impl<1>(SIGE_SG_CONV_ARGS);
+}
+extern "C" int sige_hip_scatter_gather_conv_nhwc_f16x3(const float *x, const float *y, int B, int Cin, int H, int W,
+                                                     int Rx, int Sx, int bH, int bW,
+                                                     const int32_t *active_indices, int N, const int32_t *scatter_map,
+                                                     const float *scale, int scaleB, int scaleC,
+                                                     const float *shift, int shiftB, int shiftC,
+                                                     int activation,
+                                                     const float *packed, const float *bias, int Cout, int kH, int kW,
+                                                     int strideH, int strideW, float *out, void *stream) {
+    return scatter_gather_conv_nhwc_impl<2>(SIGE_SG_CONV_ARGS);
 }
 
 // scatter_gather -> conv -> Scatter / ScatterWithBlockResidual in ONE launch: the conv's output tiles go straight
@@ -1003,6 +1146,18 @@ extern "C" int sige_hip_scatter_gather_conv_scatter_nhwc_f16c(
         float *twin1, const float *twin1_scale, const float *twin1_shift,
         float *out, void *stream) {
     return scatter_gather_conv_scatter_nhwc_impl<1>(SIGE_SGS_CONV_ARGS);
+}
+extern "C" int sige_hip_scatter_gather_conv_scatter_nhwc_f16x3(
+        const float *x, const float *y, int B, int Cin, int H, int W, int Rx, int Sx, int bH, int bW,
+        const int32_t *active_indices, int N, const int32_t *scatter_map,
+        const float *scale, int scaleB, int scaleC, const float *shift, int shiftB, int shiftC, int activation,
+        const float *packed, const float *bias, int Cout, int kH, int kW,
+        int offsetH, int offsetW, const float *residual,
+        const float *x1, const int32_t *table1, int gH1, int gW1, int N1, int R1, int S1,
+        float *twin0, const float *twin0_scale, const float *twin0_shift,
+        float *twin1, const float *twin1_scale, const float *twin1_shift,
+        float *out, void *stream) {
+    return scatter_gather_conv_scatter_nhwc_impl<2>(SIGE_SGS_CONV_ARGS);
 }
 
 extern "C" int sige_hip_block_conv_direct_f32(const float *x, int T, int Cin, int R, int S,

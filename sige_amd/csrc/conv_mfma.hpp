@@ -84,7 +84,7 @@ template <> struct MfmaH<16> {
 
 template <int KH, int STR, int R_, int MT_>
 struct ConvGeo {
-    static constexpr bool F16 = false;
+    static constexpr bool F16 = false, X3 = false;
     static constexpr int K = KH, S = STR, R = R_, MT = MT_;
     static constexpr int KK = KH * KH;
     static constexpr int RS = R_ * R_;
@@ -109,7 +109,7 @@ struct ConvGeo {
 // an A operand is 8 consecutive channels of a pixel = one ds_read_b128 of the channels-last stage.
 template <int KH, int STR, int R_, int MT_>
 struct ConvGeoH {
-    static constexpr bool F16 = true;
+    static constexpr bool F16 = true, X3 = false;
     static constexpr int K = KH, S = STR, R = R_, MT = MT_;
     static constexpr int KK = KH * KH;
     static constexpr int RS = R_ * R_;
@@ -128,6 +128,17 @@ struct ConvGeoH {
     static constexpr int BUF = TPB * TILE_FLOATS;
     static constexpr int RED = MT_ + 4;
     static_assert(MT_ % PX == 0 && TPB >= 1, "tile pixels must divide the M block");
+};
+
+// The same on SPLIT fp16 operands ("f16x3", round 3): every fp32 value -- staged activation or weight -- is carried as an fp16
+// pair hi = fp16(v), lo = fp16(v - hi); the three products hi*hi + lo*hi + hi*lo accumulate in fp32 (22-bit operands, the
+// dropped lo*lo term is 2^-22 relative): fp32-level results at a third of the fp16 matrix rate = 5.3x the f32-input rate.
+// The LDS stage holds two planes per pixel row ([hi CC halves][lo CC halves]), the packed weights two 16-byte registers per
+// k-step (hi, lo), pre-scaled by a power of two so that their lo parts are normal fp16 numbers (ConvArgs::wscale_ptr).
+template <int KH, int STR, int R_, int MT_>
+struct ConvGeoX : ConvGeoH<KH, STR, R_, MT_> {
+    static constexpr bool X3 = true;
+    static constexpr int F = 2 * ConvGeoH<KH, STR, R_, MT_>::L;  // 16-byte weight loads per lane per chunk: (hi, lo) per k-step
 };
 
 __host__ __device__ constexpr int cmax(int a, int b) { return a > b ? a : b; }
@@ -191,6 +202,8 @@ struct ConvArgs {
     // affine + SiLU applied once by the producer instead of once per output-channel block by the consumer's staging path)
     float *twin0, *twin1;
     const float *tscale0, *tshift0, *tscale1, *tshift1;
+    // split fp16 operands (ConvGeoX): the packed weights are w * 2^S; *wscale_ptr = 2^-S (written by the pack kernels)
+    const float *wscale_ptr;
 #ifdef SIGE_CONV_PROBE
     unsigned long long *probe;  // tools/conv_phase_probe.py build only: 8 timestamps per workgroup
 #endif
@@ -301,7 +314,7 @@ template <typename G, int NB, int MODE, int LAYOUT, int W>
 __host__ __device__ constexpr int conv_lds_floats() {
     constexpr int CCk = W * G::CW;
     constexpr bool NHWC = LAYOUT == LAYOUT_NHWC;
-    constexpr int LDC = G::F16 ? CCk + 8 : CCk + 4;
+    constexpr int LDC = G::F16 ? (G::X3 ? 2 * CCk + 8 : CCk + 8) : CCk + 4;
     constexpr int STAGE = NHWC ? (G::F16 ? G::TPB * G::RS * LDC / 2 : G::TPB * G::RS * LDC) : G::TPB * CCk * G::RS;
     constexpr int TABF = MODE != MODE_RAW ? 2 * (CCk + 4) : 0;
     return cmax(2 * STAGE + 2 * TABF, W * NB * G::MT * (G::MT + 4));
@@ -328,7 +341,8 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
     constexpr bool AFF = MODE != MODE_RAW;
     // LDS stage of one channel chunk: NCHW [tile][channel][R][S]; NHWC [tile][R][S][LDC] (LDC = CC + 4 pad)
     //   (f16 compute: the stage holds HALVES, row = CC + 8 halves; STAGE stays in floats)
-    constexpr int LDC = F16 ? CCk + 8 : CCk + 4;
+    constexpr bool X3 = G::X3;                   // split fp16 operands (ConvGeoX): two planes in LDS, (hi, lo) weight registers
+    constexpr int LDC = F16 ? (X3 ? 2 * CCk + 8 : CCk + 8) : CCk + 4;
     constexpr int STAGE = NHWC ? (F16 ? G::TPB * G::RS * LDC / 2 : G::TPB * G::RS * LDC) : BUFk;
     constexpr int TROW = CCk + 4;                            // table row: CC channels + 4 zeros
     constexpr int TABF = AFF ? 2 * TROW : 0;                   // scale row | shift row
@@ -438,6 +452,8 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
     // (K split with a second launch: partial sums only, bias / residual in the second pass; with in-kernel finish any
     //  workgroup may turn out to be the one that runs the epilogue)
     const bool e_first_pass = a.ksplit <= 1 || a.counters != nullptr;
+    float wsc = 1.0f;  // split fp16 operands: the weights were packed as w * 2^S, the sums come out times 2^S
+    if constexpr (X3) wsc = *a.wscale_ptr;
 
     if constexpr (NHWC) {
         // Channels-last: the slot set-up in load-batched, branch-free form.  Written slot by slot (index load ->
@@ -700,6 +716,11 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
             if constexpr (F16) {
                 const f16x4 h = {(_Float16)q.x, (_Float16)q.y, (_Float16)q.z, (_Float16)q.w};  // RNE
                 *reinterpret_cast<f16x4 *>(reinterpret_cast<_Float16 *>(buf) + s_dst[i]) = h;
+                if constexpr (X3) {  // the lo plane of the same pixel row: what fp16 rounding dropped (exact in fp32, then RNE)
+                    const f16x4 l = {(_Float16)(q.x - (float)h[0]), (_Float16)(q.y - (float)h[1]),
+                                     (_Float16)(q.z - (float)h[2]), (_Float16)(q.w - (float)h[3])};
+                    *reinterpret_cast<f16x4 *>(reinterpret_cast<_Float16 *>(buf) + s_dst[i] + CCk) = l;
+                }
             } else {
                 *reinterpret_cast<float4 *>(buf + s_dst[i]) = q;
             }
@@ -777,16 +798,28 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
         if constexpr (F16) {
             // one 16-byte A operand (8 channels of the lane's pixel at one tap) and one 16-byte B register per k-step
             const _Float16 *ah = reinterpret_cast<const _Float16 *>(smem + PAR * STAGE) + a_base;
-            f16x8 avh[G::L];
+            f16x8 avh[G::L], avl[X3 ? G::L : 1];
 #pragma unroll
-            for (int u = 0; u < G::L; ++u) avh[u] = *reinterpret_cast<const f16x8 *>(ah + a_off(u));
+            for (int u = 0; u < G::L; ++u) {
+                avh[u] = *reinterpret_cast<const f16x8 *>(ah + a_off(u));
+                if constexpr (X3) avl[u] = *reinterpret_cast<const f16x8 *>(ah + a_off(u) + CCk);
+            }
             static_for<0, G::L>([&](auto u_tag) {
                 constexpr int u = decltype(u_tag)::value;
                 static_for<0, NB>([&](auto nb_tag) {
                     constexpr int nb = decltype(nb_tag)::value;
-                    const float4 bq = bset[PAR][nb][u];
-                    const f32x4 braw = {bq.x, bq.y, bq.z, bq.w};
-                    acc[nb][u % NACC] = M::op(avh[u], __builtin_bit_cast(f16x8, braw), acc[nb][u % NACC]);
+                    if constexpr (X3) {
+                        // hi*hi and hi*lo on one accumulator, lo*hi on the other: consecutive MFMAs alternate accumulators
+                        const float4 bq = bset[PAR][nb][2 * u], bl = bset[PAR][nb][2 * u + 1];
+                        const f32x4 bhr = {bq.x, bq.y, bq.z, bq.w}, blr = {bl.x, bl.y, bl.z, bl.w};
+                        acc[nb][u % NACC] = M::op(avh[u], __builtin_bit_cast(f16x8, bhr), acc[nb][u % NACC]);
+                        acc[nb][(u + 1) % NACC] = M::op(avl[u], __builtin_bit_cast(f16x8, bhr), acc[nb][(u + 1) % NACC]);
+                        acc[nb][u % NACC] = M::op(avh[u], __builtin_bit_cast(f16x8, blr), acc[nb][u % NACC]);
+                    } else {
+                        const float4 bq = bset[PAR][nb][u];
+                        const f32x4 braw = {bq.x, bq.y, bq.z, bq.w};
+                        acc[nb][u % NACC] = M::op(avh[u], __builtin_bit_cast(f16x8, braw), acc[nb][u % NACC]);
+                    }
                 });
                 static_for<(u * NS) / G::L, ((u + 1) * NS) / G::L>([&](auto i_tag) {
                     constexpr int i = decltype(i_tag)::value;
@@ -795,7 +828,12 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
                 });
                 static_for<0, NB>([&](auto nb_tag) {
                     constexpr int nb = decltype(nb_tag)::value;
-                    b_load(bset[PAR][nb][u], nb, u);
+                    if constexpr (X3) {
+                        b_load(bset[PAR][nb][2 * u], nb, 2 * u);
+                        b_load(bset[PAR][nb][2 * u + 1], nb, 2 * u + 1);
+                    } else {
+                        b_load(bset[PAR][nb][u], nb, u);
+                    }
                 });
             });
             tab_store(tab + PAR * TABF);
@@ -970,6 +1008,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
                 const float4 v = *reinterpret_cast<const float4 *>(r0 + w * NB * G::MT * RP);
                 s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             }
+            if constexpr (X3) { s.x *= wsc; s.y *= wsc; s.z *= wsc; s.w *= wsc; }  // (a power of two: exact; K-split partials are stored scaled back)
             if (!split_k) emit(k_tag, u, s, a.out);
             else if (!a.counters) *reinterpret_cast<float4 *>(outp + u.addr) = s;
             else coherent_store(outp + u.addr, s);

@@ -124,6 +124,20 @@ _SIGNATURES = {
     "sige_hip_conv3x3_small_cin_nhwc_f32": (
         _c_int, [_c_vp] + [ctypes.c_int64] * 4 + [_c_int] * 4 + [_c_vp, _c_vp, _c_int, _c_vp, _c_vp]),
     "sige_hip_attention_nhwc_f32": (_c_int, [_c_vp, _c_int, _c_int, _c_int, ctypes.c_float, _c_vp, _c_vp, _c_vp]),
+    # split fp16 operands (tile kernels)
+    "sige_hip_block_conv_packed_size_f16x3": (_c_sz, [_c_int] * 9),
+    "sige_hip_block_conv_pack_f16x3": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp]),
+    "sige_hip_block_conv_nhwc_f16x3": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp, _c_vp]),
+    "sige_hip_gather_conv_nhwc_f16x3": (
+        _c_int, [_c_vp, _c_vp] + [_c_int] * 7 + [_c_vp, _c_int] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
+        + [_c_int] * 5 + [_c_int, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_vp, _c_sz, _c_vp, _c_vp, _c_int, _c_int] + [_c_vp] * 6
+        + [_c_vp, _c_vp]),
+    "sige_hip_scatter_gather_conv_nhwc_f16x3": (
+        _c_int, [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
+        + [_c_int] * 5 + [_c_vp, _c_vp]),
+    "sige_hip_scatter_gather_conv_scatter_nhwc_f16x3": (
+        _c_int, [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
+        + [_c_int] * 3 + [_c_int, _c_int, _c_vp] + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp] * 6 + [_c_vp, _c_vp]),
     # dense layers on the fp16 matrix cores (conv_wide)
     "sige_hip_wide_conv_supported": (_c_int, [_c_int] * 5),
     "sige_hip_wide_conv_packed_size": (_c_sz, [_c_int] * 5),
@@ -500,11 +514,15 @@ def conv_pack_weights(weight: torch.Tensor, R: int, S: int, stride: Tuple[int, i
     the returned tensor's `.compute` tells which."""
     w = _req(weight.detach(), torch.float32, "weight")
     Cout, Cin, kH, kW = w.shape
-    if compute not in ("f32", "f16"):
-        raise ValueError("compute must be 'f32' or 'f16'")
+    if compute not in ("f32", "f16", "f16x3"):
+        raise ValueError("compute must be 'f32', 'f16' or 'f16x3'")
     n = 0
     if compute == "f16":
         n = int(lib().sige_hip_block_conv_packed_size_f16c(Cout, Cin, kH, kW, R, S, stride[0], stride[1], 1))
+        if n == 0:
+            compute = "f32"
+    if compute == "f16x3":  # split fp16 operands: fp32-level results on the fp16 matrix cores
+        n = int(lib().sige_hip_block_conv_packed_size_f16x3(Cout, Cin, kH, kW, R, S, stride[0], stride[1], 1))
         if n == 0:
             compute = "f32"
     if compute == "f32":
@@ -513,14 +531,15 @@ def conv_pack_weights(weight: torch.Tensor, R: int, S: int, stride: Tuple[int, i
         return None
     packed = torch.empty((n,), dtype=torch.float32, device=w.device).as_subclass(PackedWeights)
     packed.compute = compute
-    fn = lib().sige_hip_block_conv_pack_f16c if compute == "f16" else lib().sige_hip_block_conv_pack_f32
+    fn = {"f16": lib().sige_hip_block_conv_pack_f16c, "f16x3": lib().sige_hip_block_conv_pack_f16x3,
+          "f32": lib().sige_hip_block_conv_pack_f32}[compute]
     _check(fn(w.data_ptr(), Cout, Cin, kH, kW, packed.data_ptr(), _stream(w)), "conv_pack_weights")
     return packed
 
 
 def _conv_fn(name: str, packed):
-    """The fp32 or the f16-compute entry point, according to how `packed` was laid out."""
-    return getattr(lib(), name + ("_f16c" if getattr(packed, "compute", "f32") == "f16" else "_f32"))
+    """The fp32, the f16-compute or the split-fp16 entry point, according to how `packed` was laid out."""
+    return getattr(lib(), name + {"f16": "_f16c", "f16x3": "_f16x3"}.get(getattr(packed, "compute", "f32"), "_f32"))
 
 
 # ---- dense layers on the fp16 matrix cores (csrc/conv_wide.hpp) ----

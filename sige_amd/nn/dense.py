@@ -29,10 +29,9 @@ _GEOMETRY = {
 
 
 def _tile_compute(compute: str) -> str:
-    """Arithmetic of the TILE kernels (conv_mfma.hpp) for a conv whose compute dtype is `compute`: they have exact-fp32 and
-    fp16-operand forms; "f16x3" (fp32-level results from split fp16 operands) exists in the dense-layer kernel only, so a
-    conv that asks for it runs exact fp32 there."""
-    return "f16" if compute == "f16" else "f32"
+    """Arithmetic of the TILE kernels (conv_mfma.hpp) for a conv whose compute dtype is `compute`: exact fp32, fp16 operands,
+    or split fp16 operands (geometries without such a kernel -- stride 2 -- are packed for exact fp32 by conv_pack_weights)."""
+    return compute if compute in ("f16", "f16x3") else "f32"
 
 
 # Dense layers below this many flop stay on the tile kernels (conv_mfma.hpp), by kernel size.  Measured per layer on MI355X

@@ -447,3 +447,76 @@ def test_scatter_gather_window_form_bit_exact(hip, aligned, act, first, aff):
     finally:
         hip.gather_force_rows(False)
     assert torch.equal(got, again)
+
+
+# ---- split fp16 operands in the TILE kernels (ConvGeoX) -------------------------------------------------------------------------
+@pytest.mark.parametrize("k,cin,cout,T,mt", [(3, 128, 128, 124, 0), (3, 256, 128, 40, 16), (3, 64, 256, 7, 32), (3, 192, 64, 33, 16),
+                                              (1, 256, 128, 56, 0), (1, 128, 256, 9, 32), (1, 384, 128, 30, 16), (3, 36, 64, 5, 0)])
+@pytest.mark.parametrize("wmag", [1.0, 1e-4])
+def test_f16x3_tile_conv_is_fp32_level(hip, k, cin, cout, T, mt, wmag):
+    """The stacked-block conv on split fp16 operands against an fp64 conv of the EXACT operands: max |d| <= 2e-5 * (1 + max |ref|)
+    -- also with weights of 1e-4 (the device-side power-of-two pre-scaling keeps their lo parts normal fp16 numbers)."""
+    torch.manual_seed(T + cin)
+    R = 6 if k == 3 else 4
+    x = _cl(torch.randn(T, cin, R, R, device=DEV))
+    w = torch.randn(cout, cin, k, k, device=DEV) / (k * cin ** 0.5) * wmag
+    b = torch.randn(cout, device=DEV) * wmag
+    packed = hip.conv_pack_weights(w, R, R, (1, 1), "f16x3")
+    assert packed.compute == "f16x3"
+    hip.conv_force_tile(mt, 1 if mt else 0)
+    try:
+        got = hip.block_conv_cl(x, packed, b, cout, (k, k), (1, 1))
+    finally:
+        hip.conv_force_tile(0, 0)
+    want = F.conv2d(x.double(), w.double(), b.double())
+    err = float((got.double() - want).abs().max())
+    assert err <= 2e-5 * (wmag + float(want.abs().max())), (err, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("act", ["swish", "identity"])
+def test_f16x3_fused_gather_scatter_gather_and_pair(hip, act):
+    """The fused forms (gather -> conv to tiles / into a full tensor with residual and epilogue affine, scatter_gather -> conv ->
+    scatter with block residual, shortcut + conv1 in one launch) on split fp16 operands equal the exact-fp32 kernels to 5e-5."""
+    from sige_amd.utils import reduce_mask
+
+    torch.manual_seed(3)
+    C, Co, H = 128, 128, 64
+    mask = torch.zeros(H, H, dtype=torch.bool, device=DEV)
+    mask[10:40, 20:50] = True
+    mask[0, 0] = True
+    idx = reduce_mask(mask, (6, 6), (4, 4), (1, 1))
+    idx4 = reduce_mask(mask, (4, 4), (4, 4), (0, 0))
+    x, y = _cl(torch.randn(1, C, H, H, device=DEV)), _cl(torch.randn(1, C, H, H, device=DEV))
+    w, b = torch.randn(Co, C, 3, 3, device=DEV) / 34, torch.randn(Co, device=DEV)
+    w1, b1 = torch.randn(Co, C, 1, 1, device=DEV) / 11, torch.randn(Co, device=DEV)
+    sc_, sh_ = (torch.randn(1, C, 1, 1, device=DEV), torch.randn(1, C, 1, 1, device=DEV)) if act == "swish" else (None, None)
+    oa = (torch.randn(Co, device=DEV), torch.randn(Co, device=DEV), "swish")
+    smap = hip.get_scatter_map(H, H, 6, 6, 3, 3, 1, 1, 1, 1, idx)
+    t4 = _cl(torch.randn(idx.shape[0], C, 4, 4, device=DEV))
+    res = _cl(torch.randn(1, Co, H, H, device=DEV))
+    full = dict(offset=(1, 1), out_res=(H, H), residual=res)
+
+    def run(compute):
+        p3, p1 = hip.conv_pack_weights(w, 6, 6, (1, 1), compute), hip.conv_pack_weights(w1, 4, 4, (1, 1), compute)
+        out = {}
+        out["tiles"] = hip.gather_conv_cl(x, None, (6, 6), idx, sc_, sh_, act, p3, b, Co, (3, 3), (1, 1), out_affine=oa)
+        out["full"] = hip.gather_conv_cl(x, None, (6, 6), hip.all_tiles(H, H, (4, 4), (1, 1), (1, 1), DEV), sc_, sh_, act, p3, b, Co,
+                                         (3, 3), (1, 1), full=full)
+        out["sg"] = hip.scatter_gather_conv_cl(t4, y, (6, 6), idx, smap, sc_, sh_, act, p3, b, Co, (3, 3), (1, 1))
+        o = y.clone(memory_format=torch.preserve_format)
+        hip.scatter_gather_conv_scatter_cl(t4, y, (6, 6), idx, smap, sc_, sh_, act, p3, b, Co, (3, 3), (1, 1), o, residual=res)
+        out["sgs"] = o
+        n0 = hip.conv_pairs_fused()
+        with hip.conv_pair(x):
+            out["short"] = hip.gather_conv_cl(x, None, (4, 4), idx4, None, None, "identity", p1, b1, Co, (1, 1), (1, 1))
+            out["conv1"] = hip.gather_conv_cl(x, None, (6, 6), idx, sc_ if sc_ is not None else torch.ones(1, C, 1, 1, device=DEV),
+                                              sh_ if sh_ is not None else torch.zeros(1, C, 1, 1, device=DEV), "swish", p3, b, Co,
+                                              (3, 3), (1, 1), out_affine=oa)
+        out["paired"] = hip.conv_pairs_fused() - n0
+        return out
+
+    a, bx = run("f32"), run("f16x3")
+    assert bx["paired"] == a["paired"] == 1
+    for key in ("tiles", "full", "sg", "sgs", "short", "conv1"):
+        d = float((a[key] - bx[key]).abs().max())
+        assert d <= 5e-5 * (1.0 + float(a[key].abs().max())), (key, d)
