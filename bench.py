@@ -1122,9 +1122,9 @@ def main():
         f16 = None
         gpu_out_f16 = {}
         if rank == 0 and world == 1 and args.dtype == "f32" and args.f16_sweep and args.layout == "nhwc":
-            model.set_compute_dtype("f16")
             rows = []
             for r in [float(v) for v in args.f16_sweep.split(",")]:
+                model.set_compute_dtype("f16", edit_ratio=r)  # (the model's precision policy depends on the edited area)
                 xs = prepare(r)
                 model(xs, t)
                 tracer.log = []
@@ -1136,9 +1136,10 @@ def main():
                 ms = timed_replays(gs, k, 5, 1) * 1e3 / k
                 gpu_out_f16[r] = outs.float().cpu()
                 rows.append({"edit_ratio": r, "forward_ms": round(ms, 3), "speedup_vs_dense_fp32": round(dense_ms / ms, 2),
-                             "block_conv_TFLOPs": round(conv_tf_r, 2)})
+                             "block_conv_TFLOPs": round(conv_tf_r, 2), "kept_at_higher_precision": list(model.compute_policy["keep"])})
                 del tr16
                 del gs, outs
+            model.set_compute_dtype("f16", edit_ratio=args.ratio)
             xs = prepare(args.ratio)
             model(xs, t)
             tracer.log = []
@@ -1152,10 +1153,12 @@ def main():
             del gs, outs, tr
             f16 = {"what": "convs with fp16 operands (v_mfma_f32_32x32x16_f16 / 16x16x32_f16), fp32 accumulation; activations, "
                            "caches and every other kernel fp32; GroupNorm affine + SiLU fused in fp32 before the down-convert; "
-                           "the convs named in `keep_higher_precision` (the model's F16_KEEP, from the per-layer error trace "
-                           "profiles/r3a_f16_error_trace.json) run split fp16 operands (f16x3: fp32-level) where the dense-layer "
-                           "kernel applies and exact fp32 elsewhere (tile convs, the 4 stride-2 downsample convs)",
-                   "keep_higher_precision": list(model.compute_policy["keep"]),
+                           "for edits above the model's F16_KEEP_ABOVE (5 % of the image) the convs named in F16_KEEP (from the "
+                           "per-layer error trace profiles/r3a_f16_error_trace.json; `kept_at_higher_precision` per sweep row) run "
+                           "split fp16 operands (f16x3: fp32-level) or, below 2 GFLOP per launch, exact fp32; the 4 stride-2 "
+                           "downsample convs are always exact fp32",
+                   "keep_higher_precision_above_edit_ratio": getattr(model, "F16_KEEP_ABOVE", None),
+                   "keep_higher_precision": list(getattr(model, "F16_KEEP", ())),
                    "forward_ms": round(ms16, 4), "edit_ratio": args.ratio, "speedup_vs_dense_fp32": round(dense_ms / ms16, 2),
                    "speedup_vs_f32_sparse": round(ms_steady / ms16, 2), "sweep": rows, "kernels": kern16,
                    "block_conv_tflops": round(conv_tf16, 2),

@@ -290,6 +290,7 @@ __global__ __launch_bounds__(kGatherThreads) void scatter_gather_window_kernel(G
     __shared__ int s_org[kSgGroup][3];                      // h0, w0, b
     __shared__ int u_w[MAXU], u_col[MAXU], u_len[MAXU], u_b[MAXU], u_h0[MAXU];
     __shared__ int s_col0[kSgGroup], s_nu;
+    __shared__ int t_kind[MAXU * TR], t_off[MAXU * TR];
     const int tiles = a.B * a.N;
     const int tile0 = blockIdx.x * kSgGroup;
     const int gcount = min(kSgGroup, tiles - tile0);
@@ -325,43 +326,61 @@ __global__ __launch_bounds__(kGatherThreads) void scatter_gather_window_kernel(G
     const size_t HW = (size_t)a.H * a.W;
     const bool plain = ACT == SIGE_HIP_ACT_IDENTITY && !a.scale.data && !a.shift.data;
     const int nu = s_nu;
-    // ---- fill the window: item = (unit, channel, row), row fastest ----
+    // ---- source of every (unit, row), resolved ONCE through the scatter map (not once per channel) ----
+    //   kind 0 zero fill | 1 conv-1 block row (t_off = element offset of channel 0 in x) | 2 cache row (t_off = h * W + w)
+    //   | 3 pixel by pixel through the map (a segment that is not one block's row, or that leaves the image)
+    for (int e = threadIdx.x; e < nu * TR; e += kGatherThreads) {
+        const int u = e / TR, r = e - u * TR;
+        const int h = u_h0[u] + r, w = u_w[u], len = u_len[u];
+        int kind = 0, off = 0;
+        if (h >= 0 && h < a.H) {
+            kind = 3;
+            if (w >= 0 && w + len <= a.W) {
+                const int32_t *m0 = a.map + 3 * ((size_t)h * a.W + w);
+                const int b0 = m0[0];
+                bool same = true, none = b0 < 0;
+                for (int i = 1; i < len; ++i) {
+                    same = same && m0[3 * i] == b0 && m0[3 * i + 1] == m0[1] && m0[3 * i + 2] == m0[2] + i;
+                    none = none && m0[3 * i] < 0;
+                }
+                if (b0 >= 0 && same) { kind = 1; off = b0 * a.C * a.RxSx + m0[1] * a.Sx + m0[2]; }
+                else if (none) { kind = 2; off = h * a.W + w; }
+            } else if (w + len <= 0 || w >= a.W) {
+                kind = 0;
+            }
+        }
+        t_kind[e] = kind;
+        t_off[e] = off;
+    }
+    __syncthreads();
+    // ---- fill the window: item = (unit, channel, row), row fastest (rows 1..4 of a block: one 64-byte request) ----
     for (int it = threadIdx.x; it < nu * cc * TR; it += kGatherThreads) {
         const int r = it % TR, cl = (it / TR) % cc, u = it / (TR * cc);
         const int c = c0 + cl, b = u_b[u], h = u_h0[u] + r, w = u_w[u], len = u_len[u];
+        const int kind = t_kind[u * TR + r], off = t_off[u * TR + r];
         float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (h >= 0 && h < a.H) {
+        if (kind == 1 || kind == 2) {
+            const float *src = kind == 1 ? a.x + (size_t)b * a.N * a.C * a.RxSx + (size_t)c * a.RxSx + off
+                                         : a.y + ((size_t)b * a.C + c) * HW + off;
+            if (len == 4) {
+                const f4u q = *reinterpret_cast<const f4u *>(src);
+                v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+            } else {
+                v[0] = src[0];
+            }
+            if (!plain) {
+                for (int i = 0; i < len; ++i) v[i] = affine_act<ACT, ACT_FIRST>(v[i], a.scale, a.shift, b, c, h, w + i);
+            }
+        } else if (kind == 3) {
             const float *yrow = a.y + ((size_t)b * a.C + c) * HW + (size_t)h * a.W;
             const float *xb = a.x + (size_t)b * a.N * a.C * a.RxSx;
-            bool done = false;
-            if (len == 4 && w >= 0 && w + 3 < a.W) {
-                const int32_t *m0 = a.map + 3 * ((size_t)h * a.W + w);
-                const int b0 = m0[0], b1 = m0[3], b2 = m0[6], b3 = m0[9];
-                if (b0 >= 0 && b1 == b0 && b2 == b0 && b3 == b0 && m0[10] == m0[1] && m0[11] == m0[2] + 3) {
-                    // four consecutive pixels of one block's row: 16 bytes
-                    const float *src = xb + ((size_t)b0 * a.C + c) * a.RxSx + m0[1] * a.Sx + m0[2];
-                    const f4u q = *reinterpret_cast<const f4u *>(src);
-                    v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
-                    done = true;
-                } else if (b0 < 0 && b1 < 0 && b2 < 0 && b3 < 0) {
-                    const f4u q = *reinterpret_cast<const f4u *>(yrow + w);
-                    v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
-                    done = true;
-                }
-                if (done && !plain) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = affine_act<ACT, ACT_FIRST>(v[i], a.scale, a.shift, b, c, h, w + i);
-                }
-            }
-            if (!done) {
-                for (int i = 0; i < len; ++i) {
-                    const int ww = w + i;
-                    if (ww < 0 || ww >= a.W) continue;
-                    const int32_t *m = a.map + 3 * ((size_t)h * a.W + ww);
-                    const int blk = m[0];
-                    const float z = blk >= 0 ? xb[((size_t)blk * a.C + c) * a.RxSx + m[1] * a.Sx + m[2]] : yrow[ww];
-                    v[i] = plain ? z : affine_act<ACT, ACT_FIRST>(z, a.scale, a.shift, b, c, h, ww);
-                }
+            for (int i = 0; i < len; ++i) {
+                const int ww = w + i;
+                if (ww < 0 || ww >= a.W) continue;
+                const int32_t *m = a.map + 3 * ((size_t)h * a.W + ww);
+                const int blk = m[0];
+                const float z = blk >= 0 ? xb[((size_t)blk * a.C + c) * a.RxSx + m[1] * a.Sx + m[2]] : yrow[ww];
+                v[i] = plain ? z : affine_act<ACT, ACT_FIRST>(z, a.scale, a.shift, b, c, h, ww);
             }
         }
         float *d = &win[cl][r][u_col[u]];

@@ -138,9 +138,16 @@ class SIGEConv2d(nn.Conv2d, SIGEModule):
         and the consumer is a channels-last kernel."""
         from .. import hip
 
-        from .dense import _tile_compute
+        from .dense import TILE_X3_MIN_FLOP, _tile_compute
 
         compute = _tile_compute(self.compute_dtype) if channels_last else "f32"
+        if compute == "f16x3":
+            # split operands pay off where the launch is matrix-bound; a handful of tiles is start-up-bound and the exact
+            # fp32 kernel (two output-channel sub-blocks per workgroup, half the LDS stores) is as fast or faster
+            ro, so = (x.shape[2] - self.kernel_size[0]) // self.stride[0] + 1, (x.shape[3] - self.kernel_size[1]) // self.stride[1] + 1
+            flop = 2.0 * x.shape[0] * ro * so * self.out_channels * self.in_channels * self.kernel_size[0] * self.kernel_size[1]
+            if flop < TILE_X3_MIN_FLOP:
+                compute = "f32"
         w = self.weight
         key = (w.data_ptr(), w._version, tuple(w.shape), x.shape[2], x.shape[3], w.device)
         entry = self._packed.get(compute)
@@ -289,7 +296,7 @@ class SIGEModel(nn.Module):
         for module in self._sige_modules():
             module.set_sparse_update(sparse_update)
 
-    def set_compute_dtype(self, dtype: str, keep=None):
+    def set_compute_dtype(self, dtype: str, keep=None, edit_ratio: Optional[float] = None):
         """MI355X-first option (not in the reference, which is fp32-only: sige/nn/base.py:15,55-63).
 
         "f32" (default): exact fp32 products (v_mfma_f32_*_f32).
@@ -301,11 +308,16 @@ class SIGEModel(nn.Module):
                convs, which have no such kernel, run exact fp32.
 
         `keep`: module-name prefixes of convs that stay at the higher precision when dtype is "f16" -- they run "f16x3".
-        None = the model's own default (`F16_KEEP`, from its per-layer error trace: tests/f16_error_trace.py); () = none."""
+        None = the model's own default (`F16_KEEP`, from its per-layer error trace: tests/f16_error_trace.py) -- applied only
+        when `edit_ratio` (the fraction of the image the mask covers, if the caller knows it) is above the model's
+        `F16_KEEP_ABOVE`: the fp16 rounding errors the trace attributes to those layers grow with the edited area, and small
+        edits meet the criterion with every conv in plain fp16.  () = none."""
         if dtype not in ("f32", "f16", "f16x3"):
             raise ValueError("compute dtype must be 'f32', 'f16' or 'f16x3'")
         if keep is None:
-            keep = tuple(getattr(self, "F16_KEEP", ())) if dtype == "f16" else ()
+            keep = ()
+            if dtype == "f16" and (edit_ratio is None or edit_ratio > getattr(self, "F16_KEEP_ABOVE", 0.0)):
+                keep = tuple(getattr(self, "F16_KEEP", ()))
         keep = tuple(keep)
 
         def kept(name):

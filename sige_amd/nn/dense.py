@@ -40,6 +40,11 @@ def _tile_compute(compute: str) -> str:
 # 16.6 vs 22.0; 3.6: 24.3 vs 51.4; the 19 GFLOP layers of the full pass: 73 vs 282), the 1x1 convs of the sparse pass
 # (<= 0.4 GFLOP: two k-steps per chunk, the launch is its start-up) are not (12.9 vs 7.5 us).
 WIDE_MIN_FLOP = {3: 0.25e9, 1: 2.0e9}
+# Tile convs (conv_mfma.hpp) asked for split fp16 operands run them only above this many flop per launch; below, exact fp32.
+# Measured (profiles/r3c_bench.json, DDPM-256 sparse forward, every tile conv on split operands against exact fp32): 1.2 %
+# edit (0.4 GFLOP per launch) 555 vs 521 us over the 48 launches, 5 % 2.01 vs 1.92 ms per forward, 15 % (3.9 GFLOP) 2.47 vs
+# 2.55 ms: the three-MFMA form wins once a launch is matrix-bound.
+TILE_X3_MIN_FLOP = 2.0e9
 
 
 def _wide_packed(conv: nn.Conv2d, compute: str):
@@ -116,6 +121,8 @@ def _packed(conv: nn.Conv2d, block, channels_last: bool = True):
 
     w = conv.weight
     compute = _tile_compute(getattr(conv, "compute_dtype", "f32")) if channels_last else "f32"  # (SIGEModel.set_compute_dtype)
+    if compute == "f16x3":
+        compute = "f32"  # (a dense layer too small for the wide kernel is below TILE_X3_MIN_FLOP as well)
     key = (w.data_ptr(), w._version, tuple(w.shape), block, w.device, compute)
     if getattr(conv, "_sige_packed_key", None) != key:
         conv._sige_packed = hip.conv_pack_weights(w, block[0], block[1], conv.stride, compute)

@@ -261,8 +261,8 @@ def test_f16_policy_ddpm_forward_whole_sweep(hip, ddpm_reference, ddpm_gpu, rati
         model.set_compute_dtype("f32")
         model.set_mode("full")
         model(cl(ref["x0"]), torch.zeros(1, device=DEV))  # the original's cache: the fp32 full pass
-        model.set_compute_dtype("f16")
-        assert model.compute_policy["keep"] == model.F16_KEEP
+        model.set_compute_dtype("f16", edit_ratio=ratio)
+        assert model.compute_policy["keep"] == (model.F16_KEEP if ratio > model.F16_KEEP_ABOVE else ())
         out = _gpu_sparse(model, ref, ratio)
         model.set_compute_dtype("f32")
     chk = tolerance.f16_check(out, ref["sparse"][ratio])
