@@ -266,145 +266,6 @@ __global__ __launch_bounds__(kGatherThreads) void gather_rows_grouped_kernel(Gat
 }
 
 
-// ---- scatter_gather, grouped window form (round 3) -------------------------------------------------------------------
-// The mapped form of gather_kernel reads element by element through the scatter map: 36 four-byte loads per (tile,
-// channel), every one its own address -- 0.26 of the HBM peak at the bandwidth-bound size (100 MB, 47 us).  What a 6x6
-// tile of ScatterGather reads is, for index lists from reduce_mask, ALIGNED: conv-1 output tiles are 4x4 blocks on the
-// 4-pixel grid, so rows 1..4 of the inner 4 columns are the tile's own block (64 contiguous bytes per channel), the row
-// above / below is one 16-byte row of the vertical neighbour's block (or of the cache), and only the two halo columns
-// are single pixels.  One workgroup takes kSgGroup consecutive tiles x 32 channels and builds their window in LDS out of
-// "units" -- a 4-pixel aligned segment (ONE 16-byte load from the block or from the cache row) or a single halo pixel;
-// when the tiles are a horizontal run (consecutive list entries 4 pixels apart: the usual case, lists are row-major
-// sorted) their windows overlap and the run shares one window of 4 G + 2 columns: 7.5 loads per (tile, channel) instead
-// of 36.  Lanes run row-fastest inside a (unit, channel), so rows 1..4 of a block are one 64-byte request.  The tiles then
-// leave as contiguous [C-chunk][6][6] slabs with 16-byte stores.  A segment whose four map entries are not one block's
-// row (an index list that is not on the 4-pixel grid) is read pixel by pixel: any list gives the reference's values.
-constexpr int kSgGroup = 8, kSgCh = 32;
-
-template <int TR, int TS, int ACT, bool ACT_FIRST>
-__global__ __launch_bounds__(kGatherThreads) void scatter_gather_window_kernel(GatherArgs a) {
-    static_assert(TR == 6 && TS == 6, "the window form is written for 6x6 tiles over 4x4 blocks");
-    constexpr int WC = TS * kSgGroup;                       // window columns (unmerged: one 6-wide window per tile)
-    constexpr int MAXU = 3 * kSgGroup;                      // units per window row
-    __shared__ float win[kSgCh][TR][WC + 1];
-    __shared__ int s_org[kSgGroup][3];                      // h0, w0, b
-    __shared__ int u_w[MAXU], u_col[MAXU], u_len[MAXU], u_b[MAXU], u_h0[MAXU];
-    __shared__ int s_col0[kSgGroup], s_nu;
-    __shared__ int t_kind[MAXU * TR], t_off[MAXU * TR];
-    const int tiles = a.B * a.N;
-    const int tile0 = blockIdx.x * kSgGroup;
-    const int gcount = min(kSgGroup, tiles - tile0);
-    const int c0 = blockIdx.y * kSgCh;
-    const int cc = min(kSgCh, a.C - c0);
-    if (threadIdx.x < kSgGroup) {
-        const int t = min(tile0 + (int)threadIdx.x, tiles - 1);
-        const int n = t % a.N;
-        s_org[threadIdx.x][0] = a.idx[2 * n];
-        s_org[threadIdx.x][1] = a.idx[2 * n + 1];
-        s_org[threadIdx.x][2] = t / a.N;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        bool run = true;
-        for (int g = 1; g < gcount; ++g)
-            run = run && s_org[g][0] == s_org[0][0] && s_org[g][2] == s_org[0][2] && s_org[g][1] == s_org[g - 1][1] + 4;
-        int nu = 0;
-        auto add = [&](int g, int w, int col, int len) { u_w[nu] = w; u_col[nu] = col; u_len[nu] = len; u_b[nu] = s_org[g][2]; u_h0[nu] = s_org[g][0]; ++nu; };
-        if (run) {
-            add(0, s_org[0][1], 0, 1);
-            for (int g = 0; g < gcount; ++g) { add(g, s_org[g][1] + 1, 1 + 4 * g, 4); s_col0[g] = 4 * g; }
-            add(gcount - 1, s_org[gcount - 1][1] + 5, 1 + 4 * gcount, 1);
-        } else {
-            for (int g = 0; g < gcount; ++g) {
-                add(g, s_org[g][1], 6 * g, 1); add(g, s_org[g][1] + 1, 6 * g + 1, 4); add(g, s_org[g][1] + 5, 6 * g + 5, 1);
-                s_col0[g] = 6 * g;
-            }
-        }
-        s_nu = nu;
-    }
-    __syncthreads();
-    const size_t HW = (size_t)a.H * a.W;
-    const bool plain = ACT == SIGE_HIP_ACT_IDENTITY && !a.scale.data && !a.shift.data;
-    const int nu = s_nu;
-    // ---- source of every (unit, row), resolved ONCE through the scatter map (not once per channel) ----
-    //   kind 0 zero fill | 1 conv-1 block row (t_off = element offset of channel 0 in x) | 2 cache row (t_off = h * W + w)
-    //   | 3 pixel by pixel through the map (a segment that is not one block's row, or that leaves the image)
-    for (int e = threadIdx.x; e < nu * TR; e += kGatherThreads) {
-        const int u = e / TR, r = e - u * TR;
-        const int h = u_h0[u] + r, w = u_w[u], len = u_len[u];
-        int kind = 0, off = 0;
-        if (h >= 0 && h < a.H) {
-            kind = 3;
-            if (w >= 0 && w + len <= a.W) {
-                const int32_t *m0 = a.map + 3 * ((size_t)h * a.W + w);
-                const int b0 = m0[0];
-                bool same = true, none = b0 < 0;
-                for (int i = 1; i < len; ++i) {
-                    same = same && m0[3 * i] == b0 && m0[3 * i + 1] == m0[1] && m0[3 * i + 2] == m0[2] + i;
-                    none = none && m0[3 * i] < 0;
-                }
-                if (b0 >= 0 && same) { kind = 1; off = b0 * a.C * a.RxSx + m0[1] * a.Sx + m0[2]; }
-                else if (none) { kind = 2; off = h * a.W + w; }
-            } else if (w + len <= 0 || w >= a.W) {
-                kind = 0;
-            }
-        }
-        t_kind[e] = kind;
-        t_off[e] = off;
-    }
-    __syncthreads();
-    // ---- fill the window: item = (unit, channel, row), row fastest (rows 1..4 of a block: one 64-byte request) ----
-    for (int it = threadIdx.x; it < nu * cc * TR; it += kGatherThreads) {
-        const int r = it % TR, cl = (it / TR) % cc, u = it / (TR * cc);
-        const int c = c0 + cl, b = u_b[u], h = u_h0[u] + r, w = u_w[u], len = u_len[u];
-        const int kind = t_kind[u * TR + r], off = t_off[u * TR + r];
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (kind == 1 || kind == 2) {
-            const float *src = kind == 1 ? a.x + (size_t)b * a.N * a.C * a.RxSx + (size_t)c * a.RxSx + off
-                                         : a.y + ((size_t)b * a.C + c) * HW + off;
-            if (len == 4) {
-                const f4u q = *reinterpret_cast<const f4u *>(src);
-                v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
-            } else {
-                v[0] = src[0];
-            }
-            if (!plain) {
-                for (int i = 0; i < len; ++i) v[i] = affine_act<ACT, ACT_FIRST>(v[i], a.scale, a.shift, b, c, h, w + i);
-            }
-        } else if (kind == 3) {
-            const float *yrow = a.y + ((size_t)b * a.C + c) * HW + (size_t)h * a.W;
-            const float *xb = a.x + (size_t)b * a.N * a.C * a.RxSx;
-            for (int i = 0; i < len; ++i) {
-                const int ww = w + i;
-                if (ww < 0 || ww >= a.W) continue;
-                const int32_t *m = a.map + 3 * ((size_t)h * a.W + ww);
-                const int blk = m[0];
-                const float z = blk >= 0 ? xb[((size_t)blk * a.C + c) * a.RxSx + m[1] * a.Sx + m[2]] : yrow[ww];
-                v[i] = plain ? z : affine_act<ACT, ACT_FIRST>(z, a.scale, a.shift, b, c, h, ww);
-            }
-        }
-        float *d = &win[cl][r][u_col[u]];
-        for (int i = 0; i < len; ++i) d[i] = v[i];
-    }
-    __syncthreads();
-    // ---- every tile's slab [cc][6][6]: contiguous in HBM, 16-byte pieces ----
-    const int slab = cc * TR * TS;
-    const int q4 = slab / 4;  // (36 floats per channel: a multiple of 4)
-    for (int it = threadIdx.x; it < gcount * q4; it += kGatherThreads) {
-        const int g = it / q4, i4 = it - g * q4;
-        const int col0 = s_col0[g];
-        float v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int e = 4 * i4 + k;
-            const int cl = e / (TR * TS), p = e - cl * (TR * TS);
-            v[k] = win[cl][p / TS][col0 + p % TS];
-        }
-        float *ob = a.out + ((size_t)(tile0 + g) * a.C + c0) * (TR * TS);
-        *reinterpret_cast<f4u *>(ob + 4 * i4) = f4u{v[0], v[1], v[2], v[3]};
-    }
-}
-
 template <int TR, int TS>
 static void launch_rows(const GatherArgs &a, int act, bool first, dim3 grid, hipStream_t st) {
     dim3 blk(kGatherThreads);
@@ -471,18 +332,6 @@ static int launch(GatherArgs a, int act, bool first, hipStream_t st) {
         if (a.bH == 6) launch_rows<6, 6>(a, act, first, rgrid, st);
         else if (a.bH == 5) launch_rows<5, 5>(a, act, first, rgrid, st);
         else launch_rows<4, 4>(a, act, first, rgrid, st);
-        return launch_status();
-    }
-    if (MAPPED && a.bH == 6 && a.bW == 6 && a.RxSx == 16 && a.Sx == 4 && g_gather_grouped &&
-        (long)ceil_div(tiles, kSgGroup) * ceil_div(a.C, kSgCh) >= 512) {
-        // scatter_gather of 6x6 tiles over 4x4 conv-1 blocks, enough tiles to fill the chip in groups: the window form
-        dim3 blk(kGatherThreads), wgrid(ceil_div(tiles, kSgGroup), ceil_div(a.C, kSgCh));
-        if (act == SIGE_HIP_ACT_SWISH) {
-            if (first) scatter_gather_window_kernel<6, 6, SIGE_HIP_ACT_SWISH, true><<<wgrid, blk, 0, st>>>(a);
-            else scatter_gather_window_kernel<6, 6, SIGE_HIP_ACT_SWISH, false><<<wgrid, blk, 0, st>>>(a);
-        } else {
-            scatter_gather_window_kernel<6, 6, SIGE_HIP_ACT_IDENTITY, false><<<wgrid, blk, 0, st>>>(a);
-        }
         return launch_status();
     }
     const bool vec4 = ((long)a.C * RS) % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;

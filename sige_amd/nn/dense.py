@@ -34,12 +34,16 @@ def _tile_compute(compute: str) -> str:
     return compute if compute in ("f16", "f16x3") else "f32"
 
 
-# Dense layers below this many flop stay on the tile kernels (conv_mfma.hpp), by kernel size.  Measured per layer on MI355X
-# (tools/wide_bench.py, profiles/r3b_wide_bench.jsonl; split fp16 operands vs the exact-fp32 tile kernel): every 3x3 dense
-# layer of the DDPM-256 U-Net is at least as fast on the 64 x 64 blocks of conv_wide.hpp (0.3 GFLOP: 15.8 vs 15.5 us; 1.2:
-# 16.6 vs 22.0; 3.6: 24.3 vs 51.4; the 19 GFLOP layers of the full pass: 73 vs 282), the 1x1 convs of the sparse pass
-# (<= 0.4 GFLOP: two k-steps per chunk, the launch is its start-up) are not (12.9 vs 7.5 us).
-WIDE_MIN_FLOP = {3: 0.25e9, 1: 2.0e9}
+# Which dense layers take the dense-layer kernel (conv_wide.hpp) instead of the tile kernels with every tile active: those of at
+# least this many flop, by kernel size -- in practice the convs of the FULL pass (4.8 ... 39 GFLOP each at 64^2 ... 256^2).
+# Measured on MI355X, round 3:
+#   * layer by layer with cold weights (tools/wide_bench.py, profiles/r3b_wide_bench.jsonl) the 64 x 64 blocks win on every 3x3
+#     dense layer (3.6 GFLOP: 24 vs 51 us; 19 GFLOP: 73 vs 282 us) and lose on the 1x1s (two k-steps per chunk);
+#   * inside the sparse forward they do not (tools/routing_bench.py, profiles/r3d_routing.jsonl): the tile kernels run a
+#     residual block's 1x1 shortcut INSIDE the conv1 launch (conv_pair), the wide kernel cannot, and the ten extra launches
+#     (~8 us each) eat what the dense 3x3s gain -- 1.456 vs 1.446 ms (split operands vs exact fp32, 1.2 % edit), 1.250 vs
+#     1.034 ms with plain fp16 operands.  So the dense remainder of the sparse pass stays on the tile kernels.
+WIDE_MIN_FLOP = {3: 4.0e9, 1: 2.0e9}
 # Tile convs (conv_mfma.hpp) asked for split fp16 operands run them only above this many flop per launch; below, exact fp32.
 # Measured (profiles/r3c_bench.json, DDPM-256 sparse forward, every tile conv on split operands against exact fp32): 1.2 %
 # edit (0.4 GFLOP per launch) 555 vs 521 us over the 48 launches, 5 % 2.01 vs 1.92 ms per forward, 15 % (3.9 GFLOP) 2.47 vs

@@ -142,6 +142,7 @@ def test_benchmarked_forward_vs_oracle_at_full_size(hip, ratio):
         full_g = model(cl(x0), t.to(DEV))
         model.set_masks(downsample_mask(dilate_mask(mask.to(DEV), 5), 8))
         model.set_mode("sparse")
+        model(cl(x1), t.to(DEV))  # (registers the activated twins of the conv1 inputs; from the next forward on they are read)
         eager = model(cl(x1), t.to(DEV)).clone()
         g, out = bench.capture(model, cl(x1), t.to(DEV))
         for _ in range(3):

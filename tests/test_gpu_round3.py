@@ -400,55 +400,6 @@ def test_sd_unet_at_its_own_size_vs_cpu_oracle(hip):
     torch.testing.assert_close(sparse_g.cpu(), sparse_c, rtol=0, atol=util.CONV_ATOL)
 
 
-@pytest.mark.parametrize("aligned,act,first,aff", [(True, "identity", False, None), (True, "swish", False, "channel"),
-                                                   (True, "swish", True, "spatial"), (False, "swish", False, "channel"),
-                                                   (False, "identity", False, None)])
-def test_scatter_gather_window_form_bit_exact(hip, aligned, act, first, aff):
-    """The reference-layout (NCHW) ScatterGather in its grouped window form (gather.hip: scatter_gather_window_kernel) against
-    the oracle (sige/cpu/scatter_gather.cpp:5-84): bit-exact for identity, 1e-6 relative for SiLU -- index lists from
-    reduce_mask (aligned 4x4 blocks: 16-byte segment loads, merged windows of horizontal runs), and an arbitrary list that
-    is NOT on the 4-pixel grid (every segment falls back to pixel-by-pixel reads through the map)."""
-    from sige_amd.utils import reduce_mask
-
-    g = torch.Generator().manual_seed(11)
-    B, C, H, W = 2, 256, 128, 128
-    if aligned:
-        mask = torch.zeros(H, W, dtype=torch.bool)
-        mask[0:40, 0:70] = True          # touches the top / left border
-        mask[50:120, 60:128] = True      # touches the right border
-        mask[125:128, 3:9] = True        # bottom border
-        idx = oracle.reduce_mask(mask, 6, 4, 1)
-    else:
-        hs = torch.randint(-1, H - 4, (320,), generator=g)
-        ws = torch.randint(-1, W - 4, (320,), generator=g)
-        idx = torch.unique(torch.stack([hs, ws], 1), dim=0).to(torch.int32).contiguous()
-    N = idx.shape[0]
-    assert (B * N + 7) // 8 * (C // 32) >= 512  # the window form is the one that runs
-    smap = oracle.get_scatter_map(H, W, 6, 6, 3, 3, 1, 1, 1, 1, idx)
-    x = torch.randn(B * N, C, 4, 4, generator=g)
-    y = torch.randn(B, C, H, W, generator=g)
-    if aff == "channel":
-        sc, sh = torch.randn(B, C, 1, 1, generator=g), torch.randn(1, C, 1, 1, generator=g)
-    elif aff == "spatial":
-        sc, sh = torch.randn(1, C, H, W, generator=g), torch.randn(1, 1, H, W, generator=g)
-    else:
-        sc = sh = None
-    want = oracle.scatter_gather(x, y, 6, 6, idx, smap, sc, sh, act, first)
-    d = lambda t: None if t is None else t.to(DEV)  # noqa: E731
-    got = hip.scatter_gather(d(x), d(y), 6, 6, d(idx), d(smap), d(sc), d(sh), act, first).cpu()
-    if act == "identity":
-        assert torch.equal(got, want)
-    else:
-        torch.testing.assert_close(got, want, rtol=util.SWISH_RTOL, atol=util.SWISH_ATOL)
-    # the one-tile form gives the same bits
-    hip.gather_force_rows(True)
-    try:
-        again = hip.scatter_gather(d(x), d(y), 6, 6, d(idx), d(smap), d(sc), d(sh), act, first).cpu()
-    finally:
-        hip.gather_force_rows(False)
-    assert torch.equal(got, again)
-
-
 # ---- split fp16 operands in the TILE kernels (ConvGeoX) -------------------------------------------------------------------------
 @pytest.mark.parametrize("k,cin,cout,T,mt", [(3, 128, 128, 124, 0), (3, 256, 128, 40, 16), (3, 64, 256, 7, 32), (3, 192, 64, 33, 16),
                                               (1, 256, 128, 56, 0), (1, 128, 256, 9, 32), (1, 384, 128, 30, 16), (3, 36, 64, 5, 0)])
