@@ -176,9 +176,9 @@ def test_wide_conv_twins_and_dense_module_routing(hip):
     torch.manual_seed(5)
     conv = nn.Conv2d(768, 256, 3, 1, 1).to(DEV)
     conv.compute_dtype = "f16x3"
-    x, x2 = _cl(torch.randn(1, 512, 32, 32, device=DEV)), _cl(torch.randn(1, 256, 32, 32, device=DEV))
+    x, x2 = _cl(torch.randn(1, 512, 64, 64, device=DEV)), _cl(torch.randn(1, 256, 64, 64, device=DEV))  # (14.5 GFLOP: above WIDE_MIN_FLOP)
     s, t = torch.randn(1, 768, 1, 1, device=DEV), torch.randn(1, 768, 1, 1, device=DEV)
-    res = _cl(torch.randn(1, 256, 32, 32, device=DEV))
+    res = _cl(torch.randn(1, 256, 64, 64, device=DEV))
     tw = {"a": (torch.randn(256, device=DEV), torch.randn(256, device=DEV))}
     with torch.no_grad():
         n0 = hip.launch_count()

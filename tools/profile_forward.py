@@ -26,9 +26,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ratio", type=float, default=0.012)
     ap.add_argument("--replays", type=int, default=50)
-    ap.add_argument("--mode", default="sparse", choices=["sparse", "dense", "eager"])
+    ap.add_argument("--mode", default="sparse", choices=["sparse", "dense", "eager", "full"],
+                    help="full = the cache-producing full pass (with --dtype f16x3: on the library's dense-layer kernel)")
     ap.add_argument("--layout", default="nhwc", choices=["nhwc", "nchw"])
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f16"], help="arithmetic of the tile convs (bench.py --dtype)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "f16x3"], help="arithmetic of the convs (bench.py --dtype)")
     ap.add_argument("--manifest", default="", help="eager mode: write the kernel-family sequence of one forward's conv launches here")
     a = ap.parse_args()
     dev = torch.device("cuda")
@@ -50,6 +51,8 @@ def main():
         model.set_mode("full")
         if a.mode == "dense":
             model.set_plain_dense(True)
+        elif a.mode == "full":
+            pass
         else:
             model(x0, t)
             model.set_masks(downsample_mask(dilate_mask(mask, 5), 8))
@@ -81,6 +84,8 @@ def main():
             for _ in range(a.replays):
                 model(x1, t)
         else:
+            if a.mode == "full":
+                x1 = x0
             g, _ = bench.capture(model, x1, t)
             g.replay()
             torch.cuda.synchronize()
