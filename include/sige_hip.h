@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SIGE_HIP_VERSION 302 /* 0.3.0: round 3 -- dense-layer convs on the fp16 matrix cores (fp16 / split-fp16 operands) */
+#define SIGE_HIP_VERSION 303 /* 0.3.0: round 3 -- dense-layer convs on the fp16 matrix cores (fp16 / split-fp16 operands) */
 
 enum {
     SIGE_HIP_OK = 0,
@@ -564,6 +564,12 @@ int sige_hip_wide_conv_nhwc(const float *x, const float *x2, int B, int C1, int 
                             float *twin0, const float *twin_scale0, const float *twin_shift0,
                             float *twin1, const float *twin_scale1, const float *twin_shift1,
                             float *workspace, size_t workspace_floats, float *out, void *stream);
+
+/* out = act(scale[b,c] * x + shift[b,c]) over a channels-last tensor [B,H,W,C] (scale / shift [affineB, C], affineB 1 or B):
+ * the activated copy of a ScatterGather cache that the full pass keeps next to the cache (one pass instead of the
+ * multiply / add / SiLU / copy kernels of the torch expression; sige_amd.nn.ScatterGather.cache_activated).          */
+int sige_hip_affine_act_nhwc_f32(const float *x, int B, int C, int H, int W, const float *scale, const float *shift,
+                                 int affineB, int activation, float *out, void *stream);
 
 /* ---- plain device copy used by the cache broadcast path (packs the cached
  * activations of Scatter / ScatterGather modules into one buffer) ---------- */

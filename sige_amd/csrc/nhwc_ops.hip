@@ -513,6 +513,36 @@ extern "C" int sige_hip_scatter_with_block_residual_nhwc_f32(
     return launch_status();
 }
 
+// out = act(scale[b, c] * x + shift[b, c]) over a whole channels-last tensor: the activated copy of a ScatterGather cache
+// (sige_amd.nn.ScatterGather.cache_activated) in one streaming pass -- the full pass otherwise spends a multiply, an add, a
+// SiLU and a copy kernel on it.  Same two separately rounded ops and the same fp32 SiLU as the standalone gather.
+__global__ __launch_bounds__(kT) void affine_act_nhwc_kernel(const float *__restrict__ x, const float *__restrict__ scale,
+                                                            const float *__restrict__ shift, int aff_sb, int C, size_t hwc4,
+                                                            size_t total4, int act, float *__restrict__ out) {
+    for (size_t u = (size_t)blockIdx.x * kT + threadIdx.x; u < total4; u += (size_t)gridDim.x * kT) {
+        const size_t b = u / hwc4;
+        const int c = (int)((u * 4) % C);
+        const float4 v = ld4(x + u * 4), sc = ld4(scale + b * aff_sb + c), sh = ld4(shift + b * aff_sb + c);
+        float4 z;
+        z.x = sc.x * v.x; z.y = sc.y * v.y; z.z = sc.z * v.z; z.w = sc.w * v.w;
+        z.x = sh.x + z.x; z.y = sh.y + z.y; z.z = sh.z + z.z; z.w = sh.w + z.w;
+        if (act == SIGE_HIP_ACT_SWISH) { z.x = swish(z.x); z.y = swish(z.y); z.z = swish(z.z); z.w = swish(z.w); }
+        st4(out + u * 4, z);
+    }
+}
+
+extern "C" int sige_hip_affine_act_nhwc_f32(const float *x, int B, int C, int H, int W, const float *scale, const float *shift,
+                                            int affineB, int activation, float *out, void *stream) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !x || !scale || !shift || !out) return SIGE_HIP_EINVAL;
+    if (affineB != 1 && affineB != B) return SIGE_HIP_EINVAL;
+    if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
+    if (C % 4 || !al16(x) || !al16(out) || !al16(scale) || !al16(shift)) return SIGE_HIP_EUNSUPPORTED;
+    const size_t hwc4 = (size_t)H * W * C / 4, total4 = hwc4 * B;
+    affine_act_nhwc_kernel<<<grid_for((long)total4), kT, 0, as_stream(stream)>>>(x, scale, shift, affineB > 1 ? C : 0, C, hwc4, total4,
+                                                                                activation, out);
+    return launch_status();
+}
+
 extern "C" int sige_hip_attention_nhwc_f32(const float *qkv, int B, int C, int HW, float scale, float *workspace,
                                            float *out, void *stream) {
     if (B <= 0 || C <= 0 || HW <= 0) return SIGE_HIP_EINVAL;

@@ -138,6 +138,7 @@ _SIGNATURES = {
     "sige_hip_scatter_gather_conv_scatter_nhwc_f16x3": (
         _c_int, [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
         + [_c_int] * 3 + [_c_int, _c_int, _c_vp] + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp] * 6 + [_c_vp, _c_vp]),
+    "sige_hip_affine_act_nhwc_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp, _c_int, _c_int, _c_vp, _c_vp]),
     # dense layers on the fp16 matrix cores (conv_wide)
     "sige_hip_wide_conv_supported": (_c_int, [_c_int] * 5),
     "sige_hip_wide_conv_packed_size": (_c_sz, [_c_int] * 5),
@@ -1256,6 +1257,27 @@ def group_norm_affine_cl(x, groups: int, eps: float, gamma=None, beta=None):
         return None
     _check(status, "group_norm_affine_cl")
     return scale, shift
+
+
+def affine_act_cl(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, activationName: str,
+                  out: Optional[torch.Tensor] = None):
+    """act(scale * x + shift) over a whole channels-last tensor in one launch (scale / shift [1|B, C, 1, 1]); written into `out`
+    (same shape and layout) when given.  None if unsupported."""
+    x = _req_cl(x, "x")
+    B, C, H, W = x.shape
+    (sa, s_keep), (ta, t_keep) = _cvec(scale, "scale"), _cvec(shift, "shift")
+    if s_keep is None or t_keep is None or sa[1] != ta[1] or sa[2] != C or ta[2] != C or sa[1] not in (1, B) or C % 4:
+        return None
+    if out is None:
+        out = _empty_cl((B, C, H, W), x.device)
+    elif tuple(out.shape) != (B, C, H, W) or not out.is_contiguous(memory_format=CL) or out.dtype != torch.float32:
+        return None
+    status = lib().sige_hip_affine_act_nhwc_f32(x.data_ptr(), B, C, H, W, sa[0], ta[0], sa[1], _act(activationName), out.data_ptr(),
+                                                _stream(x))
+    if status == UNSUPPORTED:
+        return None
+    _check(status, "affine_act_cl")
+    return out
 
 
 def attention_cl(qkv: torch.Tensor, scale: float):

@@ -44,6 +44,7 @@ def _tile_compute(compute: str) -> str:
 #     (~8 us each) eat what the dense 3x3s gain -- 1.456 vs 1.446 ms (split operands vs exact fp32, 1.2 % edit), 1.250 vs
 #     1.034 ms with plain fp16 operands.  So the dense remainder of the sparse pass stays on the tile kernels.
 WIDE_MIN_FLOP = {3: 4.0e9, 1: 2.0e9}
+WIDE_MIN_FLOP_FULL_PASS = {3: 0.25e9, 1: 2.0e9}
 # Tile convs (conv_mfma.hpp) asked for split fp16 operands run them only above this many flop per launch; below, exact fp32.
 # Measured (profiles/r3c_bench.json, DDPM-256 sparse forward, every tile conv on split operands against exact fp32): 1.2 %
 # edit (0.4 GFLOP per launch) 555 vs 521 us over the 48 launches, 5 % 2.01 vs 1.92 ms per forward, 15 % (3.9 GFLOP) 2.47 vs
@@ -65,7 +66,8 @@ def _wide_packed(conv: nn.Conv2d, compute: str):
     return entry[1]
 
 
-def _wide_conv(conv: nn.Conv2d, x, x2, scale, shift, activation_name, residual, out_affine, twins, made, upsample2x=False):
+def _wide_conv(conv: nn.Conv2d, x, x2, scale, shift, activation_name, residual, out_affine, twins, made, upsample2x=False,
+               min_flop=None):
     """The conv as one launch of the dense-layer kernel (csrc/conv_wide.hpp) when the layer's compute dtype asks for the fp16
     matrix cores ("f16" / "f16x3") and the shape has a kernel; None otherwise (the caller goes on to the tile kernels)."""
     from .. import hip
@@ -79,7 +81,7 @@ def _wide_conv(conv: nn.Conv2d, x, x2, scale, shift, activation_name, residual, 
         return None
     C1, C2 = x.shape[1], 0 if x2 is None else x2.shape[1]
     pix = x.shape[0] * x.shape[2] * x.shape[3] * (4 if upsample2x else 1)
-    if 2.0 * pix * conv.out_channels * (C1 + C2) * k[0] * k[1] < WIDE_MIN_FLOP[k[0]]:
+    if 2.0 * pix * conv.out_channels * (C1 + C2) * k[0] * k[1] < (WIDE_MIN_FLOP if min_flop is None else min_flop)[k[0]]:
         return None  # (small layers are latency-bound: the tile kernels' 16 / 32-pixel blocks start up faster)
     if not hip.wide_conv_supported(C1, C2, conv.out_channels, k):
         if x2 is None or upsample2x or not hip.wide_conv_supported(C1 + C2, 0, conv.out_channels, k):
@@ -108,7 +110,8 @@ def full_conv2d(conv: nn.Conv2d, x: torch.Tensor, scale=None, shift=None, activa
     launch of the dense-layer kernel with the affine + SiLU in its staging path; anywhere else exactly the torch
     expression the reference runs (a SIGEConv2d in full mode is nn.Conv2d.forward)."""
     if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4:
-        out = _wide_conv(conv, x, None, scale, shift, activation_name, None, None, None, None)
+        # (no shortcut / conv1 pairing in the full pass: every 3x3 the kernel is at least as fast on takes it)
+        out = _wide_conv(conv, x, None, scale, shift, activation_name, None, None, None, None, min_flop=WIDE_MIN_FLOP_FULL_PASS)
         if out is not None:
             return out
     h = x

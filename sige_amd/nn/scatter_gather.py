@@ -64,8 +64,19 @@ class ScatterGather(SIGEModule):
         from .utils import activation as act_fn
 
         y = self.original_outputs[self.cache_id]
-        new = deferred.keep_layout(act_fn(y * scale + shift, self.activation_name))
         old = self.activated_outputs.get(self.cache_id)
+        if y.is_cuda and y.dtype == torch.float32:
+            from .. import hip
+
+            if hip.is_cl(y) and scale.dim() == 4 and shift.dim() == 4 and self.activation_name in hip.ACT:
+                # one streaming pass, straight into the existing copy when there is one (same address: a captured hipGraph
+                # that reads it stays valid)
+                reuse = old if (old is not None and old.shape == y.shape and old.stride() == y.stride() and old.device == y.device) else None
+                done = hip.affine_act_cl(y, scale, shift, self.activation_name, out=reuse)
+                if done is not None:
+                    self.activated_outputs[self.cache_id] = done
+                    return
+        new = deferred.keep_layout(act_fn(y * scale + shift, self.activation_name))
         if old is not None and old.shape == new.shape and old.stride() == new.stride() and old.device == new.device:
             old.copy_(new)  # same address: a captured hipGraph that reads the activated copy stays valid
         else:

@@ -471,3 +471,18 @@ def test_f16x3_fused_gather_scatter_gather_and_pair(hip, act):
     for key in ("tiles", "full", "sg", "sgs", "short", "conv1"):
         d = float((a[key] - bx[key]).abs().max())
         assert d <= 5e-5 * (1.0 + float(a[key].abs().max())), (key, d)
+
+
+@pytest.mark.parametrize("B,C,H,W,act", [(1, 128, 64, 64, "swish"), (2, 256, 16, 24, "swish"), (1, 64, 8, 8, "identity")])
+def test_affine_act_cl_equals_torch(hip, B, C, H, W, act):
+    """The one-pass activated copy of a ScatterGather cache (full pass) against the torch expression it replaces."""
+    torch.manual_seed(C)
+    x = _cl(torch.randn(B, C, H, W, device=DEV))
+    sc, sh = torch.randn(B, C, 1, 1, device=DEV), torch.randn(1, C, 1, 1, device=DEV).expand(B, C, 1, 1).contiguous()
+    got = hip.affine_act_cl(x, sc, sh, act)
+    want = x * sc + sh
+    want = F.silu(want) if act == "swish" else want
+    assert got is not None and hip.is_cl(got)
+    torch.testing.assert_close(got, want, rtol=2e-6, atol=1e-6)
+    out = torch.empty_like(x)
+    assert hip.affine_act_cl(x, sc, sh, act, out=out) is out and torch.equal(out, got)
