@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SIGE_HIP_VERSION 303 /* 0.3.0: round 3 -- dense-layer convs on the fp16 matrix cores (fp16 / split-fp16 operands) */
+#define SIGE_HIP_VERSION 304 /* 0.3.0: round 3 -- dense-layer convs on the fp16 matrix cores (fp16 / split-fp16 operands) */
 
 enum {
     SIGE_HIP_OK = 0,
@@ -539,27 +539,27 @@ int sige_hip_scatter_gather_conv_scatter_nhwc_f16x3(
  * twins [B,H,W,Cout]); zero padding is applied AFTER affine + activation.  `upsample2x`: x (and x2) are the
  * half-resolution tensors [B,H/2,W/2,C] read as their nearest x2 upsampling (F.interpolate fused, sige_fused_unet.py:222-227).
  * scale / shift: [affineB, C1+C2] (affineB 1 or B) or NULL / NULL (then activation must be identity).
- * Arithmetic: v_mfma_f32_32x32x16_f16, fp32 accumulation;
- *   x3 = 0: operands rounded to fp16 (BASELINE.json configs[4]; tolerance 2e-2 + 1e-2 |ref|);
- *   x3 = 1: every operand split into fp16 hi + lo, products hi*hi + lo*hi + hi*lo (22-bit operands): fp32-level
- *           results, inside the fp32 path's 1e-3.  `wshift`: the weights were packed as w * 2^wshift (a power of two chosen
- *           by the caller so that max |w| * 2^wshift is in [2^13, 2^14): keeps the lo parts normal fp16 numbers).
+ * Arithmetic (`prec`), fp32 accumulation in every form:
+ *   0: v_mfma_f32_32x32x16_f16, operands rounded to fp16 (BASELINE.json configs[4]; tolerance 2e-2 + 1e-2 |ref|);
+ *   1: the same instruction, every operand split into fp16 hi + lo, products hi*hi + lo*hi + hi*lo (22-bit operands):
+ *      fp32-level results, inside the fp32 path's 1e-3.  `wshift`: the weights were packed as w * 2^wshift (a power of two
+ *      chosen by the caller so that max |w| * 2^wshift is in [2^13, 2^14): keeps the lo parts normal fp16 numbers);
+ *   2: v_mfma_f32_32x32x2_f32, exact fp32 products (wshift must be 0).
  * Shapes: C1, C2 multiples of 64 (3x3) / 128 (1x1), Cout a multiple of 64 (sige_hip_wide_conv_supported).
  * twinK (optional): twinK = SiLU(twin_scaleK * v + twin_shiftK), v = the value `out` receives before its out-affine.
  * workspace (optional, sige_hip_wide_conv_workspace floats): small layers split K across workgroups and finish inside
  * the launch (deterministic summation order); without it they run unsplit.                                    */
 int sige_hip_wide_conv_supported(int C1, int C2, int Cout, int kH, int kW);
 /* packed size in 4-byte units (0: unsupported shape) */
-size_t sige_hip_wide_conv_packed_size(int Cout, int Cin, int kH, int kW, int x3);
-int sige_hip_wide_conv_pack(const float *w, int Cout, int Cin, int kH, int kW, int x3, int wshift,
+size_t sige_hip_wide_conv_packed_size(int Cout, int Cin, int kH, int kW, int prec);
+int sige_hip_wide_conv_pack(const float *w, int Cout, int Cin, int kH, int kW, int prec, int wshift,
                             float *packed, void *stream);
 size_t sige_hip_wide_conv_workspace(int B, int H, int W, int C1, int C2, int Cout, int kH, int kW);
-/* benchmarking: pin the K split (0 = automatic) / the width of a workgroup's output patch (8 | 16; 0 = automatic) */
+/* benchmarking: pin the K split (0 = automatic) */
 int sige_hip_wide_conv_force_ksplit(int ksplit);
-int sige_hip_wide_conv_force_patch(int width);
 int sige_hip_wide_conv_nhwc(const float *x, const float *x2, int B, int C1, int C2, int H, int W, int upsample2x,
                             const float *scale, const float *shift, int affineB, int activation,
-                            const float *packed, int x3, int wshift, const float *bias, int Cout, int kH, int kW,
+                            const float *packed, int prec, int wshift, const float *bias, int Cout, int kH, int kW,
                             const float *residual, const float *out_scale, const float *out_shift, int out_activation,
                             float *twin0, const float *twin_scale0, const float *twin_shift0,
                             float *twin1, const float *twin_scale1, const float *twin_shift1,

@@ -7,10 +7,9 @@
 
 namespace sige {
 
-#define SIGE_WIDE_DECLARE(KH, X3)                                                                   \
-    template <> void launch_conv_wide<KH, X3, 8>(const WideArgs &, bool, bool, hipStream_t);        \
-    template <> void launch_conv_wide<KH, X3, 16>(const WideArgs &, bool, bool, hipStream_t);
-SIGE_WIDE_DECLARE(3, false) SIGE_WIDE_DECLARE(3, true) SIGE_WIDE_DECLARE(1, false) SIGE_WIDE_DECLARE(1, true)
+#define SIGE_WIDE_DECLARE(KH, PREC) template <> void launch_conv_wide<KH, PREC, 8>(const WideArgs &, bool, bool, hipStream_t);
+SIGE_WIDE_DECLARE(3, WIDE_F16) SIGE_WIDE_DECLARE(3, WIDE_X3) SIGE_WIDE_DECLARE(3, WIDE_F32)
+SIGE_WIDE_DECLARE(1, WIDE_F16) SIGE_WIDE_DECLARE(1, WIDE_X3) SIGE_WIDE_DECLARE(1, WIDE_F32)
 
 // packed[ntile][wave][chunk][ks][tap][nt][plane][lane = (kq, j)][e] =
 //     plane(w[co = 64 ntile + 32 nt + j][ci = chunk*CC + wave*CW + 16 ks + 8 kq + e][tap] * 2^wshift)
@@ -39,6 +38,29 @@ __global__ void pack_wide_kernel(const float *__restrict__ w, int Cout, int Cin,
     }
 }
 
+// exact fp32 form: packed[ntile][wave][chunk][ks][tap][nt][piece][lane = (kq, j)][e] = w[co][ci = ... + 16 ks + 2 (4 piece + e) + kq][tap]
+// (k-step 4 piece + e of the eight v_mfma_f32_32x32x2_f32 per tap; lane group kq holds channel 2 s + kq)
+template <typename G>
+__global__ void pack_wide_f32_kernel(const float *__restrict__ w, int Cout, int Cin, float *__restrict__ packed, long total) {
+    const int nchunks = (Cin + G::CC - 1) / G::CC;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i;
+        const int e = r % 4; r /= 4;
+        const int j = r % 32; r /= 32;
+        const int kq = r % 2; r /= 2;
+        const int pl = r % 2; r /= 2;
+        const int nt = r % 2; r /= 2;
+        const int tap = r % G::KK; r /= G::KK;
+        const int ks = r % G::KS; r /= G::KS;
+        const int chunk = r % nchunks; r /= nchunks;
+        const int wave = r % 4; r /= 4;
+        const int ntile = (int)r;
+        const int co = 64 * ntile + 32 * nt + j;
+        const int ci = chunk * G::CC + wave * G::CW + 16 * ks + 2 * (4 * pl + e) + kq;
+        packed[i] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * G::KK + tap] : 0.0f;
+    }
+}
+
 template <typename G>
 static size_t wide_packed_bytes(int Cout, int Cin) {
     const size_t nchunks = (Cin + G::CC - 1) / G::CC, ntn = (Cout + 63) / 64;
@@ -47,17 +69,17 @@ static size_t wide_packed_bytes(int Cout, int Cin) {
 
 static bool wide_shape_ok(int C1, int C2, int Cout, int kH, int kW) {
     if (kH != kW || (kH != 1 && kH != 3)) return false;
-    const int cc = kH == 3 ? WideGeo<3, false>::CC : WideGeo<1, false>::CC;
+    const int cc = kH == 3 ? WideGeo<3, WIDE_F16>::CC : WideGeo<1, WIDE_F16>::CC;
     return C1 > 0 && C2 >= 0 && C1 % cc == 0 && C2 % cc == 0 && Cout > 0 && Cout % 64 == 0;
 }
 
-static int g_wide_force_ksplit = 0, g_wide_force_patch = 0;
+static int g_wide_force_ksplit = 0;
 
-// width of a workgroup's output patch.  8 x 8 pixels / two waves per SIMD everywhere: the 8 x 16 form (one wave per SIMD, the
-// 512-register budget, twice the matrix work per weight byte) measured SLOWER on every layer of the DDPM-256 U-Net (256^2
-// 128->128: 92 vs 73 us; 32^2 768->256: 34 vs 24 us -- profiles/r3b_wide_bench.jsonl): one in-order wave per SIMD hides
-// nothing.  It stays selectable for measurements (sige_hip_wide_conv_force_patch).
-static int wide_patch(int W) { (void)W; return g_wide_force_patch ? g_wide_force_patch : 8; }
+// width of a workgroup's output patch: 8 x 8 pixels / two waves per SIMD.  (An 8 x 16 form -- one wave per SIMD with the
+// 512-register budget, twice the matrix work per weight byte, a whole chunk of weights in the ring -- was built and measured
+// SLOWER on every layer of the DDPM-256 U-Net, 256^2 128->128: 92 vs 73 us, 32^2 768->256: 34 vs 24 us
+// (profiles/r3b_wide_bench.jsonl): one in-order wave per SIMD hides nothing.  Removed; WideGeo keeps the parameter.)
+static int wide_patch(int W) { (void)W; return 8; }
 
 // K split of a launch with `blocks` output blocks and `nchunks` channel chunks: enough workgroups for two per CU
 static int wide_ksplit(long blocks, int nchunks, size_t out_floats, size_t ws_floats) {
@@ -76,21 +98,33 @@ extern "C" int sige_hip_wide_conv_supported(int C1, int C2, int Cout, int kH, in
     return wide_shape_ok(C1, C2, Cout, kH, kW) ? 1 : 0;
 }
 
-extern "C" size_t sige_hip_wide_conv_packed_size(int Cout, int Cin, int kH, int kW, int x3) {
-    if (!wide_shape_ok(Cin, 0, Cout, kH, kW)) return 0;
-    size_t bytes;
-    if (kH == 3) bytes = x3 ? wide_packed_bytes<WideGeo<3, true>>(Cout, Cin) : wide_packed_bytes<WideGeo<3, false>>(Cout, Cin);
-    else bytes = x3 ? wide_packed_bytes<WideGeo<1, true>>(Cout, Cin) : wide_packed_bytes<WideGeo<1, false>>(Cout, Cin);
+extern "C" size_t sige_hip_wide_conv_packed_size(int Cout, int Cin, int kH, int kW, int prec) {
+    if (!wide_shape_ok(Cin, 0, Cout, kH, kW) || prec < WIDE_F16 || prec > WIDE_F32) return 0;
+    size_t bytes;  // (the split-fp16 and the exact-fp32 forms have the same footprint: 4 bytes per weight)
+    if (kH == 3) bytes = prec != WIDE_F16 ? wide_packed_bytes<WideGeo<3, WIDE_X3>>(Cout, Cin) : wide_packed_bytes<WideGeo<3, WIDE_F16>>(Cout, Cin);
+    else bytes = prec != WIDE_F16 ? wide_packed_bytes<WideGeo<1, WIDE_X3>>(Cout, Cin) : wide_packed_bytes<WideGeo<1, WIDE_F16>>(Cout, Cin);
     return bytes / 4;
 }
 
-extern "C" int sige_hip_wide_conv_pack(const float *w, int Cout, int Cin, int kH, int kW, int x3, int wshift,
+extern "C" int sige_hip_wide_conv_pack(const float *w, int Cout, int Cin, int kH, int kW, int prec, int wshift,
                                        float *packed, void *stream) {
-    if (!w || !packed || wshift < -60 || wshift > 60) return SIGE_HIP_EINVAL;
+    if (!w || !packed || wshift < -60 || wshift > 60 || prec < WIDE_F16 || prec > WIDE_F32) return SIGE_HIP_EINVAL;
     if (!wide_shape_ok(Cin, 0, Cout, kH, kW)) return SIGE_HIP_EUNSUPPORTED;
+    if (prec == WIDE_F32 && wshift != 0) return SIGE_HIP_EINVAL;
     hipStream_t st = as_stream(stream);
-    const size_t units = sige_hip_wide_conv_packed_size(Cout, Cin, kH, kW, x3);
+    const size_t units = sige_hip_wide_conv_packed_size(Cout, Cin, kH, kW, prec);
     if (hipMemsetAsync(packed, 0, units * 4, st) != hipSuccess) return SIGE_HIP_ELAUNCH;  // (incl. the padding)
+    if (prec == WIDE_F32) {
+        auto gof = [&](auto g_tag) {
+            using G = decltype(g_tag);
+            const long total = (long)((wide_packed_bytes<G>(Cout, Cin) - (size_t)kWidePadSteps * G::STEPB) / 4);
+            const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+            pack_wide_f32_kernel<G><<<grid, 256, 0, st>>>(w, Cout, Cin, packed, total);
+        };
+        if (kH == 3) gof(WideGeo<3, WIDE_F32>{}); else gof(WideGeo<1, WIDE_F32>{});
+        return launch_status(1);
+    }
+    const bool x3 = prec == WIDE_X3;
     const float wmul = ldexpf(1.0f, wshift);
     _Float16 *ph = reinterpret_cast<_Float16 *>(packed);
     auto go = [&](auto g_tag) {
@@ -99,24 +133,18 @@ extern "C" int sige_hip_wide_conv_pack(const float *w, int Cout, int Cin, int kH
         const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
         pack_wide_kernel<G><<<grid, 256, 0, st>>>(w, Cout, Cin, wmul, ph, total);
     };
-    if (kH == 3) { if (x3) go(WideGeo<3, true>{}); else go(WideGeo<3, false>{}); }
-    else { if (x3) go(WideGeo<1, true>{}); else go(WideGeo<1, false>{}); }
+    if (kH == 3) { if (x3) go(WideGeo<3, WIDE_X3>{}); else go(WideGeo<3, WIDE_F16>{}); }
+    else { if (x3) go(WideGeo<1, WIDE_X3>{}); else go(WideGeo<1, WIDE_F16>{}); }
     return launch_status(1);
 }
 
 extern "C" size_t sige_hip_wide_conv_workspace(int B, int H, int W, int C1, int C2, int Cout, int kH, int kW) {
     if (!wide_shape_ok(C1, C2, Cout, kH, kW) || B <= 0 || H <= 0 || W <= 0) return 0;
     const long blocks = (long)B * ceil_div(H, 8) * ceil_div(W, wide_patch(W)) * (Cout / 64);
-    const int cc = kH == 3 ? WideGeo<3, false>::CC : WideGeo<1, false>::CC;
+    const int cc = kH == 3 ? WideGeo<3, WIDE_F16>::CC : WideGeo<1, WIDE_F16>::CC;
     const size_t out_floats = (size_t)B * H * W * Cout;
     const int s = wide_ksplit(blocks * (wide_patch(W) / 8), (C1 + C2) / cc, out_floats, (size_t)-1);
     return s > 1 ? (size_t)s * out_floats : 0;
-}
-
-extern "C" int sige_hip_wide_conv_force_patch(int width) {
-    if (width != 0 && width != 8 && width != 16) return SIGE_HIP_EINVAL;
-    g_wide_force_patch = width;
-    return SIGE_HIP_OK;
 }
 
 extern "C" int sige_hip_wide_conv_force_ksplit(int ksplit) {
@@ -127,12 +155,12 @@ extern "C" int sige_hip_wide_conv_force_ksplit(int ksplit) {
 
 extern "C" int sige_hip_wide_conv_nhwc(const float *x, const float *x2, int B, int C1, int C2, int H, int W, int upsample2x,
                                        const float *scale, const float *shift, int affineB, int activation,
-                                       const float *packed, int x3, int wshift, const float *bias, int Cout, int kH, int kW,
+                                       const float *packed, int prec, int wshift, const float *bias, int Cout, int kH, int kW,
                                        const float *residual, const float *out_scale, const float *out_shift, int out_activation,
                                        float *twin0, const float *twin_scale0, const float *twin_shift0,
                                        float *twin1, const float *twin_scale1, const float *twin_shift1,
                                        float *workspace, size_t workspace_floats, float *out, void *stream) {
-    if (B <= 0 || H <= 0 || W <= 0 || C1 <= 0 || C2 < 0 || Cout <= 0) return SIGE_HIP_EINVAL;
+    if (B <= 0 || H <= 0 || W <= 0 || C1 <= 0 || C2 < 0 || Cout <= 0 || prec < WIDE_F16 || prec > WIDE_F32) return SIGE_HIP_EINVAL;
     if (!x || (C2 && !x2) || !packed || !out) return SIGE_HIP_EINVAL;
     if (!wide_shape_ok(C1, C2, Cout, kH, kW)) return SIGE_HIP_EUNSUPPORTED;
     if ((scale == nullptr) != (shift == nullptr)) return SIGE_HIP_EINVAL;
@@ -159,7 +187,7 @@ extern "C" int sige_hip_wide_conv_nhwc(const float *x, const float *x2, int B, i
     a.aff_sb = (scale && affineB > 1) ? C1 + C2 : 0;
     const int pwo = wide_patch(W);
     a.th = ceil_div(H, 8); a.tw = ceil_div(W, pwo); a.ntn = Cout / 64;
-    const int cc = kH == 3 ? WideGeo<3, false>::CC : WideGeo<1, false>::CC;
+    const int cc = kH == 3 ? WideGeo<3, WIDE_F16>::CC : WideGeo<1, WIDE_F16>::CC;
     a.nchunks = (C1 + C2) / cc; a.nchunks1 = C1 / cc;
     hipStream_t st = as_stream(stream);
     const long blocks = (long)B * a.th * a.tw * a.ntn;
@@ -174,13 +202,13 @@ extern "C" int sige_hip_wide_conv_nhwc(const float *x, const float *x2, int B, i
     a.ksplit = ceil_div(a.nchunks, a.chunks_per_split);
     if (a.ksplit > 1) { a.out = workspace; a.split_stride = out_floats; }
     const bool aff = scale != nullptr, cat = C2 > 0;
-#define SIGE_WIDE_GO(KH, X3)                                                                        \
+#define SIGE_WIDE_GO(KH)                                                                            \
     do {                                                                                            \
-        if (pwo == 16) launch_conv_wide<KH, X3, 16>(a, aff, cat, st);                               \
-        else launch_conv_wide<KH, X3, 8>(a, aff, cat, st);                                          \
+        if (prec == WIDE_F32) launch_conv_wide<KH, WIDE_F32, 8>(a, aff, cat, st);                   \
+        else if (prec == WIDE_X3) launch_conv_wide<KH, WIDE_X3, 8>(a, aff, cat, st);                \
+        else launch_conv_wide<KH, WIDE_F16, 8>(a, aff, cat, st);                                    \
     } while (0)
-    if (kH == 3) { if (x3) SIGE_WIDE_GO(3, true); else SIGE_WIDE_GO(3, false); }
-    else { if (x3) SIGE_WIDE_GO(1, true); else SIGE_WIDE_GO(1, false); }
+    if (kH == 3) SIGE_WIDE_GO(3); else SIGE_WIDE_GO(1);
 #undef SIGE_WIDE_GO
     return launch_status(1);
 }

@@ -33,16 +33,21 @@ namespace sige {
 // 16 (8 x 16 pixels = four M tiles per wave, ONE wave per SIMD with the 512-register budget: every weight byte pulled from
 // L2 feeds twice the matrix work, and the weight ring holds a whole chunk -- a workgroup of the 8 x 8 form needs 4 KB of
 // weights per 384 cycles of MFMA and wave, 85 B/clk/CU with eight waves, about twice what a CU can pull from L2).
-template <int KH_, bool X3_, int PWO_ = 8>
+enum { WIDE_F16 = 0, WIDE_X3 = 1, WIDE_F32 = 2 };  // operand form (the `prec` argument of the C ABI)
+
+template <int KH_, int PREC_, int PWO_ = 8>
 struct WideGeo {
     static constexpr int KH = KH_, KK = KH_ * KH_;
-    static constexpr bool X3 = X3_;
+    static constexpr int PREC = PREC_;
+    static constexpr bool X3 = PREC_ == WIDE_X3, F32 = PREC_ == WIDE_F32;
     static constexpr int PWO = PWO_;                   // output patch: 8 rows x PWO columns
     static constexpr int MTN = PWO_ / 4;               // 32-pixel M tiles per wave (2 | 4)
     static constexpr int RPT = 32 / PWO_;              // patch rows per M tile (4 | 2)
     static constexpr int BM = 8 * PWO_;                // output pixels per workgroup
     static constexpr int OCC = PWO_ == 16 ? 1 : 2;     // waves per SIMD the register budget is set for
-    static constexpr int NP = X3_ ? 2 : 1;             // operand planes: hi | hi, lo
+    // 16-byte operand pieces per lane and k-step: F16 one (8 halves); X3 two planes (hi, lo); F32 two (8 floats = k-steps 0..3 | 4..7
+    // of the eight v_mfma_f32_32x32x2_f32 that contract the 16 channels: lane group kq holds channels 2 s + kq)
+    static constexpr int NP = PREC_ == WIDE_F16 ? 1 : 2;
     static constexpr int KS = KH_ == 1 ? 2 : 1;        // 16-channel k-steps per tap and chunk (per wave)
     static constexpr int CW = 16 * KS;                 // channels per wave per chunk
     static constexpr int CC = 4 * CW;                  // channels per chunk (4 waves split K)
@@ -53,12 +58,14 @@ struct WideGeo {
     static constexpr int QP = CW / 4;                  // float4 units per staged pixel (per wave)
     static constexpr int UNITS = NPX * QP;
     static constexpr int NS = (UNITS + 63) / 64;       // staging slots per lane
-    static constexpr int KSB = 32 * NP;                // bytes of one k-step group of a pixel row: 16 hi halves (+ 16 lo)
+    static constexpr int KSB = 32 * NP;                // bytes of one k-step group of a pixel row: 16 hi halves (+ 16 lo) | 16 floats
+    static constexpr int KQB = F32 ? 32 : 16;          // byte offset of lane group kq = 1 inside a k-step group
+    static constexpr int PLB = F32 ? 16 : 32;          // byte offset of the second operand piece
     static constexpr int ROWB = KS * KSB + 16;         // LDS row of one staged pixel (padded against bank conflicts)
     static constexpr int ABUF = NPX * ROWB;            // bytes of one stage of one wave
     static constexpr int STEPB = 2 * NP * 1024;        // packed weight bytes per k-step of one wave: [nt][plane][lane][16 B]
     // weight register ring, in k-steps (= prefetch distance): a whole chunk where the register budget allows
-    static constexpr int RB = KH_ == 3 ? (X3_ ? (PWO_ == 8 ? 3 : 6) : 9) : 4;
+    static constexpr int RB = KH_ == 3 ? (PREC_ == WIDE_F16 ? 9 : (PWO_ == 8 ? 3 : 6)) : 4;
     static_assert((2 * STEPS) % RB == 0, "the ring position of a step must not depend on the chunk");
     static_assert(RB <= 9, "kWidePadSteps");
     static constexpr int LDS_BYTES = cmax(4 * 2 * ABUF, 4 * BM * 68 * 4);
@@ -94,7 +101,7 @@ __device__ __forceinline__ f16x8 buf_h8(rsrc_t r, unsigned byte_off, int soff) {
 template <typename G, bool AFF, bool CAT>
 __global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];
-    constexpr bool X3 = G::X3;
+    constexpr bool X3 = G::X3, F32 = G::F32;
     constexpr int NS = G::NS, STEPS = G::STEPS, RB = G::RB, NP = G::NP;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -163,6 +170,7 @@ __global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a
             if (do_act) z = swish_fast(z);
             z = live ? z : 0.0f;
         }
+        if constexpr (F32) return z;
         return __builtin_fminf(__builtin_fmaxf(z, -65504.0f), 65504.0f);  // (fp16 range: saturate instead of +-inf)
     };
     auto a_store = [&](auto i_tag, unsigned char *buf, const float4 sc, const float4 sh) {
@@ -172,12 +180,18 @@ __global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a
         const float4 q = st[i];
         const float z0 = fin(q.x, sc.x, sh.x, live), z1 = fin(q.y, sc.y, sh.y, live);
         const float z2 = fin(q.z, sc.z, sh.z, live), z3 = fin(q.w, sc.w, sh.w, live);
-        const f16x4 hi = {(_Float16)z0, (_Float16)z1, (_Float16)z2, (_Float16)z3};  // RNE
-        *reinterpret_cast<f16x4 *>(buf + ldsw[i]) = hi;
-        if constexpr (X3) {
-            const f16x4 lo = {(_Float16)(z0 - (float)hi[0]), (_Float16)(z1 - (float)hi[1]),
-                              (_Float16)(z2 - (float)hi[2]), (_Float16)(z3 - (float)hi[3])};
-            *reinterpret_cast<f16x4 *>(buf + ldsw[i] + 32) = lo;
+        if constexpr (F32) {
+            // exact fp32: the even channels of the unit go to lane group 0's half of the row, the odd ones to group 1's
+            *reinterpret_cast<float2 *>(buf + ldsw[i]) = make_float2(z0, z2);
+            *reinterpret_cast<float2 *>(buf + ldsw[i] + 32) = make_float2(z1, z3);
+        } else {
+            const f16x4 hi = {(_Float16)z0, (_Float16)z1, (_Float16)z2, (_Float16)z3};  // RNE
+            *reinterpret_cast<f16x4 *>(buf + ldsw[i]) = hi;
+            if constexpr (X3) {
+                const f16x4 lo = {(_Float16)(z0 - (float)hi[0]), (_Float16)(z1 - (float)hi[1]),
+                                  (_Float16)(z2 - (float)hi[2]), (_Float16)(z3 - (float)hi[3])};
+                *reinterpret_cast<f16x4 *>(buf + ldsw[i] + 32) = lo;
+            }
         }
     };
 
@@ -201,7 +215,7 @@ __global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a
 
     // ---- A operand of this lane: pixel i of M tile mt (rows 4 mt .. 4 mt + 3 of the patch), k-group kq ----
     const int i32 = lane & 31, kq = lane >> 5;
-    const int abase = ((i32 / G::PWO) * G::PW + (i32 % G::PWO)) * G::ROWB + kq * 16;  // + mt * RPT * PW * ROWB
+    const int abase = ((i32 / G::PWO) * G::PW + (i32 % G::PWO)) * G::ROWB + kq * G::KQB;  // + mt * RPT * PW * ROWB
     constexpr int MTN = G::MTN;
     struct AHalf { f16x8 v[G::MTN]; };
     // plane 0 = hi, 1 = lo (32 bytes further in the pixel's row)
@@ -212,7 +226,7 @@ __global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a
         AHalf r;
 #pragma unroll
         for (int mt = 0; mt < MTN; ++mt)
-            r.v[mt] = *reinterpret_cast<const f16x8 *>(buf + abase + mt * G::RPT * G::PW * G::ROWB + off + plane * 32);
+            r.v[mt] = *reinterpret_cast<const f16x8 *>(buf + abase + mt * G::RPT * G::PW * G::ROWB + off + plane * G::PLB);
         return r;
     };
 
@@ -234,7 +248,7 @@ __global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a
     a_load(min(first + 1, last));
     __builtin_amdgcn_wave_barrier();
     AHalf a_hi = a_read(std::integral_constant<int, 0>{}, mybuf, 0), a_lo = a_hi;
-    if constexpr (X3) a_lo = a_read(std::integral_constant<int, 0>{}, mybuf, 1);
+    if constexpr (NP == 2) a_lo = a_read(std::integral_constant<int, 0>{}, mybuf, 1);
 
     // one chunk: MFMAs on stage PAR; the registers holding chunk+1 are finished into stage PAR^1 and re-issued as chunk+2;
     // every ring position is re-issued RB steps ahead right after its MFMAs
@@ -250,10 +264,27 @@ __global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a
         static_for<0, STEPS>([&](auto s_tag) {
             constexpr int s = decltype(s_tag)::value;
             constexpr int slot = (PAR * STEPS + s) % RB;
-            // lo*hi first: the lo operands die after the first group and next step's lo takes their registers; then hi*hi and
-            // hi*lo.  Consecutive MFMAs never share an accumulator.
             AHalf n_hi = a_hi, n_lo = a_lo;
             if constexpr (s + 1 < STEPS) n_hi = a_read(std::integral_constant<int, s + 1>{}, cur, 0);
+            if constexpr (F32) {
+                // exact fp32: eight v_mfma_f32_32x32x2_f32 per tile contract the 16 channels (k-step ss: channels 2 ss + kq);
+                // the four tiles alternate, so consecutive MFMAs never share an accumulator
+                if constexpr (s + 1 < STEPS) n_lo = a_read(std::integral_constant<int, s + 1>{}, cur, 1);
+                static_for<0, 8>([&](auto ss_tag) {
+                    constexpr int ss = decltype(ss_tag)::value;
+#pragma unroll
+                    for (int mt = 0; mt < MTN; ++mt) {
+                        const f32x4 av = __builtin_bit_cast(f32x4, ss < 4 ? a_hi.v[mt] : a_lo.v[mt]);
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const f32x4 bv = __builtin_bit_cast(f32x4, bring[slot][nt][ss / 4]);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss & 3], bv[ss & 3], acc[mt][nt], 0, 0, 0);
+                        }
+                    }
+                });
+            } else {
+            // lo*hi first: the lo operands die after the first group and next step's lo takes their registers; then hi*hi and
+            // hi*lo.  Consecutive MFMAs never share an accumulator.
             if constexpr (X3) {
 #pragma unroll
                 for (int mt = 0; mt < MTN; ++mt)
@@ -274,6 +305,7 @@ __global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a
                     for (int nt = 0; nt < 2; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi.v[mt], bring[slot][nt][NP - 1], acc[mt][nt], 0, 0, 0);
             }
+            }
             // staging slots of chunk+1 spread over the steps before the last one
             if constexpr (s < STEPS - 1 || STEPS == 1) {
                 constexpr int SD = STEPS > 1 ? STEPS - 1 : 1;
@@ -293,7 +325,7 @@ __global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a
             if constexpr (s + 1 == STEPS) {
                 __builtin_amdgcn_wave_barrier();  // (the stage was written by other lanes of this wave: LDS is in order per wave)
                 n_hi = a_read(std::integral_constant<int, 0>{}, nxt, 0);
-                if constexpr (X3) n_lo = a_read(std::integral_constant<int, 0>{}, nxt, 1);
+                if constexpr (NP == 2) n_lo = a_read(std::integral_constant<int, 0>{}, nxt, 1);
             }
             a_hi = n_hi;
             a_lo = n_lo;
@@ -419,12 +451,12 @@ __global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a
     }
 }
 
-template <int KH, bool X3, int PWO>
+template <int KH, int PREC, int PWO>
 void launch_conv_wide(const WideArgs &a, bool aff, bool cat, hipStream_t st);
 
-#define SIGE_WIDE_INSTANTIATE(KH, X3, PWO)                                                                 \
-    template <> void launch_conv_wide<KH, X3, PWO>(const WideArgs &a, bool aff, bool cat, hipStream_t st) { \
-        using G = WideGeo<KH, X3, PWO>;                                                                    \
+#define SIGE_WIDE_INSTANTIATE(KH, PREC, PWO)                                                               \
+    template <> void launch_conv_wide<KH, PREC, PWO>(const WideArgs &a, bool aff, bool cat, hipStream_t st) { \
+        using G = WideGeo<KH, PREC, PWO>;                                                                  \
         const dim3 grid(a.B * a.th * a.tw * a.ntn, a.ksplit);                                              \
         if (aff && cat) conv_wide_kernel<G, true, true><<<grid, 256, 0, st>>>(a);                          \
         else if (aff) conv_wide_kernel<G, true, false><<<grid, 256, 0, st>>>(a);                           \

@@ -145,7 +145,6 @@ _SIGNATURES = {
     "sige_hip_wide_conv_pack": (_c_int, [_c_vp] + [_c_int] * 6 + [_c_vp, _c_vp]),
     "sige_hip_wide_conv_workspace": (_c_sz, [_c_int] * 8),
     "sige_hip_wide_conv_force_ksplit": (_c_int, [_c_int]),
-    "sige_hip_wide_conv_force_patch": (_c_int, [_c_int]),
     "sige_hip_wide_conv_nhwc": (
         _c_int, [_c_vp, _c_vp] + [_c_int] * 6 + [_c_vp, _c_vp, _c_int, _c_int] + [_c_vp, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_int]
         + [_c_vp, _c_vp, _c_vp, _c_int] + [_c_vp] * 6 + [_c_vp, _c_sz, _c_vp, _c_vp]),
@@ -547,6 +546,9 @@ def _conv_fn(name: str, packed):
 COMPUTE_DTYPES = ("f32", "f16", "f16x3")
 
 
+_WIDE_PREC = {"f16": 0, "f16x3": 1, "f32": 2}  # the `prec` argument of sige_hip_wide_conv_* (conv_wide.hpp: WIDE_F16 / _X3 / _F32)
+
+
 def wide_conv_supported(C1: int, C2: int, Cout: int, kernel: Tuple[int, int]) -> bool:
     return bool(lib().sige_hip_wide_conv_supported(C1, C2, Cout, kernel[0], kernel[1]))
 
@@ -556,12 +558,13 @@ def wide_conv_pack_weights(weight: torch.Tensor, compute: str) -> Optional[torch
     rounded to fp16) or "f16x3" (operands split into fp16 hi + lo, three products: fp32-level results).  None: no kernel
     for this shape.  For "f16x3" the weights are stored as w * 2^s with max |w| * 2^s in [2^13, 2^14) (one device -> host
     read of max |w| at pack time), so that the lo parts are normal fp16 numbers."""
-    if compute not in ("f16", "f16x3"):
-        raise ValueError("compute must be 'f16' or 'f16x3'")
+    if compute not in _WIDE_PREC:
+        raise ValueError("compute must be 'f16', 'f16x3' or 'f32'")
     w = _req(weight.detach(), torch.float32, "weight")
     Cout, Cin, kH, kW = w.shape
-    x3 = int(compute == "f16x3")
-    n = int(lib().sige_hip_wide_conv_packed_size(Cout, Cin, kH, kW, x3))
+    prec = _WIDE_PREC[compute]
+    x3 = compute == "f16x3"
+    n = int(lib().sige_hip_wide_conv_packed_size(Cout, Cin, kH, kW, prec))
     if n == 0:
         return None
     wshift = 0
@@ -574,7 +577,7 @@ def wide_conv_pack_weights(weight: torch.Tensor, compute: str) -> Optional[torch
     packed = torch.empty((n,), dtype=torch.float32, device=w.device).as_subclass(PackedWeights)
     packed.compute = compute + "w"
     packed.wshift = wshift
-    _check(lib().sige_hip_wide_conv_pack(w.data_ptr(), Cout, Cin, kH, kW, x3, wshift, packed.data_ptr(), _stream(w)),
+    _check(lib().sige_hip_wide_conv_pack(w.data_ptr(), Cout, Cin, kH, kW, prec, wshift, packed.data_ptr(), _stream(w)),
            "wide_conv_pack_weights")
     return packed
 
@@ -584,11 +587,6 @@ def wide_conv_force_ksplit(ksplit: int = 0):
     _check(lib().sige_hip_wide_conv_force_ksplit(ksplit), "wide_conv_force_ksplit")
 
 
-def wide_conv_force_patch(width: int = 0):
-    """Benchmark knob: 8 x 8 or 8 x 16 output pixels per workgroup of the dense-layer conv (0 = automatic)."""
-    _check(lib().sige_hip_wide_conv_force_patch(width), "wide_conv_force_patch")
-
-
 def wide_conv_cl(x, x2, scale, shift, activationName: str, packed, bias, Cout: int, kernel: Tuple[int, int],
                  residual=None, out_affine: Optional[tuple] = None, twins=None, upsample2x: bool = False,
                  out: Optional[torch.Tensor] = None):
@@ -596,7 +594,7 @@ def wide_conv_cl(x, x2, scale, shift, activationName: str, packed, bias, Cout: i
     launch on the fp16 matrix cores (include/sige_hip.h: sige_hip_wide_conv_nhwc).  3x3 / padding 1 or 1x1, stride 1.
     `packed` from wide_conv_pack_weights.  None if the shape has no kernel."""
     compute = getattr(packed, "compute", "f32")
-    if compute not in ("f16w", "f16x3w"):
+    if compute not in ("f16w", "f16x3w", "f32w"):
         raise NotImplementedError("wide_conv_cl: weights must be packed with wide_conv_pack_weights")
     bias_keep = _vec(bias, "bias")
     x = _req_cl(x, "x")
@@ -643,7 +641,7 @@ def wide_conv_cl(x, x2, scale, shift, activationName: str, packed, bias, Cout: i
     status = lib().sige_hip_wide_conv_nhwc(
         x.data_ptr(), None if x2 is None else x2.data_ptr(), B, C1, C2, H, W, int(bool(upsample2x)),
         sa[0], ta[0], sa[1] if s_keep is not None else 0, _act(activationName),
-        packed.data_ptr(), int(compute == "f16x3w"), int(getattr(packed, "wshift", 0)), _p(bias_keep), Cout, kernel[0], kernel[1],
+        packed.data_ptr(), _WIDE_PREC[compute[:-1]], int(getattr(packed, "wshift", 0)), _p(bias_keep), Cout, kernel[0], kernel[1],
         None if r is None else r.data_ptr(), *oargs, *targs, None if ws is None else ws.data_ptr(), ws_n, out.data_ptr(), _stream(x))
     if status == UNSUPPORTED:
         return None

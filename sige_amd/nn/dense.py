@@ -45,6 +45,8 @@ def _tile_compute(compute: str) -> str:
 #     1.034 ms with plain fp16 operands.  So the dense remainder of the sparse pass stays on the tile kernels.
 WIDE_MIN_FLOP = {3: 4.0e9, 1: 2.0e9}
 WIDE_MIN_FLOP_FULL_PASS = {3: 0.25e9, 1: 2.0e9}
+# exact-fp32 form of the same kernel (matrix-bound on the f32-input MFMA; weights shared by 64 pixels instead of 16 / 32)
+WIDE_MIN_FLOP_F32 = {3: 1.0e30, 1: 1.0e30}
 # Tile convs (conv_mfma.hpp) asked for split fp16 operands run them only above this many flop per launch; below, exact fp32.
 # Measured (profiles/r3c_bench.json, DDPM-256 sparse forward, every tile conv on split operands against exact fp32): 1.2 %
 # edit (0.4 GFLOP per launch) 555 vs 521 us over the 48 launches, 5 % 2.01 vs 1.92 ms per forward, 15 % (3.9 GFLOP) 2.47 vs
@@ -73,7 +75,9 @@ def _wide_conv(conv: nn.Conv2d, x, x2, scale, shift, activation_name, residual, 
     from .. import hip
 
     compute = getattr(conv, "compute_dtype", "f32")
-    if compute not in ("f16", "f16x3") or not hip.is_cl(x) or (x2 is not None and not hip.is_cl(x2)):
+    if compute == "f32" and min_flop is None:
+        min_flop = WIDE_MIN_FLOP_F32  # (exact fp32 on v_mfma_f32_32x32x2_f32: the sparse pass's dense remainder)
+    if compute not in ("f16", "f16x3", "f32") or not hip.is_cl(x) or (x2 is not None and not hip.is_cl(x2)):
         return None
     k = tuple(conv.kernel_size)
     if (k not in ((1, 1), (3, 3)) or tuple(conv.stride) != (1, 1) or tuple(conv.padding) != (k[0] // 2, k[1] // 2)
@@ -111,7 +115,9 @@ def full_conv2d(conv: nn.Conv2d, x: torch.Tensor, scale=None, shift=None, activa
     expression the reference runs (a SIGEConv2d in full mode is nn.Conv2d.forward)."""
     if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4:
         # (no shortcut / conv1 pairing in the full pass: every 3x3 the kernel is at least as fast on takes it)
-        out = _wide_conv(conv, x, None, scale, shift, activation_name, None, None, None, None, min_flop=WIDE_MIN_FLOP_FULL_PASS)
+        out = None
+        if getattr(conv, "compute_dtype", "f32") != "f32":  # (exact fp32: the reference's own torch conv, as it was)
+            out = _wide_conv(conv, x, None, scale, shift, activation_name, None, None, None, None, min_flop=WIDE_MIN_FLOP_FULL_PASS)
         if out is not None:
             return out
     h = x

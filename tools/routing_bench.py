@@ -42,14 +42,22 @@ def main():
             m = bench.edit_mask(r).to(dev)
             x1 = x0 + noise * m
             ref = None
+            default_f32 = dict(dense.WIDE_MIN_FLOP_F32)
             for name, dtype, keep, wide, tile_x3 in (
                     ("f32 exact", "f32", (), True, default_x3),
+                    ("f32 exact, dense 3x3 on the wide kernel (all)", "f32", (), "f32:0.25", default_x3),
+                    ("f32 exact, dense 3x3 on the wide kernel (>= 1 GFLOP)", "f32", (), "f32:1.0", default_x3),
+                    ("f32 exact, dense 3x3 on the wide kernel (>= 2 GFLOP)", "f32", (), "f32:2.0", default_x3),
                     ("f16 everywhere, dense 3x3 on the wide kernel", "f16", (), True, default_x3),
                     ("f16 everywhere, tile kernels only", "f16", (), False, default_x3),
                     ("f16 + F16_KEEP as f16x3", "f16", None, True, default_x3),
                     ("f16x3: wide dense + exact tiles below 2 GFLOP", "f16x3", (), True, default_x3),
                     ("f16x3: wide dense + split-operand tiles everywhere", "f16x3", (), True, 0.0),
                     ("f16x3: tile kernels only (split operands)", "f16x3", (), False, 0.0)):
+                dense.WIDE_MIN_FLOP_F32 = default_f32
+                if isinstance(wide, str):
+                    dense.WIDE_MIN_FLOP_F32 = {3: float(wide.split(":")[1]) * 1e9, 1: 1e30}
+                    wide = True
                 dense.WIDE_MIN_FLOP = default_min if wide else {1: 1e30, 3: 1e30}
                 dense.TILE_X3_MIN_FLOP = tile_x3
                 model.set_compute_dtype(dtype, keep=keep)
@@ -71,6 +79,7 @@ def main():
                 rows.append(row)
                 del g, out
     dense.WIDE_MIN_FLOP = default_min
+    dense.WIDE_MIN_FLOP_F32 = default_f32
     dense.TILE_X3_MIN_FLOP = default_x3
     if args.out:
         with open(os.path.join(REPO, args.out), "w") as f:

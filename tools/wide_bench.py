@@ -112,14 +112,12 @@ def main():
             us = time_graph(fn, nsets)
             row["us_" + compute] = round(us, 2)
             row["TFLOPs_" + compute] = round(flops / us / 1e6, 1)
-        for c in convs:
-            c.compute_dtype = "f16x3"
-        for pw in (8, 16):
-            hip.wide_conv_force_patch(pw)
-            try:
-                row["us_f16x3_patch%d" % pw] = round(time_graph(run_as("f16x3"), nsets), 2)
-            finally:
-                hip.wide_conv_force_patch(0)
+        dense.WIDE_MIN_FLOP_F32 = {1: 0.0, 3: 0.0}   # exact fp32 on the dense-layer kernel
+        try:
+            row["us_f32_wide"] = round(time_graph(run_as("f32"), nsets), 2)
+            row["TFLOPs_f32_wide"] = round(flops / row["us_f32_wide"] / 1e6, 1)
+        finally:
+            dense.WIDE_MIN_FLOP_F32 = {1: 1e30, 3: 1e30}
         if args.ksplit_sweep and res <= 32:
             for c in convs:
                 c.compute_dtype = "f16x3"
