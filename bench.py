@@ -1196,15 +1196,20 @@ def main():
                 del gs, outs
             # the cache-producing full pass (sige/nn/base.py:85-86; one per denoising step in the reference's sampler,
             # diffusion/samplers/ddim_ddpm_sampler.py:60-66): stock torch / MIOpen in fp32 against the library's kernels
+            from sige_amd.nn import dense as _dense
+
             full = {}
-            for cdt in ("f32", "f16x3"):
-                model.set_compute_dtype(cdt)
+            for cdt in ("f32", "f16x3", "f32_native"):
+                model.set_compute_dtype("f32" if cdt == "f32_native" else cdt)
+                _dense.FULL_PASS_F32_NATIVE = cdt == "f32_native"  # exact fp32 products on the library's dense-layer kernel
                 model.set_mode("full")
                 gf, outf = capture(model, x0, t)
                 kf = max(10, args.steps // 10)
                 full[cdt] = timed_replays(gf, kf, 3, 1) * 1e3 / kf
                 full[cdt + "_out"] = outf.float().clone()
                 del gf, outf
+            _dense.FULL_PASS_F32_NATIVE = False
+            full_delta_native = float((full["f32_out"] - full.pop("f32_native_out")).abs().max())
             full_delta = float((full.pop("f32_out") - full.pop("f16x3_out")).abs().max())
             # restore the fp32 cache of the original for everything that follows
             model.set_compute_dtype("f32")
@@ -1219,7 +1224,9 @@ def main():
                   "forward_ms": base, "sweep": rows, "kernels": kern_x3,
                   "full_pass_ms": {"torch_miopen_f32": round(full["f32"], 3), "library_f16x3": round(full["f16x3"], 3),
                                    "speedup": round(full["f32"] / full["f16x3"], 2),
-                                   "max_abs_output_delta": round(full_delta, 7)},
+                                   "max_abs_output_delta": round(full_delta, 7),
+                                   "library_f32_exact": round(full["f32_native"], 3),
+                                   "library_f32_exact_max_abs_output_delta": round(full_delta_native, 7)},
                   "step_ms_full_plus_sparse": {"f32": round(full["f32"] + ms_steady, 3),
                                                "f16x3": round(full["f16x3"] + (base or ms_steady), 3),
                                                "note": "one denoising step of the reference's sampler = full pass on the original + "

@@ -45,8 +45,13 @@ def _tile_compute(compute: str) -> str:
 #     1.034 ms with plain fp16 operands.  So the dense remainder of the sparse pass stays on the tile kernels.
 WIDE_MIN_FLOP = {3: 4.0e9, 1: 2.0e9}
 WIDE_MIN_FLOP_FULL_PASS = {3: 0.25e9, 1: 2.0e9}
-# exact-fp32 form of the same kernel (matrix-bound on the f32-input MFMA; weights shared by 64 pixels instead of 16 / 32)
+# exact-fp32 form of the same kernel (v_mfma_f32_32x32x2_f32; matrix-bound).  Measured (profiles/r3g_wide_bench.jsonl,
+# r3g_routing.jsonl): on the dense remainder it only ties the tile kernels layer by layer (3.6 GFLOP: 49.8 vs 51.6 us = 73 vs
+# 70 TFLOP/s -- the f32-input MFMA is the limit for both) and loses the shortcut pairing in the forward (1.50 ... 1.67 vs 1.447
+# ms), so the sparse pass does not use it; on the big layers of the full pass it reaches 109-127 TFLOP/s (0.70-0.81 of the fp32
+# matrix peak; 283 -> 177 us), which FULL_PASS_F32_NATIVE turns on for an exact-fp32 full pass on the library's kernels.
 WIDE_MIN_FLOP_F32 = {3: 1.0e30, 1: 1.0e30}
+FULL_PASS_F32_NATIVE = False
 # Tile convs (conv_mfma.hpp) asked for split fp16 operands run them only above this many flop per launch; below, exact fp32.
 # Measured (profiles/r3c_bench.json, DDPM-256 sparse forward, every tile conv on split operands against exact fp32): 1.2 %
 # edit (0.4 GFLOP per launch) 555 vs 521 us over the 48 launches, 5 % 2.01 vs 1.92 ms per forward, 15 % (3.9 GFLOP) 2.47 vs
@@ -116,7 +121,9 @@ def full_conv2d(conv: nn.Conv2d, x: torch.Tensor, scale=None, shift=None, activa
     if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4:
         # (no shortcut / conv1 pairing in the full pass: every 3x3 the kernel is at least as fast on takes it)
         out = None
-        if getattr(conv, "compute_dtype", "f32") != "f32":  # (exact fp32: the reference's own torch conv, as it was)
+        # (exact fp32: the reference's own torch conv, as it was -- unless FULL_PASS_F32_NATIVE asks for the exact-fp32 form of the
+        #  dense-layer kernel)
+        if getattr(conv, "compute_dtype", "f32") != "f32" or FULL_PASS_F32_NATIVE:
             out = _wide_conv(conv, x, None, scale, shift, activation_name, None, None, None, None, min_flop=WIDE_MIN_FLOP_FULL_PASS)
         if out is not None:
             return out

@@ -280,7 +280,10 @@ class ResBlock(SIGEModule, _TwinProducer):
     def _full(self, x, temb):
         if self.plain:
             return self._plain(x, temb)
-        fast = getattr(self.conv1, "compute_dtype", "f32") != "f32"  # (the full pass on the fp16 matrix cores: dense.full_conv2d)
+        from ..nn import dense as _dense
+
+        # (the full pass on the library's kernels -- dense.full_conv2d -- also takes the library's GroupNorm statistics)
+        fast = getattr(self.conv1, "compute_dtype", "f32") != "f32" or _dense.FULL_PASS_F32_NATIVE
         skip = self._shortcut(x)
         h = self.main_gather(x) if self.sparse_main else x  # records the input resolution
         s1, t1 = norm_affine(h, self.norm1, fast)
