@@ -146,7 +146,9 @@ class SIGEConv2d(nn.Conv2d, SIGEModule):
             # fp32 kernel (two output-channel sub-blocks per workgroup, half the LDS stores) is as fast or faster
             ro, so = (x.shape[2] - self.kernel_size[0]) // self.stride[0] + 1, (x.shape[3] - self.kernel_size[1]) // self.stride[1] + 1
             flop = 2.0 * x.shape[0] * ro * so * self.out_channels * self.in_channels * self.kernel_size[0] * self.kernel_size[1]
-            if flop < TILE_X3_MIN_FLOP:
+            # (a residual block's 1x1 shortcut has exactly 1/9 of its conv1's flop: the same decision for both, so that the two
+            #  still share a launch -- the pair kernels exist per operand form)
+            if flop * (9 if tuple(self.kernel_size) == (1, 1) else 1) < TILE_X3_MIN_FLOP:
                 compute = "f32"
         w = self.weight
         key = (w.data_ptr(), w._version, tuple(w.shape), x.shape[2], x.shape[3], w.device)
