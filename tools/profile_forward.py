@@ -44,7 +44,7 @@ def main():
         model = model.to(memory_format=torch.channels_last)
         x0, noise = x0.contiguous(memory_format=torch.channels_last), noise.contiguous(memory_format=torch.channels_last)
         model.set_scatter_inplace(True)
-    model.set_compute_dtype(a.dtype)
+    model.set_compute_dtype(a.dtype, edit_ratio=a.ratio)  # (the f16 precision policy depends on the edited area)
     mask = bench.square_mask(a.ratio).to(dev)
     x1 = x0 + noise * mask
     with torch.no_grad():
