@@ -901,7 +901,7 @@ def main():
         x0, noise = x0.contiguous(memory_format=torch.channels_last), noise.contiguous(memory_format=torch.channels_last)
     inplace = args.layout == "nhwc" and not args.no_inplace_scatter
     model.set_scatter_inplace(inplace)
-    model.set_compute_dtype(args.dtype)
+    model.set_compute_dtype(args.dtype, edit_ratio=args.ratio)  # (the f16 precision policy depends on the edited area)
     mfma_peak = PEAK_F16_MFMA_TFS if args.dtype in ("f16", "f16x3") else PEAK_F32_MFMA_TFS
     t = torch.zeros(1, device=dev)
 
