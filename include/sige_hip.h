@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SIGE_HIP_VERSION 304 /* 0.3.0: round 3 -- dense-layer convs on the fp16 matrix cores (fp16 / split-fp16 operands) */
+#define SIGE_HIP_VERSION 305 /* 0.3.0: round 3 -- dense-layer convs on the fp16 matrix cores (fp16 / split-fp16 operands) */
 
 enum {
     SIGE_HIP_OK = 0,
@@ -467,6 +467,13 @@ size_t sige_hip_group_norm_affine_nhwc_workspace(int B, int C, int H, int W, int
 int sige_hip_group_norm_affine_nhwc_f32(const float *x, int B, int C, int H, int W, int groups, float eps,
                                         const float *gamma, const float *beta, float *workspace,
                                         float *scale, float *shift, void *stream);
+
+/* the same with a per-channel bias [C] added BEFORE the statistics (a residual block's GroupNorm of h + temb,
+ * diffusion/models/ddpm_arch/sige_fused_unet.py:116-117); the affine is returned for x itself:
+ * GroupNorm(x + channel_bias) == x * scale + shift.  One batch-independent bias vector. */
+int sige_hip_group_norm_affine_nhwc_bias_f32(const float *x, int B, int C, int H, int W, int groups, float eps,
+                                             const float *gamma, const float *beta, const float *channel_bias,
+                                             float *workspace, float *scale, float *shift, void *stream);
 
 /* ---- single-head spatial self-attention of the U-Net's dense AttnBlock ------
  * (diffusion/models/ddpm_arch/unet.py AttnBlock.forward, reached from

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(kGNThreads) void gn_partial_kernel(const float *__r
 __global__ __launch_bounds__(64) void gn_finish_kernel(const float *__restrict__ ws, int splits, int B, int C, int groups,
                                                       double group_elems, float eps, const float *__restrict__ gamma,
                                                       const float *__restrict__ beta, float *__restrict__ scale,
-                                                      float *__restrict__ shift) {
+                                                      float *__restrict__ shift, const float *__restrict__ cbias = nullptr) {
     const int bg = blockIdx.x;  // b*groups + g
     const int b = bg / groups, g = bg - b * groups;
     const int lane = threadIdx.x;
@@ -80,7 +80,8 @@ __global__ __launch_bounds__(64) void gn_finish_kernel(const float *__restrict__
         const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
         const float sc = ga * rstd;
         scale[b * C + c] = sc;
-        shift[b * C + c] = be - (float)mean * sc;
+        // (cbias: the statistics are those of x + cbias[c]; the affine is returned for x itself -- GN(x + cbias) == x * sc + shift)
+        shift[b * C + c] = be - (float)mean * sc + (cbias ? cbias[c] * sc : 0.0f);
     }
 }
 
@@ -95,7 +96,7 @@ static int gn_splits(size_t group_elems) {
 // ------------------------------------------------------- GroupNorm affine ----
 // x [B,H,W,C]: per (batch, group) sum / sum of squares over H*W pixels x (C/groups) channels
 __global__ __launch_bounds__(kGNThreads) void gn_partial_nhwc_kernel(const float *__restrict__ x, int C, int HW, int groups, int splits,
-                                                            float *__restrict__ ws) {
+                                                            float *__restrict__ ws, const float *__restrict__ cbias = nullptr) {
     // grid: (splits, B); block: each lane owns channel quad (tid % C4) of pixels (tid / C4) + k * (kGNThreads / C4) in its slice.
     // Requires C4 <= kGNThreads and kGNThreads % C4 == 0 (host side) so that a lane's channel quad is fixed.
     const int b = blockIdx.y, sp = blockIdx.x;
@@ -105,6 +106,8 @@ __global__ __launch_bounds__(kGNThreads) void gn_partial_nhwc_kernel(const float
     const int lo = sp * per, hi = min(HW, lo + per);
     float s = 0.f, ss = 0.f;
     const float *xb = x + (size_t)b * HW * C;
+    // optional per-channel bias added before the statistics (the timestep embedding of a residual block: sige_fused_unet.py:116-117)
+    const float4 cb = cbias ? *reinterpret_cast<const float4 *>(cbias + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     // 16 loads in flight per lane (a rolled loop pays the memory latency once per iteration: the [1,128,256,256]
     // output norm took 19 us as 32 dependent round trips per lane; the host sizes a slice to one round)
     constexpr int U = 16;
@@ -114,6 +117,7 @@ __global__ __launch_bounds__(kGNThreads) void gn_partial_nhwc_kernel(const float
         for (int u = 0; u < U; ++u) {
             const int p = p0 + u * ppb;
             v[u] = p < hi ? *reinterpret_cast<const float4 *>(xb + (size_t)p * C + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < hi) { v[u].x += cb.x; v[u].y += cb.y; v[u].z += cb.z; v[u].w += cb.w; }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -172,9 +176,24 @@ extern "C" size_t sige_hip_group_norm_affine_nhwc_workspace(int B, int C, int H,
     return (size_t)B * groups * gn_nhwc_splits(H * W) * 2;
 }
 
+static int group_norm_affine_nhwc(const float *x, int B, int C, int H, int W, int groups, float eps, const float *gamma,
+                                  const float *beta, const float *cbias, float *workspace, float *scale, float *shift, void *stream);
+
 extern "C" int sige_hip_group_norm_affine_nhwc_f32(const float *x, int B, int C, int H, int W, int groups, float eps,
                                                    const float *gamma, const float *beta, float *workspace,
                                                    float *scale, float *shift, void *stream) {
+    return group_norm_affine_nhwc(x, B, C, H, W, groups, eps, gamma, beta, nullptr, workspace, scale, shift, stream);
+}
+
+extern "C" int sige_hip_group_norm_affine_nhwc_bias_f32(const float *x, int B, int C, int H, int W, int groups, float eps,
+                                                        const float *gamma, const float *beta, const float *channel_bias,
+                                                        float *workspace, float *scale, float *shift, void *stream) {
+    if (!channel_bias || (reinterpret_cast<uintptr_t>(channel_bias) & 15)) return SIGE_HIP_EINVAL;
+    return group_norm_affine_nhwc(x, B, C, H, W, groups, eps, gamma, beta, channel_bias, workspace, scale, shift, stream);
+}
+
+static int group_norm_affine_nhwc(const float *x, int B, int C, int H, int W, int groups, float eps, const float *gamma,
+                                  const float *beta, const float *cbias, float *workspace, float *scale, float *shift, void *stream) {
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || groups <= 0 || C % groups) return SIGE_HIP_EINVAL;
     if (!x || !workspace || !scale || !shift) return SIGE_HIP_EINVAL;
     const int C4 = C / 4;
@@ -182,9 +201,9 @@ extern "C" int sige_hip_group_norm_affine_nhwc_f32(const float *x, int B, int C,
     if (C % 4 || (C / groups) % 4 || C4 > kGNThreads || kGNThreads % C4 || groups > kGNThreads || B > 65535 || (reinterpret_cast<uintptr_t>(x) & 15)) return SIGE_HIP_EUNSUPPORTED;
     const int HW = H * W, splits = gn_nhwc_splits(HW);
     hipStream_t st = as_stream(stream);
-    gn_partial_nhwc_kernel<<<dim3(splits, B), kGNThreads, 0, st>>>(x, C, HW, groups, splits, workspace);
+    gn_partial_nhwc_kernel<<<dim3(splits, B), kGNThreads, 0, st>>>(x, C, HW, groups, splits, workspace, cbias);
     gn_finish_kernel<<<B * groups, 64, 0, st>>>(workspace, splits, B, C, groups, (double)(C / groups) * HW, eps,
-                                                          gamma, beta, scale, shift);
+                                                          gamma, beta, scale, shift, cbias);
     return launch_status(2);
 }
 

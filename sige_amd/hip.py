@@ -118,6 +118,7 @@ _SIGNATURES = {
         _c_int, [_c_vp] * 4 + [_c_int] * 12 + [_c_vp, _c_vp, _c_int, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]),
     "sige_hip_group_norm_affine_nhwc_workspace": (_c_sz, [_c_int] * 5),
     "sige_hip_group_norm_affine_nhwc_f32": (_c_int, [_c_vp] + [_c_int] * 5 + [ctypes.c_float] + [_c_vp] * 6),
+    "sige_hip_group_norm_affine_nhwc_bias_f32": (_c_int, [_c_vp] + [_c_int] * 5 + [ctypes.c_float] + [_c_vp] * 7),
     "sige_hip_conv3x3_small_cout_nhwc_f32": (
         _c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp, _c_int, _c_vp, _c_vp]),
     "sige_hip_conv3x3_small_cout_force_scalar": (_c_int, [_c_int]),
@@ -1236,8 +1237,9 @@ def scatter_with_block_residual_cl(x0, y0, x1, y1, offset, stride, idx0, table0,
     return out
 
 
-def group_norm_affine_cl(x, groups: int, eps: float, gamma=None, beta=None):
-    """Channels-last GroupNorm statistics -> (scale, shift) [B,C,1,1]; None if the shape has no kernel."""
+def group_norm_affine_cl(x, groups: int, eps: float, gamma=None, beta=None, channel_bias=None):
+    """Channels-last GroupNorm statistics -> (scale, shift) [B,C,1,1]; None if the shape has no kernel.
+    `channel_bias` [C]: the statistics are those of x + channel_bias, the affine is for x: GN(x + bias) == x * scale + shift."""
     x = _req_cl(x, "x")
     B, C, H, W = x.shape
     n = int(lib().sige_hip_group_norm_affine_nhwc_workspace(B, C, H, W, groups))
@@ -1249,8 +1251,15 @@ def group_norm_affine_cl(x, groups: int, eps: float, gamma=None, beta=None):
     ga = _p(gamma_keep)
     beta_keep = _vec(beta, "beta")
     be = _p(beta_keep)
-    status = lib().sige_hip_group_norm_affine_nhwc_f32(x.data_ptr(), B, C, H, W, groups, eps, ga, be, buf.data_ptr(),
-                                                       scale.data_ptr(), shift.data_ptr(), _stream(x))
+    cb_keep = _vec(channel_bias, "channel_bias")
+    if cb_keep is not None:
+        if cb_keep.numel() != C:
+            raise RuntimeError("group_norm_affine_cl: channel_bias must have one entry per channel")
+        status = lib().sige_hip_group_norm_affine_nhwc_bias_f32(x.data_ptr(), B, C, H, W, groups, eps, ga, be, cb_keep.data_ptr(),
+                                                                buf.data_ptr(), scale.data_ptr(), shift.data_ptr(), _stream(x))
+    else:
+        status = lib().sige_hip_group_norm_affine_nhwc_f32(x.data_ptr(), B, C, H, W, groups, eps, ga, be, buf.data_ptr(),
+                                                           scale.data_ptr(), shift.data_ptr(), _stream(x))
     if status == UNSUPPORTED:
         return None
     _check(status, "group_norm_affine_cl")

@@ -113,8 +113,9 @@ def _wide_conv(conv: nn.Conv2d, x, x2, scale, shift, activation_name, residual, 
     return out
 
 
-def full_conv2d(conv: nn.Conv2d, x: torch.Tensor, scale=None, shift=None, activation_name: str = "identity") -> torch.Tensor:
-    """`conv(act(x * scale + shift))` of the FULL pass (the pass that produces the caches: sige/nn/base.py:85-86).  On a
+def full_conv2d(conv: nn.Conv2d, x: torch.Tensor, scale=None, shift=None, activation_name: str = "identity",
+                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`conv(act(x * scale + shift)) + residual` of the FULL pass (the pass that produces the caches: sige/nn/base.py:85-86).  On a
     channels-last GPU tensor and a conv whose compute dtype is "f16" / "f16x3" (SIGEModel.set_compute_dtype) it is one
     launch of the dense-layer kernel with the affine + SiLU in its staging path; anywhere else exactly the torch
     expression the reference runs (a SIGEConv2d in full mode is nn.Conv2d.forward)."""
@@ -124,7 +125,7 @@ def full_conv2d(conv: nn.Conv2d, x: torch.Tensor, scale=None, shift=None, activa
         # (exact fp32: the reference's own torch conv, as it was -- unless FULL_PASS_F32_NATIVE asks for the exact-fp32 form of the
         #  dense-layer kernel)
         if getattr(conv, "compute_dtype", "f32") != "f32" or FULL_PASS_F32_NATIVE:
-            out = _wide_conv(conv, x, None, scale, shift, activation_name, None, None, None, None, min_flop=WIDE_MIN_FLOP_FULL_PASS)
+            out = _wide_conv(conv, x, None, scale, shift, activation_name, residual, None, None, None, min_flop=WIDE_MIN_FLOP_FULL_PASS)
         if out is not None:
             return out
     h = x
@@ -133,7 +134,8 @@ def full_conv2d(conv: nn.Conv2d, x: torch.Tensor, scale=None, shift=None, activa
     if shift is not None:
         h = h + shift
     h = _act(h, activation_name)
-    return nn.Conv2d.forward(conv, h)
+    h = nn.Conv2d.forward(conv, h)
+    return h if residual is None else h + residual
 
 
 def _packed(conv: nn.Conv2d, block, channels_last: bool = True):
@@ -276,16 +278,23 @@ def input_conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     return conv(x)
 
 
-def group_norm_affine(x: torch.Tensor, norm: nn.GroupNorm) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(scale, shift) as [B,C,1,1] with GroupNorm(x) == x*scale + shift."""
+def group_norm_affine(x: torch.Tensor, norm: nn.GroupNorm, channel_bias: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(scale, shift) as [B,C,1,1] with GroupNorm(x) == x*scale + shift.  `channel_bias` [C]: GroupNorm(x + channel_bias) ==
+    x*scale + shift (a residual block's norm of h + temb without materialising the sum)."""
     if x.is_cuda and x.dtype == torch.float32:
         from .. import hip
 
         if hip.is_cl(x):
-            r = hip.group_norm_affine_cl(x, norm.num_groups, norm.eps, norm.weight, norm.bias)
+            r = hip.group_norm_affine_cl(x, norm.num_groups, norm.eps, norm.weight, norm.bias, channel_bias)
             if r is not None:
                 return r
+        if channel_bias is not None:
+            sc, sh = group_norm_affine(x + channel_bias.reshape(1, -1, 1, 1), norm)
+            return sc, sh + channel_bias.reshape(1, -1, 1, 1) * sc
         return hip.group_norm_affine(x, norm.num_groups, norm.eps, norm.weight, norm.bias)
+    if channel_bias is not None:
+        sc, sh = group_norm_affine(x + channel_bias.reshape(1, -1, 1, 1), norm)
+        return sc, sh + channel_bias.reshape(1, -1, 1, 1) * sc
     B, C = x.shape[:2]
     g = norm.num_groups
     var, mean = torch.var_mean(x.reshape(B, g, -1), dim=2, unbiased=False)

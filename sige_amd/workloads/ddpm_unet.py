@@ -75,14 +75,18 @@ def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
     return F.pad(emb, (0, 1)) if dim % 2 else emb
 
 
-def norm_affine(x: torch.Tensor, norm: nn.GroupNorm, fast: bool = False):
+def norm_affine(x: torch.Tensor, norm: nn.GroupNorm, fast: bool = False, cbias: Optional[torch.Tensor] = None):
     """Per-channel (scale, shift) with GroupNorm(x) == x * scale + shift, batch 1.  `fast` (the full pass on the fp16 matrix
-    cores): the library's split reduction (fp64 combine) instead of torch's var_mean + five elementwise kernels."""
+    cores): the library's split reduction (fp64 combine) instead of torch's var_mean + five elementwise kernels.
+    `cbias` [C]: the statistics are those of x + cbias (the timestep embedding); with `fast` the returned affine is for x itself
+    (GroupNorm(x + cbias) == x * scale + shift), otherwise for x + cbias as before -- the caller folds the bias."""
     n, c, h, w = x.shape
     assert n == 1, "SIGE caches one original image"
     if fast and x.is_cuda:
-        sc, sh = group_norm_affine(x, norm)
+        sc, sh = group_norm_affine(x, norm, cbias)
         return sc.reshape(-1), sh.reshape(-1)
+    if cbias is not None:
+        x = x + cbias.reshape(1, -1, 1, 1)
     g = norm.num_groups
     var, mean = torch.var_mean(x.reshape(g, -1), dim=1, unbiased=False)
     inv = torch.rsqrt(var + norm.eps).repeat_interleave(c // g)
@@ -291,14 +295,23 @@ class ResBlock(SIGEModule, _TwinProducer):
         if self.sparse_main:
             h = self.scatter_gather(h)
         te = temb.reshape(-1)
-        s2, t2 = norm_affine(h + _as4(te), self.norm2, fast)
-        t2 = t2 + te * s2  # fold the timestep-embedding add into the cached shift
+        if fast and h.is_cuda:
+            # statistics of h + temb and the embedding folded into the shift in ONE pair of launches (no h + temb tensor)
+            s2, t2 = norm_affine(h, self.norm2, True, cbias=te.contiguous())
+        else:
+            s2, t2 = norm_affine(h + _as4(te), self.norm2, fast)
+            t2 = t2 + te * s2  # fold the timestep-embedding add into the cached shift
         self._drop_twin_links()  # (twins written for the previous affine are stale)
         self.affine[self.cache_id] = tuple(_as4(v).contiguous() for v in (s1, t1, s2, t2))
         if self.sparse_main and self.preactivate:
             self.scatter_gather.cache_activated(_as4(s2), _as4(t2))
-        h = full_conv2d(self.conv2, h, _as4(s2), _as4(t2), "swish")  # conv2(silu(h * s2 + t2))
-        return self.scatter(h, skip) if self.sparse_main else h + skip
+        if self.sparse_main and self.sparse_shortcut:
+            # (ScatterWithBlockResidual caches conv2's output and the shortcut separately)
+            h = full_conv2d(self.conv2, h, _as4(s2), _as4(t2), "swish")  # conv2(silu(h * s2 + t2))
+            return self.scatter(h, skip)
+        # conv2(silu(h * s2 + t2)) + skip in one launch: a plain Scatter caches the SUM (sige/nn/scatter.py:31-37)
+        h = full_conv2d(self.conv2, h, _as4(s2), _as4(t2), "swish", residual=skip)
+        return self.scatter(h) if self.sparse_main else h
 
     def _sparse(self, x):
         s1, t1, s2, t2 = self.affine[self.cache_id]

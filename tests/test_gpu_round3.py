@@ -481,3 +481,15 @@ def test_affine_act_cl_equals_torch(hip, B, C, H, W, act):
     torch.testing.assert_close(got, want, rtol=2e-6, atol=1e-6)
     out = torch.empty_like(x)
     assert hip.affine_act_cl(x, sc, sh, act, out=out) is out and torch.equal(out, got)
+
+
+@pytest.mark.parametrize("shape,groups", [((1, 128, 64, 64), 32), ((1, 512, 16, 16), 32), ((2, 256, 8, 24), 32)])
+def test_group_norm_affine_with_channel_bias(hip, shape, groups):
+    """GroupNorm statistics of x + bias[c] without materialising the sum (a residual block's norm of h + temb in the full pass):
+    x * scale + shift == GroupNorm(x + bias)."""
+    torch.manual_seed(shape[1])
+    x = _cl(torch.randn(*shape, device=DEV) * 2 + 0.5)
+    gamma, beta, cb = (torch.randn(shape[1], device=DEV) for _ in range(3))
+    sc, sh = hip.group_norm_affine_cl(x, groups, 1e-6, gamma, beta, cb)
+    want = F.group_norm((x + cb.view(1, -1, 1, 1)).double(), groups, gamma.double(), beta.double(), 1e-6).float()
+    torch.testing.assert_close(x * sc + sh, want, rtol=0, atol=2e-5)
