@@ -574,6 +574,7 @@ class DDPMSparseUNet(SIGEModel):
         for m in self.modules():
             if isinstance(m, (ResBlock, AttnBlock, Upsample, Downsample)):
                 m.plain = plain
+        self.conv_in._plain_model = plain  # (the stock baseline keeps torch's first / last conv and GroupNorm)
 
     def _temb(self, t):
         if self.mode != "full":
@@ -588,7 +589,13 @@ class DDPMSparseUNet(SIGEModel):
         temb = self._temb(t)
         nxt = (lambda: temb.pop(0)) if temb is not None else (lambda: None)
 
-        h0 = input_conv2d(self.conv_in, x) if self.mode == "sparse" else self.conv_in(x)
+        from ..nn import dense as _dense
+
+        # the full pass on the library's kernels (compute dtype "f16" / "f16x3", or dense.FULL_PASS_F32_NATIVE) also takes the
+        # library's first / last conv and output norm -- the same launches the sparse pass uses
+        native_full = self.mode == "full" and x.is_cuda and not getattr(self.conv_in, "_plain_model", False) and (
+            getattr(self.conv_out, "compute_dtype", "f32") != "f32" or _dense.FULL_PASS_F32_NATIVE)
+        h0 = input_conv2d(self.conv_in, x) if (self.mode == "sparse" or native_full) else self.conv_in(x)
         if x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous():
             h0 = h0.contiguous(memory_format=torch.channels_last)  # (MIOpen may hand back NCHW for 3 input channels)
         hs = [h0]
@@ -613,7 +620,7 @@ class DDPMSparseUNet(SIGEModel):
                     h = stage.attn[i](h)
             if lvl != 0:
                 h = stage.upsample(h)
-        if self.mode == "sparse":
+        if self.mode == "sparse" or native_full:
             # the output norm is a TRUE GroupNorm of the edited activation (sige_fused_unet.py:430-432)
             so, to = group_norm_affine(h, self.norm_out)
             return fused_conv2d(self.conv_out, h, so, to, "swish")
