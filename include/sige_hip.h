@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SIGE_HIP_VERSION 305 /* 0.3.0: round 3 -- dense-layer convs on the fp16 matrix cores (fp16 / split-fp16 operands) */
+#define SIGE_HIP_VERSION 306 /* 0.3.0: round 3 -- dense-layer convs on the fp16 matrix cores (fp16 / split-fp16 operands) */
 
 enum {
     SIGE_HIP_OK = 0,
@@ -132,6 +132,11 @@ int sige_hip_scatter_gather_f32(const float *x, const float *y, int B, int C, in
                                 const float *scale, int scaleB, int scaleC, int scaleH, int scaleW,
                                 const float *shift, int shiftB, int shiftC, int shiftH, int shiftW,
                                 int activation, int activation_first, float *out, void *stream);
+/* Tuning knob (bit mask): 1 = scatter_gather always uses the element form (one load per output element); 2 = never the
+ * grouped row form; 0 (default) = the row form for 4x4 / 5x5 / 6x6 windows (one lane per (channel, window row), the middle
+ * four pixels with one 16-byte load), grouped (8 consecutive tiles per workgroup, halo pixels exchanged through LDS) for
+ * 6x6 windows over 4x4 tiles when there are enough tiles. */
+int sige_hip_scatter_gather_force_elements(int element_form);
 
 /* ---- mask pipeline : replaces sige.utils.compute_difference_mask / dilate_mask /
  * downsample_mask (sige/utils.py:74-85, 40-71, 88-118) for masks that live on the GPU,

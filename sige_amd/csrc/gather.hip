@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kGatherThreads) void gather_rows_kernel(GatherArgs 
                     for (int i = 0; i < TS; ++i) {
                         float z = v[i];
                         if (!ACT_FIRST) { if (a.scale.data) z = sv * z; if (a.shift.data) z = tv + z; }
-                        z = activate<ACT>(z);
+                        z = activate<ACT, ACT_FIRST>(z);
                         if (ACT_FIRST) { if (a.scale.data) z = sv * z; if (a.shift.data) z = tv + z; }
                         v[i] = z;
                     }
@@ -190,7 +190,12 @@ __global__ __launch_bounds__(kGatherThreads) void gather_rows_grouped_kernel(Gat
     extern __shared__ __attribute__((aligned(16))) float g_lds[];
     __shared__ int s_org[kGroup][2];
     const int tiles = a.B * a.N;
-    const int tile0 = blockIdx.x * kGroup;
+    // workgroup b runs on XCD b % 8: every XCD takes a contiguous eighth of the groups, so that the rows two vertically
+    // adjacent groups share are fetched into ONE L2 (the grid is padded to 8 * per_xcd)
+    const int ngroups = (tiles + kGroup - 1) / kGroup, per_xcd = (ngroups + 7) / 8;
+    const int group = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (group >= ngroups) return;
+    const int tile0 = group * kGroup;
     const int c0 = blockIdx.y * a.cchunk;
     const int cc = min(a.cchunk, a.C - c0);
     const int slab = cc * TR * TS;            // floats of one tile's output slab (contiguous in HBM)
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(kGatherThreads) void gather_rows_grouped_kernel(Gat
                     for (int i = 0; i < TS; ++i) {
                         float z = v[i];
                         if (!ACT_FIRST) { if (a.scale.data) z = sv * z; if (a.shift.data) z = tv + z; }
-                        z = activate<ACT>(z);
+                        z = activate<ACT, ACT_FIRST>(z);
                         if (ACT_FIRST) { if (a.scale.data) z = sv * z; if (a.shift.data) z = tv + z; }
                         v[i] = z;
                     }
@@ -266,6 +271,287 @@ __global__ __launch_bounds__(kGatherThreads) void gather_rows_grouped_kernel(Gat
 }
 
 
+// ---- scatter_gather, row form (round 3) -----------------------------------------------------------------------------
+// The element form above (gather_kernel<MAPPED>) issues one 4-byte load per output element plus, with an affine, two more
+// for its scale / shift: 3 loads and ~10 integer instructions per element -- 0.27 of the HBM peak, bound by instruction
+// issue, not by bytes.  The sources are far more regular than that: conv-1's tiles are compact [blk][C][Rx][Sx] slabs on
+// the stride grid, so the middle four pixels of a window row are FOUR CONSECUTIVE floats of one tile (the window's own
+// tile for the inner rows, the neighbour above / below for the halo rows) or, where no tile covers them, of one row of
+// the cached tensor.  One lane = one (channel, window row): the pixel table row comes from LDS, the middle four pixels
+// with ONE 16-byte load when the table says they are consecutive, the remaining (halo column) pixels one by one, the
+// per-(batch, channel) affine once per row; consecutive lanes store consecutive 4*TS-byte pieces of the output slab.
+// Same values, same rounding (the same affine / activation code as the element form).
+constexpr int kSgRowsChannels = 128;  // channels per workgroup, at most (3 full passes of the 256 lanes over a 6-row window)
+
+template <int TR, int TS, int ACT, bool ACT_FIRST>
+__global__ __launch_bounds__(kGatherThreads) void scatter_gather_rows_kernel(GatherArgs a) {
+    static_assert(TS >= 4 && TS <= 6, "row forms for 4-, 5- and 6-wide windows");
+    constexpr int RS = TR * TS, V0 = (TS - 4) / 2;  // the vector part: window columns [V0, V0 + 4)
+    __shared__ int s_src[RS];
+    const int tile = blockIdx.x;  // b*N + n
+    const int b = tile / a.N, n = tile - b * a.N;
+    const int c0 = blockIdx.y * a.cchunk;
+    const int cc = min(a.cchunk, a.C - c0);
+    const int h0 = a.idx[2 * n], w0 = a.idx[2 * n + 1];
+    for (int p = threadIdx.x; p < RS; p += kGatherThreads) {
+        const int r = p / TS, s = p - r * TS;
+        const int h = h0 + r, w = w0 + s;
+        int src = -2;
+        if (h >= 0 && h < a.H && w >= 0 && w < a.W) {
+            const int32_t *m = a.map + 3 * ((size_t)h * a.W + w);
+            const int blk = m[0];
+            src = blk >= 0 ? blk * a.C * a.RxSx + m[1] * a.Sx + m[2] : -1;
+        }
+        s_src[p] = src;
+    }
+    __syncthreads();
+    const size_t HW = (size_t)a.H * a.W;
+    const float *xb = a.x + (size_t)b * a.N * a.C * a.RxSx;
+    const float *yb = a.y + (size_t)b * a.C * HW;
+    float *ob = a.out + ((size_t)tile * a.C + c0) * RS;
+    const bool plain = ACT == SIGE_HIP_ACT_IDENTITY && !a.scale.data && !a.shift.data;
+    const bool row_uniform = (a.scale.sh | a.scale.sw | a.shift.sh | a.shift.sw) == 0;  // (absent operands have zero strides)
+    // All loads of the lane's (up to IT) rows are issued before the first store: written as a plain loop the stores of one
+    // row order the loads of the next behind them (the compiler cannot rule out aliasing), and every pass then pays a full
+    // memory round trip of its own -- the kernel is bound by that latency, not by bytes.
+    constexpr int IT = (kSgRowsChannels * TR + kGatherThreads - 1) / kGatherThreads;
+    int src[IT][TS];
+    float v[IT][TS], sv[IT], tv[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int u = threadIdx.x + it * kGatherThreads;
+        const bool live = u < cc * TR;
+        const int cl = live ? u / TR : 0, r = live ? u - cl * TR : 0;
+        const int c = c0 + cl, h = h0 + r;
+#pragma unroll
+        for (int i = 0; i < TS; ++i) { src[it][i] = live ? s_src[r * TS + i] : -2; v[it][i] = 0.0f; }
+        const float *xc = xb + (size_t)c * a.RxSx;
+        const float *yr = yb + (long)c * (long)HW + (long)h * a.W + w0;  // (dereferenced only where the table says "inside, no tile")
+        const int s0 = src[it][V0];
+        const bool vx = s0 >= 0 && src[it][V0 + 1] == s0 + 1 && src[it][V0 + 2] == s0 + 2 && src[it][V0 + 3] == s0 + 3;
+        const bool vy = s0 == -1 && src[it][V0 + 1] == -1 && src[it][V0 + 2] == -1 && src[it][V0 + 3] == -1;
+        if (vx || vy) {
+            const f4u q = *reinterpret_cast<const f4u *>(vx ? xc + s0 : yr + V0);
+            v[it][V0] = q[0]; v[it][V0 + 1] = q[1]; v[it][V0 + 2] = q[2]; v[it][V0 + 3] = q[3];
+        }
+#pragma unroll
+        for (int i = 0; i < TS; ++i) {
+            if ((vx || vy) && i >= V0 && i < V0 + 4) continue;
+            if (src[it][i] >= 0) v[it][i] = xc[src[it][i]];
+            else if (src[it][i] == -1) v[it][i] = yr[i];
+        }
+        sv[it] = 1.0f; tv[it] = 0.0f;
+        if (!plain && row_uniform && live) {
+            if (a.scale.data) sv[it] = bcast_load(a.scale, b, c, 0, 0);
+            if (a.shift.data) tv[it] = bcast_load(a.shift, b, c, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int u = threadIdx.x + it * kGatherThreads;
+        if (u >= cc * TR) break;
+        const int cl = u / TR, r = u - cl * TR;
+        const int c = c0 + cl, h = h0 + r;
+        if (!plain && row_uniform) {
+#pragma unroll
+            for (int i = 0; i < TS; ++i) {
+                float z = v[it][i];
+                if (!ACT_FIRST) { if (a.scale.data) z = sv[it] * z; if (a.shift.data) z = tv[it] + z; }
+                z = activate<ACT, ACT_FIRST>(z);
+                if (ACT_FIRST) { if (a.scale.data) z = sv[it] * z; if (a.shift.data) z = tv[it] + z; }
+                v[it][i] = src[it][i] != -2 ? z : 0.0f;  // (outside the image: 0, not affine-transformed -- scatter_gather.cpp:27-30)
+            }
+        } else if (!plain) {
+#pragma unroll
+            for (int i = 0; i < TS; ++i)
+                if (src[it][i] != -2) v[it][i] = affine_act<ACT, ACT_FIRST>(v[it][i], a.scale, a.shift, b, c, h, w0 + i);
+        }
+        float *dst = ob + (size_t)u * TS;
+        *reinterpret_cast<f4u *>(dst) = f4u{v[it][0], v[it][1], v[it][2], v[it][3]};
+        if (TS == 6) *reinterpret_cast<f2u *>(dst + 4) = f2u{v[it][4], v[it][5]};
+        if (TS == 5) dst[4] = v[it][4];
+    }
+}
+
+// ---- scatter_gather, grouped row form (round 3): 6x6 windows over 4x4 conv-1 tiles ------------------------------------------
+// What bounds the row form is the number of cache lines its loads touch, not bytes: a window draws on NINE conv-1 tiles
+// (its own, four edge neighbours for a row / column of four pixels each, four corner neighbours for ONE pixel each), every
+// one of them a separate 64-byte slab per channel -- nine line requests per channel pair for 36 output pixels (measured: the
+// two halo-column loads cost as much as two 16-byte loads of the middle pixels, 7 us each of a 38 us launch).  But the
+// halo column of a window row IS the first / last of the four middle pixels of the same row of the horizontally adjacent
+// window (windows overlap by two pixels), and index lists come row-major sorted from reduce_mask, so that window is usually
+// the next tile of the list.  One workgroup takes kSgGroup consecutive tiles x 16 channels; every lane loads the middle
+// four pixels of its (tile, channel, row) as before and leaves the outer two in a small LDS exchange array, from which the
+// neighbouring tile's lane takes its halo pixel -- three line requests per channel pair and tile instead of nine.  Nothing
+// is assumed about adjacency: a halo pixel is taken from the neighbour only where the scatter map says both read the same
+// element; everything else (group ends, holes in the grid, the cached tensor) is loaded as in the row form.
+// Same values, same rounding as the element form.
+constexpr int kSgGroup = 8, kSgGroupCh = 16;
+
+template <int ACT, bool ACT_FIRST, int G = kSgGroup, int CCH = kSgGroupCh>
+__global__ __launch_bounds__(kGatherThreads) void scatter_gather_rows_grouped_kernel(GatherArgs a) {
+    constexpr int TR = 6, TS = 6, RS = 36, V0 = 1, ROWS = CCH * TR;
+    __shared__ int s_src[G][RS];    // -2 outside the image (0) | -1 the cached tensor | >= 0 offset in the batch's conv-1 tiles
+    __shared__ int s_org[G][2], s_tb[G];
+    // per window row: 1 the left halo pixel = the last middle pixel of the previous tile's row | 2 the right one = the first
+    // middle pixel of the next tile's | 4 the middle four are consecutive conv-1 floats | 8 ... of the cached tensor
+    __shared__ int s_nb[G][TR];
+    __shared__ float2 s_ex[G][ROWS];  // (first, last) middle pixel of every (tile, channel, row)
+    const int tiles = a.B * a.N;
+    // workgroup b runs on XCD b % 8: every XCD takes a contiguous eighth of the groups, so that the conv-1 tiles two groups
+    // share (the rows above / below, the slab past a group end) are fetched into ONE L2 (the grid is padded to 8 * per_xcd)
+    const int ngroups = (tiles + G - 1) / G, per_xcd = (ngroups + 7) / 8;
+    const int group = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (group >= ngroups) return;
+    const int tile0 = group * G;
+    const int glast = min(G, tiles - tile0) - 1;  // last live tile of the group
+    const int c0 = blockIdx.y * CCH;
+    const int cc = min(CCH, a.C - c0);
+    const int tid = threadIdx.x;
+    if (tid < G) {
+        const int t = min(tile0 + tid, tiles - 1);
+        const int b = t / a.N, n = t - b * a.N;
+        s_tb[tid] = b;
+        s_org[tid][0] = a.idx[2 * n];
+        s_org[tid][1] = a.idx[2 * n + 1];
+    }
+    __syncthreads();
+    {
+        constexpr int NQ = (G * RS + kGatherThreads - 1) / kGatherThreads;
+        int32_t m0[NQ], m1[NQ], m2[NQ];
+        bool in[NQ];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {  // (all map entries of a lane in flight together)
+            const int q = min(tid + k * kGatherThreads, G * RS - 1);
+            const int g = q / RS, p = q - g * RS;
+            const int r = p / TS, s = p - r * TS;
+            const int h = s_org[g][0] + r, w = s_org[g][1] + s;
+            in[k] = g <= glast && h >= 0 && h < a.H && w >= 0 && w < a.W;
+            const int32_t *m = a.map + 3 * (in[k] ? (size_t)h * a.W + w : 0);
+            m0[k] = m[0]; m1[k] = m[1]; m2[k] = m[2];
+        }
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const int q = tid + k * kGatherThreads;
+            if (q < G * RS) (&s_src[0][0])[q] = !in[k] ? -2 : (m0[k] >= 0 ? m0[k] * a.C * 16 + m1[k] * 4 + m2[k] : -1);
+        }
+    }
+    __syncthreads();
+    if (tid < G * TR) {
+        const int g = tid / TR, r = tid - g * TR;
+        auto mid = [&](int gg) {  // 4: consecutive conv-1 floats | 8: the cached tensor | 0: mixed
+            const int *sp = &s_src[gg][r * TS + V0];
+            if (sp[0] >= 0 && sp[1] == sp[0] + 1 && sp[2] == sp[0] + 2 && sp[3] == sp[0] + 3) return 4;
+            if (sp[0] == -1 && sp[1] == -1 && sp[2] == -1 && sp[3] == -1) return 8;
+            return 0;
+        };
+        int f = mid(g);
+        const int *me = &s_src[g][r * TS];
+        // (same batch, both conv-1 sourced, the SAME element: codes are offsets inside one batch's tiles)
+        if (g > 0 && s_tb[g - 1] == s_tb[g] && me[0] >= 0 && mid(g - 1) == 4 && me[0] == s_src[g - 1][r * TS + V0 + 3]) f |= 1;
+        if (g < glast && s_tb[g + 1] == s_tb[g] && me[TS - 1] >= 0 && mid(g + 1) == 4 && me[TS - 1] == s_src[g + 1][r * TS + V0]) f |= 2;
+        s_nb[g][r] = f;
+    }
+    __syncthreads();
+    const size_t HW = (size_t)a.H * a.W;
+    const bool plain = ACT == SIGE_HIP_ACT_IDENTITY && !a.scale.data && !a.shift.data;
+    const bool row_uniform = (a.scale.sh | a.scale.sw | a.shift.sh | a.shift.sw) == 0;  // (absent operands have zero strides)
+    constexpr int IT = G * ROWS / kGatherThreads;
+    float v[IT][TS], sv[IT], tv[IT];
+    int fl[IT];       // the row's s_nb flags | 16 the lane has a row in this pass
+    int oob[IT];      // bit i: pixel i lies outside the image (stays 0, not affine-transformed -- scatter_gather.cpp:27-30)
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int u = tid + it * kGatherThreads;
+        const int g = u / ROWS, rem = u - g * ROWS;
+        const int cl = rem / TR, r = rem - cl * TR;
+        fl[it] = 0; oob[it] = 0; sv[it] = 1.0f; tv[it] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < TS; ++i) v[it][i] = 0.0f;
+        if (g > glast || cl >= cc) continue;
+        const int bg = s_tb[g];
+        const int c = c0 + cl, h = s_org[g][0] + r, w0 = s_org[g][1];
+        const int f = s_nb[g][r];
+        fl[it] = f | 16;
+        const float *xc = a.x + ((size_t)bg * a.N * a.C + c) * 16;
+        const float *yr = a.y + ((long)bg * a.C + c) * (long)HW + (long)h * a.W + w0;  // (dereferenced only where the table says "inside, no tile")
+        int src[TS];
+#pragma unroll
+        for (int i = 0; i < TS; ++i) { src[i] = s_src[g][r * TS + i]; if (src[i] == -2) oob[it] |= 1 << i; }
+        if (f & 12) {
+            const f4u q = *reinterpret_cast<const f4u *>((f & 4) ? xc + src[V0] : yr + V0);
+            v[it][V0] = q[0]; v[it][V0 + 1] = q[1]; v[it][V0 + 2] = q[2]; v[it][V0 + 3] = q[3];
+            if (f & 4) s_ex[g][rem] = make_float2(q[0], q[3]);
+        }
+#pragma unroll
+        for (int i = 0; i < TS; ++i) {
+            if ((f & 12) && i >= V0 && i < V0 + 4) continue;
+            if ((i == 0 && (f & 1)) || (i == TS - 1 && (f & 2))) continue;  // (from the neighbour's lane, below)
+            if (src[i] >= 0) v[it][i] = xc[src[i]];
+            else if (src[i] == -1) v[it][i] = yr[i];
+        }
+        if (!plain && row_uniform) {
+            if (a.scale.data) sv[it] = bcast_load(a.scale, bg, c, 0, 0);
+            if (a.shift.data) tv[it] = bcast_load(a.shift, bg, c, 0, 0);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        if (!(fl[it] & 16)) continue;
+        const int u = tid + it * kGatherThreads;
+        const int g = u / ROWS, rem = u - g * ROWS;
+        const int cl = rem / TR, r = rem - cl * TR;
+        if (fl[it] & 1) v[it][0] = s_ex[g - 1][rem].y;
+        if (fl[it] & 2) v[it][TS - 1] = s_ex[g + 1][rem].x;
+        const int c = c0 + cl;
+        if (!plain && row_uniform) {
+#pragma unroll
+            for (int i = 0; i < TS; ++i) {
+                float z = v[it][i];
+                if (!ACT_FIRST) { if (a.scale.data) z = sv[it] * z; if (a.shift.data) z = tv[it] + z; }
+                z = activate<ACT, ACT_FIRST>(z);
+                if (ACT_FIRST) { if (a.scale.data) z = sv[it] * z; if (a.shift.data) z = tv[it] + z; }
+                v[it][i] = (oob[it] >> i) & 1 ? 0.0f : z;
+            }
+        } else if (!plain) {
+            const int h = s_org[g][0] + r, w0 = s_org[g][1];
+#pragma unroll
+            for (int i = 0; i < TS; ++i)
+                if (!((oob[it] >> i) & 1)) v[it][i] = affine_act<ACT, ACT_FIRST>(v[it][i], a.scale, a.shift, s_tb[g], c, h, w0 + i);
+        }
+        float *dst = a.out + ((size_t)(tile0 + g) * a.C + c) * RS + r * TS;
+        *reinterpret_cast<f4u *>(dst) = f4u{v[it][0], v[it][1], v[it][2], v[it][3]};
+        *reinterpret_cast<f2u *>(dst + 4) = f2u{v[it][4], v[it][5]};
+    }
+}
+
+template <int G, int CCH>
+static void launch_sg_rows_grouped_as(const GatherArgs &a, int act, bool first, hipStream_t st) {
+    dim3 blk(kGatherThreads), grid(8 * ceil_div(ceil_div(a.B * a.N, G), 8), ceil_div(a.C, CCH));
+    if (act == SIGE_HIP_ACT_SWISH) {
+        if (first) scatter_gather_rows_grouped_kernel<SIGE_HIP_ACT_SWISH, true, G, CCH><<<grid, blk, 0, st>>>(a);
+        else scatter_gather_rows_grouped_kernel<SIGE_HIP_ACT_SWISH, false, G, CCH><<<grid, blk, 0, st>>>(a);
+    } else {
+        scatter_gather_rows_grouped_kernel<SIGE_HIP_ACT_IDENTITY, false, G, CCH><<<grid, blk, 0, st>>>(a);
+    }
+}
+
+static void launch_sg_rows_grouped(const GatherArgs &a, int act, bool first, hipStream_t st) {
+    launch_sg_rows_grouped_as<kSgGroup, kSgGroupCh>(a, act, first, st);
+}
+
+template <int TR, int TS>
+static void launch_sg_rows(const GatherArgs &a, int act, bool first, dim3 grid, hipStream_t st) {
+    dim3 blk(kGatherThreads);
+    if (act == SIGE_HIP_ACT_SWISH) {
+        if (first) scatter_gather_rows_kernel<TR, TS, SIGE_HIP_ACT_SWISH, true><<<grid, blk, 0, st>>>(a);
+        else scatter_gather_rows_kernel<TR, TS, SIGE_HIP_ACT_SWISH, false><<<grid, blk, 0, st>>>(a);
+    } else {
+        scatter_gather_rows_kernel<TR, TS, SIGE_HIP_ACT_IDENTITY, false><<<grid, blk, 0, st>>>(a);
+    }
+}
+
 template <int TR, int TS>
 static void launch_rows(const GatherArgs &a, int act, bool first, dim3 grid, hipStream_t st) {
     dim3 blk(kGatherThreads);
@@ -279,7 +565,7 @@ static void launch_rows(const GatherArgs &a, int act, bool first, dim3 grid, hip
 
 template <int TR, int TS>
 static void launch_rows_grouped(const GatherArgs &a, int act, bool first, hipStream_t st) {
-    dim3 blk(kGatherThreads), grid(ceil_div(a.B * a.N, kGroup), ceil_div(a.C, a.cchunk));
+    dim3 blk(kGatherThreads), grid(8 * ceil_div(ceil_div(a.B * a.N, kGroup), 8), ceil_div(a.C, a.cchunk));
     const size_t lds = (size_t)kGroup * (a.cchunk * TR * TS + 4) * sizeof(float);
     if (act == SIGE_HIP_ACT_SWISH) {
         if (first) gather_rows_grouped_kernel<TR, TS, SIGE_HIP_ACT_SWISH, true><<<grid, blk, lds, st>>>(a);
@@ -302,6 +588,8 @@ static void launch_act(const GatherArgs &a, int act, bool first, dim3 grid, hipS
 }
 
 static bool g_gather_grouped = true;  // sige_hip_gather_force_rows (benchmarking): false = always the one-tile row form
+static bool g_sg_grouped = true;      // (same knob, bit 1: no grouped form)
+static bool g_sg_rows = true;         // sige_hip_scatter_gather_force_elements (benchmarking / tests): false = the element form
 
 template <bool MAPPED>
 static int launch(GatherArgs a, int act, bool first, hipStream_t st) {
@@ -315,6 +603,23 @@ static int launch(GatherArgs a, int act, bool first, hipStream_t st) {
     if (cchunk < 4) cchunk = 4;
     a.cchunk = cchunk;
     dim3 grid(tiles, ceil_div(a.C, cchunk));
+    if (MAPPED && g_sg_rows && a.bH == a.bW && a.bH >= 4 && a.bH <= 6) {
+        // 6x6 windows over 4x4 tiles with enough tiles to fill the chip in groups: the grouped form (halo pixels through LDS)
+        if (g_sg_grouped && a.bH == 6 && a.RxSx == 16 && a.Sx == 4 && (long)ceil_div(tiles, kSgGroup) * ceil_div(a.C, kSgGroupCh) >= 512) {
+            launch_sg_rows_grouped(a, act, first, st);
+            return launch_status();
+        }
+        // row form: one lane per (channel, window row); 128 channels per workgroup (3 full passes of the 256 lanes for a 6-row
+        // window), but >= ~512 workgroups when the problem allows
+        int cch = kSgRowsChannels;
+        while (cch > 8 && (long)tiles * ceil_div(a.C, cch) < 512) cch /= 2;
+        a.cchunk = cch;
+        dim3 rgrid(tiles, ceil_div(a.C, cch));
+        if (a.bH == 6) launch_sg_rows<6, 6>(a, act, first, rgrid, st);
+        else if (a.bH == 5) launch_sg_rows<5, 5>(a, act, first, rgrid, st);
+        else launch_sg_rows<4, 4>(a, act, first, rgrid, st);
+        return launch_status();
+    }
     if (!MAPPED && a.bH == a.bW && a.bH >= 4 && a.bH <= 6) {
         // enough tiles to fill the chip in groups of kGroup: the grouped row form (32 channels per workgroup = 37 KB of LDS)
         if (g_gather_grouped && (long)ceil_div(tiles, kGroup) * ceil_div(a.C, 32) >= 512) {
@@ -354,6 +659,12 @@ using namespace sige;
 
 extern "C" int sige_hip_gather_force_rows(int one_tile_rows) {
     g_gather_grouped = one_tile_rows == 0;
+    return SIGE_HIP_OK;
+}
+
+extern "C" int sige_hip_scatter_gather_force_elements(int element_form) {
+    g_sg_rows = (element_form & 1) == 0;
+    g_sg_grouped = (element_form & 2) == 0;
     return SIGE_HIP_OK;
 }
 

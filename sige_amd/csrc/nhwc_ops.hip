@@ -18,7 +18,7 @@ __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 
 // per-(batch, channel) affine then activation on 4 consecutive channels; scale, then shift:
-// two separately rounded ops (gather.cpp:33-53; -ffp-contract=off), exact expf / division SiLU
+// two separately rounded ops (gather.cpp:33-53; -ffp-contract=off); SiLU as in common.hpp (~3e-7 relative)
 template <int ACT>
 __device__ __forceinline__ float4 affine_act4(float4 z, const float *scale, const float *shift, int so, int c) {
     if (scale) { const float4 s = ld4(scale + so + c); z.x = s.x * z.x; z.y = s.y * z.y; z.z = s.z * z.z; z.w = s.w * z.w; }

@@ -74,6 +74,7 @@ _SIGNATURES = {
     "sige_hip_block_conv_force_waves": (_c_int, [_c_int]),
     "sige_hip_block_conv_force_ksplit": (_c_int, [_c_int]),
     "sige_hip_gather_force_rows": (_c_int, [_c_int]),
+    "sige_hip_scatter_gather_force_elements": (_c_int, [_c_int]),
     "sige_hip_block_conv_force_ksplit_pass": (_c_int, [_c_int]),
     "sige_hip_conv_pair_begin": (_c_int, []),
     "sige_hip_conv_pair_end": (_c_int, []),
@@ -715,6 +716,12 @@ def conv_force_ksplit(ksplit: int = 0):
 def gather_force_rows(one_tile_rows: bool = False):
     """Benchmark knob: the NCHW gather's one-tile row form always (True) instead of the grouped form where it applies."""
     _check(lib().sige_hip_gather_force_rows(int(bool(one_tile_rows))), "gather_force_rows")
+
+
+def scatter_gather_force_elements(element_form=False):
+    """Benchmark / test knob: the NCHW scatter_gather's element form always (True / 1), or its one-tile row form (2: never the
+    grouped form), instead of the automatic choice (False / 0)."""
+    _check(lib().sige_hip_scatter_gather_force_elements(int(element_form)), "scatter_gather_force_elements")
 
 
 def conv_force_ksplit_pass(second_pass: bool = False):

@@ -493,3 +493,45 @@ def test_group_norm_affine_with_channel_bias(hip, shape, groups):
     sc, sh = hip.group_norm_affine_cl(x, groups, 1e-6, gamma, beta, cb)
     want = F.group_norm((x + cb.view(1, -1, 1, 1)).double(), groups, gamma.double(), beta.double(), 1e-6).float()
     torch.testing.assert_close(x * sc + sh, want, rtol=0, atol=2e-5)
+
+
+# ---- NCHW scatter_gather, row form (one lane per (channel, window row)) ------------------------------------------------
+@pytest.mark.parametrize("bsize,k,B,C,res,act,first,affine", [
+    (6, 3, 1, 200, 96, "swish", False, "channel"), (6, 3, 2, 64, 64, "identity", False, "none"),
+    (6, 3, 1, 72, 64, "swish", True, "spatial"), (4, 1, 1, 136, 64, "swish", False, "channel"),
+    (5, 3, 1, 40, 64, "identity", False, "channel"), (6, 3, 1, 8, 32, "swish", False, "batch"),
+    # enough tiles for the grouped form (8 consecutive tiles x 32 channels per workgroup, halo pixels through LDS)
+    (6, 3, 1, 200, 128, "swish", False, "channel"), (6, 3, 2, 96, 128, "identity", False, "none"),
+    (6, 3, 1, 192, 128, "swish", True, "spatial"), (6, 3, 2, 128, 128, "swish", False, "batch")])
+def test_scatter_gather_row_form_bit_exact(hip, bsize, k, B, C, res, act, first, affine):
+    """The row form of the reference-layout scatter_gather (sige/cuda/scatter_gather_kernel.cu:8-67) is bit-identical to the
+    element form and equals the oracle: windows over the image border, holes in the tile grid (rows that mix conv-1 tiles and
+    the cached tensor), tiles narrower than the vector part (5x5 windows over 3x3 tiles), ragged channel chunks, every affine
+    broadcast shape and both activation orders."""
+    g = torch.Generator().manual_seed(bsize * 1000 + C)
+    off = 1 if k == 3 else 0
+    n_side = res // 4
+    keep = torch.rand(n_side, n_side, generator=g) < 0.7
+    idx = (keep.nonzero() * 4 - off).int().contiguous()            # origins -1, 3, ... for 3x3: the first row / column leaves the image
+    N = idx.shape[0]
+    R = bsize - k + 1                                               # conv-1's output tile
+    x = torch.randn(B * N, C, R, R, generator=g)
+    y = torch.randn(B, C, res, res, generator=g)
+    shape = {"none": None, "channel": (1, C, 1, 1), "batch": (B, C, 1, 1), "spatial": (1, C, res, res)}[affine]
+    scale = None if shape is None else torch.randn(*shape, generator=g)
+    shift = None if shape is None else torch.randn(*shape, generator=g)
+    d = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    smap = hip.get_scatter_map(res, res, bsize, bsize, k, k, off, off, 1, 1, d(idx))
+    want_map = oracle.get_scatter_map(res, res, bsize, bsize, k, k, off, off, 1, 1, idx)
+    assert torch.equal(smap.cpu(), want_map)
+    try:
+        hip.scatter_gather_force_elements(True)
+        elems = hip.scatter_gather(d(x), d(y), bsize, bsize, d(idx), smap, d(scale), d(shift), act, first)
+        hip.scatter_gather_force_elements(False)
+        rows = hip.scatter_gather(d(x), d(y), bsize, bsize, d(idx), smap, d(scale), d(shift), act, first)
+    finally:
+        hip.scatter_gather_force_elements(False)
+    torch.cuda.synchronize()
+    assert torch.equal(rows, elems)
+    want = oracle.scatter_gather(x, y, bsize, bsize, idx, want_map, scale, shift, act, first)
+    torch.testing.assert_close(rows.cpu(), want, rtol=1e-6, atol=1e-6)
