@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SIGE_HIP_VERSION 306 /* 0.3.0: round 3 -- dense-layer convs on the fp16 matrix cores (fp16 / split-fp16 operands) */
+#define SIGE_HIP_VERSION 307 /* 0.3.0: round 3 -- dense-layer convs on the fp16 matrix cores (fp16 / split-fp16 operands) */
 
 enum {
     SIGE_HIP_OK = 0,
@@ -480,6 +480,20 @@ int sige_hip_group_norm_affine_nhwc_bias_f32(const float *x, int B, int C, int H
                                              const float *gamma, const float *beta, const float *channel_bias,
                                              float *workspace, float *scale, float *shift, void *stream);
 
+/* the same affine from per-channel statistics instead of the tensor: statsK [B * tilesK, CK, 2] = per pixel block and channel
+ * (sum, sum of squares) as sige_hip_wide_conv_nhwc leaves them (tilesK blocks per batch element, countK = pixels per batch
+ * element the sums run over).  Two parts = the GroupNorm of torch.cat([a, b], 1) over C1 + C2 channels without the cat
+ * (stats2 NULL / C2 0: one tensor; a group may straddle the parts).  channel_bias [C1 + C2] or NULL as above.  One launch. */
+int sige_hip_group_norm_affine_from_stats_f32(const float *stats1, int tiles1, int C1, int count1,
+                                              const float *stats2, int tiles2, int C2, int count2,
+                                              int B, int groups, float eps, const float *gamma, const float *beta,
+                                              const float *channel_bias, float *scale, float *shift, void *stream);
+
+/* per-channel statistics of a channels-last tensor x [B,H,W,C] in that layout, for a tensor whose producer left none:
+ * stats [B * sige_hip_channel_stats_tiles(H, W), C, 2], count = H * W.  One pass over x. */
+int sige_hip_channel_stats_tiles(int H, int W);
+int sige_hip_channel_stats_nhwc_f32(const float *x, int B, int C, int H, int W, float *stats, void *stream);
+
 /* ---- single-head spatial self-attention of the U-Net's dense AttnBlock ------
  * (diffusion/models/ddpm_arch/unet.py AttnBlock.forward, reached from
  * sige_fused_unet.py:186-199): qkv [B,3C,HW] = q, k, v stacked on the channel axis,
@@ -560,7 +574,10 @@ int sige_hip_scatter_gather_conv_scatter_nhwc_f16x3(
  * Shapes: C1, C2 multiples of 64 (3x3) / 128 (1x1), Cout a multiple of 64 (sige_hip_wide_conv_supported).
  * twinK (optional): twinK = SiLU(twin_scaleK * v + twin_shiftK), v = the value `out` receives before its out-affine.
  * workspace (optional, sige_hip_wide_conv_workspace floats): small layers split K across workgroups and finish inside
- * the launch (deterministic summation order); without it they run unsplit.                                    */
+ * the launch (deterministic summation order); without it they run unsplit.
+ * stats (optional, [B * ceil(H/8) * ceil(W/8), Cout, 2] floats): per 8x8 pixel block and output channel the (sum, sum of
+ * squares) of what `out` receives (before its out-affine) -- the input of sige_hip_group_norm_affine_from_stats_f32, so that
+ * the GroupNorm of the output needs no pass over it.                                                              */
 int sige_hip_wide_conv_supported(int C1, int C2, int Cout, int kH, int kW);
 /* packed size in 4-byte units (0: unsupported shape) */
 size_t sige_hip_wide_conv_packed_size(int Cout, int Cin, int kH, int kW, int prec);
@@ -575,7 +592,7 @@ int sige_hip_wide_conv_nhwc(const float *x, const float *x2, int B, int C1, int 
                             const float *residual, const float *out_scale, const float *out_shift, int out_activation,
                             float *twin0, const float *twin_scale0, const float *twin_shift0,
                             float *twin1, const float *twin_scale1, const float *twin_shift1,
-                            float *workspace, size_t workspace_floats, float *out, void *stream);
+                            float *workspace, size_t workspace_floats, float *out, float *stats, void *stream);
 
 /* out = act(scale[b,c] * x + shift[b,c]) over a channels-last tensor [B,H,W,C] (scale / shift [affineB, C], affineB 1 or B):
  * the activated copy of a ScatterGather cache that the full pass keeps next to the cache (one pass instead of the

@@ -159,7 +159,7 @@ extern "C" int sige_hip_wide_conv_nhwc(const float *x, const float *x2, int B, i
                                        const float *residual, const float *out_scale, const float *out_shift, int out_activation,
                                        float *twin0, const float *twin_scale0, const float *twin_shift0,
                                        float *twin1, const float *twin_scale1, const float *twin_shift1,
-                                       float *workspace, size_t workspace_floats, float *out, void *stream) {
+                                       float *workspace, size_t workspace_floats, float *out, float *stats, void *stream) {
     if (B <= 0 || H <= 0 || W <= 0 || C1 <= 0 || C2 < 0 || Cout <= 0 || prec < WIDE_F16 || prec > WIDE_F32) return SIGE_HIP_EINVAL;
     if (!x || (C2 && !x2) || !packed || !out) return SIGE_HIP_EINVAL;
     if (!wide_shape_ok(C1, C2, Cout, kH, kW)) return SIGE_HIP_EUNSUPPORTED;
@@ -174,7 +174,7 @@ extern "C" int sige_hip_wide_conv_nhwc(const float *x, const float *x2, int B, i
     if (src_px * (C1 > C2 ? C1 : C2) >= (1L << 29)) return SIGE_HIP_EUNSUPPORTED;  // 32-bit byte offsets in the kernel
     auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (!al(x) || !al(x2) || !al(packed) || !al(out) || !al(bias) || !al(scale) || !al(shift) || !al(residual) || !al(out_scale) ||
-        !al(out_shift) || !al(twin0) || !al(twin1) || !al(workspace))
+        !al(out_shift) || !al(twin0) || !al(twin1) || !al(workspace) || (reinterpret_cast<uintptr_t>(stats) & 7))
         return SIGE_HIP_EUNSUPPORTED;
     WideArgs a{};
     a.x = x; a.x2 = x2 ? x2 : x; a.packed = packed; a.bias = bias; a.scale = scale; a.shift = shift; a.residual = residual;
@@ -183,6 +183,7 @@ extern "C" int sige_hip_wide_conv_nhwc(const float *x, const float *x2, int B, i
     a.twin1 = twin1; a.tscale1 = twin_scale1; a.tshift1 = twin_shift1;
     if ((twin0 && !(twin_scale0 && twin_shift0)) || (twin1 && !(twin_scale1 && twin_shift1))) return SIGE_HIP_EINVAL;
     a.wscale = ldexpf(1.0f, -wshift);
+    a.stats = reinterpret_cast<float2 *>(stats);
     a.B = B; a.H = H; a.W = W; a.C1 = C1; a.C2 = C2; a.Cout = Cout; a.up = upsample2x ? 1 : 0; a.act = activation;
     a.aff_sb = (scale && affineB > 1) ? C1 + C2 : 0;
     const int pwo = wide_patch(W);

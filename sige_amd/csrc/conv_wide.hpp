@@ -83,6 +83,9 @@ struct WideArgs {
     float *twin0, *twin1;       // optional activated twins (conv_mfma.hpp: ConvArgs::twin0/1)
     const float *tscale0, *tshift0, *tscale1, *tshift1;
     int32_t *counters;          // K split: one ticket per output block
+    // optional per-channel statistics of what `out` receives (before its out-affine): stats[(pixel block) * Cout + co] =
+    // (sum, sum of squares) over the block's 8 x PWO pixels -- what a GroupNorm of the output needs, without re-reading it
+    float2 *stats;
     size_t split_stride;
     float wscale;               // 2^-S: the weights were packed as w * 2^S
     int B, H, W, C1, C2, Cout, up, act, oact, aff_sb;
@@ -368,6 +371,8 @@ __global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a
         u.addr = u.ok ? (((size_t)b * a.H + h) * a.W + w) * a.Cout + u.co : 0;
         return u;
     };
+    // (this lane's units all have the same four output channels: n4 = tid & 15)
+    float4 st_s = make_float4(0.f, 0.f, 0.f, 0.f), st_q = make_float4(0.f, 0.f, 0.f, 0.f);
     auto emit = [&](const Unit &u, float4 s) {
         s.x *= a.wscale; s.y *= a.wscale; s.z *= a.wscale; s.w *= a.wscale;  // (a power of two: exact)
         if (a.bias) {
@@ -377,6 +382,10 @@ __global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a
         if (a.residual) {
             const float4 rr = *reinterpret_cast<const float4 *>(a.residual + u.addr);
             s.x += rr.x; s.y += rr.y; s.z += rr.z; s.w += rr.w;
+        }
+        if (a.stats) {
+            st_s.x += s.x; st_s.y += s.y; st_s.z += s.z; st_s.w += s.w;
+            st_q.x += s.x * s.x; st_q.y += s.y * s.y; st_q.z += s.z * s.z; st_q.w += s.w * s.w;
         }
         auto twin = [&](float *dst2, const float *ts, const float *tt) {
             const float4 sc = *reinterpret_cast<const float4 *>(ts + u.co), sh = *reinterpret_cast<const float4 *>(tt + u.co);
@@ -396,6 +405,32 @@ __global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a
         }
         *reinterpret_cast<float4 *>((split_k ? a.fout : a.out) + u.addr) = s;
     };
+    // the workgroup's (sum, sum of squares) per output channel: 16 lanes per channel quad (4 in each wave) -> LDS -> one row
+    // of `stats`; fixed order, no atomics: the same launch gives the same bits every time
+    auto flush_stats = [&]() {
+        if (!a.stats) return;  // (uniform)
+        __syncthreads();       // every lane is done with the reduction buffer
+        float *sb = red;       // [wave][16 quads][8]
+#pragma unroll
+        for (int d = 16; d < 64; d <<= 1) {
+            st_s.x += __shfl_xor(st_s.x, d); st_s.y += __shfl_xor(st_s.y, d); st_s.z += __shfl_xor(st_s.z, d); st_s.w += __shfl_xor(st_s.w, d);
+            st_q.x += __shfl_xor(st_q.x, d); st_q.y += __shfl_xor(st_q.y, d); st_q.z += __shfl_xor(st_q.z, d); st_q.w += __shfl_xor(st_q.w, d);
+        }
+        if (lane < 16) {
+            float *d = sb + (wave * 16 + lane) * 8;
+            *reinterpret_cast<float4 *>(d) = st_s;
+            *reinterpret_cast<float4 *>(d + 4) = st_q;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int q = tid >> 2, e = tid & 3;  // channel quad, channel inside it
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s1 += sb[(w * 16 + q) * 8 + e]; s2 += sb[(w * 16 + q) * 8 + 4 + e]; }
+            const int co = ntile * 64 + tid;
+            if (co < a.Cout) a.stats[(size_t)mtile * a.Cout + co] = make_float2(s1, s2);
+        }
+    };
     constexpr int EU = G::BM * 16 / 256;  // float4 units per lane
 #pragma unroll
     for (int k = 0; k < EU; ++k) {
@@ -412,6 +447,7 @@ __global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a
         if (!split_k) emit(u, s);
         else coherent_store(outp + u.addr, s);
     }
+    if (!split_k) flush_stats();
     if (split_k) {
         // partial sums went out as device-coherent stores (complete = visible to every XCD); then the block's ticket; the
         // workgroup that draws the last one adds the copies in split order (deterministic) and runs the epilogue
@@ -447,6 +483,7 @@ __global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a
                 for (int k = 0; k < 4; ++k)
                     if (us[k].ok) emit(us[k], sum[k]);
             }
+            flush_stats();
         }
     }
 }

@@ -149,7 +149,11 @@ _SIGNATURES = {
     "sige_hip_wide_conv_force_ksplit": (_c_int, [_c_int]),
     "sige_hip_wide_conv_nhwc": (
         _c_int, [_c_vp, _c_vp] + [_c_int] * 6 + [_c_vp, _c_vp, _c_int, _c_int] + [_c_vp, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_int]
-        + [_c_vp, _c_vp, _c_vp, _c_int] + [_c_vp] * 6 + [_c_vp, _c_sz, _c_vp, _c_vp]),
+        + [_c_vp, _c_vp, _c_vp, _c_int] + [_c_vp] * 6 + [_c_vp, _c_sz, _c_vp, _c_vp, _c_vp]),
+    "sige_hip_channel_stats_tiles": (_c_int, [_c_int, _c_int]),
+    "sige_hip_channel_stats_nhwc_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp]),
+    "sige_hip_group_norm_affine_from_stats_f32": (
+        _c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_float] + [_c_vp] * 6),
 }
 
 EXPORTS = tuple(_SIGNATURES)  # every symbol include/sige_hip.h declares
@@ -591,10 +595,12 @@ def wide_conv_force_ksplit(ksplit: int = 0):
 
 def wide_conv_cl(x, x2, scale, shift, activationName: str, packed, bias, Cout: int, kernel: Tuple[int, int],
                  residual=None, out_affine: Optional[tuple] = None, twins=None, upsample2x: bool = False,
-                 out: Optional[torch.Tensor] = None):
+                 out: Optional[torch.Tensor] = None, stats: bool = False):
     """out_act(os * (conv(act(scale * cat(x, x2) + shift)) + bias + residual) + oh) over a whole channels-last tensor in one
     launch on the fp16 matrix cores (include/sige_hip.h: sige_hip_wide_conv_nhwc).  3x3 / padding 1 or 1x1, stride 1.
-    `packed` from wide_conv_pack_weights.  None if the shape has no kernel."""
+    `packed` from wide_conv_pack_weights.  None if the shape has no kernel.
+    `stats`: the launch also leaves the per-channel statistics of its output (ChannelStats, attached to the returned tensor:
+    channel_stats(out)) -- the GroupNorm of the output then needs no pass over it (group_norm_affine_from_stats)."""
     compute = getattr(packed, "compute", "f32")
     if compute not in ("f16w", "f16x3w", "f32w"):
         raise NotImplementedError("wide_conv_cl: weights must be packed with wide_conv_pack_weights")
@@ -640,15 +646,94 @@ def wide_conv_cl(x, x2, scale, shift, activationName: str, packed, bias, Cout: i
     ws, ws_n = None, int(lib().sige_hip_wide_conv_workspace(B, H, W, C1, C2, Cout, kernel[0], kernel[1])) if KSPLIT else 0
     if ws_n:
         ws = torch.empty(ws_n, dtype=torch.float32, device=x.device)
+    st = None
+    if stats and out_affine is None:
+        tiles = ((H + 7) // 8) * ((W + 7) // 8)
+        st = torch.empty((B * tiles, Cout, 2), dtype=torch.float32, device=x.device)
     status = lib().sige_hip_wide_conv_nhwc(
         x.data_ptr(), None if x2 is None else x2.data_ptr(), B, C1, C2, H, W, int(bool(upsample2x)),
         sa[0], ta[0], sa[1] if s_keep is not None else 0, _act(activationName),
         packed.data_ptr(), _WIDE_PREC[compute[:-1]], int(getattr(packed, "wshift", 0)), _p(bias_keep), Cout, kernel[0], kernel[1],
-        None if r is None else r.data_ptr(), *oargs, *targs, None if ws is None else ws.data_ptr(), ws_n, out.data_ptr(), _stream(x))
+        None if r is None else r.data_ptr(), *oargs, *targs, None if ws is None else ws.data_ptr(), ws_n, out.data_ptr(),
+        None if st is None else st.data_ptr(), _stream(x))
     if status == UNSUPPORTED:
         return None
     _check(status, "wide_conv_cl")
+    if st is not None:
+        attach_channel_stats(out, ChannelStats(st, tiles, Cout, H * W))
     return out
+
+
+class ChannelStats:
+    """Per-channel (sum, sum of squares) of a tensor, as its producer left them: `data` [B * tiles, C, 2] partial sums per pixel
+    block, `count` pixels per batch element.  Attached to the tensor OBJECT (attach_channel_stats) together with the tensor's
+    version counter and address: any torch op makes a new object without them, an in-place op bumps the version, so stale
+    statistics are never used (channel_stats returns None)."""
+
+    __slots__ = ("data", "tiles", "channels", "count", "version", "ptr")
+
+    def __init__(self, data, tiles, channels, count):
+        self.data, self.tiles, self.channels, self.count = data, tiles, channels, count
+        self.version = self.ptr = None
+
+
+def attach_channel_stats(t: torch.Tensor, st: ChannelStats) -> torch.Tensor:
+    st.version, st.ptr = t._version, t.data_ptr()
+    t._sige_channel_stats = st
+    return t
+
+
+def channel_stats(t) -> Optional[ChannelStats]:
+    st = getattr(t, "_sige_channel_stats", None)
+    if st is None or st.version != t._version or st.ptr != t.data_ptr():
+        return None
+    return st
+
+
+def channel_stats_cl(x: torch.Tensor) -> Optional[ChannelStats]:
+    """Per-channel statistics of a channels-last tensor whose producer left none, in one pass (attached to `x` as well, so that
+    a second consumer -- a skip connection -- does not read it again).  None if unsupported."""
+    st = channel_stats(x)
+    if st is not None:
+        return st
+    x = _req_cl(x, "x")
+    B, C, H, W = x.shape
+    tiles = int(lib().sige_hip_channel_stats_tiles(H, W))
+    data = torch.empty((B * tiles, C, 2), dtype=torch.float32, device=x.device)
+    status = lib().sige_hip_channel_stats_nhwc_f32(x.data_ptr(), B, C, H, W, data.data_ptr(), _stream(x))
+    if status == UNSUPPORTED:
+        return None
+    _check(status, "channel_stats_cl")
+    st = ChannelStats(data, tiles, C, H * W)
+    attach_channel_stats(x, st)
+    return st
+
+
+def group_norm_affine_from_stats(parts, groups: int, eps: float, gamma=None, beta=None, channel_bias=None):
+    """GroupNorm (scale, shift) [B,C,1,1] of torch.cat(tensors, 1) from the ChannelStats of one or two tensors, in one launch
+    over the partial sums (include/sige_hip.h: sige_hip_group_norm_affine_from_stats_f32).  None if unsupported."""
+    if len(parts) not in (1, 2):
+        return None
+    p1 = parts[0]
+    p2 = parts[1] if len(parts) == 2 else None
+    B = p1.data.shape[0] // p1.tiles
+    if p2 is not None and p2.data.shape[0] // p2.tiles != B:
+        return None
+    C = p1.channels + (p2.channels if p2 is not None else 0)
+    buf = torch.empty(2 * B * C, dtype=torch.float32, device=p1.data.device)
+    scale, shift = buf[:B * C].view(B, C, 1, 1), buf[B * C:].view(B, C, 1, 1)
+    gamma_keep, beta_keep, cb_keep = _vec(gamma, "gamma"), _vec(beta, "beta"), _vec(channel_bias, "channel_bias")
+    if cb_keep is not None and cb_keep.numel() != C:
+        raise RuntimeError("group_norm_affine_from_stats: channel_bias must have one entry per channel")
+    status = lib().sige_hip_group_norm_affine_from_stats_f32(
+        p1.data.data_ptr(), p1.tiles, p1.channels, p1.count,
+        None if p2 is None else p2.data.data_ptr(), 0 if p2 is None else p2.tiles, 0 if p2 is None else p2.channels,
+        0 if p2 is None else p2.count, B, groups, eps, _p(gamma_keep), _p(beta_keep), _p(cb_keep),
+        scale.data_ptr(), shift.data_ptr(), _stream(p1.data))
+    if status == UNSUPPORTED:
+        return None
+    _check(status, "group_norm_affine_from_stats")
+    return scale, shift
 
 
 def conv_force_tile(mt: int = 0, nb: int = 0):

@@ -74,7 +74,7 @@ def _wide_packed(conv: nn.Conv2d, compute: str):
 
 
 def _wide_conv(conv: nn.Conv2d, x, x2, scale, shift, activation_name, residual, out_affine, twins, made, upsample2x=False,
-               min_flop=None):
+               min_flop=None, stats=False):
     """The conv as one launch of the dense-layer kernel (csrc/conv_wide.hpp) when the layer's compute dtype asks for the fp16
     matrix cores ("f16" / "f16x3") and the shape has a kernel; None otherwise (the caller goes on to the tile kernels)."""
     from .. import hip
@@ -107,27 +107,48 @@ def _wide_conv(conv: nn.Conv2d, x, x2, scale, shift, activation_name, residual, 
             tw.append((key, torch.empty((B, conv.out_channels, H, W), dtype=torch.float32, device=x.device,
                                         memory_format=torch.channels_last), sc, sh))
     out = hip.wide_conv_cl(x, x2, scale, shift, activation_name, packed, conv.bias, conv.out_channels, k, residual=residual,
-                           out_affine=out_affine, twins=[(b, sc, sh) for _, b, sc, sh in tw] or None, upsample2x=upsample2x)
+                           out_affine=out_affine, twins=[(b, sc, sh) for _, b, sc, sh in tw] or None, upsample2x=upsample2x,
+                           stats=stats)
     if out is not None and made is not None:
         made.update({k_: b for k_, b, _, _ in tw})
     return out
 
 
+def fast_full_pass(conv: nn.Conv2d) -> bool:
+    """Does the full pass run this conv on the library's kernels (compute dtype "f16" / "f16x3", or FULL_PASS_F32_NATIVE for
+    exact fp32) rather than as the reference's torch conv?"""
+    return getattr(conv, "compute_dtype", "f32") != "f32" or FULL_PASS_F32_NATIVE
+
+
 def full_conv2d(conv: nn.Conv2d, x: torch.Tensor, scale=None, shift=None, activation_name: str = "identity",
-                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """`conv(act(x * scale + shift)) + residual` of the FULL pass (the pass that produces the caches: sige/nn/base.py:85-86).  On a
-    channels-last GPU tensor and a conv whose compute dtype is "f16" / "f16x3" (SIGEModel.set_compute_dtype) it is one
+                residual: Optional[torch.Tensor] = None, x2: Optional[torch.Tensor] = None, upsample2x: bool = False,
+                stats: bool = False) -> torch.Tensor:
+    """`conv(act(cat(x, x2) * scale + shift)) + residual` of the FULL pass (the pass that produces the caches: sige/nn/base.py:85-86).
+    On a channels-last GPU tensor and a conv whose compute dtype is "f16" / "f16x3" (SIGEModel.set_compute_dtype) it is one
     launch of the dense-layer kernel with the affine + SiLU in its staging path; anywhere else exactly the torch
-    expression the reference runs (a SIGEConv2d in full mode is nn.Conv2d.forward)."""
+    expression the reference runs (a SIGEConv2d in full mode is nn.Conv2d.forward).
+    `x2`: the second half of a torch.cat that then never exists; `upsample2x`: x is the half-resolution tensor, read as its
+    nearest x2 upsampling (F.interpolate fused); `stats`: the launch also leaves the per-channel statistics of its output
+    (hip.channel_stats(out)), from which group_norm_affine takes the next GroupNorm without a pass over the tensor."""
     if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4:
         # (no shortcut / conv1 pairing in the full pass: every 3x3 the kernel is at least as fast on takes it)
         out = None
         # (exact fp32: the reference's own torch conv, as it was -- unless FULL_PASS_F32_NATIVE asks for the exact-fp32 form of the
         #  dense-layer kernel)
-        if getattr(conv, "compute_dtype", "f32") != "f32" or FULL_PASS_F32_NATIVE:
-            out = _wide_conv(conv, x, None, scale, shift, activation_name, residual, None, None, None, min_flop=WIDE_MIN_FLOP_FULL_PASS)
+        if fast_full_pass(conv):
+            out = _wide_conv(conv, x, x2, scale, shift, activation_name, residual, None, None, None, upsample2x=upsample2x,
+                             min_flop=WIDE_MIN_FLOP_FULL_PASS, stats=stats)
+            if out is None and fusable(conv) and tuple(conv.stride) == (1, 1):
+                # the small layers (1x1 shortcuts at 32^2 and below, the attention blocks' qkv / proj): the tile kernels with every
+                # tile active, exactly as the sparse pass runs them -- affine, cat and residual inside the launch
+                xs = F.interpolate(x if x2 is None else torch.cat([x, x2], 1), scale_factor=2.0, mode="nearest") if upsample2x else x
+                return fused_conv2d(conv, xs, scale, shift, activation_name, x2=None if upsample2x else x2, residual=residual)
         if out is not None:
             return out
+    if x2 is not None:
+        x = torch.cat([x, x2], dim=1)
+    if upsample2x:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
     h = x
     if scale is not None:
         h = h * scale
@@ -278,9 +299,25 @@ def input_conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     return conv(x)
 
 
-def group_norm_affine(x: torch.Tensor, norm: nn.GroupNorm, channel_bias: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+def group_norm_affine(x: torch.Tensor, norm: nn.GroupNorm, channel_bias: Optional[torch.Tensor] = None,
+                      x2: Optional[torch.Tensor] = None, make_stats: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """(scale, shift) as [B,C,1,1] with GroupNorm(x) == x*scale + shift.  `channel_bias` [C]: GroupNorm(x + channel_bias) ==
-    x*scale + shift (a residual block's norm of h + temb without materialising the sum)."""
+    x*scale + shift (a residual block's norm of h + temb without materialising the sum).  `x2`: the GroupNorm of
+    torch.cat([x, x2], 1).  Tensors that carry the per-channel statistics their producer left (full_conv2d(stats=True)) are not
+    read at all: one launch over the partial sums."""
+    if x.is_cuda and x.dtype == torch.float32:
+        from .. import hip
+
+        parts = [hip.channel_stats(t) for t in ((x,) if x2 is None else (x, x2))]
+        if make_stats:  # (the full pass: a tensor without statistics gets them in one pass, kept for its next consumer)
+            parts = [p if p is not None else (hip.channel_stats_cl(t) if hip.is_cl(t) else None)
+                     for p, t in zip(parts, (x,) if x2 is None else (x, x2))]
+        if all(p is not None for p in parts):
+            r = hip.group_norm_affine_from_stats(parts, norm.num_groups, norm.eps, norm.weight, norm.bias, channel_bias)
+            if r is not None:
+                return r
+    if x2 is not None:
+        x = torch.cat([x, x2], dim=1)
     if x.is_cuda and x.dtype == torch.float32:
         from .. import hip
 

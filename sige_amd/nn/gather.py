@@ -58,6 +58,11 @@ class Gather(SIGEModule):
         self.active_indices: Optional[torch.Tensor] = None
         self._tables: Dict = {}
 
+    def note_full_input(self, res):
+        """What a full-mode forward records (sige/nn/gather.py:51-57: the input resolution) -- for a full pass whose input tensor
+        never exists as one tensor (a torch.cat / F.interpolate fused into the consuming conv)."""
+        self.input_res = torch.Size(tuple(res))
+
     def forward(
         self, x: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
         upsample2x: bool = False, preactivated: bool = False
@@ -125,7 +130,7 @@ class Gather(SIGEModule):
                          up=upsample2x))
             return run()
         if self.mode == "full":
-            self.input_res = x.shape[2:]
+            self.note_full_input(x.shape[2:])
             assert scale is None
             assert shift is None
             return x

@@ -328,9 +328,11 @@ class ScatterWithBlockResidual(SIGEModule):
                     return tag_twins(done, {k: b for k, b, _, _ in tw})
         return self.forward(conv(tiles), residual)
 
-    def forward(self, x: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, residual: torch.Tensor, x_is_sum: bool = False) -> torch.Tensor:
+        """`x_is_sum` (full mode only, not in the reference): `x` already is main + residual."""
         self.check_dtype(x, residual)
         self.check_dim(x, residual)
+        assert not x_is_sum or self.mode == "full"
         if self.mode == "sparse":
             x, residual = deferred.resolve(x), deferred.resolve(residual)
             mg: Gather = self.main_gather.module
@@ -375,7 +377,8 @@ class ScatterWithBlockResidual(SIGEModule):
                                 sg.model_stride[0], sg.model_stride[1], sg.indices_on(x.device), None))
             return tag_twins(output, emulated_twins(output, twins_for(self.twins.regs, self.cache_id)) if EMULATE_TWINS else {})  # (no twin written)
         if self.mode == "full":
-            output = x + residual
+            # (x_is_sum: the caller's conv already added the residual in its epilogue -- one launch less, one pass less)
+            output = x if x_is_sum else x + residual
             self.output_res = output.shape[2:]
             self.original_outputs[self.cache_id] = deferred.keep_layout(output)
             cl = self.original_outputs[self.cache_id].is_contiguous(memory_format=torch.channels_last)

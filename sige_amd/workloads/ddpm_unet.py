@@ -27,7 +27,7 @@ from torch.nn import functional as F
 
 from ..nn import Gather, Scatter, ScatterGather, ScatterWithBlockResidual, SIGEConv2d, SIGEModel, SIGEModule, paired_convs
 from ..nn.deferred import lazy_cat
-from ..nn.dense import full_conv2d, fused_conv2d, group_norm_affine, input_conv2d
+from ..nn.dense import fast_full_pass, full_conv2d, fused_conv2d, group_norm_affine, input_conv2d
 
 
 @dataclass
@@ -75,16 +75,21 @@ def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
     return F.pad(emb, (0, 1)) if dim % 2 else emb
 
 
-def norm_affine(x: torch.Tensor, norm: nn.GroupNorm, fast: bool = False, cbias: Optional[torch.Tensor] = None):
+def norm_affine(x: torch.Tensor, norm: nn.GroupNorm, fast: bool = False, cbias: Optional[torch.Tensor] = None,
+                x2: Optional[torch.Tensor] = None):
     """Per-channel (scale, shift) with GroupNorm(x) == x * scale + shift, batch 1.  `fast` (the full pass on the fp16 matrix
     cores): the library's split reduction (fp64 combine) instead of torch's var_mean + five elementwise kernels.
     `cbias` [C]: the statistics are those of x + cbias (the timestep embedding); with `fast` the returned affine is for x itself
     (GroupNorm(x + cbias) == x * scale + shift), otherwise for x + cbias as before -- the caller folds the bias."""
+    if fast and x.is_cuda:
+        assert x.shape[0] == 1, "SIGE caches one original image"
+        # (`x2`: the norm of torch.cat([x, x2], 1); tensors that carry their producer's per-channel statistics are not read)
+        sc, sh = group_norm_affine(x, norm, cbias, x2=x2, make_stats=True)
+        return sc.reshape(-1), sh.reshape(-1)
+    if x2 is not None:
+        x = torch.cat([x, x2], dim=1)
     n, c, h, w = x.shape
     assert n == 1, "SIGE caches one original image"
-    if fast and x.is_cuda:
-        sc, sh = group_norm_affine(x, norm, cbias)
-        return sc.reshape(-1), sh.reshape(-1)
     if cbias is not None:
         x = x + cbias.reshape(1, -1, 1, 1)
     g = norm.num_groups
@@ -257,6 +262,8 @@ class ResBlock(SIGEModule, _TwinProducer):
         sparse-mode blocks fold into their convs' two-pointer input."""
         pair = x if isinstance(x, (tuple, list)) else None
         if self.mode == "full":
+            if pair and not self.plain and self._fast_full() and pair[0].is_cuda:
+                return self._full(pair[0], temb, x2=pair[1])  # (the cat never exists: two-pointer convs, statistics per part)
             return self._full(torch.cat(pair, dim=1) if pair else x, temb)
         if self.mode in ("sparse", "profile"):
             if pair and not self.sparse_main and self.mode == "sparse":
@@ -266,9 +273,20 @@ class ResBlock(SIGEModule, _TwinProducer):
             return self._sparse(torch.cat(pair, dim=1) if pair else x)
         raise NotImplementedError("Unknown mode [%s]!!!" % self.mode)
 
-    def _shortcut(self, x):
+    def _fast_full(self) -> bool:
+        """The full pass on the library's kernels (dense.full_conv2d) rather than torch's: compute dtype "f16" / "f16x3", or
+        dense.FULL_PASS_F32_NATIVE for exact fp32."""
+        from ..nn import dense as _dense
+
+        return _dense.fast_full_pass(self.conv1)
+
+    def _shortcut(self, x, x2=None):
         if self.cin == self.cout:
             return x
+        if x2 is not None:  # (full mode, fast: the cat is read through two pointers)
+            if self.sparse_shortcut:
+                self.shortcut_gather.note_full_input(x.shape[2:])
+            return full_conv2d(self.nin_shortcut, x, x2=x2)
         if self.sparse_shortcut:
             x = self.shortcut_gather(x)
         return full_conv2d(self.nin_shortcut, x) if self.mode == "full" else self.nin_shortcut(x)
@@ -281,22 +299,26 @@ class ResBlock(SIGEModule, _TwinProducer):
         h = self.conv2(F.silu(self.norm2(h + temb.reshape(1, -1, 1, 1))))
         return h + skip
 
-    def _full(self, x, temb):
+    def _full(self, x, temb, x2=None):
         if self.plain:
             return self._plain(x, temb)
-        from ..nn import dense as _dense
-
-        # (the full pass on the library's kernels -- dense.full_conv2d -- also takes the library's GroupNorm statistics)
-        fast = getattr(self.conv1, "compute_dtype", "f32") != "f32" or _dense.FULL_PASS_F32_NATIVE
-        skip = self._shortcut(x)
-        h = self.main_gather(x) if self.sparse_main else x  # records the input resolution
-        s1, t1 = norm_affine(h, self.norm1, fast)
-        h = full_conv2d(self.conv1, h, _as4(s1), _as4(t1), "swish")  # conv1(silu(h * s1 + t1))
+        # (the full pass on the library's kernels -- dense.full_conv2d -- also takes the library's GroupNorm statistics; its
+        #  convs leave the per-channel sums of their outputs, so that a norm never reads a tensor its producer just wrote)
+        fast = self._fast_full()
+        skip = self._shortcut(x, x2)
+        if x2 is not None:
+            if self.sparse_main:
+                self.main_gather.note_full_input(x.shape[2:])
+            h = x
+        else:
+            h = self.main_gather(x) if self.sparse_main else x  # records the input resolution
+        s1, t1 = norm_affine(h, self.norm1, fast, x2=x2)
+        h = full_conv2d(self.conv1, h, _as4(s1), _as4(t1), "swish", x2=x2, stats=fast)  # conv1(silu(cat(h, x2) * s1 + t1))
         if self.sparse_main:
             h = self.scatter_gather(h)
         te = temb.reshape(-1)
         if fast and h.is_cuda:
-            # statistics of h + temb and the embedding folded into the shift in ONE pair of launches (no h + temb tensor)
+            # statistics of h + temb and the embedding folded into the shift in ONE launch (no h + temb tensor)
             s2, t2 = norm_affine(h, self.norm2, True, cbias=te.contiguous())
         else:
             s2, t2 = norm_affine(h + _as4(te), self.norm2, fast)
@@ -305,12 +327,15 @@ class ResBlock(SIGEModule, _TwinProducer):
         self.affine[self.cache_id] = tuple(_as4(v).contiguous() for v in (s1, t1, s2, t2))
         if self.sparse_main and self.preactivate:
             self.scatter_gather.cache_activated(_as4(s2), _as4(t2))
+        # conv2(silu(h * s2 + t2)) + skip in one launch: a plain Scatter caches the SUM (sige/nn/scatter.py:31-37), and so does
+        # ScatterWithBlockResidual (sige/nn/scatter.py:89-93), next to the shortcut
         if self.sparse_main and self.sparse_shortcut:
-            # (ScatterWithBlockResidual caches conv2's output and the shortcut separately)
+            if fast and h.is_cuda:
+                h = full_conv2d(self.conv2, h, _as4(s2), _as4(t2), "swish", residual=skip, stats=True)
+                return self.scatter(h, skip, x_is_sum=True)
             h = full_conv2d(self.conv2, h, _as4(s2), _as4(t2), "swish")  # conv2(silu(h * s2 + t2))
             return self.scatter(h, skip)
-        # conv2(silu(h * s2 + t2)) + skip in one launch: a plain Scatter caches the SUM (sige/nn/scatter.py:31-37)
-        h = full_conv2d(self.conv2, h, _as4(s2), _as4(t2), "swish", residual=skip)
+        h = full_conv2d(self.conv2, h, _as4(s2), _as4(t2), "swish", residual=skip, stats=fast)
         return self.scatter(h) if self.sparse_main else h
 
     def _sparse(self, x):
@@ -392,11 +417,11 @@ class AttnBlock(SIGEModule, _TwinProducer):
             h = self.norm(x)
         elif self.mode == "full":
             h = self.gather1(x) if self.sparse else x
-            s, t = norm_affine(h, self.norm, getattr(self.qkv, "compute_dtype", "f32") != "f32")
+            s, t = norm_affine(h, self.norm, fast_full_pass(self.qkv))
             self.affine[self.cache_id] = (_as4(s).contiguous(), _as4(t).contiguous())
             if not self.sparse:  # dense block: qkv(h * s + t) in one launch where the conv's compute dtype allows, then the rest
                 qkv = full_conv2d(self.qkv, h, _as4(s), _as4(t), "identity")
-                return full_conv2d(self.proj_out, self._attention(qkv)) + x
+                return full_conv2d(self.proj_out, self._attention(qkv), residual=x)
             h = h * _as4(s) + _as4(t)
         else:
             s, t = self.affine[self.cache_id]
@@ -459,6 +484,13 @@ class Upsample(SIGEModule, _TwinProducer):
         if self.mode == "sparse" and self.gather.fuses_upsample(x):
             # the upsampled tensor only feeds the gather: read the half-resolution one at (h/2, w/2) instead
             return self._produced(self.scatter.forward_fused(self.conv, self.gather(x, upsample2x=True)))
+        if self.mode == "full" and not self.plain and x.is_cuda:
+            from ..nn import dense as _dense
+
+            if _dense.fast_full_pass(self.conv):
+                # the full pass on the library's kernels: the conv reads the half-resolution tensor at (h/2, w/2) as well
+                self.gather.note_full_input((2 * x.shape[2], 2 * x.shape[3]))
+                return self.scatter(full_conv2d(self.conv, x, upsample2x=True, stats=True))
         x = F.interpolate(x, scale_factor=2.0, mode="nearest")
         if self.mode == "sparse":
             return self._produced(self.scatter.forward_fused(self.conv, self.gather(x)))
@@ -486,6 +518,14 @@ class Downsample(SIGEModule, _TwinProducer):
     def forward(self, x):
         if not self.sparse and self.mode == "sparse":
             return self._produced(fused_conv2d(self.conv, x, pad_bottom_right=True, twins=self._my_twins()))
+        if self.mode == "full" and not self.plain and x.is_cuda:
+            from ..nn import dense as _dense
+
+            if _dense.fast_full_pass(self.conv):
+                # the full pass on the library's kernels: the padding is the tile kernel's zero fill, as in the sparse pass
+                if not self.sparse:
+                    return fused_conv2d(self.conv, x, pad_bottom_right=True)
+                return self.scatter(fused_conv2d(self.conv, self.gather(x), pad_bottom_right=True))
         if not self.sparse or (self.plain and self.mode == "full"):
             return self.conv(F.pad(x, (0, 1, 0, 1)))
         x = self.gather(x)

@@ -535,3 +535,76 @@ def test_scatter_gather_row_form_bit_exact(hip, bsize, k, B, C, res, act, first,
     assert torch.equal(rows, elems)
     want = oracle.scatter_gather(x, y, bsize, bsize, idx, want_map, scale, shift, act, first)
     torch.testing.assert_close(rows.cpu(), want, rtol=1e-6, atol=1e-6)
+
+
+# ---- per-channel statistics out of the dense-layer conv: the next GroupNorm without a pass over the tensor -----------------
+@pytest.mark.parametrize("compute", ["f16x3", "f32"])
+@pytest.mark.parametrize("k,c1,c2,cout,H,W,B,res,up", [
+    (3, 128, 0, 128, 64, 64, 1, True, False),     # a full-pass layer, no K split
+    (3, 1024, 0, 512, 16, 16, 1, True, False),    # deep K: the statistics come from the workgroup that finishes the K split
+    (3, 128, 128, 256, 40, 24, 2, False, False),  # cat input, batch 2, H not a multiple of 8 (partly empty pixel blocks)
+    (1, 256, 256, 128, 32, 32, 1, False, False),  # 1x1
+    (3, 128, 0, 64, 32, 32, 1, False, True),      # nearest x2 upsampling fused into the conv
+])
+def test_wide_conv_stats_give_the_group_norm_affine(hip, compute, k, c1, c2, cout, H, W, B, res, up):
+    """wide_conv_cl(stats=True) leaves (sum, sum of squares) per 8x8 pixel block and output channel; the GroupNorm affine taken
+    from them (one launch over the partial sums) equals GroupNorm of the tensor the conv wrote -- with a per-channel bias
+    (the timestep embedding), and over two tensors as the norm of their torch.cat."""
+    g = torch.Generator().manual_seed(31 * k + cout + H)
+    r = lambda *s: torch.randn(*s, generator=g).to(DEV)  # noqa: E731
+    hs, ws = (H // 2, W // 2) if up else (H, W)
+    x, x2 = _cl(r(B, c1, hs, ws)), (_cl(r(B, c2, hs, ws)) if c2 else None)
+    w, b = r(cout, c1 + c2, k, k) / (k * (c1 + c2) ** 0.5), r(cout) * 0.5
+    residual = _cl(r(B, cout, H, W)) if res else None
+    packed = hip.wide_conv_pack_weights(w, compute)
+    out = hip.wide_conv_cl(x, x2, None, None, "identity", packed, b, cout, (k, k), residual=residual, upsample2x=up, stats=True)
+    st = hip.channel_stats(out)
+    assert st is not None and st.channels == cout and st.count == H * W and st.tiles == ((H + 7) // 8) * ((W + 7) // 8)
+    # the raw sums
+    tot = st.data.double().view(B, st.tiles, cout, 2).sum(1)
+    torch.testing.assert_close(tot[..., 0], out.double().sum((2, 3)), rtol=1e-5, atol=1e-2)
+    torch.testing.assert_close(tot[..., 1], (out.double() ** 2).sum((2, 3)), rtol=1e-5, atol=1e-2)
+    gamma, beta, cb = r(cout), r(cout), r(cout)
+    for bias in (None, cb):
+        sc, sh = hip.group_norm_affine_from_stats([st], 32, 1e-6, gamma, beta, bias)
+        xin = out if bias is None else out + bias.view(1, -1, 1, 1)
+        want = F.group_norm(xin.double(), 32, gamma.double(), beta.double(), 1e-6).float()
+        torch.testing.assert_close(out * sc + sh, want, rtol=0, atol=3e-5)
+    # two parts = the norm of the cat; the second tensor at another resolution's statistics is the caller's business: same here
+    out2 = hip.wide_conv_cl(x, x2, None, None, "identity", packed, b * 2.0, cout, (k, k), upsample2x=up, stats=True)
+    g2, b2 = r(2 * cout), r(2 * cout)
+    sc, sh = hip.group_norm_affine_from_stats([st, hip.channel_stats(out2)], 32, 1e-6, g2, b2)
+    both = torch.cat([out, out2], 1)
+    want = F.group_norm(both.double(), 32, g2.double(), b2.double(), 1e-6).float()
+    torch.testing.assert_close(both * sc + sh, want, rtol=0, atol=3e-5)
+    # an in-place change of the tensor, or any new tensor, drops the statistics
+    assert hip.channel_stats(out.clone()) is None
+    out.add_(1.0)
+    assert hip.channel_stats(out) is None
+
+
+@pytest.mark.parametrize("shape,c2", [((1, 128, 64, 64), 0), ((1, 512, 32, 32), 256), ((2, 256, 24, 40), 128), ((1, 36, 10, 6), 0)])
+def test_channel_stats_of_a_tensor_and_the_norm_of_a_cat(hip, shape, c2):
+    """hip.channel_stats_cl (one pass over a tensor whose producer left no statistics) feeds the same finisher; 768 = 512 + 256
+    channels in 32 groups of 24 (a group size that does not divide the workgroup) and 384 = 256 + 128 in groups of 12 are the
+    U-Net's up-path norms over a torch.cat that the full pass never builds."""
+    torch.manual_seed(shape[1] + c2)
+    B, C1, H, W = shape
+    x = _cl(torch.randn(*shape, device=DEV) * 1.5 + 0.3)
+    st = hip.channel_stats_cl(x)
+    assert st is not None and hip.channel_stats(x) is st and st.count == H * W
+    tot = st.data.double().view(B, st.tiles, C1, 2).sum(1)
+    torch.testing.assert_close(tot[..., 0], x.double().sum((2, 3)), rtol=1e-5, atol=1e-2)
+    groups = 32 if (C1 + c2) % 32 == 0 else 4
+    parts, full = [st], x
+    if c2:
+        x2 = _cl(torch.randn(B, c2, H, W, device=DEV) - 0.2)
+        parts.append(hip.channel_stats_cl(x2))
+        full = torch.cat([x, x2], 1)
+    C = C1 + c2
+    gamma, beta, cb = (torch.randn(C, device=DEV) for _ in range(3))
+    for bias in (None, cb):
+        sc, sh = hip.group_norm_affine_from_stats(parts, groups, 1e-6, gamma, beta, bias)
+        xin = full if bias is None else full + bias.view(1, -1, 1, 1)
+        want = F.group_norm(xin.double(), groups, gamma.double(), beta.double(), 1e-6).float()
+        torch.testing.assert_close(full * sc + sh, want, rtol=0, atol=3e-5)
