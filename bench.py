@@ -935,6 +935,20 @@ def main():
             result["dense_forward_ms_by_layout"] = dense_by_layout
             model.set_plain_dense(False)
 
+        # ---- the alternative to distributing the cache: every rank recomputes it (the full pass on the library's kernels,
+        #      split fp16 operands: fp32-level, deterministic -- the same bits on every rank; no communication) ----
+        recompute_ms = None
+        if world > 1 and args.layout == "nhwc":
+            try:
+                model.set_compute_dtype("f16x3")
+                model.set_mode("full")
+                gf, _ = capture(model, x0, t)
+                recompute_ms = round(parallel.max_over_ranks(timed_replays(gf, 5, 2, 1) * 1e3 / 5, device=dev), 3)
+                del gf
+            except Exception as e:  # (never the reason a scaling run dies)
+                recompute_ms = repr(e)[:200]
+            model.set_compute_dtype(args.dtype)
+
         # ---- cache of the original image: rank 0 computes it, one collective distributes it ----
         model.set_mode("full")
         model(x0 if rank == 0 else torch.zeros_like(x0), t)  # ranks > 0 only need the cache SLOTS (shapes) here
@@ -1228,8 +1242,13 @@ def main():
                                    "speedup": round(full["f32"] / full["f16x3"], 2),
                                    "max_abs_output_delta": round(full_delta, 7),
                                    "library_f32_exact": round(full["f32_native"], 3),
-                                   "library_f32_exact_max_abs_output_delta": round(full_delta_native, 7)},
+                                   "library_f32_exact_max_abs_output_delta": round(full_delta_native, 7),
+                                   "note": "library = the dense-layer conv (conv_wide.hpp) with cat / nearest upsampling / residual sum "
+                                           "inside the launch, GroupNorm affines from the per-channel statistics the convs leave (no pass "
+                                           "over the tensor), small convs and downsamples on the tile kernels; no torch conv / norm / "
+                                           "elementwise op left except the timestep embedding"},
                   "step_ms_full_plus_sparse": {"f32": round(full["f32"] + ms_steady, 3),
+                                               "f32_exact_library_full_pass": round(full["f32_native"] + ms_steady, 3),
                                                "f16x3": round(full["f16x3"] + (base or ms_steady), 3),
                                                "note": "one denoising step of the reference's sampler = full pass on the original + "
                                                        "sparse pass on the edit (ddim_ddpm_sampler.py:60-73)"}}
@@ -1356,12 +1375,15 @@ def main():
                 dist_info, method=distribute, pipelined=not args.no_pipeline, chunks=None if args.no_pipeline else args.chunks,
                 rccl_ranks_seen=dist.get_world_size(),
                 cache_distribution_ms=round(dist_s * 1e3, 3),
+                recompute_full_pass_ms=recompute_ms,
                 value_cache_distribution_inside_job=round(world * args.steps / dt, 2),
                 value_steady_state_cache_resident=round(world * args.steps / dt_steady, 2),
                 value_cache_refreshed_every_step=round(world / (dist_s + step_s), 2),
                 note="`value` counts ONE cache distribution (collective + local refresh of derived buffers) inside the timed "
                      "job of %d steps; steady_state = the same replays with the cache already resident; every_step = a fresh "
-                     "cache per step (SDEdit-style), computed from the two measured times" % args.steps)
+                     "cache per step (SDEdit-style), computed from the two measured times; recompute_full_pass_ms = what every rank "
+                     "would spend recomputing the cache itself instead (library full pass, split fp16 operands, hipGraph), max over "
+                     "ranks" % args.steps)
         line.update(result)
         if parity is not None:
             line["parity_max_abs"] = parity

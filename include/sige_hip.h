@@ -291,6 +291,11 @@ int sige_hip_block_conv_force_ksplit(int ksplit);
  * block adds the partial copies of that block up in split order and runs the epilogue (tickets in a library-owned,
  * per-device buffer); 1: by a second launch over the whole output.  Both add in the same order: identical results. */
 int sige_hip_block_conv_force_ksplit_pass(int second_pass);
+/* Tickets of launches made while a stream is being CAPTURED into a hipGraph are bump-allocated (a replayed graph owns its
+ * tickets for its lifetime) out of 3 M per device; when they run out, captured K-split launches fall back to the second-pass
+ * finish (still correct, one more launch).  A long-running host that re-captures per mask calls this once every hipGraph
+ * captured so far on the CURRENT device has been destroyed: the region is handed out again from the start. */
+int sige_hip_release_graph_tickets(void);
 
 /* ---- fused gather -> conv and scatter_gather -> conv ------------------------
  * The same MFMA conv with the producer of its input tiles fused into the

@@ -395,6 +395,14 @@ int32_t *split_tickets(hipStream_t st, long blocks) {
     return p;
 }
 
+int release_graph_tickets() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return SIGE_HIP_EINVAL;
+    std::lock_guard<std::mutex> lock(g_tickets_mu);
+    g_tickets[dev].graph_pos = 0;
+    return SIGE_HIP_OK;
+}
+
 struct ConvPlan { int mt, nb, waves; };
 
 // PREC: 0 exact fp32 (ConvGeo) | 1 fp16 operands (ConvGeoH) | 2 split fp16 operands (ConvGeoX)
@@ -1178,3 +1186,5 @@ extern "C" int sige_hip_block_conv_direct_f32(const float *x, int T, int Cin, in
                                                                    strideH, strideW, dilationH, dilationW, groups, Ro, So, total);
     return launch_status();
 }
+
+extern "C" int sige_hip_release_graph_tickets(void) { return sige::release_graph_tickets(); }

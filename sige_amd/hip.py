@@ -150,6 +150,7 @@ _SIGNATURES = {
     "sige_hip_wide_conv_nhwc": (
         _c_int, [_c_vp, _c_vp] + [_c_int] * 6 + [_c_vp, _c_vp, _c_int, _c_int] + [_c_vp, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_int]
         + [_c_vp, _c_vp, _c_vp, _c_int] + [_c_vp] * 6 + [_c_vp, _c_sz, _c_vp, _c_vp, _c_vp]),
+    "sige_hip_release_graph_tickets": (_c_int, []),
     "sige_hip_channel_stats_tiles": (_c_int, [_c_int, _c_int]),
     "sige_hip_channel_stats_nhwc_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp]),
     "sige_hip_group_norm_affine_from_stats_f32": (
@@ -807,6 +808,12 @@ def scatter_gather_force_elements(element_form=False):
     """Benchmark / test knob: the NCHW scatter_gather's element form always (True / 1), or its one-tile row form (2: never the
     grouped form), instead of the automatic choice (False / 0)."""
     _check(lib().sige_hip_scatter_gather_force_elements(int(element_form)), "scatter_gather_force_elements")
+
+
+def release_graph_tickets():
+    """Every hipGraph captured so far on the current device has been destroyed: hand the K-split tickets of captured launches
+    out again from the start (include/sige_hip.h: sige_hip_release_graph_tickets)."""
+    _check(lib().sige_hip_release_graph_tickets(), "release_graph_tickets")
 
 
 def conv_force_ksplit_pass(second_pass: bool = False):
