@@ -608,3 +608,38 @@ def test_channel_stats_of_a_tensor_and_the_norm_of_a_cat(hip, shape, c2):
         xin = full if bias is None else full + bias.view(1, -1, 1, 1)
         want = F.group_norm(xin.double(), groups, gamma.double(), beta.double(), 1e-6).float()
         torch.testing.assert_close(full * sc + sh, want, rtol=0, atol=3e-5)
+
+
+def test_graph_pool_recapture_per_mask(ddpm_gpu, ddpm_reference):
+    """sige_amd.graphs.GraphPool: a new mask -> capture straight away (the capture is the first forward under that mask) ->
+    replay gives exactly what an eager forward gives, for alternating masks, and the reserved memory stops growing once the pool
+    is warm (a destroyed graph's blocks are reused by its successor's capture)."""
+    import bench
+    from sige_amd.graphs import GraphPool
+    from sige_amd.utils import dilate_mask, downsample_mask
+
+    model = ddpm_gpu
+    cl = lambda a: a.to(DEV).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    x0, noise, t = cl(ddpm_reference["x0"]), cl(ddpm_reference["noise"]), torch.zeros(1, device=DEV)
+    pool = GraphPool(x0.device)
+    g = None
+    reserved = []
+    with torch.no_grad():
+        model.set_compute_dtype("f32")
+        model.set_mode("full")
+        model(x0, t)
+        for i in range(6):
+            m = bench.edit_mask((0.012, 0.03, 0.02)[i % 3]).to(x0.device)
+            x1 = x0 + noise * m
+            model.set_masks(downsample_mask(dilate_mask(m, 5), 8))
+            model.set_mode("sparse")
+            if i == 0:
+                model(x1, t)  # (after a full pass the first sparse forward registers the activated twins: DESIGN 3.1)
+            del g
+            g, out = pool.capture(lambda: model(x1, t))
+            g.replay()
+            torch.cuda.synchronize()
+            got = out.clone()
+            assert torch.equal(got, model(x1, t))
+            reserved.append(torch.cuda.memory_reserved(x0.device))
+    assert reserved[-1] == reserved[-2] == reserved[-3], reserved
