@@ -1,6 +1,6 @@
 """Debug aid: the flow of tests/test_gpu_channels_last.py::test_ddpm_unet_channels_last_equals_nchw with per-module outputs."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from sige_amd.utils import dilate_mask, downsample_mask
 from sige_amd.workloads.ddpm_unet import DDPMConfig, DDPMSparseUNet, ResBlock, AttnBlock, Upsample, Downsample
