@@ -66,11 +66,13 @@ def build_probe(verbose: bool = True) -> str:
     pdir = os.path.join(LIB_DIR, "probe" + tag)
     os.makedirs(pdir, exist_ok=True)
     objs, procs = [], []
+    wide = bool(os.environ.get("SIGE_PROBE_WIDE"))  # the dense-layer conv's stamps instead (tools/probe/wide_phase_probe.py)
     for src in SOURCES:
-        if src.startswith(("conv_k", "conv_pair", "block_conv")) and (not only or src in only or src.startswith("block_conv")):
+        if (src.startswith("conv_wide") if wide else
+                src.startswith(("conv_k", "conv_pair", "block_conv")) and (not only or src in only or src.startswith("block_conv"))):
             obj = os.path.join(pdir, src.replace(".hip", ".o"))
             # (SIGE_VARIANT_ONLY=1: an experimental variant of the product kernels -- the defines only, no phase stamps)
-            probe_def = [] if os.environ.get("SIGE_VARIANT_ONLY") else ["-DSIGE_CONV_PROBE"]
+            probe_def = [] if os.environ.get("SIGE_VARIANT_ONLY") else ["-DSIGE_WIDE_PROBE" if wide else "-DSIGE_CONV_PROBE"]
             cmd = [_hipcc(), *FLAGS, *probe_def, *os.environ.get("SIGE_PROBE_DEFS", "").split(),
                    "-I" + os.path.join(REPO, "include"), "-I" + CSRC, "-c",
                    os.path.join(CSRC, src), "-o", obj]

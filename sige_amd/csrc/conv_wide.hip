@@ -147,6 +147,20 @@ extern "C" size_t sige_hip_wide_conv_workspace(int B, int H, int W, int C1, int 
     return s > 1 ? (size_t)s * out_floats : 0;
 }
 
+#ifdef SIGE_WIDE_PROBE
+static unsigned long long *g_wprobe_buf = nullptr;
+// (measurement build only, not declared in include/sige_hip.h)
+extern "C" int sige_hip_wide_probe_read(unsigned long long *host, int workgroups) {
+    if (!g_wprobe_buf || workgroups > 4096) return SIGE_HIP_EINVAL;
+    return hipMemcpy(host, g_wprobe_buf, (size_t)workgroups * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess
+               ? SIGE_HIP_OK : SIGE_HIP_ELAUNCH;
+}
+extern "C" int sige_hip_wide_probe_clear(void) {
+    if (!g_wprobe_buf && hipMalloc(&g_wprobe_buf, 8 * 4096 * sizeof(unsigned long long)) != hipSuccess) { g_wprobe_buf = nullptr; return SIGE_HIP_ELAUNCH; }
+    return hipMemset(g_wprobe_buf, 0, 8 * 4096 * sizeof(unsigned long long)) == hipSuccess ? SIGE_HIP_OK : SIGE_HIP_ELAUNCH;
+}
+#endif
+
 extern "C" int sige_hip_wide_conv_force_ksplit(int ksplit) {
     if (ksplit < 0 || ksplit > kWideMaxSplit) return SIGE_HIP_EINVAL;
     g_wide_force_ksplit = ksplit;
@@ -184,6 +198,9 @@ extern "C" int sige_hip_wide_conv_nhwc(const float *x, const float *x2, int B, i
     if ((twin0 && !(twin_scale0 && twin_shift0)) || (twin1 && !(twin_scale1 && twin_shift1))) return SIGE_HIP_EINVAL;
     a.wscale = ldexpf(1.0f, -wshift);
     a.stats = reinterpret_cast<float2 *>(stats);
+#ifdef SIGE_WIDE_PROBE
+    a.probe = g_wprobe_buf;
+#endif
     a.B = B; a.H = H; a.W = W; a.C1 = C1; a.C2 = C2; a.Cout = Cout; a.up = upsample2x ? 1 : 0; a.act = activation;
     a.aff_sb = (scale && affineB > 1) ? C1 + C2 : 0;
     const int pwo = wide_patch(W);

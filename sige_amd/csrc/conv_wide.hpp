@@ -93,7 +93,22 @@ struct WideArgs {
     int ntn;                    // 64-channel output blocks
     int nchunks, nchunks1;      // channel chunks in total / in x
     int ksplit, chunks_per_split;
+#ifdef SIGE_WIDE_PROBE
+    unsigned long long *probe;  // tools/probe/wide_phase_probe.py build only: 8 timestamps per workgroup
+#endif
 };
+
+// Phase timestamps (s_memtime) of workgroups 0..4095, lane 0 -- compiled in only for the measurement build
+// (SIGE_PROBE_WIDE=1 python -m sige_amd.build --probe); the product library contains none of this.
+#ifdef SIGE_WIDE_PROBE
+#define SIGE_WPROBE(k)                                                                                      \
+    do {                                                                                                    \
+        if (a.probe && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096)                            \
+            a.probe[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime();                                   \
+    } while (0)
+#else
+#define SIGE_WPROBE(k)
+#endif
 
 __device__ __forceinline__ f16x8 buf_h8(rsrc_t r, unsigned byte_off, int soff) {
     const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, soff, 0));
@@ -108,6 +123,7 @@ __global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a
     constexpr int NS = G::NS, STEPS = G::STEPS, RB = G::RB, NP = G::NP;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    SIGE_WPROBE(0);  // entry
     // consecutive workgroups (= consecutive XCDs) take different output-channel blocks; all pixel blocks of one channel
     // block land on XCD (ntile mod 8) when ntn is a multiple of 8: a layer's weights are fetched into one L2 each
     const int ntile = blockIdx.x % a.ntn, mtile = blockIdx.x / a.ntn;
@@ -334,13 +350,16 @@ __global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a
             a_lo = n_lo;
         });
     };
+    SIGE_WPROBE(1);  // prologue done: first stage in LDS, weight ring filled
     for (int chunk = first; chunk <= last; chunk += 2) {
         body(std::integral_constant<int, 0>{}, chunk);
         if (chunk + 1 <= last) body(std::integral_constant<int, 1>{}, chunk + 1);
     }
 
+    SIGE_WPROBE(2);  // K loop done (this wave)
     // ---- reduction of the four waves' K shares through LDS ----
     __syncthreads();  // (the reduction buffer overlaps the other waves' stages)
+    SIGE_WPROBE(3);  // every wave's K loop done
     constexpr int RP = 68;
     float *const red = reinterpret_cast<float *>(smem);
     {
@@ -357,6 +376,7 @@ __global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a
     }
     __syncthreads();
 
+    SIGE_WPROBE(4);  // accumulators in LDS
     // ---- epilogue: one float4 = 4 consecutive output channels of one pixel per lane and step ----
     const bool split_k = a.ksplit > 1;
     float *const outp = a.out + (size_t)split * a.split_stride;
@@ -447,7 +467,9 @@ __global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a
         if (!split_k) emit(u, s);
         else coherent_store(outp + u.addr, s);
     }
+    SIGE_WPROBE(5);  // output stores issued
     if (!split_k) flush_stats();
+    SIGE_WPROBE(6);  // statistics written
     if (split_k) {
         // partial sums went out as device-coherent stores (complete = visible to every XCD); then the block's ticket; the
         // workgroup that draws the last one adds the copies in split order (deterministic) and runs the epilogue
