@@ -577,3 +577,56 @@ def test_twin_buffers_follow_cache_and_masks():
     torch.testing.assert_close(b3, want(cache2))
     tb.unregister("a")
     assert [k for k, *_ in tb.launch_args(0, cache2, stamp=2)] == ["b"] and tb.register("c", sc, sh)
+
+
+def test_full_conv2d_off_the_gpu_is_the_torch_expression():
+    """dense.full_conv2d (the full pass's conv) anywhere but on a channels-last GPU tensor with a non-fp32 compute dtype is the
+    reference's own torch expression -- also for the options the library's full pass fuses into the launch (second half of a
+    cat, nearest x2 upsampling, residual); `stats` is then simply not produced."""
+    from torch.nn import functional as F
+
+    from sige_amd import hip
+    from sige_amd.nn.dense import fast_full_pass, full_conv2d, group_norm_affine
+
+    torch.manual_seed(3)
+    conv = nn.Conv2d(12, 8, 3, 1, 1)
+    x, x2 = torch.randn(1, 8, 10, 6), torch.randn(1, 4, 10, 6)
+    s, t = torch.randn(1, 12, 1, 1), torch.randn(1, 12, 1, 1)
+    res = torch.randn(1, 8, 20, 12)
+    assert not fast_full_pass(conv)
+    with torch.no_grad():
+        got = full_conv2d(conv, x, s, t, "swish", residual=res, x2=x2, upsample2x=True, stats=True)
+        h = F.interpolate(torch.cat([x, x2], 1), scale_factor=2.0, mode="nearest")
+        want = conv(F.silu(h * s + t)) + res
+    assert torch.equal(got, want)
+    assert hip.channel_stats(got) is None
+    # the GroupNorm of a cat / of x + bias without statistics: the same affine as torch's GroupNorm
+    norm = nn.GroupNorm(4, 12)
+    with torch.no_grad():
+        norm.weight.normal_()
+        norm.bias.normal_()
+        cb = torch.randn(12)
+        sc, sh = group_norm_affine(x, norm, cb, x2=x2, make_stats=True)
+        both = torch.cat([x, x2], 1)
+        torch.testing.assert_close(both * sc + sh, norm(both + cb.view(1, -1, 1, 1)), rtol=1e-5, atol=1e-5)
+
+
+def test_block_residual_scatter_takes_a_precomputed_sum(cpu_oracle_backend):
+    """ScatterWithBlockResidual.forward(x, residual, x_is_sum=True) (full mode: the conv's epilogue already added the residual)
+    caches exactly what forward(main, residual) caches (sige/nn/scatter.py:89-93), and is refused outside full mode."""
+    from sige_amd.nn import Gather, ScatterWithBlockResidual, SIGEConv2d
+
+    torch.manual_seed(4)
+    conv, short = SIGEConv2d(4, 4, 3, 1, 1), SIGEConv2d(4, 4, 1, 1, 0)
+    g0, g1 = Gather(conv, 6), Gather(short, 4)
+    a, b = ScatterWithBlockResidual(g0, g1), ScatterWithBlockResidual(g0, g1)
+    main, resid = torch.randn(1, 4, 16, 16), torch.randn(1, 4, 16, 16)
+    for m in (g0, g1, a, b):
+        m.set_mode("full")
+    out_a = a(main, resid)
+    out_b = b(main + resid, resid, x_is_sum=True)
+    assert torch.equal(out_a, out_b)
+    assert torch.equal(a.original_outputs[0], b.original_outputs[0]) and torch.equal(a.original_residuals[0], b.original_residuals[0])
+    b.set_mode("sparse")
+    with pytest.raises(AssertionError):
+        b(main, resid, x_is_sum=True)
