@@ -859,7 +859,14 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="N > 1: one collective over the whole cache, then the local refresh "
                     "(default: chunks in module order, refresh of chunk k overlapped with the transfer of chunk k+1)")
     ap.add_argument("--chunks", type=int, default=8, help="N > 1: chunks of the pipelined cache distribution")
+    ap.add_argument("--wire-dtype", default="f32", choices=["f32", "f16"],
+                    help="N > 1: the cached activations travel as fp16 (half the bytes; every rank, the source included, ends up with "
+                         "the same fp16-rounded cache; the cached affines stay fp32).  Only with --dtype f16: the rounding costs up to "
+                         "1.6e-3 of output error at 15 %% edit (profiles/r3_f16_cache_trace.json) -- inside the f16 criterion, outside "
+                         "the fp32 path's 1e-3")
     args = ap.parse_args()
+    if args.wire_dtype == "f16" and args.dtype != "f16":
+        ap.error("--wire-dtype f16 goes with --dtype f16 (an fp16-rounded cache does not keep the fp32 path's 1e-3)")
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path; see DESIGN.md)")
@@ -957,6 +964,7 @@ def main():
         torch.cuda.synchronize()
         dist_info = {}
         distribute = None
+        wire = torch.float16 if args.wire_dtype == "f16" else None
         if world > 1:
             methods = ["broadcast", "scatter_allgather"] if args.distribute == "auto" else [args.distribute]
             best = None
@@ -967,7 +975,7 @@ def main():
                         dist.barrier()
                         torch.cuda.synchronize()
                         t0 = time.perf_counter()
-                        parallel.distribute_cache(flat, src=0, method=meth)
+                        parallel.distribute_cache(flat, src=0, method=meth, model=model if wire is not None else None, wire_dtype=wire)
                         torch.cuda.synchronize()
                         ms.append((time.perf_counter() - t0) * 1e3)
                     v = parallel.max_over_ranks(min(ms), device=dev)
@@ -1021,9 +1029,9 @@ def main():
                 # chunks in module order, issued asynchronously; what a rank derives from the cache is refreshed chunk by
                 # chunk while later chunks still move (in place: the captured graph's buffers keep their addresses)
                 if args.no_pipeline:
-                    parallel.distribute_cache(flat, src=0, method=distribute, model=model)
+                    parallel.distribute_cache(flat, src=0, method=distribute, model=model, wire_dtype=wire)
                 else:
-                    parallel.distribute_cache_pipelined(flat, model, src=0, method=distribute, n_chunks=args.chunks)
+                    parallel.distribute_cache_pipelined(flat, model, src=0, method=distribute, n_chunks=args.chunks, wire_dtype=wire)
                 torch.cuda.synchronize()
                 t_d = time.perf_counter() - t0
             for _ in range(args.steps):
@@ -1410,6 +1418,7 @@ def main():
             line["multi_gpu"] = dict(
                 dist_info, method=distribute, pipelined=not args.no_pipeline, chunks=None if args.no_pipeline else args.chunks,
                 rccl_ranks_seen=dist.get_world_size(),
+                wire_dtype=args.wire_dtype, wire_bytes=int(flat.numel() * (2 if wire is not None else 4)),
                 cache_distribution_ms=round(dist_s * 1e3, 3),
                 recompute_full_pass_ms=recompute_ms,
                 value_cache_distribution_inside_job=round(world * args.steps / dt, 2),

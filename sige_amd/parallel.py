@@ -106,7 +106,7 @@ def pack_caches(model: torch.nn.Module) -> torch.Tensor:
     total = (sum(sizes) + _PAD - 1) // _PAD * _PAD  # (see _PAD: distribute_cache splits the buffer evenly over the ranks)
     flat = torch.zeros(total, dtype=torch.float32, device=ref.device)
     off = 0
-    layout = []  # (owning module, first float, one past its last float) in module order
+    layout = []  # (owning module, first float, one past its last (padded) float, true element count) in module order
     for s, size in zip(slots, sizes):
         t = _get(s)
         if t.dtype != torch.float32:
@@ -119,7 +119,7 @@ def pack_caches(model: torch.nn.Module) -> torch.Tensor:
             view = flat[off:off + t.numel()].view(t.shape)  # (a non-dense view -- e.g. an expanded affine -- is stored dense)
         view.copy_(t)
         _set(s, view)
-        layout.append((s[4], off, off + size))
+        layout.append((s[4], off, off + size, t.numel()))
         off += size
     for m in model.modules():  # the cache tensors moved: persistent outputs are rebuilt on next use
         bufs = getattr(m, "_out_bufs", None)
@@ -144,8 +144,53 @@ def _global_rank(group, r: int) -> int:
     return r if group is None else dist.get_global_rank(group, r)
 
 
+# ---- fp16 on the wire -------------------------------------------------------------------------------------------------
+# The cached ACTIVATIONS may travel as fp16 (half the bytes over xGMI: 337 instead of 673 MB for DDPM-256): emulated on the CPU
+# oracle (profiles/r3_f16_cache_trace.json), a cache rounded to fp16 moves the sparse pass's output by 5e-4 / 5e-4 / 1.6e-3 at
+# 1.2 / 5 / 15 % edit -- 0.02-0.07 of what the f16 criterion (sige_amd/tolerance.py) allows, but above the fp32 path's 1e-3 at
+# large edits, so it is an option of the f16 compute mode, not a default.  The cached AFFINES (GroupNorm scale / shift: a few
+# KB, and the one place where 2^-11 relative is not harmless) always travel in fp32.  Every rank, the source included, ends up
+# with the SAME rounded cache: the ranks' results stay bit-identical to each other.
+_WIRE_SMALL = 1 << 16  # cache tensors below this many elements stay fp32 on the wire
+
+
+def _wire_layout(flat: torch.Tensor, model: torch.nn.Module):
+    ptr, layout = (model.__dict__.get("_sige_cache_layout", (None, None)) if model is not None else (None, None))
+    if layout is None or ptr != flat.data_ptr():
+        raise RuntimeError("wire_dtype needs `model` and the buffer pack_caches(model) returned (the layout says which tensors are "
+                           "cached affines)")
+    small, pos = [], 0
+    for _, off, _, n in layout:
+        if n < _WIRE_SMALL:
+            small.append((off, off + n, pos))  # (first float, one past the last, position in the fp32 side buffer)
+            pos += n
+    return small, pos
+
+
+def _wire_send(flat, small, side_n, src, group):
+    """The fp16 image of the packed cache (on `src`; elsewhere an empty buffer of the same size) and the fp32 side buffer with the
+    small tensors, the latter already distributed."""
+    rank = dist.get_rank(group)
+    wire = flat.to(torch.float16) if rank == src else torch.empty(flat.numel(), dtype=torch.float16, device=flat.device)
+    side = torch.empty(max(side_n, 1), dtype=torch.float32, device=flat.device)
+    if rank == src:
+        for lo, hi, pos in small:
+            side[pos:pos + hi - lo].copy_(flat[lo:hi])
+    dist.broadcast(side, src=_global_rank(group, src), group=group)
+    return wire, side
+
+
+def _wire_land(flat, wire, side, small, lo, hi):
+    """flat[lo:hi] <- the fp16 piece that has landed, the small tensors inside it from the fp32 side buffer."""
+    flat[lo:hi].copy_(wire[lo:hi])
+    for a, b, pos in small:
+        a2, b2 = max(a, lo), min(b, hi)
+        if a2 < b2:
+            flat[a2:b2].copy_(side[pos + a2 - a:pos + b2 - a])
+
+
 def distribute_cache(flat: torch.Tensor, src: int = 0, method: str = "broadcast", group=None,
-                     model: torch.nn.Module = None) -> None:
+                     model: torch.nn.Module = None, wire_dtype=None) -> None:
     """Rank `src` (a rank of `group`)'s packed cache to every rank of the group; with `model`, the buffers derived from the
     cache (activated copies, persistent outputs) are refreshed afterwards -- for both methods.
 
@@ -153,14 +198,24 @@ def distribute_cache(flat: torch.Tensor, src: int = 0, method: str = "broadcast"
     different xGMI links in parallel on an 8-GPU MI355X node), then one in-place all-gather, in which every link of the
     fully connected node carries 1/N of the buffer at the same time -- xGMI is point-to-point, so a broadcast's ring /
     tree moves the WHOLE buffer over each hop's single link (~4.4 ms vs ~1.3 ms ideal for 673 MB).
-    `flat.numel()` must be a multiple of the world size for the second form (pack_caches pads it)."""
+    `flat.numel()` must be a multiple of the world size for the second form (pack_caches pads it).
+    `wire_dtype=torch.float16` (needs `model`): the activations travel as fp16, see above."""
     world = dist.get_world_size(group)
     if world == 1:
         return
     if method not in ("broadcast", "scatter_allgather"):
         raise ValueError("unknown method %r" % method)
-    work = _issue(flat, src, method, group, world, async_op=False)
-    assert work is None
+    if wire_dtype not in (None, torch.float32, torch.float16):
+        raise ValueError("wire_dtype: torch.float32 or torch.float16")
+    if wire_dtype == torch.float16:
+        small, side_n = _wire_layout(flat, model)
+        wire, side = _wire_send(flat, small, side_n, src, group)
+        work = _issue(wire, src, method, group, world, async_op=False)
+        assert work is None
+        _wire_land(flat, wire, side, small, 0, flat.numel())
+    else:
+        work = _issue(flat, src, method, group, world, async_op=False)
+        assert work is None
     if model is not None:
         refresh_derived(model)
 
@@ -185,13 +240,14 @@ def _issue(buf: torch.Tensor, src: int, method: str, group, world: int, async_op
 
 
 def distribute_cache_pipelined(flat: torch.Tensor, model: torch.nn.Module, src: int = 0, method: str = "scatter_allgather",
-                               n_chunks: int = 8, group=None) -> dict:
+                               n_chunks: int = 8, group=None, wire_dtype=None) -> dict:
     """The same result as `distribute_cache(..., model=model)`, pipelined: the packed cache is cut into `n_chunks` pieces in
     MODULE ORDER (pack_caches lays the tensors out in the order the forward uses them), every piece's collective is issued
     asynchronously up front, and as soon as piece k has landed the buffers derived from the modules whose caches are
     complete (activated ScatterGather copies, persistent Scatter outputs, activated twins: ~0.65 GB of local copies for
     DDPM-256) are refreshed on the current stream -- while pieces k+1 ... are still moving over xGMI.  What remains exposed
-    is the transfer itself plus the last piece's refresh.  Returns {"chunks": n, "refreshed": modules refreshed}."""
+    is the transfer itself plus the last piece's refresh.  `wire_dtype=torch.float16`: see distribute_cache.
+    Returns {"chunks": n, "refreshed": modules refreshed, "wire_bytes": bytes every rank received}."""
     world = dist.get_world_size(group)
     ptr, layout = model.__dict__.get("_sige_cache_layout", (None, None))
     if layout is None or ptr != flat.data_ptr():
@@ -211,7 +267,7 @@ def distribute_cache_pipelined(flat: torch.Tensor, model: torch.nn.Module, src: 
     for name, m in model.named_modules():
         for cname, c in m.named_children():
             parents[c] = m
-    for m, _, e in layout:
+    for m, _, e, _ in layout:
         node = m
         while node is not None:
             end[node] = max(end.get(node, 0), e)
@@ -223,14 +279,23 @@ def distribute_cache_pipelined(flat: torch.Tensor, model: torch.nn.Module, src: 
         e = end.get(m, 0)
         k = next((i for i, (lo, hi) in enumerate(bounds) if e <= hi), len(bounds) - 1)
         ready[k].append(m)
-    works = [_issue(flat[lo:hi], src, method, group, world, async_op=True) for lo, hi in bounds]
+    if wire_dtype not in (None, torch.float32, torch.float16):
+        raise ValueError("wire_dtype: torch.float32 or torch.float16")
+    f16 = wire_dtype == torch.float16
+    if f16:  # (the activations travel as fp16, the cached affines in an fp32 side buffer sent first: see distribute_cache)
+        small, side_n = _wire_layout(flat, model)
+        wire, side = _wire_send(flat, small, side_n, src, group)
+    buf = wire if f16 else flat
+    works = [_issue(buf[lo:hi], src, method, group, world, async_op=True) for lo, hi in bounds]
     n = 0
     for k, work in enumerate(works):
         if work is not None:
             work.wait()
+        if f16:
+            _wire_land(flat, wire, side, small, *bounds[k])
         refresh_derived(model, ready[k])
         n += len(ready[k])
-    return {"chunks": len(bounds), "refreshed": n}
+    return {"chunks": len(bounds), "refreshed": n, "wire_bytes": int(buf.numel() * buf.element_size() + (side.numel() * 4 if f16 else 0))}
 
 
 def max_over_ranks(seconds: float, device=None, group=None) -> float:

@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--per-layer", type=float, default=0.0, help="edit ratio of the one-conv-at-a-time trace (0 = skip)")
     ap.add_argument("--storage", action="store_true", help="also round conv outputs to fp16 (f16 storage)")
     ap.add_argument("--keep", default="", help="comma-separated conv names kept in fp32 (prefix match)")
+    ap.add_argument("--cache", action="store_true", help="fp16 CACHE only: the cached activations of the full pass are rounded to fp16 (what "
+                    "parallel.distribute_cache(wire_dtype=torch.float16) leaves on every rank), the sparse pass computes in fp32 and, second "
+                    "row, with the model's f16 policy")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
 
@@ -127,6 +130,30 @@ def main():
                 rows["%g" % r] = tolerance.f16_check(run(r, names), ref[r])
             return rows
 
+        if args.cache:
+            from sige_amd import parallel
+
+            rounded = 0
+            for sl in parallel.cache_slots(model):
+                v = parallel._get(sl)
+                if v.numel() >= parallel._WIRE_SMALL:  # (the cached affines travel -- and stay -- fp32)
+                    parallel._set(sl, v.half().float())
+                    rounded += v.numel()
+            parallel.refresh_derived(model)
+            report["cache_elements_rounded_to_fp16"] = rounded
+            report["fp16_cache_fp32_compute"] = {}
+            for r in ratios:
+                out = run(r, ())
+                c = tolerance.f16_check(out, ref[r])
+                c["meets_the_fp32_tolerance_1e-3"] = bool(c["max_abs"] <= 1e-3)
+                report["fp16_cache_fp32_compute"]["%g" % r] = c
+            print(json.dumps(report["fp16_cache_fp32_compute"], indent=1), flush=True)
+            report["fp16_cache_f16_policy"] = {}
+            for r in ratios:
+                keep_r = tuple(getattr(model, "F16_KEEP", ())) if r > getattr(model, "F16_KEEP_ABOVE", 1.0) else ()
+                names = [n for n in emu.convs if not kept(n, keep_r)]
+                report["fp16_cache_f16_policy"]["%g" % r] = tolerance.f16_check(run(r, names), ref[r])
+            print(json.dumps(report["fp16_cache_f16_policy"], indent=1), flush=True)
         report["ratios"] = sweep(keep)
         report["keep_f32"] = list(keep)
         print(json.dumps(report["ratios"], indent=1), flush=True)

@@ -18,7 +18,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _build():
+def _build(affine=False):
     from tests.test_host_logic import ResNet
 
     torch.manual_seed(11)
@@ -26,6 +26,8 @@ def _build():
     blk = net.block
     blk.s1, blk.t1 = torch.randn(1, 8, 1, 1), torch.randn(1, 8, 1, 1)
     blk.s2, blk.t2 = torch.randn(1, 12, 1, 1), torch.randn(1, 12, 1, 1)
+    if affine:  # (what a workload model keeps per block: the cached GroupNorm affines travel with the activation caches)
+        blk.affine = (blk.s1.clone(), blk.t1.clone(), blk.s2.clone(), blk.t2.clone())
     return net
 
 
@@ -56,7 +58,7 @@ def _worker(rank, world, port, out_dir, method="broadcast"):
     from sige_amd import parallel, runtime
 
     runtime.register_backend("cpu", oracle)
-    net = _build()
+    net = _build(affine=method.startswith("f16wire:"))
     orig, edits = _inputs()
     with torch.no_grad():
         net.set_mode("full")
@@ -65,6 +67,20 @@ def _worker(rank, world, port, out_dir, method="broadcast"):
         flat = parallel.pack_caches(net)
         if method == "broadcast":
             parallel.broadcast_cache(flat, src=0, model=net)
+        elif method.startswith("f16wire:"):
+            # activations as fp16 on the wire, the cached affines in fp32; the source rounds its own cache the same way
+            parallel._WIRE_SMALL = 1000  # (this toy network's activations are 8 192 elements: above, its affines 8 / 12: below)
+            if rank != 0:
+                flat.fill_(7.0)  # (nothing of the receivers' own values may survive)
+            before = flat.clone()
+            kind = method.split(":")[1]
+            if kind == "pipelined":
+                info = parallel.distribute_cache_pipelined(flat, net, src=0, method="scatter_allgather", n_chunks=3, wire_dtype=torch.float16)
+                assert info["wire_bytes"] < flat.numel() * 4 * 0.6
+            else:
+                parallel.distribute_cache(flat, src=0, method=kind, model=net, wire_dtype=torch.float16)
+            if rank == 0:
+                assert not torch.equal(flat, before)  # (the source's own cache is rounded too)
         elif method.startswith("pipelined:"):
             info = parallel.distribute_cache_pipelined(flat, net, src=0, method=method.split(":")[1], n_chunks=3)
             assert info["chunks"] >= 2 and info["refreshed"] >= 1
@@ -153,3 +169,38 @@ def test_pack_caches_requires_full_pass():
 
     with pytest.raises(RuntimeError, match="full"):
         parallel.pack_caches(_build())
+
+
+@pytest.mark.parametrize("kind", ["broadcast", "scatter_allgather", "pipelined"])
+def test_cache_distribution_with_fp16_on_the_wire(tmp_path, kind):
+    """`wire_dtype=torch.float16`: every rank -- the source included -- ends up with the source's cache rounded to fp16 (big
+    tensors) resp. exact (tensors below 65 536 elements: the cached affines), so the ranks' outputs are bit-identical to a
+    single process that rounds its cache the same way."""
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "f16wire:" + kind), nprocs=world, join=True)
+    res = [torch.load(tmp_path / ("rank%d.pt" % r)) for r in range(world)]
+    assert res[0]["flat_sum"] == res[1]["flat_sum"]
+    from oracle import oracle
+    from sige_amd import parallel, runtime
+
+    runtime.register_backend("cpu", oracle)
+    try:
+        net = _build(affine=True)
+        orig, edits = _inputs()
+        with torch.no_grad():
+            net.set_mode("full")
+            net(orig)
+            flat = parallel.pack_caches(net)
+            exact = flat.clone()
+            _, layout = net.__dict__["_sige_cache_layout"]
+            assert any(n < 1000 for _, _, _, n in layout) and any(n >= 1000 for _, _, _, n in layout)
+            for _, off, _, n in layout:
+                if n >= 1000:
+                    flat[off:off + n].copy_(flat[off:off + n].half().float())
+            assert not torch.equal(flat, exact)  # (this network's caches are above the threshold: something was rounded)
+            parallel.refresh_derived(net)
+            assert float(flat.double().sum()) == res[0]["flat_sum"]
+            for i, (m, x) in enumerate(edits):
+                assert torch.equal(res[i % world]["outs"][i], _sparse(net, m, x))
+    finally:
+        runtime.unregister_backend("cpu")
