@@ -428,7 +428,15 @@ static int plan_conv(ConvArgs &a, int cap, int want_waves, bool nb1, ConvPlan &p
     const long kFill = want_waves ? 64 : 224;  // (a pair's second conv shares the chip with the first)
     int mt = 0, nb = 1;
     if (g_force_mt && !want_waves) { mt = g_force_mt == 32 ? 32 : 16; nb = (g_force_nb == 2 && kHasNB2) ? 2 : 1; if (!usable(mt)) mt = 0; }
-    if (!mt && cap > 1 && usable(16) && blocks(G16::TPB, 16, 1) < kFill) {
+    // Exact fp32, channels-last, stride 1 has 8-wave workgroups (two waves per SIMD on every CU a workgroup lands on): with
+    // those, 128 unsplit 16-channel blocks beat 32 blocks x 4 K splits -- the 8x8 layers of the DDPM U-Net, 13.4 vs 14.4 us per
+    // launch, 1.437 -> 1.419 ms per forward (tools/probe/ksplit_forward_probe.py, round 3): the split's second phase (partial
+    // sums out, ticket, the last workgroup's sum over the copies) costs more than the 4x shorter K loop saves.  Below half a
+    // chip of blocks the split still wins.
+    constexpr bool kW8Geo = LAY == LAYOUT_NHWC && STR == 1 && PREC == 0;
+    const long kSplitBelow = (kW8Geo && !want_waves) ? 112 : kFill;
+    const bool stay_unsplit = cap > 1 && usable(16) && blocks(G16::TPB, 16, 1) >= kSplitBelow && blocks(G16::TPB, 16, 1) < kFill && !g_force_ksplit;
+    if (!mt && cap > 1 && usable(16) && blocks(G16::TPB, 16, 1) < kSplitBelow) {
         // too few tiles for any block shape: split K across workgroups, largest block that then fills the chip
         const int nc32 = ceil_div(a.Cin, G32::CC), nc16 = ceil_div(a.Cin, G16::CC);
         auto filled = [&](int tpb, int m, int n, int nc) { long b = blocks(tpb, m, n); return b * ksplit_for(b, nc, cap); };
@@ -471,7 +479,7 @@ static int plan_conv(ConvArgs &a, int cap, int want_waves, bool nb1, ConvPlan &p
         a.packed += PREC == 2 ? packed_units_x(a.Cout, a.Cin, KH * KH, 32)
                               : (PREC == 1 ? packed_units_h(a.Cout, a.Cin, KH * KH, 32) : packed_floats(a.Cout, a.Cin, KH * KH, 32));
     // K split (channels-last launches that came with a workspace)
-    a.ksplit = ksplit_for((long)a.mbk * a.ngk, a.nchunks, cap);
+    a.ksplit = stay_unsplit ? 1 : ksplit_for((long)a.mbk * a.ngk, a.nchunks, cap);
     a.chunks_per_split = ceil_div(a.nchunks, a.ksplit);
     a.ksplit = ceil_div(a.nchunks, a.chunks_per_split);
 #ifdef SIGE_CONV_PROBE

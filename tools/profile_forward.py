@@ -30,6 +30,7 @@ def main():
                     help="full = the cache-producing full pass (with --dtype f16x3: on the library's dense-layer kernel)")
     ap.add_argument("--layout", default="nhwc", choices=["nhwc", "nchw"])
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "f16x3"], help="arithmetic of the convs (bench.py --dtype)")
+    ap.add_argument("--ksplit", type=int, default=0, help="pin the cross-workgroup K split of the tile convs (hip.conv_force_ksplit; 0 = automatic)")
     ap.add_argument("--manifest", default="", help="eager mode: write the kernel-family sequence of one forward's conv launches here")
     a = ap.parse_args()
     dev = torch.device("cuda")
@@ -44,6 +45,10 @@ def main():
         model = model.to(memory_format=torch.channels_last)
         x0, noise = x0.contiguous(memory_format=torch.channels_last), noise.contiguous(memory_format=torch.channels_last)
         model.set_scatter_inplace(True)
+    if a.ksplit:
+        from sige_amd import hip as _hip
+
+        _hip.conv_force_ksplit(a.ksplit)
     model.set_compute_dtype(a.dtype, edit_ratio=a.ratio)  # (the f16 precision policy depends on the edited area)
     mask = bench.square_mask(a.ratio).to(dev)
     x1 = x0 + noise * mask
