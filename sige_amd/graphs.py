@@ -4,8 +4,9 @@
 tensor the forward allocates is hipMalloc'ed again (~100 allocations), and the blocks of the graph just destroyed are handed
 back to the driver first.  Measured on MI355X for the DDPM-256 sparse forward (tools/probe/recapture_probe.py): 7.1 ms per
 capture; with ONE capture stream and ONE pool for every capture 4.7 ms, and capturing straight away -- the capture IS the
-first forward under the new mask -- 1.6 (set_masks) + 6.2 + 2.7 (first replay) = 10.5 ms from a new mask to the first output WITH
-the steady-state graph in hand, against 7.9 ms to an eager first output and 16.6 ms to the graph.
+first forward under the new mask -- 1.6 (set_masks) + 5.5 + 2.2 (first replay) = 9.4 ms from a new mask to the first output WITH
+the steady-state graph in hand (bench.py: dynamic.mask_change_capture_first), against 7.5 ms to an eager first output and 17.6 ms
+to the graph.  (Steady state of a session: an edit larger than any before grows the pool once, by hipMalloc inside the capture.)
 
 Not part of the reference (it has no graphs); pure host code on top of torch's CUDAGraph."""
 from typing import Callable, Optional, Tuple
