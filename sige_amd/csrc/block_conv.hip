@@ -428,11 +428,10 @@ static int plan_conv(ConvArgs &a, int cap, int want_waves, bool nb1, ConvPlan &p
     const long kFill = want_waves ? 64 : 224;  // (a pair's second conv shares the chip with the first)
     int mt = 0, nb = 1;
     if (g_force_mt && !want_waves) { mt = g_force_mt == 32 ? 32 : 16; nb = (g_force_nb == 2 && kHasNB2) ? 2 : 1; if (!usable(mt)) mt = 0; }
-    // Exact fp32, channels-last, stride 1 has 8-wave workgroups (two waves per SIMD on every CU a workgroup lands on): with
-    // those, 128 unsplit 16-channel blocks beat 32 blocks x 4 K splits -- the 8x8 layers of the DDPM U-Net, 13.4 vs 14.4 us per
-    // launch, 1.437 -> 1.419 ms per forward (tools/probe/ksplit_forward_probe.py, round 3): the split's second phase (partial
-    // sums out, ticket, the last workgroup's sum over the copies) costs more than the 4x shorter K loop saves.  Below half a
-    // chip of blocks the split still wins.
+    // Exact fp32, channels-last, stride 1: 128 unsplit 16-channel blocks beat 32 blocks x 4 K splits -- the 8x8 layers of the
+    // DDPM U-Net, 13.4 vs 14.4 us per launch, 1.437 -> 1.419 ms per forward (tools/probe/ksplit_forward_probe.py, round 3): the
+    // split's second phase (partial sums out, ticket, the last workgroup's sum over the copies) costs more than the 4x shorter
+    // K loop saves.  Below half a chip of blocks the split still wins.
     constexpr bool kW8Geo = LAY == LAYOUT_NHWC && STR == 1 && PREC == 0;
     const long kSplitBelow = (kW8Geo && !want_waves) ? 112 : kFill;
     const bool stay_unsplit = cap > 1 && usable(16) && blocks(G16::TPB, 16, 1) >= kSplitBelow && blocks(G16::TPB, 16, 1) < kFill && !g_force_ksplit;
@@ -466,7 +465,9 @@ static int plan_conv(ConvArgs &a, int cap, int want_waves, bool nb1, ConvPlan &p
     if (want_waves) {
         if (want_waves == 8 && !w8_ok) return SIGE_HIP_EUNSUPPORTED;
         waves = want_waves;
-    } else if (g_force_waves != 4 && (g_force_waves == 8 || (long)a.mbk * a.ngk < 160) && w8_ok) {
+    } else if (g_force_waves == 8 && w8_ok) {
+        // (round 2 picked 8 waves for grids below 160 blocks; with today's kernels and the 8x8 layers unsplit the 4-wave form wins
+        //  in the forward -- 1.398 vs 1.417 ms, tools/probe/plan_forward_probe.py -- so 8 waves are the benchmarking knob's only)
         waves = 8;
     }
     a.nchunks = waves == 8 ? nchunks4 / 2 : ceil_div(a.Cin, cc4);
