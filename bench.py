@@ -1319,6 +1319,88 @@ def main():
                     tcf["first_replay"].append((t3 - t2) * 1e3)
                     cf_equal = cf_equal and bool(torch.equal(oc, model(xe, t)))
             del gprev, gp
+            # (c) a launch plan (sige_amd/plan.py, include/sige_hip.h sige_hip_plan_*): the library calls of the mask pipeline and of
+            #     the forward recorded ONCE, replayed from C with the new mask's tile counts -- no Python per launch, no re-capture
+            plan_info = None
+            try:
+                from sige_amd.plan import FORWARD as P_FWD, MASKS as P_MASKS, LaunchPlan
+
+                def build_masks(mk):
+                    return downsample_mask(dilate_mask(mk, 5), 8)
+
+                m0, xe0 = edited(0.012)
+                xs = xe0.clone()  # (the plan's static input)
+                plan = LaunchPlan(model, dev)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                plan.record(m0, build_masks, lambda: model(xs, t))
+                torch.cuda.synchronize()
+                record_ms = (time.perf_counter() - t0) * 1e3
+                tp = {"bind_mask": [], "run_from_c": [], "capture": [], "first_replay": []}
+                plan_equal, counts_seen = True, []
+                for i in range(8):
+                    m, xe = edited((0.013, 0.021, 0.05, 0.012)[i % 4])
+                    xs.copy_(xe)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    plan.bind_mask(m)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    got = plan.run()
+                    torch.cuda.synchronize()
+                    t2 = time.perf_counter()
+                    got = got.clone()
+                    plan.capture()
+                    torch.cuda.synchronize()
+                    t3 = time.perf_counter()
+                    rep = plan.replay()
+                    torch.cuda.synchronize()
+                    t4 = time.perf_counter()
+                    plan_equal = plan_equal and bool(torch.equal(rep, got))
+                    if i >= 4:
+                        tp["bind_mask"].append((t1 - t0) * 1e3)
+                        tp["run_from_c"].append((t2 - t1) * 1e3)
+                        tp["capture"].append((t3 - t2) * 1e3)
+                        tp["first_replay"].append((t4 - t3) * 1e3)
+                    # the reference for this mask: the module-level (Python) path, twins warm
+                    model.set_masks(build_masks(m))
+                    model.set_mode("sparse")
+                    model(xe, t)
+                    plan_equal = plan_equal and bool(torch.equal(model(xe, t), got))
+                    counts_seen.append(sum(plan.counts))
+                # steady state of the C-issued eager forward (no graph at all) and of the plan's own graph
+                kp = max(20, args.steps)
+                plan.bind_mask(m0)
+                xs.copy_(xe0)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(kp):
+                    plan.run()
+                torch.cuda.synchronize()
+                run_ms = (time.perf_counter() - t0) * 1e3 / kp
+                plan.capture()
+                plan.replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(kp):
+                    plan.replay()
+                torch.cuda.synchronize()
+                replay_ms = (time.perf_counter() - t0) * 1e3 / kp
+                medp = {k: round(statistics.median(v), 3) for k, v in tp.items()}
+                plan_info = dict(
+                    medp, record_once_ms=round(record_ms, 2), to_first_output_ms=round(medp["bind_mask"] + medp["run_from_c"], 3),
+                    to_first_output_with_graph_ms=round(medp["bind_mask"] + medp["capture"] + medp["first_replay"], 3),
+                    forward_ms_issued_from_c=round(run_ms, 4), forward_ms_plan_graph=round(replay_ms, 4),
+                    calls={"masks": plan.calls(P_MASKS), "forward": plan.calls(P_FWD)}, shape_bound=plan.shape_bound,
+                    output_equals_module_forward_bit_for_bit=plan_equal, tile_counts_seen=sorted(set(counts_seen)),
+                    note="ONE recording serves every later mask: bind_mask = copy the mask, replay the recorded mask pipeline (dilate, "
+                         "pyramid, compaction, one count read-back, scatter maps, tile tables, in-place refresh of the persistent outputs "
+                         "and twins); run = the recorded forward issued from C with the new counts; capture = the same calls into a "
+                         "hipGraph for the steady state")
+                del plan
+            except Exception as e:  # (never the reason the headline dies)
+                plan_info = {"error": repr(e)[:300]}
+            model.set_masks(downsample_mask(dilate_mask(edit_mask(args.ratio, rank).to(dev), 5), 8))
             # K denoising steps with one cache per step (set_cache_id(k), sige/nn/scatter.py:59-60, diffusion_demo/runner.py:134-164)
             K = 4
             x1m = prepare(args.ratio)
@@ -1348,6 +1430,7 @@ def main():
                        note="sige_amd.graphs.GraphPool: one capture stream + one memory pool for every capture (torch.cuda.graph gives "
                             "each capture a new pool and empties the allocator cache first), and the capture itself is the first "
                             "forward under the new mask: new mask -> first output AND the steady-state graph"),
+                   "mask_change_plan": plan_info,
                    "mask_change_note": "new edit -> first sparse output: set_masks (device mask pyramid, every index list, ONE device->host "
                                        "read) + the first eager forward (tile tables, scatter maps); `recapture` = capturing and "
                                        "replaying a hipGraph for the new mask (what a multi-step loop on that mask then amortises)",

@@ -605,6 +605,40 @@ int sige_hip_wide_conv_nhwc(const float *x, const float *x2, int B, int C1, int 
 int sige_hip_affine_act_nhwc_f32(const float *x, int B, int C, int H, int W, const float *scale, const float *shift,
                                  int affineB, int activation, float *out, void *stream);
 
+/* ---- launch plans: a sparse forward that survives a mask change -------------------------------------------------
+ * The reference sizes every launch from `activeIndices.size(0)` at call time (sige/cuda/gather_kernel.cu:78-84,111 via
+ * sige/utils.py:30 and sige/nn/gather.py:101-107), and two of its three applications run ONE sparse forward per mask
+ * (gaugan/runner.py:150-195, diffusion_demo/runner.py:134-164).  A plan records the calls of this library made between
+ * sige_hip_plan_begin and _end on the calling thread (each call is executed as usual AND stored with its arguments) into
+ * one of two sections -- 0: the mask -> index pipeline (dilation / pyramid / compaction / tile tables / scatter maps / the
+ * refresh of the persistent outputs), 1: the sparse forward -- and sige_hip_plan_run replays a section on a stream without
+ * any host work per launch.  Arguments that are active-tile counts are not replayed as recorded: the host binds the
+ * pointer of every index list / tile table to a SLOT (sige_hip_plan_bind_ptr); at replay a count argument takes the
+ * current value of the slot its index-list argument is bound to.  Slots are set by the host (_set_slot) or, inside
+ * section 0, by a recorded read-back of the compaction kernels' device-side counts (_record_readback: one
+ * hipMemcpyAsync + stream synchronisation, the same single synchronisation torch.nonzero costs the reference).  Output
+ * block, grid, K split and tickets are chosen inside each entry point, i.e. again at every replay.  The host keeps every
+ * buffer a recorded call points at alive and sized for the largest count (sige_amd/plan.py).
+ * Entry points of the NCHW / two-kernel forms receive tile counts without an index list to look them up under; a plan
+ * that recorded one is "shape bound" (sige_hip_plan_shape_bound) and only valid under the counts it was recorded with.
+ * Replay stops at the first call that fails and returns its status.  A section can be replayed under hipGraph stream
+ * capture (section 1; section 0 synchronises).                                                                       */
+void *sige_hip_plan_create(void);
+int sige_hip_plan_destroy(void *plan);
+int sige_hip_plan_begin(void *plan, int section, int append);
+int sige_hip_plan_end(void *plan);
+int sige_hip_plan_recording(void);
+int sige_hip_plan_shape_bound(void *plan);
+int sige_hip_plan_calls(void *plan, int section);
+/* n new slots (initial count 0); returns the index of the first, -1 on error */
+int sige_hip_plan_new_slots(void *plan, int n);
+int sige_hip_plan_bind_ptr(void *plan, const void *ptr, int slot);
+int sige_hip_plan_set_slot(void *plan, int slot, int count);
+/* copies min(n, slots) counts to `out`; returns the number of slots */
+int sige_hip_plan_get_slots(void *plan, int32_t *out, int n);
+int sige_hip_plan_record_readback(void *plan, const int32_t *device_counts, int first_slot, int n);
+int sige_hip_plan_run(void *plan, int section, void *stream);
+
 /* ---- plain device copy used by the cache broadcast path (packs the cached
  * activations of Scatter / ScatterGather modules into one buffer) ---------- */
 int sige_hip_copy_f32(const float *src, float *dst, size_t n, void *stream);

@@ -142,6 +142,7 @@ extern "C" size_t sige_hip_attention_workspace(int B, int C, int HW) {
 
 extern "C" int sige_hip_attention_f32(const float *qkv, int B, int C, int HW, float scale, float *workspace,
                                       float *out, void *stream) {
+    SIGE_PLAN_HOOK(sige_hip_attention_f32, qkv, B, C, HW, scale, workspace, out, stream);
     if (B <= 0 || C <= 0 || HW <= 0) return SIGE_HIP_EINVAL;
     if (!qkv || !workspace || !out) return SIGE_HIP_EINVAL;
     // 16x16 tiles, 4-way channel split in 4-channel MFMA steps, 16-byte loads; P row + v chunk in 160 KiB of LDS

@@ -559,10 +559,14 @@ static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
         a.counters = split_tickets(st, (long)a.mbk * a.ngk);
         if (!a.counters && (a.twin0 || a.twin1)) {
             // (the second-pass kernel does not write twins: without tickets such a launch runs unsplit)
-            const ConvArgs keep = a;
             a = a0;
             const int rc1 = plan_conv<KH, STR, R, SRC, LAY, PREC>(a, 1, 0, false, p);
-            if (rc1 != SIGE_HIP_OK) a = keep;
+            if (rc1 != SIGE_HIP_OK) {
+                // no unsplit plan either: a split launch finished by the second pass would leave the twins unwritten while the
+                // caller reports them as written -- refuse, the caller falls back and its consumers activate for themselves
+                const int rc = flush_held();
+                return rc != SIGE_HIP_OK ? rc : SIGE_HIP_EUNSUPPORTED;
+            }
         }
     }
     if (a.ksplit > 1) {
@@ -651,12 +655,14 @@ extern "C" int sige_hip_block_conv_force_tile(int mt, int nb) {
 }
 
 extern "C" int sige_hip_conv_pair_begin(void) {
+    SIGE_PLAN_HOOK0(sige_hip_conv_pair_begin);
     const int rc = flush_held();
     g_pairing = true;
     return rc;
 }
 
 extern "C" int sige_hip_conv_pair_end(void) {
+    SIGE_PLAN_HOOK0(sige_hip_conv_pair_end);
     g_pairing = false;
     const int rc = flush_held();
     return rc != SIGE_HIP_OK ? rc : launch_status(0);
@@ -768,6 +774,7 @@ extern "C" int sige_hip_block_conv_pack_f16x3(const float *w, int Cout, int Cin,
 extern "C" int sige_hip_block_conv_f32(const float *x, int T, int Cin, int R, int S,
                                        const float *packed, const float *bias, int Cout, int kH, int kW,
                                        int strideH, int strideW, float *out, void *stream) {
+    SIGE_PLAN_HOOK_FIXED(sige_hip_block_conv_f32, x, T, Cin, R, S, packed, bias, Cout, kH, kW, strideH, strideW, out, stream);
     if (T < 0 || Cin <= 0 || Cout <= 0) return SIGE_HIP_EINVAL;
     if (T == 0) return SIGE_HIP_OK;
     if (!x || !packed || !out) return SIGE_HIP_EINVAL;
@@ -799,6 +806,7 @@ extern "C" int sige_hip_gather_conv_f32(const float *x, int B, int Cin, int H, i
                                         int activation,
                                         const float *packed, const float *bias, int Cout, int kH, int kW,
                                         int strideH, int strideW, float *out, void *stream) {
+    SIGE_PLAN_HOOK_FIXED(sige_hip_gather_conv_f32, x, B, Cin, H, W, bH, bW, active_indices, N, scale, scaleB, scaleC, scaleH, scaleW, shift, shiftB, shiftC, shiftH, shiftW, activation, packed, bias, Cout, kH, kW, strideH, strideW, out, stream);
     if (B < 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || N < 0) return SIGE_HIP_EINVAL;
     if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
     if (!channel_affine(scale, scaleB, scaleC, scaleH, scaleW, B, Cin) ||
@@ -827,6 +835,7 @@ extern "C" int sige_hip_gather_conv_nchw_f32(const float *x, const float *x2, in
                                              const float *packed, const float *bias, int Cout, int kH, int kW,
                                              int strideH, int strideW, int offsetH, int offsetW,
                                              const float *residual, int Ho, int Wo, float *out, void *stream) {
+    SIGE_PLAN_HOOK_FIXED(sige_hip_gather_conv_nchw_f32, x, x2, B, C1, C2, H, W, bH, bW, active_indices, N, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, packed, bias, Cout, kH, kW, strideH, strideW, offsetH, offsetW, residual, Ho, Wo, out, stream);
     const int Cin = C1 + C2;
     if (B < 0 || C1 <= 0 || C2 < 0 || Cout <= 0 || H <= 0 || W <= 0 || N < 0 || Ho <= 0 || Wo <= 0) return SIGE_HIP_EINVAL;
     if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
@@ -857,6 +866,7 @@ extern "C" int sige_hip_scatter_gather_conv_f32(const float *x, const float *y, 
                                                 int activation,
                                                 const float *packed, const float *bias, int Cout, int kH, int kW,
                                                 int strideH, int strideW, float *out, void *stream) {
+    SIGE_PLAN_HOOK_FIXED(sige_hip_scatter_gather_conv_f32, x, y, B, Cin, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, scaleH, scaleW, shift, shiftB, shiftC, shiftH, shiftW, activation, packed, bias, Cout, kH, kW, strideH, strideW, out, stream);
     if (B < 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || N < 0 || Rx <= 0 || Sx <= 0) return SIGE_HIP_EINVAL;
     if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
     if (!channel_affine(scale, scaleB, scaleC, scaleH, scaleW, B, Cin) ||
@@ -908,18 +918,21 @@ static int block_conv_nhwc_impl(const float *x, int T, int Cin, int R, int S,
 extern "C" int sige_hip_block_conv_nhwc_f32(const float *x, int T, int Cin, int R, int S,
                                             const float *packed, const float *bias, int Cout, int kH, int kW,
                                             int strideH, int strideW, float *out, void *stream) {
+    SIGE_PLAN_HOOK_FIXED(sige_hip_block_conv_nhwc_f32, x, T, Cin, R, S, packed, bias, Cout, kH, kW, strideH, strideW, out, stream);
     return block_conv_nhwc_impl<0>(x, T, Cin, R, S, packed, bias, Cout, kH, kW, strideH, strideW, out, stream);
 }
 
 extern "C" int sige_hip_block_conv_nhwc_f16c(const float *x, int T, int Cin, int R, int S,
                                              const float *packed, const float *bias, int Cout, int kH, int kW,
                                              int strideH, int strideW, float *out, void *stream) {
+    SIGE_PLAN_HOOK_FIXED(sige_hip_block_conv_nhwc_f16c, x, T, Cin, R, S, packed, bias, Cout, kH, kW, strideH, strideW, out, stream);
     return block_conv_nhwc_impl<1>(x, T, Cin, R, S, packed, bias, Cout, kH, kW, strideH, strideW, out, stream);
 }
 
 extern "C" int sige_hip_block_conv_nhwc_f16x3(const float *x, int T, int Cin, int R, int S,
                                               const float *packed, const float *bias, int Cout, int kH, int kW,
                                               int strideH, int strideW, float *out, void *stream) {
+    SIGE_PLAN_HOOK_FIXED(sige_hip_block_conv_nhwc_f16x3, x, T, Cin, R, S, packed, bias, Cout, kH, kW, strideH, strideW, out, stream);
     return block_conv_nhwc_impl<2>(x, T, Cin, R, S, packed, bias, Cout, kH, kW, strideH, strideW, out, stream);
 }
 
@@ -1002,6 +1015,7 @@ extern "C" int sige_hip_gather_conv_nhwc_f32(const float *x, const float *x2, in
                                              float *twin0, const float *twin0_scale, const float *twin0_shift,
                                              float *twin1, const float *twin1_scale, const float *twin1_shift,
                                              float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_gather_conv_nhwc_f32, (sige::CountOf<9, 10>), x, x2, B, C1, C2, H, W, bH, bW, active_indices, N, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, packed, bias, Cout, kH, kW, strideH, strideW, to_full, offsetH, offsetW, residual, Ho, Wo, workspace, workspace_floats, out_scale, out_shift, out_activation, upsample2x, twin0, twin0_scale, twin0_shift, twin1, twin1_scale, twin1_shift, out, stream);
     return gather_conv_nhwc_impl<0>(SIGE_GATHER_CONV_ARGS);
 }
 extern "C" int sige_hip_gather_conv_nhwc_f16c(const float *x, const float *x2, int B, int C1, int C2, int H, int W,
@@ -1018,6 +1032,7 @@ extern "C" int sige_hip_gather_conv_nhwc_f16c(const float *x, const float *x2, i
                                              float *twin0, const float *twin0_scale, const float *twin0_shift,
                                              float *twin1, const float *twin1_scale, const float *twin1_shift,
                                              float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_gather_conv_nhwc_f16c, (sige::CountOf<9, 10>), x, x2, B, C1, C2, H, W, bH, bW, active_indices, N, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, packed, bias, Cout, kH, kW, strideH, strideW, to_full, offsetH, offsetW, residual, Ho, Wo, workspace, workspace_floats, out_scale, out_shift, out_activation, upsample2x, twin0, twin0_scale, twin0_shift, twin1, twin1_scale, twin1_shift, out, stream);
     return gather_conv_nhwc_impl<1>(SIGE_GATHER_CONV_ARGS);
 }
 extern "C" int sige_hip_gather_conv_nhwc_f16x3(const float *x, const float *x2, int B, int C1, int C2, int H, int W,
@@ -1034,6 +1049,7 @@ extern "C" int sige_hip_gather_conv_nhwc_f16x3(const float *x, const float *x2, 
                                              float *twin0, const float *twin0_scale, const float *twin0_shift,
                                              float *twin1, const float *twin1_scale, const float *twin1_shift,
                                              float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_gather_conv_nhwc_f16x3, (sige::CountOf<9, 10>), x, x2, B, C1, C2, H, W, bH, bW, active_indices, N, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, packed, bias, Cout, kH, kW, strideH, strideW, to_full, offsetH, offsetW, residual, Ho, Wo, workspace, workspace_floats, out_scale, out_shift, out_activation, upsample2x, twin0, twin0_scale, twin0_shift, twin1, twin1_scale, twin1_shift, out, stream);
     return gather_conv_nhwc_impl<2>(SIGE_GATHER_CONV_ARGS);
 }
 
@@ -1072,6 +1088,7 @@ extern "C" int sige_hip_scatter_gather_conv_nhwc_f32(const float *x, const float
                                                      int activation,
                                                      const float *packed, const float *bias, int Cout, int kH, int kW,
                                                      int strideH, int strideW, float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_scatter_gather_conv_nhwc_f32, (sige::CountOf<10, 11>), x, y, B, Cin, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, packed, bias, Cout, kH, kW, strideH, strideW, out, stream);
     return scatter_gather_conv_nhwc_impl<0>(SIGE_SG_CONV_ARGS);
 }
 extern "C" int sige_hip_scatter_gather_conv_nhwc_f16c(const float *x, const float *y, int B, int Cin, int H, int W,
@@ -1082,6 +1099,7 @@ extern "C" int sige_hip_scatter_gather_conv_nhwc_f16c(const float *x, const floa
                                                      int activation,
                                                      const float *packed, const float *bias, int Cout, int kH, int kW,
                                                      int strideH, int strideW, float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_scatter_gather_conv_nhwc_f16c, (sige::CountOf<10, 11>), x, y, B, Cin, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, packed, bias, Cout, kH, kW, strideH, strideW, out, stream);
     return scatter_gather_conv_nhwc_impl<1>(SIGE_SG_CONV_ARGS);
 }
 extern "C" int sige_hip_scatter_gather_conv_nhwc_f16x3(const float *x, const float *y, int B, int Cin, int H, int W,
@@ -1092,6 +1110,7 @@ extern "C" int sige_hip_scatter_gather_conv_nhwc_f16x3(const float *x, const flo
                                                      int activation,
                                                      const float *packed, const float *bias, int Cout, int kH, int kW,
                                                      int strideH, int strideW, float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_scatter_gather_conv_nhwc_f16x3, (sige::CountOf<10, 11>), x, y, B, Cin, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, packed, bias, Cout, kH, kW, strideH, strideW, out, stream);
     return scatter_gather_conv_nhwc_impl<2>(SIGE_SG_CONV_ARGS);
 }
 
@@ -1150,6 +1169,7 @@ extern "C" int sige_hip_scatter_gather_conv_scatter_nhwc_f32(
         float *twin0, const float *twin0_scale, const float *twin0_shift,
         float *twin1, const float *twin1_scale, const float *twin1_shift,
         float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_scatter_gather_conv_scatter_nhwc_f32, (sige::CountOf<10, 11>, sige::CountOf<29, 32>), x, y, B, Cin, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, packed, bias, Cout, kH, kW, offsetH, offsetW, residual, x1, table1, gH1, gW1, N1, R1, S1, twin0, twin0_scale, twin0_shift, twin1, twin1_scale, twin1_shift, out, stream);
     return scatter_gather_conv_scatter_nhwc_impl<0>(SIGE_SGS_CONV_ARGS);
 }
 extern "C" int sige_hip_scatter_gather_conv_scatter_nhwc_f16c(
@@ -1162,6 +1182,7 @@ extern "C" int sige_hip_scatter_gather_conv_scatter_nhwc_f16c(
         float *twin0, const float *twin0_scale, const float *twin0_shift,
         float *twin1, const float *twin1_scale, const float *twin1_shift,
         float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_scatter_gather_conv_scatter_nhwc_f16c, (sige::CountOf<10, 11>, sige::CountOf<29, 32>), x, y, B, Cin, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, packed, bias, Cout, kH, kW, offsetH, offsetW, residual, x1, table1, gH1, gW1, N1, R1, S1, twin0, twin0_scale, twin0_shift, twin1, twin1_scale, twin1_shift, out, stream);
     return scatter_gather_conv_scatter_nhwc_impl<1>(SIGE_SGS_CONV_ARGS);
 }
 extern "C" int sige_hip_scatter_gather_conv_scatter_nhwc_f16x3(
@@ -1174,6 +1195,7 @@ extern "C" int sige_hip_scatter_gather_conv_scatter_nhwc_f16x3(
         float *twin0, const float *twin0_scale, const float *twin0_shift,
         float *twin1, const float *twin1_scale, const float *twin1_shift,
         float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_scatter_gather_conv_scatter_nhwc_f16x3, (sige::CountOf<10, 11>, sige::CountOf<29, 32>), x, y, B, Cin, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, packed, bias, Cout, kH, kW, offsetH, offsetW, residual, x1, table1, gH1, gW1, N1, R1, S1, twin0, twin0_scale, twin0_shift, twin1, twin1_scale, twin1_shift, out, stream);
     return scatter_gather_conv_scatter_nhwc_impl<2>(SIGE_SGS_CONV_ARGS);
 }
 
@@ -1181,6 +1203,7 @@ extern "C" int sige_hip_block_conv_direct_f32(const float *x, int T, int Cin, in
                                               const float *w, const float *bias, int Cout, int kH, int kW,
                                               int strideH, int strideW, int dilationH, int dilationW, int groups,
                                               float *out, void *stream) {
+    SIGE_PLAN_HOOK_FIXED(sige_hip_block_conv_direct_f32, x, T, Cin, R, S, w, bias, Cout, kH, kW, strideH, strideW, dilationH, dilationW, groups, out, stream);
     if (T < 0 || Cin <= 0 || Cout <= 0 || kH <= 0 || kW <= 0 || strideH <= 0 || strideW <= 0 || groups <= 0 ||
         dilationH <= 0 || dilationW <= 0)
         return SIGE_HIP_EINVAL;

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "sige_hip.h"
+#include "plan.hpp"
 
 namespace sige {
 

@@ -87,6 +87,7 @@ extern "C" int sige_hip_conv3x3_small_cin_nhwc_f32(const float *x, int64_t strid
                                                    int B, int Cin, int H, int W,
                                                    const float *weight, const float *bias, int Cout,
                                                    float *out, void *stream) {
+    SIGE_PLAN_HOOK(sige_hip_conv3x3_small_cin_nhwc_f32, x, strideB, strideC, strideH, strideW, B, Cin, H, W, weight, bias, Cout, out, stream);
     if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return SIGE_HIP_EINVAL;
     if (!x || !weight || !out) return SIGE_HIP_EINVAL;
     if (Cin > 3 || !(Cout == 32 || Cout == 64 || Cout == 128)) return SIGE_HIP_EUNSUPPORTED;

@@ -227,6 +227,7 @@ extern "C" int sige_hip_conv3x3_small_cout_nhwc_f32(const float *x, int B, int C
                                                     const float *shift, int shiftB, int shiftC, int activation,
                                                     const float *weight, const float *bias, int Cout,
                                                     float *out, void *stream) {
+    SIGE_PLAN_HOOK(sige_hip_conv3x3_small_cout_nhwc_f32, x, B, C, H, W, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, weight, bias, Cout, out, stream);
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || Cout <= 0) return SIGE_HIP_EINVAL;
     if (!x || !weight || !out) return SIGE_HIP_EINVAL;
     if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;

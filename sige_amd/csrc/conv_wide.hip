@@ -174,6 +174,7 @@ extern "C" int sige_hip_wide_conv_nhwc(const float *x, const float *x2, int B, i
                                        float *twin0, const float *twin_scale0, const float *twin_shift0,
                                        float *twin1, const float *twin_scale1, const float *twin_shift1,
                                        float *workspace, size_t workspace_floats, float *out, float *stats, void *stream) {
+    SIGE_PLAN_HOOK(sige_hip_wide_conv_nhwc, x, x2, B, C1, C2, H, W, upsample2x, scale, shift, affineB, activation, packed, prec, wshift, bias, Cout, kH, kW, residual, out_scale, out_shift, out_activation, twin0, twin_scale0, twin_shift0, twin1, twin_scale1, twin_shift1, workspace, workspace_floats, out, stats, stream);
     if (B <= 0 || H <= 0 || W <= 0 || C1 <= 0 || C2 < 0 || Cout <= 0 || prec < WIDE_F16 || prec > WIDE_F32) return SIGE_HIP_EINVAL;
     if (!x || (C2 && !x2) || !packed || !out) return SIGE_HIP_EINVAL;
     if (!wide_shape_ok(C1, C2, Cout, kH, kW)) return SIGE_HIP_EUNSUPPORTED;

@@ -269,6 +269,7 @@ extern "C" size_t sige_hip_group_norm_affine_workspace(int B, int C, int H, int 
 extern "C" int sige_hip_group_norm_affine_f32(const float *x, int B, int C, int H, int W, int groups, float eps,
                                               const float *gamma, const float *beta, float *workspace,
                                               float *scale, float *shift, void *stream) {
+    SIGE_PLAN_HOOK(sige_hip_group_norm_affine_f32, x, B, C, H, W, groups, eps, gamma, beta, workspace, scale, shift, stream);
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || groups <= 0 || C % groups) return SIGE_HIP_EINVAL;
     if (!x || !workspace || !scale || !shift) return SIGE_HIP_EINVAL;
     if ((long)B * groups > 65535) return SIGE_HIP_EUNSUPPORTED;
@@ -298,12 +299,14 @@ static int group_norm_affine_nhwc(const float *x, int B, int C, int H, int W, in
 extern "C" int sige_hip_group_norm_affine_nhwc_f32(const float *x, int B, int C, int H, int W, int groups, float eps,
                                                    const float *gamma, const float *beta, float *workspace,
                                                    float *scale, float *shift, void *stream) {
+    SIGE_PLAN_HOOK(sige_hip_group_norm_affine_nhwc_f32, x, B, C, H, W, groups, eps, gamma, beta, workspace, scale, shift, stream);
     return group_norm_affine_nhwc(x, B, C, H, W, groups, eps, gamma, beta, nullptr, workspace, scale, shift, stream);
 }
 
 extern "C" int sige_hip_group_norm_affine_nhwc_bias_f32(const float *x, int B, int C, int H, int W, int groups, float eps,
                                                         const float *gamma, const float *beta, const float *channel_bias,
                                                         float *workspace, float *scale, float *shift, void *stream) {
+    SIGE_PLAN_HOOK(sige_hip_group_norm_affine_nhwc_bias_f32, x, B, C, H, W, groups, eps, gamma, beta, channel_bias, workspace, scale, shift, stream);
     if (!channel_bias || (reinterpret_cast<uintptr_t>(channel_bias) & 15)) return SIGE_HIP_EINVAL;
     return group_norm_affine_nhwc(x, B, C, H, W, groups, eps, gamma, beta, channel_bias, workspace, scale, shift, stream);
 }
@@ -327,6 +330,7 @@ extern "C" int sige_hip_group_norm_affine_from_stats_f32(const float *stats1, in
                                                          const float *stats2, int tiles2, int C2, int count2,
                                                          int B, int groups, float eps, const float *gamma, const float *beta,
                                                          const float *channel_bias, float *scale, float *shift, void *stream) {
+    SIGE_PLAN_HOOK(sige_hip_group_norm_affine_from_stats_f32, stats1, tiles1, C1, count1, stats2, tiles2, C2, count2, B, groups, eps, gamma, beta, channel_bias, scale, shift, stream);
     if (B <= 0 || C1 <= 0 || C2 < 0 || groups <= 0 || tiles1 <= 0 || count1 <= 0 || (C2 && (tiles2 <= 0 || count2 <= 0))) return SIGE_HIP_EINVAL;
     if (!stats1 || (C2 && !stats2) || !scale || !shift) return SIGE_HIP_EINVAL;
     const int C = C1 + C2;
@@ -343,6 +347,7 @@ extern "C" int sige_hip_group_norm_affine_from_stats_f32(const float *stats1, in
 extern "C" int sige_hip_channel_stats_tiles(int H, int W) { return (H * W + kStatPix - 1) / kStatPix; }
 
 extern "C" int sige_hip_channel_stats_nhwc_f32(const float *x, int B, int C, int H, int W, float *stats, void *stream) {
+    SIGE_PLAN_HOOK(sige_hip_channel_stats_nhwc_f32, x, B, C, H, W, stats, stream);
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return SIGE_HIP_EINVAL;
     if (!x || !stats) return SIGE_HIP_EINVAL;
     const int C4 = C / 4;

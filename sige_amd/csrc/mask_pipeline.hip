@@ -125,6 +125,7 @@ using namespace sige;
 extern "C" int sige_hip_difference_mask_u8(const float *a, const float *b, int C, int H, int W,
                                            int64_t strideC, int64_t strideH, int64_t strideW, float eps,
                                            uint8_t *out, void *stream) {
+    SIGE_PLAN_HOOK(sige_hip_difference_mask_u8, a, b, C, H, W, strideC, strideH, strideW, eps, out, stream);
     if (C <= 0 || H <= 0 || W <= 0) return SIGE_HIP_EINVAL;
     if (!a || !b || !out) return SIGE_HIP_EINVAL;
     if (strideH != (int64_t)W * strideW) return SIGE_HIP_EUNSUPPORTED;  // pixels must be evenly strided (NCHW or NHWC)
@@ -136,6 +137,7 @@ extern "C" int sige_hip_difference_mask_u8(const float *a, const float *b, int C
 
 extern "C" int sige_hip_dilate_mask_u8(const uint8_t *mask, int H, int W, int dilationH, int dilationW,
                                        uint8_t *out, void *stream) {
+    SIGE_PLAN_HOOK(sige_hip_dilate_mask_u8, mask, H, W, dilationH, dilationW, out, stream);
     if (H <= 0 || W <= 0 || dilationH < 0 || dilationW < 0) return SIGE_HIP_EINVAL;
     if (!mask || !out || mask == out) return SIGE_HIP_EINVAL;
     const long n = (long)H * W;
@@ -164,6 +166,7 @@ extern "C" int sige_hip_mask_pyramid_levels(int H, int W, int min_h, int min_w, 
 extern "C" int sige_hip_mask_pyramid_u8(const uint8_t *mask, int H, int W, int min_h, int min_w,
                                         int dilationH, int dilationW, float threshold, float eps,
                                         float *scratch, size_t scratch_floats, uint8_t *out, void *stream) {
+    SIGE_PLAN_HOOK(sige_hip_mask_pyramid_u8, mask, H, W, min_h, min_w, dilationH, dilationW, threshold, eps, scratch, scratch_floats, out, stream);
     if (H <= 0 || W <= 0 || dilationH < 0 || dilationW < 0) return SIGE_HIP_EINVAL;
     if (!mask || !scratch || !out) return SIGE_HIP_EINVAL;
     // scratch: level_a [H/2 * W/2] | level_b [H/4 * W/4] floats | bits [H * W] bytes (rounded up to floats)

@@ -394,6 +394,7 @@ extern "C" int sige_hip_gather_nhwc_f32(const float *x, int B, int C, int H, int
                                         const float *scale, int scaleB, int scaleC,
                                         const float *shift, int shiftB, int shiftC,
                                         int activation, float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_gather_nhwc_f32, (sige::CountOf<7, 8>), x, B, C, H, W, bH, bW, active_indices, N, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, out, stream);
     if (B < 0 || C <= 0 || H <= 0 || W <= 0 || bH <= 0 || bW <= 0 || N < 0) return SIGE_HIP_EINVAL;
     if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
     if ((long)B * N == 0) return SIGE_HIP_OK;
@@ -416,6 +417,7 @@ extern "C" int sige_hip_scatter_gather_nhwc_f32(const float *x, const float *y, 
                                                 const float *scale, int scaleB, int scaleC,
                                                 const float *shift, int shiftB, int shiftC,
                                                 int activation, float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_scatter_gather_nhwc_f32, (sige::CountOf<10, 11>), x, y, B, C, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, out, stream);
     if (B < 0 || C <= 0 || H <= 0 || W <= 0 || Rx <= 0 || Sx <= 0 || bH <= 0 || bW <= 0 || N < 0) return SIGE_HIP_EINVAL;
     if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
     if ((long)B * N == 0) return SIGE_HIP_OK;
@@ -438,6 +440,7 @@ extern "C" int sige_hip_spade_modulate_nhwc_f32(
         const float *gb_tiles, const float *gb_full, const int32_t *map_g, int Ng, int Rg, int Sg,
         int B, int C, int H, int W, int bH, int bW, const int32_t *active_indices, int N,
         int leaky, float slope, float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_spade_modulate_nhwc_f32, (sige::CountOf<24, 25>), x_full, x_tiles, map_x, Nx, Rx, Sx, scale, scaleB, scaleC, shift, shiftB, shiftC, gb_tiles, gb_full, map_g, Ng, Rg, Sg, B, C, H, W, bH, bW, active_indices, N, leaky, slope, out, stream);
     if (B < 0 || C <= 0 || H <= 0 || W <= 0 || bH <= 0 || bW <= 0 || N < 0 || Ng < 0 || Nx < 0) return SIGE_HIP_EINVAL;
     if ((long)B * N == 0) return SIGE_HIP_OK;
     if (!x_full || !gb_full || !map_g || !active_indices || !out) return SIGE_HIP_EINVAL;
@@ -461,6 +464,7 @@ extern "C" int sige_hip_scatter_nhwc_f32(const float *x, const float *y, int B, 
                                          int offsetH, int offsetW, int strideH, int strideW,
                                          const int32_t *active_indices, const int32_t *table, int gH, int gW, int N,
                                          const float *residual, int in_place, float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_scatter_nhwc_f32, (sige::CountOf<12, 16>), x, y, B, C, H, W, R, S, offsetH, offsetW, strideH, strideW, active_indices, table, gH, gW, N, residual, in_place, out, stream);
     if (B < 0 || C <= 0 || H <= 0 || W <= 0 || R <= 0 || S <= 0 || N < 0 || strideH <= 0 || strideW <= 0) return SIGE_HIP_EINVAL;
     if ((long)B * H * W == 0) return SIGE_HIP_OK;
     if (!y || !out || (N && (!x || !table || !active_indices))) return SIGE_HIP_EINVAL;
@@ -489,6 +493,7 @@ extern "C" int sige_hip_scatter_with_block_residual_nhwc_f32(
         const int32_t *active_indices0, const int32_t *table0, int gH0, int gW0, int N0,
         const int32_t *active_indices1, const int32_t *table1, int gH1, int gW1, int N1,
         int in_place, float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_scatter_with_block_residual_nhwc_f32, (sige::CountOf<16, 20>, sige::CountOf<21, 25>), x0, y0, x1, y1, B, C, H, W, R0, S0, R1, S1, offsetH, offsetW, strideH, strideW, active_indices0, table0, gH0, gW0, N0, active_indices1, table1, gH1, gW1, N1, in_place, out, stream);
     if (B < 0 || C <= 0 || H <= 0 || W <= 0 || R0 <= 0 || S0 <= 0 || R1 <= 0 || S1 <= 0 || N0 < 0 || N1 < 0) return SIGE_HIP_EINVAL;
     if (strideH <= 0 || strideW <= 0) return SIGE_HIP_EINVAL;
     if ((long)B * H * W == 0) return SIGE_HIP_OK;
@@ -533,6 +538,7 @@ __global__ __launch_bounds__(kT) void affine_act_nhwc_kernel(const float *__rest
 
 extern "C" int sige_hip_affine_act_nhwc_f32(const float *x, int B, int C, int H, int W, const float *scale, const float *shift,
                                             int affineB, int activation, float *out, void *stream) {
+    SIGE_PLAN_HOOK(sige_hip_affine_act_nhwc_f32, x, B, C, H, W, scale, shift, affineB, activation, out, stream);
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !x || !scale || !shift || !out) return SIGE_HIP_EINVAL;
     if (affineB != 1 && affineB != B) return SIGE_HIP_EINVAL;
     if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
@@ -545,6 +551,7 @@ extern "C" int sige_hip_affine_act_nhwc_f32(const float *x, int B, int C, int H,
 
 extern "C" int sige_hip_attention_nhwc_f32(const float *qkv, int B, int C, int HW, float scale, float *workspace,
                                            float *out, void *stream) {
+    SIGE_PLAN_HOOK(sige_hip_attention_nhwc_f32, qkv, B, C, HW, scale, workspace, out, stream);
     if (B <= 0 || C <= 0 || HW <= 0) return SIGE_HIP_EINVAL;
     if (!qkv || !workspace || !out) return SIGE_HIP_EINVAL;
     // 16x16 tiles; 4 waves x 16-channel steps of 16-byte loads; P rows in LDS

@@ -70,6 +70,7 @@ extern "C" int sige_hip_reduce_mask_capacity(int H, int W, int strideH, int stri
 extern "C" int sige_hip_reduce_mask_i32(const uint8_t *mask, int H, int W, int bH, int bW,
                                         int strideH, int strideW, int padH, int padW,
                                         int32_t *indices, int capacity, int32_t *count, void *stream) {
+    SIGE_PLAN_HOOK(sige_hip_reduce_mask_i32, mask, H, W, bH, bW, strideH, strideW, padH, padW, indices, capacity, count, stream);
     if (H <= 0 || W <= 0 || bH <= 0 || bW <= 0 || strideH <= 0 || strideW <= 0 || padH < 0 || padW < 0 ||
         capacity < 0)
         return SIGE_HIP_EINVAL;

@@ -266,6 +266,7 @@ __global__ void scatter_map_kernel(int H, int W, int R, int S, int offH, int off
 using namespace sige;
 
 extern "C" int sige_hip_copy_f32(const float *src, float *dst, size_t n, void *stream) {
+    SIGE_PLAN_HOOK(sige_hip_copy_f32, src, dst, n, stream);
     if (n && (!src || !dst)) return SIGE_HIP_EINVAL;
     launch_copy(src, dst, n, as_stream(stream));
     return launch_status();
@@ -276,6 +277,7 @@ extern "C" int sige_hip_scatter_f32(const float *x, const float *y, int B, int C
                                     const int32_t *active_indices, int N,
                                     const float *residual, int resB, int resC, int resH, int resW,
                                     float *out, void *stream) {
+    SIGE_PLAN_HOOK_FIXED(sige_hip_scatter_f32, x, y, B, C, H, W, R, S, offsetH, offsetW, strideH, strideW, active_indices, N, residual, resB, resC, resH, resW, out, stream);
     if (B < 0 || C < 0 || H < 0 || W < 0 || N < 0 || R <= 0 || S <= 0 || strideH <= 0 || strideW <= 0)
         return SIGE_HIP_EINVAL;
     const size_t n = (size_t)B * C * H * W;
@@ -299,6 +301,7 @@ extern "C" int sige_hip_scatter_with_block_residual_f32(
         int offsetH, int offsetW, int strideH, int strideW,
         const int32_t *active_indices0, int N0, const int32_t *active_indices1, int N1,
         float *out, void *stream) {
+    SIGE_PLAN_HOOK_FIXED(sige_hip_scatter_with_block_residual_f32, x0, y0, x1, y1, B, C, H, W, R0, S0, R1, S1, offsetH, offsetW, strideH, strideW, active_indices0, N0, active_indices1, N1, out, stream);
     if (B < 0 || C < 0 || H < 0 || W < 0 || N0 < 0 || N1 < 0 || R0 <= 0 || S0 <= 0 || R1 <= 0 || S1 <= 0 ||
         strideH <= 0 || strideW <= 0)
         return SIGE_HIP_EINVAL;
@@ -325,6 +328,7 @@ extern "C" int sige_hip_scatter_with_block_residual_f32(
 extern "C" int sige_hip_tile_table_i32(const int32_t *active_indices, int N, int offsetH, int offsetW,
                                        int strideH, int strideW, int R, int S, int gH, int gW,
                                        int32_t *table, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_tile_table_i32, (sige::CountOf<0, 1>), active_indices, N, offsetH, offsetW, strideH, strideW, R, S, gH, gW, table, stream);
     if (N < 0 || R <= 0 || S <= 0 || gH < 0 || gW < 0 || strideH <= 0 || strideW <= 0) return SIGE_HIP_EINVAL;
     if ((long)gH * gW == 0) return SIGE_HIP_OK;
     if (!table || (N && !active_indices)) return SIGE_HIP_EINVAL;
@@ -339,6 +343,7 @@ extern "C" int sige_hip_scatter_fused_f32(const float *x, const float *y, int B,
                                           const int32_t *table, int gH, int gW, int N,
                                           const float *residual, int resB, int resC, int resH, int resW,
                                           float *out, void *stream) {
+    SIGE_PLAN_HOOK_FIXED(sige_hip_scatter_fused_f32, x, y, B, C, H, W, R, S, table, gH, gW, N, residual, resB, resC, resH, resW, out, stream);
     if (B < 0 || C < 0 || H < 0 || W < 0 || N < 0 || R <= 0 || S <= 0) return SIGE_HIP_EINVAL;
     if (gH != ceil_div(H, R) || gW != ceil_div(W, S)) return SIGE_HIP_EINVAL;
     const size_t n = (size_t)B * C * H * W;
@@ -359,6 +364,7 @@ extern "C" int sige_hip_scatter_with_block_residual_fused_f32(
         const int32_t *table0, int gH0, int gW0, int N0,
         const int32_t *table1, int gH1, int gW1, int N1,
         float *out, void *stream) {
+    SIGE_PLAN_HOOK_FIXED(sige_hip_scatter_with_block_residual_fused_f32, x0, y0, x1, y1, B, C, H, W, R0, S0, R1, S1, table0, gH0, gW0, N0, table1, gH1, gW1, N1, out, stream);
     if (B < 0 || C < 0 || H < 0 || W < 0 || N0 < 0 || N1 < 0 || R0 <= 0 || S0 <= 0 || R1 <= 0 || S1 <= 0)
         return SIGE_HIP_EINVAL;
     if (gH0 != ceil_div(H, R0) || gW0 != ceil_div(W, S0) || gH1 != ceil_div(H, R1) || gW1 != ceil_div(W, S1))
@@ -378,6 +384,7 @@ extern "C" int sige_hip_scatter_with_block_residual_fused_f32(
 extern "C" int sige_hip_scatter_map_i32(int H, int W, int bH, int bW, int kH, int kW,
                                         int offsetH, int offsetW, int strideH, int strideW,
                                         const int32_t *active_indices, int N, int32_t *map, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_scatter_map_i32, (sige::CountOf<10, 11>), H, W, bH, bW, kH, kW, offsetH, offsetW, strideH, strideW, active_indices, N, map, stream);
     if (H < 0 || W < 0 || N < 0 || strideH <= 0 || strideW <= 0 || kH <= 0 || kW <= 0 || bH < kH || bW < kW)
         return SIGE_HIP_EINVAL;
     if ((long)H * W == 0) return SIGE_HIP_OK;

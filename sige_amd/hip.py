@@ -155,6 +155,20 @@ _SIGNATURES = {
     "sige_hip_channel_stats_nhwc_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp]),
     "sige_hip_group_norm_affine_from_stats_f32": (
         _c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_float] + [_c_vp] * 6),
+    # launch plans (csrc/plan.hip; host side: sige_amd/plan.py)
+    "sige_hip_plan_create": (_c_vp, []),
+    "sige_hip_plan_destroy": (_c_int, [_c_vp]),
+    "sige_hip_plan_begin": (_c_int, [_c_vp, _c_int, _c_int]),
+    "sige_hip_plan_end": (_c_int, [_c_vp]),
+    "sige_hip_plan_recording": (_c_int, []),
+    "sige_hip_plan_shape_bound": (_c_int, [_c_vp]),
+    "sige_hip_plan_calls": (_c_int, [_c_vp, _c_int]),
+    "sige_hip_plan_new_slots": (_c_int, [_c_vp, _c_int]),
+    "sige_hip_plan_bind_ptr": (_c_int, [_c_vp, _c_vp, _c_int]),
+    "sige_hip_plan_set_slot": (_c_int, [_c_vp, _c_int, _c_int]),
+    "sige_hip_plan_get_slots": (_c_int, [_c_vp, _c_vp, _c_int]),
+    "sige_hip_plan_record_readback": (_c_int, [_c_vp, _c_vp, _c_int, _c_int]),
+    "sige_hip_plan_run": (_c_int, [_c_vp, _c_int, _c_vp]),
 }
 
 EXPORTS = tuple(_SIGNATURES)  # every symbol include/sige_hip.h declares
@@ -204,7 +218,8 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
-            setattr(table, name, _Guarded(fn) if (args and args[-1] is _c_vp and res is _c_int) else fn)
+            guarded = args and args[-1] is _c_vp and res is _c_int and (not name.startswith("sige_hip_plan_") or name == "sige_hip_plan_run")
+            setattr(table, name, _Guarded(fn) if guarded else fn)
         table.handle = handle
         _lib = table
     return _lib
@@ -270,6 +285,54 @@ def _act(name: str) -> int:
 
 
 # --------------------------------------------------------------------------
+# Launch-plan recording (sige_amd/plan.py drives it; csrc/plan.hpp replays).  While a plan records on this thread:
+#   * index lists come out of PERSISTENT buffers sized for every candidate tile (a later mask writes the same memory), bound
+#     to a slot of the plan; tile tables built from them are bound to the same slot;
+#   * tensors whose leading dimension is a tile count are allocated for the largest count and returned as a view;
+#   * every tensor a recorded call of the mask section points at is kept alive by the plan (the forward section is recorded
+#     under a hipGraph capture, whose memory pool does that).
+# --------------------------------------------------------------------------
+_plan_tls = threading.local()
+
+
+def plan_recorder():
+    """The sige_amd.plan._Recorder of this thread while a launch plan records, else None."""
+    return getattr(_plan_tls, "rec", None)
+
+
+def _plan_keep(*tensors):
+    rec = plan_recorder()
+    if rec is not None:
+        rec.keep.extend(t for t in tensors if t is not None)
+
+
+def base_ptr(t: torch.Tensor) -> int:
+    """Address of `t`'s first element also when `t` is EMPTY (Tensor.data_ptr() of an empty view is 0; an index list of zero
+    active tiles is still a view of its persistent buffer)."""
+    return t.untyped_storage().data_ptr() + t.storage_offset() * t.element_size()
+
+
+def _tile_capacity(idx: torch.Tensor) -> Optional[int]:
+    """While a plan records: how many tiles the persistent buffer behind the index list `idx` can hold (None: not one of the
+    plan's index lists -- e.g. the all-tiles list of a dense layer, whose count never changes)."""
+    rec = plan_recorder()
+    if rec is None:
+        return None
+    info = rec.idx_info.get(base_ptr(idx))
+    return None if info is None else info[1]
+
+
+def _empty_tiles_cl(B: int, idx: torch.Tensor, C: int, R: int, S: int, device) -> torch.Tensor:
+    """Channels-last tile tensor [B * N, C, R, S] for the tiles of `idx`; while a plan records, backed by memory for every
+    candidate tile (the same pointer serves any later mask)."""
+    N = idx.shape[0]
+    cap = _tile_capacity(idx)
+    if cap is None or cap <= N:
+        return _empty_cl((B * N, C, R, S), device)
+    return _empty_cl((B * cap, C, R, S), device)[:B * N]
+
+
+# --------------------------------------------------------------------------
 # The five reference-signature entry points (sige/cuda/pybind_cuda.cpp:5-12)
 # --------------------------------------------------------------------------
 def gather(x, bSizeH, bSizeW, activeIndices, scale=None, shift=None, activationName="identity",
@@ -323,6 +386,7 @@ def get_scatter_map(H, W, bSizeH, bSizeW, kSizeH, kSizeW, offsetH, offsetW, stri
     _check(lib().sige_hip_scatter_map_i32(H, W, bSizeH, bSizeW, kSizeH, kSizeW, offsetH, offsetW, strideH, strideW,
                                           idx.data_ptr(), idx.shape[0], out.data_ptr(), _stream(idx)),
            "get_scatter_map")
+    _plan_keep(out)
     return out
 
 
@@ -357,6 +421,10 @@ def tile_table(activeIndices, offset: Tuple[int, int], stride: Tuple[int, int], 
     _check(lib().sige_hip_tile_table_i32(idx.data_ptr(), idx.shape[0], offset[0], offset[1], stride[0], stride[1],
                                          out_tile[0], out_tile[1], gH, gW, table.data_ptr(), _stream(idx)),
            "tile_table")
+    rec = plan_recorder()
+    if rec is not None:  # (calls that take a tile TABLE and a count look the count up under the table's pointer)
+        rec.bind_alias(table, idx)
+        rec.keep.append(table)
     return table
 
 
@@ -393,6 +461,8 @@ def reduce_mask(mask: torch.Tensor, block_size, stride, padding) -> torch.Tensor
     torch.nonzero synchronises the same way)."""
     if mask.dim() != 2 or not mask.is_cuda:
         raise RuntimeError("sige_amd.hip.reduce_mask: expected a 2-D CUDA mask")
+    if plan_recorder() is not None:  # (a launch plan records: persistent index list, recorded read-back)
+        return reduce_mask_batch([(mask, block_size, stride, padding)])[0]
     m = mask if mask.dtype in (torch.bool, torch.uint8) else (mask != 0)
     m = m.contiguous()
     H, W = m.shape
@@ -426,6 +496,20 @@ def reduce_mask_batch(requests) -> list:
                                               padding[0], padding[1], buf.data_ptr(), cap,
                                               counts.data_ptr() + 4 * i, _stream(m)), "reduce_mask")
         bufs.append((buf, m))
+    rec = plan_recorder()
+    if rec is not None:
+        # the plan replays these compaction launches under later masks: their outputs ARE the index lists (persistent, sized
+        # for every candidate tile), and the count read-back is a recorded step that sets one slot per list
+        first = rec.new_slots(len(requests))
+        _check(lib().sige_hip_plan_record_readback(rec.handle, counts.data_ptr(), first, len(requests)), "plan_record_readback")
+        ns = counts.cpu().tolist()
+        out = []
+        for i, ((buf, m), n) in enumerate(zip(bufs, ns)):
+            rec.bind_index_list(buf, first + i, n)
+            rec.keep.extend((buf, m))
+            out.append(buf[:n])
+        rec.keep.append(counts)
+        return out
     ns = counts.cpu().tolist()  # the one synchronisation of the mask -> index pipeline
     return [buf[:n].clone() for (buf, _), n in zip(bufs, ns)]
 
@@ -468,6 +552,7 @@ def dilate_mask(mask: torch.Tensor, dilation: Tuple[int, int]) -> torch.Tensor:
     out = torch.empty_like(m)
     _check(lib().sige_hip_dilate_mask_u8(m.data_ptr(), H, W, max(0, dilation[0]), max(0, dilation[1]), out.data_ptr(),
                                          _stream(m)), "dilate_mask")
+    _plan_keep(out, m)
     return out.view(torch.bool)
 
 
@@ -486,6 +571,7 @@ def mask_pyramid(mask: torch.Tensor, min_res: Tuple[int, int], dilation: Tuple[i
     _check(lib().sige_hip_mask_pyramid_u8(m.data_ptr(), H, W, min_res[0], min_res[1], max(0, dilation[0]), max(0, dilation[1]),
                                           float(threshold), float(eps), scratch.data_ptr(), n_scratch, out.data_ptr(),
                                           _stream(m)), "mask_pyramid")
+    _plan_keep(out, scratch, m)
     pyramid, off = {}, 0
     for h, w in sizes:
         pyramid[(h, w)] = out[off:off + h * w].view(h, w).view(torch.bool)
@@ -1017,6 +1103,16 @@ def block_conv_direct(x, weight, bias, stride: Tuple[int, int], groups: int = 1,
     return out
 
 
+def copy_dense_(dst: torch.Tensor, src: torch.Tensor):
+    """dst <- src for two fp32 tensors of one shape and one DENSE layout (plain or channels-last: equal strides, no gaps), as a
+    library launch -- unlike Tensor.copy_ it is recorded by a launch plan (the refresh of a persistent Scatter output)."""
+    if (dst.shape != src.shape or dst.stride() != src.stride() or dst.dtype != torch.float32 or src.dtype != torch.float32
+            or not (dst.is_contiguous() or dst.is_contiguous(memory_format=CL))):
+        raise RuntimeError("copy_dense_: two fp32 tensors of one shape and one dense layout")
+    _check(lib().sige_hip_copy_f32(src.data_ptr(), dst.data_ptr(), src.numel(), _stream(src)), "copy")
+    return dst
+
+
 def copy_(dst: torch.Tensor, src: torch.Tensor):
     assert dst.numel() == src.numel() and dst.is_contiguous() and src.is_contiguous()
     _check(lib().sige_hip_copy_f32(src.data_ptr(), dst.data_ptr(), src.numel(), _stream(src)), "copy")
@@ -1134,7 +1230,7 @@ def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, a
     N = idx.shape[0]
     if full is None:
         Ro, So = (block[0] - kernel[0]) // stride[0] + 1, (block[1] - kernel[1]) // stride[1] + 1
-        out = _empty_cl((B * N, Cout, Ro, So), x.device)
+        out = _empty_tiles_cl(B, idx, Cout, Ro, So, x.device)
         fargs = (0, 0, 0, None, 0, 0)
     else:
         Ho, Wo = full["out_res"]
@@ -1153,7 +1249,16 @@ def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, a
     ks = lib().sige_hip_conv_ksplit_hint(B * N, C1 + C2, Cout, kernel[0], kernel[1], stride[0], stride[1])
     if full is not None and N * ((block[0] - kernel[0]) // stride[0] + 1) * ((block[1] - kernel[1]) // stride[1] + 1) < Ho * Wo:
         ks = 1  # tiles written into a larger tensor: the second pass would need whole output copies
-    if ks > 1 and KSPLIT:
+    cap = _tile_capacity(idx)
+    if cap is not None and full is None and KSPLIT:
+        # a launch plan records: the SAME call will run under other masks.  The launch splits K only while its 16 x 16 blocks
+        # do not fill the chip (sige_hip_conv_ksplit_hint: < 224 blocks); give it a workspace for the largest tile count
+        # that still splits, whatever this mask's count is (the entry point picks the factor from the workspace's capacity)
+        px = ((block[0] - kernel[0]) // stride[0] + 1) * ((block[1] - kernel[1]) // stride[1] + 1)
+        t_split = min(B * cap, max(1, 16 // px) * (224 // max(1, -(-Cout // 16)) + 1))
+        ws_n = 8 * t_split * px * Cout
+        ws = torch.empty(ws_n, dtype=torch.float32, device=x.device)
+    elif ks > 1 and KSPLIT:
         ws_n = ks * out.numel()
         ws = torch.empty(ws_n, dtype=torch.float32, device=x.device)
     fargs = fargs + (None if ws is None else ws.data_ptr(), ws_n)
@@ -1193,7 +1298,7 @@ def scatter_gather_conv_cl(x, y, block: Tuple[int, int], activeIndices, scatterM
     B, C, H, W = y.shape
     N = idx.shape[0]
     Ro, So = (block[0] - kernel[0]) // stride[0] + 1, (block[1] - kernel[1]) // stride[1] + 1
-    out = _empty_cl((B * N, Cout, Ro, So), y.device)
+    out = _empty_tiles_cl(B, idx, Cout, Ro, So, y.device)
     status = _conv_fn("sige_hip_scatter_gather_conv_nhwc", packed)(
         x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3], block[0], block[1], idx.data_ptr(), N,
         smap.data_ptr(), *sa, *ta, _act(activationName), packed.data_ptr(), _p(bias_keep), Cout, kernel[0], kernel[1],
@@ -1244,7 +1349,7 @@ def gather_cl(x, bSizeH, bSizeW, activeIndices, scale=None, shift=None, activati
     (sa, s_keep), (ta, t_keep) = _cvec(scale, "scale"), _cvec(shift, "shift")
     B, C, H, W = x.shape
     N = idx.shape[0]
-    out = _empty_cl((B * N, C, bSizeH, bSizeW), x.device)
+    out = _empty_tiles_cl(B, idx, C, bSizeH, bSizeW, x.device)
     _check(lib().sige_hip_gather_nhwc_f32(x.data_ptr(), B, C, H, W, bSizeH, bSizeW, idx.data_ptr(), N, *sa, *ta,
                                           _act(activationName), out.data_ptr(), _stream(x)), "gather_cl")
     return out
@@ -1258,7 +1363,7 @@ def scatter_gather_cl(x, y, bSizeH, bSizeW, activeIndices, scatterMap, scale=Non
     (sa, s_keep), (ta, t_keep) = _cvec(scale, "scale"), _cvec(shift, "shift")
     B, C, H, W = y.shape
     N = idx.shape[0]
-    out = _empty_cl((B * N, C, bSizeH, bSizeW), y.device)
+    out = _empty_tiles_cl(B, idx, C, bSizeH, bSizeW, y.device)
     _check(lib().sige_hip_scatter_gather_nhwc_f32(x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3],
                                                   bSizeH, bSizeW, idx.data_ptr(), N, smap.data_ptr(), *sa, *ta,
                                                   _act(activationName), out.data_ptr(), _stream(y)), "scatter_gather_cl")
@@ -1285,7 +1390,7 @@ def spade_modulate_cl(x_full, x_tiles, map_x, scale, shift, gb_tiles, gb_full, m
         xt = (x_tiles.data_ptr(), map_x.data_ptr(), x_tiles.shape[0] // B, x_tiles.shape[2], x_tiles.shape[3])
     (sa, s_keep), (ta, t_keep) = _cvec(scale, "scale"), _cvec(shift, "shift")
     N = idx.shape[0]
-    out = _empty_cl((B * N, C, block[0], block[1]), x_full.device)
+    out = _empty_tiles_cl(B, idx, C, block[0], block[1], x_full.device)
     _check(lib().sige_hip_spade_modulate_nhwc_f32(
         x_full.data_ptr(), xt[0], xt[1], xt[2], xt[3], xt[4], *sa, *ta,
         gb_tiles.data_ptr(), gb_full.data_ptr(), map_g.data_ptr(), gb_tiles.shape[0] // B, gb_tiles.shape[2], gb_tiles.shape[3],

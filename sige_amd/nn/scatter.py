@@ -39,6 +39,28 @@ def _cl_ok(cached: torch.Tensor, *others) -> bool:
     return all(o is None or tuple(o.shape) == tuple(cached.shape) for o in others)
 
 
+def _fill(buf: torch.Tensor, cached: torch.Tensor, build=None) -> torch.Tensor:
+    """buf <- cached (build None) or SiLU(scale * cached + shift) (build = (scale [C], shift [C])).  On the GPU, channels-last:
+    ONE library launch (sige_hip_copy_f32 / sige_hip_affine_act_nhwc_f32), which a launch plan records -- a torch copy would
+    be invisible to it."""
+    if cached.is_cuda and cached.dtype == torch.float32 and buf.stride() == cached.stride():
+        from .. import hip
+
+        if build is None and (cached.is_contiguous() or cached.is_contiguous(memory_format=torch.channels_last)):
+            return hip.copy_dense_(buf, cached)
+        if build is not None and hip.is_cl(cached):
+            sc, sh = build
+            done = hip.affine_act_cl(cached, sc.reshape(1, -1, 1, 1), sh.reshape(1, -1, 1, 1), "swish", out=buf)
+            if done is not None:
+                return buf
+    if build is None:
+        buf.copy_(cached)
+    else:
+        sc, sh = build
+        buf.copy_(torch.nn.functional.silu(cached * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)))
+    return buf
+
+
 class _OutputBuffers:
     """Persistent outputs of a Scatter module for the in-place mode (SIGEModel.set_scatter_inplace).
 
@@ -59,11 +81,17 @@ class _OutputBuffers:
         self.gen = {}
 
     def get(self, cache_id, cached: torch.Tensor, stamp, build=None):
-        """`build(cached)`: what a fresh buffer holds (default: a copy of the cache; an activated twin: its activation)."""
+        """`build`: what a fresh buffer holds -- None: a copy of the cache; (scale [C], shift [C]): SiLU(scale * cache + shift),
+        an activated twin."""
         entry = self.bufs.get(cache_id)
         key = (stamp, self.gen.get(cache_id, 0), tuple(cached.shape), cached.stride())
         if entry is None or entry[0] != key:
-            buf = cached.clone(memory_format=torch.preserve_format) if build is None else build(cached)
+            if entry is not None and entry[0][1:] == key[1:] and entry[1].device == cached.device:
+                # only the MASK changed: restore the buffer in place -- same address, so a launch plan or a captured hipGraph
+                # that points at it stays valid, and nothing is allocated
+                buf = _fill(entry[1], cached, build)
+            else:
+                buf = _fill(torch.empty_like(cached, memory_format=torch.preserve_format), cached, build)
             entry = (key, buf, build)
             self.bufs[cache_id] = entry
         return entry[1]
@@ -74,13 +102,16 @@ class _OutputBuffers:
             self.gen[k] = self.gen.get(k, 0) + 1
             self.bufs.pop(k, None)
 
-    def refresh(self, caches: dict):
+    def refresh(self, caches: dict, stamp=None):
         """The cached tensors were rewritten IN PLACE (same tensors, new values -- e.g. a collective into the packed
-        cache): re-copy them into the existing buffers, whose addresses a captured hipGraph may hold."""
+        cache), or (`stamp`) the mask changed: rebuild the existing buffers from them, addresses kept -- a captured hipGraph
+        or a launch plan may hold them.  `stamp`: the buffers then count as built for that mask."""
         for cid, (key, buf, build) in list(self.bufs.items()):
             cached = caches.get(cid)
             if cached is not None and tuple(cached.shape) == tuple(buf.shape) and cached.stride() == buf.stride():
-                buf.copy_(cached if build is None else build(cached))
+                _fill(buf, cached, build)
+                if stamp is not None:
+                    self.bufs[cid] = ((stamp,) + tuple(key[1:]), buf, build)
             else:
                 self.bufs.pop(cid)
 
@@ -130,10 +161,7 @@ class _TwinBuffers:
         """[(key, buffer, scale, shift)] for the fused launch; buffers are (re)built from the cache when stale."""
         out = []
         for key, (sc, sh) in twins_for(self.regs, cache_id).items():
-            def build(c, sc=sc, sh=sh):
-                return torch.nn.functional.silu(c * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).contiguous(
-                    memory_format=torch.channels_last)
-            buf = self.bufs.setdefault(key, _OutputBuffers()).get(cache_id, cached, stamp, build=build)
+            buf = self.bufs.setdefault(key, _OutputBuffers()).get(cache_id, cached, stamp, build=(sc, sh))
             out.append((key, buf, sc, sh))
         return out
 
@@ -141,9 +169,9 @@ class _TwinBuffers:
         for b in self.bufs.values():
             b.invalidate(cache_id)
 
-    def refresh(self, caches: dict):
+    def refresh(self, caches: dict, stamp=None):
         for b in self.bufs.values():
-            b.refresh(caches)
+            b.refresh(caches, stamp)
 
     def clear(self):
         self.bufs = {}
@@ -185,10 +213,19 @@ class Scatter(SIGEModule):
         self._out_bufs.clear()
         self.twins.clear()
 
-    def refresh_outputs(self):
-        """(sige_amd.parallel) the cache tensors were rewritten in place: persistent outputs follow, addresses kept."""
-        self._out_bufs.refresh(self.original_outputs)
-        self.twins.refresh(self.original_outputs)
+    def refresh_outputs(self, new_mask: bool = False):
+        """(sige_amd.parallel) the cache tensors were rewritten in place -- or (`new_mask`, sige_amd.plan) the mask changed:
+        persistent outputs follow, addresses kept."""
+        stamp = self.gather.module.timestamp if new_mask else None
+        self._out_bufs.refresh(self.original_outputs, stamp)
+        self.twins.refresh(self.original_outputs, stamp)
+
+    def plan_tables(self):
+        """(sige_amd.plan) build, now, the per-mask lookup tables this module's sparse forward would build lazily."""
+        g: Gather = self.gather.module
+        for cached in self.original_outputs.values():
+            if cached.is_cuda and g.active_indices is not None:
+                g.tile_table(cached.shape[2:], cached.device)
 
     def forward_fused(self, conv, tiles: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         """(not in the reference) `self(conv(tiles), residual)` in ONE launch when the in-place mode is on and `tiles`
@@ -304,10 +341,20 @@ class ScatterWithBlockResidual(SIGEModule):
         self._out_bufs.clear()
         self.twins.clear()
 
-    def refresh_outputs(self):
-        """(sige_amd.parallel) the cache tensors were rewritten in place: persistent outputs follow, addresses kept."""
-        self._out_bufs.refresh(self.original_outputs)
-        self.twins.refresh(self.original_outputs)
+    def refresh_outputs(self, new_mask: bool = False):
+        """(sige_amd.parallel) the cache tensors were rewritten in place -- or (`new_mask`, sige_amd.plan) the mask changed:
+        persistent outputs follow, addresses kept."""
+        stamp = (self.main_gather.module.timestamp, self.shortcut_gather.module.timestamp) if new_mask else None
+        self._out_bufs.refresh(self.original_outputs, stamp)
+        self.twins.refresh(self.original_outputs, stamp)
+
+    def plan_tables(self):
+        """(sige_amd.plan) build, now, the per-mask lookup tables this module's sparse forward would build lazily."""
+        for cached in self.original_outputs.values():
+            if cached.is_cuda:
+                for g in (self.main_gather.module, self.shortcut_gather.module):
+                    if g.active_indices is not None:
+                        g.tile_table(cached.shape[2:], cached.device)
 
     def forward_fused(self, conv, tiles: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
         """(not in the reference) `self(conv(tiles), residual)` in ONE launch (see Scatter.forward_fused): `residual` are

@@ -125,6 +125,13 @@ def pack_caches(model: torch.nn.Module) -> torch.Tensor:
         bufs = getattr(m, "_out_bufs", None)
         if bufs is not None:
             bufs.invalidate()
+        # ... and so did the cached affines: activated twins were registered with VIEWS of the old affine tensors (a consumer's
+        # conv1 affine, held by its producers).  Drop the registrations; the consumers register again, with the views of the
+        # flat buffer, on their next sparse forward (sparse -> pack -> broadcast otherwise serves twins of the OLD
+        # affine -- 0.18 max error on the oracle backend).
+        drop = getattr(m, "_drop_twin_links", None)
+        if drop is not None:
+            drop()
     model.__dict__["_sige_cache_layout"] = (flat.data_ptr(), layout)
     return flat
 
@@ -239,6 +246,47 @@ def _issue(buf: torch.Tensor, src: int, method: str, group, world: int, async_op
     return dist.all_gather_into_tensor(buf, mine, group=group, async_op=async_op)  # in place: rank r's input is chunk r of the output
 
 
+def _refresh_schedule(model: torch.nn.Module, layout, total: int, world: int, n_chunks: int):
+    """(chunk bounds, modules to refresh after each chunk) of the pipelined distribution.  A module (and its ancestors: a
+    block's derived caches read its children's) is ready once the chunk holding the END of everything its refresh reads has
+    landed: its own last cache tensor, and -- for a module that keeps activated twins (scatter._TwinBuffers), which it rebuilds
+    as SiLU(scale * cache + shift) with the CONSUMER's cached affine -- the affines of its registered consumers, which sit later
+    in module order, for a skip connection at another level of the up path (the twin was rebuilt from the previous
+    affine and never refreshed again)."""
+    gran = world * _ALIGN
+    size = max(gran, ((total + n_chunks - 1) // n_chunks + gran - 1) // gran * gran)
+    bounds = [(o, min(o + size, total)) for o in range(0, total, size)]
+    parents = {}
+    for _, m in model.named_modules():
+        for _, c in m.named_children():
+            parents[c] = m
+    own = {}
+    for m, _, e, _ in layout:
+        own[m] = max(own.get(m, 0), e)
+    by_id = {id(m): m for m in model.modules()}
+    needs = dict(own)
+    for m in by_id.values():
+        regs = getattr(getattr(m, "twins", None), "regs", None)
+        for key in (regs or ()):
+            consumer = by_id.get(key[0]) if isinstance(key, tuple) and key else None
+            if consumer is not None:
+                needs[m] = max(needs.get(m, 0), own.get(consumer, 0))
+    end = {}
+    for m, e in needs.items():
+        node = m
+        while node is not None:
+            end[node] = max(end.get(node, 0), e)
+            node = parents.get(node)
+    ready = [[] for _ in bounds]
+    for m in model.modules():
+        if getattr(m, "refresh_outputs", None) is None and getattr(m, "rebuild_derived_caches", None) is None:
+            continue
+        e = end.get(m, 0)
+        k = next((i for i, (lo, hi) in enumerate(bounds) if e <= hi), len(bounds) - 1)
+        ready[k].append(m)
+    return bounds, ready
+
+
 def distribute_cache_pipelined(flat: torch.Tensor, model: torch.nn.Module, src: int = 0, method: str = "scatter_allgather",
                                n_chunks: int = 8, group=None, wire_dtype=None) -> dict:
     """The same result as `distribute_cache(..., model=model)`, pipelined: the packed cache is cut into `n_chunks` pieces in
@@ -256,29 +304,7 @@ def distribute_cache_pipelined(flat: torch.Tensor, model: torch.nn.Module, src: 
         return {"chunks": 0, "refreshed": 0}
     if method not in ("broadcast", "scatter_allgather"):
         raise ValueError("unknown method %r" % method)
-    total = flat.numel()
-    gran = world * _ALIGN
-    size = max(gran, ((total + n_chunks - 1) // n_chunks + gran - 1) // gran * gran)
-    bounds = [(o, min(o + size, total)) for o in range(0, total, size)]
-    # every module (and its ancestors: a block's derived caches read its children's) is ready once the chunk holding
-    # the END of its last cache tensor has landed
-    end = {}
-    parents = {}
-    for name, m in model.named_modules():
-        for cname, c in m.named_children():
-            parents[c] = m
-    for m, _, e, _ in layout:
-        node = m
-        while node is not None:
-            end[node] = max(end.get(node, 0), e)
-            node = parents.get(node)
-    ready = [[] for _ in bounds]
-    for m in model.modules():
-        if getattr(m, "refresh_outputs", None) is None and getattr(m, "rebuild_derived_caches", None) is None:
-            continue
-        e = end.get(m, 0)
-        k = next((i for i, (lo, hi) in enumerate(bounds) if e <= hi), len(bounds) - 1)
-        ready[k].append(m)
+    bounds, ready = _refresh_schedule(model, layout, flat.numel(), world, n_chunks)
     if wire_dtype not in (None, torch.float32, torch.float16):
         raise ValueError("wire_dtype: torch.float32 or torch.float16")
     f16 = wire_dtype == torch.float16

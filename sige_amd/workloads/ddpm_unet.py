@@ -192,7 +192,7 @@ class ResBlock(SIGEModule, _TwinProducer):
         return self.scatter if self.sparse_main else None
 
     def _drop_twin_links(self):
-        for key, prod in self._twin_links.items():
+        for key, (prod, _) in self._twin_links.items():
             prod.unregister_twin(key)
         self._twin_links = {}
         self._aff_gen += 1
@@ -207,6 +207,13 @@ class ResBlock(SIGEModule, _TwinProducer):
             return None
         if s1.shape[0] != 1:
             return None  # (per-sample affine: the epilogue's twin vectors are per channel)
+        # A registration holds VIEWS of the affine tensors it was made with.  If the cached affine has been re-pointed since
+        # (sige_amd.parallel.pack_caches moves every cache tensor into one flat buffer; anything that assigns `affine[cid]`
+        # without going through _full), the producers would keep activating with the old tensors: drop every link and start
+        # over with the current ones (sparse -> pack_caches -> broadcast gave stale twins, max error 0.18).
+        anchor = (s1.data_ptr(), t1.data_ptr())
+        if any(a != anchor for k, (_, a) in self._twin_links.items() if k[3] == self.cache_id):
+            self._drop_twin_links()
         twins, off, complete = [], 0, True
         for i, p in enumerate(parts):
             c = p.shape[1]
@@ -219,7 +226,7 @@ class ResBlock(SIGEModule, _TwinProducer):
                     sc = s1.reshape(-1)[off:off + c].contiguous()
                     sh = t1.reshape(-1)[off:off + c].contiguous()
                     if prod.register_twin(key, sc, sh):
-                        self._twin_links[key] = prod
+                        self._twin_links[key] = (prod, anchor)
             twins.append(t)
             off += c
         return twins if complete else None
@@ -282,7 +289,7 @@ class ResBlock(SIGEModule, _TwinProducer):
 
     def _shortcut(self, x, x2=None):
         if self.cin == self.cout:
-            return x
+            return x if x2 is None else torch.cat([x, x2], dim=1)  # (identity shortcut of a concatenated input: both halves)
         if x2 is not None:  # (full mode, fast: the cat is read through two pointers)
             if self.sparse_shortcut:
                 self.shortcut_gather.note_full_input(x.shape[2:])

@@ -108,3 +108,31 @@ def test_python_binding_matches_the_header_parameter_by_parameter():
         assert got_args == want_args, (name, [(i, g, w) for i, (g, w) in enumerate(zip(got_args, want_args)) if g != w],
                                        len(got_args), len(want_args))
         assert names[res] == want_res, name
+
+
+def test_launch_plan_slot_table_without_a_gpu():
+    """csrc/plan.hip: the host-only half of a launch plan -- slots, pointer bindings, begin / end state -- needs no device
+    (no entry point is called while recording here, so nothing is launched)."""
+    import ctypes
+
+    from sige_amd import hip
+
+    L = hip.lib()
+    p = L.sige_hip_plan_create()
+    assert p
+    try:
+        assert L.sige_hip_plan_new_slots(p, 3) == 0 and L.sige_hip_plan_new_slots(p, 2) == 3
+        assert L.sige_hip_plan_set_slot(p, 4, 42) == 0 and L.sige_hip_plan_set_slot(p, 5, 1) != 0 and L.sige_hip_plan_set_slot(p, 0, -1) != 0
+        assert L.sige_hip_plan_bind_ptr(p, 0x1000, 4) == 0 and L.sige_hip_plan_bind_ptr(p, 0x1000, 9) != 0 and L.sige_hip_plan_bind_ptr(p, None, 0) != 0
+        arr = (ctypes.c_int32 * 5)()
+        assert L.sige_hip_plan_get_slots(p, ctypes.cast(arr, ctypes.c_void_p), 5) == 5 and list(arr) == [0, 0, 0, 0, 42]
+        assert L.sige_hip_plan_recording() == 0
+        assert L.sige_hip_plan_begin(p, 0, 0) == 0 and L.sige_hip_plan_recording() == 1
+        assert L.sige_hip_plan_begin(p, 1, 0) != 0          # (one recording per thread)
+        assert L.sige_hip_plan_run(p, 0, None) != 0          # (not while recording)
+        assert L.sige_hip_plan_end(p) == 0 and L.sige_hip_plan_recording() == 0
+        assert L.sige_hip_plan_calls(p, 0) == 0 and L.sige_hip_plan_calls(p, 1) == 0 and L.sige_hip_plan_calls(p, 2) == -1
+        assert L.sige_hip_plan_shape_bound(p) == 0
+        assert L.sige_hip_plan_run(p, 1, None) == 0          # (an empty section)
+    finally:
+        assert L.sige_hip_plan_destroy(p) == 0
