@@ -1509,12 +1509,25 @@ def main():
                 value_cache_distribution_inside_job=round(world * args.steps / dt, 2),
                 value_steady_state_cache_resident=round(world * args.steps / dt_steady, 2),
                 value_cache_refreshed_every_step=round(world / (dist_s + step_s), 2),
+                efficiency=round(dt_steady / dt, 4),
+                efficiency_note="value(N) / (N x steady-state value of one rank): the timed job (one cache distribution + K forwards per "
+                                "rank, max over ranks) against the same K forwards with the cache resident -- what the distribution "
+                                "costs a %d-step job; the north_star asks >= 0.85 at 8 GPUs" % args.steps,
                 note="`value` counts ONE cache distribution (collective + local refresh of derived buffers) inside the timed "
                      "job of %d steps; steady_state = the same replays with the cache already resident; every_step = a fresh "
                      "cache per step (SDEdit-style), computed from the two measured times; recompute_full_pass_ms = what every rank "
                      "would spend recomputing the cache itself instead (library full pass, split fp16 operands, hipGraph), max over "
                      "ranks" % args.steps)
         line.update(result)
+        # the >= 6x target of north_star is quoted against the stock dense forward (MIOpen: SURVEY.md 8d); the same forward on this
+        # library's own dense-layer kernels is faster than MIOpen, so both ratios are printed
+        fp = (x3 or {}).get("full_pass_ms") or {}
+        line["speedup_vs_dense_detail"] = {
+            "vs_miopen": round(dense_ms / ms_steady, 2),
+            "vs_library_full_pass_f32_exact": round(fp["library_f32_exact"] / ms_steady, 2) if fp.get("library_f32_exact") else None,
+            "vs_library_full_pass_f16x3": round(fp["library_f16x3"] / ms_steady, 2) if fp.get("library_f16x3") else None,
+            "note": "dense forward of the same U-Net on the same GPU / this sparse forward: MIOpen fp32 (best of NCHW / NHWC; the "
+                    "contract of SURVEY.md 8d), the library's own exact-fp32 full pass, the library's full pass on split fp16 operands"}
         if parity is not None:
             line["parity_max_abs"] = parity
             if args.dtype == "f16":

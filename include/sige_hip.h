@@ -59,6 +59,10 @@ const char *sige_hip_device_arch(void);
 /* number of GPU kernels this library has launched in the process so far (all entry
  * points, all streams): measurement aid -- launches per forward in bench.py. */
 int64_t sige_hip_launch_count(void);
+/* HIP's current device at the most recent kernel launch of this library (-1: none yet).  Every entry point launches on the
+ * CURRENT device with the stream it is handed (like the reference's sige/cuda wrappers, which have no CUDAGuard either); the
+ * host side guards (sige_amd/hip.py: _Guarded).  Debug aid for testing that guard. */
+int sige_hip_last_launch_device(void);
 
 /* ---- gather : replaces gather_cpu / gather_cuda -------------------------
  * (sige/cpu/gather.cpp:60-114, sige/cuda/gather_kernel.cu:69-124, gather.h:5-12)

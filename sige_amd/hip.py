@@ -37,6 +37,7 @@ _SIGNATURES = {
     "sige_hip_error_string": (ctypes.c_char_p, [_c_int]),
     "sige_hip_device_arch": (ctypes.c_char_p, []),
     "sige_hip_launch_count": (ctypes.c_int64, []),
+    "sige_hip_last_launch_device": (_c_int, []),
     "sige_hip_gather_f32": (_c_int, [_c_vp] + [_c_int] * 6 + [_c_vp, _c_int] + _BC + _BC + [_c_int, _c_int, _c_vp, _c_vp]),
     "sige_hip_scatter_f32": (_c_int, [_c_vp, _c_vp] + [_c_int] * 10 + [_c_vp, _c_int] + _BC + [_c_vp, _c_vp]),
     "sige_hip_scatter_with_block_residual_f32": (
@@ -174,6 +175,11 @@ _SIGNATURES = {
 EXPORTS = tuple(_SIGNATURES)  # every symbol include/sige_hip.h declares
 
 
+# how many guarded entry-point calls had to switch HIP's current device to the tensor's ("switched") and how many found it current
+# ("direct"); conv_pair begin / end count under "pair_switched".  A debug aid: tests/test_gpu_round4.py checks the guard with it.
+GUARD_STATS = {"switched": 0, "direct": 0, "pair_switched": 0}
+
+
 class _Guarded:
     """A C entry point that launches on the device of the tensor whose stream was just taken.
 
@@ -191,8 +197,10 @@ class _Guarded:
     def __call__(self, *args):
         dev, _tls.pending_device = getattr(_tls, "pending_device", None), None
         if dev is not None and dev != (_raw_device() if _raw_device is not None else torch.cuda.current_device()):
+            GUARD_STATS["switched"] += 1
             with torch.cuda.device(dev):
                 return self.fn(*args)
+        GUARD_STATS["direct"] += 1
         return self.fn(*args)
 
 
@@ -223,6 +231,11 @@ def lib():
         table.handle = handle
         _lib = table
     return _lib
+
+
+def last_launch_device() -> int:
+    """HIP's current device at this library's most recent kernel launch (-1: none yet)."""
+    return int(lib().sige_hip_last_launch_device())
 
 
 def launch_count() -> int:
@@ -853,6 +866,7 @@ class conv_pair:
         if self.like is not None and self.like.is_cuda:
             cur = _raw_device() if _raw_device is not None else torch.cuda.current_device()
             if self.like.device.index != cur:
+                GUARD_STATS["pair_switched"] += 1
                 return torch.cuda.device(self.like.device)
         return contextlib.nullcontext()
 

@@ -143,3 +143,130 @@ def test_launch_plan_refuses_what_it_cannot_follow(hip):
         assert torch.equal(plan.run(), out)
         with pytest.raises(RuntimeError, match="cannot follow a new mask"):
             plan.bind_mask(m1)
+
+
+# ---- hardening ----------------------------------------------------------------------------------------------
+def test_ksplit_finish_stress_two_streams(hip):
+    """Both in-launch K-split finishes (tile kernel: conv_mfma.hpp, dense-layer kernel: conv_wide.hpp) publish their partial
+    sums with relaxed agent-scope stores + s_waitcnt vmcnt(0) and take a relaxed ticket -- outside the letter of the HIP memory
+    model.  10 000 launches on TWO streams at once, four different inputs alternating over the same workspaces and
+    ticket ring: every single result must be the bits of the two-pass (second launch) result of its input."""
+    from tests.test_gpu_round2 import _pair_case
+
+    res, c1, c2, cout = 8, 512, 512, 512
+    convs = [_pair_case(hip, res, c1, c2, cout, 0, True, seed=11 + i, residual=True)[1] for i in range(4)]
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=g).to(DEV)  # noqa: E731
+    xs = [_cl(r(1, 1024, 16, 16)) for _ in range(4)]
+    w = r(512, 1024, 3, 3) / (3 * 32.0)
+    sc, sh, bias = r(1, 1024, 1, 1), r(1, 1024, 1, 1), r(512)
+    pw = hip.wide_conv_pack_weights(w, "f32")
+    wide = [lambda x=x: hip.wide_conv_cl(x, None, sc, sh, "swish", pw, bias, 512, (3, 3)) for x in xs]
+    try:
+        hip.conv_force_ksplit(4)
+        hip.conv_force_ksplit_pass(True)  # the second-pass kernel: the reference bits of the tile kernel
+        want = [c().clone() for c in convs]
+        hip.conv_force_ksplit_pass(False)
+        hip.wide_conv_force_ksplit(1)     # unsplit: the reference of the dense-layer kernel (its split sums in another order)
+        want_w1 = [f().clone() for f in wide]
+        hip.wide_conv_force_ksplit(0)
+        want_w = [f().clone() for f in wide]  # (deterministic: the same bits every time)
+        torch.cuda.synchronize()
+        for a, b in zip(want_w, want_w1):
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-4)
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        bad = torch.zeros(1, device=DEV)
+        n = 0
+
+        def check(outs):
+            for i, kind, o in outs:
+                bad.add_((o != (want_w if kind else want)[i]).any())
+
+        # (a) eager launches, two streams issuing in turn (tickets from the shared ring, workspaces from the allocator)
+        for rnd in range(5):
+            outs = [[], []]
+            for k in range(100):
+                for si, st in enumerate(streams):
+                    with torch.cuda.stream(st):
+                        i = (k + 2 * si + rnd) % 4
+                        outs[si].append((i, 0, convs[i]()))
+                        outs[si].append((i, 1, wide[i]()))
+                        n += 2
+            torch.cuda.synchronize()
+            check(outs[0] + outs[1])
+            del outs
+        # (b) two hipGraphs of 200 launches each, replayed CONCURRENTLY on the two streams (the host cannot issue eager launches
+        #     fast enough to keep two streams busy): 2 x 200 x 20 launches really overlapping on the chip
+        graphs = []
+        for si, st in enumerate(streams):
+            gph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(st):
+                torch.cuda.synchronize()
+                with torch.cuda.graph(gph, stream=st):
+                    outs = []
+                    for k in range(100):
+                        i = (k + 2 * si) % 4
+                        outs.append((i, 0, convs[i]()))
+                        outs.append((i, 1, wide[i]()))
+            graphs.append((gph, outs))
+        for rep in range(20):
+            for (gph, _), st in zip(graphs, streams):
+                with torch.cuda.stream(st):
+                    gph.replay()
+            n += 400
+            if rep % 5 == 4:
+                torch.cuda.synchronize()
+                check(graphs[0][1] + graphs[1][1])
+        torch.cuda.synchronize()
+        assert n == 10000
+        assert float(bad) == 0.0
+        del graphs
+    finally:
+        hip.conv_force_ksplit(0)
+        hip.conv_force_ksplit_pass(False)
+        hip.wide_conv_force_ksplit(0)
+
+
+def test_device_guard_on_one_gpu(hip, monkeypatch):
+    """The per-thread device guard of the ctypes bindings (hip._Guarded, hip.conv_pair._on_device): with HIP's current device
+    reported as ANOTHER one than the tensors', every entry-point call -- paired, unpaired, and a held 1x1 flushed by pair_end --
+    must run under the tensors' device (GUARD_STATS counts the switches, sige_hip_last_launch_device says where the launch
+    went).  The only other guard test needs two GPUs and is skipped on the driver's box."""
+    from tests.test_gpu_round2 import _pair_case
+
+    shortcut, conv1 = _pair_case(hip, 64, 128, 0, 256, 18, False, seed=2)
+    want_s, want_c = shortcut(), conv1()
+    real = torch.cuda.current_device()
+    monkeypatch.setattr(hip, "_raw_device", lambda: real + 7)  # "the current device is not the tensors'"
+    st = dict(hip.GUARD_STATS)
+
+    def delta():
+        d = {k: hip.GUARD_STATS[k] - st[k] for k in st}
+        st.update(hip.GUARD_STATS)
+        return d
+
+    # unpaired
+    n0 = hip.launch_count()
+    got = conv1()
+    assert delta() == {"switched": 1, "direct": 0, "pair_switched": 0}
+    assert hip.launch_count() == n0 + 1 and hip.last_launch_device() == real
+    assert torch.equal(got, want_c)
+    # paired: begin, held 1x1, 3x3 (launches both), end
+    n0, f0 = hip.launch_count(), hip.conv_pairs_fused()
+    with hip.conv_pair(want_s):
+        gs = shortcut()
+        gc = conv1()
+    assert delta() == {"switched": 2, "direct": 0, "pair_switched": 2}
+    assert hip.launch_count() == n0 + 1 and hip.conv_pairs_fused() == f0 + 1 and hip.last_launch_device() == real
+    assert torch.equal(gc, want_c)
+    torch.testing.assert_close(gs, want_s, rtol=1e-5, atol=1e-5)
+    # a held 1x1 with no partner: launched by pair_end, which has no stream argument to key the guard on
+    n0 = hip.launch_count()
+    with hip.conv_pair(want_s):
+        gs = shortcut()
+        assert hip.launch_count() == n0  # (held)
+    assert delta() == {"switched": 1, "direct": 0, "pair_switched": 2}
+    assert hip.launch_count() == n0 + 1 and hip.last_launch_device() == real
+    assert torch.equal(gs, want_s)
+    torch.cuda.synchronize()
+    assert torch.cuda.current_device() == real  # (every guard restored the device it found)
