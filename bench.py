@@ -864,7 +864,15 @@ def main():
                          "the same fp16-rounded cache; the cached affines stay fp32).  Only with --dtype f16: the rounding costs up to "
                          "1.6e-3 of output error at 15 %% edit (profiles/r3_f16_cache_trace.json) -- inside the f16 criterion, outside "
                          "the fp32 path's 1e-3")
+    ap.add_argument("--cache-dtype", default="auto", choices=["auto", "f32", "f16"],
+                    help="how the full pass's cached activations are STORED (SIGEModel.set_cache_dtype): auto = f16 with --dtype f16 "
+                         "(half the resident cache and half the bytes of its distribution, no conversion passes; cached affines stay "
+                         "fp32), f32 otherwise (the reference; the fp32 path's 1e-3 needs it)")
     args = ap.parse_args()
+    if args.cache_dtype == "auto":
+        args.cache_dtype = "f16" if args.dtype == "f16" else "f32"
+    if args.cache_dtype == "f16" and args.dtype != "f16":
+        ap.error("--cache-dtype f16 goes with --dtype f16 (an fp16-rounded cache does not keep the fp32 path's 1e-3)")
     if args.wire_dtype == "f16" and args.dtype != "f16":
         ap.error("--wire-dtype f16 goes with --dtype f16 (an fp16-rounded cache does not keep the fp32 path's 1e-3)")
 
@@ -909,6 +917,8 @@ def main():
     inplace = args.layout == "nhwc" and not args.no_inplace_scatter
     model.set_scatter_inplace(inplace)
     model.set_compute_dtype(args.dtype, edit_ratio=args.ratio)  # (the f16 precision policy depends on the edited area)
+    if args.layout == "nhwc":
+        model.set_cache_dtype(args.cache_dtype)
     mfma_peak = PEAK_F16_MFMA_TFS if args.dtype in ("f16", "f16x3") else PEAK_F32_MFMA_TFS
     t = torch.zeros(1, device=dev)
 
@@ -989,7 +999,7 @@ def main():
             distribute = best[1]
             parallel.refresh_derived(model)
             # every rank now holds rank 0's cache: compare checksums
-            chk = flat.double().sum().reshape(1)
+            chk = torch.tensor([parallel.checksum(flat)], dtype=torch.int64, device=dev)
             lo, hi = chk.clone(), chk.clone()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
@@ -1495,7 +1505,7 @@ def main():
             "forward_ms_eager": round(e_ms, 3),
             "dense_forward_ms": round(dense_ms, 3),
             "speedup_vs_dense": round(dense_ms / ms_steady, 2),
-            "cache_bytes": int(flat.numel() * 4), "cached_tensors": n_cached,
+            "cache_bytes": int(flat.numel() * flat.element_size()), "cache_dtype": args.cache_dtype, "cached_tensors": n_cached,
             "sweep": sweep,
         }
         if world > 1:
@@ -1503,7 +1513,7 @@ def main():
             line["multi_gpu"] = dict(
                 dist_info, method=distribute, pipelined=not args.no_pipeline, chunks=None if args.no_pipeline else args.chunks,
                 rccl_ranks_seen=dist.get_world_size(),
-                wire_dtype=args.wire_dtype, wire_bytes=int(flat.numel() * (2 if wire is not None else 4)),
+                wire_dtype=args.wire_dtype, wire_bytes=int(flat.numel() * (2 if (wire is not None or flat.dtype == torch.float16) else 4)),
                 cache_distribution_ms=round(dist_s * 1e3, 3),
                 recompute_full_pass_ms=recompute_ms,
                 value_cache_distribution_inside_job=round(world * args.steps / dt, 2),

@@ -609,6 +609,69 @@ int sige_hip_wide_conv_nhwc(const float *x, const float *x2, int B, int C1, int 
 int sige_hip_affine_act_nhwc_f32(const float *x, int B, int C, int H, int W, const float *scale, const float *shift,
                                  int affineB, int activation, float *out, void *stream);
 
+/* ---- fp16-STORED caches: the "_f16" forms of SURVEY.md 8b's export list (8f row 4: fp16 cache) ---------------------
+ * The reference is fp32-only (sige/nn/base.py:15,55-63).  Here the CACHED tensors of a SIGE model -- Scatter /
+ * ScatterGather `original_outputs`, ScatterWithBlockResidual `original_outputs` / `original_residuals`, and the activated
+ * copy of a ScatterGather cache -- may be stored as fp16 (SIGEModel.set_cache_dtype("f16"): half the resident bytes,
+ * half the bytes of the cache broadcast, no conversion pass on either side of the wire).  Activations, tiles, affines and
+ * outputs stay fp32; a cached value is widened exactly when it is read.  Channels-last only.  Arguments as in the
+ * "_f32" entry points of the same name, with the cached tensor(s) `const void *` = halves:
+ *   gather_nhwc_f16                       x is the fp16 tensor (tiles of a cache)
+ *   scatter_gather_nhwc_f16               y
+ *   scatter_nhwc_f16                      y          (residual fp32)
+ *   scatter_with_block_residual_nhwc_f16  y0 and y1
+ *   affine_act_nhwc_f16                   x; out fp16 (out_f16 != 0: the activated copy) or fp32 (a persistent twin)
+ *   convert_f16_f32 / convert_f32_f16     n elements, n % 4 == 0 (persistent-output refresh / storing a full-pass output)
+ *   scatter_gather_conv_nhwc_c16, scatter_gather_conv_scatter_nhwc_c16
+ *                                         the fused scatter_gather -> conv (-> scatter) launches with `y` fp16 and, in the
+ *                                         second, `residual` fp16 when residual_f16 != 0 (a fused ScatterWithBlockResidual's
+ *                                         cached shortcut); `compute`: 0 exact fp32 | 1 fp16 operands | 2 split fp16
+ *                                         operands = the packing of `packed`.  3x3 / stride 1 only.                   */
+int sige_hip_gather_nhwc_f16(const void *x, int B, int C, int H, int W, int bH, int bW,
+                             const int32_t *active_indices, int N,
+                             const float *scale, int scaleB, int scaleC,
+                             const float *shift, int shiftB, int shiftC,
+                             int activation, float *out, void *stream);
+int sige_hip_scatter_gather_nhwc_f16(const float *x, const void *y, int B, int C, int H, int W,
+                                     int Rx, int Sx, int bH, int bW,
+                                     const int32_t *active_indices, int N, const int32_t *scatter_map,
+                                     const float *scale, int scaleB, int scaleC,
+                                     const float *shift, int shiftB, int shiftC,
+                                     int activation, float *out, void *stream);
+int sige_hip_scatter_nhwc_f16(const float *x, const void *y, int B, int C, int H, int W, int R, int S,
+                              int offsetH, int offsetW, int strideH, int strideW,
+                              const int32_t *active_indices, const int32_t *table, int gH, int gW, int N,
+                              const float *residual, int in_place, float *out, void *stream);
+int sige_hip_scatter_with_block_residual_nhwc_f16(
+        const float *x0, const void *y0, const float *x1, const void *y1,
+        int B, int C, int H, int W, int R0, int S0, int R1, int S1,
+        int offsetH, int offsetW, int strideH, int strideW,
+        const int32_t *active_indices0, const int32_t *table0, int gH0, int gW0, int N0,
+        const int32_t *active_indices1, const int32_t *table1, int gH1, int gW1, int N1,
+        int in_place, float *out, void *stream);
+int sige_hip_affine_act_nhwc_f16(const void *x, int B, int C, int H, int W, const float *scale, const float *shift,
+                                 int affineB, int activation, void *out, int out_f16, void *stream);
+int sige_hip_convert_f16_f32(const void *src, float *dst, size_t n, void *stream);
+int sige_hip_convert_f32_f16(const float *src, void *dst, size_t n, void *stream);
+int sige_hip_scatter_gather_conv_nhwc_c16(int compute, const float *x, const void *y, int B, int Cin, int H, int W,
+                                          int Rx, int Sx, int bH, int bW,
+                                          const int32_t *active_indices, int N, const int32_t *scatter_map,
+                                          const float *scale, int scaleB, int scaleC,
+                                          const float *shift, int shiftB, int shiftC,
+                                          int activation,
+                                          const float *packed, const float *bias, int Cout, int kH, int kW,
+                                          int strideH, int strideW, float *out, void *stream);
+int sige_hip_scatter_gather_conv_scatter_nhwc_c16(
+        int compute, const float *x, const void *y, int B, int Cin, int H, int W, int Rx, int Sx, int bH, int bW,
+        const int32_t *active_indices, int N, const int32_t *scatter_map,
+        const float *scale, int scaleB, int scaleC, const float *shift, int shiftB, int shiftC, int activation,
+        const float *packed, const float *bias, int Cout, int kH, int kW,
+        int offsetH, int offsetW, const void *residual, int residual_f16,
+        const float *x1, const int32_t *table1, int gH1, int gW1, int N1, int R1, int S1,
+        float *twin0, const float *twin0_scale, const float *twin0_shift,
+        float *twin1, const float *twin1_scale, const float *twin1_shift,
+        float *out, void *stream);
+
 /* ---- launch plans: a sparse forward that survives a mask change -------------------------------------------------
  * The reference sizes every launch from `activeIndices.size(0)` at call time (sige/cuda/gather_kernel.cu:78-84,111 via
  * sige/utils.py:30 and sige/nn/gather.py:101-107), and two of its three applications run ONE sparse forward per mask

@@ -219,6 +219,14 @@ SIGE_CONV_DECLARE(X31_16, 1, LAYOUT_NHWC, 4) SIGE_CONV_DECLARE(X31_32, 1, LAYOUT
 SIGE_CONV_DECLARE(X11_16, 1, LAYOUT_NHWC, 4) SIGE_CONV_DECLARE(X11_32, 1, LAYOUT_NHWC, 4)
 SIGE_CONV_DECLARE_SG_FULL(X31_16, 1, 4) SIGE_CONV_DECLARE_SG_FULL(X31_32, 1, 4)
 
+// scatter_gather source with an fp16-stored cache (conv_k3s1_nhwc*_c16.hip)
+#define SIGE_CONV_DECLARE_C16(G, NB)                                                        \
+    template <> void launch_conv_c16<G, NB, DST_TILES>(ConvArgs, int, hipStream_t);         \
+    template <> void launch_conv_c16<G, NB, DST_NCHW>(ConvArgs, int, hipStream_t);
+SIGE_CONV_DECLARE_C16(K31_16, 1) SIGE_CONV_DECLARE_C16(K31_16, 2) SIGE_CONV_DECLARE_C16(K31_32, 1) SIGE_CONV_DECLARE_C16(K31_32, 2)
+SIGE_CONV_DECLARE_C16(H31_16, 1) SIGE_CONV_DECLARE_C16(H31_16, 2) SIGE_CONV_DECLARE_C16(H31_32, 1) SIGE_CONV_DECLARE_C16(H31_32, 2)
+SIGE_CONV_DECLARE_C16(X31_16, 1) SIGE_CONV_DECLARE_C16(X31_32, 1)
+
 // ---- cross-workgroup K split: deterministic second pass ------------------------
 // out[i] = sum_s ws[s][i] + bias[channel(i)] + residual[i]   (channels-last: channel = i mod C)
 __global__ __launch_bounds__(256) void splitk_reduce_nhwc_kernel(const float *__restrict__ ws, int S, size_t stride, size_t n4, int C,
@@ -584,6 +592,22 @@ static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
                 if (rc != SIGE_HIP_OK) return rc;
             }
         }
+    }
+    if constexpr (SRC == SRC_SCATTER_GATHER && LAY == LAYOUT_NHWC && KH == 3 && STR == 1) {
+        if (!done && a.y_f16) {  // the cached tensor is stored as fp16: the Y16 form of the kernel (4 waves)
+            if (waves != 4) return SIGE_HIP_EUNSUPPORTED;
+            if constexpr (kHasNB2) {
+                if (mt == 32 && nb == 2) { launch_conv_c16<G32, 2, DST>(a, mode, st); done = true; }
+                else if (nb == 2) { launch_conv_c16<G16, 2, DST>(a, mode, st); done = true; }
+            }
+            if (!done) {
+                if (mt == 32) launch_conv_c16<G32, 1, DST>(a, mode, st);
+                else launch_conv_c16<G16, 1, DST>(a, mode, st);
+                done = true;
+            }
+        }
+    } else {
+        if (a.y_f16) return SIGE_HIP_EUNSUPPORTED;
     }
     constexpr bool kHasW8 = LAY == LAYOUT_NHWC && STR == 1 && PREC == 0;
     if constexpr (kHasW8) {
@@ -1061,14 +1085,16 @@ static int scatter_gather_conv_nhwc_impl(const float *x, const float *y, int B, 
                                                      const float *shift, int shiftB, int shiftC,
                                                      int activation,
                                                      const float *packed, const float *bias, int Cout, int kH, int kW,
-                                                     int strideH, int strideW, float *out, void *stream) {
+                                                     int strideH, int strideW, float *out, void *stream, int y_f16 = 0) {
     if (B < 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || N < 0 || Rx <= 0 || Sx <= 0) return SIGE_HIP_EINVAL;
     if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
     if ((long)B * Cin * H * W >= (1L << 29) || (long)B * N * Cin * Rx * Sx >= (1L << 29)) return SIGE_HIP_EUNSUPPORTED;
     if ((long)B * N == 0) return SIGE_HIP_OK;
     if (!x || !y || !packed || !out || !active_indices || !scatter_map) return SIGE_HIP_EINVAL;
     if (!nhwc_ok(Cin, Cin, Cout, x, y, out, bias) || (reinterpret_cast<uintptr_t>(packed) & 15)) return SIGE_HIP_EUNSUPPORTED;
+    if (y_f16 && (kH != 3 || kW != 3 || strideH != 1 || strideW != 1)) return SIGE_HIP_EUNSUPPORTED;
     ConvArgs a{};
+    a.y_f16 = y_f16 ? 1 : 0;
     a.x = x; a.y = y; a.idx = active_indices; a.map = scatter_map; a.packed = packed; a.bias = bias; a.out = out;
     a.T = B * N; a.Cin = Cin; a.Cout = Cout; a.B = B; a.N = N; a.H = H; a.W = W;
     a.RxSx = Rx * Sx; a.Sx = Sx;
@@ -1126,7 +1152,7 @@ static int scatter_gather_conv_scatter_nhwc_impl(
         const float *x1, const int32_t *table1, int gH1, int gW1, int N1, int R1, int S1,
         float *twin0, const float *twin0_scale, const float *twin0_shift,
         float *twin1, const float *twin1_scale, const float *twin1_shift,
-        float *out, void *stream) {
+        float *out, void *stream, int y_f16 = 0, int res_f16 = 0) {
     if (B < 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || N < 0 || Rx <= 0 || Sx <= 0) return SIGE_HIP_EINVAL;
     if (kH != 3 || kW != 3 || bH != 6 || bW != 6) return SIGE_HIP_EUNSUPPORTED;  // the stride-1 3x3 geometry of a ResBlock's conv2
     if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
@@ -1137,7 +1163,9 @@ static int scatter_gather_conv_scatter_nhwc_impl(
     if (!nhwc_ok(Cin, Cin, Cout, x, y, out, bias) || (reinterpret_cast<uintptr_t>(packed) & 15) ||
         (reinterpret_cast<uintptr_t>(residual) & 15) || (reinterpret_cast<uintptr_t>(x1) & 15))
         return SIGE_HIP_EUNSUPPORTED;
+    if (res_f16 && !residual) return SIGE_HIP_EINVAL;
     ConvArgs a{};
+    a.y_f16 = y_f16 ? 1 : 0; a.res_f16 = res_f16 ? 1 : 0;
     a.x = x; a.y = y; a.idx = active_indices; a.map = scatter_map; a.packed = packed; a.bias = bias; a.out = out;
     a.T = B * N; a.Cin = Cin; a.Cout = Cout; a.B = B; a.N = N; a.H = H; a.W = W;
     a.RxSx = Rx * Sx; a.Sx = Sx;
@@ -1197,6 +1225,48 @@ extern "C" int sige_hip_scatter_gather_conv_scatter_nhwc_f16x3(
         float *out, void *stream) {
     SIGE_PLAN_HOOK_N(sige_hip_scatter_gather_conv_scatter_nhwc_f16x3, (sige::CountOf<10, 11>, sige::CountOf<29, 32>), x, y, B, Cin, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, packed, bias, Cout, kH, kW, offsetH, offsetW, residual, x1, table1, gH1, gW1, N1, R1, S1, twin0, twin0_scale, twin0_shift, twin1, twin1_scale, twin1_shift, out, stream);
     return scatter_gather_conv_scatter_nhwc_impl<2>(SIGE_SGS_CONV_ARGS);
+}
+
+// ---- the same two fused launches over fp16-STORED caches (SURVEY.md 8b export list "_f16", 8f row 4) ----
+// `y` (the cached tensor of the ScatterGather, or its activated copy) and -- for a fused ScatterWithBlockResidual (x1 != NULL) --
+// `residual` (the cached shortcut tensor) hold halves; everything else as in the fp32-storage entry points.  `compute`: 0 exact
+// fp32 products | 1 fp16 operands | 2 split fp16 operands (which packing `packed` has).
+extern "C" int sige_hip_scatter_gather_conv_nhwc_c16(int compute, const float *x, const void *y, int B, int Cin, int H, int W,
+                                                     int Rx, int Sx, int bH, int bW,
+                                                     const int32_t *active_indices, int N, const int32_t *scatter_map,
+                                                     const float *scale, int scaleB, int scaleC,
+                                                     const float *shift, int shiftB, int shiftC,
+                                                     int activation,
+                                                     const float *packed, const float *bias, int Cout, int kH, int kW,
+                                                     int strideH, int strideW, float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_scatter_gather_conv_nhwc_c16, (sige::CountOf<11, 12>), compute, x, y, B, Cin, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, packed, bias, Cout, kH, kW, strideH, strideW, out, stream);
+    const float *yh = static_cast<const float *>(y);  // (halves behind a float pointer: ConvArgs::y_f16)
+    if (compute == 0) return scatter_gather_conv_nhwc_impl<0>(x, yh, B, Cin, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, packed, bias, Cout, kH, kW, strideH, strideW, out, stream, 1);
+    if (compute == 1) return scatter_gather_conv_nhwc_impl<1>(x, yh, B, Cin, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, packed, bias, Cout, kH, kW, strideH, strideW, out, stream, 1);
+    if (compute == 2) return scatter_gather_conv_nhwc_impl<2>(x, yh, B, Cin, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, packed, bias, Cout, kH, kW, strideH, strideW, out, stream, 1);
+    return SIGE_HIP_EINVAL;
+}
+
+extern "C" int sige_hip_scatter_gather_conv_scatter_nhwc_c16(
+        int compute, const float *x, const void *y, int B, int Cin, int H, int W, int Rx, int Sx, int bH, int bW,
+        const int32_t *active_indices, int N, const int32_t *scatter_map,
+        const float *scale, int scaleB, int scaleC, const float *shift, int shiftB, int shiftC, int activation,
+        const float *packed, const float *bias, int Cout, int kH, int kW,
+        int offsetH, int offsetW, const void *residual, int residual_f16,
+        const float *x1, const int32_t *table1, int gH1, int gW1, int N1, int R1, int S1,
+        float *twin0, const float *twin0_scale, const float *twin0_shift,
+        float *twin1, const float *twin1_scale, const float *twin1_shift,
+        float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_scatter_gather_conv_scatter_nhwc_c16, (sige::CountOf<11, 12>, sige::CountOf<31, 34>), compute, x, y, B, Cin, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, packed, bias, Cout, kH, kW, offsetH, offsetW, residual, residual_f16, x1, table1, gH1, gW1, N1, R1, S1, twin0, twin0_scale, twin0_shift, twin1, twin1_scale, twin1_shift, out, stream);
+    const float *yh = static_cast<const float *>(y), *rh = static_cast<const float *>(residual);
+#define SIGE_SGS_C16_ARGS x, yh, B, Cin, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB, \
+    shiftC, activation, packed, bias, Cout, kH, kW, offsetH, offsetW, rh, x1, table1, gH1, gW1, N1, R1, S1, twin0, twin0_scale, twin0_shift, twin1, \
+    twin1_scale, twin1_shift, out, stream, 1, residual_f16
+    if (compute == 0) return scatter_gather_conv_scatter_nhwc_impl<0>(SIGE_SGS_C16_ARGS);
+    if (compute == 1) return scatter_gather_conv_scatter_nhwc_impl<1>(SIGE_SGS_C16_ARGS);
+    if (compute == 2) return scatter_gather_conv_scatter_nhwc_impl<2>(SIGE_SGS_C16_ARGS);
+#undef SIGE_SGS_C16_ARGS
+    return SIGE_HIP_EINVAL;
 }
 
 extern "C" int sige_hip_block_conv_direct_f32(const float *x, int T, int Cin, int R, int S,

@@ -1,0 +1,9 @@
+// 3x3 stride-1 tiles (6x6 in), channels-last, split fp16 operands, scatter_gather source whose cached tensor is stored as fp16
+// (the "_c16" entry points): explicit instantiations.
+#include "conv_mfma.hpp"
+namespace sige {
+using G16 = ConvGeoX<3, 1, 6, 16>;
+using G32 = ConvGeoX<3, 1, 6, 32>;
+SIGE_CONV_INSTANTIATE_C16(G16, 1)
+SIGE_CONV_INSTANTIATE_C16(G32, 1)
+}  // namespace sige

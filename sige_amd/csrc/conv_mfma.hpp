@@ -204,6 +204,10 @@ struct ConvArgs {
     const float *tscale0, *tshift0, *tscale1, *tshift1;
     // split fp16 operands (ConvGeoX): the packed weights are w * 2^S; *wscale_ptr = 2^-S (written by the pack kernels)
     const float *wscale_ptr;
+    // fp16-stored caches (the "_c16" entry points): `y` (SCATTER_GATHER: the cached tensor, or its
+    // activated copy) holds halves -- a compile-time form of the kernel (Y16), this field picks it on the host; `residual`
+    // holds halves (the cached shortcut tensor of a fused ScatterWithBlockResidual) -- a run-time branch of the epilogue
+    int y_f16, res_f16;
 #ifdef SIGE_CONV_PROBE
     unsigned long long *probe;  // tools/conv_phase_probe.py build only: 8 timestamps per workgroup
 #endif
@@ -274,6 +278,26 @@ __device__ __forceinline__ float4 buf_f32x4(rsrc_t r, unsigned byte_off, int sof
     return make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// fp16 storage: a window over a tensor of halves, and 4 consecutive halves widened to fp32 (exact)
+__device__ __forceinline__ rsrc_t make_rsrc_h(const float *base_as_halves, long elem_off, long total_elems) {
+    const int off = __builtin_amdgcn_readfirstlane((int)elem_off);
+    int bytes = __builtin_amdgcn_readfirstlane((int)((total_elems - elem_off) * 2));
+    bytes = bytes < 0 ? 0 : bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<_Float16 *>(const_cast<float *>(base_as_halves)) + off, 0, bytes, 0x00020000);
+}
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 buf_h4(rsrc_t r, unsigned byte_off, int soff) {
+    const f16x4 h = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, soff, 0));
+    return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
+__device__ __forceinline__ float4 ld_f32x4_or_h4(const float *base, size_t elem, bool halves) {
+    if (halves) {
+        const f16x4 h = *reinterpret_cast<const f16x4 *>(reinterpret_cast<const _Float16 *>(base) + elem);
+        return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    }
+    return *reinterpret_cast<const float4 *>(base + elem);
+}
+
 // Memory layout of every activation / tile tensor a launch touches:
 //   NCHW  [B,C,H,W] / tiles [T,C,R,S]            -- the reference's layout (torch contiguous)
 //   NHWC  [B,H,W,C] / tiles [T,R,S,C]            -- torch channels_last
@@ -321,8 +345,10 @@ __host__ __device__ constexpr int conv_lds_floats() {
 }
 
 // The whole launch of one workgroup (bx, by) = what blockIdx would be in a launch of its own.
-template <typename G, int NB, int SRC, int MODE, int DST, int LAYOUT, int W>
+template <typename G, int NB, int SRC, int MODE, int DST, int LAYOUT, int W, bool Y16 = false>
 __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, const int by, float *const smem) {
+    static_assert(!Y16 || (SRC == SRC_SCATTER_GATHER && LAYOUT == LAYOUT_NHWC), "fp16-stored cache: the channels-last scatter_gather source");
+    constexpr unsigned YB = Y16 ? 2u : 4u;       // bytes per element of the cached tensor `y`
     constexpr bool F16 = G::F16;                 // fp16 operands in LDS / registers (ConvGeoH)
     using M = std::conditional_t<F16, MfmaH<G::MT>, Mfma<G::MT>>;
     static_assert(!F16 || LAYOUT == LAYOUT_NHWC, "the f16-compute kernels are channels-last");
@@ -554,7 +580,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
                 const bool in = z_live[i];
                 const unsigned off = (in && blk >= 0)
                     ? (unsigned)(((b * a.N + blk) * a.RxSx + z_m1[i] * a.Sx + z_m2[i]) * Cin + c_l) * 4u : kOOB;
-                const unsigned off2 = (in && blk < 0) ? (unsigned)((b * HW + z_hw[i]) * Cin + c_l) * 4u : kOOB;
+                const unsigned off2 = (in && blk < 0) ? (unsigned)((b * HW + z_hw[i]) * Cin + c_l) * YB : kOOB;
                 s_off[i] = off;
                 s_off2[i] = off2;
                 if (AFF) s_tab[i] = in ? c_l : CCk;
@@ -574,7 +600,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
                 e_h[k] = h; e_w[k] = w; e_in[k] = in;
                 e_q[k] = in ? (((size_t)b * a.Ho + h) * a.Wo + w) * a.Cout + co : 0;  // (dead units: a valid address, never stored)
                 e_res[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e_first_pass && a.residual) e_res[k] = *reinterpret_cast<const float4 *>(a.residual + e_q[k]);
+                if (e_first_pass && a.residual) e_res[k] = ld_f32x4_or_h4(a.residual, e_q[k], a.res_f16 != 0);
             });
         }
     } else {
@@ -660,7 +686,8 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
             else r_a = make_rsrc(a.x2, (c0 - a.Csplit) * cstep, (long)(Cin - a.Csplit) * HW);
         } else {
             r_a = make_rsrc(a.x, (long)c0 * (NHWC ? 1 : a.RxSx), (long)a.B * a.N * Cin * a.RxSx);
-            r_a2 = make_rsrc(a.y, c0 * cstep, (long)a.B * Cin * HW);
+            if constexpr (Y16) r_a2 = make_rsrc_h(a.y, c0 * cstep, (long)a.B * Cin * HW);
+            else r_a2 = make_rsrc(a.y, c0 * cstep, (long)a.B * Cin * HW);
         }
     };
     // float4 units: a partial last chunk must not read past the source's channels
@@ -681,7 +708,8 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
             st_q[set][i] = buf_f32x4(r_a, vec_off(o, i, chunk, use2 ? Cin - a.Csplit : a.Csplit, use2 ? a.Csplit : 0), 0);
         } else {
             st_q[set][i] = buf_f32x4(r_a, vec_off(s_off[i], i, chunk, Cin, 0), 0);
-            st_q2[set][i] = buf_f32x4(r_a2, vec_off(s_off2[i], i, chunk, Cin, 0), 0);
+            if constexpr (Y16) st_q2[set][i] = buf_h4(r_a2, vec_off(s_off2[i], i, chunk, Cin, 0), 0);
+            else st_q2[set][i] = buf_f32x4(r_a2, vec_off(s_off2[i], i, chunk, Cin, 0), 0);
         }
     };
     // finish slot i (affine + activation) and write it to LDS stage `buf`; `tb` = this chunk's table.
@@ -945,7 +973,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
                 u.w = (a.offW + a.idx[2 * n + 1]) / a.strW + pxo % G::RO;
                 u.ok = u.h >= 0 && u.h < a.Ho && u.w >= 0 && u.w < a.Wo;
                 u.addr = u.ok ? (((size_t)u.b * a.Ho + u.h) * a.Wo + u.w) * a.Cout + u.co : 0;
-                if (u.ok && a.residual && want_res) u.rr = *reinterpret_cast<const float4 *>(a.residual + u.addr);
+                if (u.ok && a.residual && want_res) u.rr = ld_f32x4_or_h4(a.residual, u.addr, a.res_f16 != 0);
             }
             return u;
         };
@@ -1111,10 +1139,10 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
 // ---- launch ------------------------------------------------------------------
 inline int conv_grid_x(const ConvArgs &a) { return a.ng_fast == 2 ? 8 * ((a.mbk + 7) / 8) * a.ngk : a.mbk * a.ngk; }
 
-template <typename G, int NB, int SRC, int MODE, int DST, int LAYOUT = LAYOUT_NCHW, int W = 4>
+template <typename G, int NB, int SRC, int MODE, int DST, int LAYOUT = LAYOUT_NCHW, int W = 4, bool Y16 = false>
 __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[conv_lds_floats<G, NB, MODE, LAYOUT, W>()];
-    conv_mfma_body<G, NB, SRC, MODE, DST, LAYOUT, W>(a, blockIdx.x, blockIdx.y, smem);
+    conv_mfma_body<G, NB, SRC, MODE, DST, LAYOUT, W, Y16>(a, blockIdx.x, blockIdx.y, smem);
 }
 
 // Two independent convs of a residual block in ONE launch (horizontal fusion): workgroups [0, na) run conv A
@@ -1166,6 +1194,18 @@ void launch_conv_geo(ConvArgs a, int mode, hipStream_t st);
     SIGE_CONV_LAUNCH3(G, NB, SRC_GATHER, DST_TILES, LAY, W)                                               \
     SIGE_CONV_LAUNCH3(G, NB, SRC_GATHER, DST_NCHW, LAY, W)                                                \
     SIGE_CONV_LAUNCH3(G, NB, SRC_SCATTER_GATHER, DST_TILES, LAY, W)
+
+// scatter_gather source whose cached tensor `y` is stored as fp16 (channels-last, 4 waves): tiles or full-tensor destination
+template <typename G, int NB, int DST>
+void launch_conv_c16(ConvArgs a, int mode, hipStream_t st);
+#define SIGE_CONV_INSTANTIATE_C16_DST(G, NB, DST)                                                         \
+    template <> void launch_conv_c16<G, NB, DST>(ConvArgs a, int mode, hipStream_t st) {                  \
+        const dim3 grid(conv_grid_x(a), a.ksplit);                                                        \
+        if (mode == MODE_AFFINE_SWISH) conv_mfma_kernel<G, NB, SRC_SCATTER_GATHER, MODE_AFFINE_SWISH, DST, LAYOUT_NHWC, 4, true><<<grid, 256, 0, st>>>(a); \
+        else if (mode == MODE_AFFINE) conv_mfma_kernel<G, NB, SRC_SCATTER_GATHER, MODE_AFFINE, DST, LAYOUT_NHWC, 4, true><<<grid, 256, 0, st>>>(a);        \
+        else conv_mfma_kernel<G, NB, SRC_SCATTER_GATHER, MODE_RAW, DST, LAYOUT_NHWC, 4, true><<<grid, 256, 0, st>>>(a);             \
+    }
+#define SIGE_CONV_INSTANTIATE_C16(G, NB) SIGE_CONV_INSTANTIATE_C16_DST(G, NB, DST_TILES) SIGE_CONV_INSTANTIATE_C16_DST(G, NB, DST_NCHW)
 
 // scatter_gather source written straight into a full tensor (conv2 -> Scatter fused): channels-last 3x3 only
 #define SIGE_CONV_INSTANTIATE_SG_FULL(G, NB, LAY, W) SIGE_CONV_LAUNCH3(G, NB, SRC_SCATTER_GATHER, DST_NCHW, LAY, W)

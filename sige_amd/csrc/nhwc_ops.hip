@@ -16,6 +16,17 @@ constexpr int kT = 256;
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+// fp16 storage (the resident cache of the "_f16" entry points: SURVEY.md 8b / 8f row 4): 4 consecutive halves = one 8-byte
+// load, widened exactly; stores round to nearest even
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4(const _Float16 *p) {
+    const h16x4 h = *reinterpret_cast<const h16x4 *>(p);
+    return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
+__device__ __forceinline__ void st4(_Float16 *p, float4 v) {
+    const h16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    *reinterpret_cast<h16x4 *>(p) = h;
+}
 
 // per-(batch, channel) affine then activation on 4 consecutive channels; scale, then shift:
 // two separately rounded ops (gather.cpp:33-53; -ffp-contract=off); SiLU as in common.hpp (~3e-7 relative)
@@ -29,8 +40,8 @@ __device__ __forceinline__ float4 affine_act4(float4 z, const float *scale, cons
 
 // ------------------------------------------------------------------ gather ----
 // x [B,H,W,C] -> out [B*N, bH, bW, C]; scale/shift [1|B, C]
-template <int ACT>
-__global__ __launch_bounds__(kT) void gather_nhwc_kernel(const float *__restrict__ x, int B, int C, int H, int W, int bH, int bW,
+template <int ACT, typename XT = float>
+__global__ __launch_bounds__(kT) void gather_nhwc_kernel(const XT *__restrict__ x, int B, int C, int H, int W, int bH, int bW,
                                                         const int32_t *__restrict__ idx, int N,
                                                         const float *scale, const float *shift, int aff_sb,
                                                         float *__restrict__ out, long units) {
@@ -51,8 +62,8 @@ __global__ __launch_bounds__(kT) void gather_nhwc_kernel(const float *__restrict
 
 // ---------------------------------------------------------- scatter_gather ----
 // x [B*N, Rx, Sx, C] conv-1 tiles, y [B,H,W,C] cached, map [H,W,3] -> out [B*N, bH, bW, C]
-template <int ACT>
-__global__ __launch_bounds__(kT) void scatter_gather_nhwc_kernel(const float *__restrict__ x, const float *__restrict__ y,
+template <int ACT, typename CT = float>
+__global__ __launch_bounds__(kT) void scatter_gather_nhwc_kernel(const float *__restrict__ x, const CT *__restrict__ y,
                                                                 int B, int C, int H, int W, int Rx, int Sx, int bH, int bW,
                                                                 const int32_t *__restrict__ idx, int N,
                                                                 const int32_t *__restrict__ map,
@@ -70,9 +81,9 @@ __global__ __launch_bounds__(kT) void scatter_gather_nhwc_kernel(const float *__
         if (h >= 0 && h < H && w >= 0 && w < W) {
             const int32_t *m = map + 3 * ((size_t)h * W + w);
             const int blk = m[0];
-            const float *src = blk >= 0 ? x + ((((size_t)b * N + blk) * Rx + m[1]) * Sx + m[2]) * C + c
-                                        : y + (((size_t)b * H + h) * W + w) * C + c;
-            z = affine_act4<ACT>(ld4(src), scale, shift, b * aff_sb, c);
+            const float4 v = blk >= 0 ? ld4(x + ((((size_t)b * N + blk) * Rx + m[1]) * Sx + m[2]) * C + c)
+                                      : ld4(y + (((size_t)b * H + h) * W + w) * C + c);
+            z = affine_act4<ACT>(v, scale, shift, b * aff_sb, c);
         }
         st4(out + (size_t)u * 4, z);
     }
@@ -141,14 +152,17 @@ __global__ __launch_bounds__(kT) void spade_modulate_nhwc_kernel(SpadeArgs a, lo
 }
 
 // ------------------------------------------------------------------ scatter ----
-struct ScatterNhwcArgs {
-    const float *x0, *y0, *x1, *y1, *res;  // main tiles, cached tensor, shortcut tiles, cached shortcut tensor, residual
+template <typename CT>
+struct ScatterNhwcArgsT {
+    const float *x0, *x1, *res;  // main tiles, shortcut tiles, residual
+    const CT *y0, *y1;           // cached tensor, cached shortcut tensor (fp32, or fp16 storage: the "_f16" entry points)
     float *out;
     const int32_t *table0, *table1, *idx0, *idx1;
     int B, C, H, W;
     int R0, S0, N0, gW0, offH, offW, strH, strW;
     int R1, S1, N1, gW1;
 };
+using ScatterNhwcArgs = ScatterNhwcArgsT<float>;
 
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
@@ -156,8 +170,8 @@ __device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(
 // value of output pixel (b,h,w), channels c..c+3, given the tiles covering it (t0 / t1, -1 = none):
 //   out = y0;  main tile: out = x0 + residual (BLOCK_RES: residual = y1);  shortcut tile: out += x1 - y1
 // (scatter.cpp:4-39 then 41-68, same operation order)
-template <bool BLOCK_RES>
-__device__ __forceinline__ float4 scatter_value(const ScatterNhwcArgs &a, int b, int h, int w, int c, int t0, int t1, size_t q) {
+template <bool BLOCK_RES, typename CT>
+__device__ __forceinline__ float4 scatter_value(const ScatterNhwcArgsT<CT> &a, int b, int h, int w, int c, int t0, int t1, size_t q) {
     float4 v;
     float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (BLOCK_RES && (t0 >= 0 || t1 >= 0)) r1 = ld4(a.y1 + q);
@@ -174,8 +188,8 @@ __device__ __forceinline__ float4 scatter_value(const ScatterNhwcArgs &a, int b,
 }
 
 // reference semantics: a fresh full tensor, ONE streaming pass (no clone + overwrite)
-template <bool BLOCK_RES>
-__global__ __launch_bounds__(kT) void scatter_full_nhwc_kernel(ScatterNhwcArgs a, long units) {
+template <bool BLOCK_RES, typename CT = float>
+__global__ __launch_bounds__(kT) void scatter_full_nhwc_kernel(ScatterNhwcArgsT<CT> a, long units) {
     const int C4 = a.C / 4;
     for (long u = (long)blockIdx.x * kT + threadIdx.x; u < units; u += (long)gridDim.x * kT) {
         const int c = (int)(u % C4) * 4;
@@ -185,15 +199,15 @@ __global__ __launch_bounds__(kT) void scatter_full_nhwc_kernel(ScatterNhwcArgs a
         const int h = (int)(bh % a.H), b = (int)(bh / a.H);
         const int t0 = a.table0[(h / a.R0) * a.gW0 + w / a.S0];
         const int t1 = BLOCK_RES ? a.table1[(h / a.R1) * a.gW1 + w / a.S1] : -1;
-        st4(a.out + (size_t)u * 4, scatter_value<BLOCK_RES>(a, b, h, w, c, t0, t1, (size_t)u * 4));
+        st4(a.out + (size_t)u * 4, scatter_value<BLOCK_RES, CT>(a, b, h, w, c, t0, t1, (size_t)u * 4));
     }
 }
 
 // in-place form: `out` already holds y0 outside the covered pixels (a persistent buffer of the
 // Scatter module); only the pixels under a main tile -- and, BLOCK_RES, under a shortcut tile
 // that no main tile covers -- are written.  Traffic ~ active tiles instead of the full tensor.
-template <bool BLOCK_RES>
-__global__ __launch_bounds__(kT) void scatter_tiles_nhwc_kernel(ScatterNhwcArgs a, long units0, long units) {
+template <bool BLOCK_RES, typename CT = float>
+__global__ __launch_bounds__(kT) void scatter_tiles_nhwc_kernel(ScatterNhwcArgsT<CT> a, long units0, long units) {
     const int C4 = a.C / 4;
     for (long u = (long)blockIdx.x * kT + threadIdx.x; u < units; u += (long)gridDim.x * kT) {
         const bool main = u < units0;
@@ -212,7 +226,7 @@ __global__ __launch_bounds__(kT) void scatter_tiles_nhwc_kernel(ScatterNhwcArgs 
         if (main) { t0 = n; t1 = BLOCK_RES ? a.table1[(h / a.R1) * a.gW1 + w / a.S1] : -1; }
         else { t1 = n; t0 = a.table0[(h / a.R0) * a.gW0 + w / a.S0]; if (t0 >= 0) continue; }  // a main tile writes this pixel
         const size_t q = ((((size_t)b * a.H + h) * a.W + w) * a.C) + c;
-        st4(a.out + q, scatter_value<BLOCK_RES>(a, b, h, w, c, t0, t1, q));
+        st4(a.out + q, scatter_value<BLOCK_RES, CT>(a, b, h, w, c, t0, t1, q));
     }
 }
 
@@ -389,12 +403,12 @@ static bool affine_shape(const float *scale, int sB, int sC, const float *shift,
     return true;
 }
 
-extern "C" int sige_hip_gather_nhwc_f32(const float *x, int B, int C, int H, int W, int bH, int bW,
-                                        const int32_t *active_indices, int N,
-                                        const float *scale, int scaleB, int scaleC,
-                                        const float *shift, int shiftB, int shiftC,
-                                        int activation, float *out, void *stream) {
-    SIGE_PLAN_HOOK_N(sige_hip_gather_nhwc_f32, (sige::CountOf<7, 8>), x, B, C, H, W, bH, bW, active_indices, N, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, out, stream);
+template <typename XT>
+static int gather_nhwc_impl(const XT *x, int B, int C, int H, int W, int bH, int bW,
+                            const int32_t *active_indices, int N,
+                            const float *scale, int scaleB, int scaleC,
+                            const float *shift, int shiftB, int shiftC,
+                            int activation, float *out, void *stream) {
     if (B < 0 || C <= 0 || H <= 0 || W <= 0 || bH <= 0 || bW <= 0 || N < 0) return SIGE_HIP_EINVAL;
     if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
     if ((long)B * N == 0) return SIGE_HIP_OK;
@@ -405,19 +419,37 @@ extern "C" int sige_hip_gather_nhwc_f32(const float *x, int B, int C, int H, int
     const long units = (long)B * N * bH * bW * (C / 4);
     hipStream_t st = as_stream(stream);
     if (activation == SIGE_HIP_ACT_SWISH)
-        gather_nhwc_kernel<SIGE_HIP_ACT_SWISH><<<grid_for(units), kT, 0, st>>>(x, B, C, H, W, bH, bW, active_indices, N, scale, shift, aff_sb, out, units);
+        gather_nhwc_kernel<SIGE_HIP_ACT_SWISH, XT><<<grid_for(units), kT, 0, st>>>(x, B, C, H, W, bH, bW, active_indices, N, scale, shift, aff_sb, out, units);
     else
-        gather_nhwc_kernel<SIGE_HIP_ACT_IDENTITY><<<grid_for(units), kT, 0, st>>>(x, B, C, H, W, bH, bW, active_indices, N, scale, shift, aff_sb, out, units);
+        gather_nhwc_kernel<SIGE_HIP_ACT_IDENTITY, XT><<<grid_for(units), kT, 0, st>>>(x, B, C, H, W, bH, bW, active_indices, N, scale, shift, aff_sb, out, units);
     return launch_status();
 }
 
-extern "C" int sige_hip_scatter_gather_nhwc_f32(const float *x, const float *y, int B, int C, int H, int W,
-                                                int Rx, int Sx, int bH, int bW,
-                                                const int32_t *active_indices, int N, const int32_t *scatter_map,
-                                                const float *scale, int scaleB, int scaleC,
-                                                const float *shift, int shiftB, int shiftC,
-                                                int activation, float *out, void *stream) {
-    SIGE_PLAN_HOOK_N(sige_hip_scatter_gather_nhwc_f32, (sige::CountOf<10, 11>), x, y, B, C, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, out, stream);
+extern "C" int sige_hip_gather_nhwc_f32(const float *x, int B, int C, int H, int W, int bH, int bW,
+                                        const int32_t *active_indices, int N,
+                                        const float *scale, int scaleB, int scaleC,
+                                        const float *shift, int shiftB, int shiftC,
+                                        int activation, float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_gather_nhwc_f32, (sige::CountOf<7, 8>), x, B, C, H, W, bH, bW, active_indices, N, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, out, stream);
+    return gather_nhwc_impl<float>(x, B, C, H, W, bH, bW, active_indices, N, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, out, stream);
+}
+
+extern "C" int sige_hip_gather_nhwc_f16(const void *x, int B, int C, int H, int W, int bH, int bW,
+                                        const int32_t *active_indices, int N,
+                                        const float *scale, int scaleB, int scaleC,
+                                        const float *shift, int shiftB, int shiftC,
+                                        int activation, float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_gather_nhwc_f16, (sige::CountOf<7, 8>), x, B, C, H, W, bH, bW, active_indices, N, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, out, stream);
+    return gather_nhwc_impl<_Float16>(static_cast<const _Float16 *>(x), B, C, H, W, bH, bW, active_indices, N, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, out, stream);
+}
+
+template <typename CT>
+static int scatter_gather_nhwc_impl(const float *x, const CT *y, int B, int C, int H, int W,
+                                    int Rx, int Sx, int bH, int bW,
+                                    const int32_t *active_indices, int N, const int32_t *scatter_map,
+                                    const float *scale, int scaleB, int scaleC,
+                                    const float *shift, int shiftB, int shiftC,
+                                    int activation, float *out, void *stream) {
     if (B < 0 || C <= 0 || H <= 0 || W <= 0 || Rx <= 0 || Sx <= 0 || bH <= 0 || bW <= 0 || N < 0) return SIGE_HIP_EINVAL;
     if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
     if ((long)B * N == 0) return SIGE_HIP_OK;
@@ -428,10 +460,30 @@ extern "C" int sige_hip_scatter_gather_nhwc_f32(const float *x, const float *y, 
     const long units = (long)B * N * bH * bW * (C / 4);
     hipStream_t st = as_stream(stream);
     if (activation == SIGE_HIP_ACT_SWISH)
-        scatter_gather_nhwc_kernel<SIGE_HIP_ACT_SWISH><<<grid_for(units), kT, 0, st>>>(x, y, B, C, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, shift, aff_sb, out, units);
+        scatter_gather_nhwc_kernel<SIGE_HIP_ACT_SWISH, CT><<<grid_for(units), kT, 0, st>>>(x, y, B, C, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, shift, aff_sb, out, units);
     else
-        scatter_gather_nhwc_kernel<SIGE_HIP_ACT_IDENTITY><<<grid_for(units), kT, 0, st>>>(x, y, B, C, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, shift, aff_sb, out, units);
+        scatter_gather_nhwc_kernel<SIGE_HIP_ACT_IDENTITY, CT><<<grid_for(units), kT, 0, st>>>(x, y, B, C, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, shift, aff_sb, out, units);
     return launch_status();
+}
+
+extern "C" int sige_hip_scatter_gather_nhwc_f32(const float *x, const float *y, int B, int C, int H, int W,
+                                                int Rx, int Sx, int bH, int bW,
+                                                const int32_t *active_indices, int N, const int32_t *scatter_map,
+                                                const float *scale, int scaleB, int scaleC,
+                                                const float *shift, int shiftB, int shiftC,
+                                                int activation, float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_scatter_gather_nhwc_f32, (sige::CountOf<10, 11>), x, y, B, C, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, out, stream);
+    return scatter_gather_nhwc_impl<float>(x, y, B, C, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, out, stream);
+}
+
+extern "C" int sige_hip_scatter_gather_nhwc_f16(const float *x, const void *y, int B, int C, int H, int W,
+                                                int Rx, int Sx, int bH, int bW,
+                                                const int32_t *active_indices, int N, const int32_t *scatter_map,
+                                                const float *scale, int scaleB, int scaleC,
+                                                const float *shift, int shiftB, int shiftC,
+                                                int activation, float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_scatter_gather_nhwc_f16, (sige::CountOf<10, 11>), x, y, B, C, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, out, stream);
+    return scatter_gather_nhwc_impl<_Float16>(x, static_cast<const _Float16 *>(y), B, C, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, out, stream);
 }
 
 extern "C" int sige_hip_spade_modulate_nhwc_f32(
@@ -460,17 +512,17 @@ extern "C" int sige_hip_spade_modulate_nhwc_f32(
     return launch_status();
 }
 
-extern "C" int sige_hip_scatter_nhwc_f32(const float *x, const float *y, int B, int C, int H, int W, int R, int S,
-                                         int offsetH, int offsetW, int strideH, int strideW,
-                                         const int32_t *active_indices, const int32_t *table, int gH, int gW, int N,
-                                         const float *residual, int in_place, float *out, void *stream) {
-    SIGE_PLAN_HOOK_N(sige_hip_scatter_nhwc_f32, (sige::CountOf<12, 16>), x, y, B, C, H, W, R, S, offsetH, offsetW, strideH, strideW, active_indices, table, gH, gW, N, residual, in_place, out, stream);
+template <typename CT>
+static int scatter_nhwc_impl(const float *x, const CT *y, int B, int C, int H, int W, int R, int S,
+                             int offsetH, int offsetW, int strideH, int strideW,
+                             const int32_t *active_indices, const int32_t *table, int gH, int gW, int N,
+                             const float *residual, int in_place, float *out, void *stream) {
     if (B < 0 || C <= 0 || H <= 0 || W <= 0 || R <= 0 || S <= 0 || N < 0 || strideH <= 0 || strideW <= 0) return SIGE_HIP_EINVAL;
     if ((long)B * H * W == 0) return SIGE_HIP_OK;
     if (!y || !out || (N && (!x || !table || !active_indices))) return SIGE_HIP_EINVAL;
     if (C % 4 || !al16(x) || !al16(y) || !al16(out) || !al16(residual)) return SIGE_HIP_EUNSUPPORTED;
     if (gH < (H + R - 1) / R || gW < (W + S - 1) / S) return SIGE_HIP_EINVAL;
-    ScatterNhwcArgs a{};
+    ScatterNhwcArgsT<CT> a{};
     a.x0 = x; a.y0 = y; a.res = residual; a.out = out; a.table0 = table; a.idx0 = active_indices;
     a.B = B; a.C = C; a.H = H; a.W = W; a.R0 = R; a.S0 = S; a.N0 = N; a.gW0 = gW;
     a.offH = offsetH; a.offW = offsetW; a.strH = strideH; a.strW = strideW;
@@ -478,10 +530,58 @@ extern "C" int sige_hip_scatter_nhwc_f32(const float *x, const float *y, int B, 
     hipStream_t st = as_stream(stream);
     if (in_place) {
         const long units = (long)B * N * R * S * (C / 4);
-        if (units) scatter_tiles_nhwc_kernel<false><<<grid_for(units), kT, 0, st>>>(a, units, units);
+        if (units) scatter_tiles_nhwc_kernel<false, CT><<<grid_for(units), kT, 0, st>>>(a, units, units);
     } else {
         const long units = (long)B * H * W * (C / 4);
-        scatter_full_nhwc_kernel<false><<<grid_for(units), kT, 0, st>>>(a, units);
+        scatter_full_nhwc_kernel<false, CT><<<grid_for(units), kT, 0, st>>>(a, units);
+    }
+    return launch_status();
+}
+
+extern "C" int sige_hip_scatter_nhwc_f32(const float *x, const float *y, int B, int C, int H, int W, int R, int S,
+                                         int offsetH, int offsetW, int strideH, int strideW,
+                                         const int32_t *active_indices, const int32_t *table, int gH, int gW, int N,
+                                         const float *residual, int in_place, float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_scatter_nhwc_f32, (sige::CountOf<12, 16>), x, y, B, C, H, W, R, S, offsetH, offsetW, strideH, strideW, active_indices, table, gH, gW, N, residual, in_place, out, stream);
+    return scatter_nhwc_impl<float>(x, y, B, C, H, W, R, S, offsetH, offsetW, strideH, strideW, active_indices, table, gH, gW, N, residual, in_place, out, stream);
+}
+
+extern "C" int sige_hip_scatter_nhwc_f16(const float *x, const void *y, int B, int C, int H, int W, int R, int S,
+                                         int offsetH, int offsetW, int strideH, int strideW,
+                                         const int32_t *active_indices, const int32_t *table, int gH, int gW, int N,
+                                         const float *residual, int in_place, float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_scatter_nhwc_f16, (sige::CountOf<12, 16>), x, y, B, C, H, W, R, S, offsetH, offsetW, strideH, strideW, active_indices, table, gH, gW, N, residual, in_place, out, stream);
+    return scatter_nhwc_impl<_Float16>(x, static_cast<const _Float16 *>(y), B, C, H, W, R, S, offsetH, offsetW, strideH, strideW, active_indices, table, gH, gW, N, residual, in_place, out, stream);
+}
+
+template <typename CT>
+static int scatter_with_block_residual_nhwc_impl(
+        const float *x0, const CT *y0, const float *x1, const CT *y1,
+        int B, int C, int H, int W, int R0, int S0, int R1, int S1,
+        int offsetH, int offsetW, int strideH, int strideW,
+        const int32_t *active_indices0, const int32_t *table0, int gH0, int gW0, int N0,
+        const int32_t *active_indices1, const int32_t *table1, int gH1, int gW1, int N1,
+        int in_place, float *out, void *stream) {
+    if (B < 0 || C <= 0 || H <= 0 || W <= 0 || R0 <= 0 || S0 <= 0 || R1 <= 0 || S1 <= 0 || N0 < 0 || N1 < 0) return SIGE_HIP_EINVAL;
+    if (strideH <= 0 || strideW <= 0) return SIGE_HIP_EINVAL;
+    if ((long)B * H * W == 0) return SIGE_HIP_OK;
+    if (!y0 || !y1 || !out || !table0 || !table1 || (N0 && (!x0 || !active_indices0)) || (N1 && (!x1 || !active_indices1)))
+        return SIGE_HIP_EINVAL;
+    if (C % 4 || !al16(x0) || !al16(y0) || !al16(x1) || !al16(y1) || !al16(out)) return SIGE_HIP_EUNSUPPORTED;
+    if (gH0 < (H + R0 - 1) / R0 || gW0 < (W + S0 - 1) / S0 || gH1 < (H + R1 - 1) / R1 || gW1 < (W + S1 - 1) / S1) return SIGE_HIP_EINVAL;
+    ScatterNhwcArgsT<CT> a{};
+    a.x0 = x0; a.y0 = y0; a.x1 = x1; a.y1 = y1; a.out = out;
+    a.table0 = table0; a.table1 = table1; a.idx0 = active_indices0; a.idx1 = active_indices1;
+    a.B = B; a.C = C; a.H = H; a.W = W;
+    a.R0 = R0; a.S0 = S0; a.N0 = N0; a.gW0 = gW0; a.offH = offsetH; a.offW = offsetW; a.strH = strideH; a.strW = strideW;
+    a.R1 = R1; a.S1 = S1; a.N1 = N1; a.gW1 = gW1;
+    hipStream_t st = as_stream(stream);
+    if (in_place) {
+        const long units0 = (long)B * N0 * R0 * S0 * (C / 4), units = units0 + (long)B * N1 * R1 * S1 * (C / 4);
+        if (units) scatter_tiles_nhwc_kernel<true, CT><<<grid_for(units), kT, 0, st>>>(a, units0, units);
+    } else {
+        const long units = (long)B * H * W * (C / 4);
+        scatter_full_nhwc_kernel<true, CT><<<grid_for(units), kT, 0, st>>>(a, units);
     }
     return launch_status();
 }
@@ -494,36 +594,30 @@ extern "C" int sige_hip_scatter_with_block_residual_nhwc_f32(
         const int32_t *active_indices1, const int32_t *table1, int gH1, int gW1, int N1,
         int in_place, float *out, void *stream) {
     SIGE_PLAN_HOOK_N(sige_hip_scatter_with_block_residual_nhwc_f32, (sige::CountOf<16, 20>, sige::CountOf<21, 25>), x0, y0, x1, y1, B, C, H, W, R0, S0, R1, S1, offsetH, offsetW, strideH, strideW, active_indices0, table0, gH0, gW0, N0, active_indices1, table1, gH1, gW1, N1, in_place, out, stream);
-    if (B < 0 || C <= 0 || H <= 0 || W <= 0 || R0 <= 0 || S0 <= 0 || R1 <= 0 || S1 <= 0 || N0 < 0 || N1 < 0) return SIGE_HIP_EINVAL;
-    if (strideH <= 0 || strideW <= 0) return SIGE_HIP_EINVAL;
-    if ((long)B * H * W == 0) return SIGE_HIP_OK;
-    if (!y0 || !y1 || !out || !table0 || !table1 || (N0 && (!x0 || !active_indices0)) || (N1 && (!x1 || !active_indices1)))
-        return SIGE_HIP_EINVAL;
-    if (C % 4 || !al16(x0) || !al16(y0) || !al16(x1) || !al16(y1) || !al16(out)) return SIGE_HIP_EUNSUPPORTED;
-    if (gH0 < (H + R0 - 1) / R0 || gW0 < (W + S0 - 1) / S0 || gH1 < (H + R1 - 1) / R1 || gW1 < (W + S1 - 1) / S1) return SIGE_HIP_EINVAL;
-    ScatterNhwcArgs a{};
-    a.x0 = x0; a.y0 = y0; a.x1 = x1; a.y1 = y1; a.out = out;
-    a.table0 = table0; a.table1 = table1; a.idx0 = active_indices0; a.idx1 = active_indices1;
-    a.B = B; a.C = C; a.H = H; a.W = W;
-    a.R0 = R0; a.S0 = S0; a.N0 = N0; a.gW0 = gW0; a.offH = offsetH; a.offW = offsetW; a.strH = strideH; a.strW = strideW;
-    a.R1 = R1; a.S1 = S1; a.N1 = N1; a.gW1 = gW1;
-    hipStream_t st = as_stream(stream);
-    if (in_place) {
-        const long units0 = (long)B * N0 * R0 * S0 * (C / 4), units = units0 + (long)B * N1 * R1 * S1 * (C / 4);
-        if (units) scatter_tiles_nhwc_kernel<true><<<grid_for(units), kT, 0, st>>>(a, units0, units);
-    } else {
-        const long units = (long)B * H * W * (C / 4);
-        scatter_full_nhwc_kernel<true><<<grid_for(units), kT, 0, st>>>(a, units);
-    }
-    return launch_status();
+    return scatter_with_block_residual_nhwc_impl<float>(x0, y0, x1, y1, B, C, H, W, R0, S0, R1, S1, offsetH, offsetW, strideH, strideW,
+                                                        active_indices0, table0, gH0, gW0, N0, active_indices1, table1, gH1, gW1, N1, in_place, out, stream);
+}
+
+extern "C" int sige_hip_scatter_with_block_residual_nhwc_f16(
+        const float *x0, const void *y0, const float *x1, const void *y1,
+        int B, int C, int H, int W, int R0, int S0, int R1, int S1,
+        int offsetH, int offsetW, int strideH, int strideW,
+        const int32_t *active_indices0, const int32_t *table0, int gH0, int gW0, int N0,
+        const int32_t *active_indices1, const int32_t *table1, int gH1, int gW1, int N1,
+        int in_place, float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_scatter_with_block_residual_nhwc_f16, (sige::CountOf<16, 20>, sige::CountOf<21, 25>), x0, y0, x1, y1, B, C, H, W, R0, S0, R1, S1, offsetH, offsetW, strideH, strideW, active_indices0, table0, gH0, gW0, N0, active_indices1, table1, gH1, gW1, N1, in_place, out, stream);
+    return scatter_with_block_residual_nhwc_impl<_Float16>(x0, static_cast<const _Float16 *>(y0), x1, static_cast<const _Float16 *>(y1), B, C, H, W, R0, S0, R1, S1,
+                                                           offsetH, offsetW, strideH, strideW, active_indices0, table0, gH0, gW0, N0,
+                                                           active_indices1, table1, gH1, gW1, N1, in_place, out, stream);
 }
 
 // out = act(scale[b, c] * x + shift[b, c]) over a whole channels-last tensor: the activated copy of a ScatterGather cache
 // (sige_amd.nn.ScatterGather.cache_activated) in one streaming pass -- the full pass otherwise spends a multiply, an add, a
 // SiLU and a copy kernel on it.  Same two separately rounded ops and the same fp32 SiLU as the standalone gather.
-__global__ __launch_bounds__(kT) void affine_act_nhwc_kernel(const float *__restrict__ x, const float *__restrict__ scale,
+template <typename XT, typename OT>
+__global__ __launch_bounds__(kT) void affine_act_nhwc_kernel(const XT *__restrict__ x, const float *__restrict__ scale,
                                                             const float *__restrict__ shift, int aff_sb, int C, size_t hwc4,
-                                                            size_t total4, int act, float *__restrict__ out) {
+                                                            size_t total4, int act, OT *__restrict__ out) {
     for (size_t u = (size_t)blockIdx.x * kT + threadIdx.x; u < total4; u += (size_t)gridDim.x * kT) {
         const size_t b = u / hwc4;
         const int c = (int)((u * 4) % C);
@@ -536,16 +630,59 @@ __global__ __launch_bounds__(kT) void affine_act_nhwc_kernel(const float *__rest
     }
 }
 
-extern "C" int sige_hip_affine_act_nhwc_f32(const float *x, int B, int C, int H, int W, const float *scale, const float *shift,
-                                            int affineB, int activation, float *out, void *stream) {
-    SIGE_PLAN_HOOK(sige_hip_affine_act_nhwc_f32, x, B, C, H, W, scale, shift, affineB, activation, out, stream);
+template <typename XT, typename OT>
+static int affine_act_nhwc_impl(const XT *x, int B, int C, int H, int W, const float *scale, const float *shift,
+                                int affineB, int activation, OT *out, void *stream) {
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !x || !scale || !shift || !out) return SIGE_HIP_EINVAL;
     if (affineB != 1 && affineB != B) return SIGE_HIP_EINVAL;
     if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
     if (C % 4 || !al16(x) || !al16(out) || !al16(scale) || !al16(shift)) return SIGE_HIP_EUNSUPPORTED;
     const size_t hwc4 = (size_t)H * W * C / 4, total4 = hwc4 * B;
-    affine_act_nhwc_kernel<<<grid_for((long)total4), kT, 0, as_stream(stream)>>>(x, scale, shift, affineB > 1 ? C : 0, C, hwc4, total4,
-                                                                                activation, out);
+    affine_act_nhwc_kernel<XT, OT><<<grid_for((long)total4), kT, 0, as_stream(stream)>>>(x, scale, shift, affineB > 1 ? C : 0, C, hwc4, total4,
+                                                                                        activation, out);
+    return launch_status();
+}
+
+extern "C" int sige_hip_affine_act_nhwc_f32(const float *x, int B, int C, int H, int W, const float *scale, const float *shift,
+                                            int affineB, int activation, float *out, void *stream) {
+    SIGE_PLAN_HOOK(sige_hip_affine_act_nhwc_f32, x, B, C, H, W, scale, shift, affineB, activation, out, stream);
+    return affine_act_nhwc_impl<float, float>(x, B, C, H, W, scale, shift, affineB, activation, out, stream);
+}
+
+// ... of an fp16-stored cache: `x` fp16; `out` fp16 (out_f16 != 0: the activated copy kept next to an fp16 cache) or fp32 (a
+// persistent activated twin)
+extern "C" int sige_hip_affine_act_nhwc_f16(const void *x, int B, int C, int H, int W, const float *scale, const float *shift,
+                                            int affineB, int activation, void *out, int out_f16, void *stream) {
+    SIGE_PLAN_HOOK(sige_hip_affine_act_nhwc_f16, x, B, C, H, W, scale, shift, affineB, activation, out, out_f16, stream);
+    if (out_f16)
+        return affine_act_nhwc_impl<_Float16, _Float16>(static_cast<const _Float16 *>(x), B, C, H, W, scale, shift, affineB, activation,
+                                                        static_cast<_Float16 *>(out), stream);
+    return affine_act_nhwc_impl<_Float16, float>(static_cast<const _Float16 *>(x), B, C, H, W, scale, shift, affineB, activation,
+                                                 static_cast<float *>(out), stream);
+}
+
+// dst (fp32) <- src (fp16), n elements (n % 4 == 0, 8 / 16-byte aligned): the refresh of a persistent Scatter output from an
+// fp16-stored cache; dst (fp16) <- src (fp32): storing a full-pass output into the fp16 cache
+template <typename ST, typename DT>
+__global__ __launch_bounds__(kT) void convert4_kernel(const ST *__restrict__ src, DT *__restrict__ dst, size_t n4) {
+    for (size_t u = (size_t)blockIdx.x * kT + threadIdx.x; u < n4; u += (size_t)gridDim.x * kT) st4(dst + u * 4, ld4(src + u * 4));
+}
+
+extern "C" int sige_hip_convert_f16_f32(const void *src, float *dst, size_t n, void *stream) {
+    SIGE_PLAN_HOOK(sige_hip_convert_f16_f32, src, dst, n, stream);
+    if (!src || !dst) return SIGE_HIP_EINVAL;
+    if (n == 0) return SIGE_HIP_OK;
+    if (n % 4 || (reinterpret_cast<uintptr_t>(src) & 7) || !al16(dst)) return SIGE_HIP_EUNSUPPORTED;
+    convert4_kernel<_Float16, float><<<grid_for((long)(n / 4)), kT, 0, as_stream(stream)>>>(static_cast<const _Float16 *>(src), dst, n / 4);
+    return launch_status();
+}
+
+extern "C" int sige_hip_convert_f32_f16(const float *src, void *dst, size_t n, void *stream) {
+    SIGE_PLAN_HOOK(sige_hip_convert_f32_f16, src, dst, n, stream);
+    if (!src || !dst) return SIGE_HIP_EINVAL;
+    if (n == 0) return SIGE_HIP_OK;
+    if (n % 4 || (reinterpret_cast<uintptr_t>(dst) & 7) || !al16(src)) return SIGE_HIP_EUNSUPPORTED;
+    convert4_kernel<float, _Float16><<<grid_for((long)(n / 4)), kT, 0, as_stream(stream)>>>(src, static_cast<_Float16 *>(dst), n / 4);
     return launch_status();
 }
 

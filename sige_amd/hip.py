@@ -156,6 +156,24 @@ _SIGNATURES = {
     "sige_hip_channel_stats_nhwc_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp]),
     "sige_hip_group_norm_affine_from_stats_f32": (
         _c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_float] + [_c_vp] * 6),
+    # fp16-stored caches
+    "sige_hip_gather_nhwc_f16": (
+        _c_int, [_c_vp] + [_c_int] * 6 + [_c_vp, _c_int] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]),
+    "sige_hip_scatter_gather_nhwc_f16": (
+        _c_int, [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]),
+    "sige_hip_scatter_nhwc_f16": (
+        _c_int, [_c_vp, _c_vp] + [_c_int] * 10 + [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_int, _c_vp, _c_vp]),
+    "sige_hip_scatter_with_block_residual_nhwc_f16": (
+        _c_int, [_c_vp] * 4 + [_c_int] * 12 + [_c_vp, _c_vp, _c_int, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]),
+    "sige_hip_affine_act_nhwc_f16": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp, _c_int, _c_int, _c_vp, _c_int, _c_vp]),
+    "sige_hip_convert_f16_f32": (_c_int, [_c_vp, _c_vp, _c_sz, _c_vp]),
+    "sige_hip_convert_f32_f16": (_c_int, [_c_vp, _c_vp, _c_sz, _c_vp]),
+    "sige_hip_scatter_gather_conv_nhwc_c16": (
+        _c_int, [_c_int, _c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
+        + [_c_int] * 5 + [_c_vp, _c_vp]),
+    "sige_hip_scatter_gather_conv_scatter_nhwc_c16": (
+        _c_int, [_c_int, _c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
+        + [_c_int] * 3 + [_c_int, _c_int, _c_vp, _c_int] + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp] * 6 + [_c_vp, _c_vp]),
     # launch plans (csrc/plan.hip; host side: sige_amd/plan.py)
     "sige_hip_plan_create": (_c_vp, []),
     "sige_hip_plan_destroy": (_c_int, [_c_vp]),
@@ -652,6 +670,7 @@ def _conv_fn(name: str, packed):
 COMPUTE_DTYPES = ("f32", "f16", "f16x3")
 
 
+_COMPUTE_ID = {"f32": 0, "f16": 1, "f16x3": 2}  # the `compute` argument of the "_c16" entry points (tile kernels: how `packed` is laid out)
 _WIDE_PREC = {"f16": 0, "f16x3": 1, "f32": 2}  # the `prec` argument of sige_hip_wide_conv_* (conv_wide.hpp: WIDE_F16 / _X3 / _F32)
 
 
@@ -1120,10 +1139,17 @@ def block_conv_direct(x, weight, bias, stride: Tuple[int, int], groups: int = 1,
 def copy_dense_(dst: torch.Tensor, src: torch.Tensor):
     """dst <- src for two fp32 tensors of one shape and one DENSE layout (plain or channels-last: equal strides, no gaps), as a
     library launch -- unlike Tensor.copy_ it is recorded by a launch plan (the refresh of a persistent Scatter output)."""
-    if (dst.shape != src.shape or dst.stride() != src.stride() or dst.dtype != torch.float32 or src.dtype != torch.float32
-            or not (dst.is_contiguous() or dst.is_contiguous(memory_format=CL))):
-        raise RuntimeError("copy_dense_: two fp32 tensors of one shape and one dense layout")
-    _check(lib().sige_hip_copy_f32(src.data_ptr(), dst.data_ptr(), src.numel(), _stream(src)), "copy")
+    if (dst.shape != src.shape or dst.stride() != src.stride() or not (dst.is_contiguous() or dst.is_contiguous(memory_format=CL))):
+        raise RuntimeError("copy_dense_: two tensors of one shape and one dense layout")
+    pair = (src.dtype, dst.dtype)
+    if pair == (torch.float32, torch.float32):
+        _check(lib().sige_hip_copy_f32(src.data_ptr(), dst.data_ptr(), src.numel(), _stream(src)), "copy")
+    elif pair == (torch.float16, torch.float32) and src.numel() % 4 == 0:   # (an fp16-stored cache widened into a persistent output)
+        _check(lib().sige_hip_convert_f16_f32(src.data_ptr(), dst.data_ptr(), src.numel(), _stream(src)), "convert_f16_f32")
+    elif pair == (torch.float32, torch.float16) and src.numel() % 4 == 0:   # (a full-pass output rounded into the fp16 cache)
+        _check(lib().sige_hip_convert_f32_f16(src.data_ptr(), dst.data_ptr(), src.numel(), _stream(src)), "convert_f32_f16")
+    else:
+        raise RuntimeError("copy_dense_: fp32 -> fp32, fp16 -> fp32 or fp32 -> fp16 (element count a multiple of 4)")
     return dst
 
 
@@ -1159,6 +1185,16 @@ def _req_cl(t: torch.Tensor, name: str) -> torch.Tensor:
     if t.dim() != 4:
         raise NotImplementedError("sige_amd.hip: `%s` must have 4 dims (got %d)" % (name, t.dim()))
     return t if t.is_contiguous(memory_format=CL) else t.contiguous(memory_format=CL)
+
+
+def _req_cl_cache(t: torch.Tensor, name: str) -> torch.Tensor:
+    """A CACHED tensor: channels-last, fp32 or -- SIGEModel.set_cache_dtype("f16") -- fp16 storage (read through the "_f16" /
+    "_c16" entry points of include/sige_hip.h; widened exactly when read)."""
+    if t.dtype == torch.float16:
+        if not t.is_cuda or t.dim() != 4:
+            raise NotImplementedError("sige_amd.hip: `%s` (fp16 cache) must be a 4-D GPU tensor" % name)
+        return t if t.is_contiguous(memory_format=CL) else t.contiguous(memory_format=CL)
+    return _req_cl(t, name)
 
 
 def _empty_cl(shape, device) -> torch.Tensor:
@@ -1305,7 +1341,7 @@ def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, a
 def scatter_gather_conv_cl(x, y, block: Tuple[int, int], activeIndices, scatterMap, scale, shift, activationName: str,
                            packed, bias, Cout: int, kernel: Tuple[int, int], stride: Tuple[int, int]):
     bias_keep = _vec(bias, "bias")
-    x, y = _req_cl(x, "x"), _req_cl(y, "y")
+    x, y = _req_cl(x, "x"), _req_cl_cache(y, "y")
     idx = _req(activeIndices, torch.int32, "activeIndices", 2)
     smap = _req(scatterMap, torch.int32, "scatterMap", 3)
     (sa, s_keep), (ta, t_keep) = _cvec(scale, "scale"), _cvec(shift, "shift")
@@ -1313,10 +1349,13 @@ def scatter_gather_conv_cl(x, y, block: Tuple[int, int], activeIndices, scatterM
     N = idx.shape[0]
     Ro, So = (block[0] - kernel[0]) // stride[0] + 1, (block[1] - kernel[1]) // stride[1] + 1
     out = _empty_tiles_cl(B, idx, Cout, Ro, So, y.device)
-    status = _conv_fn("sige_hip_scatter_gather_conv_nhwc", packed)(
-        x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3], block[0], block[1], idx.data_ptr(), N,
-        smap.data_ptr(), *sa, *ta, _act(activationName), packed.data_ptr(), _p(bias_keep), Cout, kernel[0], kernel[1],
-        stride[0], stride[1], out.data_ptr(), _stream(y))
+    args = (x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3], block[0], block[1], idx.data_ptr(), N,
+            smap.data_ptr(), *sa, *ta, _act(activationName), packed.data_ptr(), _p(bias_keep), Cout, kernel[0], kernel[1],
+            stride[0], stride[1], out.data_ptr(), _stream(y))
+    if y.dtype == torch.float16:  # (fp16-stored cache)
+        status = lib().sige_hip_scatter_gather_conv_nhwc_c16(_COMPUTE_ID[getattr(packed, "compute", "f32")], *args)
+    else:
+        status = _conv_fn("sige_hip_scatter_gather_conv_nhwc", packed)(*args)
     if status == UNSUPPORTED:
         return None
     _check(status, "scatter_gather_conv_cl")
@@ -1330,14 +1369,17 @@ def scatter_gather_conv_scatter_cl(x, y, block, activeIndices, scatterMap, scale
     cached shortcut tensor, x1 = the shortcut conv's tiles, table1 = their tile table) in one launch, written into
     `out` (a persistent buffer that already equals the cache outside this mask's tiles).  None if unsupported."""
     bias_keep = _vec(bias, "bias")
-    x, y = _req_cl(x, "x"), _req_cl(y, "y")
+    x, y = _req_cl(x, "x"), _req_cl_cache(y, "y")
     idx = _req(activeIndices, torch.int32, "activeIndices", 2)
     smap = _req(scatterMap, torch.int32, "scatterMap", 3)
     (sa, s_keep), (ta, t_keep) = _cvec(scale, "scale"), _cvec(shift, "shift")
     B, C, H, W = y.shape
     if tuple(out.shape) != (B, Cout, H, W) or not out.is_contiguous(memory_format=CL):
         raise RuntimeError("scatter_gather_conv_scatter_cl: `out` must be a channels-last [B,Cout,H,W] tensor")
-    r = None if residual is None else _req_cl(residual, "residual")
+    # (an fp16 residual is the cached shortcut tensor of a fused ScatterWithBlockResidual; the cache dtype is one per model)
+    r = None if residual is None else (_req_cl_cache(residual, "residual") if x1 is not None else _req_cl(residual, "residual"))
+    if r is not None and r.dtype == torch.float16 and y.dtype != torch.float16:
+        return None
     if r is not None and tuple(r.shape) != tuple(out.shape):
         raise RuntimeError("scatter_gather_conv_scatter_cl: residual must be full size")
     if x1 is not None:
@@ -1347,10 +1389,15 @@ def scatter_gather_conv_scatter_cl(x, y, block, activeIndices, scatterMap, scale
     else:
         bargs = (None, None, 0, 0, 0, 0, 0)
     targs, twin_keep = _twin_args(twins if twins else None, out, Cout, "scatter_gather_conv_scatter_cl")
-    status = _conv_fn("sige_hip_scatter_gather_conv_scatter_nhwc", packed)(
-        x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3], block[0], block[1], idx.data_ptr(), idx.shape[0],
-        smap.data_ptr(), *sa, *ta, _act(activationName), packed.data_ptr(), _p(bias_keep), Cout, kernel[0], kernel[1],
-        offset[0], offset[1], None if r is None else r.data_ptr(), *bargs, *targs, out.data_ptr(), _stream(y))
+    head = (x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3], block[0], block[1], idx.data_ptr(), idx.shape[0],
+            smap.data_ptr(), *sa, *ta, _act(activationName), packed.data_ptr(), _p(bias_keep), Cout, kernel[0], kernel[1],
+            offset[0], offset[1], None if r is None else r.data_ptr())
+    if y.dtype == torch.float16:  # (fp16-stored caches)
+        status = lib().sige_hip_scatter_gather_conv_scatter_nhwc_c16(
+            _COMPUTE_ID[getattr(packed, "compute", "f32")], *head, int(r is not None and r.dtype == torch.float16), *bargs, *targs,
+            out.data_ptr(), _stream(y))
+    else:
+        status = _conv_fn("sige_hip_scatter_gather_conv_scatter_nhwc", packed)(*head, *bargs, *targs, out.data_ptr(), _stream(y))
     if status == UNSUPPORTED:
         return None
     _check(status, "scatter_gather_conv_scatter_cl")
@@ -1358,29 +1405,30 @@ def scatter_gather_conv_scatter_cl(x, y, block, activeIndices, scatterMap, scale
 
 
 def gather_cl(x, bSizeH, bSizeW, activeIndices, scale=None, shift=None, activationName="identity"):
-    x = _req_cl(x, "x")
+    x = _req_cl_cache(x, "x")
     idx = _req(activeIndices, torch.int32, "activeIndices", 2)
     (sa, s_keep), (ta, t_keep) = _cvec(scale, "scale"), _cvec(shift, "shift")
     B, C, H, W = x.shape
     N = idx.shape[0]
     out = _empty_tiles_cl(B, idx, C, bSizeH, bSizeW, x.device)
-    _check(lib().sige_hip_gather_nhwc_f32(x.data_ptr(), B, C, H, W, bSizeH, bSizeW, idx.data_ptr(), N, *sa, *ta,
-                                          _act(activationName), out.data_ptr(), _stream(x)), "gather_cl")
+    fn = lib().sige_hip_gather_nhwc_f16 if x.dtype == torch.float16 else lib().sige_hip_gather_nhwc_f32
+    _check(fn(x.data_ptr(), B, C, H, W, bSizeH, bSizeW, idx.data_ptr(), N, *sa, *ta, _act(activationName), out.data_ptr(), _stream(x)),
+           "gather_cl")
     return out
 
 
 def scatter_gather_cl(x, y, bSizeH, bSizeW, activeIndices, scatterMap, scale=None, shift=None,
                       activationName="identity"):
-    x, y = _req_cl(x, "x"), _req_cl(y, "y")
+    x, y = _req_cl(x, "x"), _req_cl_cache(y, "y")
     idx = _req(activeIndices, torch.int32, "activeIndices", 2)
     smap = _req(scatterMap, torch.int32, "scatterMap", 3)
     (sa, s_keep), (ta, t_keep) = _cvec(scale, "scale"), _cvec(shift, "shift")
     B, C, H, W = y.shape
     N = idx.shape[0]
     out = _empty_tiles_cl(B, idx, C, bSizeH, bSizeW, y.device)
-    _check(lib().sige_hip_scatter_gather_nhwc_f32(x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3],
-                                                  bSizeH, bSizeW, idx.data_ptr(), N, smap.data_ptr(), *sa, *ta,
-                                                  _act(activationName), out.data_ptr(), _stream(y)), "scatter_gather_cl")
+    fn = lib().sige_hip_scatter_gather_nhwc_f16 if y.dtype == torch.float16 else lib().sige_hip_scatter_gather_nhwc_f32
+    _check(fn(x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3], bSizeH, bSizeW, idx.data_ptr(), N, smap.data_ptr(),
+              *sa, *ta, _act(activationName), out.data_ptr(), _stream(y)), "scatter_gather_cl")
     return out
 
 
@@ -1417,7 +1465,7 @@ def scatter_cl(x, y, offset, stride, activeIndices, table, residual=None, out: O
     """Channels-last scatter.  `out=None`: reference semantics (a fresh tensor, one pass).
     `out=buffer`: in-place form -- `buffer` already equals y outside this mask's tiles; only
     the covered pixels are written and `buffer` is returned."""
-    x, y = _req_cl(x, "x"), _req_cl(y, "y")
+    x, y = _req_cl(x, "x"), _req_cl_cache(y, "y")
     idx = _req(activeIndices, torch.int32, "activeIndices", 2)
     table = _req(table, torch.int32, "table", 2)
     B, C, H, W = y.shape
@@ -1429,24 +1477,27 @@ def scatter_cl(x, y, offset, stride, activeIndices, table, residual=None, out: O
     in_place = out is not None
     if out is None:
         out = _empty_cl(tuple(y.shape), y.device)
-    _check(lib().sige_hip_scatter_nhwc_f32(x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3],
-                                           offset[0], offset[1], stride[0], stride[1], idx.data_ptr(), table.data_ptr(),
-                                           table.shape[0], table.shape[1], idx.shape[0],
-                                           None if r is None else r.data_ptr(), int(in_place), out.data_ptr(),
-                                           _stream(y)), "scatter_cl")
+    fn = lib().sige_hip_scatter_nhwc_f16 if y.dtype == torch.float16 else lib().sige_hip_scatter_nhwc_f32
+    _check(fn(x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3], offset[0], offset[1], stride[0], stride[1],
+              idx.data_ptr(), table.data_ptr(), table.shape[0], table.shape[1], idx.shape[0],
+              None if r is None else r.data_ptr(), int(in_place), out.data_ptr(), _stream(y)), "scatter_cl")
     return out
 
 
 def scatter_with_block_residual_cl(x0, y0, x1, y1, offset, stride, idx0, table0, idx1, table1,
                                    out: Optional[torch.Tensor] = None):
-    x0, y0, x1, y1 = _req_cl(x0, "x0"), _req_cl(y0, "y0"), _req_cl(x1, "x1"), _req_cl(y1, "y1")
+    x0, y0, x1, y1 = _req_cl(x0, "x0"), _req_cl_cache(y0, "y0"), _req_cl(x1, "x1"), _req_cl_cache(y1, "y1")
+    if y0.dtype != y1.dtype:
+        raise NotImplementedError("scatter_with_block_residual_cl: y0 and y1 must be stored in one dtype")
     i0, i1 = _req(idx0, torch.int32, "idx0", 2), _req(idx1, torch.int32, "idx1", 2)
     t0, t1 = _req(table0, torch.int32, "table0", 2), _req(table1, torch.int32, "table1", 2)
     B, C, H, W = y0.shape
     in_place = out is not None
     if out is None:
         out = _empty_cl(tuple(y0.shape), y0.device)
-    _check(lib().sige_hip_scatter_with_block_residual_nhwc_f32(
+    fn = (lib().sige_hip_scatter_with_block_residual_nhwc_f16 if y0.dtype == torch.float16
+          else lib().sige_hip_scatter_with_block_residual_nhwc_f32)
+    _check(fn(
         x0.data_ptr(), y0.data_ptr(), x1.data_ptr(), y1.data_ptr(), B, C, H, W,
         x0.shape[2], x0.shape[3], x1.shape[2], x1.shape[3], offset[0], offset[1], stride[0], stride[1],
         i0.data_ptr(), t0.data_ptr(), t0.shape[0], t0.shape[1], i0.shape[0],
@@ -1488,17 +1539,23 @@ def affine_act_cl(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, act
                   out: Optional[torch.Tensor] = None):
     """act(scale * x + shift) over a whole channels-last tensor in one launch (scale / shift [1|B, C, 1, 1]); written into `out`
     (same shape and layout) when given.  None if unsupported."""
-    x = _req_cl(x, "x")
+    x = _req_cl_cache(x, "x")
     B, C, H, W = x.shape
     (sa, s_keep), (ta, t_keep) = _cvec(scale, "scale"), _cvec(shift, "shift")
     if s_keep is None or t_keep is None or sa[1] != ta[1] or sa[2] != C or ta[2] != C or sa[1] not in (1, B) or C % 4:
         return None
-    if out is None:
-        out = _empty_cl((B, C, H, W), x.device)
-    elif tuple(out.shape) != (B, C, H, W) or not out.is_contiguous(memory_format=CL) or out.dtype != torch.float32:
+    if out is None:  # (an fp16-stored cache gets an fp16 activated copy)
+        out = torch.empty((B, C, H, W), dtype=x.dtype, device=x.device, memory_format=CL)
+    elif tuple(out.shape) != (B, C, H, W) or not out.is_contiguous(memory_format=CL) or out.dtype not in (torch.float32, torch.float16):
         return None
-    status = lib().sige_hip_affine_act_nhwc_f32(x.data_ptr(), B, C, H, W, sa[0], ta[0], sa[1], _act(activationName), out.data_ptr(),
-                                                _stream(x))
+    if x.dtype == torch.float16:
+        status = lib().sige_hip_affine_act_nhwc_f16(x.data_ptr(), B, C, H, W, sa[0], ta[0], sa[1], _act(activationName), out.data_ptr(),
+                                                    int(out.dtype == torch.float16), _stream(x))
+    elif out.dtype != torch.float32:
+        return None
+    else:
+        status = lib().sige_hip_affine_act_nhwc_f32(x.data_ptr(), B, C, H, W, sa[0], ta[0], sa[1], _act(activationName), out.data_ptr(),
+                                                    _stream(x))
     if status == UNSUPPORTED:
         return None
     _check(status, "affine_act_cl")

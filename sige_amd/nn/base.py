@@ -51,6 +51,7 @@ class SIGEModule(nn.Module):
         self.timestamp = None
         self.cache_id = 0
         self.sparse_update = False
+        self.cache_dtype = "f32"  # SIGEModel.set_cache_dtype: how Scatter / ScatterGather modules STORE their caches
 
     # -- mask / cache protocol driven by SIGEModel ---------------------------
     def set_mask(self, masks: Dict, cache: Dict, timestamp: int):
@@ -329,6 +330,21 @@ class SIGEModel(nn.Module):
         for name, module in self.named_modules():
             if isinstance(module, nn.Conv2d):
                 module.compute_dtype = "f16x3" if (dtype == "f16" and kept(name)) else dtype
+
+    def set_cache_dtype(self, dtype: str):
+        """MI355X-first option (not in the reference, whose caches are fp32: sige/nn/base.py:15,55-63): "f16" STORES the cached
+        activations of the full pass -- Scatter / ScatterGather `original_outputs`, ScatterWithBlockResidual `original_outputs` /
+        `original_residuals`, the activated ScatterGather copies -- as fp16 (channels-last GPU tensors): half the resident
+        cache, half the bytes of the multi-GPU cache distribution with no conversion pass on either side.  Cached GroupNorm
+        affines, activations, tiles and outputs stay fp32; the kernels that read a cache widen it exactly (include/sige_hip.h:
+        the "_f16" / "_c16" entry points).  Takes effect at the next full-mode forward.  Rounding the cache to fp16 moves a sparse
+        output by ~5e-4 ... 3e-3 (DDPM-256, 1 ... 20 % edit: profiles/r3_f16_cache_trace.json): inside the f16 criterion
+        (sige_amd.tolerance), outside the fp32 path's 1e-3 at large edits -- an option of the "f16" compute mode."""
+        if dtype not in ("f32", "f16"):
+            raise ValueError("cache dtype must be 'f32' or 'f16'")
+        self.cache_dtype = dtype
+        for module in self._sige_modules():
+            module.cache_dtype = dtype
 
     def set_scatter_inplace(self, inplace: bool):
         """MI355X-first option (not in the reference): Scatter / ScatterWithBlockResidual modules whose

@@ -160,10 +160,11 @@ def defer_ok(x: torch.Tensor, scale, shift, activation_first: bool, sparse_updat
     return tuple(scale.shape) == tuple(shift.shape)
 
 
-def channels_last_ok(x: torch.Tensor, scale=None, shift=None, activation_first: bool = False) -> bool:
+def channels_last_ok(x: torch.Tensor, scale=None, shift=None, activation_first: bool = False, cache: bool = False) -> bool:
     """Take the channels-last (NHWC) kernels for this gather?  `x` must be a GPU tensor stored
-    channels-last with C % 4 == 0, and the affine per-(batch, channel)."""
-    if not x.is_cuda or x.dtype != torch.float32 or activation_first:
+    channels-last with C % 4 == 0, and the affine per-(batch, channel).  `cache`: `x` is a CACHED tensor, which may be
+    stored as fp16 (SIGEModel.set_cache_dtype)."""
+    if not x.is_cuda or x.dtype not in ((torch.float32, torch.float16) if cache else (torch.float32,)) or activation_first:
         return False
     from .. import hip
 
@@ -181,3 +182,18 @@ def keep_layout(x: torch.Tensor) -> torch.Tensor:
     if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last):
         return x
     return x.contiguous()
+
+
+def to_cache(x: torch.Tensor, cache_dtype: str = "f32") -> torch.Tensor:
+    """What a module keeps of a full-mode output.  "f32": `keep_layout(x)` -- the reference's cache (sige/nn/scatter.py:31-37).
+    "f16" (SIGEModel.set_cache_dtype, not in the reference): the same tensor ROUNDED to fp16, same layout -- half the resident
+    bytes and half the bytes of a cache broadcast; the kernels that read caches widen on the fly (include/sige_hip.h "_f16")."""
+    x = keep_layout(x)
+    if cache_dtype == "f16" and x.dtype == torch.float32:
+        return x.to(torch.float16, memory_format=torch.preserve_format)
+    return x
+
+
+def from_cache(c: torch.Tensor) -> torch.Tensor:
+    """An fp32 view of a cached tensor for a path without an fp16 read kernel (NCHW / CPU-oracle paths: off the fast path)."""
+    return c.float() if c.dtype == torch.float16 else c

@@ -30,7 +30,7 @@ def hip_is_cl(t: torch.Tensor) -> bool:
 
 def _cl_ok(cached: torch.Tensor, *others) -> bool:
     """Channels-last kernels: a channels-last cache with C % 4 == 0 and full-size operands."""
-    if not cached.is_cuda or cached.dtype != torch.float32:
+    if not cached.is_cuda or cached.dtype not in (torch.float32, torch.float16):  # (fp16: SIGEModel.set_cache_dtype)
         return False
     from .. import hip
 
@@ -43,11 +43,12 @@ def _fill(buf: torch.Tensor, cached: torch.Tensor, build=None) -> torch.Tensor:
     """buf <- cached (build None) or SiLU(scale * cached + shift) (build = (scale [C], shift [C])).  On the GPU, channels-last:
     ONE library launch (sige_hip_copy_f32 / sige_hip_affine_act_nhwc_f32), which a launch plan records -- a torch copy would
     be invisible to it."""
-    if cached.is_cuda and cached.dtype == torch.float32 and buf.stride() == cached.stride():
+    if cached.is_cuda and cached.dtype in (torch.float32, torch.float16) and buf.stride() == cached.stride():
         from .. import hip
 
-        if build is None and (cached.is_contiguous() or cached.is_contiguous(memory_format=torch.channels_last)):
-            return hip.copy_dense_(buf, cached)
+        if (build is None and (cached.is_contiguous() or cached.is_contiguous(memory_format=torch.channels_last))
+                and (cached.dtype == torch.float32 or cached.numel() % 4 == 0)):
+            return hip.copy_dense_(buf, cached)  # (an fp16-stored cache is widened on the way)
         if build is not None and hip.is_cl(cached):
             sc, sh = build
             done = hip.affine_act_cl(cached, sc.reshape(1, -1, 1, 1), sh.reshape(1, -1, 1, 1), "swish", out=buf)
@@ -57,7 +58,7 @@ def _fill(buf: torch.Tensor, cached: torch.Tensor, build=None) -> torch.Tensor:
         buf.copy_(cached)
     else:
         sc, sh = build
-        buf.copy_(torch.nn.functional.silu(cached * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)))
+        buf.copy_(torch.nn.functional.silu(cached.float() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)))
     return buf
 
 
@@ -91,7 +92,8 @@ class _OutputBuffers:
                 # that points at it stays valid, and nothing is allocated
                 buf = _fill(entry[1], cached, build)
             else:
-                buf = _fill(torch.empty_like(cached, memory_format=torch.preserve_format), cached, build)
+                # (persistent outputs and twins are fp32 whatever the cache is stored as: they hold this edit's RESULTS)
+                buf = _fill(torch.empty_like(cached, dtype=torch.float32, memory_format=torch.preserve_format), cached, build)
             entry = (key, buf, build)
             self.bufs[cache_id] = entry
         return entry[1]
@@ -259,11 +261,11 @@ class Scatter(SIGEModule):
                 from .. import hip
 
                 output = hip.scatter_fused(
-                    x.contiguous(), cached, g.tile_table(cached.shape[2:], x.device), g.active_indices.size(0),
+                    x.contiguous(), deferred.from_cache(cached), g.tile_table(cached.shape[2:], x.device), g.active_indices.size(0),
                     None if residual is None else residual.contiguous())
             else:
                 fn = self.native(self.runtime, x)
-                output = fn(x.contiguous(), cached.contiguous(), g.offset[0], g.offset[1],
+                output = fn(x.contiguous(), deferred.from_cache(cached).contiguous(), g.offset[0], g.offset[1],
                             g.model_stride[0], g.model_stride[1], g.indices_on(x.device),
                             None if residual is None else residual.contiguous())
             if self.sparse_update:
@@ -275,7 +277,7 @@ class Scatter(SIGEModule):
         if self.mode == "full":
             output = x if residual is None else x + residual
             self.output_res = output.shape[2:]
-            self.original_outputs[self.cache_id] = deferred.keep_layout(output)
+            self.original_outputs[self.cache_id] = deferred.to_cache(output, self.cache_dtype)
             self._out_bufs.invalidate(self.cache_id)
             self.twins.invalidate(self.cache_id)
             return output
@@ -399,12 +401,12 @@ class ScatterWithBlockResidual(SIGEModule):
                 from .. import hip
 
                 output = hip.scatter_with_block_residual_fused(
-                    x.contiguous(), y0, residual.contiguous(), y1,
+                    x.contiguous(), deferred.from_cache(y0), residual.contiguous(), deferred.from_cache(y1),
                     mg.tile_table(res, x.device), mg.active_indices.size(0),
                     sg.tile_table(res, x.device), sg.active_indices.size(0))
             else:
                 fn = self.native(self.runtime, x)
-                output = fn(x.contiguous(), y0.contiguous(), residual.contiguous(), y1.contiguous(),
+                output = fn(x.contiguous(), deferred.from_cache(y0).contiguous(), residual.contiguous(), deferred.from_cache(y1).contiguous(),
                             mg.offset[0], mg.offset[1], mg.model_stride[0], mg.model_stride[1],
                             mg.indices_on(x.device), sg.indices_on(x.device))
             if self.sparse_update:
@@ -416,22 +418,22 @@ class ScatterWithBlockResidual(SIGEModule):
                 if _fused_ok(x):
                     from .. import hip
 
-                    y1.copy_(hip.scatter_fused(residual.contiguous(), y1, sg.tile_table(res, x.device),
+                    y1.copy_(hip.scatter_fused(residual.contiguous(), deferred.from_cache(y1), sg.tile_table(res, x.device),
                                                sg.active_indices.size(0), None))
                 else:
                     fn = self.native(self.scatter_runtime, x)
-                    y1.copy_(fn(residual.contiguous(), y1.contiguous(), sg.offset[0], sg.offset[1],
+                    y1.copy_(fn(residual.contiguous(), deferred.from_cache(y1).contiguous(), sg.offset[0], sg.offset[1],
                                 sg.model_stride[0], sg.model_stride[1], sg.indices_on(x.device), None))
             return tag_twins(output, emulated_twins(output, twins_for(self.twins.regs, self.cache_id)) if EMULATE_TWINS else {})  # (no twin written)
         if self.mode == "full":
             # (x_is_sum: the caller's conv already added the residual in its epilogue -- one launch less, one pass less)
             output = x if x_is_sum else x + residual
             self.output_res = output.shape[2:]
-            self.original_outputs[self.cache_id] = deferred.keep_layout(output)
+            self.original_outputs[self.cache_id] = deferred.to_cache(output, self.cache_dtype)
             cl = self.original_outputs[self.cache_id].is_contiguous(memory_format=torch.channels_last)
-            self.original_residuals[self.cache_id] = (
-                residual.contiguous(memory_format=torch.channels_last) if cl and not residual.is_contiguous()
-                else deferred.keep_layout(residual))
+            self.original_residuals[self.cache_id] = deferred.to_cache(
+                residual.contiguous(memory_format=torch.channels_last) if cl and not residual.is_contiguous() else residual,
+                self.cache_dtype)
             self._out_bufs.invalidate(self.cache_id)
             self.twins.invalidate(self.cache_id)
             return output

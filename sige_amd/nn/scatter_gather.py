@@ -65,19 +65,20 @@ class ScatterGather(SIGEModule):
 
         y = self.original_outputs[self.cache_id]
         old = self.activated_outputs.get(self.cache_id)
-        if y.is_cuda and y.dtype == torch.float32:
+        if y.is_cuda and y.dtype in (torch.float32, torch.float16):
             from .. import hip
 
             if hip.is_cl(y) and scale.dim() == 4 and shift.dim() == 4 and self.activation_name in hip.ACT:
                 # one streaming pass, straight into the existing copy when there is one (same address: a captured hipGraph
-                # that reads it stays valid)
-                reuse = old if (old is not None and old.shape == y.shape and old.stride() == y.stride() and old.device == y.device) else None
+                # that reads it stays valid).  An fp16-stored cache gets an fp16 activated copy: no fp32 working copy of it.
+                reuse = old if (old is not None and old.shape == y.shape and old.stride() == y.stride() and old.device == y.device
+                                and old.dtype == y.dtype) else None
                 done = hip.affine_act_cl(y, scale, shift, self.activation_name, out=reuse)
                 if done is not None:
                     self.activated_outputs[self.cache_id] = done
                     return
-        new = deferred.keep_layout(act_fn(y * scale + shift, self.activation_name))
-        if old is not None and old.shape == new.shape and old.stride() == new.stride() and old.device == new.device:
+        new = deferred.to_cache(act_fn(deferred.from_cache(y) * scale + shift, self.activation_name), self.cache_dtype)
+        if old is not None and old.shape == new.shape and old.stride() == new.stride() and old.device == new.device and old.dtype == new.dtype:
             old.copy_(new)  # same address: a captured hipGraph that reads the activated copy stays valid
         else:
             self.activated_outputs[self.cache_id] = new
@@ -93,7 +94,7 @@ class ScatterGather(SIGEModule):
             assert scale is None and shift is None and not self.sparse_update
             cached = self.activated_outputs[self.cache_id]
             x = deferred.resolve(x)
-            cl = deferred.channels_last_ok(cached)
+            cl = deferred.channels_last_ok(cached, cache=True)
             x = x.contiguous(memory_format=torch.channels_last) if cl else x.contiguous()
             idx, smap = g.indices_on(x.device), self._map_on(x.device)
             bh, bw = g.block_size
@@ -103,7 +104,7 @@ class ScatterGather(SIGEModule):
                     from .. import hip
 
                     return hip.scatter_gather_cl(x, cached, bh, bw, idx, smap, None, None, "identity")
-                return self.native(self.runtime, x)(x, cached.contiguous(), bh, bw, idx, smap, None, None, "identity", False)
+                return self.native(self.runtime, x)(x, deferred.from_cache(cached).contiguous(), bh, bw, idx, smap, None, None, "identity", False)
 
             if deferred.defer_ok(x, None, None, False, False, "identity"):
                 return deferred.DeferredTiles(
@@ -116,7 +117,7 @@ class ScatterGather(SIGEModule):
             fn = self.native(self.runtime, x)
             x = deferred.resolve(x)
             # the cache decides the layout: channels-last cache -> channels-last tiles
-            cl = deferred.channels_last_ok(cached, scale, shift, self.activation_first)
+            cl = deferred.channels_last_ok(cached, scale, shift, self.activation_first, cache=True)
             x = x.contiguous(memory_format=torch.channels_last) if cl else x.contiguous()
             idx, smap = g.indices_on(x.device), self._map_on(x.device)
             scale = None if scale is None else scale.contiguous()
@@ -129,7 +130,7 @@ class ScatterGather(SIGEModule):
                     from .. import hip
 
                     return hip.scatter_gather_cl(x, cached, bh, bw, idx, smap, scale, shift, act)
-                return fn(x, cached.contiguous(), bh, bw, idx, smap, scale, shift, act, first)
+                return fn(x, deferred.from_cache(cached).contiguous(), bh, bw, idx, smap, scale, shift, act, first)
 
             if deferred.defer_ok(x, scale, shift, first, self.sparse_update, act):
                 return deferred.DeferredTiles(
@@ -141,16 +142,16 @@ class ScatterGather(SIGEModule):
                 if x.is_cuda:
                     from .. import hip
 
-                    cached.copy_(hip.scatter_fused(x.contiguous(), cached, g.tile_table(cached.shape[2:], x.device),
+                    cached.copy_(hip.scatter_fused(x.contiguous(), deferred.from_cache(cached), g.tile_table(cached.shape[2:], x.device),
                                                    g.active_indices.size(0), None))
                 else:
                     sfn = self.native(self.scatter_runtime, x)
-                    cached.copy_(sfn(x.contiguous(), cached.contiguous(), g.offset[0], g.offset[1],
+                    cached.copy_(sfn(x.contiguous(), deferred.from_cache(cached).contiguous(), g.offset[0], g.offset[1],
                                      g.model_stride[0], g.model_stride[1], g.indices_on(x.device), None))
             return output
         if self.mode == "full":
             self.output_res = x.shape[2:]
-            self.original_outputs[self.cache_id] = deferred.keep_layout(x)
+            self.original_outputs[self.cache_id] = deferred.to_cache(x, self.cache_dtype)
             return x
         if self.mode == "profile":
             c = x.shape[1]

@@ -95,31 +95,43 @@ def refresh_derived(model: torch.nn.Module, modules=None) -> None:
 
 
 def pack_caches(model: torch.nn.Module) -> torch.Tensor:
-    """Copy every ORIGINAL cache tensor into one flat fp32 buffer and re-point the module
-    caches at views of it.  Afterwards writing the buffer (e.g. by a broadcast)
-    updates every cache in place (then call refresh_derived, or pass `model` to broadcast_cache)."""
+    """Copy every ORIGINAL cache tensor into one flat buffer and re-point the module caches at views of it.  Afterwards
+    writing the buffer (e.g. by a broadcast) updates every cache in place (then call refresh_derived, or pass `model` to
+    broadcast_cache).  The buffer is fp32 -- or, when the model stores its caches as fp16 (SIGEModel.set_cache_dtype("f16")),
+    fp16: the fp16 cache tensors lie in it as they are and the (few, small) fp32 tensors -- the cached GroupNorm affines --
+    occupy two elements per value, bit for bit; ONE collective moves both, and nothing is converted on either side of the wire."""
     slots = _slots_with_modules(model)
     if not slots:
         raise RuntimeError("pack_caches: no cached activations -- run the model in `full` mode first")
-    sizes = [(_get(s).numel() + _ALIGN - 1) // _ALIGN * _ALIGN for s in slots]
-    ref = _get(slots[0])
-    total = (sum(sizes) + _PAD - 1) // _PAD * _PAD  # (see _PAD: distribute_cache splits the buffer evenly over the ranks)
-    flat = torch.zeros(total, dtype=torch.float32, device=ref.device)
+    tensors = [_get(s) for s in slots]
+    for t in tensors:
+        if t.dtype not in (torch.float32, torch.float16):
+            raise NotImplementedError("cache tensors are fp32 or fp16 (got %s)" % t.dtype)
+    half = any(t.dtype == torch.float16 for t in tensors)
+    fdt = torch.float16 if half else torch.float32
+    es = 2 if half else 4
+    per = [(4 // es) if t.dtype == torch.float32 else 1 for t in tensors]  # flat elements per tensor element
+    align = _ALIGN * 4 // es   # 256 bytes
+    pad = _PAD * 4 // es
+    sizes = [(t.numel() * k + align - 1) // align * align for t, k in zip(tensors, per)]
+    ref = tensors[0]
+    total = (sum(sizes) + pad - 1) // pad * pad  # (see _PAD: distribute_cache splits the buffer evenly over the ranks)
+    flat = torch.zeros(total, dtype=fdt, device=ref.device)
     off = 0
-    layout = []  # (owning module, first float, one past its last (padded) float, true element count) in module order
-    for s, size in zip(slots, sizes):
-        t = _get(s)
-        if t.dtype != torch.float32:
-            raise NotImplementedError("cache tensors are fp32 (got %s)" % t.dtype)
+    layout = []  # (owning module, first element, one past its last (padded) element, true element count -- in FLAT elements) in module order
+    for s, t, size, k in zip(slots, tensors, sizes, per):
+        raw = flat[off:off + t.numel() * k]
+        if t.dtype != fdt:
+            raw = raw.view(t.dtype)  # (fp32 values inside an fp16 buffer: two elements each)
         if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous():
             # keep channels-last caches channels-last: an NHWC block of the flat buffer seen as [B,C,H,W]
-            b, c, h, w = t.shape
-            view = flat[off:off + t.numel()].view(b, h, w, c).permute(0, 3, 1, 2)
+            bb, c, h, w = t.shape
+            view = raw.view(bb, h, w, c).permute(0, 3, 1, 2)
         else:
-            view = flat[off:off + t.numel()].view(t.shape)  # (a non-dense view -- e.g. an expanded affine -- is stored dense)
+            view = raw.view(t.shape)  # (a non-dense view -- e.g. an expanded affine -- is stored dense)
         view.copy_(t)
         _set(s, view)
-        layout.append((s[4], off, off + size, t.numel()))
+        layout.append((s[4], off, off + size, t.numel() * k))
         off += size
     for m in model.modules():  # the cache tensors moved: persistent outputs are rebuilt on next use
         bufs = getattr(m, "_out_bufs", None)
@@ -134,6 +146,13 @@ def pack_caches(model: torch.nn.Module) -> torch.Tensor:
             drop()
     model.__dict__["_sige_cache_layout"] = (flat.data_ptr(), layout)
     return flat
+
+
+def checksum(flat: torch.Tensor) -> int:
+    """An exact fingerprint of a packed cache (the sum of its 32-bit words as integers): equal on every rank after a
+    distribution.  (A floating-point sum would do for an fp32 buffer; an fp16 buffer also carries fp32 bit patterns.)"""
+    words = flat.view(torch.int32) if flat.numel() * flat.element_size() % 4 == 0 else flat.view(torch.int16).to(torch.int32)
+    return int(words.sum(dtype=torch.int64).item())
 
 
 def broadcast_cache(flat: torch.Tensor, src: int = 0, group=None, async_op: bool = False, model: torch.nn.Module = None):
@@ -214,13 +233,13 @@ def distribute_cache(flat: torch.Tensor, src: int = 0, method: str = "broadcast"
         raise ValueError("unknown method %r" % method)
     if wire_dtype not in (None, torch.float32, torch.float16):
         raise ValueError("wire_dtype: torch.float32 or torch.float16")
-    if wire_dtype == torch.float16:
+    if wire_dtype == torch.float16 and flat.dtype == torch.float32:
         small, side_n = _wire_layout(flat, model)
         wire, side = _wire_send(flat, small, side_n, src, group)
         work = _issue(wire, src, method, group, world, async_op=False)
         assert work is None
         _wire_land(flat, wire, side, small, 0, flat.numel())
-    else:
+    else:  # (an fp16-STORED cache already is its wire format)
         work = _issue(flat, src, method, group, world, async_op=False)
         assert work is None
     if model is not None:
@@ -307,7 +326,7 @@ def distribute_cache_pipelined(flat: torch.Tensor, model: torch.nn.Module, src: 
     bounds, ready = _refresh_schedule(model, layout, flat.numel(), world, n_chunks)
     if wire_dtype not in (None, torch.float32, torch.float16):
         raise ValueError("wire_dtype: torch.float32 or torch.float16")
-    f16 = wire_dtype == torch.float16
+    f16 = wire_dtype == torch.float16 and flat.dtype == torch.float32  # (an fp16-STORED cache already is its wire format)
     if f16:  # (the activations travel as fp16, the cached affines in an fp32 side buffer sent first: see distribute_cache)
         small, side_n = _wire_layout(flat, model)
         wire, side = _wire_send(flat, small, side_n, src, group)

@@ -264,6 +264,47 @@ def test_f16_policy_ddpm_forward_whole_sweep(hip, ddpm_reference, ddpm_gpu, rati
     assert chk["ok"], chk
 
 
+@pytest.mark.parametrize("ratio", [0.01, 0.02, 0.05, 0.1, 0.2])
+def test_f16_cache_ddpm_forward_whole_sweep(hip, ddpm_reference, ddpm_gpu, ratio):
+    """Round 4: the same sweep with the cache STORED as fp16 -- SIGEModel.set_cache_dtype("f16"):
+    every Scatter / ScatterGather / ScatterWithBlockResidual cache and the activated copies are fp16 tensors, read by the "_c16"
+    conv kernels and the fp16 refresh; no fp32 copy of a cache exists -- under the same ONE criterion against the fp32 CPU
+    reference, and the resident cache is half the bytes."""
+    from sige_amd import parallel
+    from sige_amd.nn import Scatter, ScatterGather, ScatterWithBlockResidual
+
+    ref = ddpm_reference
+    model = ddpm_gpu
+    cl = lambda a: a.to(DEV).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    try:
+        with torch.no_grad():
+            model.set_compute_dtype("f32")
+            model.set_cache_dtype("f16")
+            model.set_mode("full")
+            model(cl(ref["x0"]), torch.zeros(1, device=DEV))
+            caches = [c for mod in model.modules() if isinstance(mod, (Scatter, ScatterGather, ScatterWithBlockResidual))
+                      for d in (mod.original_outputs, getattr(mod, "original_residuals", {}), getattr(mod, "activated_outputs", {}))
+                      for c in d.values()]
+            assert len(caches) > 40 and all(c.dtype == torch.float16 for c in caches)
+            cache_bytes = sum(parallel._get(sl).numel() * parallel._get(sl).element_size() for sl in parallel.cache_slots(model))
+            assert 3.3e8 < cache_bytes < 3.5e8, cache_bytes  # (672.9 MB in fp32: SURVEY.md 8e)
+            model.set_compute_dtype("f16", edit_ratio=ratio)
+            out = _gpu_sparse(model, ref, ratio)
+            import bench
+
+            x1 = cl(ref["x0"] + ref["noise"] * bench.edit_mask(ratio))
+            n0 = hip.launch_count()
+            again = model(x1, torch.zeros(1, device=DEV))
+            assert hip.launch_count() - n0 <= 102  # (a steady-state forward: no conversion pass in front of or behind any launch)
+            assert torch.equal(again, out)
+    finally:
+        model.set_compute_dtype("f32")
+        model.set_cache_dtype("f32")
+        model.clear_cache()
+    chk = tolerance.f16_check(out, ref["sparse"][ratio])
+    assert chk["ok"], chk
+
+
 @pytest.mark.parametrize("ratio", [0.01, 0.2])
 def test_f16x3_ddpm_forward_meets_the_fp32_tolerance(hip, ddpm_reference, ddpm_gpu, ratio):
     """Split fp16 operands ("f16x3": dense remainder AND the cache-producing full pass on the fp16 matrix cores, tile convs

@@ -674,6 +674,79 @@ def test_pipelined_refresh_waits_for_the_consumers_affine():
     assert checked >= 4 and later >= 1, (checked, later)  # (skip connections: some consumers' affines do sit in a later chunk)
 
 
+def test_fp16_stored_cache_host_logic_on_the_oracle_backend():
+    """SIGEModel.set_cache_dtype("f16"): the modules STORE their caches as fp16, every consumer reads them
+    through `from_cache` off the GPU (on the GPU: the "_f16" / "_c16" kernels); pack_caches puts fp16 caches and fp32 affines
+    into ONE fp16 buffer; the sparse output stays within the f16 criterion of the fp32-cache output and equals, to fp16 rounding of
+    the activated copies, the fp32-cache model whose caches were rounded by hand."""
+    from oracle import oracle
+    from sige_amd import parallel, runtime, tolerance
+    from sige_amd.nn import Scatter, ScatterGather, ScatterWithBlockResidual
+    from sige_amd.utils import dilate_mask, downsample_mask
+    from sige_amd.workloads.ddpm_unet import DDPMConfig, DDPMSparseUNet
+
+    cfg = DDPMConfig(ch=32, ch_mult=(1, 2, 2, 4), num_res_blocks=2, attn_resolutions=(16,), resolution=64, sparse_threshold=32, groups=8)
+    g = torch.Generator().manual_seed(7)
+    x0, noise = torch.randn(1, 3, 64, 64, generator=g), torch.randn(1, 3, 64, 64, generator=g)
+    t = torch.zeros(1)
+    m = torch.zeros(64, 64, dtype=torch.bool)
+    m[20:36, 10:34] = True
+    masks = downsample_mask(dilate_mask(m, 5), 8)
+
+    def build(cache_dtype):
+        torch.manual_seed(0)
+        net = DDPMSparseUNet(cfg).eval()
+        net.set_scatter_inplace(True)
+        net.set_cache_dtype(cache_dtype)
+        net.set_mode("full")
+        net(x0, t)
+        return net
+
+    def sparse(net):
+        net.set_masks(masks)
+        net.set_mode("sparse")
+        net(x0 + noise * m, t)
+        return net(x0 + noise * m, t).clone()
+
+    runtime.register_backend("cpu", oracle)
+    try:
+        with torch.no_grad():
+            ref = build("f32")
+            want32 = sparse(ref)
+            net = build("f16")
+            caches = [c for mod in net.modules() if isinstance(mod, (Scatter, ScatterGather, ScatterWithBlockResidual))
+                      for d in (mod.original_outputs, getattr(mod, "original_residuals", {}), getattr(mod, "activated_outputs", {}))
+                      for c in d.values()]
+            assert caches and all(c.dtype == torch.float16 for c in caches)
+            got = sparse(net)
+            chk = tolerance.f16_check(got, want32)
+            assert chk["ok"] and 0.0 < chk["max_abs"] < 2e-2, chk
+            # the fp32-cache model with its caches rounded by hand: the same values up to the second rounding of the activated copies
+            for mod in ref.modules():
+                for name in ("original_outputs", "original_residuals"):
+                    for c in getattr(mod, name, {}).values():
+                        c.copy_(c.half().float())
+            parallel.refresh_derived(ref)
+            by_hand = sparse(ref)
+            assert float((got - by_hand).abs().max()) < 0.25 * max(chk["max_abs"], 1e-6) + 2e-4
+            # one flat fp16 buffer for fp16 caches + fp32 affines; views alias it; results unchanged
+            flat = parallel.pack_caches(net)
+            assert flat.dtype == torch.float16
+            n32 = sum(parallel._get(sl).numel() for sl in parallel.cache_slots(net) if parallel._get(sl).dtype == torch.float32)
+            n16 = sum(parallel._get(sl).numel() for sl in parallel.cache_slots(net) if parallel._get(sl).dtype == torch.float16)
+            assert n32 > 0 and n16 > 100 * n32 and flat.numel() >= n16 + 2 * n32
+            assert torch.equal(sparse(net), got)
+            before = parallel.checksum(flat)
+            flat2 = flat.clone()
+            flat.zero_()
+            assert parallel.checksum(flat) == 0 != before
+            flat.copy_(flat2)  # ("the broadcast")
+            parallel.refresh_derived(net)
+            assert parallel.checksum(flat) == before and torch.equal(sparse(net), got)
+    finally:
+        runtime.unregister_backend("cpu")
+
+
 def test_twin_buffers_follow_cache_and_masks():
     """scatter._TwinBuffers (the persistent activated twins of a Scatter module's in-place output): built from the cache,
     rebuilt when the mask stamp or the cache generation changes, refreshed in place when the cache is rewritten in place,

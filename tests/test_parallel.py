@@ -58,7 +58,9 @@ def _worker(rank, world, port, out_dir, method="broadcast"):
     from sige_amd import parallel, runtime
 
     runtime.register_backend("cpu", oracle)
-    net = _build(affine=method.startswith("f16wire:"))
+    net = _build(affine=method.startswith(("f16wire:", "f16cache:")))
+    if method.startswith("f16cache:"):
+        net.set_cache_dtype("f16")  # (the caches are STORED as fp16: one fp16 buffer, nothing converted around the collective)
     orig, edits = _inputs()
     with torch.no_grad():
         net.set_mode("full")
@@ -81,6 +83,16 @@ def _worker(rank, world, port, out_dir, method="broadcast"):
                 parallel.distribute_cache(flat, src=0, method=kind, model=net, wire_dtype=torch.float16)
             if rank == 0:
                 assert not torch.equal(flat, before)  # (the source's own cache is rounded too)
+        elif method.startswith("f16cache:"):
+            assert flat.dtype == torch.float16
+            if rank != 0:
+                flat.fill_(3.0)
+            kind = method.split(":")[1]
+            if kind == "pipelined":
+                info = parallel.distribute_cache_pipelined(flat, net, src=0, method="scatter_allgather", n_chunks=3)
+                assert info["wire_bytes"] == flat.numel() * 2
+            else:
+                parallel.distribute_cache(flat, src=0, method=kind, model=net)
         elif method.startswith("pipelined:"):
             info = parallel.distribute_cache_pipelined(flat, net, src=0, method=method.split(":")[1], n_chunks=3)
             assert info["chunks"] >= 2 and info["refreshed"] >= 1
@@ -94,7 +106,8 @@ def _worker(rank, world, port, out_dir, method="broadcast"):
         mine = parallel.shard(list(range(len(edits))))
         outs = {i: _sparse(net, *edits[i]) for i in mine}
     slowest = parallel.max_over_ranks(0.25 * (rank + 1))
-    torch.save({"outs": outs, "flat_sum": float(flat.double().sum()), "slowest": slowest, "numel": flat.numel()},
+    torch.save({"outs": outs, "flat_sum": float(flat.double().sum()) if flat.dtype == torch.float32 else parallel.checksum(flat),
+                "slowest": slowest, "numel": flat.numel()},
                os.path.join(out_dir, "rank%d.pt" % rank))
     dist.destroy_process_group()
 
@@ -200,6 +213,34 @@ def test_cache_distribution_with_fp16_on_the_wire(tmp_path, kind):
             assert not torch.equal(flat, exact)  # (this network's caches are above the threshold: something was rounded)
             parallel.refresh_derived(net)
             assert float(flat.double().sum()) == res[0]["flat_sum"]
+            for i, (m, x) in enumerate(edits):
+                assert torch.equal(res[i % world]["outs"][i], _sparse(net, m, x))
+    finally:
+        runtime.unregister_backend("cpu")
+
+
+@pytest.mark.parametrize("kind", ["broadcast", "scatter_allgather", "pipelined"])
+def test_cache_distribution_of_an_fp16_stored_cache(tmp_path, kind):
+    """SIGEModel.set_cache_dtype("f16"): the packed cache IS fp16 (fp16 activations as they are, the fp32 affines bit for bit in
+    two elements each); one collective, no conversion on either side; every rank ends with identical bits and computes what a
+    single process with the same fp16-stored cache computes."""
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "f16cache:" + kind), nprocs=world, join=True)
+    res = [torch.load(tmp_path / ("rank%d.pt" % r)) for r in range(world)]
+    assert res[0]["flat_sum"] == res[1]["flat_sum"]  # cache_identical_on_all_ranks
+    from oracle import oracle
+    from sige_amd import parallel, runtime
+
+    runtime.register_backend("cpu", oracle)
+    try:
+        net = _build(affine=True)
+        net.set_cache_dtype("f16")
+        orig, edits = _inputs()
+        with torch.no_grad():
+            net.set_mode("full")
+            net(orig)
+            flat = parallel.pack_caches(net)
+            assert flat.dtype == torch.float16 and parallel.checksum(flat) == res[0]["flat_sum"]
             for i, (m, x) in enumerate(edits):
                 assert torch.equal(res[i % world]["outs"][i], _sparse(net, m, x))
     finally:
