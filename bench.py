@@ -864,6 +864,8 @@ def main():
                          "the same fp16-rounded cache; the cached affines stay fp32).  Only with --dtype f16: the rounding costs up to "
                          "1.6e-3 of output error at 15 %% edit (profiles/r3_f16_cache_trace.json) -- inside the f16 criterion, outside "
                          "the fp32 path's 1e-3")
+    ap.add_argument("--batched-edits", default="1,2,4,8",
+                    help="stacked edits (sige_amd/stacked.py): batch sizes E of the throughput section, '' = skip")
     ap.add_argument("--cache-dtype", default="auto", choices=["auto", "f32", "f16"],
                     help="how the full pass's cached activations are STORED (SIGEModel.set_cache_dtype): auto = f16 with --dtype f16 "
                          "(half the resident cache and half the bytes of its distribution, no conversion passes; cached affines stay "
@@ -1449,6 +1451,96 @@ def main():
                                           "cache (no cross-step cache residency); parity of cache_id > 0 is a -m gpu test"}}
             prepare(args.ratio)
 
+    # ---- stacked edits ("throughput mode"): E edits of ONE original, each with its own mask, through one set of launches ----
+    batched = None
+    if rank == 0 and world == 1 and not args.no_dynamic and args.layout == "nhwc" and args.batched_edits:
+        from sige_amd import stacked
+        from sige_amd.nn import dense as _dense
+
+        def build_pyr(mk):
+            return downsample_mask(dilate_mask(mk, 5), 8)
+
+        def place(e):  # (eight different places: the masks of a batch do not overlap much)
+            return square_mask(args.ratio, top=(16 + 61 * e) % 208, left=(24 + 97 * e) % 208).to(dev)
+
+        try:
+            with torch.no_grad():
+                model.set_compute_dtype(args.dtype)
+                model.set_mode("full")
+                model(x0, t)  # (a fresh, unpacked cache of the original: stacking replaces the cache tensors)
+                Es = [int(v) for v in args.batched_edits.split(",")]
+                emax = max(Es)
+                mks = [place(e) for e in range(emax)]
+                singles = []
+                for mk in mks:
+                    model.set_masks(build_pyr(mk))
+                    model.set_mode("sparse")
+                    xi = x0 + noise * mk
+                    model(xi, t)
+                    singles.append(model(xi, t).clone())
+                rows = []
+                wide_keep = dict(_dense.WIDE_MIN_FLOP_F32)
+                for E in Es:
+                    for route in (("tile",) if E == 1 else ("tile", "wide")):
+                        # `wide`: dense 3x3 layers of at least 8 GFLOP on the dense-layer kernel in its exact-fp32 form (stacking makes the
+                        # dense remainder E times as many pixels: matrix-bound there, 0.7-0.8 of the fp32 MFMA peak: DESIGN 3.7)
+                        _dense.WIDE_MIN_FLOP_F32 = {3: 8.0e9, 1: 1.0e30} if route == "wide" else dict(wide_keep)
+                        xe = torch.cat([x0 + noise * mk for mk in mks[:E]], 0).contiguous(memory_format=torch.channels_last)
+                        if E > 1:
+                            stacked.stack_caches(model, E)
+                        try:
+                            model.set_masks(stacked.stack_masks([build_pyr(mk) for mk in mks[:E]]) if E > 1 else build_pyr(mks[0]))
+                            model.set_mode("sparse")
+                            with stacked.edit_batch(model, E):
+                                gb, ob = capture(model, xe, t)
+                                kb = max(20, args.steps // 2)
+                                ms = timed_replays(gb, kb, 5, 1) * 1e3 / kb
+                                err = max(float((ob[e] - singles[e][0]).abs().max()) for e in range(E))
+                                n0 = hip.launch_count()
+                                tracer.log = []
+                                model(xe, t)
+                                trb, tracer.log = tracer.log, None
+                                nl = hip.launch_count() - n0
+                                _, _, kern_b, conv_tf_b, _ = kernel_families(trb)
+                                del trb, gb, ob
+                        finally:
+                            if E > 1:
+                                stacked.unstack_caches(model)
+                        rows.append({"edits": E, "dense_route": route, "ms_per_launch_set": round(ms, 4), "ms_per_edit": round(ms / E, 4),
+                                     "forwards_per_s": round(E / ms * 1e3, 1), "launches": nl,
+                                     "max_abs_vs_single_edit_forward": round(err, 8),
+                                     "block_conv_TFLOPs": round(conv_tf_b, 2), "block_conv_frac_of_mfma_peak": round(conv_tf_b / mfma_peak, 4),
+                                     "dense_conv_TFLOPs": kern_b.get("dense_conv_mfma", {}).get("TFLOPs"),
+                                     "block_conv_us": kern_b.get("block_conv_mfma", {}).get("us_total"),
+                                     "dense_remainder_us": kern_b.get("dense_conv_mfma", {}).get("us_total")})
+                _dense.WIDE_MIN_FLOP_F32 = wide_keep
+                base = next(r for r in rows if r["edits"] == 1)["forwards_per_s"]
+                best = {}
+                for r in rows:
+                    if r["edits"] not in best or r["forwards_per_s"] > best[r["edits"]]["forwards_per_s"]:
+                        best[r["edits"]] = r
+                batched = {"edit_ratio": args.ratio, "rows": rows,
+                           "speedup_forwards_per_s_vs_one_edit": {str(e): round(best[e]["forwards_per_s"] / base, 2) for e in sorted(best)},
+                           "note": "sige_amd/stacked.py + sige_hip_set_edit_batch: E edited versions of one original, each with its OWN mask at "
+                                   "its own place, stacked along H into one tall image (the same bytes as [E,C,H,W] channels-last; masks, "
+                                   "index lists, maps and the original's cache stacked alike): every layer is still ONE launch, which now "
+                                   "sees the active tiles of all E edits; halo rows across an image seam are zero padding inside the "
+                                   "kernels; first / last conv, attention and the output GroupNorm run per image with batch E.  "
+                                   "ms_per_edit = time of one stacked forward / E; parity against each edit's own single-edit forward "
+                                   "(fp32 summation order only).  The reference batches only under a SHARED mask (sige/cpu/gather.cpp:17-21)"}
+                # restore the single-edit state the sections below expect
+                model.set_mode("full")
+                model(x0, t)
+                flat = parallel.pack_caches(model)
+                prepare(args.ratio)
+        except Exception as e:  # (never the reason the headline dies)
+            batched = {"error": repr(e)[:400]}
+            try:
+                stacked.unstack_caches(model)
+                hip.set_edit_batch(1)
+            except Exception:
+                pass
+
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras and args.layout == "nhwc":
         for key, fn in (("gaugan", lambda: gaugan_section(dev, cpu_parity=args.cpu_seconds > 0)), ("sd_transformer", lambda: sd_transformer_section(dev))):
@@ -1557,6 +1649,8 @@ def main():
             line["f16x3_compute"] = x3
         if dyn is not None:
             line["dynamic"] = dyn
+        if batched is not None:
+            line["batched_edits"] = batched
         line.update(extras)
         if cpu is not None:
             line["cpu_baseline"] = cpu

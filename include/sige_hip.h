@@ -672,6 +672,20 @@ int sige_hip_scatter_gather_conv_scatter_nhwc_c16(
         float *twin1, const float *twin1_scale, const float *twin1_shift,
         float *out, void *stream);
 
+/* ---- stacked edits ("throughput mode"; not in the reference, whose batch shares ONE mask: sige/cpu/gather.cpp:17-21) ----
+ * E edited versions of one original image, each with ITS OWN mask, processed by one set of launches: every activation
+ * [E,C,H,W] (channels-last) is handed to this library as the tall image [1,C,E*H,W] -- the same bytes --, and masks, index
+ * lists, scatter maps, tile tables and the cached tensors are those of the tall image (the cache of the original repeated E
+ * times).  A launch then sees the active tiles of all E edits at once -- at a 1 % edit the sum of eight edits' tiles is what a
+ * 10 % edit has, and a launch leaves the launch-bound regime.  sige_hip_set_edit_batch(E) tells the library where the seams are:
+ * a halo row beyond a tile's own image is zero padding (not the neighbour image's pixels) in the channels-last fused gather /
+ * scatter_gather -> conv kernels and the dense-layer conv; entry points whose kernels have no seam test (NCHW forms, the
+ * standalone gathers, SPADE) return SIGE_HIP_EUNSUPPORTED while E > 1.  One image's height must be a power of two at every
+ * resolution.  Per host thread; 1 = off (default).  Whole-image ops (conv_in / conv_out, attention, GroupNorm) are simply
+ * called with B = E on the same memory (sige_amd/stacked.py).                                                          */
+int sige_hip_set_edit_batch(int E);
+int sige_hip_get_edit_batch(void);
+
 /* ---- launch plans: a sparse forward that survives a mask change -------------------------------------------------
  * The reference sizes every launch from `activeIndices.size(0)` at call time (sige/cuda/gather_kernel.cu:78-84,111 via
  * sige/utils.py:30 and sige/nn/gather.py:101-107), and two of its three applications run ONE sparse forward per mask

@@ -13,6 +13,34 @@ void sige::note_launches(int kernels) {
     if (kernels > 0 && hipGetDevice(&dev) == hipSuccess) g_last_device.store(dev, std::memory_order_relaxed);
 }
 
+// ---- stacked edits ("throughput mode") ----
+// E edited versions of ONE original image, each with its own mask, run as ONE tall image: every activation [E,C,H,W]
+// (channels-last) is handed over as [1,C,E*H,W] -- the same bytes --, masks and cached tensors are stacked the same way, and
+// every launch then sees the active tiles of all E edits at once (the sum of their tile counts: what lifts a 1 % edit out of the
+// launch-bound regime).  The only thing a kernel has to know is where one image ends: a halo row on the other side of a seam is
+// zero padding, not the neighbour's pixels.  Per host thread, like the conv-pair state.
+static thread_local int g_edit_batch = 1;
+
+int sige::stacked_shift(int H) {
+    const int E = g_edit_batch;
+    if (E <= 1) return 0;
+    if (H <= 0 || H % E) return -1;
+    const int hp = H / E;
+    if (hp < 4 || (hp & (hp - 1))) return -1;  // (one image's height must be a power of two: the seam test is a shift)
+    int s = 0;
+    while ((1 << s) < hp) ++s;
+    return s;
+}
+
+extern "C" int sige_hip_set_edit_batch(int E) {
+    if (sige::g_plan_rec) sige::plan_record<false>(&sige_hip_set_edit_batch, E);
+    if (E < 1 || E > 4096) return SIGE_HIP_EINVAL;
+    g_edit_batch = E;
+    return SIGE_HIP_OK;
+}
+
+extern "C" int sige_hip_get_edit_batch(void) { return g_edit_batch; }
+
 extern "C" int sige_hip_version(void) { return SIGE_HIP_VERSION; }
 
 extern "C" int64_t sige_hip_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }

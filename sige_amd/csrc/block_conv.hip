@@ -843,6 +843,7 @@ extern "C" int sige_hip_gather_conv_f32(const float *x, int B, int Cin, int H, i
     ConvArgs a{};
     a.x = x; a.idx = active_indices; a.packed = packed; a.bias = bias; a.out = out;
     a.T = B * N; a.Cin = Cin; a.Cout = Cout; a.B = B; a.N = N; a.H = H; a.W = W;
+    if (stacked_shift(H) != 0) return SIGE_HIP_EUNSUPPORTED;  // (stacked edits: channels-last fused kernels only)
     a.Csplit = Cin;
     a.x2 = x;
     a.scale = scale; a.shift = shift;
@@ -873,6 +874,7 @@ extern "C" int sige_hip_gather_conv_nchw_f32(const float *x, const float *x2, in
     ConvArgs a{};
     a.x = x; a.x2 = x2; a.Csplit = C1; a.idx = active_indices; a.packed = packed; a.bias = bias; a.out = out;
     a.T = B * N; a.Cin = Cin; a.Cout = Cout; a.B = B; a.N = N; a.H = H; a.W = W;
+    if (stacked_shift(H) != 0) return SIGE_HIP_EUNSUPPORTED;  // (stacked edits: channels-last fused kernels only)
     if (C2 && B != 1) return SIGE_HIP_EUNSUPPORTED;  // the two-tensor input is per image (conv_mfma.hpp)
     if (!x2) a.x2 = x;
     a.scale = scale; a.shift = shift;
@@ -903,6 +905,7 @@ extern "C" int sige_hip_scatter_gather_conv_f32(const float *x, const float *y, 
     ConvArgs a{};
     a.x = x; a.y = y; a.idx = active_indices; a.map = scatter_map; a.packed = packed; a.bias = bias; a.out = out;
     a.T = B * N; a.Cin = Cin; a.Cout = Cout; a.B = B; a.N = N; a.H = H; a.W = W;
+    if (stacked_shift(H) != 0) return SIGE_HIP_EUNSUPPORTED;  // (stacked edits: channels-last fused kernels only)
     a.RxSx = Rx * Sx; a.Sx = Sx;
     a.scale = scale; a.shift = shift;
     const int mode = staging_mode(scale, scaleB, scaleC, shift, shiftB, shiftC, activation, B, Cin, &a.aff_sb, &a.aff_sc);
@@ -990,6 +993,8 @@ static int gather_conv_nhwc_impl(const float *x, const float *x2, int B, int C1,
     ConvArgs a{};
     a.x = x; a.x2 = C2 ? x2 : x; a.Csplit = C1; a.idx = active_indices; a.packed = packed; a.bias = bias; a.out = out;
     a.T = B * N; a.Cin = Cin; a.Cout = Cout; a.B = B; a.N = N; a.H = H; a.W = W;
+    a.hp_shift = stacked_shift(H);  // (stacked edits: sige_hip_set_edit_batch)
+    if (a.hp_shift < 0 || (a.hp_shift && B != 1)) return SIGE_HIP_EUNSUPPORTED;
     a.scale = scale; a.shift = shift;
     const int mode = staging_mode(scale, scaleB, scaleC, shift, shiftB, shiftC, activation, B, Cin, &a.aff_sb, &a.aff_sc);
     if (mode < 0) return SIGE_HIP_EUNSUPPORTED;
@@ -1097,6 +1102,8 @@ static int scatter_gather_conv_nhwc_impl(const float *x, const float *y, int B, 
     a.y_f16 = y_f16 ? 1 : 0;
     a.x = x; a.y = y; a.idx = active_indices; a.map = scatter_map; a.packed = packed; a.bias = bias; a.out = out;
     a.T = B * N; a.Cin = Cin; a.Cout = Cout; a.B = B; a.N = N; a.H = H; a.W = W;
+    a.hp_shift = stacked_shift(H);  // (stacked edits: sige_hip_set_edit_batch)
+    if (a.hp_shift < 0 || (a.hp_shift && B != 1)) return SIGE_HIP_EUNSUPPORTED;
     a.RxSx = Rx * Sx; a.Sx = Sx;
     a.scale = scale; a.shift = shift;
     const int mode = staging_mode(scale, scaleB, scaleC, shift, shiftB, shiftC, activation, B, Cin, &a.aff_sb, &a.aff_sc);
@@ -1168,6 +1175,8 @@ static int scatter_gather_conv_scatter_nhwc_impl(
     a.y_f16 = y_f16 ? 1 : 0; a.res_f16 = res_f16 ? 1 : 0;
     a.x = x; a.y = y; a.idx = active_indices; a.map = scatter_map; a.packed = packed; a.bias = bias; a.out = out;
     a.T = B * N; a.Cin = Cin; a.Cout = Cout; a.B = B; a.N = N; a.H = H; a.W = W;
+    a.hp_shift = stacked_shift(H);  // (stacked edits: sige_hip_set_edit_batch)
+    if (a.hp_shift < 0 || (a.hp_shift && B != 1)) return SIGE_HIP_EUNSUPPORTED;
     a.RxSx = Rx * Sx; a.Sx = Sx;
     a.scale = scale; a.shift = shift;
     const int mode = staging_mode(scale, scaleB, scaleC, shift, shiftB, shiftC, activation, B, Cin, &a.aff_sb, &a.aff_sc);

@@ -83,6 +83,10 @@ __device__ __forceinline__ float affine_act(float z, const Bcast4 &scale, const 
     return z;
 }
 
+// (api.hip) stacked edits: E edited images stacked along H in every tensor a launch sees (sige_hip_set_edit_batch).  0 = off, else
+// log2 of the height of ONE image at a launch whose tensors are H rows tall; -1 = the launch cannot honour the mode.
+int stacked_shift(int H);
+
 // (api.hip) every entry point reports how many kernels it launched: sige_hip_launch_count()
 void note_launches(int kernels);
 

@@ -208,6 +208,9 @@ struct ConvArgs {
     // activated copy) holds halves -- a compile-time form of the kernel (Y16), this field picks it on the host; `residual`
     // holds halves (the cached shortcut tensor of a fused ScatterWithBlockResidual) -- a run-time branch of the epilogue
     int y_f16, res_f16;
+    // stacked edits (sige_hip_set_edit_batch): log2 of one image's height when E images are stacked along H (0 = off): a
+    // tile's halo rows beyond ITS image are zero padding (channels-last gather / scatter_gather staging)
+    int hp_shift;
 #ifdef SIGE_CONV_PROBE
     unsigned long long *probe;  // tools/conv_phase_probe.py build only: 8 timestamps per workgroup
 #endif
@@ -554,7 +557,12 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
                 off = z_live[i] ? (unsigned)((t * G::RS + z_p[i]) * Cin + c_l) * 4u : kOOB;
             } else {
                 const int h = z_h[i], w = z_w[i], b = z_b[i];
-                const bool in = z_live[i] && h >= 0 && h < a.H && w >= 0 && w < a.W;
+                int hlo = 0, hhi = a.H;
+                if (a.hp_shift) {  // (stacked edits: the image this tile belongs to -- its window's third row is always inside it)
+                    hlo = ((h - z_p[i] / G::R + 2) >> a.hp_shift) << a.hp_shift;
+                    hhi = hlo + (1 << a.hp_shift);
+                }
+                const bool in = z_live[i] && h >= hlo && h < hhi && w >= 0 && w < a.W;
                 z_live[i] = in;
                 const int hw = (SRC == SRC_GATHER) ? (h >> a.up) * (a.W >> a.up) + (w >> a.up) : h * a.W + w;
                 if (SRC == SRC_GATHER) {

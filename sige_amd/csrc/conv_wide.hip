@@ -203,6 +203,8 @@ extern "C" int sige_hip_wide_conv_nhwc(const float *x, const float *x2, int B, i
     a.probe = g_wprobe_buf;
 #endif
     a.B = B; a.H = H; a.W = W; a.C1 = C1; a.C2 = C2; a.Cout = Cout; a.up = upsample2x ? 1 : 0; a.act = activation;
+    a.hp_shift = stacked_shift(H);
+    if (a.hp_shift < 0 || (a.hp_shift && (B != 1 || (1 << a.hp_shift) % 8 || stats))) return SIGE_HIP_EUNSUPPORTED;  // (8-row patches must not straddle a seam)
     a.aff_sb = (scale && affineB > 1) ? C1 + C2 : 0;
     const int pwo = wide_patch(W);
     a.th = ceil_div(H, 8); a.tw = ceil_div(W, pwo); a.ntn = Cout / 64;

@@ -93,6 +93,7 @@ struct WideArgs {
     int ntn;                    // 64-channel output blocks
     int nchunks, nchunks1;      // channel chunks in total / in x
     int ksplit, chunks_per_split;
+    int hp_shift;               // stacked edits (sige_hip_set_edit_batch): log2 of one image's height, 0 = off
 #ifdef SIGE_WIDE_PROBE
     unsigned long long *probe;  // tools/probe/wide_phase_probe.py build only: 8 timestamps per workgroup
 #endif
@@ -139,13 +140,16 @@ __global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a
     unsigned voff[NS], voff2[CAT ? NS : 1];
     int ldsw[NS];
     unsigned livemask = 0;
+    // (stacked edits: rows of the halo patch beyond THIS patch's image are zero padding; patches never straddle a seam)
+    const int hlo = a.hp_shift ? ((ph0 >> a.hp_shift) << a.hp_shift) : 0;
+    const int hhi = a.hp_shift ? hlo + (1 << a.hp_shift) : a.H;
     static_for<0, NS>([&](auto i_tag) {
         constexpr int i = decltype(i_tag)::value;
         const int v = lane + 64 * i;
         const int p = v / G::QP, c4 = v % G::QP;
         const int hy = p / G::PW, hx = p - hy * G::PW;
         const int h = ph0 + hy - (G::KH == 3 ? 1 : 0), w = pw0 + hx - (G::KH == 3 ? 1 : 0);
-        const bool in = v < G::UNITS && h >= 0 && h < a.H && w >= 0 && w < a.W;
+        const bool in = v < G::UNITS && h >= hlo && h < hhi && w >= 0 && w < a.W;
         const int spx = (b * Hs + (h >> a.up)) * Ws + (w >> a.up);
         const int cb = wave * G::CW + c4 * 4;
         voff[i] = in ? (unsigned)(spx * a.C1 + cb) * 4u : kOOB;

@@ -674,6 +674,7 @@ extern "C" int sige_hip_gather_f32(const float *x, int B, int C, int H, int W, i
                                    const float *shift, int shiftB, int shiftC, int shiftH, int shiftW,
                                    int activation, int activation_first, float *out, void *stream) {
     SIGE_PLAN_HOOK_FIXED(sige_hip_gather_f32, x, B, C, H, W, bH, bW, active_indices, N, scale, scaleB, scaleC, scaleH, scaleW, shift, shiftB, shiftC, shiftH, shiftW, activation, activation_first, out, stream);
+    if (stacked_shift(H) != 0) return SIGE_HIP_EUNSUPPORTED;  // (stacked edits: channels-last fused kernels only)
     if (B < 0 || C < 0 || H < 0 || W < 0 || N < 0 || bH <= 0 || bW <= 0) return SIGE_HIP_EINVAL;
     if (H >= 32768 || W >= 32768) return SIGE_HIP_EUNSUPPORTED;
     if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
@@ -696,6 +697,7 @@ extern "C" int sige_hip_scatter_gather_f32(const float *x, const float *y, int B
                                            const float *shift, int shiftB, int shiftC, int shiftH, int shiftW,
                                            int activation, int activation_first, float *out, void *stream) {
     SIGE_PLAN_HOOK_FIXED(sige_hip_scatter_gather_f32, x, y, B, C, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, scaleH, scaleW, shift, shiftB, shiftC, shiftH, shiftW, activation, activation_first, out, stream);
+    if (stacked_shift(H) != 0) return SIGE_HIP_EUNSUPPORTED;  // (stacked edits: channels-last fused kernels only)
     if (B < 0 || C < 0 || H < 0 || W < 0 || N < 0 || bH <= 0 || bW <= 0 || Rx <= 0 || Sx <= 0) return SIGE_HIP_EINVAL;
     if (H >= 32768 || W >= 32768) return SIGE_HIP_EUNSUPPORTED;
     if ((long)N * C * Rx * Sx >= (1L << 31)) return SIGE_HIP_EUNSUPPORTED;

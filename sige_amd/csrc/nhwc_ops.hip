@@ -411,6 +411,7 @@ static int gather_nhwc_impl(const XT *x, int B, int C, int H, int W, int bH, int
                             int activation, float *out, void *stream) {
     if (B < 0 || C <= 0 || H <= 0 || W <= 0 || bH <= 0 || bW <= 0 || N < 0) return SIGE_HIP_EINVAL;
     if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
+    if (stacked_shift(H) != 0) return SIGE_HIP_EUNSUPPORTED;  // (stacked edits: a tile's halo would cross image seams; fused kernels only)
     if ((long)B * N == 0) return SIGE_HIP_OK;
     if (!x || !out || !active_indices) return SIGE_HIP_EINVAL;
     int aff_sb;
@@ -452,6 +453,7 @@ static int scatter_gather_nhwc_impl(const float *x, const CT *y, int B, int C, i
                                     int activation, float *out, void *stream) {
     if (B < 0 || C <= 0 || H <= 0 || W <= 0 || Rx <= 0 || Sx <= 0 || bH <= 0 || bW <= 0 || N < 0) return SIGE_HIP_EINVAL;
     if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
+    if (stacked_shift(H) != 0) return SIGE_HIP_EUNSUPPORTED;  // (stacked edits: a tile's halo would cross image seams; fused kernels only)
     if ((long)B * N == 0) return SIGE_HIP_OK;
     if (!x || !y || !out || !active_indices || !scatter_map) return SIGE_HIP_EINVAL;
     int aff_sb;
@@ -494,6 +496,7 @@ extern "C" int sige_hip_spade_modulate_nhwc_f32(
         int leaky, float slope, float *out, void *stream) {
     SIGE_PLAN_HOOK_N(sige_hip_spade_modulate_nhwc_f32, (sige::CountOf<24, 25>), x_full, x_tiles, map_x, Nx, Rx, Sx, scale, scaleB, scaleC, shift, shiftB, shiftC, gb_tiles, gb_full, map_g, Ng, Rg, Sg, B, C, H, W, bH, bW, active_indices, N, leaky, slope, out, stream);
     if (B < 0 || C <= 0 || H <= 0 || W <= 0 || bH <= 0 || bW <= 0 || N < 0 || Ng < 0 || Nx < 0) return SIGE_HIP_EINVAL;
+    if (stacked_shift(H) != 0) return SIGE_HIP_EUNSUPPORTED;
     if ((long)B * N == 0) return SIGE_HIP_OK;
     if (!x_full || !gb_full || !map_g || !active_indices || !out) return SIGE_HIP_EINVAL;
     if ((Ng > 0 && (!gb_tiles || Rg <= 0 || Sg <= 0)) || (x_tiles && (!map_x || Rx <= 0 || Sx <= 0))) return SIGE_HIP_EINVAL;

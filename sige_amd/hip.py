@@ -174,6 +174,8 @@ _SIGNATURES = {
     "sige_hip_scatter_gather_conv_scatter_nhwc_c16": (
         _c_int, [_c_int, _c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
         + [_c_int] * 3 + [_c_int, _c_int, _c_vp, _c_int] + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp] * 6 + [_c_vp, _c_vp]),
+    "sige_hip_set_edit_batch": (_c_int, [_c_int]),
+    "sige_hip_get_edit_batch": (_c_int, []),
     # launch plans (csrc/plan.hip; host side: sige_amd/plan.py)
     "sige_hip_plan_create": (_c_vp, []),
     "sige_hip_plan_destroy": (_c_int, [_c_vp]),
@@ -249,6 +251,16 @@ def lib():
         table.handle = handle
         _lib = table
     return _lib
+
+
+def set_edit_batch(E: int):
+    """Stacked edits (include/sige_hip.h: sige_hip_set_edit_batch; sige_amd/stacked.py): the tensors handed to the library from
+    now on (this thread) are E images stacked along H."""
+    _check(lib().sige_hip_set_edit_batch(int(E)), "set_edit_batch")
+
+
+def get_edit_batch() -> int:
+    return int(lib().sige_hip_get_edit_batch())
 
 
 def last_launch_device() -> int:

@@ -401,6 +401,7 @@ class AttnBlock(SIGEModule, _TwinProducer):
     def __init__(self, cfg: DDPMConfig, ch: int, sparse: bool):
         super().__init__()
         self.ch = ch
+        self.edit_batch = 1  # (sige_amd.stacked: E images stacked along H; attention is per image)
         self.twin_regs = {}
         self.quirk = cfg.reference_attn_quirk
         self.sparse = sparse and cfg.shortcut_block is not None
@@ -452,6 +453,11 @@ class AttnBlock(SIGEModule, _TwinProducer):
 
 
     def _attention(self, qkv):
+        if self.edit_batch > 1 and qkv.shape[0] == 1:
+            # stacked edits: the tall image is E images -- tokens attend within their own image (the same bytes seen as batch E)
+            from ..stacked import tall, untall
+
+            return tall(self._attention(untall(qkv, self.edit_batch)))
         b, _, hh, ww = qkv.shape
         if qkv.is_cuda and qkv.dtype == torch.float32:
             from .. import hip
@@ -557,6 +563,7 @@ class DDPMSparseUNet(SIGEModel):
     def __init__(self, cfg: DDPMConfig = DDPMConfig()):
         super().__init__()
         self.cfg = cfg
+        self.edit_batch = 1  # (sige_amd.stacked.edit_batch: E edits of one original stacked along H in every sparse-mode tensor)
         ch, mult = cfg.ch, tuple(cfg.ch_mult)
         self.ch, self.temb_ch = ch, 4 * ch
         self.num_levels = len(mult)
@@ -645,6 +652,15 @@ class DDPMSparseUNet(SIGEModel):
         h0 = input_conv2d(self.conv_in, x) if (self.mode == "sparse" or native_full) else self.conv_in(x)
         if x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous():
             h0 = h0.contiguous(memory_format=torch.channels_last)  # (MIOpen may hand back NCHW for 3 input channels)
+        E = self.edit_batch
+        if E > 1:
+            # stacked edits (sige_amd/stacked.py): x is [E,3,H,W]; from here to the output norm every tensor is the tall image
+            # [1,C,E*H,W] -- the same bytes -- and every sparse module works on it unchanged
+            if self.mode != "sparse" or x.shape[0] != E:
+                raise RuntimeError("stacked edits: sparse mode, one input image per edit")
+            from ..stacked import tall, untall
+
+            h0 = tall(h0)
         hs = [h0]
         for lvl, stage in enumerate(self.down):
             for i, block in enumerate(stage.block):
@@ -668,6 +684,8 @@ class DDPMSparseUNet(SIGEModel):
             if lvl != 0:
                 h = stage.upsample(h)
         if self.mode == "sparse" or native_full:
+            if E > 1:
+                h = untall(h, E)  # (the output norm and the last conv are per image)
             # the output norm is a TRUE GroupNorm of the edited activation (sige_fused_unet.py:430-432)
             so, to = group_norm_affine(h, self.norm_out)
             return fused_conv2d(self.conv_out, h, so, to, "swish")

@@ -374,3 +374,51 @@ def test_device_guard_on_one_gpu(hip, monkeypatch):
     assert torch.equal(gs, want_s)
     torch.cuda.synchronize()
     assert torch.cuda.current_device() == real  # (every guard restored the device it found)
+
+
+# ---- stacked edits: E edits of one original, each with its own mask, in one set of launches -------------------
+def test_stacked_edits_match_single_edits(hip, ddpm_pair):
+    """sige_amd/stacked.py + sige_hip_set_edit_batch: four edits of different size and place -- one touching the TOP rows of its
+    image and one the BOTTOM rows, so that tiles whose halo crosses a seam of the tall image are active on both sides -- through
+    one stacked forward: every edit's output equals its own single-edit forward (fp32 summation order only: another tile count
+    picks another output block / K split), in ~the same number of launches as ONE single-edit forward."""
+    from sige_amd import stacked
+
+    model, _, x0, noise, t = ddpm_pair
+    places = [(0.012, 100, 90), (0.02, 0, 40), (0.03, 256 - 44, 150), (0.05, 60, 10)]
+    masks = [_mask(*p) for p in places]
+    E = len(masks)
+    with torch.no_grad():
+        singles = []
+        for m in masks:
+            model.set_masks(_build_masks(m))
+            model.set_mode("sparse")
+            x1 = x0 + noise * m
+            model(x1, t)
+            n0 = hip.launch_count()
+            singles.append(model(x1, t).clone())
+            single_launches = hip.launch_count() - n0
+        xe = _cl(torch.cat([x0 + noise * m for m in masks], 0))
+        stacked.stack_caches(model, E)
+        try:
+            model.set_masks(stacked.stack_masks([_build_masks(m) for m in masks]))
+            with stacked.edit_batch(model, E):
+                model(xe, t)
+                model(xe, t)
+                n0 = hip.launch_count()
+                out = model(xe, t).clone()
+                launches = hip.launch_count() - n0
+            assert tuple(out.shape) == (E, 3, 256, 256)
+            for e in range(E):
+                err = float((out[e] - singles[e][0]).abs().max())
+                assert err < 1e-4, (e, err)
+            assert launches <= single_launches + 4, (launches, single_launches)
+            # without the seam test the halo of a tile at an image's first row would read the previous image's last row: the two
+            # edits at the seams are exactly where that would show (checked above); and the mode is per thread and switched off
+            assert hip.get_edit_batch() == 1
+        finally:
+            stacked.unstack_caches(model)
+        # back to single edits on the same model
+        model.set_masks(_build_masks(masks[0]))
+        model(x0 + noise * masks[0], t)
+        assert float((model(x0 + noise * masks[0], t) - singles[0]).abs().max()) < 1e-6

@@ -747,6 +747,53 @@ def test_fp16_stored_cache_host_logic_on_the_oracle_backend():
         runtime.unregister_backend("cpu")
 
 
+def test_stacked_edits_bookkeeping_off_the_gpu(cpu_oracle_backend):
+    """sige_amd/stacked.py: the tall-image views, the stacked mask pyramid, stacking / unstacking of a model's caches (values
+    repeated E times along H, Gather / Scatter resolutions scaled, everything restored afterwards).  The seam semantics live in
+    the HIP kernels (a -m gpu test); off the GPU the library refuses the mode rather than bleeding across seams."""
+    from sige_amd import stacked
+    from sige_amd.nn import Gather, Scatter, ScatterGather, ScatterWithBlockResidual
+
+    x = torch.randn(3, 8, 4, 6).contiguous(memory_format=torch.channels_last)
+    tl = stacked.tall(x)
+    assert tuple(tl.shape) == (1, 8, 12, 6) and tl.data_ptr() == x.data_ptr() and torch.equal(tl[0, :, 4:8], x[1])
+    back = stacked.untall(tl, 3)
+    assert torch.equal(back, x) and back.data_ptr() == x.data_ptr()
+    pyr = [{(8, 8): torch.rand(8, 8) > 0.5, (4, 4): torch.rand(4, 4) > 0.5} for _ in range(3)]
+    st = stacked.stack_masks(pyr)
+    assert set(st) == {(24, 8), (12, 4)} and torch.equal(st[(24, 8)][8:16], pyr[1][(8, 8)])
+
+    torch.manual_seed(0)
+    net = ResNet(8, 12).eval()
+    blk = net.block
+    blk.s1, blk.t1 = torch.randn(1, 8, 1, 1), torch.randn(1, 8, 1, 1)
+    blk.s2, blk.t2 = torch.randn(1, 12, 1, 1), torch.randn(1, 12, 1, 1)
+    orig = torch.randn(1, 8, 32, 32)
+    with torch.no_grad():
+        net.set_mode("full")
+        net(orig)
+    before = {(id(m), n, k): v.clone() for m in net.modules() for n in ("original_outputs", "original_residuals")
+              for k, v in getattr(m, n, {}).items()}
+    res_before = {id(m): tuple(m.input_res) for m in net.modules() if isinstance(m, Gather)}
+    stacked.stack_caches(net, 3)
+    for m in net.modules():
+        if isinstance(m, (Scatter, ScatterGather, ScatterWithBlockResidual)):
+            for n in ("original_outputs", "original_residuals"):
+                for k, v in getattr(m, n, {}).items():
+                    assert v.shape[2] == 96 and torch.equal(v[:, :, 32:64], before[(id(m), n, k)])
+        if isinstance(m, Gather):
+            assert tuple(m.input_res) == (3 * res_before[id(m)][0], res_before[id(m)][1])
+    with pytest.raises(RuntimeError, match="stacked already"):
+        stacked.stack_caches(net, 2)
+    stacked.unstack_caches(net)
+    for m in net.modules():
+        for n in ("original_outputs", "original_residuals"):
+            for k, v in getattr(m, n, {}).items():
+                assert torch.equal(v, before[(id(m), n, k)])
+        if isinstance(m, Gather):
+            assert tuple(m.input_res) == res_before[id(m)]
+
+
 def test_twin_buffers_follow_cache_and_masks():
     """scatter._TwinBuffers (the persistent activated twins of a Scatter module's in-place output): built from the cache,
     rebuilt when the mask stamp or the cache generation changes, refreshed in place when the cache is rewritten in place,
