@@ -466,12 +466,12 @@ def gaugan_section(dev, cpu_parity=True):
     from sige_amd.utils import compute_difference_mask, dilate_mask, downsample_mask
     from sige_amd.workloads.gaugan_spade import SPADEConfig, SpadeGenerator
 
-    def labels():
+    def labels(dy=0, dx=0):
         rs = np.random.RandomState(3)
         coarse = rs.randint(0, 36, size=(32, 64))
         lab0 = np.kron(coarse, np.ones((8, 8), dtype=np.int64))
         lab1 = lab0.copy()
-        lab1[85:136, 128:256] = (lab0[85:136, 128:256] + 5) % 36
+        lab1[85 + dy:136 + dy, 128 + dx:256 + dx] = (lab0[85 + dy:136 + dy, 128 + dx:256 + dx] + 5) % 36
         oh = lambda l: torch.nn.functional.one_hot(torch.from_numpy(l), 36).permute(2, 0, 1)[None].float().contiguous()  # noqa: E731
         return oh(lab0), oh(lab1)
 
@@ -511,6 +511,32 @@ def gaugan_section(dev, cpu_parity=True):
             res[name] = {"forward_ms": round(ms, 3), "speedup_vs_dense": round(dense_ms / ms, 2), "hip_kernel_launches": launches}
             del g
         model.cfg.fused = True
+        # the generator's REAL per-edit latency: the reference runs ONE sparse forward per edit (gaugan/runner.py:150-195), so what
+        # a user waits for is difference mask + set_masks + the first (eager) forward under the new mask -- not a graph replay
+        import statistics
+
+        lat = {"difference_mask_and_set_masks": [], "first_forward_eager": []}
+        for i, (dy, dx) in enumerate(((20, 40), (-40, -60), (60, 120), (0, -100), (35, 10))):
+            xi = cl(labels(dy, dx)[1])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            d_i = compute_difference_mask(x0, xi)
+            model.set_masks(downsample_mask(dilate_mask(d_i, 1), (model.sh, model.sw), dilation=2))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            model(xi)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            if i:  # (the first one warms the allocator up)
+                lat["difference_mask_and_set_masks"].append((t1 - t0) * 1e3)
+                lat["first_forward_eager"].append((t2 - t1) * 1e3)
+        med = {k: round(statistics.median(v), 3) for k, v in lat.items()}
+        res["per_edit_latency_ms"] = dict(med, to_first_output=round(sum(med.values()), 3),
+                                          note="a NEW edit of the same original: difference mask + set_masks + the first eager forward "
+                                               "(what gaugan/runner.py:150-195 does per edit); forward_ms above is the hipGraph replay of "
+                                               "an unchanged mask.  A launch plan (sige_amd/plan.py) does not apply yet: this generator's "
+                                               "forward still contains torch kernels (nearest upsampling x13, fc / conv_img on MIOpen), "
+                                               "which a plan cannot record")
     res["dense_forward_ms"] = round(dense_ms, 3)
     res["edit_ratio"] = round(float(diff.float().mean()), 4)
     res["fused_vs_chain_max_abs"] = round(float((outs["fused_spade_modulation"] - outs["module_chain"]).abs().max()), 8)
