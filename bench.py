@@ -308,6 +308,22 @@ def kernel_families(trace):
     return fam, per_cfg, kernels, conv_tflops, hot_us
 
 
+def flop_by_compute(trace):
+    """Conv FLOPs of one traced forward by the arithmetic they ran in ("f32" exact, "f16" operands, "f16x3" split operands): how
+    the packed weights of each conv call were laid out (hip.PackedWeights.compute)."""
+    by = {}
+    for name, a, k, orig in trace:
+        fam, nbytes, flops = op_cost(name, a, k)
+        if not flops:
+            continue
+        comp = next((getattr(v, "compute", "f32") for v in list(a) + list((k or {}).values())
+                     if isinstance(v, torch.Tensor) and type(v).__name__ == "PackedWeights"), "f32")
+        comp = comp[:-1] if comp.endswith("w") else comp  # (wide packs are tagged "f16w" / "f16x3w" / "f32w")
+        by[comp] = by.get(comp, 0.0) + flops
+    tot = sum(by.values()) or 1.0
+    return {c: round(v / tot, 4) for c, v in sorted(by.items())}
+
+
 def capture(model, x, t):
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
@@ -1193,12 +1209,14 @@ def main():
                 model(xs, t)
                 tr16, tracer.log = tracer.log, None
                 _, _, _, conv_tf_r, _ = kernel_families(tr16)
+                frac16 = flop_by_compute(tr16)
                 gs, outs = capture(model, xs, t)
                 k = max(20, args.steps // 4)
                 ms = timed_replays(gs, k, 5, 1) * 1e3 / k
                 gpu_out_f16[r] = outs.float().cpu()
                 rows.append({"edit_ratio": r, "forward_ms": round(ms, 3), "speedup_vs_dense_fp32": round(dense_ms / ms, 2),
-                             "block_conv_TFLOPs": round(conv_tf_r, 2), "kept_at_higher_precision": list(model.compute_policy["keep"])})
+                             "block_conv_TFLOPs": round(conv_tf_r, 2), "kept_at_higher_precision": list(model.compute_policy["keep"]),
+                             "conv_flop_fraction_by_arithmetic": frac16, "fp16_flop_fraction": frac16.get("f16", 0.0)})
                 del tr16
                 del gs, outs
             model.set_compute_dtype("f16", edit_ratio=args.ratio)
@@ -1515,7 +1533,10 @@ def main():
                         if E > 1:
                             stacked.stack_caches(model, E)
                         try:
-                            model.set_masks(stacked.stack_masks([build_pyr(mk) for mk in mks[:E]]) if E > 1 else build_pyr(mks[0]))
+                            if E > 1:
+                                stacked.set_masks(model, [build_pyr(mk) for mk in mks[:E]])
+                            else:
+                                model.set_masks(build_pyr(mks[0]))
                             model.set_mode("sparse")
                             with stacked.edit_batch(model, E):
                                 gb, ob = capture(model, xe, t)

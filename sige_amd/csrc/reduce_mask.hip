@@ -15,7 +15,7 @@ constexpr int kRMThreads = 1024;
 
 __global__ __launch_bounds__(kRMThreads) void reduce_mask_kernel(
         const uint8_t *__restrict__ mask, int H, int W, int bH, int bW, int strH, int strW, int padH, int padW,
-        int gh, int gw, int32_t *__restrict__ indices, int capacity, int32_t *__restrict__ count) {
+        int gh, int gw, int32_t *__restrict__ indices, int capacity, int32_t *__restrict__ count, int hp_shift) {
     __shared__ int s_wave[kRMThreads / kWave];
     __shared__ int s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -30,7 +30,16 @@ __global__ __launch_bounds__(kRMThreads) void reduce_mask_kernel(
             const int i = cand / gw, j = cand - i * gw;
             h0 = i * strH - padH;
             w0 = j * strW - padW;
-            const int ha = max(h0, 0), hb = min(h0 + bH, H);
+            int ha = max(h0, 0), hb = min(h0 + bH, H);
+            if (hp_shift) {
+                // stacked edits (sige_hip_set_edit_batch): the mask is E masks stacked along H; a candidate belongs to the image its
+                // window's third row lies in (the rule of the conv kernels' seam test) and only looks at THAT image's rows -- so the
+                // list is exactly the per-edit lists, one after the other (a window reaching into the neighbour's mask would
+                // activate a tile the single-edit forward leaves cached)
+                const int lo = ((h0 + 2) >> hp_shift) << hp_shift;
+                ha = max(ha, lo);
+                hb = min(hb, lo + (1 << hp_shift));
+            }
             const int wa = max(w0, 0), wb = min(w0 + bW, W);
             for (int h = ha; h < hb && !active; ++h)
                 for (int w = wa; w < wb; ++w)
@@ -76,7 +85,9 @@ extern "C" int sige_hip_reduce_mask_i32(const uint8_t *mask, int H, int W, int b
         return SIGE_HIP_EINVAL;
     if (!mask || !count || (capacity && !indices)) return SIGE_HIP_EINVAL;
     const int gh = (H + padH) / strideH + 1, gw = (W + padW) / strideW + 1;
+    const int hp_shift = stacked_shift(H);
+    if (hp_shift < 0) return SIGE_HIP_EUNSUPPORTED;
     reduce_mask_kernel<<<1, kRMThreads, 0, as_stream(stream)>>>(mask, H, W, bH, bW, strideH, strideW, padH, padW,
-                                                               gh, gw, indices, capacity, count);
+                                                               gh, gw, indices, capacity, count, hp_shift);
     return launch_status();
 }

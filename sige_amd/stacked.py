@@ -11,7 +11,7 @@ padding): hip.set_edit_batch(E).  Whole-image ops (first / last conv, attention,
 same memory.
 
     stacked.stack_caches(model, E)              # after the full pass on the original (B = 1)
-    model.set_masks(stacked.stack_masks([pyramid_of_edit_0, ..., pyramid_of_edit_{E-1}]))
+    stacked.set_masks(model, [pyramid_of_edit_0, ..., pyramid_of_edit_{E-1}])
     with stacked.edit_batch(model, E):
         out = model(x_edits, t)                 # x_edits [E,3,H,W] -> out [E,3,H,W]
     stacked.unstack_caches(model)               # back to single edits
@@ -47,6 +47,19 @@ def stack_masks(pyramids: List[Dict]) -> Dict:
             raise ValueError("stack_masks: the pyramids must have the same levels")
     E = len(pyramids)
     return {(E * h, w): torch.cat([p[(h, w)] for p in pyramids], dim=0).contiguous() for (h, w) in keys}
+
+
+def set_masks(model: torch.nn.Module, pyramids: List[Dict]) -> None:
+    """`model.set_masks` for E edits: the stacked pyramid, with the library told about the seams while the index lists are built
+    -- a candidate tile only looks at ITS image's mask rows, so the lists are exactly the per-edit lists one after the other (a
+    window reaching into the neighbour's mask would activate a tile that the edit's own single forward leaves cached)."""
+    E = len(pyramids)
+    prev = hip.get_edit_batch()
+    hip.set_edit_batch(E)
+    try:
+        model.set_masks(stack_masks(pyramids))
+    finally:
+        hip.set_edit_batch(prev)
 
 
 def _cache_dicts(model):

@@ -103,12 +103,13 @@ def test_launch_plan_follows_mask_changes(hip, ddpm_pair):
             seen.add(tuple(plan.counts))
         assert len(seen) >= 5  # (the masks really had different tile counts)
         assert launches_per_run is not None and launches_per_run <= 110
-        # an empty edit: every count 0, the output is the forward of the cached original outside... nothing to compare tile by
-        # tile, but it must run and equal the module-level result under the same (empty) mask
+        # an EMPTY difference mask: the reference's pyramid thresholds at min(0.3, max - eps) = -eps (sige/utils.py:88-118), i.e.
+        # every pixel counts as edited -- every candidate tile is active: the largest counts there are, which is exactly what the
+        # plan's buffers are sized for
         empty = torch.zeros_like(masks[0])
         xs.copy_(x0)
         plan.bind_mask(empty)
-        assert sum(plan.counts) == 0
+        assert max(plan.counts) == 65 * 65 and all(c > 0 for c in plan.counts)
         got = plan.run().clone()
         ref.set_masks(_build_masks(empty))
         assert torch.equal(got, ref(x0, t))
@@ -279,12 +280,18 @@ def test_ksplit_finish_stress_two_streams(hip):
         for a, b in zip(want_w, want_w1):
             torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-4)
         streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-        bad = torch.zeros(1, device=DEV)
+        stats = {}
         n = 0
 
-        def check(outs):
+        def check(tag, outs):
             for i, kind, o in outs:
-                bad.add_((o != (want_w if kind else want)[i]).any())
+                d = (o - (want_w if kind else want)[i]).abs()
+                nbad = int((d > 0).sum())
+                if nbad:
+                    st_ = stats.setdefault((tag, "wide" if kind else "tile"), [0, 0, 0.0])
+                    st_[0] += 1
+                    st_[1] += nbad
+                    st_[2] = max(st_[2], float(d.max()))
 
         # (a) eager launches, two streams issuing in turn (tickets from the shared ring, workspaces from the allocator)
         for rnd in range(5):
@@ -297,7 +304,7 @@ def test_ksplit_finish_stress_two_streams(hip):
                         outs[si].append((i, 1, wide[i]()))
                         n += 2
             torch.cuda.synchronize()
-            check(outs[0] + outs[1])
+            check("eager", outs[0] + outs[1])
             del outs
         # (b) two hipGraphs of 200 launches each, replayed CONCURRENTLY on the two streams (the host cannot issue eager launches
         #     fast enough to keep two streams busy): 2 x 200 x 20 launches really overlapping on the chip
@@ -318,12 +325,10 @@ def test_ksplit_finish_stress_two_streams(hip):
                 with torch.cuda.stream(st):
                     gph.replay()
             n += 400
-            if rep % 5 == 4:
-                torch.cuda.synchronize()
-                check(graphs[0][1] + graphs[1][1])
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            check("graphs", graphs[0][1] + graphs[1][1])
         assert n == 10000
-        assert float(bad) == 0.0
+        assert not stats, {k: v for k, v in stats.items()}  # (tag, kernel) -> [launches, elements, max |d|] that differed
         del graphs
     finally:
         hip.conv_force_ksplit(0)
@@ -401,7 +406,7 @@ def test_stacked_edits_match_single_edits(hip, ddpm_pair):
         xe = _cl(torch.cat([x0 + noise * m for m in masks], 0))
         stacked.stack_caches(model, E)
         try:
-            model.set_masks(stacked.stack_masks([_build_masks(m) for m in masks]))
+            stacked.set_masks(model, [_build_masks(m) for m in masks])
             with stacked.edit_batch(model, E):
                 model(xe, t)
                 model(xe, t)
