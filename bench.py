@@ -1525,10 +1525,14 @@ def main():
                 rows = []
                 wide_keep = dict(_dense.WIDE_MIN_FLOP_F32)
                 for E in Es:
-                    for route in (("tile",) if E == 1 else ("tile", "wide")):
-                        # `wide`: dense 3x3 layers of at least 8 GFLOP on the dense-layer kernel in its exact-fp32 form (stacking makes the
-                        # dense remainder E times as many pixels: matrix-bound there, 0.7-0.8 of the fp32 MFMA peak: DESIGN 3.7)
-                        _dense.WIDE_MIN_FLOP_F32 = {3: 8.0e9, 1: 1.0e30} if route == "wide" else dict(wide_keep)
+                    routes = ("tile",) if E == 1 else (("tile", "wide", "wide2", "f16x3") if E == emax and args.dtype == "f32" else ("tile", "wide"))
+                    for route in routes:
+                        # `wide` / `wide2`: dense 3x3 layers of at least 8 / 2 GFLOP on the dense-layer kernel in its exact-fp32 form
+                        # (stacking makes the dense remainder E times as many pixels: matrix-bound there, 0.7-0.8 of the fp32 MFMA peak:
+                        # DESIGN 3.7); `f16x3`: split fp16 operands (fp32-level results) wherever a launch is matrix-bound
+                        _dense.WIDE_MIN_FLOP_F32 = ({3: 8.0e9, 1: 1.0e30} if route == "wide" else {3: 2.0e9, 1: 1.0e30} if route == "wide2"
+                                                    else dict(wide_keep))
+                        model.set_compute_dtype("f16x3" if route == "f16x3" else args.dtype)
                         xe = torch.cat([x0 + noise * mk for mk in mks[:E]], 0).contiguous(memory_format=torch.channels_last)
                         if E > 1:
                             stacked.stack_caches(model, E)
@@ -1559,8 +1563,12 @@ def main():
                                      "block_conv_TFLOPs": round(conv_tf_b, 2), "block_conv_frac_of_mfma_peak": round(conv_tf_b / mfma_peak, 4),
                                      "dense_conv_TFLOPs": kern_b.get("dense_conv_mfma", {}).get("TFLOPs"),
                                      "block_conv_us": kern_b.get("block_conv_mfma", {}).get("us_total"),
-                                     "dense_remainder_us": kern_b.get("dense_conv_mfma", {}).get("us_total")})
+                                     "dense_remainder_us": kern_b.get("dense_conv_mfma", {}).get("us_total"),
+                                     "dense_conv_wide": kern_b.get("dense_conv_wide")})
+                        if E == emax:
+                            rows[-1]["kernels"] = kern_b
                 _dense.WIDE_MIN_FLOP_F32 = wide_keep
+                model.set_compute_dtype(args.dtype)
                 base = next(r for r in rows if r["edits"] == 1)["forwards_per_s"]
                 best = {}
                 for r in rows:
