@@ -906,7 +906,7 @@ def main():
                          "the same fp16-rounded cache; the cached affines stay fp32).  Only with --dtype f16: the rounding costs up to "
                          "1.6e-3 of output error at 15 %% edit (profiles/r3_f16_cache_trace.json) -- inside the f16 criterion, outside "
                          "the fp32 path's 1e-3")
-    ap.add_argument("--batched-edits", default="1,2,4,8",
+    ap.add_argument("--batched-edits", default="1,2,4,8,16",
                     help="stacked edits (sige_amd/stacked.py): batch sizes E of the throughput section, '' = skip")
     ap.add_argument("--cache-dtype", default="auto", choices=["auto", "f32", "f16"],
                     help="how the full pass's cached activations are STORED (SIGEModel.set_cache_dtype): auto = f16 with --dtype f16 "
@@ -1510,6 +1510,8 @@ def main():
         try:
             with torch.no_grad():
                 model.set_compute_dtype(args.dtype)
+                model.clear_cache()  # (the multi-step section left one cache per cache id)
+                model.set_cache_id(0)
                 model.set_mode("full")
                 model(x0, t)  # (a fresh, unpacked cache of the original: stacking replaces the cache tensors)
                 Es = [int(v) for v in args.batched_edits.split(",")]
@@ -1584,6 +1586,7 @@ def main():
                                    "ms_per_edit = time of one stacked forward / E; parity against each edit's own single-edit forward "
                                    "(fp32 summation order only).  The reference batches only under a SHARED mask (sige/cpu/gather.cpp:17-21)"}
                 # restore the single-edit state the sections below expect
+                model.clear_cache()
                 model.set_mode("full")
                 model(x0, t)
                 flat = parallel.pack_caches(model)
