@@ -682,7 +682,10 @@ int sige_hip_scatter_gather_conv_scatter_nhwc_c16(
  * scatter_gather -> conv kernels and the dense-layer conv; entry points whose kernels have no seam test (NCHW forms, the
  * standalone gathers, SPADE) return SIGE_HIP_EUNSUPPORTED while E > 1.  One image's height must be a power of two at every
  * resolution.  Per host thread; 1 = off (default).  Whole-image ops (conv_in / conv_out, attention, GroupNorm) are simply
- * called with B = E on the same memory (sige_amd/stacked.py).                                                          */
+ * called with B = E on the same memory (sige_amd/stacked.py).  The mask pipeline follows: sige_hip_reduce_mask_i32 lets a
+ * candidate tile see only its own image's mask rows, sige_hip_dilate_mask_u8 does not dilate across a seam, and
+ * sige_hip_mask_pyramid_u8 builds the pyramid of every image with that image's own maxima and thresholds (one workgroup per
+ * image; min_h applies to one image) -- so the index lists of a stacked mask are exactly the per-edit lists.            */
 int sige_hip_set_edit_batch(int E);
 int sige_hip_get_edit_batch(void);
 

@@ -34,11 +34,13 @@ __global__ void difference_mask_kernel(const float *__restrict__ a, const float 
     }
 }
 
-__device__ __forceinline__ uint8_t dilated(const uint8_t *__restrict__ m, int H, int W, int h, int w, int dH, int dW) {
+// (lo, hi): the rows of the image pixel (h, w) belongs to -- [0, H) normally; with stacked edits (sige_hip_set_edit_batch) the
+// mask is E masks stacked along H and a dilation must not reach into the neighbour's rows
+__device__ __forceinline__ uint8_t dilated(const uint8_t *__restrict__ m, int W, int h, int w, int dH, int dW, int lo, int hi) {
     if (m[(size_t)h * W + w]) return 1;
     for (int i = 1; i <= dH; ++i) {
-        if (h - i >= 0 && m[(size_t)(h - i) * W + w]) return 1;
-        if (h + i < H && m[(size_t)(h + i) * W + w]) return 1;
+        if (h - i >= lo && m[(size_t)(h - i) * W + w]) return 1;
+        if (h + i < hi && m[(size_t)(h + i) * W + w]) return 1;
     }
     for (int i = 1; i <= dW; ++i) {
         if (w - i >= 0 && m[(size_t)h * W + (w - i)]) return 1;
@@ -47,20 +49,31 @@ __device__ __forceinline__ uint8_t dilated(const uint8_t *__restrict__ m, int H,
     return 0;
 }
 
-__global__ void dilate_mask_kernel(const uint8_t *__restrict__ mask, int H, int W, int dH, int dW, uint8_t *__restrict__ out) {
+__global__ void dilate_mask_kernel(const uint8_t *__restrict__ mask, int H, int W, int dH, int dW, uint8_t *__restrict__ out, int hp) {
     const long n = (long)H * W;
-    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (long)gridDim.x * blockDim.x)
-        out[p] = dilated(mask, H, W, (int)(p / W), (int)(p % W), dH, dW);
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (long)gridDim.x * blockDim.x) {
+        const int h = (int)(p / W);
+        const int lo = (h / hp) * hp;
+        out[p] = dilated(mask, W, h, (int)(p % W), dH, dW, lo, lo + hp);
+    }
 }
 
 // One workgroup, all levels.  level_a / level_b: float ping-pong (H*W and (H/2)*(W/2) floats), bits: H*W bytes of scratch
 // for the thresholded (not yet dilated) bits of the current level, out: the packed pyramid (level k after level k-1).
 __global__ __launch_bounds__(kMPThreads) void mask_pyramid_kernel(
         const uint8_t *__restrict__ mask, int H, int W, int min_h, int min_w, int dH, int dW, float threshold, float eps,
-        float *__restrict__ level_a, float *__restrict__ level_b, uint8_t *__restrict__ bits, uint8_t *__restrict__ out) {
+        float *__restrict__ level_a, float *__restrict__ level_b, uint8_t *__restrict__ bits, uint8_t *__restrict__ out,
+        size_t scratch_stride_floats) {
     __shared__ float s_max[kMPThreads / kWave];
     __shared__ float s_t;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // stacked edits: workgroup e builds the pyramid of image e (H = ONE image's height; its own maxima and thresholds, as the
+    // edit's own downsample_mask call would) and writes its rows of every level of the TALL pyramid
+    const int E = gridDim.x, e = blockIdx.x;
+    mask += (size_t)e * H * W;
+    level_a += (size_t)e * scratch_stride_floats;
+    level_b += (size_t)e * scratch_stride_floats;
+    bits += (size_t)e * scratch_stride_floats * 4;
     int h = H, w = W;
     const float *cur = nullptr;  // nullptr: level 0 = the byte mask itself
     float *nxt = level_a;
@@ -87,8 +100,8 @@ __global__ __launch_bounds__(kMPThreads) void mask_pyramid_kernel(
         for (long p = tid; p < n; p += kMPThreads) bits[p] = (cur ? cur[p] : (mask[p] ? 1.0f : 0.0f)) > t ? 1 : 0;
         __syncthreads();
         // (3) dilated bits -> the packed output
-        for (long p = tid; p < n; p += kMPThreads) out[out_off + p] = dilated(bits, h, w, (int)(p / w), (int)(p % w), dH, dW);
-        out_off += (size_t)n;
+        for (long p = tid; p < n; p += kMPThreads) out[out_off + (size_t)e * n + p] = dilated(bits, w, (int)(p / w), (int)(p % w), dH, dW, 0, h);
+        out_off += (size_t)E * n;
         const int h2 = h / 2, w2 = w / 2;
         if (h2 < min_h && w2 < min_w) break;
         if (h2 <= 0 || w2 <= 0) break;  // (host side never asks for this: guards the division below)
@@ -142,7 +155,9 @@ extern "C" int sige_hip_dilate_mask_u8(const uint8_t *mask, int H, int W, int di
     if (!mask || !out || mask == out) return SIGE_HIP_EINVAL;
     const long n = (long)H * W;
     const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    dilate_mask_kernel<<<blocks, 256, 0, as_stream(stream)>>>(mask, H, W, dilationH, dilationW, out);
+    const int sh = stacked_shift(H);  // (stacked edits: a dilation stays inside its own image)
+    if (sh < 0) return SIGE_HIP_EUNSUPPORTED;
+    dilate_mask_kernel<<<blocks, 256, 0, as_stream(stream)>>>(mask, H, W, dilationH, dilationW, out, sh ? (1 << sh) : H);
     return launch_status();
 }
 
@@ -169,13 +184,18 @@ extern "C" int sige_hip_mask_pyramid_u8(const uint8_t *mask, int H, int W, int m
     SIGE_PLAN_HOOK(sige_hip_mask_pyramid_u8, mask, H, W, min_h, min_w, dilationH, dilationW, threshold, eps, scratch, scratch_floats, out, stream);
     if (H <= 0 || W <= 0 || dilationH < 0 || dilationW < 0) return SIGE_HIP_EINVAL;
     if (!mask || !scratch || !out) return SIGE_HIP_EINVAL;
-    // scratch: level_a [H/2 * W/2] | level_b [H/4 * W/4] floats | bits [H * W] bytes (rounded up to floats)
-    const size_t na = (size_t)(H / 2) * (W / 2), nb = (size_t)(H / 4) * (W / 4);
-    const size_t need = na + nb + ((size_t)H * W + 3) / 4 + 8;
-    if (scratch_floats < need) return SIGE_HIP_EINVAL;
+    // stacked edits (sige_hip_set_edit_batch): `mask` is E masks stacked along H -- one workgroup per image, each with its own
+    // slice of the scratch; `out` is the packed pyramid of the TALL image (level k: [E * h_k, w_k]); min_h applies to ONE image
+    const int sh = stacked_shift(H);
+    if (sh < 0) return SIGE_HIP_EUNSUPPORTED;
+    const int Hp = sh ? (1 << sh) : H, E = H / Hp;
+    // scratch per image: level_a [Hp/2 * W/2] | level_b [Hp/4 * W/4] floats | bits [Hp * W] bytes (rounded up to floats)
+    const size_t na = (size_t)(Hp / 2) * (W / 2), nb = (size_t)(Hp / 4) * (W / 4);
+    const size_t need = na + nb + ((size_t)Hp * W + 3) / 4 + 8;
+    if (scratch_floats < need * (size_t)E) return SIGE_HIP_EINVAL;
     float *level_a = scratch, *level_b = scratch + na + 4;
     uint8_t *bits = reinterpret_cast<uint8_t *>(scratch + na + nb + 8);
-    mask_pyramid_kernel<<<1, kMPThreads, 0, as_stream(stream)>>>(mask, H, W, min_h, min_w, dilationH, dilationW, threshold, eps,
-                                                                level_a, level_b, bits, out);
+    mask_pyramid_kernel<<<E, kMPThreads, 0, as_stream(stream)>>>(mask, Hp, W, min_h, min_w, dilationH, dilationW, threshold, eps,
+                                                                level_a, level_b, bits, out, need);
     return launch_status();
 }

@@ -604,12 +604,17 @@ def mask_pyramid(mask: torch.Tensor, min_res: Tuple[int, int], dilation: Tuple[i
     levels, no host synchronisation (the reference synchronises once per level for `level.max()`)."""
     m = _mask_u8(mask)
     H, W = m.shape
-    n = lib().sige_hip_mask_pyramid_levels(H, W, min_res[0], min_res[1], None, None, 0)
+    # stacked edits (set_edit_batch): `mask` is E masks stacked along H; the levels are those of ONE image, E times as tall
+    E = get_edit_batch()
+    if H % E:
+        raise RuntimeError("mask_pyramid: the mask's height is not a multiple of the edit batch %d" % E)
+    Hp = H // E
+    n = lib().sige_hip_mask_pyramid_levels(Hp, W, min_res[0], min_res[1], None, None, 0)
     hs, ws = (ctypes.c_int * n)(), (ctypes.c_int * n)()
-    lib().sige_hip_mask_pyramid_levels(H, W, min_res[0], min_res[1], hs, ws, n)
-    sizes = [(int(hs[i]), int(ws[i])) for i in range(n)]
+    lib().sige_hip_mask_pyramid_levels(Hp, W, min_res[0], min_res[1], hs, ws, n)
+    sizes = [(E * int(hs[i]), int(ws[i])) for i in range(n)]
     out = torch.empty(sum(h * w for h, w in sizes), dtype=torch.uint8, device=m.device)
-    n_scratch = (H // 2) * (W // 2) + (H // 4) * (W // 4) + (H * W + 3) // 4 + 8
+    n_scratch = E * ((Hp // 2) * (W // 2) + (Hp // 4) * (W // 4) + (Hp * W + 3) // 4 + 8)
     scratch = torch.empty(n_scratch, dtype=torch.float32, device=m.device)
     _check(lib().sige_hip_mask_pyramid_u8(m.data_ptr(), H, W, min_res[0], min_res[1], max(0, dilation[0]), max(0, dilation[1]),
                                           float(threshold), float(eps), scratch.data_ptr(), n_scratch, out.data_ptr(),

@@ -427,3 +427,59 @@ def test_stacked_edits_match_single_edits(hip, ddpm_pair):
         model.set_masks(_build_masks(masks[0]))
         model(x0 + noise * masks[0], t)
         assert float((model(x0 + noise * masks[0], t) - singles[0]).abs().max()) < 1e-6
+
+
+def test_stacked_mask_pipeline_and_launch_plan(hip, ddpm_pair):
+    """Stacked edits compose with the rest: (1) under set_edit_batch the device mask pipeline treats a tall mask as E masks --
+    dilation and every pyramid level (its own maximum and threshold: sige/utils.py:88-118) per image -- so
+    downsample_mask(dilate_mask(tall)) IS the stack of the per-edit pyramids, also for edits at the seams; (2) a launch plan
+    recorded on a stacked forward follows a NEW set of E masks: per-edit outputs equal the single-edit forwards."""
+    from sige_amd import stacked
+    from sige_amd.plan import LaunchPlan
+    from sige_amd.utils import dilate_mask, downsample_mask
+
+    model, _, x0, noise, t = ddpm_pair
+    sets = [[(0.012, 100, 90), (0.02, 0, 40), (0.03, 256 - 44, 150)], [(0.05, 3, 3), (0.012, 256 - 28, 200), (0.02, 120, 60)]]
+    E = 3
+    with torch.no_grad():
+        singles = []
+        for places in sets:
+            outs = []
+            for p in places:
+                m = _mask(*p)
+                model.set_masks(_build_masks(m))
+                model.set_mode("sparse")
+                x1 = x0 + noise * m
+                model(x1, t)
+                outs.append(model(x1, t).clone())
+            singles.append(outs)
+        talls = [torch.cat([_mask(*p) for p in places], 0).contiguous() for places in sets]
+        # (1) the mask pipeline on the tall mask
+        hip.set_edit_batch(E)
+        try:
+            for places, tall_mask in zip(sets, talls):
+                got = downsample_mask(dilate_mask(tall_mask, 5), 8)
+                want = stacked.stack_masks([_build_masks(_mask(*p)) for p in places])
+                assert set(got) == set(want)
+                for k in want:
+                    assert torch.equal(got[k], want[k]), k
+        finally:
+            hip.set_edit_batch(1)
+        # (2) one recording, then another set of masks
+        xs = _cl(torch.cat([x0 + noise * _mask(*p) for p in sets[0]], 0)).clone()
+        stacked.stack_caches(model, E)
+        try:
+            with stacked.edit_batch(model, E):
+                plan = LaunchPlan(model)
+                plan.record(talls[0], lambda mk: downsample_mask(dilate_mask(mk, 5), 8), lambda: model(xs, t))
+                assert not plan.shape_bound
+                for k in (1, 0):
+                    xs.copy_(_cl(torch.cat([x0 + noise * _mask(*p) for p in sets[k]], 0)))
+                    plan.bind_mask(talls[k])
+                    out = plan.run().clone()
+                    for e in range(E):
+                        err = float((out[e] - singles[k][e][0]).abs().max())
+                        assert err < 1e-4, (k, e, err)
+                del plan
+        finally:
+            stacked.unstack_caches(model)
