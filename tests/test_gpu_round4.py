@@ -455,11 +455,11 @@ def test_stacked_mask_pipeline_and_launch_plan(hip, ddpm_pair):
             singles.append(outs)
         talls = [torch.cat([_mask(*p) for p in places], 0).contiguous() for places in sets]
         # (1) the mask pipeline on the tall mask
+        wants = [stacked.stack_masks([_build_masks(_mask(*p)) for p in places]) for places in sets]
         hip.set_edit_batch(E)
         try:
-            for places, tall_mask in zip(sets, talls):
+            for want, tall_mask in zip(wants, talls):
                 got = downsample_mask(dilate_mask(tall_mask, 5), 8)
-                want = stacked.stack_masks([_build_masks(_mask(*p)) for p in places])
                 assert set(got) == set(want)
                 for k in want:
                     assert torch.equal(got[k], want[k]), k
