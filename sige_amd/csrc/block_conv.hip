@@ -534,6 +534,34 @@ static bool launch_pair(const ConvArgs &a, const ConvPlan &pa, int mode_a, ConvA
     return true;
 }
 
+// ---- the same pairing for a conv1 routed to the dense-layer kernel (conv_wide.hip asks here) ----
+// arithmetic of the 1x1 conv held on `st` for a full-tensor destination (0 exact fp32 | 1 fp16 operands | 2 split operands), or
+// -1 if nothing is held that a dense-layer launch on `st` could take along
+int held_shortcut_prec(hipStream_t st) {
+    if (!g_held.active || g_held.st != st || g_held.dst != DST_NCHW || g_held.mode != MODE_RAW) return -1;
+    return g_held.prec;
+}
+
+// plan the held 1x1 for a 4-wave partner (NB = 1, no K split) and hand it over: *b = its launch arguments, *mt = its output
+// block (16 | 32).  false: no plan for this shape -- the caller flushes it instead.
+bool take_held_shortcut(ConvArgs *b, int *mt) {
+    if (!g_held.active) return false;
+    ConvArgs a = g_held.a;
+    ConvPlan p;
+    int rc;
+    if (g_held.prec == 0) rc = plan_conv<1, 1, 4, SRC_GATHER, LAYOUT_NHWC, 0>(a, 1, 4, true, p);
+    else if (g_held.prec == 1) rc = plan_conv<1, 1, 4, SRC_GATHER, LAYOUT_NHWC, 1>(a, 1, 4, true, p);
+    else rc = plan_conv<1, 1, 4, SRC_GATHER, LAYOUT_NHWC, 2>(a, 1, 4, true, p);
+    if (rc != SIGE_HIP_OK || p.waves != 4 || p.nb != 1) return false;
+    *b = a;
+    *mt = p.mt;
+    g_held.active = false;
+    ++g_pairs_fused;
+    return true;
+}
+
+int flush_held_conv() { return flush_held(); }
+
 template <int KH, int STR, int R, int SRC, int DST, int LAY, int PREC = 0>
 static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
     using G32 = GeoOf<PREC, KH, STR, R, 32>;

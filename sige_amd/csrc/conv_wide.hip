@@ -11,6 +11,16 @@ namespace sige {
 SIGE_WIDE_DECLARE(3, WIDE_F16) SIGE_WIDE_DECLARE(3, WIDE_X3) SIGE_WIDE_DECLARE(3, WIDE_F32)
 SIGE_WIDE_DECLARE(1, WIDE_F16) SIGE_WIDE_DECLARE(1, WIDE_X3) SIGE_WIDE_DECLARE(1, WIDE_F32)
 
+// a 3x3 dense-layer conv with the block's 1x1 shortcut (tile kernel body) in the same launch: conv_wide_pair_*.hip
+using PK11_16 = ConvGeo<1, 1, 4, 16>;
+using PK11_32 = ConvGeo<1, 1, 4, 32>;
+using PH11_16 = ConvGeoH<1, 1, 4, 16>;
+using PH11_32 = ConvGeoH<1, 1, 4, 32>;
+#define SIGE_WIDE_PAIR_DECLARE(PREC, GB) template <> void launch_conv_wide_pair<PREC, GB>(const WideArgs &, bool, bool, ConvArgs, hipStream_t);
+SIGE_WIDE_PAIR_DECLARE(WIDE_F32, PK11_16) SIGE_WIDE_PAIR_DECLARE(WIDE_F32, PK11_32)
+SIGE_WIDE_PAIR_DECLARE(WIDE_X3, PK11_16) SIGE_WIDE_PAIR_DECLARE(WIDE_X3, PK11_32)
+SIGE_WIDE_PAIR_DECLARE(WIDE_F16, PH11_16) SIGE_WIDE_PAIR_DECLARE(WIDE_F16, PH11_32)
+
 // packed[ntile][wave][chunk][ks][tap][nt][plane][lane = (kq, j)][e] =
 //     plane(w[co = 64 ntile + 32 nt + j][ci = chunk*CC + wave*CW + 16 ks + 8 kq + e][tap] * 2^wshift)
 // plane 0 = fp16(v) (RNE), plane 1 = fp16(v - plane 0); 0 beyond Cout / Cin.  One wave's share of a launch is contiguous.
@@ -223,6 +233,23 @@ extern "C" int sige_hip_wide_conv_nhwc(const float *x, const float *x2, int B, i
     a.ksplit = ceil_div(a.nchunks, a.chunks_per_split);
     if (a.ksplit > 1) { a.out = workspace; a.split_stride = out_floats; }
     const bool aff = scale != nullptr, cat = C2 > 0;
+    // a residual block's 1x1 shortcut held by sige_hip_conv_pair_begin() rides along a 3x3 launch (exact-fp32 or split-operand
+    // conv1 with an exact-fp32 shortcut, fp16 conv1 with an fp16 shortcut); anything else held is launched on its own first, so
+    // that results and order never depend on pairing
+    {
+        const int hp = held_shortcut_prec(st);
+        const bool fits = kH == 3 && !stats && ((hp == 0 && (prec == WIDE_F32 || prec == WIDE_X3)) || (hp == 1 && prec == WIDE_F16));
+        ConvArgs b;
+        int bmt = 0;
+        if (fits && take_held_shortcut(&b, &bmt)) {
+            if (prec == WIDE_F32) { if (bmt == 32) launch_conv_wide_pair<WIDE_F32, PK11_32>(a, aff, cat, b, st); else launch_conv_wide_pair<WIDE_F32, PK11_16>(a, aff, cat, b, st); }
+            else if (prec == WIDE_X3) { if (bmt == 32) launch_conv_wide_pair<WIDE_X3, PK11_32>(a, aff, cat, b, st); else launch_conv_wide_pair<WIDE_X3, PK11_16>(a, aff, cat, b, st); }
+            else { if (bmt == 32) launch_conv_wide_pair<WIDE_F16, PH11_32>(a, aff, cat, b, st); else launch_conv_wide_pair<WIDE_F16, PH11_16>(a, aff, cat, b, st); }
+            return launch_status(1);
+        }
+        const int rc = flush_held_conv();
+        if (rc != SIGE_HIP_OK) return rc;
+    }
 #define SIGE_WIDE_GO(KH)                                                                            \
     do {                                                                                            \
         if (prec == WIDE_F32) launch_conv_wide<KH, WIDE_F32, 8>(a, aff, cat, st);                   \

@@ -116,10 +116,11 @@ __device__ __forceinline__ f16x8 buf_h8(rsrc_t r, unsigned byte_off, int soff) {
     return __builtin_bit_cast(f16x8, v);
 }
 
-// One workgroup of the launch.  AFF: the staging path applies scale * x + shift (and SiLU if a.act); CAT: channels from two tensors.
+// One workgroup of the launch: (bx, by) = what blockIdx would be in a launch of its own (conv_wide_pair_kernel shares a launch
+// between this body and a tile-kernel body).  AFF: the staging path applies scale * x + shift (and SiLU if a.act); CAT: channels
+// from two tensors.
 template <typename G, bool AFF, bool CAT>
-__global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];
+__device__ __forceinline__ void conv_wide_body(const WideArgs &a, const int bx, const int by, unsigned char *const smem) {
     constexpr bool X3 = G::X3, F32 = G::F32;
     constexpr int NS = G::NS, STEPS = G::STEPS, RB = G::RB, NP = G::NP;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -127,8 +128,8 @@ __global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a
     SIGE_WPROBE(0);  // entry
     // consecutive workgroups (= consecutive XCDs) take different output-channel blocks; all pixel blocks of one channel
     // block land on XCD (ntile mod 8) when ntn is a multiple of 8: a layer's weights are fetched into one L2 each
-    const int ntile = blockIdx.x % a.ntn, mtile = blockIdx.x / a.ntn;
-    const int split = blockIdx.y;
+    const int ntile = bx % a.ntn, mtile = bx / a.ntn;
+    const int split = by;
     const int first = split * a.chunks_per_split;
     const int last = min(a.nchunks, first + a.chunks_per_split) - 1;
     const int tpi = a.th * a.tw;
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a
         // workgroup that draws the last one adds the copies in split order (deterministic) and runs the epilogue
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        int32_t *const cnt = a.counters + blockIdx.x;
+        int32_t *const cnt = a.counters + bx;
         if (tid == 0) red[0] = __builtin_bit_cast(float, __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         __syncthreads();
         const int ticket = __builtin_bit_cast(int, red[0]);
@@ -513,6 +514,44 @@ __global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a
         }
     }
 }
+
+template <typename G, bool AFF, bool CAT>
+__global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];
+    conv_wide_body<G, AFF, CAT>(a, blockIdx.x, blockIdx.y, smem);
+}
+
+// A dense residual block's conv1 (this kernel, 3x3) and its 1x1 shortcut (the tile kernel's body, conv_mfma.hpp) in ONE launch:
+// workgroups [0, na) run the dense-layer conv (possibly K-split over gridDim.y), the rest the shortcut (blockIdx.y == 0 only) --
+// the horizontal fusion of conv_pair_kernel for layers routed to this kernel (round 4).  Both bodies are 256
+// lanes; LDS = the larger of the two; the register budget is this kernel's (two workgroups per CU).
+template <typename G, bool AFF, bool CAT, typename GB>
+__global__ __launch_bounds__(256, G::OCC) void conv_wide_pair_kernel(const WideArgs a, const ConvArgs b, const int na) {
+    constexpr int LB = conv_lds_floats<GB, 1, MODE_RAW, LAYOUT_NHWC, 4>() * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[cmax(G::LDS_BYTES, LB)];
+    if ((int)blockIdx.x < na) conv_wide_body<G, AFF, CAT>(a, blockIdx.x, blockIdx.y, smem);
+    else if (blockIdx.y == 0)
+        conv_mfma_body<GB, 1, SRC_GATHER, MODE_RAW, DST_NCHW, LAYOUT_NHWC, 4>(b, blockIdx.x - na, 0, reinterpret_cast<float *>(smem));
+}
+
+template <int PREC, typename GB>
+void launch_conv_wide_pair(const WideArgs &a, bool aff, bool cat, ConvArgs b, hipStream_t st);
+
+// (block_conv.hip) the conv-pair state of the calling thread, as far as a dense-layer launch needs it
+int held_shortcut_prec(hipStream_t st);
+bool take_held_shortcut(ConvArgs *b, int *mt);
+int flush_held_conv();
+
+#define SIGE_WIDE_PAIR_INSTANTIATE(PREC, GB)                                                               \
+    template <> void launch_conv_wide_pair<PREC, GB>(const WideArgs &a, bool aff, bool cat, ConvArgs b, hipStream_t st) { \
+        using G = WideGeo<3, PREC, 8>;                                                                     \
+        const int na = a.B * a.th * a.tw * a.ntn;                                                          \
+        const dim3 grid(na + conv_grid_x(b), a.ksplit);                                                    \
+        if (aff && cat) conv_wide_pair_kernel<G, true, true, GB><<<grid, 256, 0, st>>>(a, b, na);          \
+        else if (aff) conv_wide_pair_kernel<G, true, false, GB><<<grid, 256, 0, st>>>(a, b, na);           \
+        else if (cat) conv_wide_pair_kernel<G, false, true, GB><<<grid, 256, 0, st>>>(a, b, na);           \
+        else conv_wide_pair_kernel<G, false, false, GB><<<grid, 256, 0, st>>>(a, b, na);                   \
+    }
 
 template <int KH, int PREC, int PWO>
 void launch_conv_wide(const WideArgs &a, bool aff, bool cat, hipStream_t st);

@@ -44,6 +44,10 @@ def _tile_compute(compute: str) -> str:
 #     (~8 us each) eat what the dense 3x3s gain -- 1.456 vs 1.446 ms (split operands vs exact fp32, 1.2 % edit), 1.250 vs
 #     1.034 ms with plain fp16 operands.  So the dense remainder of the sparse pass stays on the tile kernels.
 WIDE_MIN_FLOP = {3: 4.0e9, 1: 2.0e9}
+# ... for split fp16 operands ("f16x3"), its own threshold since round 4: a dense-layer launch now takes the block's 1x1 shortcut
+# along (conv_wide_pair_kernel: the horizontal fusion the tile kernels had), so routing a conv1 here no longer costs a launch --
+# measured again with tools/routing_bench.py (profiles/r4f_routing.jsonl)
+WIDE_MIN_FLOP_X3 = {3: 4.0e9, 1: 2.0e9}
 WIDE_MIN_FLOP_FULL_PASS = {3: 0.25e9, 1: 2.0e9}
 # exact-fp32 form of the same kernel (v_mfma_f32_32x32x2_f32; matrix-bound).  Measured (profiles/r3g_wide_bench.jsonl,
 # r3g_routing.jsonl): on the dense remainder it only ties the tile kernels layer by layer (3.6 GFLOP: 49.8 vs 51.6 us = 73 vs
@@ -90,7 +94,9 @@ def _wide_conv(conv: nn.Conv2d, x, x2, scale, shift, activation_name, residual, 
         return None
     C1, C2 = x.shape[1], 0 if x2 is None else x2.shape[1]
     pix = x.shape[0] * x.shape[2] * x.shape[3] * (4 if upsample2x else 1)
-    if 2.0 * pix * conv.out_channels * (C1 + C2) * k[0] * k[1] < (WIDE_MIN_FLOP if min_flop is None else min_flop)[k[0]]:
+    if min_flop is None:
+        min_flop = WIDE_MIN_FLOP_X3 if compute == "f16x3" else WIDE_MIN_FLOP
+    if 2.0 * pix * conv.out_channels * (C1 + C2) * k[0] * k[1] < min_flop[k[0]]:
         return None  # (small layers are latency-bound: the tile kernels' 16 / 32-pixel blocks start up faster)
     if not hip.wide_conv_supported(C1, C2, conv.out_channels, k):
         if x2 is None or upsample2x or not hip.wide_conv_supported(C1 + C2, 0, conv.out_channels, k):

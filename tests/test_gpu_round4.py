@@ -483,3 +483,47 @@ def test_stacked_mask_pipeline_and_launch_plan(hip, ddpm_pair):
                 del plan
         finally:
             stacked.unstack_caches(model)
+
+
+# ---- the dense-layer conv takes a residual block's shortcut along -----------------------------------------
+@pytest.mark.parametrize("compute", ["f32", "f16x3", "f16"])
+@pytest.mark.parametrize("res,c1,c2,cout", [(32, 512, 256, 256), (16, 512, 512, 512), (8, 512, 512, 512), (32, 256, 0, 512)])
+def test_wide_conv_pairs_with_the_shortcut(hip, compute, res, c1, c2, cout):
+    """conv_wide_pair_kernel: inside hip.conv_pair() a held 1x1 shortcut (tile kernel) is launched INSIDE the dense-layer kernel's
+    launch of the block's conv1 -- one launch instead of two, conv1 bit-identical to its own launch (the same workgroup program,
+    incl. a K-split finish), the shortcut equal up to its output block's summation order; a held conv the dense-layer launch
+    cannot take (another arithmetic) goes out on its own first."""
+    g = torch.Generator().manual_seed(res + c1 + cout)
+    r = lambda *s: torch.randn(*s, generator=g).to(DEV)  # noqa: E731
+    cin = c1 + c2
+    x, x2 = _cl(r(1, c1, res, res)), (_cl(r(1, c2, res, res)) if c2 else None)
+    w3, b3, w1, b1 = r(cout, cin, 3, 3) / (3 * cin ** 0.5), r(cout), r(cout, cin, 1, 1) / cin ** 0.5, r(cout)
+    sc, sh, os_, oh_ = r(1, cin, 1, 1), r(1, cin, 1, 1), r(cout), r(cout)
+    p1 = hip.conv_pack_weights(w1, 4, 4, (1, 1), "f16" if compute == "f16" else "f32")
+    pw = hip.wide_conv_pack_weights(w3, compute)
+    i4 = hip.all_tiles(res, res, (4, 4), (1, 1), (0, 0), DEV)
+    f4 = dict(offset=(0, 0), out_res=(res, res), residual=None)
+    shortcut = lambda: hip.gather_conv_cl(x, x2, (4, 4), i4, None, None, "identity", p1, b1, cout, (1, 1), (1, 1), full=f4)  # noqa: E731
+    conv1 = lambda: hip.wide_conv_cl(x, x2, sc, sh, "swish", pw, b3, cout, (3, 3), out_affine=(os_, oh_, "swish"))  # noqa: E731
+    want_s, want_c = shortcut(), conv1()
+    assert want_c is not None
+    n0, f0 = hip.launch_count(), hip.conv_pairs_fused()
+    with hip.conv_pair(want_s):
+        got_s = shortcut()
+        got_c = conv1()
+    torch.cuda.synchronize()
+    assert hip.conv_pairs_fused() == f0 + 1 and hip.launch_count() == n0 + 1
+    assert torch.equal(got_c, want_c)
+    torch.testing.assert_close(got_s, want_s, rtol=1e-5, atol=1e-5 if compute != "f16" else 1e-4)
+    if compute == "f16":
+        # an exact-fp32 shortcut cannot ride along an fp16 conv1: it is launched on its own, in front of it
+        p1f = hip.conv_pack_weights(w1, 4, 4, (1, 1), "f32")
+        sf = lambda: hip.gather_conv_cl(x, x2, (4, 4), i4, None, None, "identity", p1f, b1, cout, (1, 1), (1, 1), full=f4)  # noqa: E731
+        want_sf = sf()
+        n0, f0 = hip.launch_count(), hip.conv_pairs_fused()
+        with hip.conv_pair(want_sf):
+            a = sf()
+            b = conv1()
+        torch.cuda.synchronize()
+        assert hip.conv_pairs_fused() == f0 and hip.launch_count() == n0 + 2
+        assert torch.equal(a, want_sf) and torch.equal(b, want_c)

@@ -33,6 +33,7 @@ def main():
     x0, noise = (t.to(dev).contiguous(memory_format=torch.channels_last) for t in bench.make_inputs())
     t = torch.zeros(1, device=dev)
     default_min = dict(dense.WIDE_MIN_FLOP)
+    default_min_x3 = dict(dense.WIDE_MIN_FLOP_X3)
     default_x3 = dense.TILE_X3_MIN_FLOP
     rows = []
     with torch.no_grad():
@@ -52,13 +53,26 @@ def main():
                     ("f16 everywhere, tile kernels only", "f16", (), False, default_x3),
                     ("f16 + F16_KEEP as f16x3", "f16", None, True, default_x3),
                     ("f16x3: wide dense + exact tiles below 2 GFLOP", "f16x3", (), True, default_x3),
+                    ("f16x3: wide dense (>= 2 GFLOP) + exact tiles below 2 GFLOP", "f16x3", (), "x3:2.0", default_x3),
+                    ("f16x3: wide dense (>= 1 GFLOP) + exact tiles below 2 GFLOP", "f16x3", (), "x3:1.0", default_x3),
+                    ("f16x3: wide dense (>= 0.25 GFLOP) + exact tiles below 2 GFLOP", "f16x3", (), "x3:0.25", default_x3),
+                    ("f16: wide dense (>= 1 GFLOP)", "f16", (), "f16:1.0", default_x3),
                     ("f16x3: wide dense + split-operand tiles everywhere", "f16x3", (), True, 0.0),
                     ("f16x3: tile kernels only (split operands)", "f16x3", (), False, 0.0)):
                 dense.WIDE_MIN_FLOP_F32 = default_f32
+                dense.WIDE_MIN_FLOP_X3 = default_min_x3
+                over = None
                 if isinstance(wide, str):
-                    dense.WIDE_MIN_FLOP_F32 = {3: float(wide.split(":")[1]) * 1e9, 1: 1e30}
+                    kind, val = wide.split(":")
+                    over = {3: float(val) * 1e9, 1: 1e30 if kind == "f32" else 2.0e9}
+                    if kind == "f32":
+                        dense.WIDE_MIN_FLOP_F32 = over
+                    elif kind == "x3":
+                        dense.WIDE_MIN_FLOP_X3 = over
                     wide = True
-                dense.WIDE_MIN_FLOP = default_min if wide else {1: 1e30, 3: 1e30}
+                dense.WIDE_MIN_FLOP = (over if (over is not None and kind == "f16") else default_min) if wide else {1: 1e30, 3: 1e30}
+                if not wide:
+                    dense.WIDE_MIN_FLOP_X3 = {1: 1e30, 3: 1e30}
                 dense.TILE_X3_MIN_FLOP = tile_x3
                 model.set_compute_dtype(dtype, keep=keep)
                 model.set_masks(downsample_mask(dilate_mask(m, 5), 8))
@@ -79,6 +93,7 @@ def main():
                 rows.append(row)
                 del g, out
     dense.WIDE_MIN_FLOP = default_min
+    dense.WIDE_MIN_FLOP_X3 = default_min_x3
     dense.WIDE_MIN_FLOP_F32 = default_f32
     dense.TILE_X3_MIN_FLOP = default_x3
     if args.out:
