@@ -57,7 +57,7 @@ TRACED = ("gather", "scatter_gather", "scatter_fused", "scatter_with_block_resid
           "block_conv_direct", "gather_conv", "scatter_gather_conv", "gather_conv_nchw",
           # channels-last forms (the layout the benchmark runs in)
           "gather_cl", "scatter_gather_cl", "scatter_cl", "scatter_with_block_residual_cl", "block_conv_cl",
-          "gather_conv_cl", "scatter_gather_conv_cl", "scatter_gather_conv_scatter_cl", "wide_conv_cl")
+          "gather_conv_cl", "scatter_gather_conv_cl", "scatter_gather_conv_scatter_cl", "wide_conv_cl", "attention_tokens")
 
 
 class Tracer:
@@ -112,6 +112,9 @@ def op_cost(name, a, k=None):
             # the conv -> Scatter fusion of a SIGE layer
             dense = full is not None and idx.shape[0] * ro * so >= full["out_res"][0] * full["out_res"][1]
         return ("dense_conv_mfma" if dense else "block_conv_mfma"), 0, 2 * T * ro * so * cout * cin * kernel[0] * kernel[1]
+    if name == "attention_tokens":  # q [B,Nq,C], k / v [B,Nk,C]: QK^T and PV, 2 flop per multiply-add each
+        q, kk = a[0], a[1]
+        return "attention_tokens", 0, 4 * q.shape[0] * q.shape[1] * kk.shape[1] * q.shape[2]
     if name == "wide_conv_cl":  # dense layer on the fp16 matrix cores (conv_wide.hpp): algorithmic flops of the conv
         x, x2, cout, kernel = a[0], a[1], a[7], a[8]
         cin = x.shape[1] + (0 if x2 is None else x2.shape[1])
@@ -703,6 +706,43 @@ def main_sd(args, world, rank, dev):
             dist_info["cache_identical_on_all_ranks"] = bool(lo.item() == hi.item())
         model.set_masks(masks)
         model.set_mode("sparse")
+        # the attention core / the token linears of the spatial transformers: the reference's rearrange / bmm / softmax / nn.Linear
+        # chain against the library's kernels (sige_amd/workloads/sd_transformer.py: NATIVE_ATTENTION, NATIVE_LINEAR)
+        from sige_amd.workloads import sd_transformer as _sdt
+
+        routing, kernels_sd, roof_sd = {}, None, None
+        if rank == 0 and world == 1:
+            keep_flags = (_sdt.NATIVE_ATTENTION, _sdt.NATIVE_LINEAR)
+            ref_out = None
+            for tag, att, lin in (("reference_chain", False, False), ("native_attention", True, False), ("native_attention_and_linears", True, True)):
+                _sdt.NATIVE_ATTENTION, _sdt.NATIVE_LINEAR = att, lin
+                run(x1)
+                n0 = hip.launch_count()
+                run(x1)
+                nl = hip.launch_count() - n0
+                ms_v, o_v, g_v = _replay_ms(lambda: run(x1), k=10, warm=2)
+                if ref_out is None:
+                    ref_out = o_v.float().clone()
+                routing[tag] = {"forward_ms": round(ms_v, 3), "library_launches": nl, "max_abs_vs_reference_chain": round(float((o_v.float() - ref_out).abs().max()), 8)}
+                del g_v
+            _sdt.NATIVE_ATTENTION, _sdt.NATIVE_LINEAR = keep_flags
+            # per-kernel accounting of the library's launches in one forward (the same accounting as the DDPM headline's table)
+            tracer = Tracer(hip)
+            run(x1)
+            tracer.log = []
+            run(x1)
+            tr_sd, tracer.log = tracer.log, None
+            fam_sd, _, kernels_sd, conv_tf_sd, hot_sd = kernel_families(tr_sd)
+            peak_sd = PEAK_F16_MFMA_TFS if args.dtype in ("f16", "f16x3") else PEAK_F32_MFMA_TFS
+            dom = max(fam_sd, key=lambda n_: fam_sd[n_]["us"])
+            ach = fam_sd[dom]["flops"] / max(1e-9, fam_sd[dom]["us"]) / 1e6
+            roof_sd = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": peak_sd, "unit": "TFLOP/s", "frac": round(ach / peak_sd, 4),
+                       "traffic": None, "launches_per_forward": fam_sd[dom]["launches"], "us_per_forward": round(fam_sd[dom]["us"], 1),
+                       "library_kernel_us_per_forward": round(hot_sd, 1),
+                       "note": "the library kernel family with the most time in one SD forward (warm in-situ tensors, every distinct call "
+                               "shape timed as a hipGraph of back-to-back launches); the forward also runs torch kernels (LayerNorm, GEGLU, "
+                               "adds, and the token linears unless NATIVE_LINEAR): forward_ms - library_kernel_us is theirs + launch gaps"}
+            del tr_sd, tracer
         n0 = hip.launch_count()
         run(x1)
         launches = hip.launch_count() - n0
@@ -791,12 +831,19 @@ def main_sd(args, world, rank, dev):
                            "edit_ratio": 0.15, "batch_per_gpu": 2, "parallelism": "dp%d" % world},
                 "forward_ms": round(ms_steady, 4), "dense_forward_ms": round(dense_ms, 3), "speedup_vs_dense": round(dense_ms / ms_steady, 2),
                 "hip_kernel_launches_per_forward": launches, "cache_bytes": int(flat.numel() * 4), "cached_tensors": n_cached,
-                "active_token_ratio_64": round(float(masks[(64, 64)].float().mean()), 4)}
+                "active_token_ratio_64": round(float(masks[(64, 64)].float().mean()), 4),
+                "native_attention": bool(_sdt.NATIVE_ATTENTION), "native_linear": bool(_sdt.NATIVE_LINEAR)}
+        if routing:
+            line["attention_routing"] = routing
+        if roof_sd is not None:
+            line["roofline"] = roof_sd
+            line["kernels"] = kernels_sd
         if world > 1:
             step_s = dt_steady / args.steps
             line["multi_gpu"] = dict(dist_info, method=method, cache_distribution_ms=round(dist_s * 1e3, 3),
                                      value_steady_state_cache_resident=round(world * args.steps / dt_steady, 2),
-                                     value_cache_refreshed_every_step=round(world / (dist_s + step_s), 2))
+                                     value_cache_refreshed_every_step=round(world / (dist_s + step_s), 2),
+                                     efficiency=round(dt_steady / dt, 4))
         if parity is not None:
             line.update(parity)
         print(json.dumps(line), flush=True)

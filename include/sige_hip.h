@@ -609,6 +609,17 @@ int sige_hip_wide_conv_nhwc(const float *x, const float *x2, int B, int C1, int 
 int sige_hip_affine_act_nhwc_f32(const float *x, int B, int C, int H, int W, const float *scale, const float *shift,
                                  int affineB, int activation, float *out, void *stream);
 
+/* ---- multi-head attention over token matrices (Stable Diffusion's spatial transformer) ---------------------------------
+ * out[b, i, h*d .. (h+1)*d) = softmax_j(scale * q[b,i,h] . k[b,j,h]) v[b,j,h]  for q [B,Nq,C], k / v [B,Nk,C], C = heads * d,
+ * row-major fp32 -- a channels-last [B,C,H,W] tensor IS its token matrix [B,HW,C] and channels-last tiles [T,C,4,4] ARE
+ * [T*16, C], so the sparse-query attention of stable-diffusion/ldm/modules/sige_attention.py:151-176 (queries = the tokens of
+ * the active tiles, keys / values = every token of the scattered feature map, or the text context) needs no rearrange copy
+ * and no score tensor in HBM: one launch, exact fp32 products, online softmax (attention.py's CrossAttention.forward does
+ * rearrange x 3, einsum, softmax, einsum, rearrange).  Nq % 16 == 0, d % 4 == 0, d <= 160; Nk arbitrary.                */
+int sige_hip_attention_tokens_supported(int Nq, int Nk, int C, int heads);
+int sige_hip_attention_tokens_f32(const float *q, const float *k, const float *v, int B, int Nq, int Nk, int C,
+                                  int heads, float scale, float *out, void *stream);
+
 /* ---- fp16-STORED caches: the "_f16" forms of SURVEY.md 8b's export list (8f row 4: fp16 cache) ---------------------
  * The reference is fp32-only (sige/nn/base.py:15,55-63).  Here the CACHED tensors of a SIGE model -- Scatter /
  * ScatterGather `original_outputs`, ScatterWithBlockResidual `original_outputs` / `original_residuals`, and the activated

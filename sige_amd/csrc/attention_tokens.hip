@@ -1,0 +1,198 @@
+// Multi-head attention over token matrices, one launch: out = softmax(scale * q k^T) v per (batch, head).
+//
+// Stable Diffusion's spatial transformer (stable-diffusion/ldm/modules/sige_attention.py:151-176 -> attention.py CrossAttention):
+// in sparse mode the QUERIES are the tokens of the active 4x4 tiles (a few hundred to a few thousand), the keys / values of
+// the self-attention all HW tokens of the (scattered) feature map, those of the cross-attention the 77 text tokens.  The
+// reference -- and rounds 1-3 here -- runs it as rearrange('b n (h d) -> (b h) n d') x 3 (copies), bmm, softmax, bmm,
+// rearrange back (copy): per attention 2 library GEMMs, a softmax over a [B*h, Nq, Nk] score tensor written to and read
+// from HBM, and 8 copy kernels (profiles/r2m_kerneltrace_sd_unet_sparse_15pct.csv: 138 copy kernels, 5 cunn_SoftMaxForward
+// and ~25 Cijk_* launches of this kind per forward).  Here: heads are strides, the score tile never leaves the workgroup.
+//
+//   workgroup = 16 queries of one (batch, head); its 4 waves take the key blocks (16 keys each) round-robin, each with its own
+//   running (max, sum, O) -- flash-attention's online softmax --, and meet in LDS at the end.
+//   S = Q K^T on v_mfma_f32_16x16x4_f32 (exact fp32 products): lane (kq, j) holds, per 16-channel unit, Q[j][16u + 4kq ..+3] and
+//   K[key j][same 4 channels] -- one 16-byte load each, four k-steps; the head dimension d (40 / 80 / 160 for SD v1) is padded
+//   to whole units with zeros.
+//   P = exp(S - m) goes through a wave-private 16 x 16 LDS tile (C layout -> A layout); O += P V with V[key 4t + kq][16n + j]
+//   straight from global memory (16 lanes = 64 contiguous bytes of a key's row).
+//
+// q [B,Nq,C], k / v [B,Nk,C], out [B,Nq,C], C = heads * d, all row-major fp32 (a channels-last [B,C,H,W] tensor IS [B,HW,C];
+// channels-last tiles [T,C,4,4] ARE [T*16, C]: no copy on either side).  Nq % 16 == 0; Nk arbitrary (tail keys masked).
+#include "common.hpp"
+
+namespace sige {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int UNITS>  // 16-channel units covering the head dimension: d <= 16 * UNITS
+__global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                               const float *__restrict__ v, float *__restrict__ out,
+                                                               int Nq, int Nk, int C, int heads, int d, float scale_log2e) {
+    constexpr int DT = UNITS;            // 16-column tiles of O
+    constexpr int OS = UNITS * 16 + 4;   // padded row of the merge buffer
+    __shared__ __attribute__((aligned(16))) float p_lds[4][16][20];     // wave-private P tile
+    __shared__ float m_lds[4][16], l_lds[4][16];
+    extern __shared__ __attribute__((aligned(16))) float o_lds[];       // [4 waves][16 queries][OS]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kq = lane >> 4, j = lane & 15;
+    const int head = blockIdx.y % heads, b = blockIdx.y / heads;
+    const int q0 = blockIdx.x * 16;
+    const size_t hoff = (size_t)head * d;
+    const float *qb = q + ((size_t)b * Nq + q0) * C + hoff;
+    const float *kb = k + (size_t)b * Nk * C + hoff;
+    const float *vb = v + (size_t)b * Nk * C + hoff;
+
+    // Q of this lane: row j, channels 16u + 4kq .. +3 of every unit (zeros beyond d)
+    float4 qr[UNITS];
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u) {
+        const int c = 16 * u + 4 * kq;
+        qr[u] = c < d ? *reinterpret_cast<const float4 *>(qb + (size_t)j * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // running softmax state of rows 4kq .. 4kq+3 (replicated over the 16 lanes j) and the O accumulators (C layout:
+    // o[n][r] = O[row 4kq + r][column 16n + j])
+    float m_run[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, l_run[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 o[DT];
+#pragma unroll
+    for (int n = 0; n < DT; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkb = (Nk + 15) / 16;
+    for (int kblk = wave; kblk < nkb; kblk += 4) {
+        const int key0 = kblk * 16;
+        const int key = min(key0 + j, Nk - 1);  // (tail: a valid address; the column is masked below)
+        // ---- S = Q K^T ----
+        float4 kr[UNITS];
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            const int c = 16 * u + 4 * kq;
+            kr[u] = c < d ? *reinterpret_cast<const float4 *>(kb + (size_t)key * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        // the V operands of this block do not depend on the scores: in flight under the score MFMAs and the softmax
+        float vr[4][DT];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int vk = key0 + 4 * t + kq;
+            const bool ok = vk < Nk;
+            const float *vp = vb + (size_t)(ok ? vk : Nk - 1) * C;
+#pragma unroll
+            for (int n = 0; n < DT; ++n) {
+                const int c = 16 * n + j;
+                vr[t][n] = (ok && c < d) ? vp[c] : 0.f;
+            }
+        }
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[u].x, kr[u].x, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[u].y, kr[u].y, s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[u].z, kr[u].z, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[u].w, kr[u].w, s1, 0, 0, 0);
+        }
+        // s[r] = S[row 4kq + r][key0 + j], in units of log2: exp(x) = exp2(x * log2 e)
+        float s[4];
+        const bool live = key0 + j < Nk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r] = live ? (s0[r] + s1[r]) * scale_log2e : -INFINITY;
+        // ---- online softmax: row maxima over the 16 lanes of a kq group ----
+        float alpha[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float mx = s[r];
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 16));
+            const float m_new = fmaxf(m_run[r], mx);  // (finite: every block has at least one live key)
+            alpha[r] = __builtin_amdgcn_exp2f(m_run[r] - m_new);  // (exp2(-inf) = 0 on the first block)
+            const float p = __builtin_amdgcn_exp2f(s[r] - m_new);
+            float ps = p;
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) ps += __shfl_xor(ps, off, 16);
+            l_run[r] = l_run[r] * alpha[r] + ps;
+            m_run[r] = m_new;
+            p_lds[wave][4 * kq + r][j] = p;
+        }
+#pragma unroll
+        for (int n = 0; n < DT; ++n) {
+            o[n][0] *= alpha[0]; o[n][1] *= alpha[1]; o[n][2] *= alpha[2]; o[n][3] *= alpha[3];
+        }
+        __builtin_amdgcn_wave_barrier();  // (LDS is in order per wave: the tile written above is complete for this wave's reads)
+        // ---- O += P V: A[row j][k = key 4t + kq] from the LDS tile ----
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float a = p_lds[wave][j][4 * t + kq];
+#pragma unroll
+            for (int n = 0; n < DT; ++n) o[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vr[t][n], o[n], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- merge the four waves' (m, l, O) ----
+    float *ow = o_lds + (size_t)wave * 16 * OS;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (j == 0) { m_lds[wave][4 * kq + r] = m_run[r]; l_lds[wave][4 * kq + r] = l_run[r]; }
+#pragma unroll
+        for (int n = 0; n < DT; ++n) ow[(4 * kq + r) * OS + 16 * n + j] = o[n][r];
+    }
+    __syncthreads();
+    // thread -> (query row, 4 consecutive channels)
+    const int units_per_row = d / 4;
+    for (int e = tid; e < 16 * units_per_row; e += 256) {
+        const int row = e / units_per_row, c = (e - row * units_per_row) * 4;
+        float M = fmaxf(fmaxf(m_lds[0][row], m_lds[1][row]), fmaxf(m_lds[2][row], m_lds[3][row]));
+        float L = 0.f;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float mw = m_lds[w][row];
+            const float f = mw == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mw - M);  // (a wave without a key block)
+            L += f * l_lds[w][row];
+            const float4 ov = *reinterpret_cast<const float4 *>(o_lds + ((size_t)w * 16 + row) * OS + c);
+            acc.x += f * ov.x; acc.y += f * ov.y; acc.z += f * ov.z; acc.w += f * ov.w;
+        }
+        const float inv = 1.0f / L;
+        *reinterpret_cast<float4 *>(out + ((size_t)b * Nq + q0 + row) * C + hoff + c) =
+            make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    }
+}
+
+}  // namespace sige
+
+using namespace sige;
+
+extern "C" int sige_hip_attention_tokens_supported(int Nq, int Nk, int C, int heads) {
+    if (Nq <= 0 || Nk <= 0 || C <= 0 || heads <= 0 || C % heads) return 0;
+    const int d = C / heads;
+    return (Nq % 16 == 0 && d % 4 == 0 && d <= 160 && C % 4 == 0) ? 1 : 0;
+}
+
+extern "C" int sige_hip_attention_tokens_f32(const float *q, const float *k, const float *v, int B, int Nq, int Nk, int C,
+                                             int heads, float scale, float *out, void *stream) {
+    SIGE_PLAN_HOOK(sige_hip_attention_tokens_f32, q, k, v, B, Nq, Nk, C, heads, scale, out, stream);
+    if (B < 0 || Nq < 0 || Nk <= 0 || C <= 0 || heads <= 0) return SIGE_HIP_EINVAL;
+    if ((long)B * Nq == 0) return SIGE_HIP_OK;
+    if (!q || !k || !v || !out) return SIGE_HIP_EINVAL;
+    if (!sige_hip_attention_tokens_supported(Nq, Nk, C, heads)) return SIGE_HIP_EUNSUPPORTED;
+    auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (!al(q) || !al(k) || !al(v) || !al(out) || (long)B * heads > 65535) return SIGE_HIP_EUNSUPPORTED;
+    const int d = C / heads;
+    const int units = (d + 15) / 16;
+    const float sl = scale * 1.44269504088896341f;
+    const dim3 grid(Nq / 16, B * heads);
+    hipStream_t st = as_stream(stream);
+#define SIGE_ATT_GO(U)                                                                                             \
+    attention_tokens_kernel<U><<<grid, 256, (size_t)4 * 16 * (U * 16 + 4) * sizeof(float), st>>>(q, k, v, out, Nq, Nk, C, heads, d, sl)
+    switch (units) {
+        case 1: SIGE_ATT_GO(1); break;
+        case 2: SIGE_ATT_GO(2); break;
+        case 3: SIGE_ATT_GO(3); break;
+        case 4: SIGE_ATT_GO(4); break;
+        case 5: SIGE_ATT_GO(5); break;
+        case 6: SIGE_ATT_GO(6); break;
+        case 8: SIGE_ATT_GO(8); break;
+        case 10: SIGE_ATT_GO(10); break;
+        default: return SIGE_HIP_EUNSUPPORTED;
+    }
+#undef SIGE_ATT_GO
+    return launch_status();
+}

@@ -156,6 +156,8 @@ _SIGNATURES = {
     "sige_hip_channel_stats_nhwc_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp]),
     "sige_hip_group_norm_affine_from_stats_f32": (
         _c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_float] + [_c_vp] * 6),
+    "sige_hip_attention_tokens_supported": (_c_int, [_c_int] * 4),
+    "sige_hip_attention_tokens_f32": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [ctypes.c_float, _c_vp, _c_vp]),
     # fp16-stored caches
     "sige_hip_gather_nhwc_f16": (
         _c_int, [_c_vp] + [_c_int] * 6 + [_c_vp, _c_int] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]),
@@ -1591,6 +1593,28 @@ def attention_cl(qkv: torch.Tensor, scale: float):
     if status == UNSUPPORTED:
         return None
     _check(status, "attention_cl")
+    return out
+
+
+def attention_tokens(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float) -> Optional[torch.Tensor]:
+    """softmax(scale * q k^T) v per (batch, head) for token matrices q [B,Nq,C], k / v [B,Nk,C] (C = heads * d), in ONE launch
+    with the heads as strides (include/sige_hip.h: sige_hip_attention_tokens_f32) -> [B,Nq,C].  None if unsupported (then the
+    caller runs the reference's rearrange / bmm / softmax / bmm chain)."""
+    if not (q.is_cuda and q.dtype == k.dtype == v.dtype == torch.float32 and q.dim() == k.dim() == v.dim() == 3):
+        return None
+    B, Nq, C = q.shape
+    if tuple(k.shape) != tuple(v.shape) or k.shape[0] != B or k.shape[2] != C:
+        return None
+    Nk = k.shape[1]
+    if not lib().sige_hip_attention_tokens_supported(Nq, Nk, C, heads):
+        return None
+    q, k, v = (t if t.is_contiguous() else t.contiguous() for t in (q, k, v))
+    out = torch.empty((B, Nq, C), dtype=torch.float32, device=q.device)
+    status = lib().sige_hip_attention_tokens_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), B, Nq, Nk, C, heads, float(scale),
+                                                 out.data_ptr(), _stream(q))
+    if status == UNSUPPORTED:
+        return None
+    _check(status, "attention_tokens")
     return out
 
 

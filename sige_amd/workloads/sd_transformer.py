@@ -28,6 +28,37 @@ from torch.nn import functional as F
 from ..nn import Gather, Scatter, SIGEConv2d, SIGEModule
 
 
+# MI355X-first switches of this workload (values identical either way; bench.py --workload sd prints which are on):
+#   NATIVE_ATTENTION  the attention core as ONE library launch per attention (sige_hip_attention_tokens_f32: heads as strides,
+#                     online softmax, no score tensor in HBM) instead of rearrange x 3 / bmm / softmax / bmm / rearrange
+#   NATIVE_LINEAR     the token linears (to_q / to_k / to_v / to_out, the GEGLU projection, the feed-forward's second layer) on
+#                     the library's MFMA tile kernel -- 16 tokens are one channels-last 4 x 4 tile, a Linear is a 1 x 1 conv --
+#                     instead of the generic GEMM library
+NATIVE_ATTENTION = True
+NATIVE_LINEAR = False
+
+
+def linear(lin: nn.Linear, x: torch.Tensor) -> torch.Tensor:
+    """`lin(x)` for tokens x [B,N,C]; with NATIVE_LINEAR on fp32 GPU tokens (B*N a multiple of 16, channels multiples of 4) one
+    launch of the stacked-block 1x1 conv over the tokens seen as channels-last 4x4 tiles (views on both sides)."""
+    if (NATIVE_LINEAR and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.is_contiguous()
+            and (x.shape[0] * x.shape[1]) % 16 == 0 and x.shape[2] % 4 == 0 and lin.out_features % 4 == 0):
+        from .. import hip
+
+        w = lin.weight
+        key = (w.data_ptr(), w._version, tuple(w.shape), w.device)
+        if getattr(lin, "_sige_packed_key", None) != key:
+            lin._sige_packed = hip.conv_pack_weights(w.detach().reshape(w.shape[0], w.shape[1], 1, 1), 4, 4, (1, 1))
+            lin._sige_packed_key = key
+        if lin._sige_packed is not None:
+            b, n, c = x.shape
+            tiles = x.reshape(b * n // 16, 4, 4, c).permute(0, 3, 1, 2)  # [T,C,4,4] channels-last: the same bytes
+            out = hip.block_conv_cl(tiles, lin._sige_packed, lin.bias, lin.out_features, (1, 1), (1, 1))
+            if out is not None:
+                return out.permute(0, 2, 3, 1).reshape(b, n, lin.out_features)
+    return lin(x)
+
+
 def _heads(t: torch.Tensor, h: int) -> torch.Tensor:
     b, n, c = t.shape
     return t.reshape(b, n, h, c // h).permute(0, 2, 1, 3).reshape(b * h, n, c // h)
@@ -54,19 +85,25 @@ class Attention(SIGEModule):
         self.cached_k = self.cached_v = None
 
     def attend(self, q, k, v):
+        if NATIVE_ATTENTION and q.is_cuda and q.dtype == torch.float32:
+            from .. import hip
+
+            out = hip.attention_tokens(q, k, v, self.heads, self.scale)
+            if out is not None:
+                return self.to_out[1](linear(self.to_out[0], out))
         q, k, v = _heads(q, self.heads), _heads(k, self.heads), _heads(v, self.heads)
         sim = torch.bmm(q, k.transpose(1, 2)) * self.scale
-        return self.to_out(_merge(torch.bmm(sim.softmax(dim=-1), v), self.heads))
+        return self.to_out[1](linear(self.to_out[0], _merge(torch.bmm(sim.softmax(dim=-1), v), self.heads)))
 
     def forward(self, x, context=None):
         context = x if context is None else context
         if self.cache_context and self.mode != "full":
             k, v = self.cached_k, self.cached_v
         else:
-            k, v = self.to_k(context), self.to_v(context)
+            k, v = linear(self.to_k, context), linear(self.to_v, context)
             if self.cache_context:
                 self.cached_k, self.cached_v = k, v
-        return self.attend(self.to_q(x), k, v)
+        return self.attend(linear(self.to_q, x), k, v)
 
 
 class GEGLU(nn.Module):
@@ -75,7 +112,7 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, x):
-        a, gate = self.proj(x).chunk(2, dim=-1)
+        a, gate = linear(self.proj, x).chunk(2, dim=-1)
         return a * F.gelu(gate)
 
 
@@ -85,7 +122,7 @@ class FeedForward(nn.Module):
         self.net = nn.Sequential(GEGLU(dim, dim * mult), nn.Dropout(0.0), nn.Linear(dim * mult, dim))
 
     def forward(self, x):
-        return self.net(x)
+        return linear(self.net[2], self.net[1](self.net[0](x)))
 
 
 class TransformerBlock(SIGEModule):
@@ -103,19 +140,19 @@ class TransformerBlock(SIGEModule):
         xn = self.norm1(x)
         if kv_scatter is not None and self.mode == "full":
             ctx = xn if full_x is None else self.norm1(full_x)
-            k, v = a1.to_k(ctx), a1.to_v(ctx)
+            k, v = linear(a1.to_k, ctx), linear(a1.to_v, ctx)
             sk, sv, (hh, ww) = kv_scatter
             as_map = lambda t: t.reshape(t.shape[0], hh, ww, t.shape[2]).permute(0, 3, 1, 2)  # noqa: E731  [B,C,H,W] channels-last view
             sk(as_map(k)), sv(as_map(v))  # full mode: the Scatter modules remember K / V as their cached tensors
-            x = a1.attend(a1.to_q(xn), k, v) + x
+            x = a1.attend(linear(a1.to_q, xn), k, v) + x
         elif kv_scatter is not None and self.mode == "sparse":
             sk, sv, (hh, ww) = kv_scatter
             b, n, c = xn.shape
             as_tiles = lambda t: t.reshape(-1, 4, 4, t.shape[2]).permute(0, 3, 1, 2)  # noqa: E731  tokens -> [B*N,C,4,4] channels-last view
-            k = sk(as_tiles(a1.to_k(xn)))  # rows of the active tokens over the cached K of the original image
-            v = sv(as_tiles(a1.to_v(xn)))
+            k = sk(as_tiles(linear(a1.to_k, xn)))  # rows of the active tokens over the cached K of the original image
+            v = sv(as_tiles(linear(a1.to_v, xn)))
             as_tokens = lambda t: t.permute(0, 2, 3, 1).reshape(t.shape[0], hh * ww, t.shape[1])  # noqa: E731
-            x = a1.attend(a1.to_q(xn), as_tokens(k), as_tokens(v)) + x
+            x = a1.attend(linear(a1.to_q, xn), as_tokens(k), as_tokens(v)) + x
         else:
             x = a1(xn, context=None if full_x is None else self.norm1(full_x)) + x
         x = self.attn2(self.norm2(x), context=context) + x

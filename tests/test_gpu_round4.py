@@ -527,3 +527,48 @@ def test_wide_conv_pairs_with_the_shortcut(hip, compute, res, c1, c2, cout):
         torch.cuda.synchronize()
         assert hip.conv_pairs_fused() == f0 and hip.launch_count() == n0 + 2
         assert torch.equal(a, want_sf) and torch.equal(b, want_c)
+
+
+# ---- Stable Diffusion: the attention core and the token linears on the library -----------------------------
+@pytest.mark.parametrize("B,Nq,Nk,heads,d", [(2, 1008, 4096, 8, 40), (2, 160, 1024, 8, 80), (2, 48, 256, 8, 160), (2, 1008, 77, 8, 40),
+                                             (1, 16, 5, 1, 64), (3, 32, 16, 2, 8), (1, 64, 100, 4, 96)])
+def test_attention_tokens_vs_fp64(hip, B, Nq, Nk, heads, d):
+    """sige_hip_attention_tokens_f32 (multi-head softmax(q k^T / sqrt d) v, heads as strides, online softmax over key blocks
+    split across the waves) against the same expression in fp64 torch: SD's three head sizes at its own token counts (self-
+    attention over 64^2 / 32^2 / 16^2 tokens with sparse queries, cross-attention over 77 text tokens), key counts that are
+    not multiples of 16 and fewer key blocks than waves."""
+    g = torch.Generator().manual_seed(Nq + Nk + d)
+    C = heads * d
+    q, k, v = (torch.randn(B, n, C, generator=g).to(DEV) for n in (Nq, Nk, Nk))
+    q = q * 2.0  # (scores with a spread: the softmax is not flat)
+    scale = d ** -0.5
+    got = hip.attention_tokens(q, k, v, heads, scale)
+    assert got is not None and tuple(got.shape) == (B, Nq, C)
+
+    def heads_(t):
+        b, n, c = t.shape
+        return t.double().reshape(b, n, heads, d).permute(0, 2, 1, 3)
+
+    att = torch.softmax(heads_(q) @ heads_(k).transpose(-1, -2) * scale, dim=-1) @ heads_(v)
+    want = att.permute(0, 2, 1, 3).reshape(B, Nq, C)
+    torch.testing.assert_close(got.double(), want, rtol=0, atol=2e-5 * (1.0 + float(want.abs().max())))
+
+
+def test_sd_transformer_native_attention_and_linears(hip):
+    """The SD spatial transformer with the attention core / the token linears on the library's kernels gives what the
+    reference's rearrange / bmm / softmax / nn.Linear chain gives (fp32 summation order), in fewer launches and without a torch
+    bmm / softmax / copy kernel in the attention."""
+    from sige_amd.workloads import sd_transformer as sdt
+    from tests.test_models_golden import _sd_transformer
+
+    keep = (sdt.NATIVE_ATTENTION, sdt.NATIVE_LINEAR)
+    try:
+        outs = {}
+        for att, lin in ((False, False), (True, False), (True, True)):
+            sdt.NATIVE_ATTENTION, sdt.NATIVE_LINEAR = att, lin
+            outs[(att, lin)] = _sd_transformer("cuda", True, True)
+        for key in ((True, False), (True, True)):
+            for a, b in zip(outs[key], outs[(False, False)]):
+                torch.testing.assert_close(a, b, rtol=0, atol=2e-4)
+    finally:
+        sdt.NATIVE_ATTENTION, sdt.NATIVE_LINEAR = keep
