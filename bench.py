@@ -714,8 +714,13 @@ def main_sd(args, world, rank, dev):
         if rank == 0 and world == 1:
             keep_flags = (_sdt.NATIVE_ATTENTION, _sdt.NATIVE_LINEAR)
             ref_out = None
-            for tag, att, lin in (("reference_chain", False, False), ("native_attention", True, False), ("native_attention_and_linears", True, True)):
+            for tag, att, lin, form in (("reference_chain", False, False, 0), ("native_attention", True, False, 0),
+                                        ("native_attention_16_queries_per_workgroup", True, False, 1),
+                                        ("native_attention_32_queries_per_workgroup", True, False, 3),
+                                        ("native_attention_64_queries_per_workgroup_lds", True, False, 2),
+                                        ("native_attention_and_linears", True, True, 0)):
                 _sdt.NATIVE_ATTENTION, _sdt.NATIVE_LINEAR = att, lin
+                hip.lib().sige_hip_attention_tokens_force_form(form)
                 run(x1)
                 n0 = hip.launch_count()
                 run(x1)
@@ -726,6 +731,7 @@ def main_sd(args, world, rank, dev):
                 routing[tag] = {"forward_ms": round(ms_v, 3), "library_launches": nl, "max_abs_vs_reference_chain": round(float((o_v.float() - ref_out).abs().max()), 8)}
                 del g_v
             _sdt.NATIVE_ATTENTION, _sdt.NATIVE_LINEAR = keep_flags
+            hip.lib().sige_hip_attention_tokens_force_form(0)
             # per-kernel accounting of the library's launches in one forward (the same accounting as the DDPM headline's table)
             tracer = Tracer(hip)
             run(x1)
@@ -1106,7 +1112,8 @@ def main():
 
         # ---- headline: sparse forward at --ratio ----------------------------------
         x1 = prepare(args.ratio)
-        model(x1, t)  # packs weights, builds tile tables
+        model(x1, t)  # packs weights, builds tile tables, registers the activated twins
+        model(x1, t)  # builds the twins' persistent buffers (library launches since round 4: not part of a steady-state forward)
         tracer.log = []
         n0, p0 = hip.launch_count(), hip.conv_pairs_fused()
         model(x1, t)

@@ -515,6 +515,14 @@ int sige_hip_attention_f32(const float *qkv, int B, int C, int HW, float scale, 
 /* channels-last form: qkv [B,HW,3C] -> out [B,HW,C]; C % 64 == 0 */
 int sige_hip_attention_nhwc_f32(const float *qkv, int B, int C, int HW, float scale, float *workspace,
                                 float *out, void *stream);
+/* the same in ONE launch (round 4): workgroup = 16 queries x 64 keys, exact fp32 MFMA scores, the 64-key slices of a query
+ * block combined by the last one to finish (flash-decoding split; the tickets of the conv kernels' K-split finish) -- no score
+ * tensor in HBM, 6 launches fewer per DDPM forward.  C in {64, 128, 256, 512}, HW % 16 == 0, HW <= 1024; `workspace` holds the
+ * per-slice partial outputs (sige_hip_attention_fused_workspace floats; 0 = shape unsupported).  SIGE_HIP_EUNSUPPORTED: use
+ * sige_hip_attention_nhwc_f32. */
+size_t sige_hip_attention_fused_workspace(int B, int C, int HW);
+int sige_hip_attention_fused_nhwc_f32(const float *qkv, int B, int C, int HW, float scale, float *workspace,
+                                      float *out, void *stream);
 
 /* ---- split fp16 operands ("_f16x3"): fp32-level results from the fp16 matrix cores -------------------
  * The same entry points once more: every fp32 operand (staged activation after the cached affine + SiLU, weight) is
@@ -617,6 +625,9 @@ int sige_hip_affine_act_nhwc_f32(const float *x, int B, int C, int H, int W, con
  * and no score tensor in HBM: one launch, exact fp32 products, online softmax (attention.py's CrossAttention.forward does
  * rearrange x 3, einsum, softmax, einsum, rearrange).  Nq % 16 == 0, d % 4 == 0, d <= 160; Nk arbitrary.                */
 int sige_hip_attention_tokens_supported(int Nq, int Nk, int C, int heads);
+/* benchmarking / tests: 0 automatic | 1 always 16 queries per workgroup | 2 / 3: 64 (K / V staged through LDS) / 32 (two query
+ * tiles share every K / V register fragment) queries per workgroup wherever the form exists (d <= 96) */
+int sige_hip_attention_tokens_force_form(int form);
 int sige_hip_attention_tokens_f32(const float *q, const float *k, const float *v, int B, int Nq, int Nk, int C,
                                   int heads, float scale, float *out, void *stream);
 

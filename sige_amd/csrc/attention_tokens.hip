@@ -24,51 +24,62 @@ namespace sige {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int UNITS>  // 16-channel units covering the head dimension: d <= 16 * UNITS
+template <int UNITS, int QT>  // 16-channel units covering the head dimension (d <= 16 * UNITS); 16-query tiles per workgroup
 __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                                const float *__restrict__ v, float *__restrict__ out,
                                                                int Nq, int Nk, int C, int heads, int d, float scale_log2e) {
     constexpr int DT = UNITS;            // 16-column tiles of O
     constexpr int OS = UNITS * 16 + 4;   // padded row of the merge buffer
-    __shared__ __attribute__((aligned(16))) float p_lds[4][16][20];     // wave-private P tile
-    __shared__ float m_lds[4][16], l_lds[4][16];
-    extern __shared__ __attribute__((aligned(16))) float o_lds[];       // [4 waves][16 queries][OS]
+    constexpr int QR = 16 * QT;          // query rows of the workgroup
+    __shared__ __attribute__((aligned(16))) float p_lds[4][QT][16][20];  // wave-private P tiles
+    __shared__ float m_lds[4][QR], l_lds[4][QR];
+    extern __shared__ __attribute__((aligned(16))) float o_lds[];        // [4 waves][QR queries][OS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kq = lane >> 4, j = lane & 15;
     const int head = blockIdx.y % heads, b = blockIdx.y / heads;
-    const int q0 = blockIdx.x * 16;
+    const int q0 = blockIdx.x * QR;
     const size_t hoff = (size_t)head * d;
-    const float *qb = q + ((size_t)b * Nq + q0) * C + hoff;
     const float *kb = k + (size_t)b * Nk * C + hoff;
     const float *vb = v + (size_t)b * Nk * C + hoff;
 
-    // Q of this lane: row j, channels 16u + 4kq .. +3 of every unit (zeros beyond d)
-    float4 qr[UNITS];
+    // Q of this lane: row j of every query tile, channels 16u + 4kq .. +3 of every unit (zeros beyond d; a tile past Nq -- the
+    // last workgroup of an odd tile count -- reads the last tile's rows and is not stored)
+    float4 qr[QT][UNITS];
 #pragma unroll
-    for (int u = 0; u < UNITS; ++u) {
-        const int c = 16 * u + 4 * kq;
-        qr[u] = c < d ? *reinterpret_cast<const float4 *>(qb + (size_t)j * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < QT; ++t) {
+        const int qrow = min(q0 + 16 * t, Nq - 16) + j;
+        const float *qb = q + ((size_t)b * Nq + qrow) * C + hoff;
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            const int c = 16 * u + 4 * kq;
+            qr[t][u] = c < d ? *reinterpret_cast<const float4 *>(qb + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
-    // running softmax state of rows 4kq .. 4kq+3 (replicated over the 16 lanes j) and the O accumulators (C layout:
-    // o[n][r] = O[row 4kq + r][column 16n + j])
-    float m_run[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, l_run[4] = {0.f, 0.f, 0.f, 0.f};
-    f32x4 o[DT];
+    // running softmax state of rows 4kq .. 4kq+3 of every tile (replicated over the 16 lanes j) and the O accumulators (C
+    // layout: o[t][n][r] = O[row 16t + 4kq + r][column 16n + j])
+    float m_run[QT][4], l_run[QT][4];
+    f32x4 o[QT][DT];
 #pragma unroll
-    for (int n = 0; n < DT; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < QT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { m_run[t][r] = -INFINITY; l_run[t][r] = 0.f; }
+#pragma unroll
+        for (int n = 0; n < DT; ++n) o[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     const int nkb = (Nk + 15) / 16;
     for (int kblk = wave; kblk < nkb; kblk += 4) {
         const int key0 = kblk * 16;
         const int key = min(key0 + j, Nk - 1);  // (tail: a valid address; the column is masked below)
-        // ---- S = Q K^T ----
+        // K and V of this block: loaded ONCE, used by every query tile of the workgroup.  The V operands do not depend on the
+        // scores: in flight under the score MFMAs and the softmax
         float4 kr[UNITS];
 #pragma unroll
         for (int u = 0; u < UNITS; ++u) {
             const int c = 16 * u + 4 * kq;
             kr[u] = c < d ? *reinterpret_cast<const float4 *>(kb + (size_t)key * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        // the V operands of this block do not depend on the scores: in flight under the score MFMAs and the softmax
         float vr[4][DT];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -81,63 +92,66 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
                 vr[t][n] = (ok && c < d) ? vp[c] : 0.f;
             }
         }
-        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < UNITS; ++u) {
-            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[u].x, kr[u].x, s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[u].y, kr[u].y, s1, 0, 0, 0);
-            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[u].z, kr[u].z, s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[u].w, kr[u].w, s1, 0, 0, 0);
-        }
-        // s[r] = S[row 4kq + r][key0 + j], in units of log2: exp(x) = exp2(x * log2 e)
-        float s[4];
         const bool live = key0 + j < Nk;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[r] = live ? (s0[r] + s1[r]) * scale_log2e : -INFINITY;
-        // ---- online softmax: row maxima over the 16 lanes of a kq group ----
-        float alpha[4];
+        for (int qt = 0; qt < QT; ++qt) {
+            // ---- S = Q K^T ----
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float mx = s[r];
+            for (int u = 0; u < UNITS; ++u) {
+                s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[qt][u].x, kr[u].x, s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[qt][u].y, kr[u].y, s1, 0, 0, 0);
+                s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[qt][u].z, kr[u].z, s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[qt][u].w, kr[u].w, s1, 0, 0, 0);
+            }
+            // ---- online softmax; s = S[row 4kq + r][key0 + j] in units of log2: exp(x) = exp2(x * log2 e) ----
+            float alpha[4];
 #pragma unroll
-            for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 16));
-            const float m_new = fmaxf(m_run[r], mx);  // (finite: every block has at least one live key)
-            alpha[r] = __builtin_amdgcn_exp2f(m_run[r] - m_new);  // (exp2(-inf) = 0 on the first block)
-            const float p = __builtin_amdgcn_exp2f(s[r] - m_new);
-            float ps = p;
+            for (int r = 0; r < 4; ++r) {
+                const float sv = live ? (s0[r] + s1[r]) * scale_log2e : -INFINITY;
+                const float m_new = fmaxf(m_run[qt][r], row16_max(sv));  // (finite: every block has at least one live key)
+                alpha[r] = __builtin_amdgcn_exp2f(m_run[qt][r] - m_new);  // (exp2(-inf) = 0 on the first block)
+                const float p = __builtin_amdgcn_exp2f(sv - m_new);
+                l_run[qt][r] = l_run[qt][r] * alpha[r] + row16_sum(p);
+                m_run[qt][r] = m_new;
+                p_lds[wave][qt][4 * kq + r][j] = p;
+            }
 #pragma unroll
-            for (int off = 8; off > 0; off >>= 1) ps += __shfl_xor(ps, off, 16);
-            l_run[r] = l_run[r] * alpha[r] + ps;
-            m_run[r] = m_new;
-            p_lds[wave][4 * kq + r][j] = p;
+            for (int n = 0; n < DT; ++n) {
+                o[qt][n][0] *= alpha[0]; o[qt][n][1] *= alpha[1]; o[qt][n][2] *= alpha[2]; o[qt][n][3] *= alpha[3];
+            }
         }
-#pragma unroll
-        for (int n = 0; n < DT; ++n) {
-            o[n][0] *= alpha[0]; o[n][1] *= alpha[1]; o[n][2] *= alpha[2]; o[n][3] *= alpha[3];
-        }
-        __builtin_amdgcn_wave_barrier();  // (LDS is in order per wave: the tile written above is complete for this wave's reads)
+        __builtin_amdgcn_wave_barrier();  // (LDS is in order per wave: the tiles written above are complete for this wave's reads)
         // ---- O += P V: A[row j][k = key 4t + kq] from the LDS tile ----
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const float a = p_lds[wave][j][4 * t + kq];
 #pragma unroll
-            for (int n = 0; n < DT; ++n) o[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vr[t][n], o[n], 0, 0, 0);
+            for (int qt = 0; qt < QT; ++qt) {
+                const float a = p_lds[wave][qt][j][4 * t + kq];
+#pragma unroll
+                for (int n = 0; n < DT; ++n) o[qt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vr[t][n], o[qt][n], 0, 0, 0);
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
 
     // ---- merge the four waves' (m, l, O) ----
-    float *ow = o_lds + (size_t)wave * 16 * OS;
+    float *ow = o_lds + (size_t)wave * QR * OS;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        if (j == 0) { m_lds[wave][4 * kq + r] = m_run[r]; l_lds[wave][4 * kq + r] = l_run[r]; }
+    for (int qt = 0; qt < QT; ++qt) {
 #pragma unroll
-        for (int n = 0; n < DT; ++n) ow[(4 * kq + r) * OS + 16 * n + j] = o[n][r];
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * qt + 4 * kq + r;
+            if (j == 0) { m_lds[wave][row] = m_run[qt][r]; l_lds[wave][row] = l_run[qt][r]; }
+#pragma unroll
+            for (int n = 0; n < DT; ++n) ow[row * OS + 16 * n + j] = o[qt][n][r];
+        }
     }
     __syncthreads();
     // thread -> (query row, 4 consecutive channels)
     const int units_per_row = d / 4;
-    for (int e = tid; e < 16 * units_per_row; e += 256) {
+    const int rows = min(QR, Nq - q0);
+    for (int e = tid; e < rows * units_per_row; e += 256) {
         const int row = e / units_per_row, c = (e - row * units_per_row) * 4;
         float M = fmaxf(fmaxf(m_lds[0][row], m_lds[1][row]), fmaxf(m_lds[2][row], m_lds[3][row]));
         float L = 0.f;
@@ -147,7 +161,7 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
             const float mw = m_lds[w][row];
             const float f = mw == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mw - M);  // (a wave without a key block)
             L += f * l_lds[w][row];
-            const float4 ov = *reinterpret_cast<const float4 *>(o_lds + ((size_t)w * 16 + row) * OS + c);
+            const float4 ov = *reinterpret_cast<const float4 *>(o_lds + ((size_t)w * QR + row) * OS + c);
             acc.x += f * ov.x; acc.y += f * ov.y; acc.z += f * ov.z; acc.w += f * ov.w;
         }
         const float inv = 1.0f / L;
@@ -156,9 +170,152 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
     }
 }
 
+// Many queries (the self-attention of the 64 x 64 level: ~1000 active tokens against 4096 keys): 64 queries per workgroup, one
+// 16-query tile per wave, and the key / value blocks (32 keys) staged ONCE per workgroup in LDS, double buffered -- every K / V
+// byte is pulled from L2 once per 64 queries instead of once per 16, with 16-byte coalesced loads; no merge at the end (each
+// wave owns its queries for all keys).
+template <int UNITS>
+__global__ __launch_bounds__(256) void attention_tokens_q64_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                                   const float *__restrict__ v, float *__restrict__ out,
+                                                                   int Nq, int Nk, int C, int heads, int d, float scale_log2e) {
+    constexpr int DT = UNITS, KB = 32;
+    constexpr int RS = UNITS * 16 + 4;                 // padded LDS row (floats)
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2 stages][K | V][KB][RS], then P tiles [4][16][36]
+    float *const p_lds_base = lds + 2 * 2 * KB * RS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kq = lane >> 4, j = lane & 15;
+    const int head = blockIdx.y % heads, b = blockIdx.y / heads;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+    const bool qlive = q0 < Nq;                        // (Nq % 16 == 0: a wave's tile is whole or absent)
+    const size_t hoff = (size_t)head * d;
+    const float *qb = q + ((size_t)b * Nq + (qlive ? q0 : 0)) * C + hoff;
+    const float *kb = k + (size_t)b * Nk * C + hoff;
+    const float *vb = v + (size_t)b * Nk * C + hoff;
+    float *pw = p_lds_base + wave * 16 * 36;
+
+    float4 qr[UNITS];
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u) {
+        const int c = 16 * u + 4 * kq;
+        qr[u] = c < d ? *reinterpret_cast<const float4 *>(qb + (size_t)j * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float m_run[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, l_run[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 o[DT];
+#pragma unroll
+    for (int n = 0; n < DT; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // cooperative staging: unit e of a block = (key, 4 channels); keys past Nk and channels past d are zeros
+    const int upr = UNITS * 4;                          // float4 units per row
+    constexpr int NLD = (KB * UNITS * 4 + 255) / 256;   // units per thread and tensor
+    float4 kst[NLD], vst[NLD];
+    auto g_load = [&](int key0) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + 256 * i;
+            const int row = e / upr, c = (e - row * upr) * 4;
+            const int key = key0 + row;
+            const bool ok = e < KB * upr && key < Nk && c < d;
+            const size_t off = (size_t)(ok ? key : 0) * C + (ok ? c : 0);
+            kst[i] = ok ? *reinterpret_cast<const float4 *>(kb + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            vst[i] = ok ? *reinterpret_cast<const float4 *>(vb + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto l_store = [&](int stage) {
+        float *ks = lds + (size_t)stage * 2 * KB * RS, *vs = ks + KB * RS;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + 256 * i;
+            if (e < KB * upr) {
+                const int row = e / upr, c = (e - row * upr) * 4;
+                *reinterpret_cast<float4 *>(ks + row * RS + c) = kst[i];
+                *reinterpret_cast<float4 *>(vs + row * RS + c) = vst[i];
+            }
+        }
+    };
+    const int nkb = (Nk + KB - 1) / KB;
+    g_load(0);
+    l_store(0);
+    if (nkb > 1) g_load(KB);
+    __syncthreads();
+    for (int kblk = 0; kblk < nkb; ++kblk) {
+        const int stage = kblk & 1;
+        const float *ks = lds + (size_t)stage * 2 * KB * RS, *vs = ks + KB * RS;
+        const int key0 = kblk * KB;
+        if (qlive) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {     // two 16-key tiles of the block
+                const int kt0 = key0 + 16 * half;
+                if (kt0 < Nk) {                        // (wave-uniform)
+                    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+                    const float *krow = ks + (16 * half + j) * RS + 4 * kq;
+#pragma unroll
+                    for (int u = 0; u < UNITS; ++u) {
+                        const float4 kr = *reinterpret_cast<const float4 *>(krow + 16 * u);
+                        s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[u].x, kr.x, s0, 0, 0, 0);
+                        s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[u].y, kr.y, s1, 0, 0, 0);
+                        s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[u].z, kr.z, s0, 0, 0, 0);
+                        s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[u].w, kr.w, s1, 0, 0, 0);
+                    }
+                    const bool live = kt0 + j < Nk;
+                    float alpha[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float sv = live ? (s0[r] + s1[r]) * scale_log2e : -INFINITY;
+                        const float m_new = fmaxf(m_run[r], row16_max(sv));
+                        alpha[r] = __builtin_amdgcn_exp2f(m_run[r] - m_new);
+                        const float p = __builtin_amdgcn_exp2f(sv - m_new);
+                        l_run[r] = l_run[r] * alpha[r] + row16_sum(p);
+                        m_run[r] = m_new;
+                        pw[(4 * kq + r) * 36 + j] = p;
+                    }
+#pragma unroll
+                    for (int n = 0; n < DT; ++n) {
+                        o[n][0] *= alpha[0]; o[n][1] *= alpha[1]; o[n][2] *= alpha[2]; o[n][3] *= alpha[3];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float a = pw[j * 36 + 4 * t + kq];
+                        const float *vrow = vs + (16 * half + 4 * t + kq) * RS + j;
+#pragma unroll
+                        for (int n = 0; n < DT; ++n) o[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vrow[16 * n], o[n], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        // the next block: registers -> the other stage (nobody reads it: its last readers passed the barrier below one iteration
+        // ago), then the block after that into the registers
+        if (kblk + 1 < nkb) l_store(stage ^ 1);
+        if (kblk + 2 < nkb) g_load((kblk + 2) * KB);
+        __syncthreads();
+    }
+    if (qlive) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float inv = 1.0f / l_run[r];
+            float *orow = out + ((size_t)b * Nq + q0 + 4 * kq + r) * C + hoff;
+#pragma unroll
+            for (int n = 0; n < DT; ++n) {
+                const int c = 16 * n + j;
+                if (c < d) orow[c] = o[n][r] * inv;
+            }
+        }
+    }
+}
+
 }  // namespace sige
 
 using namespace sige;
+
+static int g_attention_force_form = 0;  // benchmarking: 0 automatic | 1 16 queries per workgroup | 2 64 (K / V through LDS) | 3 32
+
+extern "C" int sige_hip_attention_tokens_force_form(int form) {
+    if (form < 0 || form > 3) return SIGE_HIP_EINVAL;
+    g_attention_force_form = form;
+    return SIGE_HIP_OK;
+}
 
 extern "C" int sige_hip_attention_tokens_supported(int Nq, int Nk, int C, int heads) {
     if (Nq <= 0 || Nk <= 0 || C <= 0 || heads <= 0 || C % heads) return 0;
@@ -178,10 +335,21 @@ extern "C" int sige_hip_attention_tokens_f32(const float *q, const float *k, con
     const int d = C / heads;
     const int units = (d + 15) / 16;
     const float sl = scale * 1.44269504088896341f;
-    const dim3 grid(Nq / 16, B * heads);
     hipStream_t st = as_stream(stream);
+    // 16 queries per workgroup, the key blocks split across its 4 waves; 32 (two tiles sharing every K / V fragment a wave loads:
+    // half the loads per MFMA) where that still leaves every CU two workgroups and the accumulators fit (d <= 96); 64 with the
+    // K / V blocks staged through LDS only on request (measured slower at SD's shapes: one wave per SIMD)
+    const long wg32 = (long)((Nq + 31) / 32) * B * heads;
+    int form = g_attention_force_form;
+    if (form == 0) form = (units <= 6 && wg32 >= 512 && Nk >= 256) ? 3 : 1;
+    if (units > 6 && form != 1) form = 1;
+    const dim3 grid16(Nq / 16, B * heads), grid32((Nq + 31) / 32, B * heads), grid64((Nq + 63) / 64, B * heads);
 #define SIGE_ATT_GO(U)                                                                                             \
-    attention_tokens_kernel<U><<<grid, 256, (size_t)4 * 16 * (U * 16 + 4) * sizeof(float), st>>>(q, k, v, out, Nq, Nk, C, heads, d, sl)
+    do {                                                                                                           \
+        if (form == 2) attention_tokens_q64_kernel<U><<<grid64, 256, (size_t)(4 * 32 * (U * 16 + 4) + 4 * 16 * 36) * sizeof(float), st>>>(q, k, v, out, Nq, Nk, C, heads, d, sl); \
+        else if (form == 3) attention_tokens_kernel<(U <= 6 ? U : 1), 2><<<grid32, 256, (size_t)4 * 32 * (U * 16 + 4) * sizeof(float), st>>>(q, k, v, out, Nq, Nk, C, heads, d, sl); \
+        else attention_tokens_kernel<U, 1><<<grid16, 256, (size_t)4 * 16 * (U * 16 + 4) * sizeof(float), st>>>(q, k, v, out, Nq, Nk, C, heads, d, sl); \
+    } while (0)
     switch (units) {
         case 1: SIGE_ATT_GO(1); break;
         case 2: SIGE_ATT_GO(2); break;

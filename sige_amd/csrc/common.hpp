@@ -99,6 +99,29 @@ inline int launch_status(int kernels = 1) {
 // (or, during a hipGraph capture, for the life of the graph); nullptr = unavailable, the caller must not split
 int32_t *split_tickets(hipStream_t st, long blocks);
 
+// All-reduce over the 16 lanes of a DPP row (lanes 16r .. 16r+15 of a wave) on the VALU's data-parallel-primitive path: quad
+// swaps (xor 1, xor 2), then the mirror of a half row and of the row -- four VALU operations, every lane ends with the same
+// bits (each step combines two disjoint, complete groups symmetrically).  __shfl_xor compiles to ds_bpermute_b32: a trip
+// through the LDS pipeline per step, ~8 dependent trips per softmax row.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_mov<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_mov<0x141>(v));  // row_half_mirror
+    v = fmaxf(v, dpp_mov<0x140>(v));  // row_mirror
+    return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    return v;
+}
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

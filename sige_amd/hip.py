@@ -127,6 +127,8 @@ _SIGNATURES = {
     "sige_hip_conv3x3_small_cin_nhwc_f32": (
         _c_int, [_c_vp] + [ctypes.c_int64] * 4 + [_c_int] * 4 + [_c_vp, _c_vp, _c_int, _c_vp, _c_vp]),
     "sige_hip_attention_nhwc_f32": (_c_int, [_c_vp, _c_int, _c_int, _c_int, ctypes.c_float, _c_vp, _c_vp, _c_vp]),
+    "sige_hip_attention_fused_workspace": (_c_sz, [_c_int] * 3),
+    "sige_hip_attention_fused_nhwc_f32": (_c_int, [_c_vp, _c_int, _c_int, _c_int, ctypes.c_float, _c_vp, _c_vp, _c_vp]),
     # split fp16 operands (tile kernels)
     "sige_hip_block_conv_packed_size_f16x3": (_c_sz, [_c_int] * 9),
     "sige_hip_block_conv_pack_f16x3": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp]),
@@ -157,6 +159,7 @@ _SIGNATURES = {
     "sige_hip_group_norm_affine_from_stats_f32": (
         _c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_float] + [_c_vp] * 6),
     "sige_hip_attention_tokens_supported": (_c_int, [_c_int] * 4),
+    "sige_hip_attention_tokens_force_form": (_c_int, [_c_int]),
     "sige_hip_attention_tokens_f32": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [ctypes.c_float, _c_vp, _c_vp]),
     # fp16-stored caches
     "sige_hip_gather_nhwc_f16": (
@@ -1581,13 +1584,29 @@ def affine_act_cl(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, act
     return out
 
 
+# attention_cl: scores + softmax + values in ONE launch (csrc/attention_fused.hip) instead of two.  Off: measured on MI355X
+# (profiles/r4h_attention_ab.json) the one-launch form is 18.8 us against 11.8 us at DDPM's 256 tokens x 512 channels (its chain
+# loads -> scores -> softmax -> values -> partials -> ticket -> combine is serial in every workgroup; the two-launch form spreads
+# each phase over 256 / 128 workgroups) and the forward 1.435 ms against 1.403 ms, with 6 launches fewer.
+FUSED_ATTENTION = False
+
+
 def attention_cl(qkv: torch.Tensor, scale: float):
     """Channels-last attention: qkv [B,3C,H,W] stored [B,H,W,3C] -> [B,C,H,W] channels-last; None if unsupported."""
     qkv = _req_cl(qkv, "qkv")
     B, C3, H, W = qkv.shape
     C, HW = C3 // 3, H * W
-    ws = torch.empty(B * HW * HW, dtype=torch.float32, device=qkv.device)
     out = _empty_cl((B, C, H, W), qkv.device)
+    if FUSED_ATTENTION:  # one launch: the key slices of a query block are combined by the last one to finish
+        n = int(lib().sige_hip_attention_fused_workspace(B, C, HW))
+        if n:
+            ws = torch.empty(n, dtype=torch.float32, device=qkv.device)
+            status = lib().sige_hip_attention_fused_nhwc_f32(qkv.data_ptr(), B, C, HW, float(scale), ws.data_ptr(), out.data_ptr(),
+                                                             _stream(qkv))
+            if status != UNSUPPORTED:
+                _check(status, "attention_fused_cl")
+                return out
+    ws = torch.empty(B * HW * HW, dtype=torch.float32, device=qkv.device)
     status = lib().sige_hip_attention_nhwc_f32(qkv.data_ptr(), B, C, HW, float(scale), ws.data_ptr(), out.data_ptr(),
                                                _stream(qkv))
     if status == UNSUPPORTED:

@@ -529,10 +529,65 @@ def test_wide_conv_pairs_with_the_shortcut(hip, compute, res, c1, c2, cout):
         assert torch.equal(a, want_sf) and torch.equal(b, want_c)
 
 
+# ---- DDPM: the attention block's scores + softmax + values in one launch (VERDICT r3 #7 / missing #5) ----------------------
+@pytest.mark.parametrize("B,C,hw", [(1, 512, 16), (1, 512, 8), (2, 64, 12), (1, 256, 32), (2, 128, 20), (3, 512, 4)])
+def test_attention_one_launch(hip, B, C, hw):
+    """sige_hip_attention_fused_nhwc_f32 -- workgroup = 16 queries x 64 keys, the slices of a query block combined by the last
+    one to finish -- against fp64 torch and against the two-launch form: DDPM's own shapes (16 x 16 and 8 x 8 tokens, C = 512),
+    token counts that are not multiples of 64 (a ragged last slice), the largest supported (1024 tokens = 16 slices), one slice
+    only; ONE launch, and the tickets are back at zero for the next one (a second launch gives the same bits)."""
+    g = torch.Generator().manual_seed(C + hw)
+    qkv = (torch.randn(B, 3 * C, hw, hw, generator=g) * 1.5).to(DEV).contiguous(memory_format=torch.channels_last)
+    keep = hip.FUSED_ATTENTION
+    try:
+        hip.FUSED_ATTENTION = True
+        assert hip.lib().sige_hip_attention_fused_workspace(B, C, hw * hw) > 0
+        n0 = hip.launch_count()
+        got = hip.attention_cl(qkv, C ** -0.5)
+        assert hip.launch_count() == n0 + 1
+        again = hip.attention_cl(qkv, C ** -0.5)
+        hip.FUSED_ATTENTION = False
+        n0 = hip.launch_count()
+        two = hip.attention_cl(qkv, C ** -0.5)  # (None at 1024 tokens: its 16 score rows do not fit the 64 KB of LDS a launch gets)
+        assert hip.launch_count() == n0 + (2 if two is not None else 0)
+    finally:
+        hip.FUSED_ATTENTION = keep
+    assert got is not None and hip.is_cl(got) and torch.equal(got, again)
+    q, k, v = qkv.double().reshape(B, 3, C, hw * hw).unbind(1)
+    attn = torch.softmax(torch.bmm(q.transpose(1, 2), k) * (C ** -0.5), dim=2)
+    want = torch.bmm(v, attn.transpose(1, 2)).reshape(B, C, hw, hw).float()
+    torch.testing.assert_close(got.contiguous(), want, rtol=0, atol=2e-5)
+    if two is not None:
+        torch.testing.assert_close(got, two, rtol=0, atol=2e-5)
+
+
+def test_attention_one_launch_under_a_graph(hip, monkeypatch):
+    """The one-launch attention inside a hipGraph (its tickets then come from the graph's own range): replays give the eager bits."""
+    monkeypatch.setattr(hip, "FUSED_ATTENTION", True)
+    torch.manual_seed(5)
+    qkv = torch.randn(1, 3 * 512, 16, 16, device=DEV).contiguous(memory_format=torch.channels_last)
+    n0 = hip.launch_count()
+    eager = hip.attention_cl(qkv, 512 ** -0.5).clone()
+    assert hip.launch_count() == n0 + 1
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        hip.attention_cl(qkv, 512 ** -0.5)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            out = hip.attention_cl(qkv, 512 ** -0.5)
+    torch.cuda.current_stream().wait_stream(s)
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager)
+
+
 # ---- Stable Diffusion: the attention core and the token linears on the library (VERDICT r3 #7) -----------------------------
+@pytest.mark.parametrize("form", [0, 1, 2, 3])
 @pytest.mark.parametrize("B,Nq,Nk,heads,d", [(2, 1008, 4096, 8, 40), (2, 160, 1024, 8, 80), (2, 48, 256, 8, 160), (2, 1008, 77, 8, 40),
-                                             (1, 16, 5, 1, 64), (3, 32, 16, 2, 8), (1, 64, 100, 4, 96)])
-def test_attention_tokens_vs_fp64(hip, B, Nq, Nk, heads, d):
+                                             (1, 16, 5, 1, 64), (3, 32, 16, 2, 8), (1, 64, 100, 4, 96), (1, 80, 33, 2, 20)])
+def test_attention_tokens_vs_fp64(hip, B, Nq, Nk, heads, d, form):
     """sige_hip_attention_tokens_f32 (multi-head softmax(q k^T / sqrt d) v, heads as strides, online softmax over key blocks
     split across the waves) against the same expression in fp64 torch: SD's three head sizes at its own token counts (self-
     attention over 64^2 / 32^2 / 16^2 tokens with sparse queries, cross-attention over 77 text tokens), key counts that are
@@ -542,7 +597,14 @@ def test_attention_tokens_vs_fp64(hip, B, Nq, Nk, heads, d):
     q, k, v = (torch.randn(B, n, C, generator=g).to(DEV) for n in (Nq, Nk, Nk))
     q = q * 2.0  # (scores with a spread: the softmax is not flat)
     scale = d ** -0.5
-    got = hip.attention_tokens(q, k, v, heads, scale)
+    # form 1: 16 queries per workgroup, key blocks split across the waves; form 3: 32 (two query tiles share every K / V fragment;
+    # an odd tile count leaves the last workgroup half empty); form 2: 64 queries per workgroup, K / V blocks staged in LDS
+    # (query counts that are not multiples of 64, one key block, a ragged last block); 0: the library's choice
+    assert hip.lib().sige_hip_attention_tokens_force_form(form) == 0
+    try:
+        got = hip.attention_tokens(q, k, v, heads, scale)
+    finally:
+        hip.lib().sige_hip_attention_tokens_force_form(0)
     assert got is not None and tuple(got.shape) == (B, Nq, C)
 
     def heads_(t):
