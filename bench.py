@@ -715,9 +715,7 @@ def main_sd(args, world, rank, dev):
             keep_flags = (_sdt.NATIVE_ATTENTION, _sdt.NATIVE_LINEAR)
             ref_out = None
             for tag, att, lin, form in (("reference_chain", False, False, 0), ("native_attention", True, False, 0),
-                                        ("native_attention_16_queries_per_workgroup", True, False, 1),
-                                        ("native_attention_32_queries_per_workgroup", True, False, 3),
-                                        ("native_attention_64_queries_per_workgroup_lds", True, False, 2),
+                                        ("native_attention_32_queries_per_workgroup", True, False, 2),
                                         ("native_attention_and_linears", True, True, 0)):
                 _sdt.NATIVE_ATTENTION, _sdt.NATIVE_LINEAR = att, lin
                 hip.lib().sige_hip_attention_tokens_force_form(form)

@@ -625,8 +625,8 @@ int sige_hip_affine_act_nhwc_f32(const float *x, int B, int C, int H, int W, con
  * and no score tensor in HBM: one launch, exact fp32 products, online softmax (attention.py's CrossAttention.forward does
  * rearrange x 3, einsum, softmax, einsum, rearrange).  Nq % 16 == 0, d % 4 == 0, d <= 160; Nk arbitrary.                */
 int sige_hip_attention_tokens_supported(int Nq, int Nk, int C, int heads);
-/* benchmarking / tests: 0 automatic | 1 always 16 queries per workgroup | 2 / 3: 64 (K / V staged through LDS) / 32 (two query
- * tiles share every K / V register fragment) queries per workgroup wherever the form exists (d <= 96) */
+/* benchmarking / tests: 0 automatic (= 1) | 1 16 queries per workgroup | 2 32 (two query tiles share every K / V register
+ * fragment) wherever the form exists (d <= 96) */
 int sige_hip_attention_tokens_force_form(int form);
 int sige_hip_attention_tokens_f32(const float *q, const float *k, const float *v, int B, int Nq, int Nk, int C,
                                   int heads, float scale, float *out, void *stream);

@@ -14,7 +14,14 @@
 //   K[key j][same 4 channels] -- one 16-byte load each, four k-steps; the head dimension d (40 / 80 / 160 for SD v1) is padded
 //   to whole units with zeros.
 //   P = exp(S - m) goes through a wave-private 16 x 16 LDS tile (C layout -> A layout); O += P V with V[key 4t + kq][16n + j]
-//   straight from global memory (16 lanes = 64 contiguous bytes of a key's row).
+//   straight from global memory (16 lanes = 64 contiguous bytes of a key's row).  Row maxima / sums over the 16 lanes of a
+//   score row on the DPP path (common.hpp row16_max / row16_sum), not through LDS shuffles.
+//   Measured at SD's shapes (1008 queries x 4096 keys x 8 heads x 40, batch 2: 10.6 GFLOP): 224 us = 47 TFLOP/s (0.30 of the
+//   fp32 MFMA peak; d = 40 fills 40 / 48 of the padded tiles).  Variants measured and not kept (profiles/r4h_bench_sd.json,
+//   r4i_bench_sd.json): 64 queries per workgroup with the K / V blocks staged through LDS (4x fewer L2 reads, but one wave per
+//   SIMD: 1.5x slower); two query tiles per wave sharing each K / V fragment (template parameter QT: equal); LDS shuffles
+//   instead of DPP (equal) -- the kernel is bound by the dependent chain scores -> softmax -> P through LDS -> values of a
+//   wave, not by loads.
 //
 // q [B,Nq,C], k / v [B,Nk,C], out [B,Nq,C], C = heads * d, all row-major fp32 (a channels-last [B,C,H,W] tensor IS [B,HW,C];
 // channels-last tiles [T,C,4,4] ARE [T*16, C]: no copy on either side).  Nq % 16 == 0; Nk arbitrary (tail keys masked).
@@ -170,149 +177,14 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
     }
 }
 
-// Many queries (the self-attention of the 64 x 64 level: ~1000 active tokens against 4096 keys): 64 queries per workgroup, one
-// 16-query tile per wave, and the key / value blocks (32 keys) staged ONCE per workgroup in LDS, double buffered -- every K / V
-// byte is pulled from L2 once per 64 queries instead of once per 16, with 16-byte coalesced loads; no merge at the end (each
-// wave owns its queries for all keys).
-template <int UNITS>
-__global__ __launch_bounds__(256) void attention_tokens_q64_kernel(const float *__restrict__ q, const float *__restrict__ k,
-                                                                   const float *__restrict__ v, float *__restrict__ out,
-                                                                   int Nq, int Nk, int C, int heads, int d, float scale_log2e) {
-    constexpr int DT = UNITS, KB = 32;
-    constexpr int RS = UNITS * 16 + 4;                 // padded LDS row (floats)
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2 stages][K | V][KB][RS], then P tiles [4][16][36]
-    float *const p_lds_base = lds + 2 * 2 * KB * RS;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kq = lane >> 4, j = lane & 15;
-    const int head = blockIdx.y % heads, b = blockIdx.y / heads;
-    const int q0 = blockIdx.x * 64 + wave * 16;
-    const bool qlive = q0 < Nq;                        // (Nq % 16 == 0: a wave's tile is whole or absent)
-    const size_t hoff = (size_t)head * d;
-    const float *qb = q + ((size_t)b * Nq + (qlive ? q0 : 0)) * C + hoff;
-    const float *kb = k + (size_t)b * Nk * C + hoff;
-    const float *vb = v + (size_t)b * Nk * C + hoff;
-    float *pw = p_lds_base + wave * 16 * 36;
-
-    float4 qr[UNITS];
-#pragma unroll
-    for (int u = 0; u < UNITS; ++u) {
-        const int c = 16 * u + 4 * kq;
-        qr[u] = c < d ? *reinterpret_cast<const float4 *>(qb + (size_t)j * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    float m_run[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, l_run[4] = {0.f, 0.f, 0.f, 0.f};
-    f32x4 o[DT];
-#pragma unroll
-    for (int n = 0; n < DT; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // cooperative staging: unit e of a block = (key, 4 channels); keys past Nk and channels past d are zeros
-    const int upr = UNITS * 4;                          // float4 units per row
-    constexpr int NLD = (KB * UNITS * 4 + 255) / 256;   // units per thread and tensor
-    float4 kst[NLD], vst[NLD];
-    auto g_load = [&](int key0) {
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int e = tid + 256 * i;
-            const int row = e / upr, c = (e - row * upr) * 4;
-            const int key = key0 + row;
-            const bool ok = e < KB * upr && key < Nk && c < d;
-            const size_t off = (size_t)(ok ? key : 0) * C + (ok ? c : 0);
-            kst[i] = ok ? *reinterpret_cast<const float4 *>(kb + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-            vst[i] = ok ? *reinterpret_cast<const float4 *>(vb + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto l_store = [&](int stage) {
-        float *ks = lds + (size_t)stage * 2 * KB * RS, *vs = ks + KB * RS;
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int e = tid + 256 * i;
-            if (e < KB * upr) {
-                const int row = e / upr, c = (e - row * upr) * 4;
-                *reinterpret_cast<float4 *>(ks + row * RS + c) = kst[i];
-                *reinterpret_cast<float4 *>(vs + row * RS + c) = vst[i];
-            }
-        }
-    };
-    const int nkb = (Nk + KB - 1) / KB;
-    g_load(0);
-    l_store(0);
-    if (nkb > 1) g_load(KB);
-    __syncthreads();
-    for (int kblk = 0; kblk < nkb; ++kblk) {
-        const int stage = kblk & 1;
-        const float *ks = lds + (size_t)stage * 2 * KB * RS, *vs = ks + KB * RS;
-        const int key0 = kblk * KB;
-        if (qlive) {
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {     // two 16-key tiles of the block
-                const int kt0 = key0 + 16 * half;
-                if (kt0 < Nk) {                        // (wave-uniform)
-                    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-                    const float *krow = ks + (16 * half + j) * RS + 4 * kq;
-#pragma unroll
-                    for (int u = 0; u < UNITS; ++u) {
-                        const float4 kr = *reinterpret_cast<const float4 *>(krow + 16 * u);
-                        s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[u].x, kr.x, s0, 0, 0, 0);
-                        s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[u].y, kr.y, s1, 0, 0, 0);
-                        s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[u].z, kr.z, s0, 0, 0, 0);
-                        s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[u].w, kr.w, s1, 0, 0, 0);
-                    }
-                    const bool live = kt0 + j < Nk;
-                    float alpha[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float sv = live ? (s0[r] + s1[r]) * scale_log2e : -INFINITY;
-                        const float m_new = fmaxf(m_run[r], row16_max(sv));
-                        alpha[r] = __builtin_amdgcn_exp2f(m_run[r] - m_new);
-                        const float p = __builtin_amdgcn_exp2f(sv - m_new);
-                        l_run[r] = l_run[r] * alpha[r] + row16_sum(p);
-                        m_run[r] = m_new;
-                        pw[(4 * kq + r) * 36 + j] = p;
-                    }
-#pragma unroll
-                    for (int n = 0; n < DT; ++n) {
-                        o[n][0] *= alpha[0]; o[n][1] *= alpha[1]; o[n][2] *= alpha[2]; o[n][3] *= alpha[3];
-                    }
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const float a = pw[j * 36 + 4 * t + kq];
-                        const float *vrow = vs + (16 * half + 4 * t + kq) * RS + j;
-#pragma unroll
-                        for (int n = 0; n < DT; ++n) o[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vrow[16 * n], o[n], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-        }
-        // the next block: registers -> the other stage (nobody reads it: its last readers passed the barrier below one iteration
-        // ago), then the block after that into the registers
-        if (kblk + 1 < nkb) l_store(stage ^ 1);
-        if (kblk + 2 < nkb) g_load((kblk + 2) * KB);
-        __syncthreads();
-    }
-    if (qlive) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float inv = 1.0f / l_run[r];
-            float *orow = out + ((size_t)b * Nq + q0 + 4 * kq + r) * C + hoff;
-#pragma unroll
-            for (int n = 0; n < DT; ++n) {
-                const int c = 16 * n + j;
-                if (c < d) orow[c] = o[n][r] * inv;
-            }
-        }
-    }
-}
-
 }  // namespace sige
 
 using namespace sige;
 
-static int g_attention_force_form = 0;  // benchmarking: 0 automatic | 1 16 queries per workgroup | 2 64 (K / V through LDS) | 3 32
+static int g_attention_force_form = 0;  // benchmarking: 0 automatic | 1 16 queries per workgroup | 2 32 (two tiles share the K / V fragments)
 
 extern "C" int sige_hip_attention_tokens_force_form(int form) {
-    if (form < 0 || form > 3) return SIGE_HIP_EINVAL;
+    if (form < 0 || form > 2) return SIGE_HIP_EINVAL;
     g_attention_force_form = form;
     return SIGE_HIP_OK;
 }
@@ -336,18 +208,14 @@ extern "C" int sige_hip_attention_tokens_f32(const float *q, const float *k, con
     const int units = (d + 15) / 16;
     const float sl = scale * 1.44269504088896341f;
     hipStream_t st = as_stream(stream);
-    // 16 queries per workgroup, the key blocks split across its 4 waves; 32 (two tiles sharing every K / V fragment a wave loads:
-    // half the loads per MFMA) where that still leaves every CU two workgroups and the accumulators fit (d <= 96); 64 with the
-    // K / V blocks staged through LDS only on request (measured slower at SD's shapes: one wave per SIMD)
-    const long wg32 = (long)((Nq + 31) / 32) * B * heads;
-    int form = g_attention_force_form;
-    if (form == 0) form = (units <= 6 && wg32 >= 512 && Nk >= 256) ? 3 : 1;
-    if (units > 6 && form != 1) form = 1;
-    const dim3 grid16(Nq / 16, B * heads), grid32((Nq + 31) / 32, B * heads), grid64((Nq + 63) / 64, B * heads);
+    // 16 queries per workgroup, the key blocks split across its 4 waves.  On request 32 (two query tiles share every K / V
+    // fragment a wave loads: half the loads per MFMA; d <= 96) -- measured equal at SD's shapes (profiles/r4i_bench_sd.json:
+    // 11.46 vs 11.47 ms per forward), so the kernel is not load-bound there and the simpler form is the default.
+    const int form = (g_attention_force_form == 2 && units <= 6) ? 2 : 1;
+    const dim3 grid16(Nq / 16, B * heads), grid32((Nq + 31) / 32, B * heads);
 #define SIGE_ATT_GO(U)                                                                                             \
     do {                                                                                                           \
-        if (form == 2) attention_tokens_q64_kernel<U><<<grid64, 256, (size_t)(4 * 32 * (U * 16 + 4) + 4 * 16 * 36) * sizeof(float), st>>>(q, k, v, out, Nq, Nk, C, heads, d, sl); \
-        else if (form == 3) attention_tokens_kernel<(U <= 6 ? U : 1), 2><<<grid32, 256, (size_t)4 * 32 * (U * 16 + 4) * sizeof(float), st>>>(q, k, v, out, Nq, Nk, C, heads, d, sl); \
+        if (form == 2) attention_tokens_kernel<(U <= 6 ? U : 1), 2><<<grid32, 256, (size_t)4 * 32 * (U * 16 + 4) * sizeof(float), st>>>(q, k, v, out, Nq, Nk, C, heads, d, sl); \
         else attention_tokens_kernel<U, 1><<<grid16, 256, (size_t)4 * 16 * (U * 16 + 4) * sizeof(float), st>>>(q, k, v, out, Nq, Nk, C, heads, d, sl); \
     } while (0)
     switch (units) {

@@ -584,7 +584,7 @@ def test_attention_one_launch_under_a_graph(hip, monkeypatch):
 
 
 # ---- Stable Diffusion: the attention core and the token linears on the library -----------------------------
-@pytest.mark.parametrize("form", [0, 1, 2, 3])
+@pytest.mark.parametrize("form", [1, 2])
 @pytest.mark.parametrize("B,Nq,Nk,heads,d", [(2, 1008, 4096, 8, 40), (2, 160, 1024, 8, 80), (2, 48, 256, 8, 160), (2, 1008, 77, 8, 40),
                                              (1, 16, 5, 1, 64), (3, 32, 16, 2, 8), (1, 64, 100, 4, 96), (1, 80, 33, 2, 20)])
 def test_attention_tokens_vs_fp64(hip, B, Nq, Nk, heads, d, form):
@@ -597,9 +597,8 @@ def test_attention_tokens_vs_fp64(hip, B, Nq, Nk, heads, d, form):
     q, k, v = (torch.randn(B, n, C, generator=g).to(DEV) for n in (Nq, Nk, Nk))
     q = q * 2.0  # (scores with a spread: the softmax is not flat)
     scale = d ** -0.5
-    # form 1: 16 queries per workgroup, key blocks split across the waves; form 3: 32 (two query tiles share every K / V fragment;
-    # an odd tile count leaves the last workgroup half empty); form 2: 64 queries per workgroup, K / V blocks staged in LDS
-    # (query counts that are not multiples of 64, one key block, a ragged last block); 0: the library's choice
+    # form 1 (the default): 16 queries per workgroup, key blocks split across the waves; form 2: 32 (two query tiles share every
+    # K / V fragment; an odd tile count leaves the last workgroup half empty)
     assert hip.lib().sige_hip_attention_tokens_force_form(form) == 0
     try:
         got = hip.attention_tokens(q, k, v, heads, scale)
