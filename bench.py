@@ -898,22 +898,24 @@ def source_hash():
     return build.source_hash()
 
 
-def pmc_traffic(family):
+def pmc_traffic(family, dtype="f32"):
     """HBM-side bytes per launch of a kernel family from the committed rocprofv3 PMC pass -- bench.py cannot run the
     profiler on itself -- but ONLY if that pass was taken on exactly these kernel sources (hash of sige_amd/csrc +
-    include/, recorded by tools/pmc_traffic.py); otherwise (None, why)."""
-    path = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    include/, recorded by tools/pmc_traffic.py) and under THIS compute dtype (the f16 forward runs other kernels:
+    profiles/pmc_traffic_f16.json); otherwise (None, why)."""
+    name = "pmc_traffic.json" if dtype == "f32" else "pmc_traffic_%s.json" % dtype
+    path = os.path.join(REPO, "profiles", name)
     try:
         with open(path) as f:
             d = json.load(f)
     except Exception:
-        return None, "no profiles/pmc_traffic.json"
+        return None, "no profiles/%s" % name
     if d.get("source_hash") != source_hash():
-        return None, "profiles/pmc_traffic.json was measured on different kernel sources (stale): not reported"
+        return None, "profiles/%s was measured on different kernel sources (stale): not reported" % name
     fam = d.get("families", {}).get(family)
     if fam is None:
-        return None, "family %s not in profiles/pmc_traffic.json" % family
-    return int(fam["traffic_MB_per_launch"] * 1e6), d.get("provenance", "profiles/pmc_traffic.json")
+        return None, "family %s not in profiles/%s" % (family, name)
+    return int(fam["traffic_MB_per_launch"] * 1e6), d.get("provenance", "profiles/" + name)
 
 
 # ------------------------------------------------------------------------ main --
@@ -1194,7 +1196,7 @@ def main():
                 is_mfma = fam[dom]["flops"] > 0
                 achieved = tot_work / tot_us / (1e6 if is_mfma else 1e3)
                 peak = mfma_peak if is_mfma else PEAK_HBM_GBS
-                traffic, traffic_note = pmc_traffic(dom)
+                traffic, traffic_note = pmc_traffic(dom, args.dtype)
                 result["roofline"] = {
                     "kernel": dom, "bound": "mfma" if is_mfma else "hbm",
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s" if is_mfma else "GB/s",
@@ -1759,6 +1761,11 @@ def main():
             line["f16x3_compute"] = x3
         if dyn is not None:
             line["dynamic"] = dyn
+            plan_row = dyn.get("mask_change_plan") or {}
+            if plan_row.get("forward_ms_issued_from_c") is not None:
+                # the forward WITHOUT a graph, issued by the launch plan from C (what a caller that cannot capture pays), beside
+                # forward_ms_eager = the same launches issued one by one from Python through ctypes
+                line["forward_ms_eager_launch_plan"] = plan_row["forward_ms_issued_from_c"]
         if batched is not None:
             line["batched_edits"] = batched
         line.update(extras)

@@ -15,5 +15,18 @@ timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2> "$OUT/${TAG}_bench
 timeout 600 python bench.py --dtype f16 --no-extras --cpu-seconds 1 2> "$OUT/${TAG}_bench_f16.err" | tail -1 > "$OUT/${TAG}_bench_f16.json"
 timeout 600 python bench.py --gpus 2 --oversubscribe --backend gloo --steps 20 --warmup 5 --no-extras --cpu-seconds 1 2> "$OUT/${TAG}_bench_2ranks.err" | grep '^{"metric"' | tail -1 > "$OUT/${TAG}_bench_2ranks_gloo.json"
 timeout 600 python bench.py --workload sd --steps 20 --warmup 5 2> "$OUT/${TAG}_bench_sd.err" | tail -1 > "$OUT/${TAG}_bench_sd.json"
+timeout 600 python bench.py --workload sd --gpus 2 --oversubscribe --backend gloo --steps 10 --warmup 3 2> "$OUT/${TAG}_bench_sd_2ranks.err" | grep '^{"metric"' | tail -1 > "$OUT/${TAG}_bench_sd_2ranks_gloo.json"
+# kernel traces of the two other workloads (10 hipGraph replays each)
+cd /tmp
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_trace_sd" -o sd -- python $ROOT/tools/profile_sd.py --replays 10 > "$OUT/${TAG}_trace_sd.log" 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_trace_gaugan" -o gg -- python $ROOT/tools/profile_gaugan.py --replays 10 > "$OUT/${TAG}_trace_gaugan.log" 2>&1
+cd "$ROOT"
+for W in sd gaugan; do
+  T=$(ls "$OUT/${TAG}_trace_$W"/*kernel_trace.csv 2>/dev/null | head -1)
+  [ -n "$T" ] && python tools/trace_summary.py "$T" --replays 10 --out "$OUT/${TAG}_kerneltrace_${W}_sparse.csv" > "$OUT/${TAG}_trace_summary_$W.txt" 2>&1
+  S=$(ls "$OUT/${TAG}_trace_$W"/*kernel_stats.csv 2>/dev/null | head -1)
+  [ -n "$S" ] && cp "$S" "$OUT/${TAG}_rocprofv3_kernel_stats_$W.csv"
+  rm -rf "$OUT/${TAG}_trace_$W"
+done
 wc -c "$OUT"/${TAG}_bench*.json
 for e in "$OUT"/${TAG}_bench*.err; do tail -n 2 "$e"; done

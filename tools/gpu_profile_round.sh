@@ -17,6 +17,9 @@ for DT in f32 f16; do
 done
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/${TAG}_pmc_fetch" -o pmc -- $PF --mode eager --replays 4 --manifest "$OUT/${TAG}_manifest.json" > "$OUT/${TAG}_pmc_fetch.log" 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/${TAG}_pmc_write" -o pmc -- $PF --mode eager --replays 4 > "$OUT/${TAG}_pmc_write.log" 2>&1
+# the f16 forward runs other kernels (ConvGeoH tile convs, the dense-layer kernel): its own traffic pass
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/${TAG}_pmc_fetch_f16" -o pmc -- $PF --mode eager --replays 4 --dtype f16 --manifest "$OUT/${TAG}_manifest_f16.json" > "$OUT/${TAG}_pmc_fetch_f16.log" 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/${TAG}_pmc_write_f16" -o pmc -- $PF --mode eager --replays 4 --dtype f16 > "$OUT/${TAG}_pmc_write_f16.log" 2>&1
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d "$OUT/${TAG}_pmc_sq" -o pmc -- $PF --mode eager --replays 4 > "$OUT/${TAG}_pmc_sq.log" 2>&1
 cd "$ROOT"
 # reduce on the box (gpurun copies at most 64 MiB back): per-replay kernel summaries, per-kernel counter means, the traffic
@@ -32,6 +35,11 @@ done
 F=$(ls "$OUT/${TAG}_pmc_fetch"/*counter_collection.csv | head -1); W=$(ls "$OUT/${TAG}_pmc_write"/*counter_collection.csv | head -1)
 Q=$(ls "$OUT/${TAG}_pmc_sq"/*counter_collection.csv | head -1)
 python tools/pmc_traffic.py "$F" "$W" "$OUT/${TAG}_manifest.json" "$OUT/${TAG}_pmc_traffic.json" > "$OUT/${TAG}_pmc_traffic.txt" 2>&1
+F16=$(ls "$OUT/${TAG}_pmc_fetch_f16"/*counter_collection.csv | head -1); W16=$(ls "$OUT/${TAG}_pmc_write_f16"/*counter_collection.csv | head -1)
+python tools/pmc_traffic.py "$F16" "$W16" "$OUT/${TAG}_manifest_f16.json" "$OUT/${TAG}_pmc_traffic_f16.json" > "$OUT/${TAG}_pmc_traffic_f16.txt" 2>&1
+python tools/pmc_summary.py "$F16" "$OUT/${TAG}_pmc_fetch_size_per_kernel_f16.csv" sige::
+python tools/pmc_summary.py "$W16" "$OUT/${TAG}_pmc_write_size_per_kernel_f16.csv" sige::
+rm -rf "$OUT/${TAG}_pmc_fetch_f16" "$OUT/${TAG}_pmc_write_f16"
 python tools/pmc_summary.py "$F" "$OUT/${TAG}_pmc_fetch_size_per_kernel.csv" sige::
 python tools/pmc_summary.py "$W" "$OUT/${TAG}_pmc_write_size_per_kernel.csv" sige::
 python tools/pmc_summary.py "$Q" "$OUT/${TAG}_pmc_sq_counters_per_kernel.csv" sige::
