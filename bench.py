@@ -209,15 +209,32 @@ def time_graph_of(fn, reps, iters=5):
     return a.elapsed_time(b) * 1e3 / (reps * iters)  # us per launch
 
 
-def data_movement_rooflines(hip, dev):
+def pmc_data_movement():
+    """Counter bytes per launch of the data-movement rows (profiles/pmc_data_movement.json: rocprofv3 FETCH_SIZE / WRITE_SIZE passes
+    over tools/profile_data_movement.py --pmc-manifest, reduced by tools/pmc_data_movement.py), if measured on THESE kernel sources."""
+    try:
+        with open(os.path.join(REPO, "profiles", "pmc_data_movement.json")) as f:
+            d = json.load(f)
+    except Exception:
+        return {}
+    if d.get("source_hash") != source_hash():
+        return {}
+    return {(r["op"], r["layout"], r["edit_ratio"]): r for r in d.get("rows", [])}
+
+
+def data_movement_rooflines(hip, dev, pmc_manifest=None):
     """HBM roofline of the data-movement kernels that replace sige/cuda/gather_kernel.cu:7-67, scatter_gather_kernel.cu:8-67 and
     scatter_kernel.cu:8-44, standalone (the forward fuses most of them away), NCHW and channels-last, at a bandwidth-bound size
     (15 % edit, C = 256, B = 2, 256 x 256) and at the headline's launch-bound size (1.2 %, C = 128, B = 1).  Algorithmic bytes =
     SURVEY.md 8(d), reference out-of-place semantics; the in-place scatter is listed under its own name with the
-    cache-preserving minimum.  HIP events on the launch stream, rotating buffer sets larger than the 256 MiB Infinity Cache."""
+    cache-preserving minimum.  HIP events on the launch stream, rotating buffer sets larger than the 256 MiB Infinity Cache.
+    Next to the algorithmic bytes every row carries the COUNTER bytes of its launch (fabric-side reads, gfx950-corrected, + writes)
+    when a PMC pass on these kernel sources is committed.  `pmc_manifest` (a list): the profiling mode of that pass -- no timing,
+    three eager launches per row, their positions in the library's launch sequence appended to the list."""
     from sige_amd.utils import reduce_mask
 
     rows = []
+    counters = {} if pmc_manifest is not None else pmc_data_movement()
     for ratio, B, C in ((0.15, 2, 256), (0.012, 1, 128)):
         mask = square_mask(ratio).to(dev)
         idx6 = reduce_mask(mask, 6, 4, 1)
@@ -252,6 +269,16 @@ def data_movement_rooflines(hip, dev):
                 ops["scatter (in-place persistent output, + full residual)"] = (
                     3 * tile_bytes, lambda i: hip.scatter_cl(t4[i], ys[i], (1, 1), (1, 1), idx6, table, rs[i], out=ys[(i + 1) % nsets]))
             for name, (nbytes, f) in ops.items():
+                if pmc_manifest is not None:
+                    f(0)
+                    torch.cuda.synchronize()
+                    n0 = hip.launch_count()
+                    for i in range(3):
+                        f((i + 1) % nsets)
+                    torch.cuda.synchronize()
+                    pmc_manifest.append({"op": name, "layout": layout, "edit_ratio": ratio, "alg_MB": round(nbytes / 1e6, 2),
+                                         "first_launch": n0, "launches": hip.launch_count() - n0, "calls": 3})
+                    continue
                 it = [0]
 
                 def rot():
@@ -260,11 +287,19 @@ def data_movement_rooflines(hip, dev):
 
                 us = time_graph_of(rot, reps=nsets * 2)
                 gbs = nbytes / us / 1e3
-                rows.append({"op": name, "layout": layout, "edit_ratio": ratio, "B": B, "C": C, "active_tiles": int(n6),
-                             "alg_MB": round(nbytes / 1e6, 2), "us": round(us, 2), "GBps": round(gbs, 1),
-                             "frac_of_hbm_peak": round(gbs / PEAK_HBM_GBS, 4),
-                             "regime": "bandwidth-bound" if nbytes / 6.3e6 > 10.0 else "launch-bound (< 10 us of traffic at the measured copy ceiling)"})
+                row = {"op": name, "layout": layout, "edit_ratio": ratio, "B": B, "C": C, "active_tiles": int(n6),
+                       "alg_MB": round(nbytes / 1e6, 2), "us": round(us, 2), "GBps": round(gbs, 1),
+                       "frac_of_hbm_peak": round(gbs / PEAK_HBM_GBS, 4),
+                       "regime": "bandwidth-bound" if nbytes / 6.3e6 > 10.0 else "launch-bound (< 10 us of traffic at the measured copy ceiling)"}
+                cnt = counters.get((name, layout, ratio))
+                if cnt is not None:  # what the launch moved according to the memory counters, and the rate that gives
+                    row["counter_MB"] = cnt["counter_MB"]
+                    row["counter_GBps"] = round(cnt["counter_MB"] * 1e3 / us, 1)
+                    row["counter_frac_of_hbm_peak"] = round(cnt["counter_MB"] * 1e3 / us / PEAK_HBM_GBS, 4)
+                rows.append(row)
             del ys, rs, t4
+    if pmc_manifest is not None:
+        return {}
     pick = lambda op, lay, r: next(x for x in rows if x["op"].startswith(op) and x["layout"] == lay and x["edit_ratio"] == r)  # noqa: E731
     g = pick("gather (6x6, affine", "nhwc", 0.15)
     sg = pick("scatter_gather", "nhwc", 0.15)
@@ -273,7 +308,9 @@ def data_movement_rooflines(hip, dev):
     def roof(x):
         return {"kernel": x["op"], "layout": x["layout"], "shape": "[%d,%d,256,256], %d active tiles (%.0f %% edit)"
                 % (x["B"], x["C"], x["active_tiles"], x["edit_ratio"] * 100), "bound": "hbm", "alg_MB": x["alg_MB"], "us": x["us"],
-                "achieved": x["GBps"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": x["frac_of_hbm_peak"]}
+                "achieved": x["GBps"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": x["frac_of_hbm_peak"],
+                "traffic": int(x["counter_MB"] * 1e6) if "counter_MB" in x else None,
+                "frac_on_counter_bytes": x.get("counter_frac_of_hbm_peak")}
 
     return {"data_movement": rows, "roofline_gather": roof(g), "roofline_scatter_gather": roof(sg), "roofline_hbm": roof(so)}
 
@@ -927,6 +964,7 @@ def main():
     ap.add_argument("--ratio", type=float, default=0.012, help="edit ratio of the headline workload")
     ap.add_argument("--sweep", default="0.012,0.05,0.15", help="edit ratios for the sweep section ('' = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline timing (0 = skip the CPU leg)")
+    ap.add_argument("--dump-calls", default="", help="write the per-call-shape table of the headline forward (us, GFLOP) to this JSON file")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layout", default="nhwc", choices=["nhwc", "nchw"],
                     help="memory format of the activations: nhwc = torch.channels_last (default), nchw = the reference's")
@@ -988,10 +1026,13 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+
+        limit = datetime.timedelta(seconds=300)  # (a collective that hangs fails the run in minutes, not after the default 10-30)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=limit)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=limit)
 
     if args.workload == "sd":
         return main_sd(args, world, rank, dev)
@@ -1165,6 +1206,12 @@ def main():
         if rank == 0:
             # ---- per-kernel accounting of the hot path (warm, in-situ tensors) ----
             fam, per_cfg, kernels, conv_tflops, hot_us = kernel_families(trace)
+            if args.dump_calls:  # the per-call-shape table behind `kernels` (which layers are furthest from the matrix rate)
+                rows = [{"call": repr(key)[:400], "family": c["family"], "count": c["count"], "us": round(c["us"], 2),
+                         "GFLOP": round(c["flops"] / 1e9, 4), "TFLOPs": round(c["flops"] / max(1e-9, c["us"]) / 1e6, 2),
+                         "MB": round(c["bytes"] / 1e6, 3)} for key, c in per_cfg.items()]
+                with open(args.dump_calls, "w") as f:
+                    json.dump(sorted(rows, key=lambda r: -r["us"] * r["count"]), f, indent=1)
             result.update(kernels=kernels, hot_path_us=round(hot_us, 1), block_conv_tflops=round(conv_tflops, 2),
                           launches_per_forward=launches_per_forward, conv_pairs_per_forward=pairs_per_forward,
                           launches_note="conv calls = launches + pairs; K-split convs finish inside their launch (no second pass)")

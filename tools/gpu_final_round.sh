@@ -11,6 +11,16 @@ cd "$ROOT"
 T=$(ls "$OUT/${TAG}_dm"/*kernel_trace.csv 2>/dev/null | head -1)
 [ -n "$T" ] && python tools/trace_summary.py "$T" --replays 1 --by-grid --gap-ms 100 --top 0 --out "$OUT/${TAG}_kerneltrace_data_movement.csv" > /dev/null 2>&1
 rm -rf "$OUT/${TAG}_dm"
+# counter bytes of the data-movement rows (two passes, one counter each); bench.py prints them when profiles/pmc_data_movement.json
+# carries the hash of these sources -- so this comes BEFORE the bench lines
+mkdir -p "$OUT/${TAG}_dmpmc"
+cd /tmp
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/${TAG}_dmpmc/fetch" -o pmc -- python $ROOT/tools/profile_data_movement.py --pmc-manifest "$OUT/${TAG}_dm_manifest.json" > "$OUT/${TAG}_dm_fetch.log" 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/${TAG}_dmpmc/write" -o pmc -- python $ROOT/tools/profile_data_movement.py --pmc-manifest "$OUT/${TAG}_dm_manifest.json" > "$OUT/${TAG}_dm_write.log" 2>&1
+cd "$ROOT"
+python tools/pmc_data_movement.py "$(ls $OUT/${TAG}_dmpmc/fetch/*counter_collection.csv | head -1)" "$(ls $OUT/${TAG}_dmpmc/write/*counter_collection.csv | head -1)" "$OUT/${TAG}_dm_manifest.json" "$OUT/${TAG}_pmc_data_movement.json" > "$OUT/${TAG}_pmc_data_movement.txt" 2>&1
+[ -s "$OUT/${TAG}_pmc_data_movement.json" ] && cp "$OUT/${TAG}_pmc_data_movement.json" profiles/pmc_data_movement.json
+find "$OUT/${TAG}_dmpmc" -type f -delete; find "$OUT/${TAG}_dmpmc" -type d -empty -delete
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2> "$OUT/${TAG}_bench.err" | tail -1 > "$OUT/${TAG}_bench.json"
 timeout 600 python bench.py --dtype f16 --no-extras --cpu-seconds 1 2> "$OUT/${TAG}_bench_f16.err" | tail -1 > "$OUT/${TAG}_bench_f16.json"
 timeout 600 python bench.py --gpus 2 --oversubscribe --backend gloo --steps 20 --warmup 5 --no-extras --cpu-seconds 1 2> "$OUT/${TAG}_bench_2ranks.err" | grep '^{"metric"' | tail -1 > "$OUT/${TAG}_bench_2ranks_gloo.json"
