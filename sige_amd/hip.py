@@ -73,6 +73,7 @@ _SIGNATURES = {
     "sige_hip_block_conv_direct_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_vp]),
     "sige_hip_block_conv_force_tile": (_c_int, [_c_int, _c_int]),
     "sige_hip_block_conv_force_waves": (_c_int, [_c_int]),
+    "sige_hip_block_conv_large_grid_nb1": (_c_int, [_c_int]),
     "sige_hip_block_conv_force_ksplit": (_c_int, [_c_int]),
     "sige_hip_gather_force_rows": (_c_int, [_c_int]),
     "sige_hip_scatter_gather_force_elements": (_c_int, [_c_int]),
@@ -880,6 +881,12 @@ def group_norm_affine_from_stats(parts, groups: int, eps: float, gamma=None, bet
 def conv_force_tile(mt: int = 0, nb: int = 0):
     """Benchmark knob: pin the MFMA conv's output block (0, 0 = automatic)."""
     _check(lib().sige_hip_block_conv_force_tile(mt, nb), "conv_force_tile")
+
+
+def conv_large_grid_nb1(min_blocks: int = 0):
+    """Plan policy: tile-conv launches with at least `min_blocks` 32 x 64 output blocks use 32 x 32 blocks (more workgroups per
+    CU); 0 = never (include/sige_hip.h: sige_hip_block_conv_large_grid_nb1)."""
+    _check(lib().sige_hip_block_conv_large_grid_nb1(int(min_blocks)), "conv_large_grid_nb1")
 
 
 def conv_force_waves(waves: int = 0):
