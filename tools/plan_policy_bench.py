@@ -23,6 +23,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="")
     ap.add_argument("--edits", type=int, default=8)
+    ap.add_argument("--thresholds", type=lambda v: [int(x) for x in v.split(",")], default=[1024, 512, 256])
+    ap.add_argument("--ratios", type=lambda v: [float(x) for x in v.split(",")], default=[0.05, 0.15])
+    ap.add_argument("--waves8", action="store_true")
     args = ap.parse_args()
     import bench
     from sige_amd import hip, stacked
@@ -40,8 +43,7 @@ def main():
     def build_pyr(mk):
         return downsample_mask(dilate_mask(mk, 5), 8)
 
-    policies = [("default", 0, 0), ("nb1 >= 1024 blocks", 1024, 0), ("nb1 >= 512 blocks", 512, 0), ("nb1 >= 256 blocks", 256, 0),
-                ("waves 8", 0, 8), ("nb1 >= 512 blocks + waves 8", 512, 8)]
+    policies = [("default", 0, 0)] + [("nb1 >= %d blocks" % n, n, 0) for n in args.thresholds] + ([("waves 8", 0, 8)] if args.waves8 else [])
     res = {"cases": {}}
 
     def set_policy(nb1, waves):
@@ -65,7 +67,7 @@ def main():
         model.set_mode("full")
         model(x0, t)
         # ---- one image, larger edits ----
-        for ratio in (0.05, 0.15):
+        for ratio in args.ratios:
             m = bench.edit_mask(ratio).to(dev)
             x1 = x0 + noise * m
             model.set_masks(build_pyr(m))
