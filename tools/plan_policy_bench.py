@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--thresholds", type=lambda v: [int(x) for x in v.split(",")], default=[1024, 512, 256])
     ap.add_argument("--ratios", type=lambda v: [float(x) for x in v.split(",")], default=[0.05, 0.15])
     ap.add_argument("--waves8", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "f16x3"])
     args = ap.parse_args()
     import bench
     from sige_amd import hip, stacked
@@ -44,7 +45,7 @@ def main():
         return downsample_mask(dilate_mask(mk, 5), 8)
 
     policies = [("default", 0, 0)] + [("nb1 >= %d blocks" % n, n, 0) for n in args.thresholds] + ([("waves 8", 0, 8)] if args.waves8 else [])
-    res = {"cases": {}}
+    res = {"dtype": args.dtype, "cases": {}}
 
     def set_policy(nb1, waves):
         hip.conv_large_grid_nb1(nb1)
@@ -64,10 +65,13 @@ def main():
         return e0.elapsed_time(e1) / k, out
 
     with torch.no_grad():
+        model.set_compute_dtype(args.dtype)
         model.set_mode("full")
         model(x0, t)
         # ---- one image, larger edits ----
         for ratio in args.ratios:
+            if args.dtype == "f16":
+                model.set_compute_dtype("f16", edit_ratio=ratio)
             m = bench.edit_mask(ratio).to(dev)
             x1 = x0 + noise * m
             model.set_masks(build_pyr(m))
