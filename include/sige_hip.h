@@ -278,8 +278,9 @@ int sige_hip_block_conv_force_tile(int mt, int nb);
 /* Tuning knob: waves per workgroup of the channels-last stride-1 kernels: 4, 8 (two waves per SIMD),
  * or 0 = per launch (8 when the grid has fewer than 160 workgroups). */
 int sige_hip_block_conv_force_waves(int waves);
-/* plan policy (per process): launches with at least `min_blocks` 32-pixel x 64-channel output blocks use 32 x 32 blocks instead
- * (two or three workgroups per CU instead of one: large edits, stacked edits); 0 = never (default). */
+/* plan policy (per process): unsplit launches that 32-pixel x 64-channel output blocks would fill the chip with use 32 x 32 blocks
+ * (two or three workgroups per CU instead of one) from `min_blocks` such blocks on; -1 = the library's choice (default: exact
+ * fp32 always, other operand forms never), 0 = never.  Results do not depend on it (the same summation order). */
 int sige_hip_block_conv_large_grid_nb1(int min_blocks);
 /* Horizontal fusion of the two independent convs at the head of a residual block.  After pair_begin() the next
  * channels-last fp32 1x1 gather -> conv launch with raw staging (the block's shortcut) is HELD: the call returns

@@ -286,10 +286,14 @@ static int ksplit_for(long blocks, int nchunks, int cap) {
 // CU leaves matrix cores idle while a larger block only saves operand traffic).
 // sige_hip_block_conv_force_tile(mt, nb) overrides the choice (benchmarking).
 static int g_force_mt = 0, g_force_nb = 0, g_force_waves = 0;
-// Launches with at least this many (32 pixel x 64 channel) output blocks take NB = 1 instead (0 = never): the NB = 2 kernels of
-// the exact-fp32 3x3 geometry need 290-320 registers = ONE workgroup per CU, the NB = 1 kernels 150-190 = two or three -- on a grid
-// of several blocks per CU (large edits, stacked edits) the start-up of one workgroup then runs under the K loop of another.
-static int g_large_grid_nb1 = 0;
+// Unsplit launches that 32 pixel x 64 channel output blocks (NB = 2) would fill the chip with: from this many such blocks on they
+// take 32 x 32 blocks (NB = 1) instead.  The NB = 2 kernels of the exact-fp32 3x3 geometry need 290-320 registers = ONE workgroup
+// per CU, the NB = 1 kernels 150-190 = two or three: on a grid of several blocks per CU the start-up of one workgroup runs under
+// the K loop of another.  Measured (tools/plan_policy_bench.py, profiles/r4k_plan_policy*.json; same bits either way): exact fp32
+// one image at 1.2 / 5 / 15 % edit 1.406 / 1.874 / 2.509 -> 1.406 / 1.765 / 2.306 ms, 8 stacked edits 6.26 -> 5.61 ms, for every
+// threshold from 1 to 192 blocks; fp16 operands: no gain.  -1 = the library's choice (exact fp32: always; other operand forms:
+// never), 0 = never, n > 0 = from n blocks on in every operand form (benchmarking).
+static int g_large_grid_nb1 = -1;
 __device__ int32_t g_zero_idx[2] = {0, 0};
 
 #ifdef SIGE_CONV_PROBE
@@ -457,7 +461,7 @@ static int plan_conv(ConvArgs &a, int cap, int want_waves, bool nb1, ConvPlan &p
         else { mt = 16; nb = 1; }
     }
     if (!mt) {
-        const bool many = g_large_grid_nb1 > 0 && blocks(G32::TPB, 32, 2) >= g_large_grid_nb1;
+        const bool many = g_large_grid_nb1 < 0 ? PREC == 0 : (g_large_grid_nb1 > 0 && blocks(G32::TPB, 32, 2) >= g_large_grid_nb1);
         if (usable(32) && kHasNB2 && !many && blocks(G32::TPB, 32, 2) >= kFill) { mt = 32; nb = 2; }
         else if (usable(32) && blocks(G32::TPB, 32, 1) >= kFill) { mt = 32; nb = 1; }
         else if (usable(16) && kHasNB2 && blocks(G16::TPB, 16, 2) >= kFill) { mt = 16; nb = 2; }
@@ -739,7 +743,7 @@ extern "C" int sige_hip_block_conv_force_ksplit(int ksplit) {
 }
 
 extern "C" int sige_hip_block_conv_large_grid_nb1(int min_blocks) {
-    if (min_blocks < 0) return SIGE_HIP_EINVAL;
+    if (min_blocks < -1) return SIGE_HIP_EINVAL;
     g_large_grid_nb1 = min_blocks;
     return SIGE_HIP_OK;
 }

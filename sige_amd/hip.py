@@ -883,9 +883,10 @@ def conv_force_tile(mt: int = 0, nb: int = 0):
     _check(lib().sige_hip_block_conv_force_tile(mt, nb), "conv_force_tile")
 
 
-def conv_large_grid_nb1(min_blocks: int = 0):
-    """Plan policy: tile-conv launches with at least `min_blocks` 32 x 64 output blocks use 32 x 32 blocks (more workgroups per
-    CU); 0 = never (include/sige_hip.h: sige_hip_block_conv_large_grid_nb1)."""
+def conv_large_grid_nb1(min_blocks: int = -1):
+    """Plan policy: unsplit tile-conv launches that 32 x 64 output blocks would fill the chip with use 32 x 32 blocks (more
+    workgroups per CU) from `min_blocks` such blocks on; -1 = the library's default (exact fp32: always), 0 = never
+    (include/sige_hip.h: sige_hip_block_conv_large_grid_nb1)."""
     _check(lib().sige_hip_block_conv_large_grid_nb1(int(min_blocks)), "conv_large_grid_nb1")
 
 
