@@ -282,9 +282,6 @@ int sige_hip_block_conv_force_waves(int waves);
  * (two or three workgroups per CU instead of one) from `min_blocks` such blocks on; -1 = the library's choice (default: exact
  * fp32 always, other operand forms never), 0 = never.  Results do not depend on it (the same summation order). */
 int sige_hip_block_conv_large_grid_nb1(int min_blocks);
-/* benchmarking: the number of workgroups at which a launch stops splitting K across workgroups / shrinking its output block
- * (default 224 = one per CU; 0 restores it); split_nb1 != 0: K-split launches take 32 x 32 blocks (two workgroups fit a CU). */
-int sige_hip_block_conv_fill_target(int workgroups, int split_nb1);
 /* Horizontal fusion of the two independent convs at the head of a residual block.  After pair_begin() the next
  * channels-last fp32 1x1 gather -> conv launch with raw staging (the block's shortcut) is HELD: the call returns
  * SIGE_HIP_OK without launching.  The next channels-last fp32 3x3/s1 gather -> conv launch with affine + SiLU staging on

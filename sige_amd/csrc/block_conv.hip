@@ -268,16 +268,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_nhwc_kernel(const float *__
 // cover the chip: every wave then runs K/4 MFMA steps back to back however few tiles there are
 // (the 8x8 layers of the U-Net: 64 pixels, K = 4608..9216), so the chunks are shared out.
 static int g_force_ksplit = 0;  // sige_hip_block_conv_force_ksplit (benchmarking)
-// How many workgroups a launch should have before it stops splitting K across workgroups: 224 = one per CU
-// (sige_hip_block_conv_fill_target; benchmarking: two workgroups of the 32 x 32 kernels fit a CU).  g_split_nb1: launches of
-// the too-few-tiles branch take 32 x 32 / 16 x 16 blocks, never the NB = 2 ones (one workgroup per CU).
-static int g_fill = 224;
-static int g_split_nb1 = 0;
 static int ksplit_for(long blocks, int nchunks, int cap) {
     // (the second pass costs ~4.7 us per launch; measured on the DDPM-256 dense remainder the split still
     //  wins 140 us per forward: 923 vs 1064 us over its 58 conv launches)
-    if (cap <= 1 || (blocks >= g_fill && !g_force_ksplit)) return 1;
-    int s = g_force_ksplit ? g_force_ksplit : (int)((g_fill + blocks - 1) / blocks);
+    if (cap <= 1 || (blocks >= 224 && !g_force_ksplit)) return 1;
+    int s = g_force_ksplit ? g_force_ksplit : (int)((224 + blocks - 1) / blocks);
     s = s < nchunks / 2 ? s : nchunks / 2;  // >= 2 chunks per split (the software pipeline's depth)
     s = s < 8 ? s : 8;
     s = s < cap ? s : cap;
@@ -460,9 +455,9 @@ static int plan_conv(ConvArgs &a, int cap, int want_waves, bool nb1, ConvPlan &p
         // too few tiles for any block shape: split K across workgroups, largest block that then fills the chip
         const int nc32 = ceil_div(a.Cin, G32::CC), nc16 = ceil_div(a.Cin, G16::CC);
         auto filled = [&](int tpb, int m, int n, int nc) { long b = blocks(tpb, m, n); return b * ksplit_for(b, nc, cap); };
-        if (usable(32) && kHasNB2 && !g_split_nb1 && filled(G32::TPB, 32, 2, nc32) >= kFill) { mt = 32; nb = 2; }
+        if (usable(32) && kHasNB2 && filled(G32::TPB, 32, 2, nc32) >= kFill) { mt = 32; nb = 2; }
         else if (usable(32) && filled(G32::TPB, 32, 1, nc32) >= kFill) { mt = 32; nb = 1; }
-        else if (kHasNB2 && !g_split_nb1 && filled(G16::TPB, 16, 2, nc16) >= kFill) { mt = 16; nb = 2; }
+        else if (kHasNB2 && filled(G16::TPB, 16, 2, nc16) >= kFill) { mt = 16; nb = 2; }
         else { mt = 16; nb = 1; }
     }
     if (!mt) {
@@ -747,13 +742,6 @@ extern "C" int sige_hip_block_conv_force_ksplit(int ksplit) {
     return SIGE_HIP_OK;
 }
 
-extern "C" int sige_hip_block_conv_fill_target(int workgroups, int split_nb1) {
-    if (workgroups != 0 && (workgroups < 64 || workgroups > 4096)) return SIGE_HIP_EINVAL;
-    g_fill = workgroups ? workgroups : 224;
-    g_split_nb1 = split_nb1 ? 1 : 0;
-    return SIGE_HIP_OK;
-}
-
 extern "C" int sige_hip_block_conv_large_grid_nb1(int min_blocks) {
     if (min_blocks < -1) return SIGE_HIP_EINVAL;
     g_large_grid_nb1 = min_blocks;
@@ -978,12 +966,7 @@ extern "C" int sige_hip_conv_ksplit_hint(int T, int Cin, int Cout, int kH, int k
     if (T <= 0 || Cin <= 0 || Cout <= 0) return 1;
     const int px = (kH == 3 && strideH == 2) ? 4 : 16;  // output pixels per tile
     const long blocks16 = (long)ceil_div(T, 16 / px) * ceil_div(Cout, 16);
-    if (g_fill == 224) {
-        if (blocks16 >= 224 && !g_force_ksplit) return 1;
-    } else {  // (a raised target: launches whose 32 x 32 blocks do not reach it may split)
-        const long blocks32 = (long)ceil_div(T, 32 / px) * ceil_div(Cout, 32);
-        if (blocks32 >= g_fill && !g_force_ksplit) return 1;
-    }
+    if (blocks16 >= 224 && !g_force_ksplit) return 1;
     return 8;  // (the launch decides the actual factor, at most 8)
 }
 

@@ -27,8 +27,6 @@ def main():
     ap.add_argument("--ratios", type=lambda v: [float(x) for x in v.split(",")], default=[0.05, 0.15])
     ap.add_argument("--waves8", action="store_true")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "f16x3"])
-    ap.add_argument("--fills", default="", help="K-split targets to try instead of block shapes: 'workgroups:split_nb1,...' (0:0 = default)")
-    ap.add_argument("--no-stacked", action="store_true")
     args = ap.parse_args()
     import bench
     from sige_amd import hip, stacked
@@ -47,15 +45,9 @@ def main():
         return downsample_mask(dilate_mask(mk, 5), 8)
 
     policies = [("32 x 64 blocks (the default until round 4)", 0, 0)] + [("library default" if n < 0 else "32 x 32 blocks from %d blocks on" % n, n, 0) for n in args.thresholds] + ([("waves 8", 0, 8)] if args.waves8 else [])
-    if args.fills:  # (the policy tuple's slots then mean: K-split target in workgroups, NB = 1 in the too-few-tiles branch)
-        policies = [("K split up to %d workgroups%s" % (int(f.split(":")[0]) or 224, ", 32 x 32 blocks" if int(f.split(":")[1]) else ""),
-                     int(f.split(":")[0]), int(f.split(":")[1])) for f in args.fills.split(",")]
     res = {"dtype": args.dtype, "cases": {}}
 
     def set_policy(nb1, waves):
-        if args.fills:
-            hip.conv_fill_target(max(0, nb1), bool(waves))
-            return
         hip.conv_large_grid_nb1(nb1)
         hip.conv_force_waves(waves)
 
@@ -97,13 +89,6 @@ def main():
                     ref = out.clone()
                 rows[name] = {"forward_ms": round(ms, 4), "launches": nl, "max_abs_vs_first_row": float((out - ref).abs().max())}
             res["cases"]["one image, %g %% edit" % (ratio * 100)] = rows
-        if args.no_stacked:
-            set_policy(0 if args.fills else -1, 0)
-            print(json.dumps(res, indent=1))
-            if args.out:
-                with open(args.out, "w") as f:
-                    json.dump(res, f, indent=1)
-            return
         # ---- E stacked edits at 1.2 % ----
         E = args.edits
         set_policy(-1, 0)
