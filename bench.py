@@ -749,12 +749,13 @@ def main_sd(args, world, rank, dev):
 
         routing, kernels_sd, roof_sd = {}, None, None
         if rank == 0 and world == 1:
-            keep_flags = (_sdt.NATIVE_ATTENTION, _sdt.NATIVE_LINEAR)
+            keep_flags = (_sdt.NATIVE_ATTENTION, _sdt.NATIVE_LINEAR, _sdt.BATCHED_QKV)
             ref_out = None
-            for tag, att, lin, form in (("reference_chain", False, False, 0), ("native_attention", True, False, 0),
-                                        ("native_attention_32_queries_per_workgroup", True, False, 2),
-                                        ("native_attention_and_linears", True, True, 0)):
-                _sdt.NATIVE_ATTENTION, _sdt.NATIVE_LINEAR = att, lin
+            for tag, att, lin, form, bq in (("reference_chain", False, False, 0, False), ("native_attention", True, False, 0, True),
+                                            ("native_attention_separate_qkv_projections", True, False, 0, False),
+                                            ("native_attention_32_queries_per_workgroup", True, False, 2, True),
+                                            ("native_attention_and_linears", True, True, 0, False)):
+                _sdt.NATIVE_ATTENTION, _sdt.NATIVE_LINEAR, _sdt.BATCHED_QKV = att, lin, bq
                 hip.lib().sige_hip_attention_tokens_force_form(form)
                 run(x1)
                 n0 = hip.launch_count()
@@ -765,7 +766,7 @@ def main_sd(args, world, rank, dev):
                     ref_out = o_v.float().clone()
                 routing[tag] = {"forward_ms": round(ms_v, 3), "library_launches": nl, "max_abs_vs_reference_chain": round(float((o_v.float() - ref_out).abs().max()), 8)}
                 del g_v
-            _sdt.NATIVE_ATTENTION, _sdt.NATIVE_LINEAR = keep_flags
+            _sdt.NATIVE_ATTENTION, _sdt.NATIVE_LINEAR, _sdt.BATCHED_QKV = keep_flags
             hip.lib().sige_hip_attention_tokens_force_form(0)
             # per-kernel accounting of the library's launches in one forward (the same accounting as the DDPM headline's table)
             tracer = Tracer(hip)
@@ -873,7 +874,7 @@ def main_sd(args, world, rank, dev):
                 "forward_ms": round(ms_steady, 4), "dense_forward_ms": round(dense_ms, 3), "speedup_vs_dense": round(dense_ms / ms_steady, 2),
                 "hip_kernel_launches_per_forward": launches, "cache_bytes": int(flat.numel() * 4), "cached_tensors": n_cached,
                 "active_token_ratio_64": round(float(masks[(64, 64)].float().mean()), 4),
-                "native_attention": bool(_sdt.NATIVE_ATTENTION), "native_linear": bool(_sdt.NATIVE_LINEAR)}
+                "native_attention": bool(_sdt.NATIVE_ATTENTION), "native_linear": bool(_sdt.NATIVE_LINEAR), "batched_qkv": bool(_sdt.BATCHED_QKV)}
         if routing:
             line["attention_routing"] = routing
         if roof_sd is not None:

@@ -34,8 +34,11 @@ from ..nn import Gather, Scatter, SIGEConv2d, SIGEModule
 #   NATIVE_LINEAR     the token linears (to_q / to_k / to_v / to_out, the GEGLU projection, the feed-forward's second layer) on
 #                     the library's MFMA tile kernel -- 16 tokens are one channels-last 4 x 4 tile, a Linear is a 1 x 1 conv --
 #                     instead of the generic GEMM library
+#   BATCHED_QKV       the three bias-free projections of a self-attention's input as ONE strided-batched GEMM (x broadcast
+#                     against the stacked weights [3, C, inner]: three dense outputs, one launch instead of three)
 NATIVE_ATTENTION = True
 NATIVE_LINEAR = False
+BATCHED_QKV = True
 
 
 def linear(lin: nn.Linear, x: torch.Tensor) -> torch.Tensor:
@@ -83,6 +86,19 @@ class Attention(SIGEModule):
         self.to_out = nn.Sequential(nn.Linear(inner, query_dim), nn.Dropout(0.0))
         self.cache_context = cache_context
         self.cached_k = self.cached_v = None
+
+    def qkv(self, x):
+        """(to_q(x), to_k(x), to_v(x)) for a self-attention whose queries, keys and values come from the same tokens x [B,n,C]."""
+        if not (BATCHED_QKV and not NATIVE_LINEAR and x.is_cuda and self.to_k.in_features == self.to_q.in_features):
+            return linear(self.to_q, x), linear(self.to_k, x), linear(self.to_v, x)
+        ws = (self.to_q.weight, self.to_k.weight, self.to_v.weight)
+        key = tuple((w.data_ptr(), w._version) for w in ws)
+        if getattr(self, "_qkv_key", None) != key:
+            self._qkv_w = torch.stack([w.detach().t() for w in ws]).contiguous()  # [3, C, inner]
+            self._qkv_key = key
+        b, n, c = x.shape
+        out = torch.matmul(x.reshape(1, b * n, c), self._qkv_w)  # [3, B*n, inner]: one strided-batched GEMM
+        return tuple(t.reshape(b, n, -1) for t in out.unbind(0))
 
     def attend(self, q, k, v):
         if NATIVE_ATTENTION and q.is_cuda and q.dtype == torch.float32:
@@ -149,10 +165,11 @@ class TransformerBlock(SIGEModule):
             sk, sv, (hh, ww) = kv_scatter
             b, n, c = xn.shape
             as_tiles = lambda t: t.reshape(-1, 4, 4, t.shape[2]).permute(0, 3, 1, 2)  # noqa: E731  tokens -> [B*N,C,4,4] channels-last view
-            k = sk(as_tiles(linear(a1.to_k, xn)))  # rows of the active tokens over the cached K of the original image
-            v = sv(as_tiles(linear(a1.to_v, xn)))
+            q_t, k_t, v_t = a1.qkv(xn)
+            k = sk(as_tiles(k_t))  # rows of the active tokens over the cached K of the original image
+            v = sv(as_tiles(v_t))
             as_tokens = lambda t: t.permute(0, 2, 3, 1).reshape(t.shape[0], hh * ww, t.shape[1])  # noqa: E731
-            x = a1.attend(linear(a1.to_q, xn), as_tokens(k), as_tokens(v)) + x
+            x = a1.attend(q_t, as_tokens(k), as_tokens(v)) + x
         else:
             x = a1(xn, context=None if full_x is None else self.norm1(full_x)) + x
         x = self.attn2(self.norm2(x), context=context) + x
