@@ -282,10 +282,6 @@ int sige_hip_block_conv_force_waves(int waves);
  * (two or three workgroups per CU instead of one) from `min_blocks` such blocks on; -1 = the library's choice (default: exact
  * fp32 always, other operand forms never), 0 = never.  Results do not depend on it (the same summation order). */
 int sige_hip_block_conv_large_grid_nb1(int min_blocks);
-/* ... and 64 x 32 blocks (two M tiles per workgroup sharing every weight register: half the weight stream per MFMA, still two
- * workgroups per CU) from `min_blocks` such blocks on; exact fp32, channels-last 3x3 stride-1 launches with an fp32-stored cache.
- * -1 = the library's choice, 0 = never.  Results do not depend on it. */
-int sige_hip_block_conv_two_m_tiles(int min_blocks);
 /* Horizontal fusion of the two independent convs at the head of a residual block.  After pair_begin() the next
  * channels-last fp32 1x1 gather -> conv launch with raw staging (the block's shortcut) is HELD: the call returns
  * SIGE_HIP_OK without launching.  The next channels-last fp32 3x3/s1 gather -> conv launch with affine + SiLU staging on

@@ -294,11 +294,6 @@ static int g_force_mt = 0, g_force_nb = 0, g_force_waves = 0;
 // threshold from 1 to 192 blocks; fp16 operands: no gain.  -1 = the library's choice (exact fp32: always; other operand forms:
 // never), 0 = never, n > 0 = from n blocks on in every operand form (benchmarking).
 static int g_large_grid_nb1 = -1;
-// ... and from this many 64 pixel x 32 channel blocks on (-1: the library's choice; 0: never) two M tiles per workgroup (MB = 2 in
-// conv_mfma.hpp): the weight stream per MFMA of the 32 x 64 blocks at the register cost of the 32 x 32 ones (two workgroups per
-// CU).  Exact fp32, channels-last, 3x3 stride 1, fp32-stored cache.
-static int g_mb2_min_blocks = -1;
-constexpr int kMb2Default = 0;  // (set after measurement: tools/plan_policy_bench.py --mb2)
 __device__ int32_t g_zero_idx[2] = {0, 0};
 
 #ifdef SIGE_CONV_PROBE
@@ -359,15 +354,6 @@ void launch_conv_pair(ConvArgs a, ConvArgs b, int mode_a, hipStream_t st);
     template <> void launch_conv_pair<K31_32, 2, K11_16, DST, W>(ConvArgs, ConvArgs, int, hipStream_t);       \
     template <> void launch_conv_pair<K31_32, 2, K11_32, DST, W>(ConvArgs, ConvArgs, int, hipStream_t);
 SIGE_PAIR_DECLARE(DST_TILES, 4) SIGE_PAIR_DECLARE(DST_TILES, 8) SIGE_PAIR_DECLARE(DST_NCHW, 4) SIGE_PAIR_DECLARE(DST_NCHW, 8)
-// 64 x 32 blocks (conv_k3s1_nhwc_mb2.hip, conv_pair_nhwc_mb2.hip)
-template <> void launch_conv_mb2<SRC_GATHER, DST_TILES>(ConvArgs, int, hipStream_t);
-template <> void launch_conv_mb2<SRC_GATHER, DST_NCHW>(ConvArgs, int, hipStream_t);
-template <> void launch_conv_mb2<SRC_SCATTER_GATHER, DST_TILES>(ConvArgs, int, hipStream_t);
-template <> void launch_conv_mb2<SRC_SCATTER_GATHER, DST_NCHW>(ConvArgs, int, hipStream_t);
-template <> void launch_conv_pair_mb2<K11_16, DST_TILES>(ConvArgs, ConvArgs, int, hipStream_t);
-template <> void launch_conv_pair_mb2<K11_32, DST_TILES>(ConvArgs, ConvArgs, int, hipStream_t);
-template <> void launch_conv_pair_mb2<K11_16, DST_NCHW>(ConvArgs, ConvArgs, int, hipStream_t);
-template <> void launch_conv_pair_mb2<K11_32, DST_NCHW>(ConvArgs, ConvArgs, int, hipStream_t);
 #define SIGE_PAIR_DECLARE_H(DST)                                                                         \
     template <> void launch_conv_pair<H31_16, 1, H11_16, DST, 4>(ConvArgs, ConvArgs, int, hipStream_t);       \
     template <> void launch_conv_pair<H31_16, 1, H11_32, DST, 4>(ConvArgs, ConvArgs, int, hipStream_t);       \
@@ -433,7 +419,7 @@ int release_graph_tickets() {
     return SIGE_HIP_OK;
 }
 
-struct ConvPlan { int mt, nb, waves, mb; };
+struct ConvPlan { int mt, nb, waves; };
 
 // PREC: 0 exact fp32 (ConvGeo) | 1 fp16 operands (ConvGeoH) | 2 split fp16 operands (ConvGeoX)
 template <int PREC, int KH, int STR, int R, int MT>
@@ -483,17 +469,7 @@ static int plan_conv(ConvArgs &a, int cap, int want_waves, bool nb1, ConvPlan &p
         else if (usable(32)) { mt = 32; nb = 1; }
         else return SIGE_HIP_EUNSUPPORTED;
     }
-    int tpb = mt == 32 ? G32::TPB : G16::TPB;
-    p.mb = 1;
-    if constexpr (PREC == 0 && KH == 3 && STR == 1 && LAY == LAYOUT_NHWC && SRC != SRC_TILES) {
-        const int want = g_mb2_min_blocks < 0 ? kMb2Default : g_mb2_min_blocks;
-        const bool batch_ok = !(a.aff_sb != 0 && a.B > 1 && a.N % (2 * tpb));  // (a per-batch affine: one batch per M block)
-        if (want > 0 && mt == 32 && nb == 1 && !want_waves && !a.y_f16 && batch_ok && g_force_waves != 8 &&
-            blocks(2 * G32::TPB, 32, 1) >= want && blocks(G32::TPB, 32, 1) >= kFill) {
-            p.mb = 2;
-            tpb *= 2;
-        }
-    }
+    const int tpb = mt == 32 ? G32::TPB : G16::TPB;
     a.mbk = ceil_div(a.T, tpb);
     a.ngk = ceil_div(a.Cout, mt * nb);
     const int cc4 = mt == 32 ? G32::CC : G16::CC;
@@ -540,14 +516,6 @@ static bool launch_pair(const ConvArgs &a, const ConvPlan &pa, int mode_a, ConvA
     using B32 = GeoOf<PREC, 1, 1, 4, 32>;
     ConvPlan pb;
     if (plan_conv<1, 1, 4, SRC_GATHER, LAYOUT_NHWC, PREC>(b, 1, pa.waves, true, pb) != SIGE_HIP_OK) return false;
-    if constexpr (PREC == 0) {
-        if (pa.mb == 2) {  // 64 x 32 blocks (conv_mfma.hpp: MB = 2)
-            if (pb.mt == 32) launch_conv_pair_mb2<B32, DST>(a, b, mode_a, st);
-            else launch_conv_pair_mb2<B16, DST>(a, b, mode_a, st);
-            ++g_pairs_fused;
-            return true;
-        }
-    }
 #define SIGE_PAIR_GO(GA, NBA, W)                                                                         \
     do {                                                                                                 \
         if (pb.mt == 32) launch_conv_pair<GA, NBA, B32, DST, W>(a, b, mode_a, st);                       \
@@ -662,9 +630,6 @@ static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
             }
         }
     }
-    if constexpr (PREC == 0 && KH == 3 && STR == 1 && LAY == LAYOUT_NHWC && SRC != SRC_TILES) {
-        if (!done && p.mb == 2) { launch_conv_mb2<SRC, DST>(a, mode, st); done = true; }
-    }
     if constexpr (SRC == SRC_SCATTER_GATHER && LAY == LAYOUT_NHWC && KH == 3 && STR == 1) {
         if (!done && a.y_f16) {  // the cached tensor is stored as fp16: the Y16 form of the kernel (4 waves)
             if (waves != 4) return SIGE_HIP_EUNSUPPORTED;
@@ -774,12 +739,6 @@ extern "C" int sige_hip_block_conv_force_ksplit_pass(int second_pass) {
 extern "C" int sige_hip_block_conv_force_ksplit(int ksplit) {
     if (ksplit < 0 || ksplit > 8) return SIGE_HIP_EINVAL;
     g_force_ksplit = ksplit;
-    return SIGE_HIP_OK;
-}
-
-extern "C" int sige_hip_block_conv_two_m_tiles(int min_blocks) {
-    if (min_blocks < -1) return SIGE_HIP_EINVAL;
-    g_mb2_min_blocks = min_blocks;
     return SIGE_HIP_OK;
 }
 

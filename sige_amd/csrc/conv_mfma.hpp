@@ -337,28 +337,19 @@ __device__ __forceinline__ float4 coherent_load(const float *p) {
 
 // LDS floats of one workgroup (the kernels below declare the array; the body only receives the pointer, so that two
 // bodies sharing a launch -- conv_pair_kernel -- share one allocation)
-template <typename G, int NB, int MODE, int LAYOUT, int W, int MB = 1>
+template <typename G, int NB, int MODE, int LAYOUT, int W>
 __host__ __device__ constexpr int conv_lds_floats() {
     constexpr int CCk = W * G::CW;
     constexpr bool NHWC = LAYOUT == LAYOUT_NHWC;
     constexpr int LDC = G::F16 ? (G::X3 ? 2 * CCk + 8 : CCk + 8) : CCk + 4;
-    constexpr int TPBk = G::TPB * MB;
-    constexpr int STAGE = NHWC ? (G::F16 ? TPBk * G::RS * LDC / 2 : TPBk * G::RS * LDC) : TPBk * CCk * G::RS;
+    constexpr int STAGE = NHWC ? (G::F16 ? G::TPB * G::RS * LDC / 2 : G::TPB * G::RS * LDC) : G::TPB * CCk * G::RS;
     constexpr int TABF = MODE != MODE_RAW ? 2 * (CCk + 4) : 0;
-    return cmax(2 * STAGE + 2 * TABF, W * NB * MB * G::MT * (G::MT + 4));
+    return cmax(2 * STAGE + 2 * TABF, W * NB * G::MT * (G::MT + 4));
 }
 
 // The whole launch of one workgroup (bx, by) = what blockIdx would be in a launch of its own.
-// MB (round 4): M tiles per workgroup -- the output block is MB * MT pixels x NB * MT channels.  MB = 2 is to the pixels what
-// NB = 2 is to the channels, with the roles of the operands swapped: the two M tiles share every weight register (B) and read
-// their own A values from the (twice as large) LDS stage, so the weight stream per MFMA halves WITHOUT a second weight ring
-// in registers -- the 32 x 64 kernels (NB = 2) need ~300 registers (one workgroup per CU), 64 x 32 (MB = 2, NB = 1) ~200.
-// Channels-last exact-fp32 kernels only.
-template <typename G, int NB, int SRC, int MODE, int DST, int LAYOUT, int W, bool Y16 = false, int MB = 1>
+template <typename G, int NB, int SRC, int MODE, int DST, int LAYOUT, int W, bool Y16 = false>
 __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, const int by, float *const smem) {
-    static_assert(MB == 1 || (MB == 2 && LAYOUT == LAYOUT_NHWC && !G::F16 && NB == 1 && W == 4), "two M tiles: channels-last, exact fp32, NB = 1, 4 waves");
-    constexpr int TPBk = G::TPB * MB;            // tiles of this workgroup's M block
-    constexpr int MP = G::MT * MB;               // its output pixels
     static_assert(!Y16 || (SRC == SRC_SCATTER_GATHER && LAYOUT == LAYOUT_NHWC), "fp16-stored cache: the channels-last scatter_gather source");
     constexpr unsigned YB = Y16 ? 2u : 4u;       // bytes per element of the cached tensor `y`
     constexpr bool F16 = G::F16;                 // fp16 operands in LDS / registers (ConvGeoH)
@@ -381,12 +372,12 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
     //   (f16 compute: the stage holds HALVES, row = CC + 8 halves; STAGE stays in floats)
     constexpr bool X3 = G::X3;                   // split fp16 operands (ConvGeoX): two planes in LDS, (hi, lo) weight registers
     constexpr int LDC = F16 ? (X3 ? 2 * CCk + 8 : CCk + 8) : CCk + 4;
-    constexpr int STAGE = NHWC ? (F16 ? TPBk * G::RS * LDC / 2 : TPBk * G::RS * LDC) : BUFk;
+    constexpr int STAGE = NHWC ? (F16 ? G::TPB * G::RS * LDC / 2 : G::TPB * G::RS * LDC) : BUFk;
     constexpr int TROW = CCk + 4;                            // table row: CC channels + 4 zeros
     constexpr int TABF = AFF ? 2 * TROW : 0;                   // scale row | shift row
     constexpr int RP = G::MT + 4;                              // padded row of the reduction buffer
-    constexpr int LDS_FLOATS = cmax(2 * STAGE + 2 * TABF, W * NB * MP * RP);
-    static_assert(LDS_FLOATS == conv_lds_floats<G, NB, MODE, LAYOUT, W, MB>(), "conv_lds_floats() out of step with the body");
+    constexpr int LDS_FLOATS = cmax(2 * STAGE + 2 * TABF, W * NB * G::MT * RP);
+    static_assert(LDS_FLOATS == conv_lds_floats<G, NB, MODE, LAYOUT, W>(), "conv_lds_floats() out of step with the body");
     float *const tab = smem + 2 * STAGE;
 
     SIGE_PROBE(0);  // entry
@@ -450,7 +441,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
     //   TILES           s_off  into the tile slab
     //   GATHER          s_off  into x, s_off2 into x2 (NHWC only: the two have different pitches)
     //   SCATTER_GATHER  s_off  into the conv-1 tiles, s_off2 into the cached tensor y (one of them kOOB)
-    constexpr int UNITS = VEC ? (NHWC ? TPBk * G::RS * CCk / 4 : BUFk / 4) : BUFk;
+    constexpr int UNITS = VEC ? (NHWC ? G::TPB * G::RS * CCk / 4 : BUFk / 4) : BUFk;
     constexpr int NS = (UNITS + NT - 1) / NT;
     constexpr bool TWO = SRC == SRC_SCATTER_GATHER || (NHWC && SRC == SRC_GATHER);
     float st_z[2][VEC ? 1 : NS], st_z2[2][(!VEC && TWO) ? NS : 1];
@@ -462,7 +453,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
 
     // (scale, shift) of channel chunk `chunk` for table entry (tid mod CC); entries past Cin are 0
     const int trow = tid % CCk;
-    const int tab_b0 = AFF ? ((mb * TPBk) / a.N) * a.aff_sb : 0;  // (a per-batch affine needs one batch per M block: host side)
+    const int tab_b0 = AFF ? ((mb * G::TPB) / a.N) * a.aff_sb : 0;  // (a per-batch affine needs one batch per M block: host side)
     auto tab_fetch = [&](int chunk, float &sc, float &sh) {
         const int c = chunk * CCk + trow;
         const int cc = c < Cin ? c : 0;
@@ -476,18 +467,16 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
     // Channels-last, full-tensor destination: where each of this lane's (at most EU) units goes, its bias and its
     // residual are fetched HERE, with the prologue's loads -- left to the epilogue, tile origin -> address -> residual
     // -> store are two more dependent memory round trips at the end of every launch.
-    constexpr int UNITS_NB = MP * G::MT / 4;            // float4 units per N sub-block
+    constexpr int UNITS_NB = G::MT * G::MT / 4;         // float4 units per N sub-block
     constexpr int OUT_UNITS = NB * UNITS_NB;
     constexpr int EU = (OUT_UNITS + NT - 1) / NT;
     // (4-wave workgroups only: with 8 waves the register budget per lane is 256 and the loop needs it)
-    // (two M tiles: not there either -- these kernels run two workgroups per CU, which hides the epilogue's round trips, and the
-    //  ~40 registers are what that occupancy needs)
-    constexpr bool EPRE = NHWC && DST != DST_TILES && (W == 4 || NB == 1) && MB == 1;
+    constexpr bool EPRE = NHWC && DST != DST_TILES && (W == 4 || NB == 1);
     int e_h[EPRE ? EU : 1], e_w[EPRE ? EU : 1];          // tile origin, then the unit's output pixel
     size_t e_q[EPRE ? EU : 1];                            // element offset of the unit in the output tensor
     bool e_in[EPRE ? EU : 1];                             // the unit exists and its pixel is inside the output
     float4 e_res[EPRE ? EU : 1];
-    constexpr bool EPV = NHWC && (W == 4 || NB == 1) && MB == 1;                 // per-channel epilogue vectors (bias, out_affine) fetched up front
+    constexpr bool EPV = NHWC && (W == 4 || NB == 1);                 // per-channel epilogue vectors (bias, out_affine) fetched up front
     float4 e_bias[EPV ? EU : 1], e_os[EPV ? EU : 1], e_oh[EPV ? EU : 1];
     // (K split with a second launch: partial sums only, bias / residual in the second pass; with in-kernel finish any
     //  workgroup may turn out to be the one that runs the epilogue)
@@ -514,7 +503,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
             s_dst[i] = (t_l * G::RS + p) * LDC + c_l;
             s_cl[i] = c_l;
             z_c[i] = c_l; z_p[i] = p;
-            z_t[i] = mb * TPBk + t_l;
+            z_t[i] = mb * G::TPB + t_l;
             z_live[i] = v < UNITS && z_t[i] < a.T;
         });
         if (SRC != SRC_TILES) {
@@ -532,7 +521,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
                 const int o = tid + k * NT;
                 const int nb = o / UNITS_NB, o1 = o - nb * UNITS_NB;
                 const int m = o1 / (G::MT / 4);
-                const int tt = min(mb * TPBk + m / G::PX, a.T - 1);
+                const int tt = min(mb * G::TPB + m / G::PX, a.T - 1);
                 const int n = tt - (tt / a.N) * a.N;
                 const int2 og = *reinterpret_cast<const int2 *>(a.idx + 2 * n);
                 e_h[k] = og.x; e_w[k] = og.y;
@@ -612,7 +601,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
                 const int nb = o / UNITS_NB, o1 = o - nb * UNITS_NB;
                 const int n4 = o1 % (G::MT / 4), m = o1 / (G::MT / 4);
                 const int pxo = m % G::PX;
-                const int t = mb * TPBk + m / G::PX, co = (ng * NB + nb) * G::MT + 4 * n4;
+                const int t = mb * G::TPB + m / G::PX, co = (ng * NB + nb) * G::MT + 4 * n4;
                 const int b = min(t, a.T - 1) / a.N;
                 const int h = (a.offH + e_h[k]) / a.strH + pxo / G::RO, w = (a.offW + e_w[k]) / a.strW + pxo % G::RO;
                 const bool in = o < OUT_UNITS && t < a.T && co < a.Cout && h >= 0 && h < a.Ho && w >= 0 && w < a.Wo;
@@ -785,15 +774,13 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
         if (AFF) tab_put(tb, t_sc, t_sh);
     };
 
-    typename M::acc_t acc[MB][NB][NACC];
+    typename M::acc_t acc[NB][NACC];
 #pragma unroll
-    for (int m2 = 0; m2 < MB; ++m2)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
+        for (int q = 0; q < NACC; ++q)
 #pragma unroll
-            for (int q = 0; q < NACC; ++q)
-#pragma unroll
-                for (int i = 0; i < M::REGS; ++i) acc[m2][nb][q][i] = 0.0f;
+            for (int i = 0; i < M::REGS; ++i) acc[nb][q][i] = 0.0f;
 
     // A: this lane's output pixel = row j of the M block; k-step u = (channel group q, tap)
     const int tl = j / G::PX, px = j % G::PX;
@@ -861,13 +848,13 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
                         // hi*hi and hi*lo on one accumulator, lo*hi on the other: consecutive MFMAs alternate accumulators
                         const float4 bq = bset[PAR][nb][2 * u], bl = bset[PAR][nb][2 * u + 1];
                         const f32x4 bhr = {bq.x, bq.y, bq.z, bq.w}, blr = {bl.x, bl.y, bl.z, bl.w};
-                        acc[0][nb][u % NACC] = M::op(avh[u], __builtin_bit_cast(f16x8, bhr), acc[0][nb][u % NACC]);
-                        acc[0][nb][(u + 1) % NACC] = M::op(avl[u], __builtin_bit_cast(f16x8, bhr), acc[0][nb][(u + 1) % NACC]);
-                        acc[0][nb][u % NACC] = M::op(avh[u], __builtin_bit_cast(f16x8, blr), acc[0][nb][u % NACC]);
+                        acc[nb][u % NACC] = M::op(avh[u], __builtin_bit_cast(f16x8, bhr), acc[nb][u % NACC]);
+                        acc[nb][(u + 1) % NACC] = M::op(avl[u], __builtin_bit_cast(f16x8, bhr), acc[nb][(u + 1) % NACC]);
+                        acc[nb][u % NACC] = M::op(avh[u], __builtin_bit_cast(f16x8, blr), acc[nb][u % NACC]);
                     } else {
                         const float4 bq = bset[PAR][nb][u];
                         const f32x4 braw = {bq.x, bq.y, bq.z, bq.w};
-                        acc[0][nb][u % NACC] = M::op(avh[u], __builtin_bit_cast(f16x8, braw), acc[0][nb][u % NACC]);
+                        acc[nb][u % NACC] = M::op(avh[u], __builtin_bit_cast(f16x8, braw), acc[nb][u % NACC]);
                     }
                 });
                 static_for<(u * NS) / G::L, ((u + 1) * NS) / G::L>([&](auto i_tag) {
@@ -890,21 +877,11 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
             return;
         } else {
         // all A values of the chunk up front: LDS reads overlap with the matrix pipe for free
-        // (one M tile: all of the chunk's A values; two: a window of two 4-step groups, the next group's reads issued under this
-        //  group's MFMAs -- 72 live registers less, which is what lets two of these workgroups share a CU)
-        constexpr int AW = MB == 1 ? G::L : 8;
-        float av[MB][AW];
-        auto a_get = [&](auto u_tag) {
-            constexpr int u = decltype(u_tag)::value;
+        float av[G::L];
 #pragma unroll
-            for (int m2 = 0; m2 < MB; ++m2)
-                av[m2][u % AW] = SIGE_ABL_HAS(16) ? __builtin_bit_cast(float, 0x3f800000 + u + lane) : as[m2 * (G::TPB * G::RS * LDC) + a_off(u)];
-        };
-        static_for<0, (MB == 1 ? G::L : 4)>([&](auto u_tag) { a_get(u_tag); });
+        for (int u = 0; u < G::L; ++u) av[u] = SIGE_ABL_HAS(16) ? __builtin_bit_cast(float, 0x3f800000 + u + lane) : as[a_off(u)];
         static_for<0, G::L / 4>([&](auto g_tag) {
             constexpr int g = decltype(g_tag)::value;
-            if constexpr (MB != 1 && 4 * (g + 1) < G::L)
-                static_for<4 * (g + 1), 4 * (g + 2)>([&](auto u_tag) { a_get(u_tag); });
             static_for<0, 4>([&](auto e_tag) {
                 constexpr int e = decltype(e_tag)::value;
                 constexpr int u = 4 * g + e;
@@ -912,8 +889,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
                     constexpr int nb = decltype(nb_tag)::value;
                     const float4 bq = bset[PAR][nb][g];
                     const float bv = (e == 0) ? bq.x : (e == 1) ? bq.y : (e == 2) ? bq.z : bq.w;
-#pragma unroll
-                    for (int m2 = 0; m2 < MB; ++m2) acc[m2][nb][u % NACC] = M::op(av[m2][u % AW], bv, acc[m2][nb][u % NACC]);
+                    acc[nb][u % NACC] = M::op(av[u], bv, acc[nb][u % NACC]);
                 });
                 // staging slots spread evenly over the k-steps
                 static_for<(u * NS) / G::L, ((u + 1) * NS) / G::L>([&](auto i_tag) {
@@ -942,17 +918,15 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
     // MT=32: reg r of lane (kq, j): pixel row m = (r&3) + 8*(r>>2) + 4*kq ; MT=16: m = 4*kq + r ; column (cout) = j
     float *red = smem;  // safe: the loop ended with a barrier
 #pragma unroll
-    for (int m2 = 0; m2 < MB; ++m2)
-#pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        typename M::acc_t s = acc[m2][nb][0];
+        typename M::acc_t s = acc[nb][0];
         if (NACC == 2) {
 #pragma unroll
-            for (int i = 0; i < M::REGS; ++i) s[i] += acc[m2][nb][NACC - 1][i];
+            for (int i = 0; i < M::REGS; ++i) s[i] += acc[nb][NACC - 1][i];
         }
         if (NHWC) {
             // red[wave][nb][pixel m][cout n]
-            float *r = red + ((wave * NB + nb) * MP + m2 * G::MT) * RP + j;
+            float *r = red + ((wave * NB + nb) * G::MT) * RP + j;
 #pragma unroll
             for (int q = 0; q < M::REGS; ++q) {
                 const int m = G::MT == 32 ? (q & 3) + 8 * (q >> 2) + 4 * kq : 4 * kq + q;
@@ -991,7 +965,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
             const int nb = o / UNITS_NB, o1 = o - nb * UNITS_NB;
             const int n4 = o1 % (G::MT / 4), m = o1 / (G::MT / 4);
             const int t_l = m / G::PX, pxo = m % G::PX;
-            const int t = mb * TPBk + t_l;
+            const int t = mb * G::TPB + t_l;
             u.co = (ng * NB + nb) * G::MT + 4 * n4;
             if (!(t < a.T && u.co < a.Cout)) return u;  // (Cout % 4 == 0: host side)
             u.b = t / a.N;
@@ -1063,11 +1037,11 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
             const int o = tid + k * NT;
             const int nb = o / UNITS_NB, o1 = o - nb * UNITS_NB;
             const int n4 = o1 % (G::MT / 4), m = o1 / (G::MT / 4);
-            const float *r0 = red + (nb * MP + m) * RP + 4 * n4;
+            const float *r0 = red + (nb * G::MT + m) * RP + 4 * n4;
             float4 s = *reinterpret_cast<const float4 *>(r0);
 #pragma unroll
             for (int w = 1; w < W; ++w) {
-                const float4 v = *reinterpret_cast<const float4 *>(r0 + w * NB * MP * RP);
+                const float4 v = *reinterpret_cast<const float4 *>(r0 + w * NB * G::MT * RP);
                 s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             }
             if constexpr (X3) { s.x *= wsc; s.y *= wsc; s.z *= wsc; s.w *= wsc; }  // (a power of two: exact; K-split partials are stored scaled back)
@@ -1173,10 +1147,10 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
 // ---- launch ------------------------------------------------------------------
 inline int conv_grid_x(const ConvArgs &a) { return a.ng_fast == 2 ? 8 * ((a.mbk + 7) / 8) * a.ngk : a.mbk * a.ngk; }
 
-template <typename G, int NB, int SRC, int MODE, int DST, int LAYOUT = LAYOUT_NCHW, int W = 4, bool Y16 = false, int MB = 1>
-__global__ __launch_bounds__(64 * W, MB == 2 ? 2 : 1) void conv_mfma_kernel(const ConvArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[conv_lds_floats<G, NB, MODE, LAYOUT, W, MB>()];
-    conv_mfma_body<G, NB, SRC, MODE, DST, LAYOUT, W, Y16, MB>(a, blockIdx.x, blockIdx.y, smem);
+template <typename G, int NB, int SRC, int MODE, int DST, int LAYOUT = LAYOUT_NCHW, int W = 4, bool Y16 = false>
+__global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[conv_lds_floats<G, NB, MODE, LAYOUT, W>()];
+    conv_mfma_body<G, NB, SRC, MODE, DST, LAYOUT, W, Y16>(a, blockIdx.x, blockIdx.y, smem);
 }
 
 // Two independent convs of a residual block in ONE launch (horizontal fusion): workgroups [0, na) run conv A
@@ -1185,13 +1159,13 @@ __global__ __launch_bounds__(64 * W, MB == 2 ? 2 : 1) void conv_mfma_kernel(cons
 // gridDim.y; B never is (its workgroups with blockIdx.y > 0 leave at once).
 // MODEA: staging of conv A -- MODE_AFFINE_SWISH (the consumer activates its input), or MODE_RAW (its producers wrote an
 // activated twin: ConvArgs::twin0/1)
-template <typename GA, int NBA, typename GB, int DST, int W, int MODEA, int MBA = 1>
+template <typename GA, int NBA, typename GB, int DST, int W, int MODEA>
 __global__ __launch_bounds__(64 * W) void conv_pair_kernel(const ConvArgs a, const ConvArgs b, const int na) {
-    constexpr int LA = conv_lds_floats<GA, NBA, MODEA, LAYOUT_NHWC, W, MBA>();
+    constexpr int LA = conv_lds_floats<GA, NBA, MODEA, LAYOUT_NHWC, W>();
     constexpr int LB = conv_lds_floats<GB, 1, MODE_RAW, LAYOUT_NHWC, W>();
     __shared__ __attribute__((aligned(16))) float smem[cmax(LA, LB)];
     if ((int)blockIdx.x < na)
-        conv_mfma_body<GA, NBA, SRC_GATHER, MODEA, DST, LAYOUT_NHWC, W, false, MBA>(a, blockIdx.x, blockIdx.y, smem);
+        conv_mfma_body<GA, NBA, SRC_GATHER, MODEA, DST, LAYOUT_NHWC, W>(a, blockIdx.x, blockIdx.y, smem);
     else if (blockIdx.y == 0)
         conv_mfma_body<GB, 1, SRC_GATHER, MODE_RAW, DST, LAYOUT_NHWC, W>(b, blockIdx.x - na, 0, smem);
 }
@@ -1228,29 +1202,6 @@ void launch_conv_geo(ConvArgs a, int mode, hipStream_t st);
     SIGE_CONV_LAUNCH3(G, NB, SRC_GATHER, DST_TILES, LAY, W)                                               \
     SIGE_CONV_LAUNCH3(G, NB, SRC_GATHER, DST_NCHW, LAY, W)                                                \
     SIGE_CONV_LAUNCH3(G, NB, SRC_SCATTER_GATHER, DST_TILES, LAY, W)
-
-// 64 pixel x 32 channel blocks (MB = 2; G = ConvGeo<3, 1, 6, 32>, channels-last, 4 waves): gather / scatter_gather sources, tiles or
-// full-tensor destination, and the pair kernel with a 1x1 shortcut
-template <int SRC, int DST>
-void launch_conv_mb2(ConvArgs a, int mode, hipStream_t st);
-#define SIGE_CONV_INSTANTIATE_MB2(SRC, DST)                                                               \
-    template <> void launch_conv_mb2<SRC, DST>(ConvArgs a, int mode, hipStream_t st) {                    \
-        using G = ConvGeo<3, 1, 6, 32>;                                                                   \
-        const dim3 grid(conv_grid_x(a), a.ksplit);                                                        \
-        if (mode == MODE_AFFINE_SWISH) conv_mfma_kernel<G, 1, SRC, MODE_AFFINE_SWISH, DST, LAYOUT_NHWC, 4, false, 2><<<grid, 256, 0, st>>>(a); \
-        else if (mode == MODE_AFFINE) conv_mfma_kernel<G, 1, SRC, MODE_AFFINE, DST, LAYOUT_NHWC, 4, false, 2><<<grid, 256, 0, st>>>(a);        \
-        else conv_mfma_kernel<G, 1, SRC, MODE_RAW, DST, LAYOUT_NHWC, 4, false, 2><<<grid, 256, 0, st>>>(a); \
-    }
-template <typename GB, int DST>
-void launch_conv_pair_mb2(ConvArgs a, ConvArgs b, int mode_a, hipStream_t st);
-#define SIGE_CONV_PAIR_INSTANTIATE_MB2(GB, DST)                                                           \
-    template <> void launch_conv_pair_mb2<GB, DST>(ConvArgs a, ConvArgs b, int mode_a, hipStream_t st) {  \
-        using GA = ConvGeo<3, 1, 6, 32>;                                                                  \
-        const int na = conv_grid_x(a);                                                                    \
-        const dim3 grid(na + conv_grid_x(b), a.ksplit);                                                   \
-        if (mode_a == MODE_RAW) conv_pair_kernel<GA, 1, GB, DST, 4, MODE_RAW, 2><<<grid, 256, 0, st>>>(a, b, na); \
-        else conv_pair_kernel<GA, 1, GB, DST, 4, MODE_AFFINE_SWISH, 2><<<grid, 256, 0, st>>>(a, b, na);    \
-    }
 
 // scatter_gather source whose cached tensor `y` is stored as fp16 (channels-last, 4 waves): tiles or full-tensor destination
 template <typename G, int NB, int DST>

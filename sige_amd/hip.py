@@ -74,7 +74,6 @@ _SIGNATURES = {
     "sige_hip_block_conv_force_tile": (_c_int, [_c_int, _c_int]),
     "sige_hip_block_conv_force_waves": (_c_int, [_c_int]),
     "sige_hip_block_conv_large_grid_nb1": (_c_int, [_c_int]),
-    "sige_hip_block_conv_two_m_tiles": (_c_int, [_c_int]),
     "sige_hip_block_conv_force_ksplit": (_c_int, [_c_int]),
     "sige_hip_gather_force_rows": (_c_int, [_c_int]),
     "sige_hip_scatter_gather_force_elements": (_c_int, [_c_int]),
@@ -889,12 +888,6 @@ def conv_large_grid_nb1(min_blocks: int = -1):
     workgroups per CU) from `min_blocks` such blocks on; -1 = the library's default (exact fp32: always), 0 = never
     (include/sige_hip.h: sige_hip_block_conv_large_grid_nb1)."""
     _check(lib().sige_hip_block_conv_large_grid_nb1(int(min_blocks)), "conv_large_grid_nb1")
-
-
-def conv_two_m_tiles(min_blocks: int = -1):
-    """Plan policy: 64 x 32 output blocks (two M tiles per workgroup) for tile-conv launches with at least `min_blocks` of them;
-    -1 = the library's default, 0 = never (include/sige_hip.h: sige_hip_block_conv_two_m_tiles)."""
-    _check(lib().sige_hip_block_conv_two_m_tiles(int(min_blocks)), "conv_two_m_tiles")
 
 
 def conv_force_waves(waves: int = 0):

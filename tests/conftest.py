@@ -23,18 +23,3 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(pytest.mark.skip(reason="no GPU in this container"))
         if "reference" in item.keywords and not has_ref:
             item.add_marker(pytest.mark.skip(reason="/root/reference not mounted"))
-
-
-@pytest.fixture(scope="session", autouse=True)
-def _plan_policy_from_env():
-    """SIGE_TEST_TWO_M_TILES=n: run the GPU suite with the tile conv's 64 x 32 blocks from n blocks on (1 = wherever they exist) --
-    every parity test then also covers that form of the kernel (sige_hip_block_conv_two_m_tiles)."""
-    n = os.environ.get("SIGE_TEST_TWO_M_TILES")
-    if n is not None:
-        import torch
-
-        if torch.cuda.is_available():
-            from sige_amd import hip
-
-            hip.conv_two_m_tiles(int(n))
-    yield

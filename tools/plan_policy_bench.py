@@ -27,8 +27,6 @@ def main():
     ap.add_argument("--ratios", type=lambda v: [float(x) for x in v.split(",")], default=[0.05, 0.15])
     ap.add_argument("--waves8", action="store_true")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "f16x3"])
-    ap.add_argument("--mb2", type=lambda v: [int(x) for x in v.split(",")], default=[],
-                    help="instead of the block-shape thresholds: 64 x 32 blocks (two M tiles per workgroup) from these many blocks on")
     args = ap.parse_args()
     import bench
     from sige_amd import hip, stacked
@@ -47,14 +45,9 @@ def main():
         return downsample_mask(dilate_mask(mk, 5), 8)
 
     policies = [("32 x 64 blocks (the default until round 4)", 0, 0)] + [("library default" if n < 0 else "32 x 32 blocks from %d blocks on" % n, n, 0) for n in args.thresholds] + ([("waves 8", 0, 8)] if args.waves8 else [])
-    if args.mb2:  # (the policy tuple's first slot then is the two-M-tiles threshold; block shapes at the library default)
-        policies = [("32 x 32 blocks (two M tiles never)", 0, 0)] + [("64 x 32 blocks from %d blocks on" % n, n, 0) for n in args.mb2]
     res = {"dtype": args.dtype, "cases": {}}
 
     def set_policy(nb1, waves):
-        if args.mb2:
-            hip.conv_two_m_tiles(max(0, nb1))
-            return
         hip.conv_large_grid_nb1(nb1)
         hip.conv_force_waves(waves)
 
