@@ -1,0 +1,60 @@
+"""The committed evidence is reproducible from what is committed: the traffic tables bench.py reads can be re-derived from the raw
+counter rows kept next to them, and the bench lines under profiles/ carry the fields of the contract.  (CPU only.)"""
+import gzip
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(REPO, "profiles")
+
+
+@pytest.mark.parametrize("suffix", ["", "_f16"])
+def test_traffic_table_rederives_from_the_raw_counter_rows(tmp_path, suffix):
+    """tools/pmc_traffic.py over the kept FETCH_SIZE / WRITE_SIZE rows of the conv kernels (profiles/r4_pmc_*_rows*.csv.gz) and
+    the manifest gives the per-family figures of profiles/pmc_traffic*.json (what `roofline.traffic` prints)."""
+    table = os.path.join(PROF, "pmc_traffic%s.json" % suffix)
+    rows = {c: os.path.join(PROF, "r4_pmc_%s_rows%s.csv.gz" % (c, suffix)) for c in ("fetch", "write")}
+    manifest = os.path.join(PROF, "r4_manifest%s.json" % suffix)
+    for f in [table, manifest, *rows.values()]:
+        if not os.path.exists(f):
+            pytest.skip("%s not committed" % os.path.basename(f))
+    want = json.load(open(table))
+    if want["source_hash"] != json.load(open(manifest))["source_hash"]:
+        pytest.skip("the traffic table was re-measured after these rows were kept")
+    plain = {}
+    for c, path in rows.items():
+        plain[c] = str(tmp_path / (c + ".csv"))
+        with gzip.open(path, "rt") as src, open(plain[c], "w") as dst:
+            dst.write(src.read())
+    out = str(tmp_path / "traffic.json")
+    subprocess.run([sys.executable, os.path.join(REPO, "tools", "pmc_traffic.py"), plain["fetch"], plain["write"], manifest, out],
+                   check=True, capture_output=True)
+    got = json.load(open(out))
+    for fam in ("block_conv_mfma", "dense_conv_mfma"):
+        assert got["families"][fam] == want["families"][fam]
+    assert got["source_hash"] == want["source_hash"]
+
+
+@pytest.mark.parametrize("name", ["r4_bench.json", "r4_bench_f16.json", "r4_bench_2ranks_gloo.json", "r4_bench_sd.json"])
+def test_bench_lines_carry_the_contract(name):
+    path = os.path.join(PROF, name)
+    if not os.path.exists(path):
+        pytest.skip("%s not committed" % name)
+    d = json.loads(open(path).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config"):
+        assert k in d, k
+    assert d["higher_is_better"] is True and d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+    if name in ("r4_bench.json", "r4_bench_f16.json"):
+        r = d["roofline"]
+        assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["frac"] < 1.0
+        assert r["traffic"] is None or r["traffic"] > 0
+    if name == "r4_bench.json":
+        c = d["cpu_baseline"]
+        assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+        assert d["parity_ok"] is True
