@@ -58,9 +58,8 @@ def _plain_conv(conv: nn.Conv2d, x: torch.Tensor, sparse: bool, residual: Option
         from .. import hip
         from ..nn.dense import fusable, fused_conv2d
 
-        if fusable(conv) and x.shape[1] % 4 == 0 and (residual is None or hip.is_cl(residual)):
-            # (torch's GroupNorm hands back NCHW whatever came in: a small copy in front of the channels-last kernel)
-            return fused_conv2d(conv, x if hip.is_cl(x) else x.contiguous(memory_format=torch.channels_last), residual=residual)
+        if hip.is_cl(x) and fusable(conv) and x.shape[1] % 4 == 0 and (residual is None or hip.is_cl(residual)):
+            return fused_conv2d(conv, x, residual=residual)
     out = conv(x)
     return out if residual is None else residual + out
 
