@@ -47,23 +47,6 @@ def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
     return torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1) if dim % 2 else emb
 
 
-# The convs the reference leaves to the dense library in every mode -- the middle block's (1280 -> 1280 at 8 x 8: 59 MB of weights
-# for 0.4 GFLOP, 60 us each on MIOpen's implicit GEMM), the first (4 -> 320) and the last (320 -> 4) -- on the library's kernels
-# in a SPARSE forward (channels-last fp32 GPU tensors; the full pass keeps the stock path).  Same values to fp32 summation order.
-NATIVE_PLAIN_CONVS = True
-
-
-def _plain_conv(conv: nn.Conv2d, x: torch.Tensor, sparse: bool, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-    if NATIVE_PLAIN_CONVS and sparse and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4:
-        from .. import hip
-        from ..nn.dense import fusable, fused_conv2d
-
-        if hip.is_cl(x) and fusable(conv) and x.shape[1] % 4 == 0 and (residual is None or hip.is_cl(residual)):
-            return fused_conv2d(conv, x, residual=residual)
-    out = conv(x)
-    return out if residual is None else residual + out
-
-
 class GroupNorm32(nn.GroupNorm):
     def forward(self, x):
         return super().forward(x.float()).type(x.dtype)
@@ -94,11 +77,9 @@ class ResBlock(SIGEModule):
 
     def forward(self, x, emb):
         if not self.tiled:
-            sparse = self.mode == "sparse"
-            h = _plain_conv(self.in_layers[2], self.in_layers[1](self.in_layers[0](x)), sparse)
+            h = self.in_layers(x)
             h = h + self.emb_layers(emb)[:, :, None, None]
-            return _plain_conv(self.out_layers[3], self.out_layers[2](self.out_layers[1](self.out_layers[0](h))), sparse,
-                               residual=self.skip_connection(x))
+            return self.skip_connection(x) + self.out_layers(h)
         if self.mode == "full":
             skip = x if self.cin == self.cout else self.skip_connection(self.shortcut_gather(x))
             h, s1, t1 = group_norm_affine(self.main_gather(x), self.in_layers[0])
@@ -201,8 +182,8 @@ class SDUNet(SIGEModel):
         emb = self.time_embed(timestep_embedding(timesteps, self.cfg.model_channels))
         hs = []
         h = x
-        for i, blk in enumerate(self.input_blocks):
-            h = _plain_conv(blk[0], h, self.mode == "sparse") if i == 0 else self._run(blk, h, emb, context)
+        for blk in self.input_blocks:
+            h = self._run(blk, h, emb, context)
             hs.append(h)
         h = self._run(self.middle_block, h, emb, context)
         for blk in self.output_blocks:
@@ -213,4 +194,4 @@ class SDUNet(SIGEModel):
             else:
                 h = torch.cat([h, skip], dim=1)
             h = self._run(blk, h, emb, context)
-        return _plain_conv(self.out[2], self.out[1](self.out[0](h)), self.mode == "sparse")
+        return self.out(h)
