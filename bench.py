@@ -1627,15 +1627,16 @@ def main():
                     model(xi, t)
                     singles.append(model(xi, t).clone())
                 rows = []
-                wide_keep = dict(_dense.WIDE_MIN_FLOP_F32)
+                wide_keep = dict(_dense.WIDE_MIN_FLOP_F32_STACKED)
                 for E in Es:
                     routes = ("tile",) if E == 1 else (("tile", "wide", "wide2", "f16x3") if E == emax and args.dtype == "f32" else ("tile", "wide"))
                     for route in routes:
                         # `wide` / `wide2`: dense 3x3 layers of at least 8 / 2 GFLOP on the dense-layer kernel in its exact-fp32 form
                         # (stacking makes the dense remainder E times as many pixels: matrix-bound there, 0.7-0.8 of the fp32 MFMA peak:
                         # DESIGN 3.7); `f16x3`: split fp16 operands (fp32-level results) wherever a launch is matrix-bound
-                        _dense.WIDE_MIN_FLOP_F32 = ({3: 8.0e9, 1: 1.0e30} if route == "wide" else {3: 2.0e9, 1: 1.0e30} if route == "wide2"
-                                                    else dict(wide_keep))
+                        # (the library's stacked-mode default is the `wide` route; `tile` switches it off for the comparison)
+                        _dense.WIDE_MIN_FLOP_F32_STACKED = ({3: 2.0e9, 1: 1.0e30} if route == "wide2" else {3: 1.0e30, 1: 1.0e30} if route == "tile"
+                                                            else {3: 8.0e9, 1: 1.0e30})
                         model.set_compute_dtype("f16x3" if route == "f16x3" else args.dtype)
                         xe = torch.cat([x0 + noise * mk for mk in mks[:E]], 0).contiguous(memory_format=torch.channels_last)
                         if E > 1:
@@ -1671,7 +1672,7 @@ def main():
                                      "dense_conv_wide": kern_b.get("dense_conv_wide")})
                         if E == emax:
                             rows[-1]["kernels"] = kern_b
-                _dense.WIDE_MIN_FLOP_F32 = wide_keep
+                _dense.WIDE_MIN_FLOP_F32_STACKED = wide_keep
                 model.set_compute_dtype(args.dtype)
                 base = next(r for r in rows if r["edits"] == 1)["forwards_per_s"]
                 best = {}

@@ -55,6 +55,10 @@ WIDE_MIN_FLOP_FULL_PASS = {3: 0.25e9, 1: 2.0e9}
 # ms), so the sparse pass does not use it; on the big layers of the full pass it reaches 109-127 TFLOP/s (0.70-0.81 of the fp32
 # matrix peak; 283 -> 177 us), which FULL_PASS_F32_NATIVE turns on for an exact-fp32 full pass on the library's kernels.
 WIDE_MIN_FLOP_F32 = {3: 1.0e30, 1: 1.0e30}
+# ... with E stacked edits (sige_amd.stacked) a dense layer has E times the pixels: from 8 GFLOP per launch on the exact-fp32
+# dense-layer kernel wins (profiles/r4_bench.json: batched_edits -- E = 8: 5.27 vs 5.58 ms per 8 edits, the routed layers at 128
+# TFLOP/s = 0.81 of the fp32 MFMA peak; E = 16: 9.66 vs 10.31 ms; E = 4: a tie).  One image never reaches it (<= 3.6 GFLOP).
+WIDE_MIN_FLOP_F32_STACKED = {3: 8.0e9, 1: 1.0e30}
 FULL_PASS_F32_NATIVE = False
 # Tile convs (conv_mfma.hpp) asked for split fp16 operands run them only above this many flop per launch; below, exact fp32.
 # Measured (profiles/r3c_bench.json, DDPM-256 sparse forward, every tile conv on split operands against exact fp32): 1.2 %
@@ -85,7 +89,10 @@ def _wide_conv(conv: nn.Conv2d, x, x2, scale, shift, activation_name, residual, 
 
     compute = getattr(conv, "compute_dtype", "f32")
     if compute == "f32" and min_flop is None:
-        min_flop = WIDE_MIN_FLOP_F32  # (exact fp32 on v_mfma_f32_32x32x2_f32: the sparse pass's dense remainder)
+        # (exact fp32 on v_mfma_f32_32x32x2_f32: the sparse pass's dense remainder)
+        min_flop = WIDE_MIN_FLOP_F32
+        if hip.get_edit_batch() > 1 and min_flop[3] >= 1.0e30:
+            min_flop = WIDE_MIN_FLOP_F32_STACKED
     if compute not in ("f16", "f16x3", "f32") or not hip.is_cl(x) or (x2 is not None and not hip.is_cl(x2)):
         return None
     k = tuple(conv.kernel_size)
