@@ -888,7 +888,9 @@ def main_sd(args, world, rank, dev):
                                      efficiency=round(dt_steady / dt, 4))
         if parity is not None:
             line.update(parity)
-        print(json.dumps(line), flush=True)
+        from benchlib.line import emit
+
+        emit(line, name="bench_detail_sd.json")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -1820,7 +1822,9 @@ def main():
         line.update(extras)
         if cpu is not None:
             line["cpu_baseline"] = cpu
-        print(json.dumps(line), flush=True)
+        from benchlib.line import emit
+
+        emit(line)  # the detail file + an earlier stdout line carry everything; the LAST line is the <= 4 KB contract line
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
