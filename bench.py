@@ -36,21 +36,10 @@ sys.path.insert(0, REPO)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-# hipGraph captures: "thread_local" -- another thread of the process (RCCL's watchdog at N > 1) calling into HIP while this
-# thread records must not invalidate the capture; the recording thread itself makes no capture-unsafe call either way.
-CAPTURE_MODE = "thread_local"
-
-PEAK_HBM_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md)
-PEAK_F32_MFMA_TFS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
-PEAK_F16_MFMA_TFS = 2500.0  # v_mfma_f32_32x32x16_f16 dense peak (not the 2:1-sparsity figure)
-
-
-def square_mask(ratio, H=256, W=256, top=100, left=90):
-    side = int(round((ratio ** 0.5) * H))
-    m = torch.zeros(H, W, dtype=torch.bool)
-    m[top:top + side, left:left + side] = True
-    return m
-
+from benchlib.common import (CAPTURE_MODE, PEAK_F16_MFMA_TFS, PEAK_F32_MFMA_TFS, PEAK_HBM_GBS, _hip, _replay_ms, capture,  # noqa: E402,F401
+                             capture_fn, eager_ms, square_mask, time_graph_of, timed_replays)
+from benchlib.gaugan import gaugan_section  # noqa: E402
+from benchlib.sd_transformer import sd_transformer_section  # noqa: E402
 
 # ------------------------------------------------------------------ op trace --
 TRACED = ("gather", "scatter_gather", "scatter_fused", "scatter_with_block_residual_fused", "block_conv",
@@ -184,29 +173,6 @@ def shape_key(name, a):
         elif isinstance(v, (int, str, bool, tuple)) or v is None:
             parts.append(v)
     return tuple(parts)
-
-
-def time_graph_of(fn, reps, iters=5):
-    """Average device time of one `fn()` launch: a hipGraph of `reps` back-to-back
-    launches, replayed `iters` times between HIP events on the capture stream."""
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        fn()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=s, capture_error_mode=CAPTURE_MODE):
-            for _ in range(reps):
-                fn()
-        g.replay()
-        s.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(s)
-        for _ in range(iters):
-            g.replay()
-        b.record(s)
-        s.synchronize()
-    torch.cuda.current_stream().wait_stream(s)
-    return a.elapsed_time(b) * 1e3 / (reps * iters)  # us per launch
 
 
 def pmc_data_movement():
@@ -364,51 +330,6 @@ def flop_by_compute(trace):
     return {c: round(v / tot, 4) for c, v in sorted(by.items())}
 
 
-def capture(model, x, t):
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        for _ in range(2):
-            model(x, t)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=s, capture_error_mode=CAPTURE_MODE):
-            out = model(x, t)
-    torch.cuda.current_stream().wait_stream(s)
-    torch.cuda.synchronize()
-    return g, out
-
-
-def timed_replays(g, steps, warmup, world):
-    for _ in range(warmup):
-        g.replay()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        g.replay()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        v = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(v, op=dist.ReduceOp.MAX)
-        dt = float(v.item())
-    return dt
-
-
-def eager_ms(model, x, t, steps):
-    for _ in range(3):
-        model(x, t)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        model(x, t)
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) * 1e3 / steps
-
-
 # ------------------------------------------------------ inputs shared by both legs --
 def make_inputs():
     """The original image and the edit noise, on the CPU (both legs start from exactly these)."""
@@ -497,191 +418,6 @@ def cpu_reference(ratios, headline_ratio, seconds):
 
 
 # ------------------------------------------------- BASELINE configs[2] / [3] sections --
-def _replay_ms(fn, k=30, warm=5):
-    """ms per call of `fn()` replayed as a hipGraph."""
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        for _ in range(2):
-            out = fn()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=s, capture_error_mode=CAPTURE_MODE):
-            out = fn()
-    torch.cuda.current_stream().wait_stream(s)
-    torch.cuda.synchronize()
-    ms = timed_replays(g, k, warm, 1) * 1e3 / k
-    return ms, out, g
-
-
-def gaugan_section(dev, cpu_parity=True):
-    """BASELINE.json configs[2]: GauGAN SPADE generator (ngf 64, 93 M parameters, random init), 256 x 512 label map
-    (crop 512, aspect 2 -- gaugan/test.py:53-54), ~5 % relabelled rectangle; fp32, channels-last."""
-    import numpy as np
-
-    from sige_amd import runtime
-    from sige_amd.utils import compute_difference_mask, dilate_mask, downsample_mask
-    from sige_amd.workloads.gaugan_spade import SPADEConfig, SpadeGenerator
-
-    def labels(dy=0, dx=0):
-        rs = np.random.RandomState(3)
-        coarse = rs.randint(0, 36, size=(32, 64))
-        lab0 = np.kron(coarse, np.ones((8, 8), dtype=np.int64))
-        lab1 = lab0.copy()
-        lab1[85 + dy:136 + dy, 128 + dx:256 + dx] = (lab0[85 + dy:136 + dy, 128 + dx:256 + dx] + 5) % 36
-        oh = lambda l: torch.nn.functional.one_hot(torch.from_numpy(l), 36).permute(2, 0, 1)[None].float().contiguous()  # noqa: E731
-        return oh(lab0), oh(lab1)
-
-    def build():
-        torch.manual_seed(0)
-        m = SpadeGenerator(SPADEConfig()).eval()
-        g = torch.Generator().manual_seed(7)
-        for n_, b_ in m.named_buffers():  # running statistics away from (0, 1): the cached affine matters
-            if n_.endswith("running_mean"):
-                b_.copy_(torch.randn(b_.shape, generator=g) * 0.3)
-            elif n_.endswith("running_var"):
-                b_.copy_(torch.rand(b_.shape, generator=g) + 0.5)
-        return m
-
-    x0c, x1c = labels()
-    cl = lambda t_: t_.to(dev).contiguous(memory_format=torch.channels_last)  # noqa: E731
-    model = build().to(dev).to(memory_format=torch.channels_last)
-    model.set_scatter_inplace(True)
-    x0, x1 = cl(x0c), cl(x1c)
-    res = {}
-    with torch.no_grad():
-        model.set_mode("full")
-        dense_ms, _, gd = _replay_ms(lambda: model(x1))
-        del gd
-        model(x0)
-        diff = compute_difference_mask(x0, x1)
-        model.set_masks(downsample_mask(dilate_mask(diff, 1), (model.sh, model.sw), dilation=2))
-        model.set_mode("sparse")
-        outs = {}
-        for name, fused in (("fused_spade_modulation", True), ("module_chain", False)):
-            model.cfg.fused = fused
-            n0 = _hip().launch_count()
-            model(x1)
-            launches = _hip().launch_count() - n0
-            ms, out, g = _replay_ms(lambda: model(x1))
-            outs[name] = out.float().cpu()
-            res[name] = {"forward_ms": round(ms, 3), "speedup_vs_dense": round(dense_ms / ms, 2), "hip_kernel_launches": launches}
-            del g
-        model.cfg.fused = True
-        # the generator's REAL per-edit latency: the reference runs ONE sparse forward per edit (gaugan/runner.py:150-195), so what
-        # a user waits for is difference mask + set_masks + the first (eager) forward under the new mask -- not a graph replay
-        import statistics
-
-        lat = {"difference_mask_and_set_masks": [], "first_forward_eager": []}
-        for i, (dy, dx) in enumerate(((20, 40), (-40, -60), (60, 120), (0, -100), (35, 10))):
-            xi = cl(labels(dy, dx)[1])
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            d_i = compute_difference_mask(x0, xi)
-            model.set_masks(downsample_mask(dilate_mask(d_i, 1), (model.sh, model.sw), dilation=2))
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            model(xi)
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            if i:  # (the first one warms the allocator up)
-                lat["difference_mask_and_set_masks"].append((t1 - t0) * 1e3)
-                lat["first_forward_eager"].append((t2 - t1) * 1e3)
-        med = {k: round(statistics.median(v), 3) for k, v in lat.items()}
-        res["per_edit_latency_ms"] = dict(med, to_first_output=round(sum(med.values()), 3),
-                                          note="a NEW edit of the same original: difference mask + set_masks + the first eager forward "
-                                               "(what gaugan/runner.py:150-195 does per edit); forward_ms above is the hipGraph replay of "
-                                               "an unchanged mask.  A launch plan (sige_amd/plan.py) does not apply yet: this generator's "
-                                               "forward still contains torch kernels (nearest upsampling x13, fc / conv_img on MIOpen), "
-                                               "which a plan cannot record")
-    res["dense_forward_ms"] = round(dense_ms, 3)
-    res["edit_ratio"] = round(float(diff.float().mean()), 4)
-    res["fused_vs_chain_max_abs"] = round(float((outs["fused_spade_modulation"] - outs["module_chain"]).abs().max()), 8)
-    if cpu_parity:
-        from oracle import oracle
-
-        ref = None
-        try:
-            from oracle import build_ref
-
-            ref = build_ref.load()
-        except Exception:
-            ref = None
-        runtime.register_backend("cpu", oracle.as_backend(ref) if ref is not None else oracle)
-        try:
-            cm = build()
-            with torch.no_grad():
-                cm.set_mode("full")
-                cm(x0c)
-                d = compute_difference_mask(x0c, x1c)
-                cm.set_masks(downsample_mask(dilate_mask(d, 1), (cm.sh, cm.sw), dilation=2))
-                cm.set_mode("sparse")
-                want = cm(x1c)
-        finally:
-            runtime.unregister_backend("cpu")
-        res["parity_max_abs"] = round(float((outs["fused_spade_modulation"] - want).abs().max()), 7)
-        res["parity_against"] = "the same generator on the CPU, native ops = %s" % ("oracle/_ref (reference sige/cpu)" if ref is not None else "oracle C restatement")
-    res["workload"] = "GauGAN SPADE generator ngf 64 (%.1fM params, random init), one-hot label map [1,36,256,512], %.1f%% relabelled, fp32 NHWC, hipGraph replay" % (
-        sum(p_.numel() for p_ in model.parameters()) / 1e6, 100 * res["edit_ratio"])
-    return res
-
-
-def sd_transformer_section(dev):
-    """BASELINE.json configs[3], the part that is specific to Stable Diffusion: one sparse-query spatial transformer at the SD
-    v1 level-1 shape (320 channels, 8 heads, text context 768), 64 x 64 latent, CFG batch 2, 15 % edit."""
-    from sige_amd.nn import SIGEModel
-    from sige_amd.utils import downsample_mask
-    from sige_amd.workloads.sd_transformer import SpatialTransformer
-
-    class Wrap(SIGEModel):
-        def __init__(self, m):
-            super().__init__()
-            self.m = m
-
-        def forward(self, x, **kw):
-            return self.m(x, **kw)
-
-    res = {}
-    cl = lambda t_: t_.contiguous(memory_format=torch.channels_last)  # noqa: E731
-    gen = torch.Generator().manual_seed(5)
-    x0 = cl(torch.randn(2, 320, 64, 64, generator=gen).to(dev))
-    noise = cl(torch.randn(2, 320, 64, 64, generator=gen).to(dev))
-    ctx = torch.randn(2, 77, 768, generator=gen).to(dev)
-    mask512 = torch.zeros(512, 512, dtype=torch.bool, device=dev)
-    mask512[150:348, 120:318] = True
-    masks = downsample_mask(mask512, min_res=8, dilation=1)
-    x1 = cl(x0 + noise * masks[(64, 64)])
-    outs = {}
-    with torch.no_grad():
-        for name, kv in (("sparse_queries_kv_scattered", True), ("sparse_queries_kv_reprojected", False)):
-            torch.manual_seed(0)
-            model = Wrap(SpatialTransformer(320, 8, 40, depth=1, context_dim=768, block_size=4, sparse_kv=kv)).to(dev).eval()
-            for p_ in model.parameters():
-                if p_.dim() >= 2:
-                    p_.data.normal_(0, 1.0 / float(p_[0].numel()) ** 0.5)
-            model = model.to(memory_format=torch.channels_last)
-            model.set_scatter_inplace(True)
-            model.set_mode("full")
-            if "dense_forward_ms" not in res:
-                res["dense_forward_ms"] = round(_replay_ms(lambda: model(x1, context=ctx))[0], 3)
-            model(x0, context=ctx)
-            model.set_masks(masks)
-            model.set_mode("sparse")
-            ms, out, g = _replay_ms(lambda: model(x1, context=ctx))
-            outs[name] = out.float().cpu()
-            res[name] = {"forward_ms": round(ms, 3), "speedup_vs_dense": round(res["dense_forward_ms"] / ms, 2)}
-            del g, model
-    res["kv_scattered_vs_reprojected_max_abs"] = round(float((outs["sparse_queries_kv_scattered"] - outs["sparse_queries_kv_reprojected"]).abs().max()), 8)
-    res["active_token_ratio"] = round(float(masks[(64, 64)].float().mean()), 4)
-    res["workload"] = "SD v1 spatial transformer (320 ch, 8 heads x 40, context 768), latent [2,320,64,64] (CFG batch 2), fp32 NHWC, hipGraph replay"
-    return res
-
-
-def _hip():
-    from sige_amd import hip
-
-    return hip
-
-
 def main_sd(args, world, rank, dev):
     """--workload sd: BASELINE.json configs[3] -- the Stable Diffusion v1 U-Net (860 M parameters, random init) on a 64 x 64
     latent with classifier-free-guidance batch 2, a 15 % square edit of the 512 x 512 image; N different edits of ONE original
@@ -756,7 +492,10 @@ def main_sd(args, world, rank, dev):
                                             ("native_attention_32_queries_per_workgroup", True, False, 2, True),
                                             ("native_attention_and_linears", True, True, 0, False)):
                 _sdt.NATIVE_ATTENTION, _sdt.NATIVE_LINEAR, _sdt.BATCHED_QKV = att, lin, bq
-                hip.lib().sige_hip_attention_tokens_force_form(form)
+                if form and not hip.lib().has_tuning:
+                    continue  # (a kernel-form comparison: only in the measurement build, SIGE_HIP_LIB=.../libsige_hip_tuning.so)
+                if hip.lib().has_tuning:
+                    hip.tuning_set("attention_form", form)
                 run(x1)
                 n0 = hip.launch_count()
                 run(x1)
@@ -767,7 +506,8 @@ def main_sd(args, world, rank, dev):
                 routing[tag] = {"forward_ms": round(ms_v, 3), "library_launches": nl, "max_abs_vs_reference_chain": round(float((o_v.float() - ref_out).abs().max()), 8)}
                 del g_v
             _sdt.NATIVE_ATTENTION, _sdt.NATIVE_LINEAR, _sdt.BATCHED_QKV = keep_flags
-            hip.lib().sige_hip_attention_tokens_force_form(0)
+            if hip.lib().has_tuning:
+                hip.tuning_set("attention_form", 0)
             # per-kernel accounting of the library's launches in one forward (the same accounting as the DDPM headline's table)
             tracer = Tracer(hip)
             run(x1)
@@ -894,20 +634,6 @@ def main_sd(args, world, rank, dev):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def capture_fn(fn, warm=2):
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        for _ in range(warm):
-            fn()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=s, capture_error_mode=CAPTURE_MODE):
-            out = fn()
-    torch.cuda.current_stream().wait_stream(s)
-    torch.cuda.synchronize()
-    return g, out
 
 
 # ---------------------------------------------------------------- launching --

@@ -1,0 +1,118 @@
+"""bench.py section: the GauGAN SPADE generator (BASELINE.json configs[2])."""
+import time
+
+import torch
+
+from .common import _hip, _replay_ms
+
+
+def gaugan_section(dev, cpu_parity=True):
+    """BASELINE.json configs[2]: GauGAN SPADE generator (ngf 64, 93 M parameters, random init), 256 x 512 label map
+    (crop 512, aspect 2 -- gaugan/test.py:53-54), ~5 % relabelled rectangle; fp32, channels-last."""
+    import numpy as np
+
+    from sige_amd import runtime
+    from sige_amd.utils import compute_difference_mask, dilate_mask, downsample_mask
+    from sige_amd.workloads.gaugan_spade import SPADEConfig, SpadeGenerator
+
+    def labels(dy=0, dx=0):
+        rs = np.random.RandomState(3)
+        coarse = rs.randint(0, 36, size=(32, 64))
+        lab0 = np.kron(coarse, np.ones((8, 8), dtype=np.int64))
+        lab1 = lab0.copy()
+        lab1[85 + dy:136 + dy, 128 + dx:256 + dx] = (lab0[85 + dy:136 + dy, 128 + dx:256 + dx] + 5) % 36
+        oh = lambda l: torch.nn.functional.one_hot(torch.from_numpy(l), 36).permute(2, 0, 1)[None].float().contiguous()  # noqa: E731
+        return oh(lab0), oh(lab1)
+
+    def build():
+        torch.manual_seed(0)
+        m = SpadeGenerator(SPADEConfig()).eval()
+        g = torch.Generator().manual_seed(7)
+        for n_, b_ in m.named_buffers():  # running statistics away from (0, 1): the cached affine matters
+            if n_.endswith("running_mean"):
+                b_.copy_(torch.randn(b_.shape, generator=g) * 0.3)
+            elif n_.endswith("running_var"):
+                b_.copy_(torch.rand(b_.shape, generator=g) + 0.5)
+        return m
+
+    x0c, x1c = labels()
+    cl = lambda t_: t_.to(dev).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    model = build().to(dev).to(memory_format=torch.channels_last)
+    model.set_scatter_inplace(True)
+    x0, x1 = cl(x0c), cl(x1c)
+    res = {}
+    with torch.no_grad():
+        model.set_mode("full")
+        dense_ms, _, gd = _replay_ms(lambda: model(x1))
+        del gd
+        model(x0)
+        diff = compute_difference_mask(x0, x1)
+        model.set_masks(downsample_mask(dilate_mask(diff, 1), (model.sh, model.sw), dilation=2))
+        model.set_mode("sparse")
+        outs = {}
+        for name, fused in (("fused_spade_modulation", True), ("module_chain", False)):
+            model.cfg.fused = fused
+            n0 = _hip().launch_count()
+            model(x1)
+            launches = _hip().launch_count() - n0
+            ms, out, g = _replay_ms(lambda: model(x1))
+            outs[name] = out.float().cpu()
+            res[name] = {"forward_ms": round(ms, 3), "speedup_vs_dense": round(dense_ms / ms, 2), "hip_kernel_launches": launches}
+            del g
+        model.cfg.fused = True
+        # the generator's REAL per-edit latency: the reference runs ONE sparse forward per edit (gaugan/runner.py:150-195), so what
+        # a user waits for is difference mask + set_masks + the first (eager) forward under the new mask -- not a graph replay
+        import statistics
+
+        lat = {"difference_mask_and_set_masks": [], "first_forward_eager": []}
+        for i, (dy, dx) in enumerate(((20, 40), (-40, -60), (60, 120), (0, -100), (35, 10))):
+            xi = cl(labels(dy, dx)[1])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            d_i = compute_difference_mask(x0, xi)
+            model.set_masks(downsample_mask(dilate_mask(d_i, 1), (model.sh, model.sw), dilation=2))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            model(xi)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            if i:  # (the first one warms the allocator up)
+                lat["difference_mask_and_set_masks"].append((t1 - t0) * 1e3)
+                lat["first_forward_eager"].append((t2 - t1) * 1e3)
+        med = {k: round(statistics.median(v), 3) for k, v in lat.items()}
+        res["per_edit_latency_ms"] = dict(med, to_first_output=round(sum(med.values()), 3),
+                                          note="a NEW edit of the same original: difference mask + set_masks + the first eager forward "
+                                               "(what gaugan/runner.py:150-195 does per edit); forward_ms above is the hipGraph replay of "
+                                               "an unchanged mask.  A launch plan (sige_amd/plan.py) does not apply yet: this generator's "
+                                               "forward still contains torch kernels (nearest upsampling x13, fc / conv_img on MIOpen), "
+                                               "which a plan cannot record")
+    res["dense_forward_ms"] = round(dense_ms, 3)
+    res["edit_ratio"] = round(float(diff.float().mean()), 4)
+    res["fused_vs_chain_max_abs"] = round(float((outs["fused_spade_modulation"] - outs["module_chain"]).abs().max()), 8)
+    if cpu_parity:
+        from oracle import oracle
+
+        ref = None
+        try:
+            from oracle import build_ref
+
+            ref = build_ref.load()
+        except Exception:
+            ref = None
+        runtime.register_backend("cpu", oracle.as_backend(ref) if ref is not None else oracle)
+        try:
+            cm = build()
+            with torch.no_grad():
+                cm.set_mode("full")
+                cm(x0c)
+                d = compute_difference_mask(x0c, x1c)
+                cm.set_masks(downsample_mask(dilate_mask(d, 1), (cm.sh, cm.sw), dilation=2))
+                cm.set_mode("sparse")
+                want = cm(x1c)
+        finally:
+            runtime.unregister_backend("cpu")
+        res["parity_max_abs"] = round(float((outs["fused_spade_modulation"] - want).abs().max()), 7)
+        res["parity_against"] = "the same generator on the CPU, native ops = %s" % ("oracle/_ref (reference sige/cpu)" if ref is not None else "oracle C restatement")
+    res["workload"] = "GauGAN SPADE generator ngf 64 (%.1fM params, random init), one-hot label map [1,36,256,512], %.1f%% relabelled, fp32 NHWC, hipGraph replay" % (
+        sum(p_.numel() for p_ in model.parameters()) / 1e6, 100 * res["edit_ratio"])
+    return res

@@ -52,6 +52,48 @@ enum {
  * (sige/common.cpp:4,11-23). */
 enum { SIGE_HIP_ACT_IDENTITY = 0, SIGE_HIP_ACT_SWISH = 1 };
 
+/* ---- thread-safety ("re-entrant, no global state") ---------------------------------------------------------
+ * Every compute entry point (gather / scatter / scatter_gather / scatter_map / reduce_mask / mask pipeline / block_conv /
+ * wide_conv / group_norm / attention / spade / conv_in / conv_out ...) is RE-ENTRANT: it reads its arguments, enqueues on
+ * the stream it is handed and returns; the kernels a call runs depend on its arguments alone.  The product library keeps
+ * no process-global mutable dispatch state.  What state there is:
+ *   per HOST THREAD  : sige_hip_set_edit_batch (the stacked-edit factor E of the tensors this thread hands over; a launch
+ *                      plan records the call, so a replayed plan restores it), sige_hip_conv_pair_begin / _end (the held
+ *                      shortcut conv of a pair), sige_hip_plan_begin / _end (the plan this thread is recording into);
+ *   per DEVICE, mutex: the K-split ticket buffer (sige_hip_split_tickets_reset) and sige_hip_preload's loaded-device set;
+ *   atomic counters  : sige_hip_launch_count, sige_hip_last_launch_device, sige_hip_conv_pairs_fused (measurement aids);
+ *   a plan OBJECT    : one thread at a time per plan (create / record / bind / run / destroy are not internally locked).
+ *
+ * ---- measurement builds only: dispatch knobs ----------------------------------------------------------------------------
+ * Round 4 shipped ten process-global `sige_hip_*_force_*` setters.  They are gone from the product library; a library built
+ * with -DSIGE_HIP_TUNING (lib/libsige_hip_tuning.so; tools/, bench sections that compare kernel forms, tests that force a form)
+ * exports ONE setter / getter over the keys below (atomic; process-wide; 0 / -1 defaults = the product's behaviour). */
+enum {
+    SIGE_HIP_TUNE_CONV_TILE_MT = 0,          /* pin the tile conv's output block: 16 | 32 pixels (0 = per launch) */
+    SIGE_HIP_TUNE_CONV_TILE_NB = 1,          /* ... x nb * mt output channels, nb 1 | 2 (with CONV_TILE_MT) */
+    SIGE_HIP_TUNE_CONV_WAVES = 2,            /* waves per workgroup of the channels-last stride-1 kernels: 4 | 8 (0 = per launch) */
+    SIGE_HIP_TUNE_CONV_LARGE_GRID_NB1 = 3,   /* unsplit full grids take 32 x 32 blocks from this many 32 x 64 blocks on (-1 = library: exact fp32 always; 0 never) */
+    SIGE_HIP_TUNE_CONV_KSPLIT = 4,           /* cross-workgroup K split: 1..8 = at most this many (0 = per launch) */
+    SIGE_HIP_TUNE_CONV_KSPLIT_SECOND_PASS = 5, /* 1 = finish a K split by a second launch instead of inside the launch */
+    SIGE_HIP_TUNE_GATHER_ONE_TILE_ROWS = 6,  /* 1 = the NCHW gather always in its one-tile-per-workgroup row form */
+    SIGE_HIP_TUNE_SCATTER_GATHER_FORM = 7,   /* bit 0: always the element form; bit 1: never the grouped row form */
+    SIGE_HIP_TUNE_SMALL_COUT_SCALAR = 8,     /* 1 = conv3x3_small_cout always on its scalar-weight kernel */
+    SIGE_HIP_TUNE_WIDE_KSPLIT = 9,           /* dense-layer conv: pin the K split (0 = automatic) */
+    SIGE_HIP_TUNE_ATTENTION_FORM = 10,       /* attention_tokens: 1 = 16 queries per workgroup | 2 = 32 (0 = automatic) */
+    SIGE_HIP_TUNE_CONV_V3 = 11,              /* the weight-sharing tile conv (conv_tile3): -1 = library's rule | 0 never | 1 wherever it exists */
+    SIGE_HIP_TUNE_COUNT = 12
+};
+#ifdef SIGE_HIP_TUNING
+int sige_hip_tuning_set(int key, int value); /* SIGE_HIP_EINVAL for an unknown key or a value outside the key's range */
+int sige_hip_tuning_get(int key);            /* the current value (the default if never set); INT_MIN for an unknown key */
+#endif
+
+/* Load the code objects of every translation unit of this library on the CURRENT device now (HIP loads a code object on the
+ * first launch of one of its kernels: 44 of them, 0.3 - 40 ms each, which otherwise lands on the first forward that happens to
+ * select a not-yet-used kernel variant -- e.g. a new mask whose tile count picks another block shape).  Idempotent per
+ * device; not capturable (call it before capturing).  Returns the number of code objects touched, or a negative status. */
+int sige_hip_preload(void);
+
 int sige_hip_version(void);
 const char *sige_hip_error_string(int status);
 /* name of device 0's gcnArchName ("gfx950...") or NULL if no device. */
@@ -72,9 +114,6 @@ int sige_hip_gather_f32(const float *x, int B, int C, int H, int W, int bH, int 
                         const float *scale, int scaleB, int scaleC, int scaleH, int scaleW,
                         const float *shift, int shiftB, int shiftC, int shiftH, int shiftW,
                         int activation, int activation_first, float *out, void *stream);
-/* Tuning knob: 1 = the NCHW gather always uses the one-tile-per-workgroup row form; 0 (default) = groups of 8 consecutive
- * tiles per workgroup when there are enough tiles (merged cache-line requests for horizontally adjacent tiles). */
-int sige_hip_gather_force_rows(int one_tile_rows);
 
 /* ---- scatter : replaces scatter_cpu / scatter_cuda ----------------------
  * (sige/cpu/scatter.cpp:70-109, sige/cuda/scatter_kernel.cu:76-117, scatter.h:5-11)
@@ -136,11 +175,6 @@ int sige_hip_scatter_gather_f32(const float *x, const float *y, int B, int C, in
                                 const float *scale, int scaleB, int scaleC, int scaleH, int scaleW,
                                 const float *shift, int shiftB, int shiftC, int shiftH, int shiftW,
                                 int activation, int activation_first, float *out, void *stream);
-/* Tuning knob (bit mask): 1 = scatter_gather always uses the element form (one load per output element); 2 = never the
- * grouped row form; 0 (default) = the row form for 4x4 / 5x5 / 6x6 windows (one lane per (channel, window row), the middle
- * four pixels with one 16-byte load), grouped (8 consecutive tiles per workgroup, halo pixels exchanged through LDS) for
- * 6x6 windows over 4x4 tiles when there are enough tiles. */
-int sige_hip_scatter_gather_force_elements(int element_form);
 
 /* ---- mask pipeline : replaces sige.utils.compute_difference_mask / dilate_mask /
  * downsample_mask (sige/utils.py:74-85, 40-71, 88-118) for masks that live on the GPU,
@@ -271,34 +305,19 @@ int sige_hip_scatter_gather_conv_scatter_nhwc_f16c(
         float *twin1, const float *twin1_scale, const float *twin1_shift,
         float *out, void *stream);
 
-/* Tuning knob (process-wide, not thread-safe): pin the MFMA kernel's output block to
- * mt pixels x (nb*mt) output channels, mt in {16, 32}, nb in {1, 2}; (0, 0) restores the
- * per-launch choice.  Results do not depend on it beyond fp32 summation order. */
-int sige_hip_block_conv_force_tile(int mt, int nb);
-/* Tuning knob: waves per workgroup of the channels-last stride-1 kernels: 4, 8 (two waves per SIMD),
- * or 0 = per launch (8 when the grid has fewer than 160 workgroups). */
-int sige_hip_block_conv_force_waves(int waves);
-/* plan policy (per process): unsplit launches that 32-pixel x 64-channel output blocks would fill the chip with use 32 x 32 blocks
- * (two or three workgroups per CU instead of one) from `min_blocks` such blocks on; -1 = the library's choice (default: exact
- * fp32 always, other operand forms never), 0 = never.  Results do not depend on it (the same summation order). */
-int sige_hip_block_conv_large_grid_nb1(int min_blocks);
 /* Horizontal fusion of the two independent convs at the head of a residual block.  After pair_begin() the next
  * channels-last fp32 1x1 gather -> conv launch with raw staging (the block's shortcut) is HELD: the call returns
  * SIGE_HIP_OK without launching.  The next channels-last fp32 3x3/s1 gather -> conv launch with affine + SiLU staging on
  * the same stream and with the same destination kind (the block's conv1) then runs both in ONE kernel (workgroups of
  * both convs side by side; the 1x1's own ~5 us launch disappears).  Any other conv launch, and pair_end(), launch the held
  * conv on its own first, so results never depend on whether a pair was formed.  Per host thread; the pointers of the
- * held call must stay valid until it has been launched.  pairs_fused(): how many pairs this process has formed. */
+ * held call must stay valid until it has been launched.  pairs_fused(): how many pairs this process has formed (atomic). */
 int sige_hip_conv_pair_begin(void);
 int sige_hip_conv_pair_end(void);
 int64_t sige_hip_conv_pairs_fused(void);
-/* Tuning knob: cross-workgroup K split of the channels-last launches that come with a workspace: 1..8 = at most this
- * many splits whatever the grid size (clamped to the workspace and to >= 2 channel chunks per split), 0 = per launch. */
-int sige_hip_block_conv_force_ksplit(int ksplit);
-/* Tuning knob: how a K-split launch is finished.  0 (default): inside the launch -- the last workgroup to finish an output
- * block adds the partial copies of that block up in split order and runs the epilogue (tickets in a library-owned,
- * per-device buffer); 1: by a second launch over the whole output.  Both add in the same order: identical results. */
-int sige_hip_block_conv_force_ksplit_pass(int second_pass);
+/* A K-split launch is finished inside the launch: the last workgroup to finish an output block adds the partial copies of
+ * that block up in split order and runs the epilogue (tickets in a library-owned, per-device buffer); when no tickets are to
+ * be had, by a second launch over the whole output.  Both add in the same order: identical results. */
 /* Tickets of launches made while a stream is being CAPTURED into a hipGraph are bump-allocated (a replayed graph owns its
  * tickets for its lifetime) out of 3 M per device; when they run out, captured K-split launches fall back to the second-pass
  * finish (still correct, one more launch).  A long-running host that re-captures per mask calls this once every hipGraph
@@ -457,9 +476,6 @@ int sige_hip_conv3x3_small_cout_nhwc_f32(const float *x, int B, int C, int H, in
                                          const float *shift, int shiftB, int shiftC, int activation,
                                          const float *weight, const float *bias, int Cout,
                                          float *out, void *stream);
-/* benchmarking / tests: 1 = always the scalar-weight kernel; 0 (default) = the tap-GEMM MFMA kernel
- * where it applies (C = 64 / 128, Cout <= 3). */
-int sige_hip_conv3x3_small_cout_force_scalar(int on);
 
 /* ---- 3x3 / padding-1 conv with <= 3 input channels and Cout = 32 / 64 / 128 over a full image
  * (the U-Net's conv_in, sige_fused_unet.py:395: a plain nn.Conv2d in every mode):
@@ -605,8 +621,6 @@ size_t sige_hip_wide_conv_packed_size(int Cout, int Cin, int kH, int kW, int pre
 int sige_hip_wide_conv_pack(const float *w, int Cout, int Cin, int kH, int kW, int prec, int wshift,
                             float *packed, void *stream);
 size_t sige_hip_wide_conv_workspace(int B, int H, int W, int C1, int C2, int Cout, int kH, int kW);
-/* benchmarking: pin the K split (0 = automatic) */
-int sige_hip_wide_conv_force_ksplit(int ksplit);
 int sige_hip_wide_conv_nhwc(const float *x, const float *x2, int B, int C1, int C2, int H, int W, int upsample2x,
                             const float *scale, const float *shift, int affineB, int activation,
                             const float *packed, int prec, int wshift, const float *bias, int Cout, int kH, int kW,
@@ -629,9 +643,6 @@ int sige_hip_affine_act_nhwc_f32(const float *x, int B, int C, int H, int W, con
  * and no score tensor in HBM: one launch, exact fp32 products, online softmax (attention.py's CrossAttention.forward does
  * rearrange x 3, einsum, softmax, einsum, rearrange).  Nq % 16 == 0, d % 4 == 0, d <= 160; Nk arbitrary.                */
 int sige_hip_attention_tokens_supported(int Nq, int Nk, int C, int heads);
-/* benchmarking / tests: 0 automatic (= 1) | 1 16 queries per workgroup | 2 32 (two query tiles share every K / V register
- * fragment) wherever the form exists (d <= 96) */
-int sige_hip_attention_tokens_force_form(int form);
 int sige_hip_attention_tokens_f32(const float *q, const float *k, const float *v, int B, int Nq, int Nk, int C,
                                   int heads, float scale, float *out, void *stream);
 
@@ -744,6 +755,14 @@ int sige_hip_plan_calls(void *plan, int section);
 int sige_hip_plan_new_slots(void *plan, int n);
 int sige_hip_plan_bind_ptr(void *plan, const void *ptr, int slot);
 int sige_hip_plan_set_slot(void *plan, int slot, int count);
+/* `ptr` is an index list whose tile count does not depend on the mask (the all-tiles list of a dense layer): a count
+ * recorded next to it keeps its value.  A count recorded next to a pointer that is neither bound nor constant cannot follow
+ * a new mask: it is counted (plan_unbound) and marks the plan shape bound. */
+int sige_hip_plan_bind_const(void *plan, const void *ptr);
+int sige_hip_plan_unbound(void *plan);
+/* Drop the calls of `section` recorded after the first `calls` (the host side removes an entry-point call that returned an
+ * error status while recording: the hook stores a call before the entry point validates it). */
+int sige_hip_plan_truncate(void *plan, int section, int calls);
 /* copies min(n, slots) counts to `out`; returns the number of slots */
 int sige_hip_plan_get_slots(void *plan, int32_t *out, int n);
 int sige_hip_plan_record_readback(void *plan, const int32_t *device_counts, int first_slot, int n);

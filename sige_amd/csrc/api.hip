@@ -2,6 +2,84 @@
 #include "common.hpp"
 
 #include <atomic>
+#include <climits>
+#include <mutex>
+#include <vector>
+
+// ---- measurement builds: the dispatch knobs (csrc/tuning.hpp) ----
+#ifdef SIGE_HIP_TUNING
+namespace sige {
+std::atomic<int> g_tuning[SIGE_HIP_TUNE_COUNT] = {{kTuningDefaults[0]}, {kTuningDefaults[1]}, {kTuningDefaults[2]}, {kTuningDefaults[3]},
+                                                  {kTuningDefaults[4]}, {kTuningDefaults[5]}, {kTuningDefaults[6]}, {kTuningDefaults[7]},
+                                                  {kTuningDefaults[8]}, {kTuningDefaults[9]}, {kTuningDefaults[10]}, {kTuningDefaults[11]}};
+}
+static_assert(SIGE_HIP_TUNE_COUNT == 12, "g_tuning's initialiser lists every key");
+
+extern "C" int sige_hip_tuning_set(int key, int value) {
+    bool ok = false;
+    switch (key) {
+        case SIGE_HIP_TUNE_CONV_TILE_MT: ok = value == 0 || value == 16 || value == 32; break;
+        case SIGE_HIP_TUNE_CONV_TILE_NB: ok = value >= 0 && value <= 2; break;
+        case SIGE_HIP_TUNE_CONV_WAVES: ok = value == 0 || value == 4 || value == 8; break;
+        case SIGE_HIP_TUNE_CONV_LARGE_GRID_NB1: ok = value >= -1; break;
+        case SIGE_HIP_TUNE_CONV_KSPLIT: ok = value >= 0 && value <= 8; break;
+        case SIGE_HIP_TUNE_CONV_KSPLIT_SECOND_PASS: ok = value == 0 || value == 1; break;
+        case SIGE_HIP_TUNE_GATHER_ONE_TILE_ROWS: ok = value == 0 || value == 1; break;
+        case SIGE_HIP_TUNE_SCATTER_GATHER_FORM: ok = value >= 0 && value <= 3; break;
+        case SIGE_HIP_TUNE_SMALL_COUT_SCALAR: ok = value == 0 || value == 1; break;
+        case SIGE_HIP_TUNE_WIDE_KSPLIT: ok = value >= 0 && value <= 8; break;
+        case SIGE_HIP_TUNE_ATTENTION_FORM: ok = value >= 0 && value <= 2; break;
+        case SIGE_HIP_TUNE_CONV_V3: ok = value >= -1 && value <= 1; break;
+        default: return SIGE_HIP_EINVAL;
+    }
+    if (!ok) return SIGE_HIP_EINVAL;
+    sige::g_tuning[key].store(value, std::memory_order_relaxed);
+    return SIGE_HIP_OK;
+}
+
+extern "C" int sige_hip_tuning_get(int key) {
+    if (key < 0 || key >= SIGE_HIP_TUNE_COUNT) return INT_MIN;
+    return sige::g_tuning[key].load(std::memory_order_relaxed);
+}
+#endif
+
+// ---- code-object preload (include/sige_hip.h: sige_hip_preload) ----
+namespace {
+struct PreloadState {
+    std::mutex mu;
+    std::vector<const void *> anchors;  // one kernel per translation unit
+    bool loaded[64] = {};
+};
+PreloadState &preload_state() {
+    static PreloadState s;  // (constructed on first use: the registrars below run from other units' static initialisers)
+    return s;
+}
+}  // namespace
+
+void sige::preload_register(const void *host_kernel) {
+    PreloadState &s = preload_state();
+    std::lock_guard<std::mutex> lock(s.mu);
+    s.anchors.push_back(host_kernel);
+}
+
+extern "C" int sige_hip_preload(void) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return SIGE_HIP_ENODEVICE;
+    PreloadState &s = preload_state();
+    std::lock_guard<std::mutex> lock(s.mu);
+    if (dev < 64 && s.loaded[dev]) return 0;
+    int n = 0;
+    for (const void *k : s.anchors) {
+        hipFuncAttributes attr;
+        if (hipFuncGetAttributes(&attr, k) != hipSuccess) {
+            (void)hipGetLastError();
+            return SIGE_HIP_ELAUNCH;
+        }
+        ++n;
+    }
+    if (dev < 64) s.loaded[dev] = true;
+    return n;
+}
 
 static std::atomic<long> g_launches{0};
 static std::atomic<int> g_last_device{-1};

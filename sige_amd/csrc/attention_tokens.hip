@@ -181,14 +181,6 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
 
 using namespace sige;
 
-static int g_attention_force_form = 0;  // benchmarking: 0 automatic | 1 16 queries per workgroup | 2 32 (two tiles share the K / V fragments)
-
-extern "C" int sige_hip_attention_tokens_force_form(int form) {
-    if (form < 0 || form > 2) return SIGE_HIP_EINVAL;
-    g_attention_force_form = form;
-    return SIGE_HIP_OK;
-}
-
 extern "C" int sige_hip_attention_tokens_supported(int Nq, int Nk, int C, int heads) {
     if (Nq <= 0 || Nk <= 0 || C <= 0 || heads <= 0 || C % heads) return 0;
     const int d = C / heads;
@@ -211,7 +203,7 @@ extern "C" int sige_hip_attention_tokens_f32(const float *q, const float *k, con
     // 16 queries per workgroup, the key blocks split across its 4 waves.  On request 32 (two query tiles share every K / V
     // fragment a wave loads: half the loads per MFMA; d <= 96) -- measured equal at SD's shapes (profiles/r4i_bench_sd.json:
     // 11.46 vs 11.47 ms per forward), so the kernel is not load-bound there and the simpler form is the default.
-    const int form = (g_attention_force_form == 2 && units <= 6) ? 2 : 1;
+    const int form = (tuning(SIGE_HIP_TUNE_ATTENTION_FORM) == 2 && units <= 6) ? 2 : 1;
     const dim3 grid16(Nq / 16, B * heads), grid32((Nq + 31) / 32, B * heads);
 #define SIGE_ATT_GO(U)                                                                                             \
     do {                                                                                                           \

@@ -267,12 +267,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_nhwc_kernel(const float *__
 // K split factor for a conv whose smallest-tile grid (16 pixels x 16 channels per workgroup) cannot
 // cover the chip: every wave then runs K/4 MFMA steps back to back however few tiles there are
 // (the 8x8 layers of the U-Net: 64 pixels, K = 4608..9216), so the chunks are shared out.
-static int g_force_ksplit = 0;  // sige_hip_block_conv_force_ksplit (benchmarking)
 static int ksplit_for(long blocks, int nchunks, int cap) {
     // (the second pass costs ~4.7 us per launch; measured on the DDPM-256 dense remainder the split still
     //  wins 140 us per forward: 923 vs 1064 us over its 58 conv launches)
-    if (cap <= 1 || (blocks >= 224 && !g_force_ksplit)) return 1;
-    int s = g_force_ksplit ? g_force_ksplit : (int)((224 + blocks - 1) / blocks);
+    const int force = tuning(SIGE_HIP_TUNE_CONV_KSPLIT);  // (a measurement build's knob; 0 in the product)
+    if (cap <= 1 || (blocks >= 224 && !force)) return 1;
+    int s = force ? force : (int)((224 + blocks - 1) / blocks);
     s = s < nchunks / 2 ? s : nchunks / 2;  // >= 2 chunks per split (the software pipeline's depth)
     s = s < 8 ? s : 8;
     s = s < cap ? s : cap;
@@ -284,8 +284,7 @@ static int ksplit_for(long blocks, int nchunks, int cap) {
 // whose grid still covers the 256 CUs (every workgroup runs the full K, the f32
 // matrix pipe is saturated by one wave per SIMD, so a grid below ~1 workgroup per
 // CU leaves matrix cores idle while a larger block only saves operand traffic).
-// sige_hip_block_conv_force_tile(mt, nb) overrides the choice (benchmarking).
-static int g_force_mt = 0, g_force_nb = 0, g_force_waves = 0;
+// (SIGE_HIP_TUNE_CONV_TILE_MT / _NB override the choice in a measurement build.)
 // Unsplit launches that 32 pixel x 64 channel output blocks (NB = 2) would fill the chip with: from this many such blocks on they
 // take 32 x 32 blocks (NB = 1) instead.  The NB = 2 kernels of the exact-fp32 3x3 geometry need 290-320 registers = ONE workgroup
 // per CU, the NB = 1 kernels 150-190 = two or three: on a grid of several blocks per CU the start-up of one workgroup runs under
@@ -293,7 +292,6 @@ static int g_force_mt = 0, g_force_nb = 0, g_force_waves = 0;
 // one image at 1.2 / 5 / 15 % edit 1.406 / 1.874 / 2.509 -> 1.406 / 1.765 / 2.306 ms, 8 stacked edits 6.26 -> 5.61 ms, for every
 // threshold from 1 to 192 blocks; fp16 operands: no gain.  -1 = the library's choice (exact fp32: always; other operand forms:
 // never), 0 = never, n > 0 = from n blocks on in every operand form (benchmarking).
-static int g_large_grid_nb1 = -1;
 __device__ int32_t g_zero_idx[2] = {0, 0};
 
 #ifdef SIGE_CONV_PROBE
@@ -328,7 +326,7 @@ struct HeldConv {
 };
 static thread_local HeldConv g_held;
 static thread_local bool g_pairing = false;
-static long g_pairs_fused = 0;
+static std::atomic<long> g_pairs_fused{0};
 
 static int flush_held() {
     if (!g_held.active) return SIGE_HIP_OK;
@@ -380,11 +378,10 @@ constexpr size_t kTicketRing = size_t(1) << 20, kTicketGraph = size_t(3) << 20;
 struct TicketPool { int32_t *buf = nullptr; size_t ring_pos = 0, graph_pos = 0; bool failed = false; };
 static TicketPool g_tickets[32];
 static std::mutex g_tickets_mu;
-static bool g_inkernel_splitk = true;  // sige_hip_block_conv_force_ksplit_pass (benchmarking)
 
 int32_t *split_tickets(hipStream_t st, long blocks) {
     int dev = -1;
-    if (!g_inkernel_splitk || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32 || blocks > (long)kTicketRing) return nullptr;
+    if (tuning(SIGE_HIP_TUNE_CONV_KSPLIT_SECOND_PASS) || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32 || blocks > (long)kTicketRing) return nullptr;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess) return nullptr;
     const bool capturing = cs != hipStreamCaptureStatusNone;
@@ -443,14 +440,16 @@ static int plan_conv(ConvArgs &a, int cap, int want_waves, bool nb1, ConvPlan &p
     };
     const long kFill = want_waves ? 64 : 224;  // (a pair's second conv shares the chip with the first)
     int mt = 0, nb = 1;
-    if (g_force_mt && !want_waves) { mt = g_force_mt == 32 ? 32 : 16; nb = (g_force_nb == 2 && kHasNB2) ? 2 : 1; if (!usable(mt)) mt = 0; }
+    const int force_mt = tuning(SIGE_HIP_TUNE_CONV_TILE_MT), force_nb = tuning(SIGE_HIP_TUNE_CONV_TILE_NB), force_waves = tuning(SIGE_HIP_TUNE_CONV_WAVES);
+    const int large_grid_nb1 = tuning(SIGE_HIP_TUNE_CONV_LARGE_GRID_NB1), force_ksplit = tuning(SIGE_HIP_TUNE_CONV_KSPLIT);
+    if (force_mt && !want_waves) { mt = force_mt == 32 ? 32 : 16; nb = (force_nb == 2 && kHasNB2) ? 2 : 1; if (!usable(mt)) mt = 0; }
     // Exact fp32, channels-last, stride 1: 128 unsplit 16-channel blocks beat 32 blocks x 4 K splits -- the 8x8 layers of the
     // DDPM U-Net, 13.4 vs 14.4 us per launch, 1.437 -> 1.419 ms per forward (tools/probe/ksplit_forward_probe.py, round 3): the
     // split's second phase (partial sums out, ticket, the last workgroup's sum over the copies) costs more than the 4x shorter
     // K loop saves.  Below half a chip of blocks the split still wins.
     constexpr bool kW8Geo = LAY == LAYOUT_NHWC && STR == 1 && PREC == 0;
     const long kSplitBelow = (kW8Geo && !want_waves) ? 112 : kFill;
-    const bool stay_unsplit = cap > 1 && usable(16) && blocks(G16::TPB, 16, 1) >= kSplitBelow && blocks(G16::TPB, 16, 1) < kFill && !g_force_ksplit;
+    const bool stay_unsplit = cap > 1 && usable(16) && blocks(G16::TPB, 16, 1) >= kSplitBelow && blocks(G16::TPB, 16, 1) < kFill && !force_ksplit;
     if (!mt && cap > 1 && usable(16) && blocks(G16::TPB, 16, 1) < kSplitBelow) {
         // too few tiles for any block shape: split K across workgroups, largest block that then fills the chip
         const int nc32 = ceil_div(a.Cin, G32::CC), nc16 = ceil_div(a.Cin, G16::CC);
@@ -461,7 +460,7 @@ static int plan_conv(ConvArgs &a, int cap, int want_waves, bool nb1, ConvPlan &p
         else { mt = 16; nb = 1; }
     }
     if (!mt) {
-        const bool many = g_large_grid_nb1 < 0 ? PREC == 0 : (g_large_grid_nb1 > 0 && blocks(G32::TPB, 32, 2) >= g_large_grid_nb1);
+        const bool many = large_grid_nb1 < 0 ? PREC == 0 : (large_grid_nb1 > 0 && blocks(G32::TPB, 32, 2) >= large_grid_nb1);
         if (usable(32) && kHasNB2 && !many && blocks(G32::TPB, 32, 2) >= kFill) { mt = 32; nb = 2; }
         else if (usable(32) && blocks(G32::TPB, 32, 1) >= kFill) { mt = 32; nb = 1; }
         else if (usable(16) && kHasNB2 && blocks(G16::TPB, 16, 2) >= kFill) { mt = 16; nb = 2; }
@@ -482,7 +481,7 @@ static int plan_conv(ConvArgs &a, int cap, int want_waves, bool nb1, ConvPlan &p
     if (want_waves) {
         if (want_waves == 8 && !w8_ok) return SIGE_HIP_EUNSUPPORTED;
         waves = want_waves;
-    } else if (g_force_waves == 8 && w8_ok) {
+    } else if (force_waves == 8 && w8_ok) {
         // (round 2 picked 8 waves for grids below 160 blocks; with today's kernels and the 8x8 layers unsplit the 4-wave form wins
         //  in the forward -- 1.398 vs 1.417 ms, tools/probe/plan_forward_probe.py -- so 8 waves are the benchmarking knob's only)
         waves = 8;
@@ -539,7 +538,7 @@ static bool launch_pair(const ConvArgs &a, const ConvPlan &pa, int mode_a, ConvA
     }
 #undef SIGE_PAIR_W
 #undef SIGE_PAIR_GO
-    ++g_pairs_fused;
+    g_pairs_fused.fetch_add(1, std::memory_order_relaxed);
     return true;
 }
 
@@ -565,7 +564,7 @@ bool take_held_shortcut(ConvArgs *b, int *mt) {
     *b = a;
     *mt = p.mt;
     g_held.active = false;
-    ++g_pairs_fused;
+    g_pairs_fused.fetch_add(1, std::memory_order_relaxed);
     return true;
 }
 
@@ -585,7 +584,7 @@ static int launch_kind(ConvArgs a, int mode, hipStream_t st) {
         const int rc = flush_held();
         if (rc != SIGE_HIP_OK) return rc;
     }
-    if (kPairSecond && g_pairing && !g_held.active && mode == MODE_RAW && !g_force_mt) {
+    if (kPairSecond && g_pairing && !g_held.active && mode == MODE_RAW && !tuning(SIGE_HIP_TUNE_CONV_TILE_MT)) {
         g_held.active = true; g_held.a = a; g_held.mode = mode; g_held.dst = DST; g_held.st = st; g_held.prec = PREC;
         g_held.launch = &launch_kind<KH, STR, R, SRC, DST, LAY, PREC>;
         note_launches(-1);  // (the caller counts one launch per call: this one happens later, or inside its partner's)
@@ -707,14 +706,6 @@ static int staging_mode(const float *scale, int sB, int sC, const float *shift, 
 
 using namespace sige;
 
-extern "C" int sige_hip_block_conv_force_tile(int mt, int nb) {
-    if (mt != 0 && mt != 16 && mt != 32) return SIGE_HIP_EINVAL;
-    if (nb < 0 || nb > 2) return SIGE_HIP_EINVAL;
-    g_force_mt = mt;
-    g_force_nb = nb;
-    return SIGE_HIP_OK;
-}
-
 extern "C" int sige_hip_conv_pair_begin(void) {
     SIGE_PLAN_HOOK0(sige_hip_conv_pair_begin);
     const int rc = flush_held();
@@ -729,30 +720,7 @@ extern "C" int sige_hip_conv_pair_end(void) {
     return rc != SIGE_HIP_OK ? rc : launch_status(0);
 }
 
-extern "C" int64_t sige_hip_conv_pairs_fused(void) { return (int64_t)g_pairs_fused; }
-
-extern "C" int sige_hip_block_conv_force_ksplit_pass(int second_pass) {
-    g_inkernel_splitk = second_pass == 0;
-    return SIGE_HIP_OK;
-}
-
-extern "C" int sige_hip_block_conv_force_ksplit(int ksplit) {
-    if (ksplit < 0 || ksplit > 8) return SIGE_HIP_EINVAL;
-    g_force_ksplit = ksplit;
-    return SIGE_HIP_OK;
-}
-
-extern "C" int sige_hip_block_conv_large_grid_nb1(int min_blocks) {
-    if (min_blocks < -1) return SIGE_HIP_EINVAL;
-    g_large_grid_nb1 = min_blocks;
-    return SIGE_HIP_OK;
-}
-
-extern "C" int sige_hip_block_conv_force_waves(int waves) {
-    if (waves != 0 && waves != 4 && waves != 8) return SIGE_HIP_EINVAL;
-    g_force_waves = waves;
-    return SIGE_HIP_OK;
-}
+extern "C" int64_t sige_hip_conv_pairs_fused(void) { return (int64_t)g_pairs_fused.load(std::memory_order_relaxed); }
 
 extern "C" size_t sige_hip_block_conv_packed_size(int Cout, int Cin, int kH, int kW, int R, int S,
                                                   int strideH, int strideW, int groups) {
@@ -966,7 +934,7 @@ extern "C" int sige_hip_conv_ksplit_hint(int T, int Cin, int Cout, int kH, int k
     if (T <= 0 || Cin <= 0 || Cout <= 0) return 1;
     const int px = (kH == 3 && strideH == 2) ? 4 : 16;  // output pixels per tile
     const long blocks16 = (long)ceil_div(T, 16 / px) * ceil_div(Cout, 16);
-    if (blocks16 >= 224 && !g_force_ksplit) return 1;
+    if (blocks16 >= 224 && !tuning(SIGE_HIP_TUNE_CONV_KSPLIT)) return 1;
     return 8;  // (the launch decides the actual factor, at most 8)
 }
 

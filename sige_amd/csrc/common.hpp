@@ -5,6 +5,18 @@
 
 #include "sige_hip.h"
 #include "plan.hpp"
+#include "tuning.hpp"
+
+// One empty kernel per translation unit (build.py passes -DSIGE_TU_ID=<n>): sige_hip_preload() asks HIP for its attributes,
+// which loads the code object of this translation unit -- and with it every kernel the unit holds -- on the current device.
+namespace sige {
+void preload_register(const void *host_kernel);
+#ifdef SIGE_TU_ID
+template <int ID> __global__ void tu_anchor_kernel() {}
+template __global__ void tu_anchor_kernel<SIGE_TU_ID>();
+static const int g_tu_anchor_registered = (preload_register((const void *)&tu_anchor_kernel<SIGE_TU_ID>), 0);
+#endif
+}  // namespace sige
 
 namespace sige {
 

@@ -214,13 +214,6 @@ __global__ __launch_bounds__(256) void conv_out_gemm_kernel(const float *__restr
 
 using namespace sige;
 
-static int g_force_scalar = 0;
-
-// benchmarking / tests: 1 = always the scalar-weight kernel, 0 = the tap-GEMM kernel where it applies
-extern "C" int sige_hip_conv3x3_small_cout_force_scalar(int on) {
-    g_force_scalar = on ? 1 : 0;
-    return SIGE_HIP_OK;
-}
 
 extern "C" int sige_hip_conv3x3_small_cout_nhwc_f32(const float *x, int B, int C, int H, int W,
                                                     const float *scale, int scaleB, int scaleC,
@@ -242,7 +235,7 @@ extern "C" int sige_hip_conv3x3_small_cout_nhwc_f32(const float *x, int B, int C
     const long blocks = (long)B * ((H + kTH - 1) / kTH) * ((W + kTW - 1) / kTW);
     if (blocks > 0x7fffffffL) return SIGE_HIP_EUNSUPPORTED;
     hipStream_t st = as_stream(stream);
-    if (Cout <= 3 && (C == 128 || C == 64) && !g_force_scalar) {
+    if (Cout <= 3 && (C == 128 || C == 64) && !tuning(SIGE_HIP_TUNE_SMALL_COUT_SCALAR)) {
         const long tiles = (long)B * ((H + kGT - 1) / kGT) * ((W + kGT - 1) / kGT);
         if (tiles > 0x7fffffffL) return SIGE_HIP_EUNSUPPORTED;
 #define SIGE_CG(CI, N)                                                                                                 \

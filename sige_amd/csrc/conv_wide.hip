@@ -83,7 +83,6 @@ static bool wide_shape_ok(int C1, int C2, int Cout, int kH, int kW) {
     return C1 > 0 && C2 >= 0 && C1 % cc == 0 && C2 % cc == 0 && Cout > 0 && Cout % 64 == 0;
 }
 
-static int g_wide_force_ksplit = 0;
 
 // width of a workgroup's output patch: 8 x 8 pixels / two waves per SIMD.  (An 8 x 16 form -- one wave per SIMD with the
 // 512-register budget, twice the matrix work per weight byte, a whole chunk of weights in the ring -- was built and measured
@@ -93,7 +92,8 @@ static int wide_patch(int W) { (void)W; return 8; }
 
 // K split of a launch with `blocks` output blocks and `nchunks` channel chunks: enough workgroups for two per CU
 static int wide_ksplit(long blocks, int nchunks, size_t out_floats, size_t ws_floats) {
-    int s = g_wide_force_ksplit ? g_wide_force_ksplit : (blocks >= 384 ? 1 : (int)((512 + blocks - 1) / blocks));
+    const int force = tuning(SIGE_HIP_TUNE_WIDE_KSPLIT);
+    int s = force ? force : (blocks >= 384 ? 1 : (int)((512 + blocks - 1) / blocks));
     s = s < nchunks ? s : nchunks;
     s = s < kWideMaxSplit ? s : kWideMaxSplit;
     while (s > 1 && (size_t)s * out_floats > ws_floats) --s;
@@ -170,12 +170,6 @@ extern "C" int sige_hip_wide_probe_clear(void) {
     return hipMemset(g_wprobe_buf, 0, 8 * 4096 * sizeof(unsigned long long)) == hipSuccess ? SIGE_HIP_OK : SIGE_HIP_ELAUNCH;
 }
 #endif
-
-extern "C" int sige_hip_wide_conv_force_ksplit(int ksplit) {
-    if (ksplit < 0 || ksplit > kWideMaxSplit) return SIGE_HIP_EINVAL;
-    g_wide_force_ksplit = ksplit;
-    return SIGE_HIP_OK;
-}
 
 extern "C" int sige_hip_wide_conv_nhwc(const float *x, const float *x2, int B, int C1, int C2, int H, int W, int upsample2x,
                                        const float *scale, const float *shift, int affineB, int activation,

@@ -587,9 +587,6 @@ static void launch_act(const GatherArgs &a, int act, bool first, dim3 grid, hipS
     }
 }
 
-static bool g_gather_grouped = true;  // sige_hip_gather_force_rows (benchmarking): false = always the one-tile row form
-static bool g_sg_grouped = true;      // (same knob, bit 1: no grouped form)
-static bool g_sg_rows = true;         // sige_hip_scatter_gather_force_elements (benchmarking / tests): false = the element form
 
 template <bool MAPPED>
 static int launch(GatherArgs a, int act, bool first, hipStream_t st) {
@@ -603,9 +600,9 @@ static int launch(GatherArgs a, int act, bool first, hipStream_t st) {
     if (cchunk < 4) cchunk = 4;
     a.cchunk = cchunk;
     dim3 grid(tiles, ceil_div(a.C, cchunk));
-    if (MAPPED && g_sg_rows && a.bH == a.bW && a.bH >= 4 && a.bH <= 6) {
+    if (MAPPED && !(tuning(SIGE_HIP_TUNE_SCATTER_GATHER_FORM) & 1) && a.bH == a.bW && a.bH >= 4 && a.bH <= 6) {
         // 6x6 windows over 4x4 tiles with enough tiles to fill the chip in groups: the grouped form (halo pixels through LDS)
-        if (g_sg_grouped && a.bH == 6 && a.RxSx == 16 && a.Sx == 4 && (long)ceil_div(tiles, kSgGroup) * ceil_div(a.C, kSgGroupCh) >= 512) {
+        if (!(tuning(SIGE_HIP_TUNE_SCATTER_GATHER_FORM) & 2) && a.bH == 6 && a.RxSx == 16 && a.Sx == 4 && (long)ceil_div(tiles, kSgGroup) * ceil_div(a.C, kSgGroupCh) >= 512) {
             launch_sg_rows_grouped(a, act, first, st);
             return launch_status();
         }
@@ -622,7 +619,7 @@ static int launch(GatherArgs a, int act, bool first, hipStream_t st) {
     }
     if (!MAPPED && a.bH == a.bW && a.bH >= 4 && a.bH <= 6) {
         // enough tiles to fill the chip in groups of kGroup: the grouped row form (32 channels per workgroup = 37 KB of LDS)
-        if (g_gather_grouped && (long)ceil_div(tiles, kGroup) * ceil_div(a.C, 32) >= 512) {
+        if (!tuning(SIGE_HIP_TUNE_GATHER_ONE_TILE_ROWS) && (long)ceil_div(tiles, kGroup) * ceil_div(a.C, 32) >= 512) {
             a.cchunk = 32;
             if (a.bH == 6) launch_rows_grouped<6, 6>(a, act, first, st);
             else if (a.bH == 5) launch_rows_grouped<5, 5>(a, act, first, st);
@@ -656,17 +653,6 @@ static int launch(GatherArgs a, int act, bool first, hipStream_t st) {
 }  // namespace sige
 
 using namespace sige;
-
-extern "C" int sige_hip_gather_force_rows(int one_tile_rows) {
-    g_gather_grouped = one_tile_rows == 0;
-    return SIGE_HIP_OK;
-}
-
-extern "C" int sige_hip_scatter_gather_force_elements(int element_form) {
-    g_sg_rows = (element_form & 1) == 0;
-    g_sg_grouped = (element_form & 2) == 0;
-    return SIGE_HIP_OK;
-}
 
 extern "C" int sige_hip_gather_f32(const float *x, int B, int C, int H, int W, int bH, int bW,
                                    const int32_t *active_indices, int N,

@@ -494,7 +494,7 @@ extern "C" int sige_hip_spade_modulate_nhwc_f32(
         const float *gb_tiles, const float *gb_full, const int32_t *map_g, int Ng, int Rg, int Sg,
         int B, int C, int H, int W, int bH, int bW, const int32_t *active_indices, int N,
         int leaky, float slope, float *out, void *stream) {
-    SIGE_PLAN_HOOK_N(sige_hip_spade_modulate_nhwc_f32, (sige::CountOf<24, 25>), x_full, x_tiles, map_x, Nx, Rx, Sx, scale, scaleB, scaleC, shift, shiftB, shiftC, gb_tiles, gb_full, map_g, Ng, Rg, Sg, B, C, H, W, bH, bW, active_indices, N, leaky, slope, out, stream);
+    SIGE_PLAN_HOOK_N(sige_hip_spade_modulate_nhwc_f32, (sige::CountOf<24, 25>, sige::CountOf<2, 3>, sige::CountOf<14, 15>), x_full, x_tiles, map_x, Nx, Rx, Sx, scale, scaleB, scaleC, shift, shiftB, shiftC, gb_tiles, gb_full, map_g, Ng, Rg, Sg, B, C, H, W, bH, bW, active_indices, N, leaky, slope, out, stream);
     if (B < 0 || C <= 0 || H <= 0 || W <= 0 || bH <= 0 || bW <= 0 || N < 0 || Ng < 0 || Nx < 0) return SIGE_HIP_EINVAL;
     if (stacked_shift(H) != 0) return SIGE_HIP_EUNSUPPORTED;
     if ((long)B * N == 0) return SIGE_HIP_OK;

@@ -51,6 +51,7 @@ extern "C" int sige_hip_plan_destroy(void *plan) {
     Plan *p = static_cast<Plan *>(plan);
     if (!p) return SIGE_HIP_EINVAL;
     if (g_plan_rec == p) g_plan_rec = nullptr;
+    else if (p->recording.load(std::memory_order_acquire)) return SIGE_HIP_EINVAL;  // (another thread records into it: its thread-local pointer cannot be cleared from here)
     delete p;
     return SIGE_HIP_OK;
 }
@@ -59,6 +60,7 @@ extern "C" int sige_hip_plan_begin(void *plan, int section, int append) {
     Plan *p = static_cast<Plan *>(plan);
     if (!p || section < 0 || section >= PLAN_SECTIONS || g_plan_rec) return SIGE_HIP_EINVAL;
     if (!append) p->calls[section].clear();
+    p->recording.store(true, std::memory_order_release);
     g_plan_rec = p;
     g_plan_section = section;
     return SIGE_HIP_OK;
@@ -67,6 +69,7 @@ extern "C" int sige_hip_plan_begin(void *plan, int section, int append) {
 extern "C" int sige_hip_plan_end(void *plan) {
     if (!plan || g_plan_rec != static_cast<Plan *>(plan)) return SIGE_HIP_EINVAL;
     g_plan_rec = nullptr;
+    static_cast<Plan *>(plan)->recording.store(false, std::memory_order_release);
     return SIGE_HIP_OK;
 }
 
@@ -95,6 +98,25 @@ extern "C" int sige_hip_plan_bind_ptr(void *plan, const void *ptr, int slot) {
     Plan *p = static_cast<Plan *>(plan);
     if (!p || !ptr || slot < 0 || slot >= (int)p->slots.size()) return SIGE_HIP_EINVAL;
     p->slot_of[ptr] = slot;
+    return SIGE_HIP_OK;
+}
+
+extern "C" int sige_hip_plan_bind_const(void *plan, const void *ptr) {
+    Plan *p = static_cast<Plan *>(plan);
+    if (!p || !ptr) return SIGE_HIP_EINVAL;
+    p->const_ptrs.insert(ptr);
+    return SIGE_HIP_OK;
+}
+
+extern "C" int sige_hip_plan_unbound(void *plan) {
+    Plan *p = static_cast<Plan *>(plan);
+    return p ? p->unbound : -1;
+}
+
+extern "C" int sige_hip_plan_truncate(void *plan, int section, int calls) {
+    Plan *p = static_cast<Plan *>(plan);
+    if (!p || section < 0 || section >= PLAN_SECTIONS || calls < 0 || calls > (int)p->calls[section].size()) return SIGE_HIP_EINVAL;
+    p->calls[section].resize((size_t)calls);
     return SIGE_HIP_OK;
 }
 
@@ -130,7 +152,10 @@ extern "C" int sige_hip_plan_run(void *plan, int section, void *stream) {
         const int rc = c->run(*p, st);
         // (SIGE_HIP_EUNSUPPORTED from a call that succeeded when it was recorded means the new counts left the shapes its
         //  kernels cover: the caller records again under the new mask)
-        if (rc != SIGE_HIP_OK) return rc;
+        if (rc != SIGE_HIP_OK) {
+            (void)sige_hip_conv_pair_end();  // (a replay that stops between pair_begin and pair_end must not leave a held conv behind)
+            return rc;
+        }
     }
     return SIGE_HIP_OK;
 }

@@ -15,10 +15,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <memory>
 #include <tuple>
 #include <type_traits>
 #include <unordered_map>
+#include <unordered_set>
 #include <utility>
 #include <vector>
 
@@ -41,9 +43,16 @@ struct Plan {
     int host_cap = 0;
     int device = -1;
     long runs[PLAN_SECTIONS] = {0, 0};
+    std::atomic<bool> recording{false};                  // between plan_begin and plan_end (on some thread)
     // a recorded call sizes its work from a count that has no index-list argument to look it up under (the NCHW / two-kernel
     // forms: tiles = B * N handed over as one number): such a plan only replays under the counts it was recorded with
     bool shape_bound = false;
+    // pointers of index lists whose count never changes with the mask (the all-tiles list of a dense layer): a count argument
+    // next to one of these keeps its recorded value by design
+    std::unordered_set<const void *> const_ptrs;
+    // count arguments recorded next to a pointer that is neither bound to a slot nor registered as constant (a copy of an index
+    // list made outside the recorded mask pipeline): such a count cannot follow a new mask, so the plan is marked shape_bound
+    int unbound = 0;
     ~Plan() {
         if (host_counts) (void)hipHostFree(host_counts);
     }
@@ -69,6 +78,16 @@ inline void plan_patch(const Plan &p, T &t) {
     std::get<P::np>(t) = p.lookup(static_cast<const void *>(std::get<P::ip>(t)), std::get<P::np>(t));
 }
 
+// at RECORD time: is the pointer a count argument hangs on known to the plan?  (a miss used to fall back to the
+// recorded count silently -- stale counts under every later mask.)  A null pointer is an absent operand (its count is 0).
+template <typename P, typename T>
+inline void plan_check_key(Plan &p, const T &t) {
+    const void *key = static_cast<const void *>(std::get<P::ip>(t));
+    if (!key || p.slot_of.count(key) || p.const_ptrs.count(key)) return;
+    ++p.unbound;
+    p.shape_bound = true;
+}
+
 // one recorded entry-point call: the function, its arguments by value, which of them are counts.  STREAM: the last argument
 // is the stream (replaced by the replay's).
 template <bool STREAM, typename Patches, typename... A>
@@ -90,7 +109,9 @@ template <bool STREAM, typename... Ps, typename... A, typename... B>
 inline void plan_record(int (*fn)(A...), B... b) {
     Plan *p = g_plan_rec;
     if (!p) return;
-    p->calls[g_plan_section].emplace_back(new TypedCall<STREAM, std::tuple<Ps...>, A...>(fn, static_cast<A>(b)...));
+    auto *call = new TypedCall<STREAM, std::tuple<Ps...>, A...>(fn, static_cast<A>(b)...);
+    (plan_check_key<Ps>(*p, call->args), ...);
+    p->calls[g_plan_section].emplace_back(call);
 }
 
 }  // namespace sige

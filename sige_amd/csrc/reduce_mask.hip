@@ -34,8 +34,9 @@ __global__ __launch_bounds__(kRMThreads) void reduce_mask_kernel(
             if (hp_shift) {
                 // stacked edits (sige_hip_set_edit_batch): the mask is E masks stacked along H; a candidate belongs to the image its
                 // window's third row lies in (the rule of the conv kernels' seam test) and only looks at THAT image's rows -- so the
-                // list is exactly the per-edit lists, one after the other (a window reaching into the neighbour's mask would
-                // activate a tile the single-edit forward leaves cached)
+                // list holds the per-edit lists, one after the other (a window reaching into the neighbour's mask would activate a
+                // tile the single-edit forward leaves cached).  The trailing candidate of an image (h0 = hp - pad) is assigned to
+                // the NEXT image: harmless, its output rows are out of that image's range)
                 const int lo = ((h0 + 2) >> hp_shift) << hp_shift;
                 ha = max(ha, lo);
                 hb = min(hb, lo + (1 << hp_shift));
@@ -87,6 +88,9 @@ extern "C" int sige_hip_reduce_mask_i32(const uint8_t *mask, int H, int W, int b
     const int gh = (H + padH) / strideH + 1, gw = (W + padW) / strideW + 1;
     const int hp_shift = stacked_shift(H);
     if (hp_shift < 0) return SIGE_HIP_EUNSUPPORTED;
+    // (the seam rule below places a window by its third row: with a padding above 2 the first candidate's third row is above
+    //  row 0 and would be assigned to "image -1"; the tile convs have padding <= 1)
+    if (hp_shift > 0 && padH > 2) return SIGE_HIP_EUNSUPPORTED;
     reduce_mask_kernel<<<1, kRMThreads, 0, as_stream(stream)>>>(mask, H, W, bH, bW, strideH, strideW, padH, padW,
                                                                gh, gw, indices, capacity, count, hp_shift);
     return launch_status();

@@ -38,6 +38,7 @@ _SIGNATURES = {
     "sige_hip_device_arch": (ctypes.c_char_p, []),
     "sige_hip_launch_count": (ctypes.c_int64, []),
     "sige_hip_last_launch_device": (_c_int, []),
+    "sige_hip_preload": (_c_int, []),
     "sige_hip_gather_f32": (_c_int, [_c_vp] + [_c_int] * 6 + [_c_vp, _c_int] + _BC + _BC + [_c_int, _c_int, _c_vp, _c_vp]),
     "sige_hip_scatter_f32": (_c_int, [_c_vp, _c_vp] + [_c_int] * 10 + [_c_vp, _c_int] + _BC + [_c_vp, _c_vp]),
     "sige_hip_scatter_with_block_residual_f32": (
@@ -71,13 +72,6 @@ _SIGNATURES = {
     "sige_hip_group_norm_affine_workspace": (_c_sz, [_c_int] * 5),
     "sige_hip_group_norm_affine_f32": (_c_int, [_c_vp] + [_c_int] * 5 + [ctypes.c_float] + [_c_vp] * 6),
     "sige_hip_block_conv_direct_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_vp]),
-    "sige_hip_block_conv_force_tile": (_c_int, [_c_int, _c_int]),
-    "sige_hip_block_conv_force_waves": (_c_int, [_c_int]),
-    "sige_hip_block_conv_large_grid_nb1": (_c_int, [_c_int]),
-    "sige_hip_block_conv_force_ksplit": (_c_int, [_c_int]),
-    "sige_hip_gather_force_rows": (_c_int, [_c_int]),
-    "sige_hip_scatter_gather_force_elements": (_c_int, [_c_int]),
-    "sige_hip_block_conv_force_ksplit_pass": (_c_int, [_c_int]),
     "sige_hip_conv_pair_begin": (_c_int, []),
     "sige_hip_conv_pair_end": (_c_int, []),
     "sige_hip_conv_pairs_fused": (ctypes.c_int64, []),
@@ -124,7 +118,6 @@ _SIGNATURES = {
     "sige_hip_group_norm_affine_nhwc_bias_f32": (_c_int, [_c_vp] + [_c_int] * 5 + [ctypes.c_float] + [_c_vp] * 7),
     "sige_hip_conv3x3_small_cout_nhwc_f32": (
         _c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp, _c_int, _c_vp, _c_vp]),
-    "sige_hip_conv3x3_small_cout_force_scalar": (_c_int, [_c_int]),
     "sige_hip_conv3x3_small_cin_nhwc_f32": (
         _c_int, [_c_vp] + [ctypes.c_int64] * 4 + [_c_int] * 4 + [_c_vp, _c_vp, _c_int, _c_vp, _c_vp]),
     "sige_hip_attention_nhwc_f32": (_c_int, [_c_vp, _c_int, _c_int, _c_int, ctypes.c_float, _c_vp, _c_vp, _c_vp]),
@@ -150,7 +143,6 @@ _SIGNATURES = {
     "sige_hip_wide_conv_packed_size": (_c_sz, [_c_int] * 5),
     "sige_hip_wide_conv_pack": (_c_int, [_c_vp] + [_c_int] * 6 + [_c_vp, _c_vp]),
     "sige_hip_wide_conv_workspace": (_c_sz, [_c_int] * 8),
-    "sige_hip_wide_conv_force_ksplit": (_c_int, [_c_int]),
     "sige_hip_wide_conv_nhwc": (
         _c_int, [_c_vp, _c_vp] + [_c_int] * 6 + [_c_vp, _c_vp, _c_int, _c_int] + [_c_vp, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_int]
         + [_c_vp, _c_vp, _c_vp, _c_int] + [_c_vp] * 6 + [_c_vp, _c_sz, _c_vp, _c_vp, _c_vp]),
@@ -160,7 +152,6 @@ _SIGNATURES = {
     "sige_hip_group_norm_affine_from_stats_f32": (
         _c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_float] + [_c_vp] * 6),
     "sige_hip_attention_tokens_supported": (_c_int, [_c_int] * 4),
-    "sige_hip_attention_tokens_force_form": (_c_int, [_c_int]),
     "sige_hip_attention_tokens_f32": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [ctypes.c_float, _c_vp, _c_vp]),
     # fp16-stored caches
     "sige_hip_gather_nhwc_f16": (
@@ -193,12 +184,25 @@ _SIGNATURES = {
     "sige_hip_plan_new_slots": (_c_int, [_c_vp, _c_int]),
     "sige_hip_plan_bind_ptr": (_c_int, [_c_vp, _c_vp, _c_int]),
     "sige_hip_plan_set_slot": (_c_int, [_c_vp, _c_int, _c_int]),
+    "sige_hip_plan_bind_const": (_c_int, [_c_vp, _c_vp]),
+    "sige_hip_plan_unbound": (_c_int, [_c_vp]),
+    "sige_hip_plan_truncate": (_c_int, [_c_vp, _c_int, _c_int]),
     "sige_hip_plan_get_slots": (_c_int, [_c_vp, _c_vp, _c_int]),
     "sige_hip_plan_record_readback": (_c_int, [_c_vp, _c_vp, _c_int, _c_int]),
     "sige_hip_plan_run": (_c_int, [_c_vp, _c_int, _c_vp]),
 }
 
-EXPORTS = tuple(_SIGNATURES)  # every symbol include/sige_hip.h declares
+EXPORTS = tuple(_SIGNATURES)  # every symbol include/sige_hip.h declares for the PRODUCT library
+
+# measurement builds only (-DSIGE_HIP_TUNING: lib/libsige_hip_tuning.so and the probe builds): the one pair of knob entry points
+_TUNING_SIGNATURES = {
+    "sige_hip_tuning_set": (_c_int, [_c_int, _c_int]),
+    "sige_hip_tuning_get": (_c_int, [_c_int]),
+}
+TUNING_LIB_PATH = os.path.join(_PKG, "lib", "libsige_hip_tuning.so")
+# include/sige_hip.h: SIGE_HIP_TUNE_*
+TUNE = {"conv_tile_mt": 0, "conv_tile_nb": 1, "conv_waves": 2, "conv_large_grid_nb1": 3, "conv_ksplit": 4, "conv_ksplit_second_pass": 5,
+        "gather_one_tile_rows": 6, "scatter_gather_form": 7, "small_cout_scalar": 8, "wide_ksplit": 9, "attention_form": 10, "conv_v3": 11}
 
 
 # how many guarded entry-point calls had to switch HIP's current device to the tensor's ("switched") and how many found it current
@@ -221,6 +225,9 @@ class _Guarded:
         self.fn = fn
 
     def __call__(self, *args):
+        rec = getattr(_plan_tls, "rec", None)
+        if rec is not None:
+            return self._recorded(rec, args)
         dev, _tls.pending_device = getattr(_tls, "pending_device", None), None
         if dev is not None and dev != (_raw_device() if _raw_device is not None else torch.cuda.current_device()):
             GUARD_STATS["switched"] += 1
@@ -228,6 +235,23 @@ class _Guarded:
                 return self.fn(*args)
         GUARD_STATS["direct"] += 1
         return self.fn(*args)
+
+    def _recorded(self, rec, args):
+        """While a launch plan records: the entry point's hook stores the call BEFORE the entry point validates it, so a call that
+        returns an error status (a probe the wrapper then routes elsewhere) is taken out of the plan again."""
+        L = lib()
+        n0 = L.sige_hip_plan_calls(rec.handle, rec.section)
+        dev, _tls.pending_device = getattr(_tls, "pending_device", None), None
+        if dev is not None and dev != (_raw_device() if _raw_device is not None else torch.cuda.current_device()):
+            GUARD_STATS["switched"] += 1
+            with torch.cuda.device(dev):
+                status = self.fn(*args)
+        else:
+            GUARD_STATS["direct"] += 1
+            status = self.fn(*args)
+        if status != 0 and n0 >= 0 and L.sige_hip_plan_calls(rec.handle, rec.section) > n0:
+            L.sige_hip_plan_truncate(rec.handle, rec.section, n0)
+        return status
 
 
 class _Lib:
@@ -239,24 +263,117 @@ class _Lib:
 _tls = threading.local()
 
 
+def _load(path):
+    if not os.path.isfile(path):
+        raise RuntimeError(
+            "sige_amd: %s not found -- the HIP extension is not built "
+            "(run `python -m sige_amd.build%s`); there is no CPU fallback." % (path, " --tuning" if "tuning" in os.path.basename(path) else ""))
+    handle = ctypes.CDLL(path)
+    table = _Lib()
+    sigs = dict(_SIGNATURES)
+    if hasattr(handle, "sige_hip_tuning_set"):
+        sigs.update(_TUNING_SIGNATURES)
+    for name, (res, args) in sigs.items():
+        fn = getattr(handle, name)
+        fn.restype, fn.argtypes = res, args
+        guarded = args and args[-1] is _c_vp and res is _c_int and (not name.startswith("sige_hip_plan_") or name == "sige_hip_plan_run")
+        setattr(table, name, _Guarded(fn) if guarded else fn)
+    table.handle = handle
+    table.path = path
+    table.has_tuning = hasattr(handle, "sige_hip_tuning_set")
+    table.preloaded = set()
+    table.preloaded_units = {}  # device -> code objects sige_hip_preload touched there
+    return table
+
+
+_libs = {}
+
+
 def lib():
     """Load libsige_hip.so (once).  Raises if it has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.isfile(LIB_PATH):
-            raise RuntimeError(
-                "sige_amd: %s not found -- the HIP extension is not built "
-                "(run `python -m sige_amd.build`); there is no CPU fallback." % LIB_PATH)
-        handle = ctypes.CDLL(LIB_PATH)
-        table = _Lib()
-        for name, (res, args) in _SIGNATURES.items():
-            fn = getattr(handle, name)
-            fn.restype, fn.argtypes = res, args
-            guarded = args and args[-1] is _c_vp and res is _c_int and (not name.startswith("sige_hip_plan_") or name == "sige_hip_plan_run")
-            setattr(table, name, _Guarded(fn) if guarded else fn)
-        table.handle = handle
-        _lib = table
+        _lib = _libs.setdefault(LIB_PATH, None) or _load(LIB_PATH)
+        _libs[LIB_PATH] = _lib
     return _lib
+
+
+def use_library(path: Optional[str] = None):
+    """Switch this process's bindings to another build of the library (None = the product build); returns the previous path.
+    Objects a library owns (launch plans, the held conv of a pair) must not cross the switch."""
+    global _lib
+    prev = _lib.path if _lib is not None else LIB_PATH
+    path = path or LIB_PATH
+    if _libs.get(path) is None:
+        _libs[path] = _load(path)
+    _lib = _libs[path]
+    return prev
+
+
+class tuning_build:
+    """`with hip.tuning_build():` -- run on lib/libsige_hip_tuning.so (the measurement build that exports sige_hip_tuning_set:
+    include/sige_hip.h); every knob is reset to its default on exit and the product library comes back."""
+
+    def __init__(self, path: Optional[str] = None):
+        self.path = path or os.environ.get("SIGE_HIP_TUNING_LIB", TUNING_LIB_PATH)
+
+    def __enter__(self):
+        self.prev = use_library(self.path)
+        return lib()
+
+    def __exit__(self, *exc):
+        try:
+            tuning_reset()
+        finally:
+            use_library(self.prev)
+        return False
+
+
+def tuning_set(key, value: int):
+    """sige_hip_tuning_set (measurement builds only): `key` a SIGE_HIP_TUNE_* number or its lower-case name in TUNE."""
+    L = lib()
+    if not L.has_tuning:
+        raise RuntimeError("sige_amd.hip: dispatch knobs exist only in the measurement build -- `with hip.tuning_build(): ...` "
+                           "(lib/libsige_hip_tuning.so, `python -m sige_amd.build --tuning`); the product library has none")
+    _check(L.sige_hip_tuning_set(TUNE[key] if isinstance(key, str) else int(key), int(value)), "tuning_set(%s, %s)" % (key, value))
+
+
+def tuning_get(key) -> int:
+    L = lib()
+    if not L.has_tuning:
+        raise RuntimeError("sige_amd.hip: dispatch knobs exist only in the measurement build (hip.tuning_build())")
+    return int(L.sige_hip_tuning_get(TUNE[key] if isinstance(key, str) else int(key)))
+
+
+_TUNE_DEFAULTS = {"conv_large_grid_nb1": -1, "conv_v3": -1}
+
+
+def tuning_reset():
+    if lib().has_tuning:
+        for k in TUNE:
+            tuning_set(k, _TUNE_DEFAULTS.get(k, 0))
+
+
+def preload(device: Optional[int] = None) -> int:
+    """sige_hip_preload on `device` (default: the current one): load every code object of the library now instead of on the
+    first launch that needs it.  Called by the first launch on a device (see _stream); returns the number touched."""
+    L = lib()
+    if device is None:
+        device = _raw_device() if _raw_device is not None else torch.cuda.current_device()
+    if device in L.preloaded:
+        return 0
+    L.preloaded.add(device)
+    if os.environ.get("SIGE_HIP_NO_PRELOAD"):
+        return 0
+    if torch.cuda.is_current_stream_capturing():
+        L.preloaded.discard(device)  # (loading is not capturable; the kernels of a capture were warmed up before it)
+        return 0
+    with torch.cuda.device(device):
+        n = int(L.sige_hip_preload())
+    if n < 0:
+        raise RuntimeError("sige_amd.hip: sige_hip_preload failed: %s" % L.sige_hip_error_string(n).decode())
+    L.preloaded_units[device] = n
+    return n
 
 
 def set_edit_batch(E: int):
@@ -302,6 +419,8 @@ def _stream(t: torch.Tensor) -> int:
     """Stream handle for a launch on `t`'s device (and note that device for the guard, see _Guarded)."""
     idx = t.device.index
     _tls.pending_device = idx
+    if _lib is not None and idx not in _lib.preloaded and idx is not None:
+        preload(idx)
     if _raw_stream is not None and idx is not None:
         return _raw_stream(idx)
     return torch.cuda.current_stream(t.device).cuda_stream
@@ -435,7 +554,10 @@ def get_scatter_map(H, W, bSizeH, bSizeW, kSizeH, kSizeW, offsetH, offsetW, stri
     _check(lib().sige_hip_scatter_map_i32(H, W, bSizeH, bSizeW, kSizeH, kSizeW, offsetH, offsetW, strideH, strideW,
                                           idx.data_ptr(), idx.shape[0], out.data_ptr(), _stream(idx)),
            "get_scatter_map")
-    _plan_keep(out)
+    rec = plan_recorder()
+    if rec is not None:  # (spade_modulate takes the tile count of a scatter MAP's list: looked up under the map's pointer)
+        rec.bind_alias(out, idx)
+        rec.keep.append(out)
     return out
 
 
@@ -732,7 +854,7 @@ def wide_conv_pack_weights(weight: torch.Tensor, compute: str) -> Optional[torch
 
 def wide_conv_force_ksplit(ksplit: int = 0):
     """Benchmark knob: pin the cross-workgroup K split of the dense-layer conv (0 = automatic)."""
-    _check(lib().sige_hip_wide_conv_force_ksplit(ksplit), "wide_conv_force_ksplit")
+    tuning_set("wide_ksplit", ksplit)
 
 
 def wide_conv_cl(x, x2, scale, shift, activationName: str, packed, bias, Cout: int, kernel: Tuple[int, int],
@@ -880,19 +1002,20 @@ def group_norm_affine_from_stats(parts, groups: int, eps: float, gamma=None, bet
 
 def conv_force_tile(mt: int = 0, nb: int = 0):
     """Benchmark knob: pin the MFMA conv's output block (0, 0 = automatic)."""
-    _check(lib().sige_hip_block_conv_force_tile(mt, nb), "conv_force_tile")
+    tuning_set("conv_tile_mt", mt)
+    tuning_set("conv_tile_nb", nb)
 
 
 def conv_large_grid_nb1(min_blocks: int = -1):
     """Plan policy: unsplit tile-conv launches that 32 x 64 output blocks would fill the chip with use 32 x 32 blocks (more
     workgroups per CU) from `min_blocks` such blocks on; -1 = the library's default (exact fp32: always), 0 = never
     (include/sige_hip.h: sige_hip_block_conv_large_grid_nb1)."""
-    _check(lib().sige_hip_block_conv_large_grid_nb1(int(min_blocks)), "conv_large_grid_nb1")
+    tuning_set("conv_large_grid_nb1", int(min_blocks))
 
 
 def conv_force_waves(waves: int = 0):
     """Benchmark knob: 4 or 8 waves per workgroup for the channels-last stride-1 convs (0 = automatic)."""
-    _check(lib().sige_hip_block_conv_force_waves(waves), "conv_force_waves")
+    tuning_set("conv_waves", waves)
 
 
 _pair_state = threading.local()  # .keep: operands of the launches of the open conv_pair() block; .depth: nesting
@@ -945,18 +1068,18 @@ def conv_pairs_fused() -> int:
 
 def conv_force_ksplit(ksplit: int = 0):
     """Benchmark knob: cross-workgroup K split of the channels-last launches with a workspace (0 = automatic)."""
-    _check(lib().sige_hip_block_conv_force_ksplit(ksplit), "conv_force_ksplit")
+    tuning_set("conv_ksplit", ksplit)
 
 
 def gather_force_rows(one_tile_rows: bool = False):
     """Benchmark knob: the NCHW gather's one-tile row form always (True) instead of the grouped form where it applies."""
-    _check(lib().sige_hip_gather_force_rows(int(bool(one_tile_rows))), "gather_force_rows")
+    tuning_set("gather_one_tile_rows", int(bool(one_tile_rows)))
 
 
 def scatter_gather_force_elements(element_form=False):
     """Benchmark / test knob: the NCHW scatter_gather's element form always (True / 1), or its one-tile row form (2: never the
     grouped form), instead of the automatic choice (False / 0)."""
-    _check(lib().sige_hip_scatter_gather_force_elements(int(element_form)), "scatter_gather_force_elements")
+    tuning_set("scatter_gather_form", int(element_form))
 
 
 def release_graph_tickets():
@@ -967,7 +1090,7 @@ def release_graph_tickets():
 
 def conv_force_ksplit_pass(second_pass: bool = False):
     """Benchmark knob: finish K-split launches with a second launch (True) instead of inside the launch (default)."""
-    _check(lib().sige_hip_block_conv_force_ksplit_pass(int(bool(second_pass))), "conv_force_ksplit_pass")
+    tuning_set("conv_ksplit_second_pass", int(bool(second_pass)))
 
 
 def _f32_packed(packed):
@@ -1062,6 +1185,9 @@ def all_tiles(H: int, W: int, out_tile: Tuple[int, int], stride: Tuple[int, int]
         ww = torch.arange(nw, dtype=torch.int32) * pw - offset[1]
         idx = torch.stack(torch.meshgrid(hh, ww, indexing="ij"), dim=-1).reshape(-1, 2).contiguous().to(device)
         _all_tiles_cache[key] = idx
+    rec = plan_recorder()
+    if rec is not None:  # (a count next to this list never changes with the mask: csrc/plan.hpp const_ptrs)
+        rec.bind_constant(idx)
     return idx
 
 
@@ -1667,7 +1793,7 @@ def conv3x3_small_cout_cl(x, weight, bias, scale=None, shift=None, activationNam
 
 def conv3x3_small_cout_force_scalar(on: bool):
     """Benchmarking / tests: route conv3x3_small_cout_cl through the scalar-weight kernel only."""
-    _check(lib().sige_hip_conv3x3_small_cout_force_scalar(int(bool(on))), "conv3x3_small_cout_force_scalar")
+    tuning_set("small_cout_scalar", int(bool(on)))
 
 
 def conv3x3_small_cin_cl(x, weight, bias):

@@ -89,7 +89,10 @@ class _OutputBuffers:
         if entry is None or entry[0] != key:
             if entry is not None and entry[0][1:] == key[1:] and entry[1].device == cached.device:
                 # only the MASK changed: restore the buffer in place -- same address, so a launch plan or a captured hipGraph
-                # that points at it stays valid, and nothing is allocated
+                # that points at it stays valid, and nothing is allocated.  CONSEQUENCE: a hipGraph captured under an
+                # EARLIER mask shares this buffer and does not contain the restore -- after set_masks() graphs of earlier masks
+                # are invalid (alternating replays of two masks' graphs would leave the other mask's tiles in the buffer):
+                # re-capture per mask (GraphPool / LaunchPlan.capture do), and clone() a model output that must outlive set_masks
                 buf = _fill(entry[1], cached, build)
             else:
                 # (persistent outputs and twins are fp32 whatever the cache is stored as: they hold this edit's RESULTS)

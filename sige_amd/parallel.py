@@ -16,7 +16,8 @@ the forward (halos come from the local cache).  So:
 
 `torch.distributed` backend "nccl" is RCCL on ROCm; "gloo" works for CPU tests.
 """
-from typing import List, Sequence, Tuple
+import time
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -350,6 +351,88 @@ def max_over_ranks(seconds: float, device=None, group=None) -> float:
     v = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(v, op=dist.ReduceOp.MAX, group=group)
     return float(v.item())
+
+
+WATCHDOG_S = 2.0  # a cache distribution slower than this loses to recomputing the cache (a DDPM-256 full pass is ~4 ms)
+
+
+def _all_ok(ok: bool, device=None, group=None) -> bool:
+    """True iff `ok` on EVERY rank (the ranks must take the same branch after a candidate failed somewhere)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return bool(ok)
+    v = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if device is not None else "cpu")
+    dist.all_reduce(v, op=dist.ReduceOp.MIN, group=group)
+    return bool(v.item())
+
+
+def choose_distribution(candidates: Dict[str, Callable[[], None]], recompute: Optional[Callable[[], None]] = None,
+                        watchdog_s: float = WATCHDOG_S, repeats: int = 2, device=None, group=None,
+                        sync: Optional[Callable[[], None]] = None, clock: Callable[[], float] = time.perf_counter) -> dict:
+    """How should the original image's cache reach every rank of THIS job on THIS node?  Decide by measuring, once, at start-up.
+
+    `candidates`: name -> callable that performs one complete distribution (collective + local refresh), tried in order;
+    `recompute`: callable with which every rank rebuilds the cache itself (no communication), or None.  Every candidate runs
+    once (communicator set-up included); if that run took longer than `watchdog_s` on the slowest rank, or raised on any
+    rank, the candidate is out -- it is not given a second chance to hang the job; otherwise it runs `repeats - 1` more times
+    and its figure is the best run, max over ranks.  The fastest survivor wins, `recompute` competing like any other; if no
+    candidate survives, `recompute` is the fallback (and if there is none, RuntimeError).  Every rank takes the same decision:
+    times are max-reduced and failures min-reduced across the group before they are compared.
+
+    Returns {"method_chosen", "methods_ms": {name: ms or None}, "errors": {name: text}, "fallback": reason or None,
+    "watchdog_s"}.  (RCCL has not run in this project's sessions -- whichever collective this build of it
+    handles badly, the scaling bench still finishes and says which one it used.)"""
+    if sync is None:
+        sync = (lambda: torch.cuda.synchronize()) if torch.cuda.is_available() else (lambda: None)
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+    def barrier():
+        if world > 1:
+            dist.barrier(group=group)
+
+    def one_run(fn):
+        barrier()
+        sync()
+        t0 = clock()
+        err = None
+        try:
+            fn()
+            sync()
+        except Exception as e:  # noqa: BLE001 -- a collective this RCCL build cannot run must not end the job
+            err = repr(e)[:200]
+        dt = clock() - t0
+        ok = _all_ok(err is None, device=device, group=group)
+        return (max_over_ranks(dt, device=device, group=group) if ok else None), err
+
+    methods_ms, errors = {}, {}
+    todo = list(candidates.items()) + ([("recompute", recompute)] if recompute is not None else [])
+    for name, fn in todo:
+        first, err = one_run(fn)
+        if first is None:
+            errors[name] = err or "failed on another rank"
+            methods_ms[name] = None
+            continue
+        if first > watchdog_s and name != "recompute":
+            errors[name] = "exceeded the %.1f s watchdog (%.2f s)" % (watchdog_s, first)
+            methods_ms[name] = round(first * 1e3, 3)
+            continue
+        best = first
+        for _ in range(max(0, repeats - 1)):
+            again, err = one_run(fn)
+            if again is None:
+                errors[name] = err or "failed on another rank"
+                best = None
+                break
+            best = min(best, again)
+        methods_ms[name] = None if best is None else round(best * 1e3, 3)
+    alive = {k: v for k, v in methods_ms.items() if v is not None and k not in errors}
+    fallback = None
+    if not alive:
+        raise RuntimeError("choose_distribution: no method worked: %r" % errors)
+    chosen = min(alive, key=lambda k: alive[k])
+    collectives_alive = [k for k in alive if k != "recompute"]
+    if chosen == "recompute" and candidates and not collectives_alive:
+        fallback = "every collective failed or exceeded the watchdog: " + "; ".join("%s: %s" % kv for kv in errors.items())
+    return {"method_chosen": chosen, "methods_ms": methods_ms, "errors": errors, "fallback": fallback, "watchdog_s": watchdog_s}
 
 
 def shard(units: Sequence, rank: int = None, world: int = None) -> List:

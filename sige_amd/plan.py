@@ -54,6 +54,12 @@ class _Recorder:
         hip._check(hip.lib().sige_hip_plan_set_slot(self.handle, slot, n), "plan_set_slot")
         self.idx_info[buf.data_ptr()] = (slot, buf.shape[0], buf)
 
+    def bind_constant(self, idx: torch.Tensor):
+        """`idx` is an index list whose tile count does not depend on the mask (hip.all_tiles: a dense layer)."""
+        if idx.numel():
+            hip._check(hip.lib().sige_hip_plan_bind_const(self.handle, idx.data_ptr()), "plan_bind_const")
+            self.keep.append(idx)
+
     def bind_alias(self, table: torch.Tensor, idx: torch.Tensor):
         info = self.idx_info.get(hip.base_ptr(idx))
         if info is not None:
@@ -158,6 +164,12 @@ class LaunchPlan:
         counts replay."""
         return bool(hip.lib().sige_hip_plan_shape_bound(self.handle))
 
+    @property
+    def unbound_counts(self) -> int:
+        """How many recorded count arguments hang on a pointer the plan knows nothing about (an index list that did not come from
+        the recorded mask pipeline and is not a registered constant).  Any such argument makes the plan shape bound."""
+        return int(hip.lib().sige_hip_plan_unbound(self.handle))
+
     def calls(self, section: int) -> int:
         return int(hip.lib().sige_hip_plan_calls(self.handle, section))
 
@@ -185,13 +197,21 @@ class LaunchPlan:
             raise RuntimeError("LaunchPlan.bind_mask before record")
         if mask.shape != self.mask.shape or mask.dtype != torch.bool:
             raise ValueError("bind_mask: a bool mask shaped like the recorded one")
-        self.graph = None  # (a graph of the previous mask's counts)
+        bound = self.shape_bound
+        prev = self.mask.clone() if bound else None
         self.mask.copy_(mask, non_blocking=True)
         self._run(MASKS)
         self._read_counts()
-        if self.shape_bound and self.counts != self._recorded_counts:
+        if bound and self.counts != self._recorded_counts:
+            # a shape-bound plan replays the recorded counts only: put the previous mask's lists, tables and persistent outputs
+            # back (the FORWARD section would otherwise run the recorded counts over the new mask's lists) and refuse
+            self.mask.copy_(prev, non_blocking=True)
+            self._run(MASKS)
+            self._read_counts()
             raise RuntimeError("LaunchPlan: this plan recorded calls whose sizes cannot follow a new mask (NCHW or unfused tile "
-                               "kernels); it only replays the recorded mask")
+                               "kernels, or %d count argument(s) on index lists the plan does not own); it only replays masks "
+                               "with the recorded tile counts -- the previous mask is still bound" % self.unbound_counts)
+        self.graph = None  # (a graph of the previous mask's counts)
         if adopt:
             self._adopt()
 

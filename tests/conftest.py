@@ -23,3 +23,14 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(pytest.mark.skip(reason="no GPU in this container"))
         if "reference" in item.keywords and not has_ref:
             item.add_marker(pytest.mark.skip(reason="/root/reference not mounted"))
+
+
+@pytest.fixture
+def tuning():
+    """Run the test on the measurement build (lib/libsige_hip_tuning.so), the only library with dispatch knobs
+    (include/sige_hip.h: sige_hip_tuning_set); knobs are reset and the product library restored afterwards."""
+    from sige_amd import build, hip
+
+    build.build_tuning(verbose=False)
+    with hip.tuning_build():
+        yield hip

@@ -92,7 +92,7 @@ def test_scatter_cl_full_and_in_place(hip, B, C, res):
 @pytest.mark.parametrize("cin,c2,cout,k,stride,blk,off", [(128, 0, 128, 3, 1, 6, 1), (64, 40, 200, 3, 1, 6, 1), (96, 0, 64, 1, 1, 4, 0),
                                                           (256, 44, 40, 1, 1, 4, 0), (64, 0, 72, 3, 2, 5, 0), (68, 0, 24, 3, 1, 6, 1),
                                                           (128, 64, 64, 3, 1, 6, 1), (512, 256, 48, 1, 1, 4, 0)])
-def test_conv_cl_vs_nchw(hip, waves, mt, nb, cin, c2, cout, k, stride, blk, off):
+def test_conv_cl_vs_nchw(hip, waves, mt, nb, cin, c2, cout, k, stride, blk, off, tuning):
     from sige_amd.utils import reduce_mask
 
     torch.manual_seed(cin + cout + mt + nb)
@@ -208,7 +208,7 @@ def test_ddpm_unet_channels_last_equals_nchw(inplace):
 
 @pytest.mark.parametrize("B,C,H,W,cout,act", [(1, 128, 256, 256, 3, "swish"), (2, 36, 19, 45, 4, "identity"), (1, 64, 8, 8, 1, "swish"),
                                               (2, 128, 37, 21, 3, "swish"), (1, 64, 33, 16, 2, "identity"), (3, 128, 16, 50, 1, "swish")])
-def test_conv3x3_small_cout_cl(hip, B, C, H, W, cout, act):
+def test_conv3x3_small_cout_cl(hip, B, C, H, W, cout, act, tuning):
     torch.manual_seed(C + H)
     x = torch.randn(B, C, H, W, device=DEV)
     w = torch.randn(cout, C, 3, 3, device=DEV) / (3 * C ** 0.5)

@@ -215,7 +215,7 @@ def test_fused_gather_conv_equals_two_kernels(hip, C, cout, res, ratio, B):
 @pytest.mark.parametrize("mt,nb", [(16, 1), (16, 2), (32, 1), (32, 2)])
 @pytest.mark.parametrize("cin,c2,cout,k,stride,blk,off", [(128, 0, 128, 3, 1, 6, 1), (64, 40, 200, 3, 1, 6, 1), (96, 0, 64, 1, 1, 4, 0),
                                                           (256, 44, 40, 1, 1, 4, 0), (64, 0, 72, 3, 2, 5, 0), (70, 0, 24, 3, 1, 6, 1)])
-def test_conv_every_output_block_shape(hip, mt, nb, cin, c2, cout, k, stride, blk, off):
+def test_conv_every_output_block_shape(hip, mt, nb, cin, c2, cout, k, stride, blk, off, tuning):
     """Every (pixels x channels) output block of the MFMA kernel, pinned with
     sige_hip_block_conv_force_tile, for the tile / gather / scatter_gather / NCHW
     forms: channel counts that are not multiples of the chunk, a fused torch.cat (per

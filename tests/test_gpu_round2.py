@@ -270,7 +270,7 @@ def _cl(t):
 @pytest.mark.parametrize("k,cin,cout,T,mt,nb", [(3, 128, 128, 124, 0, 0), (3, 256, 128, 40, 16, 1), (3, 64, 256, 7, 32, 1),
                                                  (3, 192, 64, 33, 16, 2), (3, 128, 128, 70, 32, 2), (1, 256, 128, 56, 0, 0),
                                                  (1, 128, 256, 9, 32, 1), (1, 384, 128, 30, 16, 2), (3, 36, 64, 5, 0, 0)])
-def test_f16_compute_block_conv_exact_products(hip, k, cin, cout, T, mt, nb):
+def test_f16_compute_block_conv_exact_products(hip, k, cin, cout, T, mt, nb, tuning):
     """The f16-compute tile conv equals an fp64 conv of the fp16-ROUNDED operands to fp32 summation accuracy (products
     of two fp16 values are exact in fp32), and the fp32 oracle within the stated f16 tolerance."""
     torch.manual_seed(T + cin)
@@ -516,7 +516,7 @@ def test_ddpm_forward_paired_vs_unpaired(hip):
 
 @pytest.mark.parametrize("res,c1,c2,cout,residual", [(8, 512, 512, 512, False), (8, 512, 0, 512, True), (16, 512, 512, 512, True),
                                                       (8, 512, 0, 256, True)])
-def test_ksplit_finished_inside_the_launch(hip, res, c1, c2, cout, residual):
+def test_ksplit_finished_inside_the_launch(hip, res, c1, c2, cout, residual, tuning):
     """Cross-workgroup K split: the last workgroup of an output block adds the partial copies up in split order and runs the
     epilogue -- bit-identical to the second-pass kernel, one launch instead of two; the tickets are back at zero afterwards
     and no workgroup reads a stale partial sum (two different inputs alternate over the same workspace memory, eagerly and
@@ -555,7 +555,7 @@ def test_ksplit_finished_inside_the_launch(hip, res, c1, c2, cout, residual):
 # ---- NCHW gather, grouped row form (8 consecutive tiles per workgroup) ----------------------------------------------
 @pytest.mark.parametrize("bsize,B,C,res,act,first", [(6, 1, 256, 128, "swish", False), (6, 2, 160, 96, "identity", False),
                                                       (4, 1, 256, 128, "identity", False), (5, 1, 264, 128, "swish", True)])
-def test_grouped_nchw_gather_bit_exact(hip, bsize, B, C, res, act, first):
+def test_grouped_nchw_gather_bit_exact(hip, bsize, B, C, res, act, first, tuning):
     """Enough tiles for the grouped form (merged cache-line requests for neighbouring tiles): bit-identical to the one-tile
     row form and to the oracle, including tiles over the image border, a ragged last group and a ragged channel chunk."""
     g = torch.Generator().manual_seed(bsize * 100 + C)

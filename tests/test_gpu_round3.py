@@ -110,7 +110,7 @@ def test_wide_conv_vs_fp64(hip, compute, k, c1, c2, cout, H, W, B, aff, act, res
         assert float(bad.double().mean()) < 1e-3
 
 
-def test_wide_conv_split_k_is_deterministic_and_equals_unsplit(hip):
+def test_wide_conv_split_k_is_deterministic_and_equals_unsplit(hip, tuning):
     """The in-launch K-split finish: same bits on every run (fixed summation order), fp32-close to the unsplit launch, and no
     stale partial sum when two inputs alternate over the same workspace memory -- eagerly and in graph replays."""
     g = torch.Generator().manual_seed(7)
@@ -440,7 +440,7 @@ def test_sd_unet_at_its_own_size_vs_cpu_oracle(hip):
 @pytest.mark.parametrize("k,cin,cout,T,mt", [(3, 128, 128, 124, 0), (3, 256, 128, 40, 16), (3, 64, 256, 7, 32), (3, 192, 64, 33, 16),
                                               (1, 256, 128, 56, 0), (1, 128, 256, 9, 32), (1, 384, 128, 30, 16), (3, 36, 64, 5, 0)])
 @pytest.mark.parametrize("wmag", [1.0, 1e-4])
-def test_f16x3_tile_conv_is_fp32_level(hip, k, cin, cout, T, mt, wmag):
+def test_f16x3_tile_conv_is_fp32_level(hip, k, cin, cout, T, mt, wmag, tuning):
     """The stacked-block conv on split fp16 operands against an fp64 conv of the EXACT operands: max |d| <= 2e-5 * (1 + max |ref|)
     -- also with weights of 1e-4 (the device-side power-of-two pre-scaling keeps their lo parts normal fp16 numbers)."""
     torch.manual_seed(T + cin)
@@ -544,7 +544,7 @@ def test_group_norm_affine_with_channel_bias(hip, shape, groups):
     # enough tiles for the grouped form (8 consecutive tiles x 32 channels per workgroup, halo pixels through LDS)
     (6, 3, 1, 200, 128, "swish", False, "channel"), (6, 3, 2, 96, 128, "identity", False, "none"),
     (6, 3, 1, 192, 128, "swish", True, "spatial"), (6, 3, 2, 128, 128, "swish", False, "batch")])
-def test_scatter_gather_row_form_bit_exact(hip, bsize, k, B, C, res, act, first, affine):
+def test_scatter_gather_row_form_bit_exact(hip, bsize, k, B, C, res, act, first, affine, tuning):
     """The row form of the reference-layout scatter_gather (sige/cuda/scatter_gather_kernel.cu:8-67) is bit-identical to the
     element form and equals the oracle: windows over the image border, holes in the tile grid (rows that mix conv-1 tiles and
     the cached tensor), tiles narrower than the vector part (5x5 windows over 3x3 tiles), ragged channel chunks, every affine

@@ -251,7 +251,7 @@ def test_f16_cache_fused_conv_bit_exact(hip, compute, T, cin, cout):
 
 
 # ---- hardening ----------------------------------------------------------------------------------------------
-def test_ksplit_finish_stress_two_streams(hip):
+def test_ksplit_finish_stress_two_streams(hip, tuning):
     """Both in-launch K-split finishes (tile kernel: conv_mfma.hpp, dense-layer kernel: conv_wide.hpp) publish their partial
     sums with relaxed agent-scope stores + s_waitcnt vmcnt(0) and take a relaxed ticket -- outside the letter of the HIP memory
     model.  10 000 launches on TWO streams at once, four different inputs alternating over the same workspaces and
@@ -587,7 +587,7 @@ def test_attention_one_launch_under_a_graph(hip, monkeypatch):
 @pytest.mark.parametrize("form", [1, 2])
 @pytest.mark.parametrize("B,Nq,Nk,heads,d", [(2, 1008, 4096, 8, 40), (2, 160, 1024, 8, 80), (2, 48, 256, 8, 160), (2, 1008, 77, 8, 40),
                                              (1, 16, 5, 1, 64), (3, 32, 16, 2, 8), (1, 64, 100, 4, 96), (1, 80, 33, 2, 20)])
-def test_attention_tokens_vs_fp64(hip, B, Nq, Nk, heads, d, form):
+def test_attention_tokens_vs_fp64(hip, B, Nq, Nk, heads, d, form, tuning):
     """sige_hip_attention_tokens_f32 (multi-head softmax(q k^T / sqrt d) v, heads as strides, online softmax over key blocks
     split across the waves) against the same expression in fp64 torch: SD's three head sizes at its own token counts (self-
     attention over 64^2 / 32^2 / 16^2 tokens with sparse queries, cross-attention over 77 text tokens), key counts that are
@@ -599,11 +599,11 @@ def test_attention_tokens_vs_fp64(hip, B, Nq, Nk, heads, d, form):
     scale = d ** -0.5
     # form 1 (the default): 16 queries per workgroup, key blocks split across the waves; form 2: 32 (two query tiles share every
     # K / V fragment; an odd tile count leaves the last workgroup half empty)
-    assert hip.lib().sige_hip_attention_tokens_force_form(form) == 0
+    hip.tuning_set("attention_form", form)
     try:
         got = hip.attention_tokens(q, k, v, heads, scale)
     finally:
-        hip.lib().sige_hip_attention_tokens_force_form(0)
+        hip.tuning_set("attention_form", 0)
     assert got is not None and tuple(got.shape) == (B, Nq, C)
 
     def heads_(t):

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "f16x3"])
     args = ap.parse_args()
     import bench
+    import os as _os; _os.environ.setdefault("SIGE_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "sige_amd", "lib", "libsige_hip_tuning.so"))  # noqa: E702 -- dispatch knobs exist only in the measurement build (python -m sige_amd.build --tuning)
     from sige_amd import hip, stacked
     from sige_amd.utils import dilate_mask, downsample_mask
     from sige_amd.workloads.ddpm_unet import DDPMConfig, DDPMSparseUNet

@@ -5,6 +5,7 @@ import sys
 import torch
 
 sys.path.insert(0, ".")
+import os as _os; _os.environ.setdefault("SIGE_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "..", "sige_amd", "lib", "libsige_hip_tuning.so"))  # noqa: E702 -- dispatch knobs exist only in the measurement build (python -m sige_amd.build --tuning)
 from sige_amd import hip  # noqa: E402
 from tests.test_gpu_round2 import _pair_case  # noqa: E402
 

@@ -12,6 +12,7 @@ sys.path.insert(0, REPO)
 
 def main():
     import bench
+    import os as _os; _os.environ.setdefault("SIGE_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "..", "sige_amd", "lib", "libsige_hip_tuning.so"))  # noqa: E702 -- dispatch knobs exist only in the measurement build (python -m sige_amd.build --tuning)
     from sige_amd import hip
     from sige_amd.utils import dilate_mask, downsample_mask
     from sige_amd.workloads.ddpm_unet import DDPMConfig, DDPMSparseUNet

@@ -18,6 +18,7 @@ warnings.simplefilter("ignore")
 import torch  # noqa: E402
 
 import bench  # noqa: E402
+import os as _os; _os.environ.setdefault("SIGE_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "sige_amd", "lib", "libsige_hip_tuning.so"))  # noqa: E702 -- dispatch knobs exist only in the measurement build (python -m sige_amd.build --tuning)
 from sige_amd.utils import dilate_mask, downsample_mask  # noqa: E402
 from sige_amd.workloads.ddpm_unet import DDPMConfig, DDPMSparseUNet  # noqa: E402
 

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     import bench
+    import os as _os; _os.environ.setdefault("SIGE_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "sige_amd", "lib", "libsige_hip_tuning.so"))  # noqa: E702 -- dispatch knobs exist only in the measurement build (python -m sige_amd.build --tuning)
     from sige_amd import hip
 
     hip.lib()

@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--ksplit-sweep", action="store_true")
     args = ap.parse_args()
+    import os as _os; _os.environ.setdefault("SIGE_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "sige_amd", "lib", "libsige_hip_tuning.so"))  # noqa: E702 -- dispatch knobs exist only in the measurement build (python -m sige_amd.build --tuning)
     from sige_amd import hip
     from sige_amd.nn import dense
     from sige_amd.nn.dense import fused_conv2d
