@@ -455,23 +455,14 @@ def main_sd(args, world, rank, dev):
         n_cached = len(parallel.cache_slots(model))
         method, dist_info = None, {}
         if world > 1:
-            for meth in (["broadcast", "scatter_allgather"] if args.distribute == "auto" else [args.distribute]):
-                try:
-                    ms = []
-                    for _ in range(2):
-                        dist.barrier()
-                        torch.cuda.synchronize()
-                        t0 = time.perf_counter()
-                        parallel.distribute_cache(flat, src=0, method=meth)
-                        torch.cuda.synchronize()
-                        ms.append((time.perf_counter() - t0) * 1e3)
-                    v = parallel.max_over_ranks(min(ms), device=dev)
-                    dist_info[meth + "_ms"] = round(v, 3)
-                    if method is None or v < dist_info[method + "_ms"]:
-                        method = meth
-                except Exception as e:
-                    dist_info[meth + "_error"] = repr(e)[:200]
-            parallel.refresh_derived(model)
+            names = ["broadcast", "scatter_allgather"] if args.distribute in ("auto", "recompute") else [args.distribute]
+            cands = {m_: (lambda m_=m_: parallel.distribute_cache(flat, src=0, method=m_, model=model)) for m_ in names}
+            choice = parallel.choose_distribution(cands, recompute=None, device=dev)  # (same selection + watchdog as the DDPM job)
+            method = choice["method_chosen"]
+            dist_info.update(method_chosen=method, methods_ms=choice["methods_ms"], watchdog_s=choice["watchdog_s"])
+            if choice["errors"]:
+                dist_info["errors"] = choice["errors"]
+            cands[method]()
             chk = flat.double().sum().reshape(1)
             lo, hi = chk.clone(), chk.clone()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
@@ -716,7 +707,7 @@ def main():
                     "exercise the multi-rank code path without N GPUs)")
     ap.add_argument("--oversubscribe", action="store_true", help="debugging: all ranks on GPU 0 (with --backend gloo): runs the "
                     "multi-rank code path on a one-GPU box; the numbers mean nothing")
-    ap.add_argument("--distribute", default="auto", choices=["auto", "broadcast", "scatter_allgather"],
+    ap.add_argument("--distribute", default="auto", choices=["auto", "broadcast", "scatter_allgather", "recompute"],
                     help="N > 1: collective that distributes the original image's cache")
     ap.add_argument("--no-pipeline", action="store_true", help="N > 1: one collective over the whole cache, then the local refresh "
                     "(default: chunks in module order, refresh of chunk k overlapped with the transfer of chunk k+1)")
@@ -822,15 +813,19 @@ def main():
         # ---- the alternative to distributing the cache: every rank recomputes it (the full pass on the library's kernels,
         #      split fp16 operands: fp32-level, deterministic -- the same bits on every rank; no communication) ----
         recompute_ms = None
+        gf, gf_caches = None, None
         if world > 1 and args.layout == "nhwc":
             try:
                 model.set_compute_dtype("f16x3")
                 model.set_mode("full")
                 gf, _ = capture(model, x0, t)
+                # the cache tensors this graph writes (static: they live in the graph's pool); the model is re-pointed at views of
+                # the packed buffer below, so a recompute = replay + one copy per cache tensor into those views
+                gf_caches = [parallel._get(s) for s in parallel.cache_slots(model)]
                 recompute_ms = round(parallel.max_over_ranks(timed_replays(gf, 5, 2, 1) * 1e3 / 5, device=dev), 3)
-                del gf
             except Exception as e:  # (never the reason a scaling run dies)
                 recompute_ms = repr(e)[:200]
+                gf, gf_caches = None, None
             model.set_compute_dtype(args.dtype)
 
         # ---- cache of the original image: rank 0 computes it, one collective distributes it ----
@@ -842,29 +837,28 @@ def main():
         dist_info = {}
         distribute = None
         wire = torch.float16 if args.wire_dtype == "f16" else None
+        recompute_cache = None
         if world > 1:
-            methods = ["broadcast", "scatter_allgather"] if args.distribute == "auto" else [args.distribute]
-            best = None
-            for meth in methods:
-                try:
-                    ms = []
-                    for _ in range(2):  # first = communicator set-up, second = steady state
-                        dist.barrier()
-                        torch.cuda.synchronize()
-                        t0 = time.perf_counter()
-                        parallel.distribute_cache(flat, src=0, method=meth, model=model if wire is not None else None, wire_dtype=wire)
-                        torch.cuda.synchronize()
-                        ms.append((time.perf_counter() - t0) * 1e3)
-                    v = parallel.max_over_ranks(min(ms), device=dev)
-                    dist_info[meth + "_ms"] = round(v, 3)
-                    if best is None or v < best[0]:
-                        best = (v, meth)
-                except Exception as e:  # a collective this RCCL build cannot run: keep the other
-                    dist_info[meth + "_error"] = repr(e)[:200]
-            if best is None:
-                raise SystemExit("no cache distribution method worked: %r" % dist_info)
-            distribute = best[1]
-            parallel.refresh_derived(model)
+            cache_views = [parallel._get(s) for s in parallel.cache_slots(model)]
+            if gf is not None and len(gf_caches) == len(cache_views) and all(a.shape == b.shape and a.dtype == b.dtype for a, b in zip(gf_caches, cache_views)):
+                def recompute_cache():
+                    """No communication: this rank's own full pass (library kernels, split fp16 operands: the same bits on every
+                    rank), copied into the packed cache the sparse graph reads, derived buffers refreshed."""
+                    gf.replay()
+                    torch._foreach_copy_(cache_views, gf_caches)
+                    parallel.refresh_derived(model)
+            # measured ONCE at start-up, the same decision on every rank: broadcast | scatter + all-gather | recompute; a
+            # collective that takes longer than parallel.WATCHDOG_S (or raises) on any rank is dropped (VERDICT r4 next #8)
+            names = ["broadcast", "scatter_allgather"] if args.distribute == "auto" else ([] if args.distribute == "recompute" else [args.distribute])
+            cands = {m_: (lambda m_=m_: parallel.distribute_cache(flat, src=0, method=m_, model=model, wire_dtype=wire)) for m_ in names}
+            choice = parallel.choose_distribution(cands, recompute=recompute_cache if args.distribute in ("auto", "recompute") else None, device=dev)
+            distribute = choice["method_chosen"]
+            dist_info.update(method_chosen=distribute, methods_ms=choice["methods_ms"], fallback=choice["fallback"], watchdog_s=choice["watchdog_s"])
+            if choice["errors"]:
+                dist_info["errors"] = choice["errors"]
+            # one more run of the winner, so that what the ranks hold now is what the timed job will hand them: rank 0's cache (a
+            # collective) or each rank's own recomputation (deterministic: the checksum comparison below covers it)
+            (recompute_cache if distribute == "recompute" else cands[distribute])()
             # every rank now holds rank 0's cache: compare checksums
             chk = torch.tensor([parallel.checksum(flat)], dtype=torch.int64, device=dev)
             lo, hi = chk.clone(), chk.clone()
@@ -906,7 +900,9 @@ def main():
             if with_distribution:
                 # chunks in module order, issued asynchronously; what a rank derives from the cache is refreshed chunk by
                 # chunk while later chunks still move (in place: the captured graph's buffers keep their addresses)
-                if args.no_pipeline:
+                if distribute == "recompute":
+                    recompute_cache()
+                elif args.no_pipeline:
                     parallel.distribute_cache(flat, src=0, method=distribute, model=model, wire_dtype=wire)
                 else:
                     parallel.distribute_cache_pipelined(flat, model, src=0, method=distribute, n_chunks=args.chunks, wire_dtype=wire)

@@ -50,7 +50,9 @@ enum {
 
 /* activation ids: the two names the reference's native code knows
  * (sige/common.cpp:4,11-23). */
-enum { SIGE_HIP_ACT_IDENTITY = 0, SIGE_HIP_ACT_SWISH = 1 };
+enum { SIGE_HIP_ACT_IDENTITY = 0, SIGE_HIP_ACT_SWISH = 1,
+       /* library extensions, accepted only by the entry points that say so (the GauGAN helpers below): */
+       SIGE_HIP_ACT_RELU = 2, SIGE_HIP_ACT_LEAKY = 3 /* leaky ReLU with the call's `slope` */, SIGE_HIP_ACT_TANH = 4 };
 
 /* ---- thread-safety ("re-entrant, no global state") ---------------------------------------------------------
  * Every compute entry point (gather / scatter / scatter_gather / scatter_map / reduce_mask / mask pipeline / block_conv /
@@ -476,6 +478,31 @@ int sige_hip_conv3x3_small_cout_nhwc_f32(const float *x, int B, int C, int H, in
                                          const float *shift, int shiftB, int shiftC, int activation,
                                          const float *weight, const float *bias, int Cout,
                                          float *out, void *stream);
+
+/* ... with an activation in front (SIGE_HIP_ACT_IDENTITY | _SWISH | _LEAKY with `slope`) and one behind (_IDENTITY | _TANH): GauGAN's
+ * tanh(conv_img(leaky_relu(x, 0.2))) (gaugan/models/spade_generators/sige_fused_spade_generator.py:259-260) in one launch. */
+int sige_hip_conv3x3_small_cout_act_nhwc_f32(const float *x, int B, int C, int H, int W, int activation, float slope,
+                                             const float *weight, const float *bias, int Cout, int out_activation,
+                                             float *out, void *stream);
+
+/* ---- channels-last helpers of the GauGAN SPADE generator's sparse forward (csrc/spade_ops.hip): what was left to torch kernels
+ * in round 4, so that the whole forward goes through this library and a launch plan can record it.
+ * resize_nearest: F.interpolate(mode="nearest") by an INTEGER factor up or down, x [B,H,W,C] -> out [B,Ho,Wo,C]
+ *   (sige_fused_spade_generator.py:143-146 the label map per block, :243-257 the x2 up-sampling between blocks).
+ * act_split: out[part] = act(x[..., part*C/parts : (part+1)*C/parts]) as `parts` dense [pixels, C/parts] tensors one after
+ *   the other (ReLU + torch.split of a block's label features); act in IDENTITY | RELU | LEAKY.
+ * scatter_gather_split: scatter_gather (sige/cpu/scatter_gather.cpp:5-56; no affine) + the same act + split in one pass;
+ *   out = `parts` dense [B*N,bH,bW,C/parts] tile slabs.
+ * spade_modulate_dense: out = leaky?((scale*x + shift) * (1 + gamma) + beta) on a FULL tensor, gb [B,H,W,2C] = gamma | beta,
+ *   scale / shift [affineB in {1, B}, C] (sige_normalization.py:74-88 for the blocks below num_sparse_layers). */
+int sige_hip_resize_nearest_nhwc_f32(const float *x, int B, int C, int H, int W, int Ho, int Wo, float *out, void *stream);
+int sige_hip_act_split_nhwc_f32(const float *x, int64_t pixels, int C, int parts, int activation, float slope, float *out,
+                                void *stream);
+int sige_hip_scatter_gather_split_nhwc_f32(const float *x, const float *y, int B, int C, int H, int W, int Rx, int Sx, int bH,
+                                           int bW, const int32_t *active_indices, int N, const int32_t *scatter_map,
+                                           int activation, float slope, int parts, float *out, void *stream);
+int sige_hip_spade_modulate_dense_nhwc_f32(const float *x, const float *scale, const float *shift, int affineB, const float *gb,
+                                           int B, int C, int H, int W, int leaky, float slope, float *out, void *stream);
 
 /* ---- 3x3 / padding-1 conv with <= 3 input channels and Cout = 32 / 64 / 128 over a full image
  * (the U-Net's conv_in, sige_fused_unet.py:395: a plain nn.Conv2d in every mode):

@@ -27,7 +27,7 @@ extern "C" int sige_hip_tuning_set(int key, int value) {
         case SIGE_HIP_TUNE_GATHER_ONE_TILE_ROWS: ok = value == 0 || value == 1; break;
         case SIGE_HIP_TUNE_SCATTER_GATHER_FORM: ok = value >= 0 && value <= 3; break;
         case SIGE_HIP_TUNE_SMALL_COUT_SCALAR: ok = value == 0 || value == 1; break;
-        case SIGE_HIP_TUNE_WIDE_KSPLIT: ok = value >= 0 && value <= 8; break;
+        case SIGE_HIP_TUNE_WIDE_KSPLIT: ok = value >= 0 && value <= 16; break;  // (conv_wide.hpp: kWideMaxSplit)
         case SIGE_HIP_TUNE_ATTENTION_FORM: ok = value >= 0 && value <= 2; break;
         case SIGE_HIP_TUNE_CONV_V3: ok = value >= -1 && value <= 1; break;
         default: return SIGE_HIP_EINVAL;

@@ -26,7 +26,7 @@ template <int COUT, int ACT>
 __global__ __launch_bounds__(256) void conv_out_nhwc_kernel(const float *__restrict__ x, int B, int C, int H, int W,
                                                            const float *__restrict__ scale, const float *__restrict__ shift, int aff_sb,
                                                            const float *__restrict__ w,  // [COUT, C, 3, 3]
-                                                           const float *__restrict__ bias, float *__restrict__ out) {
+                                                           const float *__restrict__ bias, float *__restrict__ out, float slope, int out_act) {
     __shared__ __attribute__((aligned(16))) float tile[kPH * kPW * kLDC];
     const int tid = threadIdx.x;
     const int tx = tid % kTW, ty = tid / kTW;
@@ -70,6 +70,10 @@ __global__ __launch_bounds__(256) void conv_out_nhwc_kernel(const float *__restr
                 if (ACT == SIGE_HIP_ACT_SWISH) {  // v_exp_f32 / v_rcp_f32 form (<= 1e-6 relative), as in the fused conv staging
                     v.x = silu_fast(v.x); v.y = silu_fast(v.y); v.z = silu_fast(v.z); v.w = silu_fast(v.w);
                 }
+                if (ACT == SIGE_HIP_ACT_LEAKY) {
+                    v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+                    v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+                }
             }
             *reinterpret_cast<float4 *>(tile + p * kLDC + c4) = v;
         }
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256) void conv_out_nhwc_kernel(const float *__restr
     if (h < H && ww < W) {
         float *o = out + (((size_t)b * H + h) * W + ww) * COUT;
 #pragma unroll
-        for (int co = 0; co < COUT; ++co) o[co] = acc[co];
+        for (int co = 0; co < COUT; ++co) o[co] = out_act == SIGE_HIP_ACT_TANH ? tanhf(acc[co]) : acc[co];
     }
 }
 
@@ -123,7 +127,7 @@ template <int CIN, int COUT, int ACT>
 __global__ __launch_bounds__(256) void conv_out_gemm_kernel(const float *__restrict__ x, int B, int H, int W,
                                                            const float *__restrict__ scale, const float *__restrict__ shift, int aff_sb,
                                                            const float *__restrict__ w,  // [COUT, CIN, 3, 3]
-                                                           const float *__restrict__ bias, float *__restrict__ out) {
+                                                           const float *__restrict__ bias, float *__restrict__ out, float slope, int out_act) {
     constexpr int KS = CIN / 2;  // MFMA steps (K = 2 each: one channel of either half)
     constexpr int NV = KS / 4;   // 16-byte loads per lane and block
     constexpr int NP = 9 * COUT;
@@ -171,6 +175,10 @@ __global__ __launch_bounds__(256) void conv_out_gemm_kernel(const float *__restr
             v.x = s4.x * v.x; v.y = s4.y * v.y; v.z = s4.z * v.z; v.w = s4.w * v.w;
             v.x = t4.x + v.x; v.y = t4.y + v.y; v.z = t4.z + v.z; v.w = t4.w + v.w;
             if (ACT == SIGE_HIP_ACT_SWISH) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); v.z = silu_fast(v.z); v.w = silu_fast(v.w); }
+            if (ACT == SIGE_HIP_ACT_LEAKY) {
+                v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+                v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+            }
             a[4 * i] = v.x; a[4 * i + 1] = v.y; a[4 * i + 2] = v.z; a[4 * i + 3] = v.w;
         }
         if (blk + 4 < kGBlocks) {  // (wave-uniform) next block's pixel while this one is in the matrix pipe
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(256) void conv_out_gemm_kernel(const float *__restr
         }
         float *op = out + (((size_t)b * H + h) * W + ww) * COUT;
 #pragma unroll
-        for (int co = 0; co < COUT; ++co) op[co] = o[co];
+        for (int co = 0; co < COUT; ++co) op[co] = out_act == SIGE_HIP_ACT_TANH ? tanhf(o[co]) : o[co];
     }
 }
 
@@ -215,15 +223,15 @@ __global__ __launch_bounds__(256) void conv_out_gemm_kernel(const float *__restr
 using namespace sige;
 
 
-extern "C" int sige_hip_conv3x3_small_cout_nhwc_f32(const float *x, int B, int C, int H, int W,
-                                                    const float *scale, int scaleB, int scaleC,
-                                                    const float *shift, int shiftB, int shiftC, int activation,
-                                                    const float *weight, const float *bias, int Cout,
-                                                    float *out, void *stream) {
-    SIGE_PLAN_HOOK(sige_hip_conv3x3_small_cout_nhwc_f32, x, B, C, H, W, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, weight, bias, Cout, out, stream);
+static int conv3x3_small_cout_impl(const float *x, int B, int C, int H, int W,
+                                   const float *scale, int scaleB, int scaleC,
+                                   const float *shift, int shiftB, int shiftC, int activation, float slope,
+                                   const float *weight, const float *bias, int Cout, int out_act,
+                                   float *out, void *stream) {
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || Cout <= 0) return SIGE_HIP_EINVAL;
     if (!x || !weight || !out) return SIGE_HIP_EINVAL;
-    if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
+    if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH && activation != SIGE_HIP_ACT_LEAKY) return SIGE_HIP_EUNSUPPORTED;
+    if (out_act != SIGE_HIP_ACT_IDENTITY && out_act != SIGE_HIP_ACT_TANH) return SIGE_HIP_EUNSUPPORTED;
     if (Cout > 4 || C % 4 || (reinterpret_cast<uintptr_t>(x) & 15)) return SIGE_HIP_EUNSUPPORTED;
     if ((scale == nullptr) != (shift == nullptr)) return SIGE_HIP_EUNSUPPORTED;
     int aff_sb = 0;
@@ -240,9 +248,11 @@ extern "C" int sige_hip_conv3x3_small_cout_nhwc_f32(const float *x, int B, int C
         if (tiles > 0x7fffffffL) return SIGE_HIP_EUNSUPPORTED;
 #define SIGE_CG(CI, N)                                                                                                 \
     if (activation == SIGE_HIP_ACT_SWISH)                                                                             \
-        conv_out_gemm_kernel<CI, N, SIGE_HIP_ACT_SWISH><<<(int)tiles, 256, 0, st>>>(x, B, H, W, scale, shift, aff_sb, weight, bias, out); \
+        conv_out_gemm_kernel<CI, N, SIGE_HIP_ACT_SWISH><<<(int)tiles, 256, 0, st>>>(x, B, H, W, scale, shift, aff_sb, weight, bias, out, slope, out_act); \
+    else if (activation == SIGE_HIP_ACT_LEAKY)                                                                        \
+        conv_out_gemm_kernel<CI, N, SIGE_HIP_ACT_LEAKY><<<(int)tiles, 256, 0, st>>>(x, B, H, W, scale, shift, aff_sb, weight, bias, out, slope, out_act); \
     else                                                                                                              \
-        conv_out_gemm_kernel<CI, N, SIGE_HIP_ACT_IDENTITY><<<(int)tiles, 256, 0, st>>>(x, B, H, W, scale, shift, aff_sb, weight, bias, out);
+        conv_out_gemm_kernel<CI, N, SIGE_HIP_ACT_IDENTITY><<<(int)tiles, 256, 0, st>>>(x, B, H, W, scale, shift, aff_sb, weight, bias, out, slope, out_act);
         if (C == 128) { if (Cout == 1) { SIGE_CG(128, 1) } else if (Cout == 2) { SIGE_CG(128, 2) } else { SIGE_CG(128, 3) } }
         else { if (Cout == 1) { SIGE_CG(64, 1) } else if (Cout == 2) { SIGE_CG(64, 2) } else { SIGE_CG(64, 3) } }
 #undef SIGE_CG
@@ -250,9 +260,11 @@ extern "C" int sige_hip_conv3x3_small_cout_nhwc_f32(const float *x, int B, int C
     }
 #define SIGE_CO(N)                                                                                                    \
     if (activation == SIGE_HIP_ACT_SWISH)                                                                             \
-        conv_out_nhwc_kernel<N, SIGE_HIP_ACT_SWISH><<<(int)blocks, 256, 0, st>>>(x, B, C, H, W, scale, shift, aff_sb, weight, bias, out); \
+        conv_out_nhwc_kernel<N, SIGE_HIP_ACT_SWISH><<<(int)blocks, 256, 0, st>>>(x, B, C, H, W, scale, shift, aff_sb, weight, bias, out, slope, out_act); \
+    else if (activation == SIGE_HIP_ACT_LEAKY)                                                                        \
+        conv_out_nhwc_kernel<N, SIGE_HIP_ACT_LEAKY><<<(int)blocks, 256, 0, st>>>(x, B, C, H, W, scale, shift, aff_sb, weight, bias, out, slope, out_act); \
     else                                                                                                              \
-        conv_out_nhwc_kernel<N, SIGE_HIP_ACT_IDENTITY><<<(int)blocks, 256, 0, st>>>(x, B, C, H, W, scale, shift, aff_sb, weight, bias, out);
+        conv_out_nhwc_kernel<N, SIGE_HIP_ACT_IDENTITY><<<(int)blocks, 256, 0, st>>>(x, B, C, H, W, scale, shift, aff_sb, weight, bias, out, slope, out_act);
     switch (Cout) {
         case 1: SIGE_CO(1) break;
         case 2: SIGE_CO(2) break;
@@ -261,4 +273,24 @@ extern "C" int sige_hip_conv3x3_small_cout_nhwc_f32(const float *x, int B, int C
     }
 #undef SIGE_CO
     return launch_status();
+}
+
+extern "C" int sige_hip_conv3x3_small_cout_nhwc_f32(const float *x, int B, int C, int H, int W,
+                                                    const float *scale, int scaleB, int scaleC,
+                                                    const float *shift, int shiftB, int shiftC, int activation,
+                                                    const float *weight, const float *bias, int Cout,
+                                                    float *out, void *stream) {
+    SIGE_PLAN_HOOK(sige_hip_conv3x3_small_cout_nhwc_f32, x, B, C, H, W, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, weight, bias, Cout, out, stream);
+    if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
+    return conv3x3_small_cout_impl(x, B, C, H, W, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, 0.f, weight, bias, Cout,
+                                   SIGE_HIP_ACT_IDENTITY, out, stream);
+}
+
+// ... with a leaky-ReLU in front and a tanh behind: GauGAN's `tanh(conv_img(leaky_relu(x, 0.2)))` (sige_fused_spade_generator.py:259-260)
+extern "C" int sige_hip_conv3x3_small_cout_act_nhwc_f32(const float *x, int B, int C, int H, int W, int activation, float slope,
+                                                        const float *weight, const float *bias, int Cout, int out_activation,
+                                                        float *out, void *stream) {
+    SIGE_PLAN_HOOK(sige_hip_conv3x3_small_cout_act_nhwc_f32, x, B, C, H, W, activation, slope, weight, bias, Cout, out_activation, out, stream);
+    return conv3x3_small_cout_impl(x, B, C, H, W, nullptr, 0, 0, nullptr, 0, 0, activation, slope, weight, bias, Cout, out_activation, out,
+                                   stream);
 }

@@ -245,3 +245,77 @@ def test_cache_distribution_of_an_fp16_stored_cache(tmp_path, kind):
                 assert torch.equal(res[i % world]["outs"][i], _sparse(net, m, x))
     finally:
         runtime.unregister_backend("cpu")
+
+
+# ---- which distribution does a job use?  measured once at start-up, the same decision on every rank --------
+def _choose_worker(rank, world, port, out_dir):
+    import time
+
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sige_amd import parallel
+
+    buf = torch.full((1024,), float(rank))
+    log = []
+
+    def broadcast():
+        log.append("broadcast")
+        dist.broadcast(buf, src=0)
+
+    def slow_on_one_rank():  # a collective that crawls on ONE rank: the max over ranks is what the watchdog sees
+        log.append("slow")
+        if rank == world - 1:
+            time.sleep(0.6)
+        dist.broadcast(buf, src=0)
+
+    def broken_on_one_rank():  # a method one rank cannot run (the others can): every rank must drop it
+        log.append("broken")
+        if rank == 1:
+            raise RuntimeError("unsupported here")
+
+    def recompute():
+        log.append("recompute")
+        time.sleep(0.05)
+        buf.fill_(0.0)
+
+    res = {}
+    # 1: a healthy collective beats a slower recompute; the slow and the broken ones are dropped after ONE run
+    res["healthy"] = parallel.choose_distribution({"slow": slow_on_one_rank, "broken": broken_on_one_rank, "broadcast": broadcast},
+                                                  recompute=recompute, watchdog_s=0.3, sync=lambda: None)
+    res["healthy_log"] = list(log)
+    del log[:]
+    # 2: every collective fails or trips the watchdog: fall back to recompute, and say why
+    res["fallback"] = parallel.choose_distribution({"slow": slow_on_one_rank, "broken": broken_on_one_rank},
+                                                   recompute=recompute, watchdog_s=0.3, sync=lambda: None)
+    # 3: recompute wins on merit (no fallback reason) when it is simply faster
+    res["merit"] = parallel.choose_distribution({"slow": slow_on_one_rank}, recompute=recompute, watchdog_s=5.0, sync=lambda: None)
+    # 4: nothing works and there is no recompute: every rank raises
+    try:
+        parallel.choose_distribution({"broken": broken_on_one_rank}, recompute=None, watchdog_s=0.3, sync=lambda: None)
+        res["nothing"] = "no error"
+    except RuntimeError as e:
+        res["nothing"] = str(e)
+    torch.save(res, os.path.join(out_dir, "choose%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_choose_distribution_eight_ranks(tmp_path):
+    world = 8
+    mp.spawn(_choose_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(tmp_path / ("choose%d.pt" % r)) for r in range(world)]
+    for key in ("healthy", "fallback", "merit"):
+        assert len({r[key]["method_chosen"] for r in res}) == 1, key          # one decision
+        assert all(r[key]["methods_ms"] == res[0][key]["methods_ms"] for r in res)  # from the same (max-over-ranks) numbers
+    h = res[0]["healthy"]
+    assert h["method_chosen"] == "broadcast" and h["fallback"] is None
+    assert "watchdog" in h["errors"]["slow"] and h["methods_ms"]["slow"] >= 600 and h["methods_ms"]["broken"] is None
+    assert h["methods_ms"]["broadcast"] < h["methods_ms"]["recompute"]
+    # dropped candidates ran once, survivors `repeats` times -- on every rank, also the rank that could have run `broken`
+    for r in res:
+        assert r["healthy_log"] == ["slow", "broken", "broadcast", "broadcast", "recompute", "recompute"]
+    f = res[0]["fallback"]
+    assert f["method_chosen"] == "recompute" and "watchdog" in f["fallback"] and "broken" in f["fallback"]
+    m = res[0]["merit"]
+    assert m["method_chosen"] == "recompute" and m["fallback"] is None and m["methods_ms"]["slow"] >= 600
+    assert all("no method worked" in r["nothing"] for r in res)

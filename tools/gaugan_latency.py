@@ -35,7 +35,11 @@ def labels(dy=0, dx=0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
+    ap.add_argument("--gc", default="default", choices=["default", "freeze", "off"],
+                    help="Python's cyclic collector during the edits: default | freeze (gc.collect(); gc.freeze() after the full pass: "
+                         "what exists then is never traversed again) | off (gc.disable())")
     a = ap.parse_args()
+    import gc
     from sige_amd import hip
     from sige_amd.utils import compute_difference_mask, dilate_mask, downsample_mask
     from sige_amd.workloads.gaugan_spade import SPADEConfig, SpadeGenerator
@@ -62,11 +66,18 @@ def main():
         sync()
         t_full = time.perf_counter() - t0
         edits = ((20, 40), (-40, -60), (60, 120), (0, -100), (35, 10))
+        if a.gc == "freeze":
+            gc.collect()
+            gc.freeze()
+        elif a.gc == "off":
+            gc.collect()
+            gc.disable()
         for rnd in range(2):
             for dy, dx in edits:
                 xi = cl(labels(dy, dx)[1])
                 sync()
                 n0 = hip.launch_count()
+                g0 = [g_["collections"] for g_ in gc.get_stats()]
                 ts = [time.perf_counter()]
                 d = compute_difference_mask(x0, xi)
                 sync(); ts.append(time.perf_counter())
@@ -83,8 +94,9 @@ def main():
                 rows.append({"pass": rnd, "edit": [dy, dx], "difference_mask": ms[0], "mask_pyramid": ms[1], "set_masks": ms[2],
                              "first_forward": ms[3], "second_forward": ms[4], "to_first_output": round(sum(ms[:4]), 3),
                              "library_launches": hip.launch_count() - n0,
+                             "gc_collections_gen0_1_2": [g_["collections"] - b for g_, b in zip(gc.get_stats(), g0)],
                              "reserved_MB": round(torch.cuda.memory_reserved() / 2 ** 20, 1)})
-    res = {"preload": not os.environ.get("SIGE_HIP_NO_PRELOAD"), "preload_units": n_units, "preload_ms": round(t_pre * 1e3, 1),
+    res = {"gc": a.gc, "gc_objects": len(gc.get_objects()), "preload": not os.environ.get("SIGE_HIP_NO_PRELOAD"), "preload_units": n_units, "preload_ms": round(t_pre * 1e3, 1),
            "context_ms": round(t_ctx * 1e3, 1), "full_forward_first_ms": round(t_full * 1e3, 1), "rows": rows}
     text = json.dumps(res, indent=1)
     print(text)
