@@ -110,8 +110,9 @@ def compact(full):
         for k in ("fused_spade_modulation", "module_chain", "library_forward"):
             if isinstance(g.get(k), dict) and "forward_ms" in g[k]:
                 o[k + "_ms"] = g[k]["forward_ms"]
-        if isinstance(g.get("per_edit_latency_ms"), dict):
-            o["per_edit_latency_ms"] = {k: v for k, v in g["per_edit_latency_ms"].items() if not isinstance(v, str)}
+        for key in ("per_edit_latency_ms", "per_edit_latency_plan_ms"):
+            if isinstance(g.get(key), dict):
+                o[key] = {k: v for k, v in g[key].items() if isinstance(v, (int, float)) and not isinstance(v, bool) and k != "record_once_ms"}
         if "error" in g:
             o["error"] = _short(g["error"], 120)
         line["gaugan"] = o

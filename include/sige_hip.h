@@ -490,17 +490,19 @@ int sige_hip_conv3x3_small_cout_act_nhwc_f32(const float *x, int B, int C, int H
  * resize_nearest: F.interpolate(mode="nearest") by an INTEGER factor up or down, x [B,H,W,C] -> out [B,Ho,Wo,C]
  *   (sige_fused_spade_generator.py:143-146 the label map per block, :243-257 the x2 up-sampling between blocks).
  * act_split: out[part] = act(x[..., part*C/parts : (part+1)*C/parts]) as `parts` dense [pixels, C/parts] tensors one after
- *   the other (ReLU + torch.split of a block's label features); act in IDENTITY | RELU | LEAKY.
+ *   the other, `part_stride` floats apart (>= pixels * C/parts: a launch plan sizes it for every candidate tile, so the parts'
+ *   addresses do not move with the mask) -- ReLU + torch.split of a block's label features; act in IDENTITY | RELU | LEAKY.
  * scatter_gather_split: scatter_gather (sige/cpu/scatter_gather.cpp:5-56; no affine) + the same act + split in one pass;
  *   out = `parts` dense [B*N,bH,bW,C/parts] tile slabs.
  * spade_modulate_dense: out = leaky?((scale*x + shift) * (1 + gamma) + beta) on a FULL tensor, gb [B,H,W,2C] = gamma | beta,
  *   scale / shift [affineB in {1, B}, C] (sige_normalization.py:74-88 for the blocks below num_sparse_layers). */
 int sige_hip_resize_nearest_nhwc_f32(const float *x, int B, int C, int H, int W, int Ho, int Wo, float *out, void *stream);
-int sige_hip_act_split_nhwc_f32(const float *x, int64_t pixels, int C, int parts, int activation, float slope, float *out,
-                                void *stream);
+int sige_hip_act_split_nhwc_f32(const float *x, int64_t pixels, int C, int parts, int64_t part_stride, int activation, float slope,
+                                float *out, void *stream);
 int sige_hip_scatter_gather_split_nhwc_f32(const float *x, const float *y, int B, int C, int H, int W, int Rx, int Sx, int bH,
                                            int bW, const int32_t *active_indices, int N, const int32_t *scatter_map,
-                                           int activation, float slope, int parts, float *out, void *stream);
+                                           int activation, float slope, int parts, int64_t part_stride, float *out,
+                                           void *stream);
 int sige_hip_spade_modulate_dense_nhwc_f32(const float *x, const float *scale, const float *shift, int affineB, const float *gb,
                                            int B, int C, int H, int W, int leaky, float slope, float *out, void *stream);
 

@@ -53,13 +53,13 @@ __global__ __launch_bounds__(kT) void resize_nearest_nhwc_kernel(const float *__
 }
 
 // x [P, C] -> out [parts][P, C / parts]
-__global__ __launch_bounds__(kT) void act_split_nhwc_kernel(const float *__restrict__ x, long P, int C4, int Cp4, int act, float slope,
+__global__ __launch_bounds__(kT) void act_split_nhwc_kernel(const float *__restrict__ x, long part_stride, int C4, int Cp4, int act, float slope,
                                                            float *__restrict__ out, long units) {
     for (long u = (long)blockIdx.x * kT + threadIdx.x; u < units; u += (long)gridDim.x * kT) {
         const int c = (int)(u % C4);
         const long p = u / C4;
         const int part = c / Cp4;
-        st4(out + (((long)part * P + p) * Cp4 + (c - part * Cp4)) * 4, act4(ld4(x + u * 4), act, slope));
+        st4(out + (long)part * part_stride + (p * Cp4 + (c - part * Cp4)) * 4, act4(ld4(x + u * 4), act, slope));
     }
 }
 
@@ -68,9 +68,8 @@ __global__ __launch_bounds__(kT) void scatter_gather_split_nhwc_kernel(const flo
                                                                       int B, int C, int H, int W, int Rx, int Sx, int bH, int bW,
                                                                       const int32_t *__restrict__ idx, int N,
                                                                       const int32_t *__restrict__ map, int act, float slope, int Cp4,
-                                                                      float *__restrict__ out, long units) {
+                                                                      long part_stride, float *__restrict__ out, long units) {
     const int C4 = C / 4, RS = bH * bW;
-    const long P = (long)B * N * RS;
     for (long u = (long)blockIdx.x * kT + threadIdx.x; u < units; u += (long)gridDim.x * kT) {
         const int c4 = (int)(u % C4);
         const long tp = u / C4;
@@ -87,7 +86,7 @@ __global__ __launch_bounds__(kT) void scatter_gather_split_nhwc_kernel(const flo
             z = act4(v, act, slope);
         }
         const int part = c4 / Cp4;
-        st4(out + (((long)part * P + tp) * Cp4 + (c4 - part * Cp4)) * 4, z);
+        st4(out + (long)part * part_stride + (tp * Cp4 + (c4 - part * Cp4)) * 4, z);
     }
 }
 
@@ -133,32 +132,35 @@ extern "C" int sige_hip_resize_nearest_nhwc_f32(const float *x, int B, int C, in
     return launch_status();
 }
 
-extern "C" int sige_hip_act_split_nhwc_f32(const float *x, int64_t pixels, int C, int parts, int activation, float slope, float *out,
-                                           void *stream) {
-    SIGE_PLAN_HOOK(sige_hip_act_split_nhwc_f32, x, pixels, C, parts, activation, slope, out, stream);
+extern "C" int sige_hip_act_split_nhwc_f32(const float *x, int64_t pixels, int C, int parts, int64_t part_stride, int activation,
+                                           float slope, float *out, void *stream) {
+    SIGE_PLAN_HOOK(sige_hip_act_split_nhwc_f32, x, pixels, C, parts, part_stride, activation, slope, out, stream);
     if (pixels < 0 || C <= 0 || parts <= 0) return SIGE_HIP_EINVAL;
+    if (part_stride < pixels * (C / parts) || part_stride % 4) return SIGE_HIP_EINVAL;
     if (!act_ok(activation)) return SIGE_HIP_EUNSUPPORTED;
     if (pixels == 0) return SIGE_HIP_OK;
     if (!x || !out) return SIGE_HIP_EINVAL;
     if (C % (4 * parts) || !al16(x) || !al16(out)) return SIGE_HIP_EUNSUPPORTED;
     const long units = (long)pixels * (C / 4);
-    act_split_nhwc_kernel<<<grid_of(units), kT, 0, as_stream(stream)>>>(x, (long)pixels, C / 4, C / 4 / parts, activation, slope, out, units);
+    act_split_nhwc_kernel<<<grid_of(units), kT, 0, as_stream(stream)>>>(x, (long)part_stride, C / 4, C / 4 / parts, activation, slope, out, units);
     return launch_status();
 }
 
 extern "C" int sige_hip_scatter_gather_split_nhwc_f32(const float *x, const float *y, int B, int C, int H, int W, int Rx, int Sx, int bH,
                                                       int bW, const int32_t *active_indices, int N, const int32_t *scatter_map,
-                                                      int activation, float slope, int parts, float *out, void *stream) {
-    SIGE_PLAN_HOOK_N(sige_hip_scatter_gather_split_nhwc_f32, (sige::CountOf<10, 11>), x, y, B, C, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, activation, slope, parts, out, stream);
+                                                      int activation, float slope, int parts, int64_t part_stride, float *out,
+                                                      void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_scatter_gather_split_nhwc_f32, (sige::CountOf<10, 11>), x, y, B, C, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, activation, slope, parts, part_stride, out, stream);
     if (B < 0 || C <= 0 || H <= 0 || W <= 0 || Rx <= 0 || Sx <= 0 || bH <= 0 || bW <= 0 || N < 0 || parts <= 0) return SIGE_HIP_EINVAL;
     if (!act_ok(activation)) return SIGE_HIP_EUNSUPPORTED;
     if (stacked_shift(H) != 0) return SIGE_HIP_EUNSUPPORTED;
     if ((long)B * N == 0) return SIGE_HIP_OK;
     if (!x || !y || !out || !active_indices || !scatter_map) return SIGE_HIP_EINVAL;
     if (C % (4 * parts) || !al16(x) || !al16(y) || !al16(out)) return SIGE_HIP_EUNSUPPORTED;
+    if (part_stride < (int64_t)B * N * bH * bW * (C / parts) || part_stride % 4) return SIGE_HIP_EINVAL;  // (a part holds every tile of THIS mask)
     const long units = (long)B * N * bH * bW * (C / 4);
     scatter_gather_split_nhwc_kernel<<<grid_of(units), kT, 0, as_stream(stream)>>>(x, y, B, C, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map,
-                                                                                  activation, slope, C / 4 / parts, out, units);
+                                                                                  activation, slope, C / 4 / parts, (long)part_stride, out, units);
     return launch_status();
 }
 

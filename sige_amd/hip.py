@@ -26,6 +26,8 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SIGE_HIP_LIB", os.path.join(_PKG, "lib", "libsige_hip.so"))
 
 ACT = {"identity": 0, "swish": 1}
+# library extensions (include/sige_hip.h), accepted by the GauGAN helpers only
+ACT_EXT = {"identity": 0, "relu": 2, "leaky": 3, "tanh": 4}
 
 _c_int, _c_vp, _c_sz = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
 _lib = None
@@ -171,6 +173,12 @@ _SIGNATURES = {
     "sige_hip_scatter_gather_conv_scatter_nhwc_c16": (
         _c_int, [_c_int, _c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
         + [_c_int] * 3 + [_c_int, _c_int, _c_vp, _c_int] + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp] * 6 + [_c_vp, _c_vp]),
+    "sige_hip_conv3x3_small_cout_act_nhwc_f32": (_c_int, [_c_vp] + [_c_int] * 5 + [ctypes.c_float, _c_vp, _c_vp, _c_int, _c_int, _c_vp, _c_vp]),
+    "sige_hip_resize_nearest_nhwc_f32": (_c_int, [_c_vp] + [_c_int] * 6 + [_c_vp, _c_vp]),
+    "sige_hip_act_split_nhwc_f32": (_c_int, [_c_vp, ctypes.c_int64, _c_int, _c_int, ctypes.c_int64, _c_int, ctypes.c_float, _c_vp, _c_vp]),
+    "sige_hip_scatter_gather_split_nhwc_f32": (
+        _c_int, [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp, _c_int, ctypes.c_float, _c_int, ctypes.c_int64, _c_vp, _c_vp]),
+    "sige_hip_spade_modulate_dense_nhwc_f32": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_vp] + [_c_int] * 5 + [ctypes.c_float, _c_vp, _c_vp]),
     "sige_hip_set_edit_batch": (_c_int, [_c_int]),
     "sige_hip_get_edit_batch": (_c_int, []),
     # launch plans (csrc/plan.hip; host side: sige_amd/plan.py)
@@ -1614,6 +1622,84 @@ def spade_modulate_cl(x_full, x_tiles, map_x, scale, shift, gb_tiles, gb_full, m
         gb_tiles.data_ptr(), gb_full.data_ptr(), map_g.data_ptr(), gb_tiles.shape[0] // B, gb_tiles.shape[2], gb_tiles.shape[3],
         B, C, H, W, block[0], block[1], idx.data_ptr(), N, int(slope is not None), float(slope or 0.0), out.data_ptr(),
         _stream(x_full)), "spade_modulate_cl")
+    return out
+
+
+# ---- GauGAN helpers (csrc/spade_ops.hip): the sparse forward of the SPADE generator without a torch kernel ----------------------
+def resize_nearest_cl(x, size: Tuple[int, int]):
+    """F.interpolate(x, size=size, mode="nearest") for an integer factor up or down, channels-last; None if unsupported."""
+    x = _req_cl(x, "x")
+    B, C, H, W = x.shape
+    out = _empty_cl((B, C, int(size[0]), int(size[1])), x.device)
+    status = lib().sige_hip_resize_nearest_nhwc_f32(x.data_ptr(), B, C, H, W, int(size[0]), int(size[1]), out.data_ptr(), _stream(x))
+    if status == UNSUPPORTED:
+        return None
+    _check(status, "resize_nearest_cl")
+    return out
+
+
+def act_split_cl(x, parts: int, activationName: str = "relu", slope: float = 0.0):
+    """tuple(act(x[:, k*C/parts:(k+1)*C/parts]) for k in range(parts)), each a dense channels-last tensor, in one pass."""
+    x = _req_cl(x, "x")
+    B, C, H, W = x.shape
+    Cp = C // parts
+    out = torch.empty((parts, B, H, W, Cp), dtype=torch.float32, device=x.device)
+    _check(lib().sige_hip_act_split_nhwc_f32(x.data_ptr(), B * H * W, C, parts, B * H * W * Cp, ACT_EXT[activationName], float(slope),
+                                             out.data_ptr(), _stream(x)), "act_split_cl")
+    return tuple(out[k].permute(0, 3, 1, 2) for k in range(parts))
+
+
+def scatter_gather_split_cl(x, y, bSizeH, bSizeW, activeIndices, scatterMap, parts: int, activationName: str = "relu", slope: float = 0.0):
+    """scatter_gather_cl (no affine) + activation + a split into `parts` channel groups in one pass: a tuple of `parts` dense
+    channels-last tile slabs [B*N, C/parts, bH, bW].  While a launch plan records, every part is backed by memory for every
+    candidate tile, so the parts keep their addresses under later masks."""
+    x, y = _req_cl(x, "x"), _req_cl(y, "y")
+    idx = _req(activeIndices, torch.int32, "activeIndices", 2)
+    smap = _req(scatterMap, torch.int32, "scatterMap", 3)
+    B, C, H, W = y.shape
+    N = idx.shape[0]
+    Cp = C // parts
+    cap = _tile_capacity(idx)
+    cap = N if cap is None else max(cap, N)
+    out = torch.empty((parts, B * cap, bSizeH, bSizeW, Cp), dtype=torch.float32, device=y.device)
+    _check(lib().sige_hip_scatter_gather_split_nhwc_f32(
+        x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3], bSizeH, bSizeW, idx.data_ptr(), N, smap.data_ptr(),
+        ACT_EXT[activationName], float(slope), parts, B * cap * bSizeH * bSizeW * Cp, out.data_ptr(), _stream(y)), "scatter_gather_split_cl")
+    return tuple(out[k, :B * N].permute(0, 3, 1, 2) for k in range(parts))
+
+
+def spade_modulate_dense_cl(x, scale, shift, gb, slope: Optional[float] = None):
+    """leaky((scale * x + shift) * (1 + gamma) + beta) on a full channels-last tensor; gb [B,2C,H,W] = gamma | beta."""
+    x, gb = _req_cl(x, "x"), _req_cl(gb, "gb")
+    B, C, H, W = x.shape
+    if tuple(gb.shape) != (B, 2 * C, H, W):
+        raise RuntimeError("spade_modulate_dense_cl: gamma|beta must be [B, 2C, H, W]")
+    (sa, s_keep), (ta, t_keep) = _cvec(scale, "scale"), _cvec(shift, "shift")
+    if s_keep is None or t_keep is None or sa[1] != ta[1] or sa[2] != C or ta[2] != C:
+        raise RuntimeError("spade_modulate_dense_cl: scale and shift [1|B, C, 1, 1]")
+    out = _empty_cl((B, C, H, W), x.device)
+    _check(lib().sige_hip_spade_modulate_dense_nhwc_f32(x.data_ptr(), sa[0], ta[0], sa[1], gb.data_ptr(), B, C, H, W,
+                                                        int(slope is not None), float(slope or 0.0), out.data_ptr(), _stream(x)),
+           "spade_modulate_dense_cl")
+    return out
+
+
+def conv3x3_small_cout_act_cl(x, weight, bias, activationName: str = "identity", slope: float = 0.0, outActivationName: str = "identity"):
+    """out_act(conv(act(x))) for a 3x3 / padding-1 conv with <= 4 output channels on a full channels-last tensor (GauGAN's
+    tanh(conv_img(leaky_relu(x)))); None if unsupported."""
+    x = _req_cl(x, "x")
+    B, C, H, W = x.shape
+    w = _req(weight.detach(), torch.float32, "weight")
+    Cout = w.shape[0]
+    if tuple(w.shape[1:]) != (C, 3, 3):
+        return None
+    bias_keep = _vec(bias, "bias")
+    out = _empty_cl((B, Cout, H, W), x.device)
+    status = lib().sige_hip_conv3x3_small_cout_act_nhwc_f32(x.data_ptr(), B, C, H, W, ACT_EXT[activationName], float(slope), w.data_ptr(),
+                                                            _p(bias_keep), Cout, ACT_EXT[outActivationName], out.data_ptr(), _stream(x))
+    if status == UNSUPPORTED:
+        return None
+    _check(status, "conv3x3_small_cout_act_cl")
     return out
 
 

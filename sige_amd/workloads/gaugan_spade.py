@@ -50,15 +50,31 @@ def _cl_gpu(t: torch.Tensor) -> bool:
     return hip.is_cl(t)
 
 
-def _dense_conv(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
-    """A dense (non-tiled) conv of a sparse-mode forward: on channels-last GPU tensors one launch of the MFMA tile kernel with
-    every tile active (sige_amd.nn.dense.fused_conv2d), else the plain conv -- the blocks below `num_sparse_layers` are
-    recomputed densely in sparse mode exactly as in the reference (sige_fused_spade_generator.py:133-173)."""
+def _dense_conv(conv: nn.Conv2d, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """A dense (non-tiled) conv of a sparse-mode forward (+ residual): on channels-last GPU tensors one launch of the MFMA tile
+    kernel with every tile active (sige_amd.nn.dense.fused_conv2d), else the plain conv -- the blocks below `num_sparse_layers`
+    are recomputed densely in sparse mode exactly as in the reference (sige_fused_spade_generator.py:133-173)."""
     from ..nn.dense import fusable, fused_conv2d
 
     if _cl_gpu(x) and fusable(conv) and conv.out_channels % 4 == 0:
-        return fused_conv2d(conv, x)
-    return conv(x)
+        return fused_conv2d(conv, x, residual=residual)
+    out = conv(x)
+    return out if residual is None else residual + out
+
+
+def _resize(x: torch.Tensor, size) -> torch.Tensor:
+    """F.interpolate(x, size=size, mode="nearest"); on channels-last GPU tensors one library launch (csrc/spade_ops.hip), so that
+    a launch plan sees it."""
+    size = (int(size[0]), int(size[1]))
+    if tuple(x.shape[2:]) == size:
+        return x  # (nearest resize to the same size is the identity: skip the copy)
+    if _cl_gpu(x):
+        from .. import hip
+
+        out = hip.resize_nearest_cl(x, size)
+        if out is not None:
+            return out
+    return F.interpolate(x, size=size, mode="nearest")
 
 
 class SpadeNorm(SIGEModule):
@@ -107,7 +123,21 @@ class SpadeNorm(SIGEModule):
         gamma, beta = torch.split(self._retile(gb), self.channels, dim=1)
         return n * (1 + gamma) + beta
 
-    # -- fused sparse form ----------------------------------------------------------
+    # -- fused sparse forms ---------------------------------------------------------
+    def modulated_dense(self, x: torch.Tensor, actv: torch.Tensor, slope: Optional[float]) -> Optional[torch.Tensor]:
+        """A NON-tiled layer in sparse mode on channels-last GPU tensors: leaky((scale * x + shift) * (1 + gamma) + beta) in one
+        pass over the full tensor, the param-free norm as its cached affine (what the tiled layers do); None if it does not
+        apply.  Replaces BatchNorm + split + three elementwise kernels + leaky ReLU of the module chain."""
+        if self.tiled or self.mode != "sparse" or self.scale is None or not (_cl_gpu(x) and _cl_gpu(actv)):
+            return None
+        from .. import hip
+
+        gb = _dense_conv(self.mlp_gamma_beta, actv)
+        if not _cl_gpu(gb):
+            return None
+        sc, sh = self.affine4()
+        return hip.spade_modulate_dense_cl(x, sc.contiguous(), sh.contiguous(), gb, slope)
+
     def modulated_tiles(self, source, actv_tiles: torch.Tensor, slope: Optional[float]) -> Optional[torch.Tensor]:
         """leaky(norm(x) * (1 + gamma) + beta) on this layer's tiles in one pass, or None if the fused kernel does not apply.
         source = ("gather", gather_module, x_full) | ("scatter_gather", sg_module, conv_tiles)."""
@@ -190,8 +220,12 @@ class SpadeResBlock(SIGEModule):
 
     def _label_features(self, seg, res):
         """ReLU(conv3x3(label map at this resolution)), split into one part per SPADE layer of the block."""
-        if tuple(seg.shape[2:]) != tuple(res):  # (nearest resize to the same size is the identity: skip the copy)
-            seg = F.interpolate(seg, size=res, mode="nearest")
+        seg = _resize(seg, res)
+        fused = self.cfg.fused and self.mode == "sparse" and _cl_gpu(seg)
+        if fused:
+            parts = self._label_features_fused(seg)
+            if parts is not None:
+                return parts
         if self.tiled:
             seg = self.seg_gather(seg)
         if not self.tiled and self.mode == "sparse":
@@ -205,6 +239,29 @@ class SpadeResBlock(SIGEModule):
             # channel slices of channels-last tiles are strided: give every consumer conv its own dense channels-last slab
             parts = tuple(p.contiguous(memory_format=torch.channels_last) for p in parts)
         return parts
+
+    def _label_features_fused(self, seg):
+        """The label branch of a sparse forward without a torch kernel: conv (tiles or dense), then ONE pass that re-tiles
+        (ScatterGather), applies the ReLU and writes one dense slab per SPADE layer of the block (csrc/spade_ops.hip) -- in place
+        of ReLU, ScatterGather, torch.split and one copy per part."""
+        from .. import hip
+
+        n_parts = 3 if self.learned_shortcut else 2
+        if not self.tiled:
+            a = _dense_conv(self.mlp_shared[0], seg)
+            return hip.act_split_cl(a, n_parts, "relu") if _cl_gpu(a) else None
+        sg = self.seg_scatter_gather
+        if sg.sparse_update or sg.mode != "sparse":
+            return None
+        cached = sg.original_outputs[sg.cache_id]
+        if not (_cl_gpu(cached) and cached.shape[1] % (4 * n_parts) == 0):
+            return None
+        t = deferred.resolve(self.mlp_shared[0](self.seg_gather(seg)))
+        if not hip.is_cl(t):
+            t = t.contiguous(memory_format=torch.channels_last)
+        g = sg.gather.module
+        return hip.scatter_gather_split_cl(t, cached, g.block_size[0], g.block_size[1], g.indices_on(t.device), sg._map_on(t.device),
+                                           n_parts, "relu")
 
     def forward(self, x, seg):
         if self.mode == "full":
@@ -234,6 +291,8 @@ class SpadeResBlock(SIGEModule):
         # shortcut branch
         if self.learned_shortcut:
             t = self.norm_s.modulated_tiles(("gather", self.shortcut_gather, x), a[2], None) if (fused and self.tiled_shortcut) else None
+            if t is None and self.cfg.fused and not self.tiled and self.mode == "sparse":
+                t = self.norm_s.modulated_dense(x, a[2], None)
             if t is None:
                 xs = self.shortcut_gather(x, *self.norm_s.affine4()) if self.tiled_shortcut else self.norm_s.param_free_norm(x)
                 t = self.norm_s(xs, a[2])
@@ -241,17 +300,21 @@ class SpadeResBlock(SIGEModule):
         else:
             xs = x
         # main branch
-        t = self.norm_0.modulated_tiles(("gather", self.main_gather, x), a[0], slope) if fused else None
+        dense_fused = self.cfg.fused and not self.tiled and self.mode == "sparse"
+        t = self.norm_0.modulated_tiles(("gather", self.main_gather, x), a[0], slope) if fused else (
+            self.norm_0.modulated_dense(x, a[0], slope) if dense_fused else None)
         if t is None:
             dx = self.main_gather(x, *self.norm_0.affine4()) if self.tiled else self.norm_0.param_free_norm(x)
             t = self._lrelu(self.norm_0(dx, a[0]))
         dx = self.conv_0(t) if self.tiled else _dense_conv(self.conv_0, t)
-        t = self.norm_1.modulated_tiles(("scatter_gather", self.main_scatter_gather, dx), a[1], slope) if fused else None
+        t = self.norm_1.modulated_tiles(("scatter_gather", self.main_scatter_gather, dx), a[1], slope) if fused else (
+            self.norm_1.modulated_dense(dx, a[1], slope) if dense_fused else None)
         if t is None:
             dx = self.main_scatter_gather(dx, *self.norm_1.affine4()) if self.tiled else self.norm_1.param_free_norm(dx)
             t = self._lrelu(self.norm_1(dx, a[1]))
-        dx = self.conv_1(t) if self.tiled else _dense_conv(self.conv_1, t)
-        return self.scatter(dx, xs) if self.tiled else xs + dx
+        if self.tiled:
+            return self.scatter(self.conv_1(t), xs)
+        return _dense_conv(self.conv_1, t, residual=xs)  # (xs + dx inside the conv's epilogue)
 
 
 class SpadeGenerator(SIGEModel):
@@ -279,13 +342,27 @@ class SpadeGenerator(SIGEModel):
             final = nf // 2
         self.conv_img = nn.Conv2d(final, 3, 3, padding=1)
 
-    @staticmethod
-    def _up(x):
+    def _up(self, x):
+        if self.cfg.fused and self.mode == "sparse" and _cl_gpu(x):
+            return _resize(x, (2 * x.shape[2], 2 * x.shape[3]))
         return F.interpolate(x, scale_factor=2.0, mode="nearest")
+
+    def _tail(self, x):
+        cfg = self.cfg
+        if cfg.fused and self.mode == "sparse" and _cl_gpu(x):
+            from .. import hip
+
+            out = hip.conv3x3_small_cout_act_cl(x, self.conv_img.weight, self.conv_img.bias, "leaky", cfg.leaky_slope, "tanh")
+            if out is not None:
+                return out
+        return torch.tanh(self.conv_img(F.leaky_relu(x, cfg.leaky_slope)))
 
     def forward(self, seg: torch.Tensor) -> torch.Tensor:
         cfg = self.cfg
-        x = self.fc(F.interpolate(seg, size=(self.sh, self.sw)))
+        if cfg.fused and self.mode == "sparse" and _cl_gpu(seg):
+            x = _dense_conv(self.fc, _resize(seg, (self.sh, self.sw)))
+        else:
+            x = self.fc(F.interpolate(seg, size=(self.sh, self.sw)))
         x = self._up(self.head_0(x, seg))
         x = self.G_middle_0(x, seg)
         if cfg.num_upsampling_layers in ("more", "most"):
@@ -297,4 +374,4 @@ class SpadeGenerator(SIGEModel):
         x = self.up_3(x, seg)
         if cfg.num_upsampling_layers == "most":
             x = self.up_4(self._up(x), seg)
-        return torch.tanh(self.conv_img(F.leaky_relu(x, cfg.leaky_slope)))
+        return self._tail(x)

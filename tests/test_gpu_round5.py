@@ -119,3 +119,142 @@ def test_preload_touches_every_translation_unit(hip):
     # ... and the first one touched one anchor kernel per translation unit of the library
     if not os.environ.get("SIGE_HIP_NO_PRELOAD"):
         assert hip.lib().preloaded_units[torch.cuda.current_device()] == len(build.SOURCES)
+
+
+# ---- the GauGAN helpers (csrc/spade_ops.hip, conv_out.hip): what was left to torch kernels in round 4 -----
+def test_resize_nearest_is_torch_nearest(hip):
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(1)
+    for (C, H, W), size in (((36, 256, 512), (4, 8)), ((36, 256, 512), (128, 256)), ((36, 256, 512), (16, 32)), ((64, 8, 16), (16, 32)),
+                            ((128, 32, 64), (64, 128)), ((4, 6, 10), (6, 10))):
+        x = _cl(torch.randn(2, C, H, W, generator=g).to(DEV))
+        got = hip.resize_nearest_cl(x, size)
+        assert got is not None and hip.is_cl(got)
+        assert torch.equal(got, F.interpolate(x, size=size, mode="nearest"))
+    assert hip.resize_nearest_cl(_cl(torch.randn(1, 8, 6, 6, device=DEV)), (9, 9)) is None  # (not an integer factor)
+
+
+def test_act_split_and_scatter_gather_split(hip):
+    from sige_amd.utils import reduce_mask
+
+    g = torch.Generator().manual_seed(2)
+    x = _cl(torch.randn(2, 384, 8, 16, generator=g).to(DEV))
+    for parts in (2, 3):
+        got = hip.act_split_cl(x, parts, "relu")
+        want = torch.split(torch.relu(x), 384 // parts, dim=1)
+        assert len(got) == parts and all(hip.is_cl(a) and torch.equal(a, b) for a, b in zip(got, want))
+    got = hip.act_split_cl(x, 2, "leaky", 0.2)
+    assert torch.equal(torch.cat(got, 1), torch.nn.functional.leaky_relu(x, 0.2))
+    # scatter_gather + relu + split == the three torch steps after scatter_gather_cl
+    H, W, C = 32, 64, 384
+    mask = torch.zeros(H, W, dtype=torch.bool)
+    mask[5:14, 20:41] = True
+    mask[0, 0] = mask[31, 63] = True
+    idx = reduce_mask(mask.to(DEV), 6, 4, 1)
+    smap = hip.get_scatter_map(H, W, 6, 6, 3, 3, 1, 1, 1, 1, idx)
+    y = _cl(torch.randn(1, C, H, W, generator=g).to(DEV))
+    t = _cl(torch.randn(idx.shape[0], C, 4, 4, generator=g).to(DEV))
+    ref = torch.relu(hip.scatter_gather_cl(t, y, 6, 6, idx, smap))
+    for parts in (2, 3):
+        got = hip.scatter_gather_split_cl(t, y, 6, 6, idx, smap, parts, "relu")
+        want = torch.split(ref, C // parts, dim=1)
+        assert all(hip.is_cl(a) and torch.equal(a, b) for a, b in zip(got, want))
+
+
+def test_spade_modulate_dense_and_conv_img_tail(hip):
+    g = torch.Generator().manual_seed(3)
+    B, C, H, W = 1, 1024, 4, 8
+    x = _cl(torch.randn(B, C, H, W, generator=g).to(DEV))
+    gb = _cl(torch.randn(B, 2 * C, H, W, generator=g).to(DEV))
+    sc, sh = (torch.randn(1, C, 1, 1, generator=g).to(DEV) for _ in range(2))
+    gamma, beta = torch.split(gb, C, dim=1)
+    n = sc * x
+    n = sh + n
+    want = n * (1 + gamma) + beta
+    assert torch.equal(hip.spade_modulate_dense_cl(x, sc, sh, gb, None), want)
+    assert torch.equal(hip.spade_modulate_dense_cl(x, sc, sh, gb, 0.2), torch.nn.functional.leaky_relu(want, 0.2))
+    # tanh(conv_img(leaky_relu(x))) -- 64 -> 3 channels at the generator's output resolution
+    conv = torch.nn.Conv2d(64, 3, 3, padding=1).to(DEV)
+    xi = _cl(torch.randn(1, 64, 256, 512, generator=g).to(DEV))
+    with torch.no_grad():
+        want = torch.tanh(conv(torch.nn.functional.leaky_relu(xi, 0.2)))
+        got = hip.conv3x3_small_cout_act_cl(xi, conv.weight, conv.bias, "leaky", 0.2, "tanh")
+    assert got is not None
+    torch.testing.assert_close(got, want, rtol=0, atol=2e-5)
+
+
+def _gaugan(fused=True):
+    from sige_amd.workloads.gaugan_spade import SPADEConfig, SpadeGenerator
+
+    torch.manual_seed(0)
+    m = SpadeGenerator(SPADEConfig(fused=fused)).eval()
+    g = torch.Generator().manual_seed(7)
+    for n_, b_ in m.named_buffers():  # running statistics away from (0, 1): the cached affine matters
+        if n_.endswith("running_mean"):
+            b_.copy_(torch.randn(b_.shape, generator=g) * 0.3)
+        elif n_.endswith("running_var"):
+            b_.copy_(torch.rand(b_.shape, generator=g) + 0.5)
+    m = m.to(DEV).to(memory_format=torch.channels_last)
+    m.set_scatter_inplace(True)
+    return m
+
+
+def _gaugan_labels(dy=0, dx=0):
+    import numpy as np
+
+    rs = np.random.RandomState(3)
+    lab0 = np.kron(rs.randint(0, 36, size=(32, 64)), np.ones((8, 8), dtype=np.int64))
+    lab1 = lab0.copy()
+    lab1[85 + dy:136 + dy, 128 + dx:256 + dx] = (lab0[85 + dy:136 + dy, 128 + dx:256 + dx] + 5) % 36
+    oh = lambda l: _cl(torch.nn.functional.one_hot(torch.from_numpy(l), 36).permute(2, 0, 1)[None].float().to(DEV))  # noqa: E731
+    return oh(lab0), oh(lab1)
+
+
+def test_gaugan_sparse_forward_on_the_library_follows_a_launch_plan(hip):
+    """The SPADE generator's sparse forward in its all-library form (cfg.fused): equal to the module chain the reference runs
+    (sige_normalization.py:62-88 as torch ops); and ONE launch plan recorded under one edit serves later edits -- new label map,
+    new mask, other tile counts -- bit for bit the module-level forward.  A torch kernel left in the forward would not be replayed
+    by the plan: its stale output shows as a difference under the new input."""
+    from sige_amd.plan import LaunchPlan
+    from sige_amd.utils import compute_difference_mask, dilate_mask, downsample_mask
+
+    model = _gaugan()
+    x0, x1 = _gaugan_labels()
+
+    def build(mask):
+        return downsample_mask(dilate_mask(mask, 1), (model.sh, model.sw), dilation=2)
+
+    with torch.no_grad():
+        model.set_mode("full")
+        model(x0)
+        model.set_masks(build(compute_difference_mask(x0, x1)))
+        model.set_mode("sparse")
+        model.cfg.fused = False
+        chain = model(x1).clone()
+        model.cfg.fused = True
+        n0 = hip.launch_count()
+        fused = model(x1).clone()
+        launches = hip.launch_count() - n0
+        assert float((fused - chain).abs().max()) < 2e-5
+        seg = x1.clone()
+        plan = LaunchPlan(model)
+        out = plan.record(compute_difference_mask(x0, seg), build, lambda: model(seg))
+        assert not plan.shape_bound and plan.unbound_counts == 0
+        assert plan.calls(1) == launches  # every launch of the forward is a recorded library call
+        assert torch.equal(out, fused)
+        seen = set()
+        for dy, dx in ((20, 40), (-40, -60), (60, 120), (35, 10)):
+            xi = _gaugan_labels(dy, dx)[1]
+            seg.copy_(xi)
+            plan.bind_mask(compute_difference_mask(x0, seg))
+            got = plan.run().clone()
+            seen.add(tuple(plan.counts))
+            # the module-level forward under the same edit (bind_mask adopted the plan's index lists: the modules agree)
+            want = model(xi).clone()
+            assert torch.equal(got, want), (dy, dx, float((got - want).abs().max()))
+            model.cfg.fused = False
+            ref = model(xi).clone()
+            model.cfg.fused = True
+            assert float((got - ref).abs().max()) < 2e-5
+        assert len(seen) >= 2  # (the edits did change the tile counts)

@@ -38,8 +38,16 @@ def main():
     ap.add_argument("--gc", default="default", choices=["default", "freeze", "off"],
                     help="Python's cyclic collector during the edits: default | freeze (gc.collect(); gc.freeze() after the full pass: "
                          "what exists then is never traversed again) | off (gc.disable())")
+    ap.add_argument("--spin", action="store_true", help="hipSetDeviceFlags(hipDeviceScheduleSpin) before the context exists: host "
+                                                        "waits poll instead of sleeping on an interrupt")
     a = ap.parse_args()
     import gc
+
+    if a.spin:
+        import ctypes
+
+        rc = ctypes.CDLL("libamdhip64.so").hipSetDeviceFlags(1)  # hipDeviceScheduleSpin
+        print("hipSetDeviceFlags(spin) ->", rc, file=sys.stderr)
     from sige_amd import hip
     from sige_amd.utils import compute_difference_mask, dilate_mask, downsample_mask
     from sige_amd.workloads.gaugan_spade import SPADEConfig, SpadeGenerator
@@ -96,7 +104,7 @@ def main():
                              "library_launches": hip.launch_count() - n0,
                              "gc_collections_gen0_1_2": [g_["collections"] - b for g_, b in zip(gc.get_stats(), g0)],
                              "reserved_MB": round(torch.cuda.memory_reserved() / 2 ** 20, 1)})
-    res = {"gc": a.gc, "gc_objects": len(gc.get_objects()), "preload": not os.environ.get("SIGE_HIP_NO_PRELOAD"), "preload_units": n_units, "preload_ms": round(t_pre * 1e3, 1),
+    res = {"spin": a.spin, "HSA_ENABLE_INTERRUPT": os.environ.get("HSA_ENABLE_INTERRUPT"), "gc": a.gc, "gc_objects": len(gc.get_objects()), "preload": not os.environ.get("SIGE_HIP_NO_PRELOAD"), "preload_units": n_units, "preload_ms": round(t_pre * 1e3, 1),
            "context_ms": round(t_ctx * 1e3, 1), "full_forward_first_ms": round(t_full * 1e3, 1), "rows": rows}
     text = json.dumps(res, indent=1)
     print(text)
