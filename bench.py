@@ -717,6 +717,7 @@ def main():
                          "the same fp16-rounded cache; the cached affines stay fp32).  Only with --dtype f16: the rounding costs up to "
                          "1.6e-3 of output error at 15 %% edit (profiles/r3_f16_cache_trace.json) -- inside the f16 criterion, outside "
                          "the fp32 path's 1e-3")
+    ap.add_argument("--batched-ratios", default="0.05,0.15", help="stacked edits also at these edit ratios (E = 1 and 8), '' = skip")
     ap.add_argument("--batched-edits", default="1,2,4,8,16",
                     help="stacked edits (sige_amd/stacked.py): batch sizes E of the throughput section, '' = skip")
     ap.add_argument("--cache-dtype", default="auto", choices=["auto", "f32", "f16"],
@@ -1331,7 +1332,11 @@ def main():
             return downsample_mask(dilate_mask(mk, 5), 8)
 
         def place(e):  # (eight different places: the masks of a batch do not overlap much)
-            return square_mask(args.ratio, top=(16 + 61 * e) % 208, left=(24 + 97 * e) % 208).to(dev)
+            r_ = batch_ratio[0]
+            mod = 208 if r_ == args.ratio else 256 - int(round(r_ ** 0.5 * 256))  # (the whole square inside the image)
+            return square_mask(r_, top=(16 + 61 * e) % mod, left=(24 + 97 * e) % mod).to(dev)
+
+        batch_ratio = [args.ratio]
 
         try:
             with torch.no_grad():
@@ -1398,12 +1403,43 @@ def main():
                             rows[-1]["kernels"] = kern_b
                 _dense.WIDE_MIN_FLOP_F32_STACKED = wide_keep
                 model.set_compute_dtype(args.dtype)
+                # the same at the sweep's larger edits: E = 1 and 8, the library's own routing
+                other = []
+                for ratio in [float(v) for v in args.batched_ratios.split(",") if v]:
+                    batch_ratio[0] = ratio
+                    mks_r = [place(e) for e in range(8)]
+                    for E in (1, 8):
+                        xe = torch.cat([x0 + noise * mk for mk in mks_r[:E]], 0).contiguous(memory_format=torch.channels_last)
+                        if E > 1:
+                            stacked.stack_caches(model, E)
+                        try:
+                            if E > 1:
+                                stacked.set_masks(model, [build_pyr(mk) for mk in mks_r[:E]])
+                            else:
+                                model.set_masks(build_pyr(mks_r[0]))
+                            model.set_mode("sparse")
+                            with stacked.edit_batch(model, E):
+                                gb, ob = capture(model, xe, t)
+                                ms = timed_replays(gb, 20, 5, 1) * 1e3 / 20
+                                tracer.log = []
+                                model(xe, t)
+                                trb, tracer.log = tracer.log, None
+                                _, _, kern_b, conv_tf_b, _ = kernel_families(trb)
+                                del trb, gb, ob
+                        finally:
+                            if E > 1:
+                                stacked.unstack_caches(model)
+                        other.append({"edit_ratio": ratio, "edits": E, "ms_per_launch_set": round(ms, 4), "ms_per_edit": round(ms / E, 4),
+                                      "forwards_per_s": round(E / ms * 1e3, 1), "block_conv_TFLOPs": round(conv_tf_b, 2),
+                                      "block_conv_frac_of_mfma_peak": round(conv_tf_b / mfma_peak, 4),
+                                      "dense_conv_wide": kern_b.get("dense_conv_wide")})
+                batch_ratio[0] = args.ratio
                 base = next(r for r in rows if r["edits"] == 1)["forwards_per_s"]
                 best = {}
                 for r in rows:
                     if r["edits"] not in best or r["forwards_per_s"] > best[r["edits"]]["forwards_per_s"]:
                         best[r["edits"]] = r
-                batched = {"edit_ratio": args.ratio, "rows": rows,
+                batched = {"edit_ratio": args.ratio, "rows": rows, "rows_at_other_edit_ratios": other,
                            "speedup_forwards_per_s_vs_one_edit": {str(e): round(best[e]["forwards_per_s"] / base, 2) for e in sorted(best)},
                            "note": "sige_amd/stacked.py + sige_hip_set_edit_batch: E edited versions of one original, each with its OWN mask at "
                                    "its own place, stacked along H into one tall image (the same bytes as [E,C,H,W] channels-last; masks, "

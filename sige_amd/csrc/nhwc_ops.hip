@@ -38,13 +38,18 @@ __device__ __forceinline__ float4 affine_act4(float4 z, const float *scale, cons
     return z;
 }
 
+// Stacked edits (sige_hip_set_edit_batch: E images stacked along H, hp_shift = log2 of one image's height): a tile belongs to the
+// image its window's THIRD row lies in (the rule of reduce_mask.hip and of the conv kernels' staging) and rows of its window
+// beyond that image are zero padding, not the neighbour's pixels.  First row of the tile's image (0 when the mode is off).
+__device__ __forceinline__ int seam_lo(int h0, int hp_shift) { return hp_shift ? (((h0 + 2) >> hp_shift) << hp_shift) : 0; }
+
 // ------------------------------------------------------------------ gather ----
 // x [B,H,W,C] -> out [B*N, bH, bW, C]; scale/shift [1|B, C]
 template <int ACT, typename XT = float>
 __global__ __launch_bounds__(kT) void gather_nhwc_kernel(const XT *__restrict__ x, int B, int C, int H, int W, int bH, int bW,
                                                         const int32_t *__restrict__ idx, int N,
                                                         const float *scale, const float *shift, int aff_sb,
-                                                        float *__restrict__ out, long units) {
+                                                        float *__restrict__ out, long units, int hp_shift) {
     const int C4 = C / 4, RS = bH * bW;
     for (long u = (long)blockIdx.x * kT + threadIdx.x; u < units; u += (long)gridDim.x * kT) {
         const int c = (int)(u % C4) * 4;
@@ -52,9 +57,11 @@ __global__ __launch_bounds__(kT) void gather_nhwc_kernel(const XT *__restrict__ 
         const int p = (int)(tp % RS);
         const int t = (int)(tp / RS);
         const int b = t / N, n = t - b * N;
-        const int h = idx[2 * n] + p / bW, w = idx[2 * n + 1] + p % bW;
+        const int h0 = idx[2 * n];
+        const int h = h0 + p / bW, w = idx[2 * n + 1] + p % bW;
+        const int hlo = seam_lo(h0, hp_shift), hhi = hp_shift ? hlo + (1 << hp_shift) : H;
         float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (h >= 0 && h < H && w >= 0 && w < W)
+        if (h >= hlo && h < hhi && w >= 0 && w < W)
             z = affine_act4<ACT>(ld4(x + (((size_t)b * H + h) * W + w) * C + c), scale, shift, b * aff_sb, c);
         st4(out + (size_t)u * 4, z);
     }
@@ -68,7 +75,7 @@ __global__ __launch_bounds__(kT) void scatter_gather_nhwc_kernel(const float *__
                                                                 const int32_t *__restrict__ idx, int N,
                                                                 const int32_t *__restrict__ map,
                                                                 const float *scale, const float *shift, int aff_sb,
-                                                                float *__restrict__ out, long units) {
+                                                                float *__restrict__ out, long units, int hp_shift) {
     const int C4 = C / 4, RS = bH * bW;
     for (long u = (long)blockIdx.x * kT + threadIdx.x; u < units; u += (long)gridDim.x * kT) {
         const int c = (int)(u % C4) * 4;
@@ -76,9 +83,11 @@ __global__ __launch_bounds__(kT) void scatter_gather_nhwc_kernel(const float *__
         const int p = (int)(tp % RS);
         const int t = (int)(tp / RS);
         const int b = t / N, n = t - b * N;
-        const int h = idx[2 * n] + p / bW, w = idx[2 * n + 1] + p % bW;
+        const int h0 = idx[2 * n];
+        const int h = h0 + p / bW, w = idx[2 * n + 1] + p % bW;
+        const int hlo = seam_lo(h0, hp_shift), hhi = hp_shift ? hlo + (1 << hp_shift) : H;
         float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (h >= 0 && h < H && w >= 0 && w < W) {
+        if (h >= hlo && h < hhi && w >= 0 && w < W) {
             const int32_t *m = map + 3 * ((size_t)h * W + w);
             const int blk = m[0];
             const float4 v = blk >= 0 ? ld4(x + ((((size_t)b * N + blk) * Rx + m[1]) * Sx + m[2]) * C + c)
@@ -112,6 +121,7 @@ struct SpadeArgs {
     float slope;
     int leaky;
     float *out;
+    int hp_shift;  // stacked edits: log2 of one image's height (0 = off)
 };
 
 __global__ __launch_bounds__(kT) void spade_modulate_nhwc_kernel(SpadeArgs a, long units) {
@@ -122,9 +132,11 @@ __global__ __launch_bounds__(kT) void spade_modulate_nhwc_kernel(SpadeArgs a, lo
         const int p = (int)(tp % RS);
         const int t = (int)(tp / RS);
         const int b = t / a.N, n = t - b * a.N;
-        const int h = a.idx[2 * n] + p / a.bW, w = a.idx[2 * n + 1] + p % a.bW;
+        const int h0 = a.idx[2 * n];
+        const int h = h0 + p / a.bW, w = a.idx[2 * n + 1] + p % a.bW;
+        const int hlo = seam_lo(h0, a.hp_shift), hhi = a.hp_shift ? hlo + (1 << a.hp_shift) : a.H;
         float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (h >= 0 && h < a.H && w >= 0 && w < a.W) {
+        if (h >= hlo && h < hhi && w >= 0 && w < a.W) {
             const size_t pix = ((size_t)b * a.H + h) * a.W + w;
             // everything this unit reads is addressed before the first value is used: the three loads go out together
             const float *xs = a.x_full + pix * a.C + c;
@@ -411,7 +423,8 @@ static int gather_nhwc_impl(const XT *x, int B, int C, int H, int W, int bH, int
                             int activation, float *out, void *stream) {
     if (B < 0 || C <= 0 || H <= 0 || W <= 0 || bH <= 0 || bW <= 0 || N < 0) return SIGE_HIP_EINVAL;
     if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
-    if (stacked_shift(H) != 0) return SIGE_HIP_EUNSUPPORTED;  // (stacked edits: a tile's halo would cross image seams; fused kernels only)
+    const int hp_shift = stacked_shift(H);  // (stacked edits: halo rows beyond a tile's own image are zero padding)
+    if (hp_shift < 0 || (hp_shift && B != 1)) return SIGE_HIP_EUNSUPPORTED;
     if ((long)B * N == 0) return SIGE_HIP_OK;
     if (!x || !out || !active_indices) return SIGE_HIP_EINVAL;
     int aff_sb;
@@ -420,9 +433,9 @@ static int gather_nhwc_impl(const XT *x, int B, int C, int H, int W, int bH, int
     const long units = (long)B * N * bH * bW * (C / 4);
     hipStream_t st = as_stream(stream);
     if (activation == SIGE_HIP_ACT_SWISH)
-        gather_nhwc_kernel<SIGE_HIP_ACT_SWISH, XT><<<grid_for(units), kT, 0, st>>>(x, B, C, H, W, bH, bW, active_indices, N, scale, shift, aff_sb, out, units);
+        gather_nhwc_kernel<SIGE_HIP_ACT_SWISH, XT><<<grid_for(units), kT, 0, st>>>(x, B, C, H, W, bH, bW, active_indices, N, scale, shift, aff_sb, out, units, hp_shift);
     else
-        gather_nhwc_kernel<SIGE_HIP_ACT_IDENTITY, XT><<<grid_for(units), kT, 0, st>>>(x, B, C, H, W, bH, bW, active_indices, N, scale, shift, aff_sb, out, units);
+        gather_nhwc_kernel<SIGE_HIP_ACT_IDENTITY, XT><<<grid_for(units), kT, 0, st>>>(x, B, C, H, W, bH, bW, active_indices, N, scale, shift, aff_sb, out, units, hp_shift);
     return launch_status();
 }
 
@@ -453,7 +466,8 @@ static int scatter_gather_nhwc_impl(const float *x, const CT *y, int B, int C, i
                                     int activation, float *out, void *stream) {
     if (B < 0 || C <= 0 || H <= 0 || W <= 0 || Rx <= 0 || Sx <= 0 || bH <= 0 || bW <= 0 || N < 0) return SIGE_HIP_EINVAL;
     if (activation != SIGE_HIP_ACT_IDENTITY && activation != SIGE_HIP_ACT_SWISH) return SIGE_HIP_EUNSUPPORTED;
-    if (stacked_shift(H) != 0) return SIGE_HIP_EUNSUPPORTED;  // (stacked edits: a tile's halo would cross image seams; fused kernels only)
+    const int hp_shift = stacked_shift(H);
+    if (hp_shift < 0 || (hp_shift && B != 1)) return SIGE_HIP_EUNSUPPORTED;
     if ((long)B * N == 0) return SIGE_HIP_OK;
     if (!x || !y || !out || !active_indices || !scatter_map) return SIGE_HIP_EINVAL;
     int aff_sb;
@@ -462,9 +476,9 @@ static int scatter_gather_nhwc_impl(const float *x, const CT *y, int B, int C, i
     const long units = (long)B * N * bH * bW * (C / 4);
     hipStream_t st = as_stream(stream);
     if (activation == SIGE_HIP_ACT_SWISH)
-        scatter_gather_nhwc_kernel<SIGE_HIP_ACT_SWISH, CT><<<grid_for(units), kT, 0, st>>>(x, y, B, C, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, shift, aff_sb, out, units);
+        scatter_gather_nhwc_kernel<SIGE_HIP_ACT_SWISH, CT><<<grid_for(units), kT, 0, st>>>(x, y, B, C, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, shift, aff_sb, out, units, hp_shift);
     else
-        scatter_gather_nhwc_kernel<SIGE_HIP_ACT_IDENTITY, CT><<<grid_for(units), kT, 0, st>>>(x, y, B, C, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, shift, aff_sb, out, units);
+        scatter_gather_nhwc_kernel<SIGE_HIP_ACT_IDENTITY, CT><<<grid_for(units), kT, 0, st>>>(x, y, B, C, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, shift, aff_sb, out, units, hp_shift);
     return launch_status();
 }
 
@@ -496,7 +510,8 @@ extern "C" int sige_hip_spade_modulate_nhwc_f32(
         int leaky, float slope, float *out, void *stream) {
     SIGE_PLAN_HOOK_N(sige_hip_spade_modulate_nhwc_f32, (sige::CountOf<24, 25>, sige::CountOf<2, 3>, sige::CountOf<14, 15>), x_full, x_tiles, map_x, Nx, Rx, Sx, scale, scaleB, scaleC, shift, shiftB, shiftC, gb_tiles, gb_full, map_g, Ng, Rg, Sg, B, C, H, W, bH, bW, active_indices, N, leaky, slope, out, stream);
     if (B < 0 || C <= 0 || H <= 0 || W <= 0 || bH <= 0 || bW <= 0 || N < 0 || Ng < 0 || Nx < 0) return SIGE_HIP_EINVAL;
-    if (stacked_shift(H) != 0) return SIGE_HIP_EUNSUPPORTED;
+    const int hp_shift = stacked_shift(H);
+    if (hp_shift < 0 || (hp_shift && B != 1)) return SIGE_HIP_EUNSUPPORTED;
     if ((long)B * N == 0) return SIGE_HIP_OK;
     if (!x_full || !gb_full || !map_g || !active_indices || !out) return SIGE_HIP_EINVAL;
     if ((Ng > 0 && (!gb_tiles || Rg <= 0 || Sg <= 0)) || (x_tiles && (!map_x || Rx <= 0 || Sx <= 0))) return SIGE_HIP_EINVAL;
@@ -509,7 +524,7 @@ extern "C" int sige_hip_spade_modulate_nhwc_f32(
     a.scale = scale; a.shift = shift; a.aff_sb = aff_sb;
     a.gb_tiles = gb_tiles; a.gb_full = gb_full; a.map_g = map_g; a.Ng = Ng; a.Rg = Rg; a.Sg = Sg;
     a.idx = active_indices; a.N = N; a.bH = bH; a.bW = bW; a.B = B; a.C = C; a.H = H; a.W = W;
-    a.slope = slope; a.leaky = leaky; a.out = out;
+    a.slope = slope; a.leaky = leaky; a.out = out; a.hp_shift = hp_shift;
     const long units = (long)B * N * bH * bW * (C / 4);
     spade_modulate_nhwc_kernel<<<grid_for(units), kT, 0, as_stream(stream)>>>(a, units);
     return launch_status();

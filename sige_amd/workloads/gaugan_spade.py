@@ -351,8 +351,10 @@ class SpadeGenerator(SIGEModel):
         cfg = self.cfg
         if cfg.fused and self.mode == "sparse" and _cl_gpu(x):
             from .. import hip
+            from ..nn.dense import _plain_weight
 
-            out = hip.conv3x3_small_cout_act_cl(x, self.conv_img.weight, self.conv_img.bias, "leaky", cfg.leaky_slope, "tanh")
+            # (a channels-last model holds the weight permuted: the dense copy is made once per weight version, not per forward)
+            out = hip.conv3x3_small_cout_act_cl(x, _plain_weight(self.conv_img), self.conv_img.bias, "leaky", cfg.leaky_slope, "tanh")
             if out is not None:
                 return out
         return torch.tanh(self.conv_img(F.leaky_relu(x, cfg.leaky_slope)))

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--gc", default="default", choices=["default", "freeze", "off"],
                     help="Python's cyclic collector during the edits: default | freeze (gc.collect(); gc.freeze() after the full pass: "
                          "what exists then is never traversed again) | off (gc.disable())")
+    ap.add_argument("--host-inputs", action="store_true", help="build every edit's label map on the host inside the loop (pageable upload)")
     ap.add_argument("--spin", action="store_true", help="hipSetDeviceFlags(hipDeviceScheduleSpin) before the context exists: host "
                                                         "waits poll instead of sleeping on an interrupt")
     a = ap.parse_args()
@@ -74,6 +75,12 @@ def main():
         sync()
         t_full = time.perf_counter() - t0
         edits = ((20, 40), (-40, -60), (60, 120), (0, -100), (35, 10))
+        # every edited label map resident on the GPU BEFORE the loop (default).  --host-inputs: built with numpy and uploaded from
+        # pageable memory inside the loop, as round 4's bench did -- the driver registers such a buffer as a userptr, and when
+        # Python frees it the MMU notifier evicts this process's queues; the restore is scheduled ~100 ms later (amdgpu KFD): the
+        # ~85 ms stalls of profiles/r5b_gaugan_latency_*.json, at a random point of the next few milliseconds of GPU work
+        resident = None if a.host_inputs else {e: cl(labels(*e)[1]) for e in edits}
+        sync()
         if a.gc == "freeze":
             gc.collect()
             gc.freeze()
@@ -82,7 +89,7 @@ def main():
             gc.disable()
         for rnd in range(2):
             for dy, dx in edits:
-                xi = cl(labels(dy, dx)[1])
+                xi = cl(labels(dy, dx)[1]) if resident is None else resident[(dy, dx)]
                 sync()
                 n0 = hip.launch_count()
                 g0 = [g_["collections"] for g_ in gc.get_stats()]
@@ -104,7 +111,7 @@ def main():
                              "library_launches": hip.launch_count() - n0,
                              "gc_collections_gen0_1_2": [g_["collections"] - b for g_, b in zip(gc.get_stats(), g0)],
                              "reserved_MB": round(torch.cuda.memory_reserved() / 2 ** 20, 1)})
-    res = {"spin": a.spin, "HSA_ENABLE_INTERRUPT": os.environ.get("HSA_ENABLE_INTERRUPT"), "gc": a.gc, "gc_objects": len(gc.get_objects()), "preload": not os.environ.get("SIGE_HIP_NO_PRELOAD"), "preload_units": n_units, "preload_ms": round(t_pre * 1e3, 1),
+    res = {"host_inputs": a.host_inputs, "spin": a.spin, "HSA_ENABLE_INTERRUPT": os.environ.get("HSA_ENABLE_INTERRUPT"), "gc": a.gc, "gc_objects": len(gc.get_objects()), "preload": not os.environ.get("SIGE_HIP_NO_PRELOAD"), "preload_units": n_units, "preload_ms": round(t_pre * 1e3, 1),
            "context_ms": round(t_ctx * 1e3, 1), "full_forward_first_ms": round(t_full * 1e3, 1), "rows": rows}
     text = json.dumps(res, indent=1)
     print(text)
