@@ -587,6 +587,11 @@ int sige_hip_block_conv_pack_f16x3(const float *w, int Cout, int Cin, int kH, in
 int sige_hip_block_conv_nhwc_f16x3(const float *x, int T, int Cin, int R, int S,
                                   const float *packed, const float *bias, int Cout, int kH, int kW,
                                   int strideH, int strideW, float *out, void *stream);
+/* ... over the tiles of an index list, T = B * N: `count_key` is that list's pointer (not read); a launch plan looks N up under
+ * it, so a conv over a tile SLAB follows a new mask like the gather-type entry points do.  compute: 0 fp32 | 1 f16c | 2 f16x3. */
+int sige_hip_block_conv_nhwc_keyed(int compute, const float *x, const int32_t *count_key, int B, int N, int Cin, int R, int S,
+                                   const float *packed, const float *bias, int Cout, int kH, int kW,
+                                   int strideH, int strideW, float *out, void *stream);
 int sige_hip_gather_conv_nhwc_f16x3(const float *x, const float *x2, int B, int C1, int C2, int H, int W,
                                    int bH, int bW, const int32_t *active_indices, int N,
                                    const float *scale, int scaleB, int scaleC,

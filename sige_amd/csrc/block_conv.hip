@@ -974,6 +974,21 @@ extern "C" int sige_hip_block_conv_nhwc_f16x3(const float *x, int T, int Cin, in
     return block_conv_nhwc_impl<2>(x, T, Cin, R, S, packed, bias, Cout, kH, kW, strideH, strideW, out, stream);
 }
 
+// ... over the tiles of an index list: T = B * N.  `count_key` is the index list the N tiles belong to; it is not read -- a launch
+// plan looks N up under it (plan.hpp: CountOf), like the tile count of every gather-type entry point, so that a conv over a
+// tile SLAB (GauGAN: the convs behind the SPADE modulation) follows a new mask too.  compute: 0 fp32 | 1 f16 operands | 2 split fp16.
+extern "C" int sige_hip_block_conv_nhwc_keyed(int compute, const float *x, const int32_t *count_key, int B, int N, int Cin, int R, int S,
+                                              const float *packed, const float *bias, int Cout, int kH, int kW,
+                                              int strideH, int strideW, float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_block_conv_nhwc_keyed, (sige::CountOf<2, 4>), compute, x, count_key, B, N, Cin, R, S, packed, bias, Cout, kH, kW, strideH, strideW, out, stream);
+    if (B < 0 || N < 0 || !count_key || (long)B * N > 0x7fffffffL) return SIGE_HIP_EINVAL;
+    const int T = B * N;
+    if (compute == 0) return block_conv_nhwc_impl<0>(x, T, Cin, R, S, packed, bias, Cout, kH, kW, strideH, strideW, out, stream);
+    if (compute == 1) return block_conv_nhwc_impl<1>(x, T, Cin, R, S, packed, bias, Cout, kH, kW, strideH, strideW, out, stream);
+    if (compute == 2) return block_conv_nhwc_impl<2>(x, T, Cin, R, S, packed, bias, Cout, kH, kW, strideH, strideW, out, stream);
+    return SIGE_HIP_EINVAL;
+}
+
 template <int PREC>
 static int gather_conv_nhwc_impl(const float *x, const float *x2, int B, int C1, int C2, int H, int W,
                                              int bH, int bW, const int32_t *active_indices, int N,

@@ -179,6 +179,7 @@ _SIGNATURES = {
     "sige_hip_scatter_gather_split_nhwc_f32": (
         _c_int, [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp, _c_int, ctypes.c_float, _c_int, ctypes.c_int64, _c_vp, _c_vp]),
     "sige_hip_spade_modulate_dense_nhwc_f32": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_vp] + [_c_int] * 5 + [ctypes.c_float, _c_vp, _c_vp]),
+    "sige_hip_block_conv_nhwc_keyed": (_c_int, [_c_int, _c_vp, _c_vp] + [_c_int] * 5 + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp, _c_vp]),
     "sige_hip_set_edit_batch": (_c_int, [_c_int]),
     "sige_hip_get_edit_batch": (_c_int, []),
     # launch plans (csrc/plan.hip; host side: sige_amd/plan.py)
@@ -1408,11 +1409,29 @@ def _twin_args(twins, like: torch.Tensor, Cout: int, name: str):
     return args, keep
 
 
+def tag_tiles(t: torch.Tensor, idx: torch.Tensor, B: int) -> torch.Tensor:
+    """Remember on a tile tensor [B*N,C,R,S] which index list its N tiles belong to: a conv over the slab (block_conv_cl) then
+    takes the keyed entry point, whose tile count a launch plan can follow (include/sige_hip.h: sige_hip_block_conv_nhwc_keyed)."""
+    t._sige_count_key = (idx, int(B))
+    return t
+
+
 def block_conv_cl(x, packed, bias, Cout: int, kernel: Tuple[int, int], stride: Tuple[int, int]):
     bias_keep = _vec(bias, "bias")
+    key = getattr(x, "_sige_count_key", None)
     x = _req_cl(x, "x")
     T, Cin, R, S = x.shape
     Ro, So = (R - kernel[0]) // stride[0] + 1, (S - kernel[1]) // stride[1] + 1
+    if key is not None and key[0].shape[0] * key[1] == T and T > 0:
+        idx, B = key
+        out = _empty_tiles_cl(B, idx, Cout, Ro, So, x.device)
+        status = lib().sige_hip_block_conv_nhwc_keyed(_COMPUTE_ID[getattr(packed, "compute", "f32")], x.data_ptr(), idx.data_ptr(), B,
+                                                      idx.shape[0], Cin, R, S, packed.data_ptr(), _p(bias_keep), Cout,
+                                                      kernel[0], kernel[1], stride[0], stride[1], out.data_ptr(), _stream(x))
+        if status == UNSUPPORTED:
+            return None
+        _check(status, "block_conv_cl")
+        return tag_tiles(out, idx, B)
     out = _empty_cl((T, Cout, Ro, So), x.device)
     status = _conv_fn("sige_hip_block_conv_nhwc", packed)(x.data_ptr(), T, Cin, R, S, packed.data_ptr(), _p(bias_keep), Cout,
                                                 kernel[0], kernel[1], stride[0], stride[1], out.data_ptr(), _stream(x))
@@ -1578,7 +1597,7 @@ def gather_cl(x, bSizeH, bSizeW, activeIndices, scale=None, shift=None, activati
     fn = lib().sige_hip_gather_nhwc_f16 if x.dtype == torch.float16 else lib().sige_hip_gather_nhwc_f32
     _check(fn(x.data_ptr(), B, C, H, W, bSizeH, bSizeW, idx.data_ptr(), N, *sa, *ta, _act(activationName), out.data_ptr(), _stream(x)),
            "gather_cl")
-    return out
+    return tag_tiles(out, idx, B)
 
 
 def scatter_gather_cl(x, y, bSizeH, bSizeW, activeIndices, scatterMap, scale=None, shift=None,
@@ -1593,7 +1612,7 @@ def scatter_gather_cl(x, y, bSizeH, bSizeW, activeIndices, scatterMap, scale=Non
     fn = lib().sige_hip_scatter_gather_nhwc_f16 if y.dtype == torch.float16 else lib().sige_hip_scatter_gather_nhwc_f32
     _check(fn(x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3], bSizeH, bSizeW, idx.data_ptr(), N, smap.data_ptr(),
               *sa, *ta, _act(activationName), out.data_ptr(), _stream(y)), "scatter_gather_cl")
-    return out
+    return tag_tiles(out, idx, B)
 
 
 def spade_modulate_cl(x_full, x_tiles, map_x, scale, shift, gb_tiles, gb_full, map_g, activeIndices, block: Tuple[int, int],
@@ -1622,7 +1641,7 @@ def spade_modulate_cl(x_full, x_tiles, map_x, scale, shift, gb_tiles, gb_full, m
         gb_tiles.data_ptr(), gb_full.data_ptr(), map_g.data_ptr(), gb_tiles.shape[0] // B, gb_tiles.shape[2], gb_tiles.shape[3],
         B, C, H, W, block[0], block[1], idx.data_ptr(), N, int(slope is not None), float(slope or 0.0), out.data_ptr(),
         _stream(x_full)), "spade_modulate_cl")
-    return out
+    return tag_tiles(out, idx, B)
 
 
 # ---- GauGAN helpers (csrc/spade_ops.hip): the sparse forward of the SPADE generator without a torch kernel ----------------------
@@ -1665,7 +1684,7 @@ def scatter_gather_split_cl(x, y, bSizeH, bSizeW, activeIndices, scatterMap, par
     _check(lib().sige_hip_scatter_gather_split_nhwc_f32(
         x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3], bSizeH, bSizeW, idx.data_ptr(), N, smap.data_ptr(),
         ACT_EXT[activationName], float(slope), parts, B * cap * bSizeH * bSizeW * Cp, out.data_ptr(), _stream(y)), "scatter_gather_split_cl")
-    return tuple(out[k, :B * N].permute(0, 3, 1, 2) for k in range(parts))
+    return tuple(tag_tiles(out[k, :B * N].permute(0, 3, 1, 2), idx, B) for k in range(parts))
 
 
 def spade_modulate_dense_cl(x, scale, shift, gb, slope: Optional[float] = None):

@@ -233,14 +233,16 @@ def test_gaugan_sparse_forward_on_the_library_follows_a_launch_plan(hip):
         model.cfg.fused = False
         chain = model(x1).clone()
         model.cfg.fused = True
+        model(x1)  # (the first forward of a form packs weights: not part of the steady-state launch count)
         n0 = hip.launch_count()
         fused = model(x1).clone()
         launches = hip.launch_count() - n0
+        assert launches <= 100
         assert float((fused - chain).abs().max()) < 2e-5
         seg = x1.clone()
         plan = LaunchPlan(model)
         out = plan.record(compute_difference_mask(x0, seg), build, lambda: model(seg))
-        assert not plan.shape_bound and plan.unbound_counts == 0
+        assert not plan.shape_bound and plan.unbound_counts == 0, (plan.shape_bound, plan.unbound_counts)
         assert plan.calls(1) == launches  # every launch of the forward is a recorded library call
         assert torch.equal(out, fused)
         seen = set()
