@@ -21,11 +21,17 @@ cd "$ROOT"
 python tools/pmc_data_movement.py "$(ls $OUT/${TAG}_dmpmc/fetch/*counter_collection.csv | head -1)" "$(ls $OUT/${TAG}_dmpmc/write/*counter_collection.csv | head -1)" "$OUT/${TAG}_dm_manifest.json" "$OUT/${TAG}_pmc_data_movement.json" > "$OUT/${TAG}_pmc_data_movement.txt" 2>&1
 [ -s "$OUT/${TAG}_pmc_data_movement.json" ] && cp "$OUT/${TAG}_pmc_data_movement.json" profiles/pmc_data_movement.json
 find "$OUT/${TAG}_dmpmc" -type f -delete; find "$OUT/${TAG}_dmpmc" -type d -empty -delete
+# (since round 5 the LAST stdout line is the <= 4 KB contract line and the whole result is bench_detail*.json: both are kept)
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2> "$OUT/${TAG}_bench.err" | tail -1 > "$OUT/${TAG}_bench.json"
+cp bench_detail.json "$OUT/${TAG}_bench_detail.json"
 timeout 600 python bench.py --dtype f16 --no-extras --cpu-seconds 1 2> "$OUT/${TAG}_bench_f16.err" | tail -1 > "$OUT/${TAG}_bench_f16.json"
+cp bench_detail.json "$OUT/${TAG}_bench_f16_detail.json"
 timeout 600 python bench.py --gpus 2 --oversubscribe --backend gloo --steps 20 --warmup 5 --no-extras --cpu-seconds 1 2> "$OUT/${TAG}_bench_2ranks.err" | grep '^{"metric"' | tail -1 > "$OUT/${TAG}_bench_2ranks_gloo.json"
+cp bench_detail.json "$OUT/${TAG}_bench_2ranks_gloo_detail.json"
 timeout 600 python bench.py --workload sd --steps 20 --warmup 5 2> "$OUT/${TAG}_bench_sd.err" | tail -1 > "$OUT/${TAG}_bench_sd.json"
+cp bench_detail_sd.json "$OUT/${TAG}_bench_sd_detail.json"
 timeout 600 python bench.py --workload sd --gpus 2 --oversubscribe --backend gloo --steps 10 --warmup 3 2> "$OUT/${TAG}_bench_sd_2ranks.err" | grep '^{"metric"' | tail -1 > "$OUT/${TAG}_bench_sd_2ranks_gloo.json"
+cp bench_detail_sd.json "$OUT/${TAG}_bench_sd_2ranks_gloo_detail.json"
 # kernel traces of the two other workloads (10 hipGraph replays each)
 cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_trace_sd" -o sd -- python $ROOT/tools/profile_sd.py --replays 10 > "$OUT/${TAG}_trace_sd.log" 2>&1
