@@ -82,8 +82,7 @@ enum {
     SIGE_HIP_TUNE_SMALL_COUT_SCALAR = 8,     /* 1 = conv3x3_small_cout always on its scalar-weight kernel */
     SIGE_HIP_TUNE_WIDE_KSPLIT = 9,           /* dense-layer conv: pin the K split (0 = automatic) */
     SIGE_HIP_TUNE_ATTENTION_FORM = 10,       /* attention_tokens: 1 = 16 queries per workgroup | 2 = 32 (0 = automatic) */
-    SIGE_HIP_TUNE_CONV_V3 = 11,              /* the weight-sharing tile conv (conv_tile3): -1 = library's rule | 0 never | 1 wherever it exists */
-    SIGE_HIP_TUNE_COUNT = 12
+    SIGE_HIP_TUNE_COUNT = 11
 };
 #ifdef SIGE_HIP_TUNING
 int sige_hip_tuning_set(int key, int value); /* SIGE_HIP_EINVAL for an unknown key or a value outside the key's range */
@@ -468,6 +467,29 @@ int sige_hip_scatter_with_block_residual_nhwc_f32(
         const int32_t *active_indices0, const int32_t *table0, int gH0, int gW0, int N0,
         const int32_t *active_indices1, const int32_t *table1, int gH1, int gW1, int N1,
         int in_place, float *out, void *stream);
+
+/* ---- tile conv v3 (csrc/conv_tile3.hpp): the 3x3 / stride-1 stacked-block conv over 6x6 tiles with the dense-layer kernel's
+ * K loop -- wave-private stages (no workgroup barrier per channel chunk), 64 output channels per workgroup -- for grids that
+ * fill the chip (large edits, stacked edits); exact fp32 (v_mfma_f32_32x32x2_f32).  Replaces, on those grids, what
+ * sige_hip_gather_conv_nhwc_f32 (source 1) and sige_hip_scatter_gather_conv[_scatter]_nhwc_f32 (source 2) do:
+ *   source 1: tiles of x [B,H>>up,W>>up,C1] (+ x2 [.., C2]: a fused torch.cat) at active_indices, zero padded, optional cached
+ *             affine [affineB in {1,B}, C1+C2] + SiLU;   source 2: x = conv tiles [B*N,Rx,Sx,C1], x2 = the cached tensor
+ *             [B,H,W,C1] through scatter_map (raw);
+ *   to_full 0: out = tiles [B*N,4,4,Cout];  1: straight into out [B,Ho,Wo,Cout] at offset + origin, clipped, + residual, with x1 /
+ *             table1: + (x1 - residual) where a shortcut tile covers the pixel (ScatterWithBlockResidual), twins, out-affine.
+ * `packed` = sige_hip_wide_conv_pack(prec = 2) of the [Cout, C1+C2, 3, 3] weight; C1, C2, Cout multiples of 64. */
+int sige_hip_tile_conv3_supported(int C1, int C2, int Cout);
+int sige_hip_tile_conv3_nhwc_f32(
+        int source, const float *x, const float *x2, int B, int C1, int C2, int H, int W, int upsample2x,
+        const int32_t *active_indices, int N, const int32_t *scatter_map, int Rx, int Sx,
+        const float *scale, const float *shift, int affineB, int activation,
+        const float *packed, const float *bias, int Cout,
+        int to_full, int offsetH, int offsetW, int Ho, int Wo, const float *residual,
+        const float *x1, const int32_t *table1, int gH1, int gW1, int N1, int R1, int S1,
+        const float *out_scale, const float *out_shift, int out_activation,
+        float *twin0, const float *twin_scale0, const float *twin_shift0,
+        float *twin1, const float *twin_scale1, const float *twin_shift1,
+        float *out, void *stream);
 
 /* ---- 3x3 / padding-1 conv with <= 4 output channels over a full channels-last tensor
  * (the U-Net's conv_out after norm_out + SiLU, sige_fused_unet.py:430-434, which the

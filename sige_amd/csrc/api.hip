@@ -11,9 +11,9 @@
 namespace sige {
 std::atomic<int> g_tuning[SIGE_HIP_TUNE_COUNT] = {{kTuningDefaults[0]}, {kTuningDefaults[1]}, {kTuningDefaults[2]}, {kTuningDefaults[3]},
                                                   {kTuningDefaults[4]}, {kTuningDefaults[5]}, {kTuningDefaults[6]}, {kTuningDefaults[7]},
-                                                  {kTuningDefaults[8]}, {kTuningDefaults[9]}, {kTuningDefaults[10]}, {kTuningDefaults[11]}};
+                                                  {kTuningDefaults[8]}, {kTuningDefaults[9]}, {kTuningDefaults[10]}};
 }
-static_assert(SIGE_HIP_TUNE_COUNT == 12, "g_tuning's initialiser lists every key");
+static_assert(SIGE_HIP_TUNE_COUNT == 11, "g_tuning's initialiser lists every key");
 
 extern "C" int sige_hip_tuning_set(int key, int value) {
     bool ok = false;
@@ -29,7 +29,6 @@ extern "C" int sige_hip_tuning_set(int key, int value) {
         case SIGE_HIP_TUNE_SMALL_COUT_SCALAR: ok = value == 0 || value == 1; break;
         case SIGE_HIP_TUNE_WIDE_KSPLIT: ok = value >= 0 && value <= 16; break;  // (conv_wide.hpp: kWideMaxSplit)
         case SIGE_HIP_TUNE_ATTENTION_FORM: ok = value >= 0 && value <= 2; break;
-        case SIGE_HIP_TUNE_CONV_V3: ok = value >= -1 && value <= 1; break;
         default: return SIGE_HIP_EINVAL;
     }
     if (!ok) return SIGE_HIP_EINVAL;

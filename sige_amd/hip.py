@@ -180,6 +180,10 @@ _SIGNATURES = {
         _c_int, [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp, _c_int, ctypes.c_float, _c_int, ctypes.c_int64, _c_vp, _c_vp]),
     "sige_hip_spade_modulate_dense_nhwc_f32": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_vp] + [_c_int] * 5 + [ctypes.c_float, _c_vp, _c_vp]),
     "sige_hip_block_conv_nhwc_keyed": (_c_int, [_c_int, _c_vp, _c_vp] + [_c_int] * 5 + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp, _c_vp]),
+    "sige_hip_tile_conv3_supported": (_c_int, [_c_int] * 3),
+    "sige_hip_tile_conv3_nhwc_f32": (
+        _c_int, [_c_int, _c_vp, _c_vp] + [_c_int] * 6 + [_c_vp, _c_int, _c_vp, _c_int, _c_int] + [_c_vp, _c_vp, _c_int, _c_int]
+        + [_c_vp, _c_vp, _c_int] + [_c_int] * 5 + [_c_vp] + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp, _c_vp, _c_int] + [_c_vp] * 6 + [_c_vp, _c_vp]),
     "sige_hip_set_edit_batch": (_c_int, [_c_int]),
     "sige_hip_get_edit_batch": (_c_int, []),
     # launch plans (csrc/plan.hip; host side: sige_amd/plan.py)
@@ -211,7 +215,7 @@ _TUNING_SIGNATURES = {
 TUNING_LIB_PATH = os.path.join(_PKG, "lib", "libsige_hip_tuning.so")
 # include/sige_hip.h: SIGE_HIP_TUNE_*
 TUNE = {"conv_tile_mt": 0, "conv_tile_nb": 1, "conv_waves": 2, "conv_large_grid_nb1": 3, "conv_ksplit": 4, "conv_ksplit_second_pass": 5,
-        "gather_one_tile_rows": 6, "scatter_gather_form": 7, "small_cout_scalar": 8, "wide_ksplit": 9, "attention_form": 10, "conv_v3": 11}
+        "gather_one_tile_rows": 6, "scatter_gather_form": 7, "small_cout_scalar": 8, "wide_ksplit": 9, "attention_form": 10}
 
 
 # how many guarded entry-point calls had to switch HIP's current device to the tensor's ("switched") and how many found it current
@@ -354,7 +358,7 @@ def tuning_get(key) -> int:
     return int(L.sige_hip_tuning_get(TUNE[key] if isinstance(key, str) else int(key)))
 
 
-_TUNE_DEFAULTS = {"conv_large_grid_nb1": -1, "conv_v3": -1}
+_TUNE_DEFAULTS = {"conv_large_grid_nb1": -1}
 
 
 def tuning_reset():
@@ -812,6 +816,11 @@ def conv_pack_weights(weight: torch.Tensor, R: int, S: int, stride: Tuple[int, i
     fn = {"f16": lib().sige_hip_block_conv_pack_f16c, "f16x3": lib().sige_hip_block_conv_pack_f16x3,
           "f32": lib().sige_hip_block_conv_pack_f32}[compute]
     _check(fn(w.data_ptr(), Cout, Cin, kH, kW, packed.data_ptr(), _stream(w)), "conv_pack_weights")
+    if (compute == "f32" and (kH, kW) == (3, 3) and (R, S) == (6, 6) and tuple(stride) == (1, 1) and Cin % 64 == 0 and Cout % 64 == 0
+            and TILE3 is not False):
+        # the same weights in the dense-layer kernel's exact-fp32 order: launches whose grid fills the chip run on the tile conv
+        # with that kernel's K loop (csrc/conv_tile3.hpp; routed per launch by _tile3_route)
+        packed.tile3 = wide_conv_pack_weights(w, "f32")
     return packed
 
 
@@ -1441,6 +1450,57 @@ def block_conv_cl(x, packed, bias, Cout: int, kernel: Tuple[int, int], stride: T
     return out
 
 
+# ---- tile conv v3 (csrc/conv_tile3.hpp): routing --------------------------------------------------------------------------
+# A launch takes the v3 kernel when its grid -- pairs of tiles x 64-channel output blocks -- has at least TILE3_MIN_BLOCKS
+# workgroups (two per CU: the kernel's start-up is longer than conv_mfma.hpp's, its K loop faster; measured by tools/tile3_bench.py,
+# profiles/r5*_tile3_bench.json).  TILE3: None = that rule | True = wherever the kernel exists | False = never (tests, A/B).
+TILE3 = None
+TILE3_MIN_BLOCKS = 512
+
+
+def _tile3_route(packed, T: int, C1: int, C2: int, Cout: int, kernel, stride, block):
+    t3 = getattr(packed, "tile3", None)
+    if TILE3 is False or t3 is None or tuple(kernel) != (3, 3) or tuple(stride) != (1, 1) or tuple(block) != (6, 6):
+        return None
+    if C1 % 64 or C2 % 64 or Cout % 64:
+        return None
+    if TILE3 is None and -(-T // 2) * (Cout // 64) < TILE3_MIN_BLOCKS:
+        return None
+    return t3
+
+
+def tile_conv3_cl(source: int, x, x2, B, C1, C2, H, W, up, idx, smap, rx_sx, scale, shift, activationName, t3, bias, Cout,
+                  full, residual, bargs, out_affine, targs, out):
+    """One launch of sige_hip_tile_conv3_nhwc_f32 (include/sige_hip.h); `full` = None (tiles) | (offH, offW, Ho, Wo).
+    UNSUPPORTED -> None."""
+    bias_keep = _vec(bias, "bias")
+    sc = sh = None
+    affB = 0
+    if scale is not None:
+        (sa, s_keep), (ta, t_keep) = _cvec(scale, "scale"), _cvec(shift, "shift")
+        if sa[2] != C1 + C2 or ta[2] != C1 + C2 or sa[1] != ta[1]:
+            return None
+        sc, sh, affB = sa[0], ta[0], sa[1]
+    if out_affine is not None:
+        os_, oh_, oact = out_affine
+        os_, oh_ = _req(os_.reshape(-1), torch.float32, "out_scale", 1), _req(oh_.reshape(-1), torch.float32, "out_shift", 1)
+        if os_.numel() != Cout or oh_.numel() != Cout:
+            raise RuntimeError("tile_conv3_cl: out_affine must have one entry per output channel")
+        oargs = (os_.data_ptr(), oh_.data_ptr(), _act(oact))
+    else:
+        oargs = (None, None, 0)
+    fargs = (0, 0, 0, 0, 0) if full is None else (1, *full)
+    status = lib().sige_hip_tile_conv3_nhwc_f32(
+        source, x.data_ptr(), None if x2 is None else x2.data_ptr(), B, C1, C2, H, W, int(bool(up)), idx.data_ptr(), idx.shape[0],
+        None if smap is None else smap.data_ptr(), rx_sx[0], rx_sx[1], sc, sh, affB, _act(activationName),
+        t3.data_ptr(), _p(bias_keep), Cout, *fargs, None if residual is None else residual.data_ptr(), *bargs, *oargs, *targs,
+        out.data_ptr(), _stream(x))
+    if status == UNSUPPORTED:
+        return None
+    _check(status, "tile_conv3_cl")
+    return out
+
+
 def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, activationName: str,
                    packed, bias, Cout: int, kernel: Tuple[int, int], stride: Tuple[int, int],
                    full: Optional[dict] = None, out_affine: Optional[tuple] = None, upsample2x: bool = False,
@@ -1477,6 +1537,18 @@ def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, a
             if tuple(r.shape) != tuple(out.shape):
                 raise RuntimeError("gather_conv_cl: residual %s != output %s" % (tuple(r.shape), tuple(out.shape)))
         fargs = (1, full["offset"][0], full["offset"][1], None if r is None else r.data_ptr(), Ho, Wo)
+    # (inside conv_pair(): a held 1x1 shortcut is launched on its own by the v3 entry point -- one more launch, on a grid where
+    #  the launch is not what counts)
+    t3 = _tile3_route(packed, B * N, C1, C2, Cout, kernel, stride, block)
+    if t3 is not None and N > 0:
+        if twins and full is None:
+            raise RuntimeError("gather_conv_cl: twins need a full-tensor destination")
+        targs3, twin_keep3 = _twin_args(twins if twins else None, out, Cout, "gather_conv_cl")
+        got = tile_conv3_cl(1, x, x2, B, C1, C2, H, W, upsample2x, idx, None, (0, 0), scale, shift, activationName, t3, bias, Cout,
+                            None if full is None else (full["offset"][0], full["offset"][1], Ho, Wo),
+                            None if full is None else r, (None, None, 0, 0, 0, 0, 0), out_affine, targs3, out)
+        if got is not None:
+            return got if full is not None else tag_tiles(got, idx, B)
     # deep-K convs over a handful of tiles: workspace for the cross-workgroup K split
     ws, ws_n = None, 0
     ks = lib().sige_hip_conv_ksplit_hint(B * N, C1 + C2, Cout, kernel[0], kernel[1], stride[0], stride[1])
@@ -1572,6 +1644,13 @@ def scatter_gather_conv_scatter_cl(x, y, block, activeIndices, scatterMap, scale
     else:
         bargs = (None, None, 0, 0, 0, 0, 0)
     targs, twin_keep = _twin_args(twins if twins else None, out, Cout, "scatter_gather_conv_scatter_cl")
+    t3 = _tile3_route(packed, B * idx.shape[0], C, 0, Cout, kernel, (1, 1), block)
+    if (t3 is not None and idx.shape[0] > 0 and y.dtype == torch.float32 and (r is None or r.dtype == torch.float32)
+            and scale is None and shift is None and activationName == "identity"):
+        got = tile_conv3_cl(2, x, y, B, C, 0, H, W, False, idx, smap, (x.shape[2], x.shape[3]), None, None, "identity", t3, bias, Cout,
+                            (offset[0], offset[1], H, W), r, bargs, None, targs, out)
+        if got is not None:
+            return got
     head = (x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3], block[0], block[1], idx.data_ptr(), idx.shape[0],
             smap.data_ptr(), *sa, *ta, _act(activationName), packed.data_ptr(), _p(bias_keep), Cout, kernel[0], kernel[1],
             offset[0], offset[1], None if r is None else r.data_ptr())

@@ -78,7 +78,7 @@ def test_tuning_build_exports_one_setter_and_getter():
     assert names - set(_declared()) == {"sige_hip_tuning_set", "sige_hip_tuning_get"}
     with hip.tuning_build() as L:
         assert L.has_tuning
-        for key, default in (("conv_tile_mt", 0), ("conv_large_grid_nb1", -1), ("conv_v3", -1), ("scatter_gather_form", 0)):
+        for key, default in (("conv_tile_mt", 0), ("conv_large_grid_nb1", -1), ("scatter_gather_form", 0)):
             assert hip.tuning_get(key) == default
         hip.tuning_set("conv_ksplit", 4)
         assert hip.tuning_get("conv_ksplit") == 4

@@ -322,3 +322,180 @@ def test_standalone_gathers_and_spade_in_stacked_mode(hip):
     # and without the seam rule the two differ: the bottom tiles of image 0 see image 1's first rows in the tall tensor
     plain = hip.gather_cl(tall(xs), 6, 6, idx_t, sc, sh, "swish")
     assert not torch.equal(plain, got["gather"])
+
+
+# ---- tile conv v3 (csrc/conv_tile3.hpp): the dense-layer kernel's K loop over SIGE tiles ------------------
+@pytest.mark.parametrize("c1,c2,cout,up", [(128, 0, 128, False), (64, 64, 64, False), (128, 64, 192, False), (64, 0, 128, True)])
+def test_tile_conv3_gather_forms_vs_fp64(hip, c1, c2, cout, up):
+    """Source 1 (gather, + fused cat, + x2 nearest upsampling in the addressing, raw and affine + SiLU) to tiles and into a full
+    tensor with residual, out-affine and twins: against an fp64 conv of the standalone gather's tiles (which are pinned to the
+    oracle), and against the conv_mfma.hpp launch of the same call.  Border tiles, B = 2 with a per-batch affine."""
+    import torch.nn.functional as F
+    from sige_amd.utils import reduce_mask
+
+    torch.manual_seed(c1 + c2 + cout)
+    B, res = 2, 64
+    C = c1 + c2
+    src = res // 2 if up else res
+    mask = torch.zeros(res, res, dtype=torch.bool)
+    mask[10:40, 5:50] = True
+    mask[0, 0] = mask[res - 1, res - 1] = True
+    idx = reduce_mask(mask.to(DEV), 6, 4, 1)
+    assert idx.shape[0] % 2 == 0 or True
+    x = _cl(torch.randn(B, c1, src, src, device=DEV))
+    x2 = _cl(torch.randn(1, c2, src, src, device=DEV)) if c2 else None
+    w = torch.randn(cout, C, 3, 3, device=DEV) / (3 * C ** 0.5)
+    bias = torch.randn(cout, device=DEV)
+    packed = hip.conv_pack_weights(w, 6, 6, (1, 1))
+    assert getattr(packed, "tile3", None) is not None
+    conv = lambda t: F.conv2d(t.double(), w.double(), bias.double()).float()  # noqa: E731
+    Bs = 1 if c2 else B  # (a fused cat is per image)
+    xs = x[:Bs]
+    full_in = xs if x2 is None else torch.cat([xs, x2], 1)
+    if up:
+        full_in = F.interpolate(full_in, scale_factor=2.0, mode="nearest")
+    full_in = _cl(full_in)
+    scale, shift = torch.randn(Bs, C, 1, 1, device=DEV), torch.randn(Bs, C, 1, 1, device=DEV)
+    os_, oh_ = torch.randn(cout, device=DEV), torch.randn(cout, device=DEV)
+
+    def run(**kw):
+        outs = []
+        for flag in (True, False):
+            hip.TILE3 = flag
+            try:
+                outs.append(hip.gather_conv_cl(xs, x2, (6, 6), idx, kw.get("sc"), kw.get("sh"), kw.get("act", "identity"), packed, bias,
+                                               cout, (3, 3), (1, 1), full=kw.get("full"), out_affine=kw.get("oa"), upsample2x=up,
+                                               twins=kw.get("twins")))
+            finally:
+                hip.TILE3 = None
+        return outs
+
+    for act, sc, sh in (("swish", scale, shift), ("identity", scale, shift), ("identity", None, None)):
+        if Bs > 1 and sc is not None and idx.shape[0] % 2:
+            continue  # (a per-batch affine needs whole tile pairs per image: the entry point says unsupported and the old kernel runs)
+        tiles = hip.gather_cl(full_in, 6, 6, idx, sc, sh, act)
+        want = conv(tiles)
+        new, old = run(sc=sc, sh=sh, act=act)
+        assert new is not None and old is not None
+        torch.testing.assert_close(new, want, rtol=0, atol=1e-4)
+        torch.testing.assert_close(new, old, rtol=0, atol=1e-4)
+        # the consumer's out-affine + SiLU in the epilogue
+        new, old = run(sc=sc, sh=sh, act=act, oa=(os_, oh_, "swish"))
+        torch.testing.assert_close(new, F.silu(want * os_.view(1, -1, 1, 1) + oh_.view(1, -1, 1, 1)), rtol=0, atol=2e-4)
+        torch.testing.assert_close(new, old, rtol=0, atol=2e-4)
+    # into a full tensor: + residual, two activated twins
+    residual = _cl(torch.randn(Bs, cout, res, res, device=DEV))
+    ts0, tt0, ts1, tt1 = (torch.randn(cout, device=DEV) for _ in range(4))
+
+    def twins():
+        return [(_cl(torch.zeros(Bs, cout, res, res, device=DEV)), ts0, tt0), (_cl(torch.zeros(Bs, cout, res, res, device=DEV)), ts1, tt1)]
+
+    outs = []
+    for flag in (True, False):
+        hip.TILE3 = flag
+        try:
+            tw = twins()
+            o = hip.gather_conv_cl(xs, x2, (6, 6), idx, scale, shift, "swish", packed, bias, cout, (3, 3), (1, 1),
+                                   full=dict(offset=(1, 1), out_res=(res, res), residual=residual), upsample2x=up, twins=tw,
+                                   out=_cl(torch.zeros(Bs, cout, res, res, device=DEV)))
+            outs.append((o, tw[0][0], tw[1][0]))
+        finally:
+            hip.TILE3 = None
+    for a_, b_ in zip(outs[0], outs[1]):
+        torch.testing.assert_close(a_, b_, rtol=0, atol=2e-4)
+    assert float(outs[0][0].abs().max()) > 0.1 and float(outs[0][1].abs().max()) > 0.01
+
+
+def test_tile_conv3_scatter_gather_to_full_vs_old_kernel_and_fp64(hip):
+    """Source 2 (conv-1 tiles + cached tensor through the scatter map, raw) written into a full tensor: plain residual, block
+    residual (ScatterWithBlockResidual: x1 tiles through their table), twins; against the conv_mfma.hpp launch and, tile by tile,
+    against an fp64 conv of the standalone scatter_gather's tiles."""
+    import torch.nn.functional as F
+    from sige_amd.utils import reduce_mask
+
+    torch.manual_seed(9)
+    B, C, cout, res = 1, 128, 128, 64
+    mask = torch.zeros(res, res, dtype=torch.bool)
+    mask[8:44, 12:60] = True
+    mask[0, 0] = mask[res - 1, res - 1] = True
+    idx = reduce_mask(mask.to(DEV), 6, 4, 1)
+    idx1 = reduce_mask(mask.to(DEV), 4, 4, 0)
+    smap = hip.get_scatter_map(res, res, 6, 6, 3, 3, 1, 1, 1, 1, idx)
+    y = _cl(torch.randn(B, C, res, res, device=DEV))
+    t4 = _cl(torch.randn(B * idx.shape[0], C, 4, 4, device=DEV))
+    w = torch.randn(cout, C, 3, 3, device=DEV) / (3 * C ** 0.5)
+    bias = torch.randn(cout, device=DEV)
+    packed = hip.conv_pack_weights(w, 6, 6, (1, 1))
+    y1 = _cl(torch.randn(B, cout, res, res, device=DEV))
+    x1 = _cl(torch.randn(B * idx1.shape[0], cout, 4, 4, device=DEV))
+    table1 = hip.tile_table(idx1, (0, 0), (1, 1), (4, 4), (res, res))
+    cache_out = _cl(torch.randn(B, cout, res, res, device=DEV))  # (what the persistent output holds outside the tiles)
+    ts0, tt0 = torch.randn(cout, device=DEV), torch.randn(cout, device=DEV)
+    for block_res in (False, True):
+        outs = []
+        for flag in (True, False):
+            hip.TILE3 = flag
+            try:
+                out = cache_out.clone(memory_format=torch.preserve_format)
+                tw = [(_cl(torch.zeros(B, cout, res, res, device=DEV)), ts0, tt0)]
+                o = hip.scatter_gather_conv_scatter_cl(t4, y, (6, 6), idx, smap, None, None, "identity", packed, bias, cout, (3, 3), (1, 1),
+                                                       out, residual=y1, x1=x1 if block_res else None,
+                                                       table1=table1 if block_res else None, twins=tw)
+                assert o is not None
+                outs.append((o.clone(), tw[0][0]))
+            finally:
+                hip.TILE3 = None
+        torch.testing.assert_close(outs[0][0], outs[1][0], rtol=0, atol=2e-4)
+        torch.testing.assert_close(outs[0][1], outs[1][1], rtol=0, atol=2e-4)
+        # tile by tile against fp64: conv of the scatter-gathered window + bias + y1 (+ x1 - y1 where a shortcut tile covers the pixel)
+        sg = hip.scatter_gather_cl(t4, y, 6, 6, idx, smap)
+        conv = F.conv2d(sg.double(), w.double(), bias.double()).float()
+        tab = table1.cpu()
+        for n in (0, idx.shape[0] // 2, idx.shape[0] - 1):
+            h0, w0 = int(idx[n, 0]) + 1, int(idx[n, 1]) + 1
+            h1, w1 = min(h0 + 4, res), min(w0 + 4, res)
+            want = conv[n][:, :h1 - h0, :w1 - w0] + y1[0, :, h0:h1, w0:w1]
+            if block_res:
+                t1 = int(tab[h0 // 4, w0 // 4])
+                if t1 >= 0:
+                    want = want + (x1[t1][:, :h1 - h0, :w1 - w0] - y1[0, :, h0:h1, w0:w1])
+            torch.testing.assert_close(outs[0][0][0, :, h0:h1, w0:w1], want, rtol=0, atol=2e-4)
+        # pixels outside every tile keep what the buffer held
+        cover = torch.zeros(res, res, dtype=torch.bool)
+        for h0, w0 in idx.cpu().tolist():
+            cover[max(h0 + 1, 0):h0 + 5, max(w0 + 1, 0):w0 + 5] = True
+        assert torch.equal(outs[0][0][0][:, ~cover], cache_out[0][:, ~cover])
+
+
+def test_ddpm_forward_with_and_without_tile_conv3(hip):
+    """The whole sparse forward at a 15 % edit with every eligible launch on the v3 kernel (TILE3 = True) against the same
+    forward on conv_mfma.hpp only (TILE3 = False): fp32 summation order only."""
+    import bench
+    from sige_amd.utils import dilate_mask, downsample_mask
+    from sige_amd.workloads.ddpm_unet import DDPMConfig, DDPMSparseUNet
+
+    torch.manual_seed(0)
+    model = DDPMSparseUNet(DDPMConfig()).eval().to(DEV).to(memory_format=torch.channels_last)
+    model.set_scatter_inplace(True)
+    x0, noise = bench.make_inputs()
+    x0, noise, t = _cl(x0.to(DEV)), _cl(noise.to(DEV)), torch.zeros(1, device=DEV)
+    mask = bench.square_mask(0.15).to(DEV)
+    outs = {}
+    with torch.no_grad():
+        model.set_mode("full")
+        model(x0, t)
+        model.set_masks(downsample_mask(dilate_mask(mask, 5), 8))
+        model.set_mode("sparse")
+        x1 = x0 + noise * mask
+        for flag in (False, True, None):
+            hip.TILE3 = flag
+            try:
+                model(x1, t)
+                n0 = hip.launch_count()
+                outs[flag] = model(x1, t).clone()
+                launches = hip.launch_count() - n0
+            finally:
+                hip.TILE3 = None
+            assert launches <= 125
+    assert float((outs[True] - outs[False]).abs().max()) < 2e-4 * (1 + float(outs[False].abs().max()))
+    assert float((outs[None] - outs[False]).abs().max()) < 2e-4 * (1 + float(outs[False].abs().max()))
