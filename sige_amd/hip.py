@@ -816,8 +816,7 @@ def conv_pack_weights(weight: torch.Tensor, R: int, S: int, stride: Tuple[int, i
     fn = {"f16": lib().sige_hip_block_conv_pack_f16c, "f16x3": lib().sige_hip_block_conv_pack_f16x3,
           "f32": lib().sige_hip_block_conv_pack_f32}[compute]
     _check(fn(w.data_ptr(), Cout, Cin, kH, kW, packed.data_ptr(), _stream(w)), "conv_pack_weights")
-    if (compute == "f32" and (kH, kW) == (3, 3) and (R, S) == (6, 6) and tuple(stride) == (1, 1) and Cin % 64 == 0 and Cout % 64 == 0
-            and TILE3 is not False):
+    if compute == "f32" and (kH, kW) == (3, 3) and (R, S) == (6, 6) and tuple(stride) == (1, 1) and Cin % 64 == 0 and Cout % 64 == 0:
         # the same weights in the dense-layer kernel's exact-fp32 order: launches whose grid fills the chip run on the tile conv
         # with that kernel's K loop (csrc/conv_tile3.hpp; routed per launch by _tile3_route)
         packed.tile3 = wide_conv_pack_weights(w, "f32")

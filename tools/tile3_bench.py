@@ -31,7 +31,7 @@ def main():
     cl = lambda t_: t_.contiguous(memory_format=torch.channels_last)  # noqa: E731
     res = {"layers": [], "forward": []}
     torch.manual_seed(0)
-    for ratio in (0.012, 0.05, 0.15):
+    for ratio in (0.012, 0.05, 0.10, 0.15, 0.20):
         pyr = downsample_mask(dilate_mask(bench.square_mask(ratio).to(dev), 5), 8)
         for (R, C, Cout) in ((256, 128, 128), (128, 128, 128), (64, 256, 256)):
             m = pyr[(R, R)]
@@ -73,7 +73,7 @@ def main():
     with torch.no_grad():
         model.set_mode("full")
         model(x0, t)
-        for ratio in (0.012, 0.05, 0.15):
+        for ratio in (0.012, 0.05, 0.10, 0.15, 0.20):
             mask = bench.square_mask(ratio).to(dev)
             model.set_masks(downsample_mask(dilate_mask(mask, 5), 8))
             model.set_mode("sparse")
