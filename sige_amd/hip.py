@@ -1451,8 +1451,14 @@ def block_conv_cl(x, packed, bias, Cout: int, kernel: Tuple[int, int], stride: T
 
 # ---- tile conv v3 (csrc/conv_tile3.hpp): routing --------------------------------------------------------------------------
 # A launch takes the v3 kernel when its grid -- pairs of tiles x 64-channel output blocks -- has at least TILE3_MIN_BLOCKS
-# workgroups (two per CU: the kernel's start-up is longer than conv_mfma.hpp's, its K loop faster; measured by tools/tile3_bench.py,
-# profiles/r5*_tile3_bench.json).  TILE3: None = that rule | True = wherever the kernel exists | False = never (tests, A/B).
+# workgroups (two per CU) and no 1x1 shortcut is waiting to share the launch of a conv_mfma.hpp conv1 (conv_pair()).  Measured
+# (tools/tile3_bench.py, tools/tile3_router_bench.py, kernel traces of the forward; profiles/r5h_tile3_bench.json, r5i_tile3_router.json,
+# r5j_sequence_15pct_*.csv): launch by launch with L2-warm operands v3 is 1.05-1.26x conv_mfma.hpp from ~150 workgroups on
+# (gather + affine + SiLU -> tiles: 85-92 TFLOP/s = 0.54-0.58 of the fp32 MFMA peak at 834-1080 workgroups against 0.42-0.45)
+# and 0.5-0.9x below; INSIDE the DDPM forward at a 15 % edit the same launches gain 14 % (affine + SiLU staging: the activation
+# is computed once per 64 output channels instead of once per 32), 4 % (scatter_gather) and 0 % (raw gather), and a conv1 that
+# gives up its shared launch with the 1x1 shortcut loses what it gained -- so the forward moves by 0.5 % at 15 %, 1.3 % at 20 %,
+# 0.6 % with eight stacked edits.  TILE3: None = the rule | True = wherever the kernel exists | False = never (tests, A/B).
 TILE3 = None
 TILE3_MIN_BLOCKS = 512
 
@@ -1536,9 +1542,10 @@ def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, a
             if tuple(r.shape) != tuple(out.shape):
                 raise RuntimeError("gather_conv_cl: residual %s != output %s" % (tuple(r.shape), tuple(out.shape)))
         fargs = (1, full["offset"][0], full["offset"][1], None if r is None else r.data_ptr(), Ho, Wo)
-    # (inside conv_pair(): a held 1x1 shortcut is launched on its own by the v3 entry point -- one more launch, on a grid where
-    #  the launch is not what counts)
-    t3 = _tile3_route(packed, B * N, C1, C2, Cout, kernel, stride, block)
+    # (inside conv_pair() a held 1x1 shortcut shares the conv_mfma.hpp launch of this conv1: measured, keeping the pair beats
+    #  the v3 kernel + a launch of its own for the shortcut -- 46.7 vs 39.5 + 8.7 us at 15 % edit -- so v3 is not routed there
+    #  unless forced)
+    t3 = _tile3_route(packed, B * N, C1, C2, Cout, kernel, stride, block) if (TILE3 is True or getattr(_pair_state, "keep", None) is None) else None
     if t3 is not None and N > 0:
         if twins and full is None:
             raise RuntimeError("gather_conv_cl: twins need a full-tensor destination")

@@ -32,9 +32,14 @@ def main():
     ap.add_argument("--layout", default="nhwc", choices=["nhwc", "nchw"])
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "f16x3"], help="arithmetic of the convs (bench.py --dtype)")
     ap.add_argument("--ksplit", type=int, default=0, help="pin the cross-workgroup K split of the tile convs (hip.conv_force_ksplit; 0 = automatic)")
+    ap.add_argument("--tile3-min-blocks", type=int, default=None, help="sige_amd.hip.TILE3_MIN_BLOCKS (the tile conv v3's routing threshold)")
     ap.add_argument("--manifest", default="", help="eager mode: write the kernel-family sequence of one forward's conv launches here")
     a = ap.parse_args()
     dev = torch.device("cuda")
+    if a.tile3_min_blocks is not None:
+        from sige_amd import hip as _hip3
+
+        _hip3.TILE3_MIN_BLOCKS = a.tile3_min_blocks
     torch.backends.cudnn.benchmark = True
     torch.manual_seed(0)
     model = DDPMSparseUNet(DDPMConfig()).to(dev).eval()
