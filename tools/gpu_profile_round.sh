@@ -37,9 +37,14 @@ Q=$(ls "$OUT/${TAG}_pmc_sq"/*counter_collection.csv | head -1)
 python tools/pmc_traffic.py "$F" "$W" "$OUT/${TAG}_manifest.json" "$OUT/${TAG}_pmc_traffic.json" > "$OUT/${TAG}_pmc_traffic.txt" 2>&1
 F16=$(ls "$OUT/${TAG}_pmc_fetch_f16"/*counter_collection.csv | head -1); W16=$(ls "$OUT/${TAG}_pmc_write_f16"/*counter_collection.csv | head -1)
 python tools/pmc_traffic.py "$F16" "$W16" "$OUT/${TAG}_manifest_f16.json" "$OUT/${TAG}_pmc_traffic_f16.json" > "$OUT/${TAG}_pmc_traffic_f16.txt" 2>&1
+grep -E "Counter_Name|sige::conv|sige::attn" "$F16" | gzip > "$OUT/${TAG}_pmc_fetch_rows_f16.csv.gz"
+grep -E "Counter_Name|sige::conv|sige::attn" "$W16" | gzip > "$OUT/${TAG}_pmc_write_rows_f16.csv.gz"
 python tools/pmc_summary.py "$F16" "$OUT/${TAG}_pmc_fetch_size_per_kernel_f16.csv" sige::
 python tools/pmc_summary.py "$W16" "$OUT/${TAG}_pmc_write_size_per_kernel_f16.csv" sige::
 rm -rf "$OUT/${TAG}_pmc_fetch_f16" "$OUT/${TAG}_pmc_write_f16"
+# (the raw counter rows of the conv / attention kernels, so that the traffic tables can be re-derived without the GPU: tests/test_profiles.py)
+grep -E "Counter_Name|sige::conv|sige::attn" "$F" | gzip > "$OUT/${TAG}_pmc_fetch_rows.csv.gz"
+grep -E "Counter_Name|sige::conv|sige::attn" "$W" | gzip > "$OUT/${TAG}_pmc_write_rows.csv.gz"
 python tools/pmc_summary.py "$F" "$OUT/${TAG}_pmc_fetch_size_per_kernel.csv" sige::
 python tools/pmc_summary.py "$W" "$OUT/${TAG}_pmc_write_size_per_kernel.csv" sige::
 python tools/pmc_summary.py "$Q" "$OUT/${TAG}_pmc_sq_counters_per_kernel.csv" sige::
