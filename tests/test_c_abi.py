@@ -198,3 +198,33 @@ def test_launch_plan_slot_table_without_a_gpu():
         assert L.sige_hip_plan_run(p, 1, None) == 0          # (an empty section)
     finally:
         assert L.sige_hip_plan_destroy(p) == 0
+
+
+def test_plan_marks_count_arguments_on_unknown_pointers_without_a_gpu():
+    """a count argument recorded next to a pointer the plan does not own used to replay the RECORDED count under
+    every later mask, silently.  The hook runs before the entry point validates anything, so this needs no device: a
+    gather call with a null tensor (-> EINVAL) still records; its index-list pointer is unknown -> unbound + shape bound; bound to a
+    slot or registered as a constant -> neither; and a failed call can be truncated out of the plan."""
+    from sige_amd import hip
+
+    L = hip.lib()
+    gather = L.sige_hip_gather_nhwc_f32.fn  # (the raw ctypes function: no device guard)
+
+    def call(idx_ptr):
+        return gather(None, 1, 4, 8, 8, 6, 6, idx_ptr, 5, None, 0, 0, None, 0, 0, 0, None, None)
+
+    for bind, want_unbound in (("none", 1), ("slot", 0), ("const", 0)):
+        p = L.sige_hip_plan_create()
+        try:
+            if bind == "slot":
+                assert L.sige_hip_plan_new_slots(p, 1) == 0 and L.sige_hip_plan_bind_ptr(p, 0x3000, 0) == 0
+            elif bind == "const":
+                assert L.sige_hip_plan_bind_const(p, 0x3000) == 0
+            assert L.sige_hip_plan_begin(p, 1, 0) == 0
+            assert call(0x3000) == -1                      # (x is null: EINVAL -- after the hook stored the call)
+            assert L.sige_hip_plan_calls(p, 1) == 1
+            assert L.sige_hip_plan_truncate(p, 1, 0) == 0 and L.sige_hip_plan_calls(p, 1) == 0   # what hip._Guarded does on an error status
+            assert L.sige_hip_plan_end(p) == 0
+            assert L.sige_hip_plan_unbound(p) == want_unbound and L.sige_hip_plan_shape_bound(p) == (1 if want_unbound else 0)
+        finally:
+            assert L.sige_hip_plan_destroy(p) == 0
