@@ -817,9 +817,9 @@ def conv_pack_weights(weight: torch.Tensor, R: int, S: int, stride: Tuple[int, i
           "f32": lib().sige_hip_block_conv_pack_f32}[compute]
     _check(fn(w.data_ptr(), Cout, Cin, kH, kW, packed.data_ptr(), _stream(w)), "conv_pack_weights")
     if compute == "f32" and (kH, kW) == (3, 3) and (R, S) == (6, 6) and tuple(stride) == (1, 1) and Cin % 64 == 0 and Cout % 64 == 0:
-        # the same weights in the dense-layer kernel's exact-fp32 order: launches whose grid fills the chip run on the tile conv
-        # with that kernel's K loop (csrc/conv_tile3.hpp; routed per launch by _tile3_route)
-        packed.tile3 = wide_conv_pack_weights(w, "f32")
+        # the tile conv v3 (csrc/conv_tile3.hpp) reads the same weights in the dense-layer kernel's exact-fp32 order: packed on
+        # demand, the first time _tile3_route sends a launch there (the router is off by default)
+        packed._tile3_src = w
     return packed
 
 
@@ -1458,19 +1458,30 @@ def block_conv_cl(x, packed, bias, Cout: int, kernel: Tuple[int, int], stride: T
 # and 0.5-0.9x below; INSIDE the DDPM forward at a 15 % edit the same launches gain 14 % (affine + SiLU staging: the activation
 # is computed once per 64 output channels instead of once per 32), 4 % (scatter_gather) and 0 % (raw gather), and a conv1 that
 # gives up its shared launch with the 1x1 shortcut loses what it gained -- so the forward moves by 0.5 % at 15 %, 1.3 % at 20 %,
-# 0.6 % with eight stacked edits.  TILE3: None = the rule | True = wherever the kernel exists | False = never (tests, A/B).
+# 0.6 % with eight stacked edits.
+# DEFAULT: OFF (TILE3_MIN_BLOCKS = None).  For that half a percent the router would cost two guarantees the rest of the library
+# gives: a launch plan replays the entry point it RECORDED, so under a mask whose tile count crosses the threshold the plan and the
+# module-level forward would run different kernels (equal to 1e-5, not bit for bit: test_launch_plan_follows_mask_changes), and the
+# fp16-cache kernels (`_c16`) would no longer be bit-identical to the fp32-cache ones on the widened cache.  Opt in with
+# `sige_amd.hip.TILE3_MIN_BLOCKS = 512` (what the measurements above used); TILE3 = True forces v3 wherever the kernel exists,
+# False switches it off whatever the threshold (tests, A/B).
 TILE3 = None
-TILE3_MIN_BLOCKS = 512
+TILE3_MIN_BLOCKS = None
 
 
 def _tile3_route(packed, T: int, C1: int, C2: int, Cout: int, kernel, stride, block):
-    t3 = getattr(packed, "tile3", None)
-    if TILE3 is False or t3 is None or tuple(kernel) != (3, 3) or tuple(stride) != (1, 1) or tuple(block) != (6, 6):
+    if TILE3 is False or (TILE3 is None and TILE3_MIN_BLOCKS is None):
         return None
-    if C1 % 64 or C2 % 64 or Cout % 64:
+    if tuple(kernel) != (3, 3) or tuple(stride) != (1, 1) or tuple(block) != (6, 6) or C1 % 64 or C2 % 64 or Cout % 64:
         return None
     if TILE3 is None and -(-T // 2) * (Cout // 64) < TILE3_MIN_BLOCKS:
         return None
+    t3 = getattr(packed, "tile3", None)
+    if t3 is None:
+        src = getattr(packed, "_tile3_src", None)
+        if src is None or torch.cuda.is_current_stream_capturing():
+            return None  # (packing is a launch of its own: never inside a capture -- the warm-up forwards come first)
+        t3 = packed.tile3 = wide_conv_pack_weights(src, "f32")
     return t3
 
 

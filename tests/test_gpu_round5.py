@@ -347,7 +347,7 @@ def test_tile_conv3_gather_forms_vs_fp64(hip, c1, c2, cout, up):
     w = torch.randn(cout, C, 3, 3, device=DEV) / (3 * C ** 0.5)
     bias = torch.randn(cout, device=DEV)
     packed = hip.conv_pack_weights(w, 6, 6, (1, 1))
-    assert getattr(packed, "tile3", None) is not None
+    assert getattr(packed, "_tile3_src", None) is not None  # (the v3 layout is packed on demand)
     conv = lambda t: F.conv2d(t.double(), w.double(), bias.double()).float()  # noqa: E731
     Bs = 1 if c2 else B  # (a fused cat is per image)
     xs = x[:Bs]
@@ -490,14 +490,15 @@ def test_ddpm_forward_with_and_without_tile_conv3(hip):
         model.set_mode("sparse")
         x1 = x0 + noise * mask
         for flag in (False, True, None):
-            hip.TILE3 = flag
+            hip.TILE3, keep_th = flag, hip.TILE3_MIN_BLOCKS
+            hip.TILE3_MIN_BLOCKS = 512 if flag is None else keep_th  # (None: the opt-in routing rule the measurements used)
             try:
                 model(x1, t)
                 n0 = hip.launch_count()
                 outs[flag] = model(x1, t).clone()
                 launches = hip.launch_count() - n0
             finally:
-                hip.TILE3 = None
+                hip.TILE3, hip.TILE3_MIN_BLOCKS = None, keep_th
             assert launches <= 135  # (102; with TILE3 = True the 1x1 shortcuts of the pairs run as launches of their own)
     assert float((outs[True] - outs[False]).abs().max()) < 2e-4 * (1 + float(outs[False].abs().max()))
     assert float((outs[None] - outs[False]).abs().max()) < 2e-4 * (1 + float(outs[False].abs().max()))

@@ -79,6 +79,7 @@ def main():
             model.set_mode("sparse")
             x1 = x0 + noise * mask
             row = {"edit_ratio": ratio}
+            hip.TILE3_MIN_BLOCKS = 512  # (the opt-in routing rule; the library's default is None = never)
             for tag, flag in (("conv_mfma_only", False), ("tile3_everywhere", True), ("router", None)):
                 hip.TILE3 = flag
                 try:
