@@ -49,7 +49,8 @@ def block():
     f16, sd, gl = load("r5_bench_f16_detail.json"), load("r5_bench_sd_detail.json"), load("r5_bench_2ranks_gloo_detail.json")
     out = []
     out.append("Source: `profiles/r5_bench.json` (the <= 4 KB contract line as the driver reads it), `profiles/r5_bench_detail.json` (everything), "
-               "`r5_bench_f16*`, `r5_bench_sd*`, `r5_bench_2ranks_gloo*`; kernel sources `%s`." % g(det, "roofline", "source_hash", default=g(det, "source_hash", default="?")))
+               "`r5_bench_f16*`, `r5_bench_sd*`, `r5_bench_2ranks_gloo*`; kernel sources `%s` (= `sige_amd.build.source_hash()`, the hash `profiles/pmc_traffic.json` "
+               "was measured on)." % g(load("pmc_traffic.json"), "source_hash", default="?"))
     out.append("")
     out.append("| DDPM-256 sparse forward, 1×MI355X, exact fp32 | value |")
     out.append("|---|---|")
