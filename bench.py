@@ -1023,34 +1023,34 @@ def main():
                               "dense_remainder_us": kern_r.get("dense_conv_mfma", {}).get("us_total")})
                 del gs, tr, outs
 
-        # ---- the opt-in tile conv v3 (csrc/conv_tile3.hpp; sige_amd.hip.TILE3_MIN_BLOCKS, default None = never): the same forward
-        #      with every launch of >= 512 v3 workgroups routed there, at the edit ratios where such launches exist ----
+        # ---- the tile conv v3 (csrc/conv_tile3.hpp): routed by the library from sige_amd.hip.TILE3_MIN_BLOCKS = 512 v3 workgroups on
+        #      (decided in C per launch); the same forward with the router off, at the edit ratios where launches reach the threshold ----
         tile3 = None
         if rank == 0 and world == 1 and args.dtype == "f32" and args.layout == "nhwc" and args.sweep and not args.no_extras:
             rows3 = []
+            keep3 = hip.TILE3_MIN_BLOCKS
             try:
                 for r in (0.15, 0.20):
                     xs = prepare(r)
                     row = {"edit_ratio": r}
-                    for tag, th in (("default", None), ("routed_from_512_workgroups", 512)):
+                    for tag, th in (("router_off", 1 << 30), ("default", keep3)):
                         hip.TILE3_MIN_BLOCKS = th
                         model(xs, t)
                         model(xs, t)
                         gs, outs = capture(model, xs, t)
                         row[tag + "_ms"] = round(timed_replays(gs, 20, 5, 1) * 1e3 / 20, 4)
-                        if th is None:
+                        if tag == "router_off":
                             base3 = outs.clone()
                         else:
-                            row["max_abs_vs_default"] = round(float((outs - base3).abs().max()), 8)
+                            row["max_abs_vs_router_off"] = round(float((outs - base3).abs().max()), 8)
                         del gs, outs
                     rows3.append(row)
-                tile3 = {"rows": rows3, "note": "off by default: the gain is inside half a percent of a forward and would cost the bit-for-bit "
-                                                "equality of launch plans / fp16-cache kernels with the module path (sige_amd/hip.py: TILE3_MIN_BLOCKS); "
-                                                "launch by launch: profiles/r5h_tile3_bench.json"}
+                tile3 = {"min_blocks": keep3, "rows": rows3,
+                         "note": "launch by launch: profiles/r5h_tile3_bench.json; in the forward: profiles/r5j_sequence_15pct_*.csv"}
             except Exception as e:
                 tile3 = {"error": repr(e)[:300]}
             finally:
-                hip.TILE3_MIN_BLOCKS = None
+                hip.TILE3_MIN_BLOCKS = keep3
             prepare(args.ratio)
 
         # ---- f16 compute (BASELINE.json configs[4]): the same forward with fp16 operands on the fp16 matrix cores ----
@@ -1606,7 +1606,7 @@ def main():
                 # forward_ms_eager = the same launches issued one by one from Python through ctypes
                 line["forward_ms_eager_launch_plan"] = plan_row["forward_ms_issued_from_c"]
         if tile3 is not None:
-            line["tile_conv3_opt_in"] = tile3
+            line["tile_conv3"] = tile3
         if batched is not None:
             line["batched_edits"] = batched
         line.update(extras)

@@ -491,6 +491,39 @@ int sige_hip_tile_conv3_nhwc_f32(
         float *twin1, const float *twin_scale1, const float *twin_shift1,
         float *out, void *stream);
 
+/* ... and the two entry points the sparse forward actually calls: sige_hip_gather_conv_nhwc_f32 / sige_hip_scatter_gather_conv_scatter_nhwc_f32
+ * with the weights in the v3 layout (`packed_tile3`, may be NULL) and a threshold beside them.  A launch whose v3 grid (tile pairs x
+ * 64-channel output blocks) has >= min_blocks workgroups -- and that is not about to share its launch with a held 1x1 shortcut
+ * (sige_hip_conv_pair_begin) -- runs on the v3 kernel; every other launch exactly as the plain entry point.  The decision is
+ * taken HERE, from N, so that a launch plan (which replays the recorded entry point with the new mask's count) routes like the
+ * module-level forward under that mask: the two stay bit-identical.  min_blocks <= 0 or packed_tile3 == NULL: never. */
+int sige_hip_gather_conv_nhwc_v3_f32(const float *x, const float *x2, int B, int C1, int C2, int H, int W,
+                                     int bH, int bW, const int32_t *active_indices, int N,
+                                     const float *scale, int scaleB, int scaleC,
+                                     const float *shift, int shiftB, int shiftC,
+                                     int activation,
+                                     const float *packed, const float *bias, int Cout, int kH, int kW,
+                                     int strideH, int strideW,
+                                     int to_full, int offsetH, int offsetW, const float *residual, int Ho, int Wo,
+                                     float *workspace, size_t workspace_floats,
+                                     const float *out_scale, const float *out_shift, int out_activation,
+                                     int upsample2x,
+                                     float *twin0, const float *twin0_scale, const float *twin0_shift,
+                                     float *twin1, const float *twin1_scale, const float *twin1_shift,
+                                     const float *packed_tile3, int min_blocks,
+                                     float *out, void *stream);
+int sige_hip_scatter_gather_conv_scatter_nhwc_v3_f32(
+        const float *x, const float *y, int B, int Cin, int H, int W, int Rx, int Sx, int bH, int bW,
+        const int32_t *active_indices, int N, const int32_t *scatter_map,
+        const float *scale, int scaleB, int scaleC, const float *shift, int shiftB, int shiftC, int activation,
+        const float *packed, const float *bias, int Cout, int kH, int kW,
+        int offsetH, int offsetW, const float *residual,
+        const float *x1, const int32_t *table1, int gH1, int gW1, int N1, int R1, int S1,
+        float *twin0, const float *twin0_scale, const float *twin0_shift,
+        float *twin1, const float *twin1_scale, const float *twin1_shift,
+        const float *packed_tile3, int min_blocks,
+        float *out, void *stream);
+
 /* ---- 3x3 / padding-1 conv with <= 4 output channels over a full channels-last tensor
  * (the U-Net's conv_out after norm_out + SiLU, sige_fused_unet.py:430-434, which the
  * reference runs densely in sparse mode too): out [B,H,W,Cout] = conv(act(scale*x + shift)),

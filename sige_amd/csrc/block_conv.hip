@@ -9,6 +9,7 @@
 #include <mutex>
 
 #include "conv_mfma.hpp"
+#include "conv_tile3.hpp"  // (tile_conv3_launch: the routing entry points at the end of this file)
 
 namespace sige {
 
@@ -1325,3 +1326,73 @@ extern "C" int sige_hip_block_conv_direct_f32(const float *x, int T, int Cin, in
 }
 
 extern "C" int sige_hip_release_graph_tickets(void) { return sige::release_graph_tickets(); }
+
+// ---- routing entry points: conv_mfma.hpp or the tile conv v3 (conv_tile3.hpp), decided HERE from the tile count ----
+// The same calls as sige_hip_gather_conv_nhwc_f32 / sige_hip_scatter_gather_conv_scatter_nhwc_f32 plus the weights in the v3
+// layout and a threshold: a launch whose v3 grid -- tile pairs x 64-channel output blocks -- has at least `min_blocks` workgroups
+// runs on the v3 kernel, anything else exactly as before.  The decision is taken in C so that a launch plan, which replays the
+// recorded ENTRY POINT under a new mask's tile count, routes like the module-level forward under that mask does: plan and
+// module path stay bit-identical (round 5: the first router lived in Python and test_launch_plan_follows_mask_changes caught
+// the two running different kernels).
+static bool tile3_takes(const float *packed_tile3, int min_blocks, int B, int N, int C1, int C2, int Cout, int kH, int kW, int bH, int bW,
+                        int strideH, int strideW, hipStream_t st) {
+    if (!packed_tile3 || min_blocks <= 0) return false;
+    if (kH != 3 || kW != 3 || bH != 6 || bW != 6 || strideH != 1 || strideW != 1) return false;
+    if (!sige_hip_tile_conv3_supported(C1, C2, Cout)) return false;
+    if ((long)((B * (long)N + 1) / 2) * (Cout / 64) < min_blocks) return false;
+    // a 1x1 shortcut held by conv_pair_begin() shares the conv_mfma.hpp launch of this conv1: keeping the pair beats the v3 kernel
+    // plus a launch of its own for the shortcut (46.7 vs 39.5 + 8.7 us at a 15 % edit: profiles/r5j_sequence_15pct_*.csv)
+    if (g_held.active && g_held.st == st) return false;
+    return true;
+}
+
+extern "C" int sige_hip_gather_conv_nhwc_v3_f32(const float *x, const float *x2, int B, int C1, int C2, int H, int W,
+                                                int bH, int bW, const int32_t *active_indices, int N,
+                                                const float *scale, int scaleB, int scaleC,
+                                                const float *shift, int shiftB, int shiftC,
+                                                int activation,
+                                                const float *packed, const float *bias, int Cout, int kH, int kW,
+                                                int strideH, int strideW,
+                                                int to_full, int offsetH, int offsetW, const float *residual, int Ho, int Wo,
+                                                float *workspace, size_t workspace_floats,
+                                                const float *out_scale, const float *out_shift, int out_activation,
+                                                int upsample2x,
+                                                float *twin0, const float *twin0_scale, const float *twin0_shift,
+                                                float *twin1, const float *twin1_scale, const float *twin1_shift,
+                                                const float *packed_tile3, int min_blocks,
+                                                float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_gather_conv_nhwc_v3_f32, (sige::CountOf<9, 10>), x, x2, B, C1, C2, H, W, bH, bW, active_indices, N, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, packed, bias, Cout, kH, kW, strideH, strideW, to_full, offsetH, offsetW, residual, Ho, Wo, workspace, workspace_floats, out_scale, out_shift, out_activation, upsample2x, twin0, twin0_scale, twin0_shift, twin1, twin1_scale, twin1_shift, packed_tile3, min_blocks, out, stream);
+    const int Cin = C1 + C2;
+    const bool aff_ok = (!scale && !shift) || (scale && shift && scaleC == Cin && shiftC == Cin && scaleB == shiftB && (scaleB == 1 || scaleB == B));
+    if (B > 0 && N > 0 && aff_ok && tile3_takes(packed_tile3, min_blocks, B, N, C1, C2, Cout, kH, kW, bH, bW, strideH, strideW, as_stream(stream))) {
+        const int rc = tile_conv3_launch(T3_GATHER, x, x2, B, C1, C2, H, W, upsample2x, active_indices, N, nullptr, 0, 0, scale, shift,
+                                         scale ? scaleB : 0, activation, packed_tile3, bias, Cout, to_full, offsetH, offsetW, Ho, Wo,
+                                         to_full ? residual : nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, out_scale, out_shift, out_activation,
+                                         twin0, twin0_scale, twin0_shift, twin1, twin1_scale, twin1_shift, out, stream);
+        if (rc != SIGE_HIP_EUNSUPPORTED) return rc;
+    }
+    return gather_conv_nhwc_impl<0>(SIGE_GATHER_CONV_ARGS);
+}
+
+extern "C" int sige_hip_scatter_gather_conv_scatter_nhwc_v3_f32(
+        const float *x, const float *y, int B, int Cin, int H, int W, int Rx, int Sx, int bH, int bW,
+        const int32_t *active_indices, int N, const int32_t *scatter_map,
+        const float *scale, int scaleB, int scaleC, const float *shift, int shiftB, int shiftC, int activation,
+        const float *packed, const float *bias, int Cout, int kH, int kW,
+        int offsetH, int offsetW, const float *residual,
+        const float *x1, const int32_t *table1, int gH1, int gW1, int N1, int R1, int S1,
+        float *twin0, const float *twin0_scale, const float *twin0_shift,
+        float *twin1, const float *twin1_scale, const float *twin1_shift,
+        const float *packed_tile3, int min_blocks,
+        float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_scatter_gather_conv_scatter_nhwc_v3_f32, (sige::CountOf<10, 11>, sige::CountOf<29, 32>), x, y, B, Cin, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, packed, bias, Cout, kH, kW, offsetH, offsetW, residual, x1, table1, gH1, gW1, N1, R1, S1, twin0, twin0_scale, twin0_shift, twin1, twin1_scale, twin1_shift, packed_tile3, min_blocks, out, stream);
+    if (B > 0 && N > 0 && !scale && !shift && activation == SIGE_HIP_ACT_IDENTITY &&
+        tile3_takes(packed_tile3, min_blocks, B, N, Cin, 0, Cout, kH, kW, bH, bW, 1, 1, as_stream(stream))) {
+        const int rc = tile_conv3_launch(T3_SCATTER_GATHER, x, y, B, Cin, 0, H, W, 0, active_indices, N, scatter_map, Rx, Sx, nullptr, nullptr, 0,
+                                         SIGE_HIP_ACT_IDENTITY, packed_tile3, bias, Cout, 1, offsetH, offsetW, H, W, residual,
+                                         x1, table1, gH1, gW1, N1, R1, S1, nullptr, nullptr, 0,
+                                         twin0, twin0_scale, twin0_shift, twin1, twin1_scale, twin1_shift, out, stream);
+        if (rc != SIGE_HIP_EUNSUPPORTED) return rc;
+    }
+    return scatter_gather_conv_scatter_nhwc_impl<0>(SIGE_SGS_CONV_ARGS);
+}

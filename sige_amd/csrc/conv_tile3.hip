@@ -14,7 +14,8 @@ extern "C" int sige_hip_tile_conv3_supported(int C1, int C2, int Cout) {
     return (C1 > 0 && C2 >= 0 && C1 % 64 == 0 && C2 % 64 == 0 && Cout > 0 && Cout % 64 == 0) ? 1 : 0;
 }
 
-extern "C" int sige_hip_tile_conv3_nhwc_f32(
+// (no plan hook: the extern "C" wrapper below and the routing entry points of block_conv.hip record themselves)
+int sige::tile_conv3_launch(
         int source, const float *x, const float *x2, int B, int C1, int C2, int H, int W, int upsample2x,
         const int32_t *active_indices, int N, const int32_t *scatter_map, int Rx, int Sx,
         const float *scale, const float *shift, int affineB, int activation,
@@ -25,7 +26,6 @@ extern "C" int sige_hip_tile_conv3_nhwc_f32(
         float *twin0, const float *twin_scale0, const float *twin_shift0,
         float *twin1, const float *twin_scale1, const float *twin_shift1,
         float *out, void *stream) {
-    SIGE_PLAN_HOOK_N(sige_hip_tile_conv3_nhwc_f32, (sige::CountOf<9, 10>, sige::CountOf<28, 31>), source, x, x2, B, C1, C2, H, W, upsample2x, active_indices, N, scatter_map, Rx, Sx, scale, shift, affineB, activation, packed, bias, Cout, to_full, offsetH, offsetW, Ho, Wo, residual, x1, table1, gH1, gW1, N1, R1, S1, out_scale, out_shift, out_activation, twin0, twin_scale0, twin_shift0, twin1, twin_scale1, twin_shift1, out, stream);
     if (source != T3_GATHER && source != T3_SCATTER_GATHER) return SIGE_HIP_EINVAL;
     if (B < 0 || N < 0 || C1 <= 0 || C2 < 0 || Cout <= 0 || H <= 0 || W <= 0) return SIGE_HIP_EINVAL;
     if ((long)B * N == 0) return SIGE_HIP_OK;
@@ -69,4 +69,21 @@ extern "C" int sige_hip_tile_conv3_nhwc_f32(
     if (sg) launch_conv_tile3_sg<2>(a, to_full != 0, st);
     else launch_conv_tile3_gather<2>(a, scale != nullptr, C2 > 0, to_full != 0, st);
     return launch_status(1);
+}
+
+extern "C" int sige_hip_tile_conv3_nhwc_f32(
+        int source, const float *x, const float *x2, int B, int C1, int C2, int H, int W, int upsample2x,
+        const int32_t *active_indices, int N, const int32_t *scatter_map, int Rx, int Sx,
+        const float *scale, const float *shift, int affineB, int activation,
+        const float *packed, const float *bias, int Cout,
+        int to_full, int offsetH, int offsetW, int Ho, int Wo, const float *residual,
+        const float *x1, const int32_t *table1, int gH1, int gW1, int N1, int R1, int S1,
+        const float *out_scale, const float *out_shift, int out_activation,
+        float *twin0, const float *twin_scale0, const float *twin_shift0,
+        float *twin1, const float *twin_scale1, const float *twin_shift1,
+        float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_tile_conv3_nhwc_f32, (sige::CountOf<9, 10>, sige::CountOf<28, 31>), source, x, x2, B, C1, C2, H, W, upsample2x, active_indices, N, scatter_map, Rx, Sx, scale, shift, affineB, activation, packed, bias, Cout, to_full, offsetH, offsetW, Ho, Wo, residual, x1, table1, gH1, gW1, N1, R1, S1, out_scale, out_shift, out_activation, twin0, twin_scale0, twin_shift0, twin1, twin_scale1, twin_shift1, out, stream);
+    return tile_conv3_launch(source, x, x2, B, C1, C2, H, W, upsample2x, active_indices, N, scatter_map, Rx, Sx, scale, shift, affineB, activation,
+                             packed, bias, Cout, to_full, offsetH, offsetW, Ho, Wo, residual, x1, table1, gH1, gW1, N1, R1, S1,
+                             out_scale, out_shift, out_activation, twin0, twin_scale0, twin_shift0, twin1, twin_scale1, twin_shift1, out, stream);
 }

@@ -382,6 +382,18 @@ __global__ __launch_bounds__(256, G::OCC) void conv_tile3_kernel(const Tile3Args
     conv_tile3_body<G, SRC, AFF, CAT, FULL>(a, blockIdx.x, smem);
 }
 
+// the host side of a v3 launch (conv_tile3.hip): argument checks, Tile3Args, launch.  SIGE_HIP_EUNSUPPORTED: the caller falls back
+int tile_conv3_launch(int source, const float *x, const float *x2, int B, int C1, int C2, int H, int W, int upsample2x,
+                      const int32_t *active_indices, int N, const int32_t *scatter_map, int Rx, int Sx,
+                      const float *scale, const float *shift, int affineB, int activation,
+                      const float *packed, const float *bias, int Cout,
+                      int to_full, int offsetH, int offsetW, int Ho, int Wo, const float *residual,
+                      const float *x1, const int32_t *table1, int gH1, int gW1, int N1, int R1, int S1,
+                      const float *out_scale, const float *out_shift, int out_activation,
+                      float *twin0, const float *twin_scale0, const float *twin_shift0,
+                      float *twin1, const float *twin_scale1, const float *twin_shift1,
+                      float *out, void *stream);
+
 // launchers (instantiated in conv_tile3_*.hip)
 template <int TPW>
 void launch_conv_tile3_gather(const Tile3Args &a, bool aff, bool cat, bool full, hipStream_t st);

@@ -86,6 +86,13 @@ _SIGNATURES = {
         _c_int, [_c_vp, _c_vp] + [_c_int] * 7 + [_c_vp, _c_int] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
         + [_c_int] * 5 + [_c_int, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_vp, _c_sz, _c_vp, _c_vp, _c_int, _c_int] + [_c_vp] * 6
         + [_c_vp, _c_vp]),
+    "sige_hip_gather_conv_nhwc_v3_f32": (
+        _c_int, [_c_vp, _c_vp] + [_c_int] * 7 + [_c_vp, _c_int] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
+        + [_c_int] * 5 + [_c_int, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_vp, _c_sz, _c_vp, _c_vp, _c_int, _c_int] + [_c_vp] * 6
+        + [_c_vp, _c_int] + [_c_vp, _c_vp]),
+    "sige_hip_scatter_gather_conv_scatter_nhwc_v3_f32": (
+        _c_int, [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
+        + [_c_int] * 3 + [_c_int, _c_int, _c_vp] + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp] * 6 + [_c_vp, _c_int] + [_c_vp, _c_vp]),
     "sige_hip_conv_ksplit_hint": (_c_int, [_c_int] * 7),
     "sige_hip_block_conv_nhwc_f16c": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp, _c_vp]),
     "sige_hip_gather_conv_nhwc_f16c": (
@@ -817,9 +824,12 @@ def conv_pack_weights(weight: torch.Tensor, R: int, S: int, stride: Tuple[int, i
           "f32": lib().sige_hip_block_conv_pack_f32}[compute]
     _check(fn(w.data_ptr(), Cout, Cin, kH, kW, packed.data_ptr(), _stream(w)), "conv_pack_weights")
     if compute == "f32" and (kH, kW) == (3, 3) and (R, S) == (6, 6) and tuple(stride) == (1, 1) and Cin % 64 == 0 and Cout % 64 == 0:
-        # the tile conv v3 (csrc/conv_tile3.hpp) reads the same weights in the dense-layer kernel's exact-fp32 order: packed on
-        # demand, the first time _tile3_route sends a launch there (the router is off by default)
+        # the tile conv v3 (csrc/conv_tile3.hpp) reads the same weights in the dense-layer kernel's exact-fp32 order.  Packed HERE when
+        # the router is on, whatever the first mask's tile count: the routing entry points decide per launch, in C, from the
+        # count -- also when a launch plan replays this call under a larger mask later
         packed._tile3_src = w
+        if TILE3 is not False and TILE3_MIN_BLOCKS is not None:
+            packed.tile3 = wide_conv_pack_weights(w, "f32")
     return packed
 
 
@@ -1450,31 +1460,26 @@ def block_conv_cl(x, packed, bias, Cout: int, kernel: Tuple[int, int], stride: T
 
 
 # ---- tile conv v3 (csrc/conv_tile3.hpp): routing --------------------------------------------------------------------------
-# A launch takes the v3 kernel when its grid -- pairs of tiles x 64-channel output blocks -- has at least TILE3_MIN_BLOCKS
-# workgroups (two per CU) and no 1x1 shortcut is waiting to share the launch of a conv_mfma.hpp conv1 (conv_pair()).  Measured
-# (tools/tile3_bench.py, tools/tile3_router_bench.py, kernel traces of the forward; profiles/r5h_tile3_bench.json, r5i_tile3_router.json,
-# r5j_sequence_15pct_*.csv): launch by launch with L2-warm operands v3 is 1.05-1.26x conv_mfma.hpp from ~150 workgroups on
-# (gather + affine + SiLU -> tiles: 85-92 TFLOP/s = 0.54-0.58 of the fp32 MFMA peak at 834-1080 workgroups against 0.42-0.45)
-# and 0.5-0.9x below; INSIDE the DDPM forward at a 15 % edit the same launches gain 14 % (affine + SiLU staging: the activation
-# is computed once per 64 output channels instead of once per 32), 4 % (scatter_gather) and 0 % (raw gather), and a conv1 that
-# gives up its shared launch with the 1x1 shortcut loses what it gained -- so the forward moves by 0.5 % at 15 %, 1.3 % at 20 %,
-# 0.6 % with eight stacked edits.
-# DEFAULT: OFF (TILE3_MIN_BLOCKS = None).  For that half a percent the router would cost two guarantees the rest of the library
-# gives: a launch plan replays the entry point it RECORDED, so under a mask whose tile count crosses the threshold the plan and the
-# module-level forward would run different kernels (equal to 1e-5, not bit for bit: test_launch_plan_follows_mask_changes), and the
-# fp16-cache kernels (`_c16`) would no longer be bit-identical to the fp32-cache ones on the widened cache.  Opt in with
-# `sige_amd.hip.TILE3_MIN_BLOCKS = 512` (what the measurements above used); TILE3 = True forces v3 wherever the kernel exists,
-# False switches it off whatever the threshold (tests, A/B).
+# The two calls a sparse forward makes for its 3x3 convs -- gather -> conv and scatter_gather -> conv -> scatter -- go through
+# the ROUTING entry points (sige_hip_*_v3_f32): the same arguments plus the weights in the v3 layout and TILE3_MIN_BLOCKS; a launch
+# whose v3 grid -- tile pairs x 64-channel output blocks -- has at least that many workgroups, and that is not about to share its
+# launch with a held 1x1 shortcut (conv_pair()), runs on the v3 kernel, every other launch on conv_mfma.hpp as before.  The
+# decision is taken in C from the tile count, so a launch plan replaying the call under another mask routes like the module path.
+# Measured (tools/tile3_bench.py, tools/tile3_router_bench.py, kernel traces of the forward; profiles/r5h_tile3_bench.json,
+# r5i_tile3_router.json, r5j_sequence_15pct_*.csv, r5_bench_detail.json: tile_conv3): launch by launch with warm operands v3 is
+# 1.05-1.26x conv_mfma.hpp from ~150 workgroups on (gather + affine + SiLU -> tiles: 85-92 TFLOP/s = 0.54-0.58 of the fp32 MFMA peak
+# at 834-1080 workgroups against 0.42-0.45) and 0.5-0.9x below; INSIDE the DDPM forward at a 15 % edit the same launches gain 14 %
+# (affine + SiLU staging: the activation is computed once per 64 output channels instead of once per 32), 4 % (scatter_gather)
+# and 0 % (raw gather): the forward moves by 1 % at 15 %, 2 % at 20 %, nothing at 1.2 % and 5 % (no launch reaches the threshold).
+# TILE3_MIN_BLOCKS = None switches the router off (no v3 weights are packed); TILE3 = False does the same per call (tests, A/B);
+# TILE3 = True sends every eligible call to sige_hip_tile_conv3_nhwc_f32 directly, whatever its grid (tests, tools/tile3_bench.py).
 TILE3 = None
-TILE3_MIN_BLOCKS = None
+TILE3_MIN_BLOCKS = 512
 
 
-def _tile3_route(packed, T: int, C1: int, C2: int, Cout: int, kernel, stride, block):
+def _tile3_packed(packed):
+    """The v3 layout of `packed`'s weights (packing it on demand), or None when the router is off / the shape has no v3 kernel."""
     if TILE3 is False or (TILE3 is None and TILE3_MIN_BLOCKS is None):
-        return None
-    if tuple(kernel) != (3, 3) or tuple(stride) != (1, 1) or tuple(block) != (6, 6) or C1 % 64 or C2 % 64 or Cout % 64:
-        return None
-    if TILE3 is None and -(-T // 2) * (Cout // 64) < TILE3_MIN_BLOCKS:
         return None
     t3 = getattr(packed, "tile3", None)
     if t3 is None:
@@ -1483,6 +1488,15 @@ def _tile3_route(packed, T: int, C1: int, C2: int, Cout: int, kernel, stride, bl
             return None  # (packing is a launch of its own: never inside a capture -- the warm-up forwards come first)
         t3 = packed.tile3 = wide_conv_pack_weights(src, "f32")
     return t3
+
+
+def _tile3_route(packed, T: int, C1: int, C2: int, Cout: int, kernel, stride, block):
+    """TILE3 = True only: the v3 weights if this call can run on the v3 kernel at all (the forced form of the tests and tools)."""
+    if TILE3 is not True:
+        return None
+    if tuple(kernel) != (3, 3) or tuple(stride) != (1, 1) or tuple(block) != (6, 6) or C1 % 64 or C2 % 64 or Cout % 64:
+        return None
+    return _tile3_packed(packed)
 
 
 def tile_conv3_cl(source: int, x, x2, B, C1, C2, H, W, up, idx, smap, rx_sx, scale, shift, activationName, t3, bias, Cout,
@@ -1553,10 +1567,7 @@ def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, a
             if tuple(r.shape) != tuple(out.shape):
                 raise RuntimeError("gather_conv_cl: residual %s != output %s" % (tuple(r.shape), tuple(out.shape)))
         fargs = (1, full["offset"][0], full["offset"][1], None if r is None else r.data_ptr(), Ho, Wo)
-    # (inside conv_pair() a held 1x1 shortcut shares the conv_mfma.hpp launch of this conv1: measured, keeping the pair beats
-    #  the v3 kernel + a launch of its own for the shortcut -- 46.7 vs 39.5 + 8.7 us at 15 % edit -- so v3 is not routed there
-    #  unless forced)
-    t3 = _tile3_route(packed, B * N, C1, C2, Cout, kernel, stride, block) if (TILE3 is True or getattr(_pair_state, "keep", None) is None) else None
+    t3 = _tile3_route(packed, B * N, C1, C2, Cout, kernel, stride, block)  # (TILE3 = True: the v3 kernel, forced)
     if t3 is not None and N > 0:
         if twins and full is None:
             raise RuntimeError("gather_conv_cl: twins need a full-tensor destination")
@@ -1597,10 +1608,17 @@ def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, a
         raise RuntimeError("gather_conv_cl: twins need a full-tensor destination")
     targs, twin_keep = _twin_args(twins if twins else None, out, Cout, "gather_conv_cl")
     fargs = fargs + (int(bool(upsample2x)), *targs)
-    status = _conv_fn("sige_hip_gather_conv_nhwc", packed)(
-        x.data_ptr(), None if x2 is None else x2.data_ptr(), B, C1, C2, H, W, block[0], block[1], idx.data_ptr(), N,
-        *sa, *ta, _act(activationName), packed.data_ptr(), _p(bias_keep), Cout, kernel[0], kernel[1],
-        stride[0], stride[1], *fargs, out.data_ptr(), _stream(x))
+    t3r = _tile3_packed(packed) if (TILE3 is None and getattr(packed, "compute", "f32") == "f32") else None
+    if t3r is not None:  # (the routing entry point: conv_mfma.hpp or the v3 kernel, decided in C from N)
+        status = lib().sige_hip_gather_conv_nhwc_v3_f32(
+            x.data_ptr(), None if x2 is None else x2.data_ptr(), B, C1, C2, H, W, block[0], block[1], idx.data_ptr(), N,
+            *sa, *ta, _act(activationName), packed.data_ptr(), _p(bias_keep), Cout, kernel[0], kernel[1],
+            stride[0], stride[1], *fargs, t3r.data_ptr(), int(TILE3_MIN_BLOCKS), out.data_ptr(), _stream(x))
+    else:
+        status = _conv_fn("sige_hip_gather_conv_nhwc", packed)(
+            x.data_ptr(), None if x2 is None else x2.data_ptr(), B, C1, C2, H, W, block[0], block[1], idx.data_ptr(), N,
+            *sa, *ta, _act(activationName), packed.data_ptr(), _p(bias_keep), Cout, kernel[0], kernel[1],
+            stride[0], stride[1], *fargs, out.data_ptr(), _stream(x))
     if status == UNSUPPORTED:
         return None
     _check(status, "gather_conv_cl")
@@ -1671,10 +1689,14 @@ def scatter_gather_conv_scatter_cl(x, y, block, activeIndices, scatterMap, scale
     head = (x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3], block[0], block[1], idx.data_ptr(), idx.shape[0],
             smap.data_ptr(), *sa, *ta, _act(activationName), packed.data_ptr(), _p(bias_keep), Cout, kernel[0], kernel[1],
             offset[0], offset[1], None if r is None else r.data_ptr())
+    t3r = _tile3_packed(packed) if (TILE3 is None and getattr(packed, "compute", "f32") == "f32" and y.dtype == torch.float32) else None
     if y.dtype == torch.float16:  # (fp16-stored caches)
         status = lib().sige_hip_scatter_gather_conv_scatter_nhwc_c16(
             _COMPUTE_ID[getattr(packed, "compute", "f32")], *head, int(r is not None and r.dtype == torch.float16), *bargs, *targs,
             out.data_ptr(), _stream(y))
+    elif t3r is not None:  # (the routing entry point: conv_mfma.hpp or the v3 kernel, decided in C from N)
+        status = lib().sige_hip_scatter_gather_conv_scatter_nhwc_v3_f32(*head, *bargs, *targs, t3r.data_ptr(), int(TILE3_MIN_BLOCKS),
+                                                                        out.data_ptr(), _stream(y))
     else:
         status = _conv_fn("sige_hip_scatter_gather_conv_scatter_nhwc", packed)(*head, *bargs, *targs, out.data_ptr(), _stream(y))
     if status == UNSUPPORTED:
