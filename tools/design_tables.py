@@ -86,6 +86,14 @@ def block():
     for row in det.get("sweep") or []:
         out.append("| %.1f %% | %s | %s× | %s | %s |" % (100 * row["edit_ratio"], fmt(row.get("forward_ms")), fmt(row.get("speedup_vs_dense"), 2),
                                                      fmt(row.get("block_conv_TFLOPs"), 1), fmt(row.get("block_conv_frac_of_mfma_peak"), 3)))
+    t3 = det.get("tile_conv3") or {}
+    if t3.get("rows"):
+        out.append("")
+        out.append("| tile conv v3 (routed from %s v3 workgroups on; §3.14) | router off | default | max \\|Δ\\| |" % t3.get("min_blocks"))
+        out.append("|---|---|---|---|")
+        for row in t3["rows"]:
+            out.append("| forward at %.0f %% | %s ms | **%s ms** | %s |" % (100 * row["edit_ratio"], fmt(row.get("router_off_ms")), fmt(row.get("default_ms")),
+                                                                     row.get("max_abs_vs_router_off")))
     b = det.get("batched_edits") or {}
     if b.get("rows"):
         out.append("")
