@@ -524,6 +524,15 @@ int sige_hip_scatter_gather_conv_scatter_nhwc_v3_f32(
         const float *packed_tile3, int min_blocks,
         float *out, void *stream);
 
+/* ---- token-matrix helpers of Stable Diffusion's spatial transformer (csrc/token_ops.hip; sige_attention.py:86-185): tokens [T,C]
+ * row-major fp32.  add_layer_norm: y = x (+ delta + bias[c] when delta != NULL; bias may be NULL); sum_out = y when not NULL;
+ * out = LayerNorm(y) * gamma + beta (eps as nn.LayerNorm's).  geglu: out[t,d] = x[t,d] * gelu(x[t,D+d]), x [T,2D] (F.gelu's erf
+ * form).  add_bias: out = x + delta + bias[c] (bias may be NULL). */
+int sige_hip_add_layer_norm_tokens_f32(const float *x, const float *delta, const float *bias, const float *gamma,
+                                       const float *beta, int64_t T, int C, float eps, float *sum_out, float *out, void *stream);
+int sige_hip_geglu_tokens_f32(const float *x, int64_t T, int D, float *out, void *stream);
+int sige_hip_add_bias_tokens_f32(const float *x, const float *delta, const float *bias, int64_t T, int C, float *out, void *stream);
+
 /* ---- 3x3 / padding-1 conv with <= 4 output channels over a full channels-last tensor
  * (the U-Net's conv_out after norm_out + SiLU, sige_fused_unet.py:430-434, which the
  * reference runs densely in sparse mode too): out [B,H,W,Cout] = conv(act(scale*x + shift)),

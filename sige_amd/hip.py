@@ -191,6 +191,9 @@ _SIGNATURES = {
     "sige_hip_tile_conv3_nhwc_f32": (
         _c_int, [_c_int, _c_vp, _c_vp] + [_c_int] * 6 + [_c_vp, _c_int, _c_vp, _c_int, _c_int] + [_c_vp, _c_vp, _c_int, _c_int]
         + [_c_vp, _c_vp, _c_int] + [_c_int] * 5 + [_c_vp] + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp, _c_vp, _c_int] + [_c_vp] * 6 + [_c_vp, _c_vp]),
+    "sige_hip_add_layer_norm_tokens_f32": (_c_int, [_c_vp] * 5 + [ctypes.c_int64, _c_int, ctypes.c_float, _c_vp, _c_vp, _c_vp]),
+    "sige_hip_geglu_tokens_f32": (_c_int, [_c_vp, ctypes.c_int64, _c_int, _c_vp, _c_vp]),
+    "sige_hip_add_bias_tokens_f32": (_c_int, [_c_vp, _c_vp, _c_vp, ctypes.c_int64, _c_int, _c_vp, _c_vp]),
     "sige_hip_set_edit_batch": (_c_int, [_c_int]),
     "sige_hip_get_edit_batch": (_c_int, []),
     # launch plans (csrc/plan.hip; host side: sige_amd/plan.py)
@@ -1760,6 +1763,44 @@ def spade_modulate_cl(x_full, x_tiles, map_x, scale, shift, gb_tiles, gb_full, m
         B, C, H, W, block[0], block[1], idx.data_ptr(), N, int(slope is not None), float(slope or 0.0), out.data_ptr(),
         _stream(x_full)), "spade_modulate_cl")
     return tag_tiles(out, idx, B)
+
+
+# ---- token helpers of the SD spatial transformer (csrc/token_ops.hip) --------------------------------------------------------------
+def _tok(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 3):
+        raise NotImplementedError("sige_amd.hip: `%s` must be fp32 GPU tokens [B,N,C]" % name)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def add_layer_norm_tokens(x, delta, bias, norm: torch.nn.LayerNorm, want_sum: bool = True):
+    """(x + delta + bias, LayerNorm(x + delta + bias)) in one launch (delta None: just LayerNorm(x), the sum is x itself)."""
+    x = _tok(x, "x")
+    B, N, C = x.shape
+    d = None if delta is None else _tok(delta, "delta")
+    out = torch.empty_like(x)
+    s = torch.empty_like(x) if (d is not None and want_sum) else None
+    _check(lib().sige_hip_add_layer_norm_tokens_f32(x.data_ptr(), _p(d), _p(bias if d is not None else None), norm.weight.data_ptr(),
+                                                    norm.bias.data_ptr(), B * N, C, float(norm.eps), _p(s), out.data_ptr(), _stream(x)),
+           "add_layer_norm_tokens")
+    return (x if d is None else s), out
+
+
+def geglu_tokens(x):
+    """a * gelu(gate) for x = [a | gate] along the last axis, one launch."""
+    x = _tok(x, "x")
+    B, N, C2 = x.shape
+    out = torch.empty((B, N, C2 // 2), dtype=torch.float32, device=x.device)
+    _check(lib().sige_hip_geglu_tokens_f32(x.data_ptr(), B * N, C2 // 2, out.data_ptr(), _stream(x)), "geglu_tokens")
+    return out
+
+
+def add_bias_tokens(x, delta, bias):
+    """x + delta + bias in one launch."""
+    x, delta = _tok(x, "x"), _tok(delta, "delta")
+    out = torch.empty_like(x)
+    _check(lib().sige_hip_add_bias_tokens_f32(x.data_ptr(), delta.data_ptr(), _p(bias), x.shape[0] * x.shape[1], x.shape[2], out.data_ptr(),
+                                              _stream(x)), "add_bias_tokens")
+    return out
 
 
 # ---- GauGAN helpers (csrc/spade_ops.hip): the sparse forward of the SPADE generator without a torch kernel ----------------------
