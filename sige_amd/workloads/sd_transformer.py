@@ -38,11 +38,14 @@ from ..nn import Gather, Scatter, SIGEConv2d, SIGEModule
 #                     against the stacked weights [3, C, inner]: three dense outputs, one launch instead of three)
 #   FUSED_TOKENS      (round 5) what sits between the GEMMs of a block as one library launch each (csrc/token_ops.hip): residual add
 #                     + the projection's bias + the next LayerNorm; GEGLU's a * gelu(gate); the block's last residual add + bias --
-#                     48 torch kernels fewer per forward of the SD v1 U-Net (16 blocks x 3), same arithmetic
+#                     48 kernels fewer per forward of the SD v1 U-Net (16 blocks x 3), same arithmetic.  MEASURED SLOWER and therefore
+#                     OFF: 10.98 vs 10.84 ms per forward (profiles/r5m_bench_sd_fused_tokens.json): every kernel involved sits at
+#                     the ~5 us launch floor either way, and the bias-free projections (aten.mm) cost more than the addmm they
+#                     replace saves -- the bias has to move into the fused add for the fusion to exist at all
 NATIVE_ATTENTION = True
 NATIVE_LINEAR = False
 BATCHED_QKV = True
-FUSED_TOKENS = True
+FUSED_TOKENS = False
 
 
 def linear(lin: nn.Linear, x: torch.Tensor) -> torch.Tensor:

@@ -536,8 +536,18 @@ def test_sd_transformer_fused_tokens_equal_the_module_chain(hip):
     from sige_amd.utils import downsample_mask
     from sige_amd.workloads import sd_transformer as sdt
 
+    from sige_amd.nn import SIGEModel
+
+    class Wrap(SIGEModel):
+        def __init__(self):
+            super().__init__()
+            self.t = sdt.SpatialTransformer(320, 8, 40, depth=1, context_dim=768)
+
+        def forward(self, x, context=None):
+            return self.t(x, context=context)
+
     torch.manual_seed(0)
-    m = sdt.SpatialTransformer(320, 8, 40, depth=1, context_dim=768).eval().to(DEV).to(memory_format=torch.channels_last)
+    m = Wrap().eval().to(DEV).to(memory_format=torch.channels_last)
     with torch.no_grad():
         for p_ in m.parameters():
             if p_.dim() > 1 and float(p_.abs().max()) == 0.0:
@@ -555,6 +565,7 @@ def test_sd_transformer_fused_tokens_equal_the_module_chain(hip):
         m.set_masks({(64, 64): mask})
         m.set_mode("sparse")
         for flag in (False, True):
+            keep = sdt.FUSED_TOKENS
             sdt.FUSED_TOKENS = flag
             try:
                 m(x1, context=ctx)
@@ -562,7 +573,7 @@ def test_sd_transformer_fused_tokens_equal_the_module_chain(hip):
                 outs[flag] = m(x1, context=ctx).clone()
                 launches = hip.launch_count() - n0
             finally:
-                sdt.FUSED_TOKENS = True
+                sdt.FUSED_TOKENS = keep
             assert launches >= (9 if flag else 4)
     err = float((outs[True] - outs[False]).abs().max())
     assert err <= 2e-5 * (1 + float(outs[False].abs().max())), err
