@@ -101,13 +101,13 @@ def gaugan_section(dev, cpu_parity=True):
         # ... and through a launch plan (sige_amd/plan.py): since round 5 the sparse forward reaches the GPU through the library only
         # (csrc/spade_ops.hip: nearest resizes, ReLU + split of the label features, dense SPADE modulation, conv_img with its leaky
         # ReLU / tanh), so ONE recording serves every later edit: copy the label map, difference mask, bind_mask, run
+        def build_masks(m_):
+            return downsample_mask(dilate_mask(m_, 1), (model.sh, model.sw), dilation=2)
+
         try:
             from sige_amd.plan import LaunchPlan
 
             seg = x1.clone()
-
-            def build_masks(m_):
-                return downsample_mask(dilate_mask(m_, 1), (model.sh, model.sw), dilation=2)
 
             t0 = time.perf_counter()
             plan = LaunchPlan(model)
@@ -142,6 +142,45 @@ def gaugan_section(dev, cpu_parity=True):
             del plan
         except Exception as e:  # (never the reason the section dies)
             res["per_edit_latency_plan_ms"] = {"error": repr(e)[:300]}
+        # ---- stacked edits (sige_amd/stacked.py): E edited label maps of ONE original, each with its own mask,
+        # through one set of launches -- every tensor of the sparse forward is the tall image [1,C,E*h,w]
+        try:
+            from sige_amd import stacked
+
+            edits8 = ([x1] + edit_inputs)[:8]
+            pyrs = [build_masks(compute_difference_mask(x0, xi)) for xi in edits8]
+            singles = []
+            for xi, p in zip(edits8, pyrs):
+                model.set_masks(p)
+                singles.append(model(xi).clone())
+            one_ms = res["fused_spade_modulation"]["forward_ms"]
+            rows = {}
+            for E in (2, 4, 8):
+                xs = torch.cat(edits8[:E], 0).contiguous(memory_format=torch.channels_last)
+                stacked.stack_caches(model, E)
+                try:
+                    stacked.set_masks(model, pyrs[:E])
+                    with stacked.edit_batch(model, E):
+                        model(xs)
+                        n0 = _hip().launch_count()
+                        out = model(xs)
+                        launches = _hip().launch_count() - n0
+                        worst = max(float((out[e] - singles[e][0]).abs().max()) for e in range(E))
+                        ms, _, g = _replay_ms(lambda: model(xs))
+                        del g
+                finally:
+                    stacked.unstack_caches(model)
+                rows[str(E)] = {"forward_ms": round(ms, 3), "ms_per_edit": round(ms / E, 3), "edits_per_s": round(1e3 * E / ms, 1),
+                                "speedup_vs_one_edit_per_forward": round(one_ms * E / ms, 2), "hip_kernel_launches": launches,
+                                "max_abs_vs_single_edit_forward": round(worst, 9)}
+            res["batched_edits"] = {"one_edit_forward_ms": one_ms, "E": rows,
+                                    "note": "E edited label maps of one original (different rectangles), each with its own mask, stacked "
+                                            "along H (sige_amd/stacked.py + sige_hip_set_edit_batch): one launch per layer sees the tiles of "
+                                            "all E edits; hipGraph replay; parity against each edit's own single-edit sparse forward"}
+        except Exception as e:  # (never the reason the section dies)
+            res["batched_edits"] = {"error": repr(e)[:300]}
+        finally:
+            model.set_masks(build_masks(diff))
     res["dense_forward_ms"] = round(dense_ms, 3)
     res["edit_ratio"] = round(float(diff.float().mean()), 4)
     res["fused_vs_chain_max_abs"] = round(float((outs["fused_spade_modulation"] - outs["module_chain"]).abs().max()), 8)

@@ -814,9 +814,10 @@ int sige_hip_scatter_gather_conv_scatter_nhwc_c16(
  * times).  A launch then sees the active tiles of all E edits at once -- at a 1 % edit the sum of eight edits' tiles is what a
  * 10 % edit has, and a launch leaves the launch-bound regime.  sige_hip_set_edit_batch(E) tells the library where the seams are:
  * a halo row beyond a tile's own image is zero padding (not the neighbour image's pixels) in the channels-last fused gather /
- * scatter_gather -> conv kernels and the dense-layer conv; entry points whose kernels have no seam test (NCHW forms, the
- * standalone gathers, SPADE) return SIGE_HIP_EUNSUPPORTED while E > 1.  One image's height must be a power of two at every
- * resolution.  Per host thread; 1 = off (default).  Whole-image ops (conv_in / conv_out, attention, GroupNorm) are simply
+ * scatter_gather -> conv kernels, the dense-layer conv, the standalone channels-last gather / scatter_gather, the SPADE
+ * modulation and sige_hip_scatter_gather_split_nhwc_f32; entry points whose kernels have no seam test (the NCHW forms) return
+ * SIGE_HIP_EUNSUPPORTED while E > 1; per-pixel helpers (nearest resize by an integer factor, act_split, the dense SPADE
+ * modulation) need none.  One image's height must be a power of two at every resolution.  Per host thread; 1 = off (default).  Whole-image ops (conv_in / conv_out, attention, GroupNorm) are simply
  * called with B = E on the same memory (sige_amd/stacked.py).  The mask pipeline follows: sige_hip_reduce_mask_i32 lets a
  * candidate tile see only its own image's mask rows, sige_hip_dilate_mask_u8 does not dilate across a seam, and
  * sige_hip_mask_pyramid_u8 builds the pyramid of every image with that image's own maxima and thresholds (one workgroup per

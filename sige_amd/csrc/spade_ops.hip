@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kT) void scatter_gather_split_nhwc_kernel(const flo
                                                                       int B, int C, int H, int W, int Rx, int Sx, int bH, int bW,
                                                                       const int32_t *__restrict__ idx, int N,
                                                                       const int32_t *__restrict__ map, int act, float slope, int Cp4,
-                                                                      long part_stride, float *__restrict__ out, long units) {
+                                                                      long part_stride, float *__restrict__ out, long units, int hp_shift) {
     const int C4 = C / 4, RS = bH * bW;
     for (long u = (long)blockIdx.x * kT + threadIdx.x; u < units; u += (long)gridDim.x * kT) {
         const int c4 = (int)(u % C4);
@@ -76,9 +76,12 @@ __global__ __launch_bounds__(kT) void scatter_gather_split_nhwc_kernel(const flo
         const int p = (int)(tp % RS);
         const int t = (int)(tp / RS);
         const int b = t / N, n = t - b * N;
-        const int h = idx[2 * n] + p / bW, w = idx[2 * n + 1] + p % bW;
+        const int h0 = idx[2 * n];
+        const int h = h0 + p / bW, w = idx[2 * n + 1] + p % bW;
+        // (stacked edits: the tile belongs to the image its third row lies in -- csrc/nhwc_ops.hip seam_lo -- rows beyond are padding)
+        const int hlo = hp_shift ? (((h0 + 2) >> hp_shift) << hp_shift) : 0, hhi = hp_shift ? hlo + (1 << hp_shift) : H;
         float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (h >= 0 && h < H && w >= 0 && w < W) {
+        if (h >= hlo && h < hhi && w >= 0 && w < W) {
             const int32_t *m = map + 3 * ((size_t)h * W + w);
             const int blk = m[0];
             const float4 v = blk >= 0 ? ld4(x + ((((size_t)b * N + blk) * Rx + m[1]) * Sx + m[2]) * C + 4 * c4)
@@ -126,7 +129,8 @@ extern "C" int sige_hip_resize_nearest_nhwc_f32(const float *x, int B, int C, in
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || !x || !out) return SIGE_HIP_EINVAL;
     // integer factors only: torch computes the source index in floating point, which agrees with the integer form exactly there
     if (!((Ho % H == 0 || H % Ho == 0) && (Wo % W == 0 || W % Wo == 0))) return SIGE_HIP_EUNSUPPORTED;
-    if (C % 4 || !al16(x) || !al16(out) || stacked_shift(H) != 0) return SIGE_HIP_EUNSUPPORTED;
+    if (C % 4 || !al16(x) || !al16(out)) return SIGE_HIP_EUNSUPPORTED;
+    // (stacked edits: an integer factor maps image e's rows onto image e's rows of the tall result -- nothing to do)
     const long units = (long)B * Ho * Wo * (C / 4);
     resize_nearest_nhwc_kernel<<<grid_of(units), kT, 0, as_stream(stream)>>>(x, C / 4, H, W, Ho, Wo, out, units);
     return launch_status();
@@ -153,14 +157,15 @@ extern "C" int sige_hip_scatter_gather_split_nhwc_f32(const float *x, const floa
     SIGE_PLAN_HOOK_N(sige_hip_scatter_gather_split_nhwc_f32, (sige::CountOf<10, 11>), x, y, B, C, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, activation, slope, parts, part_stride, out, stream);
     if (B < 0 || C <= 0 || H <= 0 || W <= 0 || Rx <= 0 || Sx <= 0 || bH <= 0 || bW <= 0 || N < 0 || parts <= 0) return SIGE_HIP_EINVAL;
     if (!act_ok(activation)) return SIGE_HIP_EUNSUPPORTED;
-    if (stacked_shift(H) != 0) return SIGE_HIP_EUNSUPPORTED;
+    const int hp_shift = stacked_shift(H);  // (stacked edits: halo rows beyond a tile's own image are zero padding)
+    if (hp_shift < 0 || (hp_shift && B != 1)) return SIGE_HIP_EUNSUPPORTED;
     if ((long)B * N == 0) return SIGE_HIP_OK;
     if (!x || !y || !out || !active_indices || !scatter_map) return SIGE_HIP_EINVAL;
     if (C % (4 * parts) || !al16(x) || !al16(y) || !al16(out)) return SIGE_HIP_EUNSUPPORTED;
     if (part_stride < (int64_t)B * N * bH * bW * (C / parts) || part_stride % 4) return SIGE_HIP_EINVAL;  // (a part holds every tile of THIS mask)
     const long units = (long)B * N * bH * bW * (C / 4);
     scatter_gather_split_nhwc_kernel<<<grid_of(units), kT, 0, as_stream(stream)>>>(x, y, B, C, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map,
-                                                                                  activation, slope, C / 4 / parts, (long)part_stride, out, units);
+                                                                                  activation, slope, C / 4 / parts, (long)part_stride, out, units, hp_shift);
     return launch_status();
 }
 
@@ -169,7 +174,7 @@ extern "C" int sige_hip_spade_modulate_dense_nhwc_f32(const float *x, const floa
     SIGE_PLAN_HOOK(sige_hip_spade_modulate_dense_nhwc_f32, x, scale, shift, affineB, gb, B, C, H, W, leaky, slope, out, stream);
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !x || !scale || !shift || !gb || !out) return SIGE_HIP_EINVAL;
     if (affineB != 1 && affineB != B) return SIGE_HIP_EINVAL;
-    if (C % 4 || !al16(x) || !al16(gb) || !al16(out) || !al16(scale) || !al16(shift) || stacked_shift(H) != 0) return SIGE_HIP_EUNSUPPORTED;
+    if (C % 4 || !al16(x) || !al16(gb) || !al16(out) || !al16(scale) || !al16(shift)) return SIGE_HIP_EUNSUPPORTED;  // (per pixel: stacked edits change nothing)
     const long units = (long)B * H * W * (C / 4);
     spade_modulate_dense_nhwc_kernel<<<grid_of(units), kT, 0, as_stream(stream)>>>(x, scale, shift, affineB > 1 ? C : 0, gb, C / 4, (long)H * W,
                                                                                   leaky, slope, out, units);

@@ -341,6 +341,7 @@ class SpadeGenerator(SIGEModel):
             self.up_4 = SpadeResBlock(cfg, nf, nf // 2, k >= 1)
             final = nf // 2
         self.conv_img = nn.Conv2d(final, 3, 3, padding=1)
+        self.edit_batch = 1  # (sige_amd.stacked.edit_batch: E edits of one original stacked along H in every sparse-mode tensor)
 
     def _up(self, x):
         if self.cfg.fused and self.mode == "sparse" and _cl_gpu(x):
@@ -349,6 +350,10 @@ class SpadeGenerator(SIGEModel):
 
     def _tail(self, x):
         cfg = self.cfg
+        if self.edit_batch > 1:
+            from ..stacked import untall
+
+            x = untall(x, self.edit_batch)  # (the image conv is a whole-image op: batch E on the same bytes)
         if cfg.fused and self.mode == "sparse" and _cl_gpu(x):
             from .. import hip
             from ..nn.dense import _plain_weight
@@ -361,8 +366,19 @@ class SpadeGenerator(SIGEModel):
 
     def forward(self, seg: torch.Tensor) -> torch.Tensor:
         cfg = self.cfg
+        E = self.edit_batch
+        if E > 1:
+            # stacked edits (sige_amd/stacked.py): seg is [E,36,H,W], one edited label map per edit; from here to the image conv
+            # every tensor is the tall image [1,C,E*h,w] -- the same bytes.  Every op of the all-library sparse forward is either
+            # per pixel (nearest resize by an integer factor, ReLU + split, the dense SPADE modulation), seam-aware (the tile and
+            # dense-layer convs, the SPADE modulation of tiles, scatter_gather_split) or tile-local (convs over tile slabs)
+            if not (cfg.fused and self.mode == "sparse" and _cl_gpu(seg) and seg.shape[0] == E):
+                raise RuntimeError("stacked edits: the fused sparse forward on channels-last GPU label maps, one per edit")
+            from ..stacked import tall
+
+            seg = tall(seg)
         if cfg.fused and self.mode == "sparse" and _cl_gpu(seg):
-            x = _dense_conv(self.fc, _resize(seg, (self.sh, self.sw)))
+            x = _dense_conv(self.fc, _resize(seg, (E * self.sh, self.sw)))
         else:
             x = self.fc(F.interpolate(seg, size=(self.sh, self.sw)))
         x = self._up(self.head_0(x, seg))
