@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SIGE_HIP_VERSION 307 /* 0.3.0: round 3 -- dense-layer convs on the fp16 matrix cores (fp16 / split-fp16 operands) */
+#define SIGE_HIP_VERSION 308 /* 0.3.8: round 5 -- tile conv v3, GauGAN helpers, stacked SPADE */
 
 enum {
     SIGE_HIP_OK = 0,
