@@ -24,6 +24,11 @@ from ..nn.deferred import lazy_cat
 from .sd_transformer import SpatialTransformer, group_norm_affine
 
 
+# the 1x1 skip_connection of a channel-changing residual block rides in conv1's launch (sige_amd.hip.conv_pair).  A paired
+# conv1 stays on csrc/conv_mfma.hpp; unpaired it may be routed to the tile conv v3 (tools/sd_route_bench.py measures both)
+PAIRED_SHORTCUT = True
+
+
 @dataclass
 class SDConfig:
     in_channels: int = 4
@@ -90,7 +95,7 @@ class ResBlock(SIGEModule):
             return self.scatter(self.out_layers[3](F.silu(h)), skip)
         if self.mode in ("sparse", "profile"):
             s1, t1, s2, t2 = self.affine
-            with paired_convs(x, enabled=self.cin != self.cout and self.mode == "sparse"):  # the 1x1 rides in conv1's launch
+            with paired_convs(x, enabled=PAIRED_SHORTCUT and self.cin != self.cout and self.mode == "sparse"):  # the 1x1 rides in conv1's launch
                 skip = x if self.cin == self.cout else self.skip_connection(self.shortcut_gather(x))
                 h = self.in_layers[2](self.main_gather(x, s1, t1))
             tiles = self.scatter_gather(h, s2, t2)

@@ -125,6 +125,12 @@ def block():
             fmt(pp.get("input_and_difference_mask")), fmt(pp.get("bind_mask")), fmt(pp.get("run")), fmt(pp.get("to_first_output")),
             g(pp, "calls", "forward"), pp.get("max_abs_vs_module_forward")))
         out.append("| parity vs the same generator on the CPU (reference natives) | %s |" % gg.get("parity_max_abs"))
+        be = (gg.get("batched_edits") or {}).get("E") or {}
+        if be:
+            out.append("| stacked edits (E label maps of one original in one forward), ms per edit | %s (one edit per forward: %s ms) |" % (
+                ", ".join("E = %s: **%s** (%s×, max \\|Δ\\| %s)" % (e, fmt(r.get("ms_per_edit")), fmt(r.get("speedup_vs_one_edit_per_forward"), 2),
+                                                                   r.get("max_abs_vs_single_edit_forward")) for e, r in sorted(be.items(), key=lambda kv: int(kv[0]))),
+                fmt(g(gg, "batched_edits", "one_edit_forward_ms"))))
     if f16:
         fr = f16.get("roofline") or {}
         out.append("")
