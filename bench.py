@@ -735,6 +735,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path; see DESIGN.md)")
     self_launch(args)
+    from benchlib.line import reserve_stdout
+
+    reserve_stdout()  # (whatever a library prints to stdout -- RCCL's banner, at exit -- goes to stderr: the contract line stays the last line)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

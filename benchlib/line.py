@@ -143,9 +143,32 @@ def compact(full):
     return line
 
 
+_RESULT_STREAM = None
+
+
+def reserve_stdout():
+    """From here on file descriptor 1 IS stderr for everything except the result lines.  Libraries write to stdout too: RCCL prints a
+    five-line banner ("RCCL version : ... Librccl path : ...") through C stdio when its first communicator is created -- buffered on a
+    pipe, so it comes out when the process exits, AFTER the contract line (measured on the GPU box with a one-rank group:
+    tools/probe/rccl_stdout_probe.py).  Returns the stream emit() writes to (the process's original stdout)."""
+    global _RESULT_STREAM
+    if _RESULT_STREAM is None:
+        import ctypes
+
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        real = os.dup(1)
+        os.dup2(2, 1)
+        _RESULT_STREAM = os.fdopen(real, "w")
+    return _RESULT_STREAM
+
+
 def emit(full, stream=None, detail_dirs=None, name="bench_detail.json"):
     """Write the detail file(s), print the detail line, then the compact line LAST."""
-    stream = stream or sys.stdout
+    stream = stream or _RESULT_STREAM or sys.stdout
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if detail_dirs is None:
         detail_dirs = [here] + ([os.path.join(here, "gpurun_out")] if os.path.isdir(os.path.join(here, "gpurun_out")) else [])

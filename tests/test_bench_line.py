@@ -77,3 +77,31 @@ def test_emit_prints_the_compact_line_last(tmp_path):
     # the tail the driver keeps (8 KB) contains the whole last line
     tail = out.getvalue()[-8192:]
     assert json.loads(tail.strip().splitlines()[-1]) == last
+
+
+def test_result_lines_are_the_only_stdout_whatever_libraries_print(tmp_path):
+    """bench.py reserves the process's stdout for its result lines (benchlib.line.reserve_stdout): what a library prints to stdout
+    afterwards -- RCCL's banner sits in a C stdio buffer until the process exits, i.e. AFTER the contract line -- lands on stderr, so
+    the last stdout line is the contract line for every N."""
+    import subprocess
+    import sys
+
+    script = r'''
+import ctypes, json, sys
+sys.path.insert(0, %r)
+from benchlib import line
+canned = json.loads(open(%r).read().strip().splitlines()[-1])
+line.reserve_stdout()
+libc = ctypes.CDLL(None)
+libc.printf(b"Librccl path : /somewhere/librccl.so\n")   # buffered C stdio: flushed at exit
+print("python noise")
+line.emit(canned, detail_dirs=[%r], name="detail.json")
+libc.printf(b"more noise at the end\n")
+''' % (REPO, os.path.join(REPO, "profiles", "r4_bench.json"), str(tmp_path))
+    p = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = p.stdout.strip().splitlines()
+    assert len(out) == 2 and "bench_detail" in json.loads(out[0])
+    last = json.loads(out[-1])
+    assert last["metric"] and len(out[-1]) < 4096
+    assert "Librccl path" in p.stderr and "python noise" in p.stderr and "more noise" in p.stderr
