@@ -757,6 +757,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev, timeout=limit)
         else:
             dist.init_process_group("gloo", timeout=limit)
+        from benchlib.line import flush_c_stdio
+
+        flush_c_stdio()  # (RCCL's banner, written through C stdio when the communicator is created: out now, not at exit)
 
     if args.workload == "sd":
         return main_sd(args, world, rank, dev)

@@ -146,6 +146,17 @@ def compact(full):
 _RESULT_STREAM = None
 
 
+def flush_c_stdio():
+    """Push out whatever libraries left in C stdio buffers (RCCL's banner) NOW -- before, not after, the result lines, for a
+    caller that merges stdout and stderr."""
+    try:
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+
+
 def reserve_stdout():
     """From here on file descriptor 1 IS stderr for everything except the result lines.  Libraries write to stdout too: RCCL prints a
     five-line banner ("RCCL version : ... Librccl path : ...") through C stdio when its first communicator is created -- buffered on a
@@ -169,6 +180,9 @@ def reserve_stdout():
 def emit(full, stream=None, detail_dirs=None, name="bench_detail.json"):
     """Write the detail file(s), print the detail line, then the compact line LAST."""
     stream = stream or _RESULT_STREAM or sys.stdout
+    sys.stdout.flush()
+    sys.stderr.flush()
+    flush_c_stdio()
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if detail_dirs is None:
         detail_dirs = [here] + ([os.path.join(here, "gpurun_out")] if os.path.isdir(os.path.join(here, "gpurun_out")) else [])

@@ -105,3 +105,26 @@ libc.printf(b"more noise at the end\n")
     last = json.loads(out[-1])
     assert last["metric"] and len(out[-1]) < 4096
     assert "Librccl path" in p.stderr and "python noise" in p.stderr and "more noise" in p.stderr
+
+
+def test_contract_line_is_last_even_when_the_caller_merges_the_streams():
+    """... and for a caller that reads stdout and stderr as ONE stream, emit() first flushes what sits in C stdio buffers (RCCL's
+    banner is written when the communicator is created, long before the result): the contract line still ends the stream."""
+    import subprocess
+    import sys
+
+    script = r'''
+import ctypes, json, sys
+sys.path.insert(0, %r)
+from benchlib import line
+canned = json.loads(open(%r).read().strip().splitlines()[-1])
+line.reserve_stdout()
+ctypes.CDLL(None).printf(b"Librccl path : /somewhere/librccl.so\n")
+print("python noise")
+line.emit(canned, detail_dirs=[])
+''' % (REPO, os.path.join(REPO, "profiles", "r4_bench.json"))
+    p = subprocess.run([sys.executable, "-c", script], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout[-2000:]
+    out = p.stdout.strip().splitlines()
+    assert any("Librccl path" in ln for ln in out[:-2])
+    assert json.loads(out[-1])["metric"] and "bench_detail" in json.loads(out[-2])
