@@ -289,7 +289,9 @@ def test_standalone_gathers_and_spade_in_stacked_mode(hip):
         return dict(gather=hip.gather_cl(x, 6, 6, idx, sc, sh, "swish"),
                     sg=hip.scatter_gather_cl(t, y, 6, 6, idx, smap, sc, sh, "swish"),
                     spade_g=hip.spade_modulate_cl(x, None, None, sc, sh, tg, gb, smap, idx, (6, 6), 0.2),
-                    spade_sg=hip.spade_modulate_cl(y, t, smap, sc, sh, tg, gb, smap, idx, (6, 6), None))
+                    spade_sg=hip.spade_modulate_cl(y, t, smap, sc, sh, tg, gb, smap, idx, (6, 6), None),
+                    # (GauGAN's label branch: scatter_gather + ReLU + split into two slabs -- seam-aware since the stacked generator)
+                    sg_split=torch.cat(hip.scatter_gather_split_cl(t, y, 6, 6, idx, smap, 2, "relu"), dim=1))
 
     hip.set_edit_batch(E)
     try:
