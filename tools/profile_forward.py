@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "f16x3"], help="arithmetic of the convs (bench.py --dtype)")
     ap.add_argument("--ksplit", type=int, default=0, help="pin the cross-workgroup K split of the tile convs (hip.conv_force_ksplit; 0 = automatic)")
     ap.add_argument("--tile3-min-blocks", type=int, default=None, help="sige_amd.hip.TILE3_MIN_BLOCKS (the tile conv v3's routing threshold)")
+    ap.add_argument("--edits", type=int, default=1, help="E > 1: E edits of one original, each with its own mask, stacked into one forward "
+                                                        "(sige_amd/stacked.py; sparse mode, channels-last)")
     ap.add_argument("--manifest", default="", help="eager mode: write the kernel-family sequence of one forward's conv launches here")
     a = ap.parse_args()
     dev = torch.device("cuda")
@@ -94,6 +96,22 @@ def main():
             time.sleep(0.5)
             for _ in range(a.replays):
                 model(x1, t)
+        elif a.edits > 1:
+            # the masks of bench.py's batched_edits section: E squares of the same size at different places
+            from sige_amd import stacked
+
+            assert a.mode == "sparse" and a.layout == "nhwc"
+            mks = [bench.square_mask(a.ratio, top=(16 + 61 * e) % 208, left=(24 + 97 * e) % 208).to(dev) for e in range(a.edits)]
+            xe = torch.cat([x0 + noise * mk for mk in mks], 0).contiguous(memory_format=torch.channels_last)
+            stacked.stack_caches(model, a.edits)
+            stacked.set_masks(model, [downsample_mask(dilate_mask(mk, 5), 8) for mk in mks])
+            with stacked.edit_batch(model, a.edits):
+                g, _ = bench.capture(model, xe, t)
+                g.replay()
+                torch.cuda.synchronize()
+                time.sleep(0.5)
+                for _ in range(a.replays):
+                    g.replay()
         else:
             if a.mode == "full":
                 x1 = x0
