@@ -1,5 +1,7 @@
 #!/bin/bash
-# round 5, GPU session 15: dense layers without an index list (the kernel computes the tile origins) -- parity tests, A/B of the headline
+# round 5, GPU session 15: dense layers without an index list (the kernel computes the tile origins) -- parity tests, A/B of the headline.
+# A RECORD, not a tool: the kernel change it measured gained nothing (profiles/r5p_bench_grid_origins_*.json) and was reverted; the
+# SIGE_HIP_GRID_ORIGINS switch and the grid_origins test no longer exist.
 mkdir -p gpurun_out/r5p
 cd /root/repo
 export TMPDIR=/tmp
