@@ -876,3 +876,22 @@ def test_block_residual_scatter_takes_a_precomputed_sum(cpu_oracle_backend):
     b.set_mode("sparse")
     with pytest.raises(AssertionError):
         b(main, resid, x_is_sum=True)
+
+
+def test_gaugan_stacked_mode_refuses_off_the_gpu():
+    """The SPADE generator's stacked mode exists on the all-library GPU path only (every op seam-aware, per pixel or tile-local):
+    anywhere else -- CPU tensors, the torch module chain -- the forward raises instead of running ops that would read across the
+    seams of the tall image."""
+    from sige_amd.workloads.gaugan_spade import SPADEConfig, SpadeGenerator
+
+    model = SpadeGenerator(SPADEConfig(ngf=8, crop_size=64)).eval()
+    seg = torch.zeros(2, 36, 32, 64)
+    model.set_mode("sparse")
+    for m in model.modules():
+        if hasattr(m, "edit_batch"):
+            m.edit_batch = 2
+    with pytest.raises(RuntimeError, match="stacked edits"):
+        model(seg)
+    model.cfg.fused = False
+    with pytest.raises(RuntimeError, match="stacked edits"):
+        model(seg)
