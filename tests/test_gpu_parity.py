@@ -307,6 +307,7 @@ def test_deferred_fusion_in_modules():
     torch.testing.assert_close(fused, dense, rtol=0, atol=util.CONV_ATOL)
 
 
+@pytest.mark.oracle_parity  # (the reference computes this row with the torch op compared here)
 @pytest.mark.parametrize("res,c1,c2,cout,k,stride", [(32, 256, 0, 256, 3, 1), (16, 512, 512, 512, 3, 1), (8, 512, 256, 512, 1, 1),
                                                      (32, 96, 40, 72, 3, 1), (16, 512, 0, 1536, 1, 1), (32, 256, 0, 256, 3, 2),
                                                      (256, 128, 0, 3, 3, 1), (18, 64, 0, 64, 3, 1)])
@@ -340,6 +341,7 @@ def test_dense_fused_conv_vs_torch(res, c1, c2, cout, k, stride):
         torch.testing.assert_close(plain, conv(h), rtol=0, atol=2e-4)
 
 
+@pytest.mark.oracle_parity  # (the reference computes this row with the torch op compared here)
 @pytest.mark.parametrize("B,C,hw", [(1, 512, 16), (1, 512, 8), (2, 64, 12), (1, 48, 32)])
 def test_attention_vs_torch(hip, B, C, hw):
     """AttnBlock core (bmm -> softmax -> bmm on NCHW q, k, v) against torch in fp64."""
@@ -353,6 +355,7 @@ def test_attention_vs_torch(hip, B, C, hw):
     torch.testing.assert_close(got, want, rtol=0, atol=2e-5)
 
 
+@pytest.mark.oracle_parity  # (the reference computes this row with the torch op compared here)
 @pytest.mark.parametrize("shape,groups", [((1, 128, 256, 256), 32), ((2, 64, 17, 23), 32), ((1, 512, 8, 8), 32)])
 def test_group_norm_affine_vs_torch(hip, shape, groups):
     torch.manual_seed(shape[1])

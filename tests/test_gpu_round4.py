@@ -4,6 +4,8 @@ and of the device guard."""
 import pytest
 import torch
 
+from tests import util
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
@@ -37,7 +39,7 @@ def ddpm_pair():
     from sige_amd import parallel
 
     models = []
-    with torch.no_grad():
+    with util.native_full_pass(), torch.no_grad():  # (fixed kernels: the same caches on every box)
         for m in (a, b):
             m = m.to(DEV).to(memory_format=torch.channels_last)
             m.set_scatter_inplace(True)
@@ -385,11 +387,14 @@ def test_device_guard_on_one_gpu(hip, monkeypatch):
 
 
 # ---- stacked edits: E edits of one original, each with its own mask, in one set of launches -------------------
+@pytest.mark.selfcheck
 def test_stacked_edits_match_single_edits(hip, ddpm_pair):
     """sige_amd/stacked.py + sige_hip_set_edit_batch: four edits of different size and place -- one touching the TOP rows of its
     image and one the BOTTOM rows, so that tiles whose halo crosses a seam of the tall image are active on both sides -- through
     one stacked forward: every edit's output equals its own single-edit forward (fp32 summation order only: another tile count
-    picks another output block / K split), in ~the same number of launches as ONE single-edit forward."""
+    picks another output block / K split; a halo read across a seam is an error of 1e-2 and more), in ~the same number of
+    launches as ONE single-edit forward.  The row-defining check of the mode is tests/test_gpu_round5.py
+    test_stacked_edits_vs_cpu_oracle; this one is a HIP-vs-HIP statement, bounded by the row's own tolerance and recorded."""
     from sige_amd import stacked
 
     model, _, x0, noise, t = ddpm_pair
@@ -418,8 +423,8 @@ def test_stacked_edits_match_single_edits(hip, ddpm_pair):
                 launches = hip.launch_count() - n0
             assert tuple(out.shape) == (E, 3, 256, 256)
             for e in range(E):
-                err = float((out[e] - singles[e][0]).abs().max())
-                assert err < 1e-4, (e, err)
+                err = util.record_margin("stacked_vs_single", "edit %d" % e, (out[e] - singles[e][0]).abs().max(), util.SELF_ATOL)
+                assert err <= util.SELF_ATOL, (e, err)
             assert launches <= single_launches + 4, (launches, single_launches)
             # without the seam test the halo of a tile at an image's first row would read the previous image's last row: the two
             # edits at the seams are exactly where that would show (checked above); and the mode is per thread and switched off

@@ -238,7 +238,8 @@ def test_gaugan_sparse_forward_on_the_library_follows_a_launch_plan(hip):
         fused = model(x1).clone()
         launches = hip.launch_count() - n0
         assert launches <= 100
-        assert float((fused - chain).abs().max()) < 2e-5
+        d = util.record_margin("gaugan_fused_vs_chain", "first edit", (fused - chain).abs().max(), util.SELF_ATOL)
+        assert d <= util.SELF_ATOL, d  # (HIP launches vs the torch module chain on the same caches: fp32 summation order)
         seg = x1.clone()
         plan = LaunchPlan(model)
         out = plan.record(compute_difference_mask(x0, seg), build, lambda: model(seg))
@@ -258,7 +259,8 @@ def test_gaugan_sparse_forward_on_the_library_follows_a_launch_plan(hip):
             model.cfg.fused = False
             ref = model(xi).clone()
             model.cfg.fused = True
-            assert float((got - ref).abs().max()) < 2e-5
+            d = util.record_margin("gaugan_fused_vs_chain", "edit %d,%d" % (dy, dx), (got - ref).abs().max(), util.SELF_ATOL)
+            assert d <= util.SELF_ATOL, d
         assert len(seen) >= 2  # (the edits did change the tile counts)
 
 
@@ -326,6 +328,7 @@ def test_standalone_gathers_and_spade_in_stacked_mode(hip):
     assert not torch.equal(plain, got["gather"])
 
 
+@pytest.mark.selfcheck
 def test_gaugan_stacked_edits_match_single_edits(hip):
     """The SPADE generator in stacked mode: four edited label maps of ONE original -- a rectangle in the
     middle, one on the TOP rows of its image, one on the BOTTOM rows, one at the left edge -- each with its own mask, through ONE
@@ -373,11 +376,15 @@ def test_gaugan_stacked_edits_match_single_edits(hip):
         # own instead of holding it for the pair kernel: a few more, never a per-edit multiple)
         assert single_launches <= launches <= single_launches + 8, (launches, single_launches)
         for e in range(E):
-            assert float((got[e] - wants[e][0]).abs().max()) < 2e-5, (e, float((got[e] - wants[e][0]).abs().max()))
+            # (HIP vs HIP, fp32 summation order only; a halo row read across a seam is an error of 1e-2 and more.  Round 5 asserted
+            #  2e-5 here, one box's margin; the row's own criterion -- SPADE generator vs the reference fixture, 1e-3 -- is
+            #  tests/test_models_golden.py test_gaugan_generator_on_the_gpu_matches_the_reference_fixture)
+            err = util.record_margin("gaugan_stacked_vs_single", "edit %d" % e, (got[e] - wants[e][0]).abs().max(), util.SELF_ATOL)
+            assert err <= util.SELF_ATOL, (e, err)
         assert float((got[0] - got[1]).abs().max()) > 1e-3  # (the edits do differ)
         # back to single edits: the caches are the original's again
         model.set_masks(pyrs[1])
-        assert float((model(edits[1]) - wants[1]).abs().max()) < 2e-5
+        assert float((model(edits[1]) - wants[1]).abs().max()) <= util.SELF_ATOL
         # the module chain (torch ops between the library calls) refuses the mode loudly instead of bleeding across seams
         stacked.stack_caches(model, E)
         try:
@@ -536,9 +543,12 @@ def test_tile_conv3_scatter_gather_to_full_vs_old_kernel_and_fp64(hip):
         assert torch.equal(outs[0][0][0][:, ~cover], cache_out[0][:, ~cover])
 
 
+@pytest.mark.selfcheck
 def test_ddpm_forward_with_and_without_tile_conv3(hip):
-    """The whole sparse forward at a 15 % edit with every eligible launch on the v3 kernel (TILE3 = True) against the same
-    forward on conv_mfma.hpp only (TILE3 = False): fp32 summation order only."""
+    """The whole sparse forward at a 15 % edit with every eligible launch on the v3 kernel (TILE3 = True), on conv_mfma.hpp only
+    (TILE3 = False) and under the routing rule (None): ALL THREE within the north_star tolerance of the CPU oracle's sparse
+    forward of the same edit (tests/util.py ddpm_cpu_oracle; /root/reference/sige/cpu/gather.cpp:4-58, scatter_gather.cpp:5-56);
+    their mutual differences (fp32 summation order only) are recorded and bounded by the same tolerance."""
     import bench
     from sige_amd.utils import dilate_mask, downsample_mask
     from sige_amd.workloads.ddpm_unet import DDPMConfig, DDPMSparseUNet
@@ -547,10 +557,12 @@ def test_ddpm_forward_with_and_without_tile_conv3(hip):
     model = DDPMSparseUNet(DDPMConfig()).eval().to(DEV).to(memory_format=torch.channels_last)
     model.set_scatter_inplace(True)
     x0, noise = bench.make_inputs()
+    mask = bench.square_mask(0.15)
+    _, (want,) = util.ddpm_cpu_oracle([mask])
     x0, noise, t = _cl(x0.to(DEV)), _cl(noise.to(DEV)), torch.zeros(1, device=DEV)
-    mask = bench.square_mask(0.15).to(DEV)
+    mask = mask.to(DEV)
     outs = {}
-    with torch.no_grad():
+    with util.native_full_pass(), torch.no_grad():
         model.set_mode("full")
         model(x0, t)
         model.set_masks(downsample_mask(dilate_mask(mask, 5), 8))
@@ -567,8 +579,12 @@ def test_ddpm_forward_with_and_without_tile_conv3(hip):
             finally:
                 hip.TILE3, hip.TILE3_MIN_BLOCKS = None, keep_th
             assert launches <= 135  # (102; with TILE3 = True the 1x1 shortcuts of the pairs run as launches of their own)
-    assert float((outs[True] - outs[False]).abs().max()) < 2e-4 * (1 + float(outs[False].abs().max()))
-    assert float((outs[None] - outs[False]).abs().max()) < 2e-4 * (1 + float(outs[False].abs().max()))
+    for flag, o in outs.items():
+        err = util.record_margin("tile_conv3_on_off", "TILE3=%s vs cpu oracle" % flag, (o.cpu() - want).abs().max(), util.CONV_ATOL)
+        assert err <= util.CONV_ATOL, (flag, err)
+    for flag in (True, None):
+        diff = util.record_margin("tile_conv3_on_off", "TILE3=%s vs False" % flag, (outs[flag] - outs[False]).abs().max(), util.SELF_ATOL)
+        assert diff <= util.SELF_ATOL, (flag, diff)
 
 
 # ---- token helpers of the SD spatial transformer (csrc/token_ops.hip; VERDICT r4 next #5, the cheap part) ----------------------

@@ -14,6 +14,7 @@ if REPO not in sys.path:
 
 from tests.golden.model_init import gaugan_labels, init_by_name, sd_transformer_inputs, sd_unet_inputs, summarize  # noqa: E402
 
+pytestmark = pytest.mark.oracle_parity  # (every test here is pinned to tests/golden/models.npz = the real reference's outputs)
 GOLDEN = np.load(os.path.join(REPO, "tests", "golden", "models.npz"))
 ATOL = 1e-3  # north_star: activations within 1e-3 fp32 on conv-containing paths
 

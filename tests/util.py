@@ -62,3 +62,93 @@ def unpack(bits, shape):
 SWISH_RTOL = 1e-6  # swish <= 1e-6 rel (reference computes it in mixed float/double)
 SWISH_ATOL = 1e-7
 CONV_ATOL = 1e-3   # north_star: activations within 1e-3 fp32 on conv-containing paths
+
+
+# ---- the benchmark network on the CPU with the oracle as native backend: what model-level GPU tests are pinned to ----------
+_ddpm_oracle = {}
+
+
+def cpu_backend():
+    """The reference's own sige/cpu (oracle/_ref, built in the container from /root/reference and shipped as a .so) when it is
+    there, else the C restatement -- the same choice as bench.py's parity leg."""
+    from oracle import oracle
+
+    try:
+        from oracle import build_ref
+
+        return oracle.as_backend(build_ref.load()), "oracle/_ref"
+    except Exception:
+        return oracle, "oracle (C restatement)"
+
+
+def ddpm_cpu_oracle(masks, flip=False):
+    """bench.py's DDPM-256 network (seed-0 weights, bench.make_inputs) on the CPU with the oracle natives
+    (/root/reference/sige/cpu/gather.cpp:4-58, scatter.cpp:4-68, scatter_gather.cpp:5-84 restated / compiled): the full pass on
+    the original (`flip`: its mirror image) and one sparse forward per mask in `masks` ([256,256] bool, CPU).  Returns
+    (full, [sparse per mask]) as CPU tensors; memoised per process, so every model-level GPU test of one run compares with the
+    SAME reference outputs.  A HIP-vs-HIP self-check is only a statement about two HIP paths; this is the row-defining one."""
+    import bench
+    from oracle import oracle
+    from sige_amd import runtime
+    from sige_amd.utils import dilate_mask, downsample_mask
+    from sige_amd.workloads.ddpm_unet import DDPMConfig, DDPMSparseUNet
+
+    keys = [(bool(flip), m.numpy().tobytes()) for m in masks]
+    if ("full", bool(flip)) not in _ddpm_oracle or any(k not in _ddpm_oracle for k in keys):
+        torch.manual_seed(0)
+        model = DDPMSparseUNet(DDPMConfig()).eval()
+        x0, noise = bench.make_inputs()
+        if flip:
+            x0 = x0.flip(-1).contiguous()
+        t = torch.zeros(1)
+        n_thr = min(32, os.cpu_count() or 1)
+        torch.set_num_threads(n_thr)
+        oracle.set_num_threads(n_thr)
+        backend, _ = cpu_backend()
+        runtime.register_backend("cpu", backend)
+        try:
+            with torch.no_grad():
+                model.set_mode("full")
+                _ddpm_oracle[("full", bool(flip))] = model(x0, t).clone()
+                for k, m in zip(keys, masks):
+                    if k in _ddpm_oracle:
+                        continue
+                    model.set_masks(downsample_mask(dilate_mask(m, 5), 8))
+                    model.set_mode("sparse")
+                    _ddpm_oracle[k] = model(x0 + noise * m, t).clone()
+        finally:
+            runtime.unregister_backend("cpu")
+    return _ddpm_oracle[("full", bool(flip))], [_ddpm_oracle[k] for k in keys]
+
+
+class native_full_pass:
+    """Model-level GPU tests produce their caches with the library's exact-fp32 full pass (sige_amd/nn/dense.py
+    FULL_PASS_F32_NATIVE): fixed kernels, fixed summation order -> the same caches bit for bit on every MI355X.  torch's conv
+    goes through MIOpen's find mode, whose algorithm choice (and with it the last bits of every cache) may differ per box."""
+
+    def __enter__(self):
+        from sige_amd.nn import dense
+
+        self._dense, self._keep = dense, dense.FULL_PASS_F32_NATIVE
+        dense.FULL_PASS_F32_NATIVE = True
+        return self
+
+    def __exit__(self, *exc):
+        self._dense.FULL_PASS_F32_NATIVE = self._keep
+        return False
+
+
+SELF_ATOL = 1e-3   # two HIP forms of one forward against EACH OTHER: never tighter than the row's own tolerance (CONV_ATOL)
+
+
+def record_margin(test, what, value, tol):
+    """Append (measured difference, tolerance) of a model-level comparison to gpurun_out/test_margins.jsonl (when that scratch
+    directory exists: the GPU sessions copy it to profiles/), so tolerances are set from a recorded distribution over boxes
+    instead of one run's margin (VERDICT r5 next #1a)."""
+    import json
+
+    out = os.path.join(os.path.dirname(GOLDEN), os.pardir, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "test_margins.jsonl"), "a") as f:
+            f.write(json.dumps({"test": test, "what": what, "value": float(value), "tol": float(tol)}) + "\n")
+    return float(value)
