@@ -345,10 +345,71 @@ def edit_mask(ratio, rank=0):
 
 
 # ---------------------------------------------------------------- cpu baseline --
+CPU_THREADS_CAP = 32
+CPU_THREADS_CAP_REASON = ("OpenMP over all 256 hardware threads of the GPU box is slower than 16-32 threads on loops this small "
+                          "(124 tiles per layer at a 1.2 % edit; measured in round 2); SIGE_CPU_THREADS overrides")
+REPO_MODEL = "repo workload on reference natives"
+REFERENCE_MODEL = "reference sige.nn + diffusion/models/ddpm_arch/sige_fused_unet.py (unmodified) on oracle/_ref"
+
+
+def cpu_threads():
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(1, min(avail, int(os.environ.get("SIGE_CPU_THREADS", str(CPU_THREADS_CAP)))))
+
+
+def reference_root():
+    """The mounted reference (build container only; absent on the GPU box), or None."""
+    root = os.environ.get("SIGE_REFERENCE", "/root/reference")
+    ok = os.path.isfile(os.path.join(root, "diffusion", "models", "ddpm_arch", "sige_fused_unet.py")) and os.path.isdir(os.path.join(root, "sige", "nn"))
+    return root if ok else None
+
+
+def cpu_reference_unmodified(root, ratios, headline_ratio, seconds, cores):
+    """BASELINE.md 3 to the letter: the reference's OWN `sige.nn` and `sige_fused_unet.py`, unmodified, on its
+    compiled sige/cpu (oracle/_ref), in a process of its own (benchlib/ref_cpu_leg.py) with this run's weights / image / noise /
+    masks.  Returns (times, {ratio: sparse output}) or None when that stack cannot be set up."""
+    import subprocess
+    import tempfile
+
+    from oracle import build_ref
+    from sige_amd.workloads.ddpm_unet import DDPMConfig, DDPMSparseUNet
+
+    try:
+        build_ref.load()
+    except Exception:
+        return None
+    torch.manual_seed(0)
+    model = DDPMSparseUNet(DDPMConfig()).eval()
+    x0, noise = make_inputs()
+    with tempfile.TemporaryDirectory() as d:
+        job, out = os.path.join(d, "job.pt"), os.path.join(d, "out.pt")
+        torch.save({"state": model.state_dict(), "x0": x0, "noise": noise, "masks": {r: edit_mask(r) for r in ratios},
+                    "headline": headline_ratio}, job)
+        cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "benchlib", "ref_cpu_leg.py"),
+               "--reference", root, "--job", job, "--seconds", str(seconds), "--threads", str(cores), "--out", out]
+        try:
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=max(600.0, 20 * seconds))
+        except subprocess.TimeoutExpired:
+            return None
+        if res.returncode != 0:
+            sys.stderr.write("cpu_baseline: the unmodified reference stack failed, falling back to the repo workload:\n" + res.stderr[-1500:] + "\n")
+            return None
+        info = json.loads(res.stdout.strip().splitlines()[-1])
+        return info["times"], torch.load(out)
+
+
 def cpu_reference(ratios, headline_ratio, seconds):
-    """The same U-Net, weights, original image, noise and masks as the GPU run (rank 0's edit) on the host cores, native
-    ops from oracle/_ref (the reference's own compiled sige/cpu backend) or, if that is absent, from the C restatement;
-    the tile convs are the reference's own F.conv2d call.  Returns (cpu_baseline dict, {ratio: sparse output}).
+    """The same weights, original image, noise and masks as the GPU run (rank 0's edit) on the host cores.  Returns
+    (cpu_baseline dict, {ratio: sparse output}).
+    * the reference is mounted (build container): its unmodified `sige.nn` + `sige_fused_unet.py` on oracle/_ref --
+      `"model": REFERENCE_MODEL` (cpu_reference_unmodified);
+    * otherwise (the GPU box: /root/reference does not exist there): this repo's DDPMSparseUNet / sige_amd.nn on the natives of
+      oracle/_ref (the reference's own compiled sige/cpu backend, shipped as a .so) or, if that is absent, of the C restatement --
+      `"model": REPO_MODEL`; the workload is pinned to the reference model by tests/test_reference_models.py
+      (test_workload_unet_equals_reference_model); the tile convs are the reference's own F.conv2d call either way.
     Timing protocol: 5 warm-up + up to 20 timed sparse forwards at the headline ratio, bounded by
     `seconds`; `value` is quoted on the MEDIAN."""
     import statistics
@@ -358,62 +419,65 @@ def cpu_reference(ratios, headline_ratio, seconds):
     from sige_amd.utils import dilate_mask, downsample_mask
     from sige_amd.workloads.ddpm_unet import DDPMConfig, DDPMSparseUNet
 
-    ref = None
-    try:
-        ref = build_ref.load()
-    except Exception:
+    cores = cpu_threads()
+    outs, times, model_name, kind = {}, [], REPO_MODEL, None
+    root = reference_root()
+    if root is not None and seconds > 0:
+        got = cpu_reference_unmodified(root, ratios, headline_ratio, seconds, cores)
+        if got is not None:
+            times, outs = got
+            model_name, kind = REFERENCE_MODEL, "reference"
+    if kind is None:
         ref = None
-    kind = "reference" if ref is not None else "port"
-    # threads actually used: the affinity mask, capped -- OpenMP over 256 hardware
-    # threads on loops this small is slower than 16-32 (measured on the GPU box)
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    cores = max(1, min(avail, int(os.environ.get("SIGE_CPU_THREADS", "32"))))
-    torch.set_num_threads(cores)
-    oracle.set_num_threads(cores)
-    os.environ["OMP_NUM_THREADS"] = str(cores)
-    runtime.register_backend("cpu", oracle.as_backend(ref) if ref is not None else oracle)
-    outs, times = {}, []
-    try:
-        torch.manual_seed(0)
-        model = DDPMSparseUNet(DDPMConfig()).eval()
-        x0, noise = make_inputs()
-        t = torch.zeros(1)
-        with torch.no_grad():
-            model.set_mode("full")
-            model(x0, t)
-            for r in ratios:
-                mask = edit_mask(r)
-                model.set_masks(downsample_mask(dilate_mask(mask, 5), 8))
-                model.set_mode("sparse")
-                outs[r] = model(x0 + noise * mask, t)
-            if seconds > 0:
-                mask = edit_mask(headline_ratio)
-                x1 = x0 + noise * mask
-                model.set_masks(downsample_mask(dilate_mask(mask, 5), 8))
-                t_begin = time.perf_counter()
-                for i in range(25):
-                    t0 = time.perf_counter()
-                    model(x1, t)
-                    if i >= 5:
-                        times.append(time.perf_counter() - t0)
-                    if time.perf_counter() - t_begin > seconds and len(times) >= 3:
-                        break
-    finally:
-        runtime.unregister_backend("cpu")
+        try:
+            ref = build_ref.load()
+        except Exception:
+            ref = None
+        kind = "reference" if ref is not None else "port"
+        # threads actually used: the affinity mask, capped (CPU_THREADS_CAP_REASON)
+        torch.set_num_threads(cores)
+        oracle.set_num_threads(cores)
+        os.environ["OMP_NUM_THREADS"] = str(cores)
+        runtime.register_backend("cpu", oracle.as_backend(ref) if ref is not None else oracle)
+        try:
+            torch.manual_seed(0)
+            model = DDPMSparseUNet(DDPMConfig()).eval()
+            x0, noise = make_inputs()
+            t = torch.zeros(1)
+            with torch.no_grad():
+                model.set_mode("full")
+                model(x0, t)
+                for r in ratios:
+                    mask = edit_mask(r)
+                    model.set_masks(downsample_mask(dilate_mask(mask, 5), 8))
+                    model.set_mode("sparse")
+                    outs[r] = model(x0 + noise * mask, t)
+                if seconds > 0:
+                    mask = edit_mask(headline_ratio)
+                    x1 = x0 + noise * mask
+                    model.set_masks(downsample_mask(dilate_mask(mask, 5), 8))
+                    t_begin = time.perf_counter()
+                    for i in range(25):
+                        t0 = time.perf_counter()
+                        model(x1, t)
+                        if i >= 5:
+                            times.append(time.perf_counter() - t0)
+                        if time.perf_counter() - t_begin > seconds and len(times) >= 3:
+                            break
+        finally:
+            runtime.unregister_backend("cpu")
+        natives = "oracle/_ref (reference sige/cpu)" if ref is not None else "oracle C restatement"
+    else:
+        natives = "oracle/_ref (reference sige/cpu)"
     base = None
     if times:
         med = statistics.median(times)
         base = {"value": round(1.0 / med, 3), "unit": "forward/s", "ms_per_forward": round(med * 1e3, 2),
                 "ms_per_forward_mean": round(sum(times) / len(times) * 1e3, 2), "statistic": "median", "cores": cores,
-                "host_cpus": os.cpu_count(), "kind": kind,
+                "host_cpus": os.cpu_count(), "kind": kind, "model": model_name, "threads_cap_reason": CPU_THREADS_CAP_REASON,
                 "sample": "%d timed sparse DDPM-256 U-Net forwards at %.1f%% edit after 5 warm-ups (same weights, original "
-                          "image, noise and masks as the GPU run; native ops = %s, tile convs = torch CPU F.conv2d as in "
-                          "sige/nn/base.py:88-89)" % (len(times), headline_ratio * 100,
-                                                     "oracle/_ref (reference sige/cpu)" if ref is not None
-                                                     else "oracle C restatement")}
+                          "image, noise and masks as the GPU run; model = %s; native ops = %s, tile convs = torch CPU F.conv2d "
+                          "as in sige/nn/base.py:88-89)" % (len(times), headline_ratio * 100, model_name, natives)}
     return base, outs
 
 

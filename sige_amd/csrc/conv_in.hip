@@ -4,11 +4,8 @@
 //
 // With K = 9*Cin = 27 the layer is one thin GEMM per pixel block: M = 32 pixels, N = Cout,
 // K = 27 (padded to 28 = 14 steps of the 32x32x2 f32 MFMA).  It is bound by the 33.5 MB of
-// channels-last output (0.8 MB in), so the kernel is arranged around the stores: in the
-// 32x32 accumulator layout the 32 lanes of a half-wave hold 32 consecutive output channels
-// of one pixel = one 128-byte segment per pixel and store instruction.
-// Lane (kq, j) owns pixel j of the block and the K indices 2s + kq; the weights
-// (Cout/32 x 14 registers) and the bias stay in registers for all blocks of the wave.
+// channels-last output (0.8 MB in), so the kernel is arranged around the stores.
+// Lane (kq, j) owns pixel j of the block and the K indices 2s + kq.
 // The input is addressed through element strides (NCHW or channels-last alike).
 #include "common.hpp"
 
@@ -16,66 +13,75 @@ namespace sige {
 
 typedef float floatx16_in __attribute__((ext_vector_type(16)));
 
-constexpr int kInBPW = 2;  // pixel blocks per wave
-
+// Round 6 (16.6 us = 2.0 TB/s of stores, one wave per SIMD running load -> MFMA -> store in sequence):
+//   * ONE 32-pixel block per wave and 8 waves per CU (512 workgroups at 256 x 256): the A loads of one wave, the matrix
+//     instructions of another and the stores of a third overlap;
+//   * the weights reach the lanes through LDS (one coalesced read of the 13.8 KB tensor per workgroup; before: 56 dword loads
+//     per lane at a 108-byte lane stride);
+//   * the accumulators go through a wave-private LDS tile [32 pixels][Cout] and leave as 16-byte stores whose 64 lanes cover
+//     1 KB of consecutive addresses (before: 64 dword stores per lane).
 template <int CIN, int NBK>
 __global__ __launch_bounds__(256) void conv_in_gemm_kernel(const float *__restrict__ x, long sb, long sc, long sh, long sw,
                                                           int B, int H, int W, const float *__restrict__ w,  // [Cout, CIN, 3, 3]
                                                           const float *__restrict__ bias, float *__restrict__ out, long npix) {
     constexpr int K = 9 * CIN, KS = (K + 1) / 2, COUT = 32 * NBK;
+    constexpr int KP = 2 * KS + 1;  // odd row pitch of the weight stage: lane j reads row j -> 32 different banks
+    __shared__ __attribute__((aligned(16))) float wl[COUT * KP];
+    __shared__ __attribute__((aligned(16))) float tile[4][32 * COUT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kq = lane >> 5;
-    const long blk0 = ((long)blockIdx.x * 4 + wave) * kInBPW;
+    const long blk = (long)blockIdx.x * 4 + wave;
+    const long p = blk * 32 + j;
+    const bool live = p < npix;
 
-    // A operand of both blocks first (the longest dependency chain), then the weights
-    float a[kInBPW][KS];
-#pragma unroll
-    for (int i = 0; i < kInBPW; ++i) {
-        const long p = (blk0 + i) * 32 + j;
-        const bool live = p < npix;
+    // A operand first (the longest dependency chain): lane (kq, j) owns pixel j and the K indices 2s + kq = ci*9 + tap
+    float a[KS];
+    {
         const int b = (int)(p / ((long)H * W));
         const int rem = (int)(p - (long)b * H * W);
         const int h = rem / W, ww = rem - h * W;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            // k = 2s + kq = ci*9 + tap  (the weight's own [ci][ky][kx] order)
             const int k = 2 * s + kq;
             const int ci = kq ? (2 * s + 1) / 9 : (2 * s) / 9;
             const int tap = kq ? (2 * s + 1) % 9 : (2 * s) % 9;
             const int ih = h + tap / 3 - 1, iw = ww + tap % 3 - 1;
             const bool ok = live && k < K && ih >= 0 && ih < H && iw >= 0 && iw < W;
-            a[i][s] = ok ? x[b * sb + ci * sc + ih * sh + iw * sw] : 0.f;
+            a[s] = ok ? x[b * sb + ci * sc + ih * sh + iw * sw] : 0.f;
         }
     }
-    float breg[NBK][KS], biasr[NBK];
+    for (int i = tid; i < COUT * K; i += 256) wl[(i / K) * KP + i % K] = w[i];
+    if (K < 2 * KS)
+        for (int n = tid; n < COUT; n += 256) wl[n * KP + K] = 0.f;  // (K odd: the padded k index)
+    float biasr[NBK];
 #pragma unroll
-    for (int nb = 0; nb < NBK; ++nb) {
-        const int n = nb * 32 + j;
-        biasr[nb] = bias ? bias[n] : 0.f;
+    for (int nb = 0; nb < NBK; ++nb) biasr[nb] = bias ? bias[nb * 32 + j] : 0.f;
+    __syncthreads();
+    if (blk * 32 >= npix) return;  // (wave-uniform; after the only barrier)
+
+    floatx16_in acc[NBK];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) breg[nb][s] = (2 * s + kq < K) ? w[(size_t)n * K + 2 * s + kq] : 0.f;
-    }
+    for (int nb = 0; nb < NBK; ++nb)
 #pragma unroll
-    for (int i = 0; i < kInBPW; ++i) {
-        const long pb = (blk0 + i) * 32;
-        if (pb >= npix) break;  // wave-uniform
-        floatx16_in acc[NBK];
+        for (int r = 0; r < 16; ++r) acc[nb][r] = biasr[nb];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
 #pragma unroll
         for (int nb = 0; nb < NBK; ++nb)
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wl[(nb * 32 + j) * KP + 2 * s + kq], acc[nb], 0, 0, 0);
+    // reg r of lane (kq, j): pixel row m = (r & 3) + 8 * (r >> 2) + 4 * kq, output channel nb*32 + j  ->  tile[m][channel]
+    float *const tl = tile[wave];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nb][r] = biasr[nb];
+    for (int r = 0; r < 16; ++r)
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
+        for (int nb = 0; nb < NBK; ++nb) tl[((r & 3) + 8 * (r >> 2) + 4 * kq) * COUT + nb * 32 + j] = acc[nb][r];
+    __builtin_amdgcn_wave_barrier();  // (LDS is in order per wave: the tile is this wave's own)
+    // the tile is 32 * COUT consecutive floats of the output: 64 lanes x 16 bytes = 1 KB per store instruction
+    float *const ob = out + blk * 32 * COUT;
+    const long left = (npix - blk * 32) * COUT;  // floats of the output from this block on
 #pragma unroll
-            for (int nb = 0; nb < NBK; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], breg[nb][s], acc[nb], 0, 0, 0);
-        // reg r of lane (kq, j): pixel row m = (r & 3) + 8 * (r >> 2) + 4 * kq, output channel nb*32 + j
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long p = pb + (r & 3) + 8 * (r >> 2) + 4 * kq;
-            if (p < npix) {
-#pragma unroll
-                for (int nb = 0; nb < NBK; ++nb) out[p * COUT + nb * 32 + j] = acc[nb][r];
-            }
-        }
+    for (int i = 0; i < 32 * COUT / 256; ++i) {
+        const int o = (i * 64 + lane) * 4;
+        if (o < left) *reinterpret_cast<float4 *>(ob + o) = *reinterpret_cast<const float4 *>(tl + o);
     }
 }
 
@@ -93,7 +99,7 @@ extern "C" int sige_hip_conv3x3_small_cin_nhwc_f32(const float *x, int64_t strid
     if (Cin > 3 || !(Cout == 32 || Cout == 64 || Cout == 128)) return SIGE_HIP_EUNSUPPORTED;
     const long npix = (long)B * H * W;
     if (npix * Cout >= (1L << 40)) return SIGE_HIP_EUNSUPPORTED;
-    const long nblk = (npix + 31) / 32, grid = (nblk + 4 * kInBPW - 1) / (4 * kInBPW);
+    const long nblk = (npix + 31) / 32, grid = (nblk + 3) / 4;  // one 32-pixel block per wave
     if (grid > 0x7fffffffL) return SIGE_HIP_EUNSUPPORTED;
     hipStream_t st = as_stream(stream);
 #define SIGE_CI(CI, NBK) \

@@ -117,6 +117,14 @@ extern "C" int sige_hip_plan_truncate(void *plan, int section, int calls) {
     Plan *p = static_cast<Plan *>(plan);
     if (!p || section < 0 || section >= PLAN_SECTIONS || calls < 0 || calls > (int)p->calls[section].size()) return SIGE_HIP_EINVAL;
     p->calls[section].resize((size_t)calls);
+    // what the removed calls had marked goes with them: the plan is shape bound iff a REMAINING call says so
+    p->unbound = 0;
+    p->shape_bound = false;
+    for (int s = 0; s < PLAN_SECTIONS; ++s)
+        for (const auto &c : p->calls[s]) {
+            p->unbound += c->unbound;
+            p->shape_bound = p->shape_bound || c->fixed || c->unbound > 0;
+        }
     return SIGE_HIP_OK;
 }
 

@@ -29,6 +29,10 @@ namespace sige {
 struct Plan;
 
 struct PlanCall {
+    // what THIS call contributed to Plan::unbound / Plan::shape_bound when it was recorded: a call truncated out of the plan (a probe
+    // that returned an error, sige_hip_plan_truncate) takes its contribution with it
+    int unbound = 0;
+    bool fixed = false;
     virtual ~PlanCall() {}
     virtual int run(Plan &p, hipStream_t st) = 0;
 };
@@ -81,9 +85,10 @@ inline void plan_patch(const Plan &p, T &t) {
 // at RECORD time: is the pointer a count argument hangs on known to the plan?  (a miss used to fall back to the
 // recorded count silently -- stale counts under every later mask.)  A null pointer is an absent operand (its count is 0).
 template <typename P, typename T>
-inline void plan_check_key(Plan &p, const T &t) {
+inline void plan_check_key(Plan &p, PlanCall &call, const T &t) {
     const void *key = static_cast<const void *>(std::get<P::ip>(t));
     if (!key || p.slot_of.count(key) || p.const_ptrs.count(key)) return;
+    ++call.unbound;
     ++p.unbound;
     p.shape_bound = true;
 }
@@ -110,7 +115,7 @@ inline void plan_record(int (*fn)(A...), B... b) {
     Plan *p = g_plan_rec;
     if (!p) return;
     auto *call = new TypedCall<STREAM, std::tuple<Ps...>, A...>(fn, static_cast<A>(b)...);
-    (plan_check_key<Ps>(*p, call->args), ...);
+    (plan_check_key<Ps>(*p, *call, call->args), ...);
     p->calls[g_plan_section].emplace_back(call);
 }
 
@@ -127,6 +132,7 @@ inline void plan_record(int (*fn)(A...), B... b) {
         if (sige::g_plan_rec) {                                                        \
             sige::g_plan_rec->shape_bound = true;                                      \
             sige::plan_record<true>(&fn, __VA_ARGS__);                                 \
+            sige::g_plan_rec->calls[sige::g_plan_section].back()->fixed = true;        \
         }                                                                              \
     } while (0)
 // ... with the (index list, count) argument positions: SIGE_PLAN_HOOK_N(fn, (sige::CountOf<9, 10>), args...)

@@ -830,9 +830,11 @@ def conv_pack_weights(weight: torch.Tensor, R: int, S: int, stride: Tuple[int, i
         # the tile conv v3 (csrc/conv_tile3.hpp) reads the same weights in the dense-layer kernel's exact-fp32 order.  Packed HERE when
         # the router is on, whatever the first mask's tile count: the routing entry points decide per launch, in C, from the
         # count -- also when a launch plan replays this call under a larger mask later
+        # (memory: a second fp32 copy of these weights -- 455 MB for the DDPM U-Net, of 288 GB.  The source tensor is only kept
+        #  until the layout exists, and a shape without a v3 layout is remembered as such: ADVICE r5)
         packed._tile3_src = w
         if TILE3 is not False and TILE3_MIN_BLOCKS is not None:
-            packed.tile3 = wide_conv_pack_weights(w, "f32")
+            _tile3_pack_now(packed)
     return packed
 
 
@@ -1480,16 +1482,25 @@ TILE3 = None
 TILE3_MIN_BLOCKS = 512
 
 
+def _tile3_pack_now(packed):
+    t3 = wide_conv_pack_weights(packed._tile3_src, "f32")
+    packed.tile3 = False if t3 is None else t3  # (False: asked once, there is no v3 layout for this shape -- not asked again)
+    packed._tile3_src = None                    # (the contiguous copy of a channels-last weight is not kept alive)
+    return t3
+
+
 def _tile3_packed(packed):
     """The v3 layout of `packed`'s weights (packing it on demand), or None when the router is off / the shape has no v3 kernel."""
     if TILE3 is False or (TILE3 is None and TILE3_MIN_BLOCKS is None):
         return None
     t3 = getattr(packed, "tile3", None)
+    if t3 is False:
+        return None
     if t3 is None:
         src = getattr(packed, "_tile3_src", None)
         if src is None or torch.cuda.is_current_stream_capturing():
             return None  # (packing is a launch of its own: never inside a capture -- the warm-up forwards come first)
-        t3 = packed.tile3 = wide_conv_pack_weights(src, "f32")
+        t3 = _tile3_pack_now(packed)
     return t3
 
 

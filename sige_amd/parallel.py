@@ -365,50 +365,154 @@ def _all_ok(ok: bool, device=None, group=None) -> bool:
     return bool(v.item())
 
 
+_agree_calls = 0  # (every rank calls choose_distribution the same number of times: the same key prefix on every rank)
+
+
+def _default_store():
+    try:
+        return dist.distributed_c10d._get_default_store()
+    except Exception:  # noqa: BLE001
+        return None
+
+
+class _StoreAgreement:
+    """Status / time exchange between the ranks through the rendezvous store (a TCP key-value server), NOT through the process
+    group whose collectives are on trial: a rank whose candidate raised must not enter an all_reduce while the others are still
+    inside the candidate's broadcast (mismatched collectives deadlock), and a rank whose candidate hangs cannot answer through
+    the communicator it hangs in."""
+
+    def __init__(self, store, rank, world, prefix):
+        self.store, self.rank, self.world, self.prefix, self.n = store, rank, world, prefix, 0
+
+    def exchange(self, text: str, timeout_s: float) -> Optional[List[str]]:
+        """Every rank's `text`, or None if some rank did not answer within `timeout_s` (it hangs, or it died)."""
+        from datetime import timedelta
+
+        self.n += 1
+        key = "%s/%d/" % (self.prefix, self.n)
+        self.store.set(key + str(self.rank), text)
+        keys = [key + str(r) for r in range(self.world)]
+        try:
+            self.store.wait(keys, timedelta(seconds=timeout_s))
+        except Exception:  # noqa: BLE001 -- timeout
+            return None
+        return [self.store.get(k).decode() for k in keys]
+
+
+def _run_with_timeout(fn: Callable[[], None], timeout_s: float):
+    """fn() on a daemon thread of its own: (finished, error text or None).  A collective that never returns leaves the thread
+    blocked inside it; the caller goes on without it (and must not touch the communicator again)."""
+    import threading
+
+    box = {}
+    dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+
+    def target():
+        try:
+            if dev is not None:
+                torch.cuda.set_device(dev)  # (the current device is per thread)
+            fn()
+        except BaseException as e:  # noqa: BLE001 -- a collective this RCCL build cannot run must not end the job
+            box["err"] = repr(e)[:200]
+        box["done"] = True
+
+    th = threading.Thread(target=target, name="sige-distribution-trial", daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if not box.get("done"):
+        return False, "no return within %.1f s (hung collective)" % timeout_s
+    return True, box.get("err")
+
+
 def choose_distribution(candidates: Dict[str, Callable[[], None]], recompute: Optional[Callable[[], None]] = None,
                         watchdog_s: float = WATCHDOG_S, repeats: int = 2, device=None, group=None,
-                        sync: Optional[Callable[[], None]] = None, clock: Callable[[], float] = time.perf_counter) -> dict:
+                        sync: Optional[Callable[[], None]] = None, clock: Callable[[], float] = time.perf_counter,
+                        hang_timeout_s: Optional[float] = None) -> dict:
     """How should the original image's cache reach every rank of THIS job on THIS node?  Decide by measuring, once, at start-up.
 
     `candidates`: name -> callable that performs one complete distribution (collective + local refresh), tried in order;
     `recompute`: callable with which every rank rebuilds the cache itself (no communication), or None.  Every candidate runs
-    once (communicator set-up included); if that run took longer than `watchdog_s` on the slowest rank, or raised on any
-    rank, the candidate is out -- it is not given a second chance to hang the job; otherwise it runs `repeats - 1` more times
-    and its figure is the best run, max over ranks.  The fastest survivor wins, `recompute` competing like any other; if no
-    candidate survives, `recompute` is the fallback (and if there is none, RuntimeError).  Every rank takes the same decision:
-    times are max-reduced and failures min-reduced across the group before they are compared.
+    once (communicator set-up included) on a thread of its own, with three ways out:
+      * SLOW: the run took longer than `watchdog_s` on the slowest rank -> the candidate is out after that one run;
+      * RAISED on any rank -> out; the ranks learn of it through the rendezvous store, not through a collective, so the rank that
+        raised never enters a collective the others are not in;
+      * HUNG: no return within `hang_timeout_s` (default max(10 s, 5 x watchdog_s)) on any rank -> out, and the communicator counts
+        as poisoned: no further collective candidate is tried (a hung collective cannot be cancelled from Python; its thread stays
+        blocked, its stream is abandoned), the decision falls to `recompute`, which needs no communication.
+    Survivors run `repeats - 1` more times; the figure is the best run, max over ranks.  The fastest survivor wins, `recompute`
+    competing like any other; if no candidate survives, `recompute` is the fallback (and if there is none, RuntimeError).  Every
+    rank takes the same decision: times and failures are exchanged through the store before they are compared.
 
     Returns {"method_chosen", "methods_ms": {name: ms or None}, "errors": {name: text}, "fallback": reason or None,
-    "watchdog_s"}.  (RCCL has not run in this project's sessions -- whichever collective this build of it
-    handles badly, the scaling bench still finishes and says which one it used.)"""
+    "watchdog_s", "hang_timeout_s", "poisoned"}.  (VERDICT r4 next #8 / ADVICE r5: RCCL has only run with one rank in this
+    project's sessions -- whichever collective this build of it handles badly, slow, raising or hanging, the scaling bench still
+    finishes and says which one it used.)"""
+    global _agree_calls
     if sync is None:
         sync = (lambda: torch.cuda.synchronize()) if torch.cuda.is_available() else (lambda: None)
-    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    if hang_timeout_s is None:
+        hang_timeout_s = max(10.0, 5.0 * watchdog_s)
+    multi = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if multi else 1
+    rank = dist.get_rank(group) if multi else 0
+    agree = None
+    if world > 1:
+        store = _default_store()
+        if store is not None:
+            _agree_calls += 1
+            agree = _StoreAgreement(store, rank, world, "sige/choose/%d" % _agree_calls)
+    state = {"poisoned": False}
 
-    def barrier():
-        if world > 1:
-            dist.barrier(group=group)
+    def exchange(ok: bool, dt: float, hung: bool = False):
+        """(every rank ok, max time over the ranks); a rank that does not answer = a hang somewhere."""
+        if world == 1:
+            return ok, dt
+        if agree is None:  # (no store: the collectives of the group itself, as before round 6)
+            all_ok = _all_ok(ok, device=device, group=group)
+            return all_ok, (max_over_ranks(dt, device=device, group=group) if all_ok else dt)
+        # 1 = ran, 0 = raised, 2 = hung here (every rank must then stop using the communicator, not only this one)
+        got = agree.exchange("%d %.9f" % (2 if hung else (1 if ok else 0), dt), hang_timeout_s + 5.0)
+        if got is None or any(g.split()[0] == "2" for g in got):
+            state["poisoned"] = True
+            return False, dt
+        return all(g.split()[0] == "1" for g in got), max(float(g.split()[1]) for g in got)
 
-    def one_run(fn):
-        barrier()
-        sync()
+    def one_run(fn, is_collective):
+        if world > 1 and not state["poisoned"]:
+            if agree is not None:
+                if agree.exchange("b", hang_timeout_s + 5.0) is None:  # (a barrier that cannot hang in the communicator on trial)
+                    state["poisoned"] = True
+            else:
+                dist.barrier(group=group)
         t0 = clock()
-        err = None
-        try:
+
+        def trial():
+            sync()
             fn()
             sync()
-        except Exception as e:  # noqa: BLE001 -- a collective this RCCL build cannot run must not end the job
-            err = repr(e)[:200]
+
+        finished, err = _run_with_timeout(trial, hang_timeout_s) if is_collective else (True, None)
+        if not is_collective:
+            try:
+                trial()
+            except Exception as e:  # noqa: BLE001
+                err = repr(e)[:200]
         dt = clock() - t0
-        ok = _all_ok(err is None, device=device, group=group)
-        return (max_over_ranks(dt, device=device, group=group) if ok else None), err
+        if not finished:
+            state["poisoned"] = True
+        all_ok, worst = exchange(finished and err is None, dt, hung=not finished)
+        return (worst if all_ok else None), err
 
     methods_ms, errors = {}, {}
-    todo = list(candidates.items()) + ([("recompute", recompute)] if recompute is not None else [])
-    for name, fn in todo:
-        first, err = one_run(fn)
+    todo = [(n, f, True) for n, f in candidates.items()] + ([("recompute", recompute, False)] if recompute is not None else [])
+    for name, fn, is_collective in todo:
+        if is_collective and state["poisoned"]:
+            errors[name] = "skipped: a collective hung before it, the communicator is not used again"
+            methods_ms[name] = None
+            continue
+        first, err = one_run(fn, is_collective)
         if first is None:
-            errors[name] = err or "failed on another rank"
+            errors[name] = err or ("hung on another rank" if state["poisoned"] else "failed on another rank")
             methods_ms[name] = None
             continue
         if first > watchdog_s and name != "recompute":
@@ -417,7 +521,7 @@ def choose_distribution(candidates: Dict[str, Callable[[], None]], recompute: Op
             continue
         best = first
         for _ in range(max(0, repeats - 1)):
-            again, err = one_run(fn)
+            again, err = one_run(fn, is_collective)
             if again is None:
                 errors[name] = err or "failed on another rank"
                 best = None
@@ -425,14 +529,17 @@ def choose_distribution(candidates: Dict[str, Callable[[], None]], recompute: Op
             best = min(best, again)
         methods_ms[name] = None if best is None else round(best * 1e3, 3)
     alive = {k: v for k, v in methods_ms.items() if v is not None and k not in errors}
+    if state["poisoned"]:
+        alive = {k: v for k, v in alive.items() if k == "recompute"}  # (survivors measured before the hang share its communicator)
     fallback = None
     if not alive:
         raise RuntimeError("choose_distribution: no method worked: %r" % errors)
     chosen = min(alive, key=lambda k: alive[k])
     collectives_alive = [k for k in alive if k != "recompute"]
     if chosen == "recompute" and candidates and not collectives_alive:
-        fallback = "every collective failed or exceeded the watchdog: " + "; ".join("%s: %s" % kv for kv in errors.items())
-    return {"method_chosen": chosen, "methods_ms": methods_ms, "errors": errors, "fallback": fallback, "watchdog_s": watchdog_s}
+        fallback = "every collective failed, hung or exceeded the watchdog: " + "; ".join("%s: %s" % kv for kv in errors.items())
+    return {"method_chosen": chosen, "methods_ms": methods_ms, "errors": errors, "fallback": fallback, "watchdog_s": watchdog_s,
+            "hang_timeout_s": hang_timeout_s, "poisoned": state["poisoned"]}
 
 
 def shard(units: Sequence, rank: int = None, world: int = None) -> List:

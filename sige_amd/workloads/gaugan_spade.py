@@ -50,6 +50,17 @@ def _cl_gpu(t: torch.Tensor) -> bool:
     return hip.is_cl(t)
 
 
+def _refuse_in_stacked_mode(x: torch.Tensor, what: str) -> None:
+    """A torch fallback is not seam-aware: on the tall [1,C,E*h,w] tensor of a stacked forward (sige_amd/stacked.py) it would read
+    the neighbouring edit's rows as halo.  The standard configuration never gets here; anything that does fails loudly."""
+    if x.is_cuda:
+        from .. import hip
+
+        if hip.get_edit_batch() > 1:
+            raise RuntimeError("SpadeGenerator, stacked edits: %s has no library (seam-aware) form for this shape; refusing the "
+                               "torch fallback, which would mix neighbouring edits" % what)
+
+
 def _dense_conv(conv: nn.Conv2d, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """A dense (non-tiled) conv of a sparse-mode forward (+ residual): on channels-last GPU tensors one launch of the MFMA tile
     kernel with every tile active (sige_amd.nn.dense.fused_conv2d), else the plain conv -- the blocks below `num_sparse_layers`
@@ -58,6 +69,7 @@ def _dense_conv(conv: nn.Conv2d, x: torch.Tensor, residual: Optional[torch.Tenso
 
     if _cl_gpu(x) and fusable(conv) and conv.out_channels % 4 == 0:
         return fused_conv2d(conv, x, residual=residual)
+    _refuse_in_stacked_mode(x, "a dense conv")
     out = conv(x)
     return out if residual is None else residual + out
 
@@ -74,6 +86,7 @@ def _resize(x: torch.Tensor, size) -> torch.Tensor:
         out = hip.resize_nearest_cl(x, size)
         if out is not None:
             return out
+    _refuse_in_stacked_mode(x, "the nearest resize")
     return F.interpolate(x, size=size, mode="nearest")
 
 

@@ -128,3 +128,56 @@ line.emit(canned, detail_dirs=[])
     out = p.stdout.strip().splitlines()
     assert any("Librccl path" in ln for ln in out[:-2])
     assert json.loads(out[-1])["metric"] and "bench_detail" in json.loads(out[-2])
+
+
+# ---- cpu_baseline: which model ran on the CPU leg ---------------------------------------------------------
+def test_cpu_baseline_names_its_model_on_both_branches(monkeypatch):
+    """With the reference mounted the CPU leg is the reference's unmodified sige.nn + sige_fused_unet.py on oracle/_ref (a
+    process of its own); without it -- the GPU box -- this repo's workload on the same natives.  Either way the line says which,
+    and why the thread count is capped; the two legs compute the same sparse output."""
+    import pytest
+    import torch
+
+    import bench
+    from benchlib import line as bl
+
+    monkeypatch.setenv("SIGE_CPU_THREADS", "8")
+    r = 0.012
+    monkeypatch.setenv("SIGE_REFERENCE", "/nonexistent")
+    assert bench.reference_root() is None
+    base_repo, outs_repo = bench.cpu_reference([r], r, 0.5)
+    assert base_repo["model"] == bench.REPO_MODEL and base_repo["cores"] == 8 and "threads_cap_reason" in base_repo
+    assert bench.REPO_MODEL in base_repo["sample"]
+    compact = bl.compact({"metric": "m", "value": 1.0, "unit": "u", "cpu_baseline": base_repo})
+    assert compact["cpu_baseline"]["model"] == bench.REPO_MODEL and compact["cpu_baseline"]["kind"] in ("reference", "port")
+    monkeypatch.delenv("SIGE_REFERENCE")
+    if bench.reference_root() is None:
+        pytest.skip("the reference is not mounted: only the GPU-box branch can run")
+    base_ref, outs_ref = bench.cpu_reference([r], r, 0.5)
+    assert base_ref["model"] == bench.REFERENCE_MODEL and base_ref["kind"] == "reference"
+    assert base_ref["value"] > 0 and "sige_fused_unet.py" in base_ref["sample"]
+    # the same weights, inputs and mask through both stacks.  The reference's attention block keeps its cached GroupNorm affine
+    # as a TENSOR and indexes it with cache_id (sige_fused_unet.py:163-174): its sparse pass normalises every channel with channel
+    # 0's statistics.  The repo's workload reproduces that with reference_attn_quirk=True (and then agrees with the reference model
+    # file); the benchmarked configuration runs the intended math (DDPMConfig.reference_attn_quirk = False).
+    from oracle import oracle
+    from sige_amd import runtime
+    from sige_amd.utils import dilate_mask, downsample_mask
+    from sige_amd.workloads.ddpm_unet import DDPMConfig, DDPMSparseUNet
+
+    torch.manual_seed(0)
+    model = DDPMSparseUNet(DDPMConfig(reference_attn_quirk=True)).eval()
+    x0, noise = bench.make_inputs()
+    mask = bench.edit_mask(r)
+    runtime.register_backend("cpu", oracle)
+    try:
+        with torch.no_grad():
+            model.set_mode("full")
+            model(x0, torch.zeros(1))
+            model.set_masks(downsample_mask(dilate_mask(mask, 5), 8))
+            model.set_mode("sparse")
+            quirk = model(x0 + noise * mask, torch.zeros(1))
+    finally:
+        runtime.unregister_backend("cpu")
+    assert float((outs_ref[r] - quirk).abs().max()) < 2e-4
+    assert float((outs_ref[r] - outs_repo[r]).abs().max()) > 1e-3  # (the quirk is real: the two maths differ)

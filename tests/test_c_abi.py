@@ -223,8 +223,10 @@ def test_plan_marks_count_arguments_on_unknown_pointers_without_a_gpu():
             assert L.sige_hip_plan_begin(p, 1, 0) == 0
             assert call(0x3000) == -1                      # (x is null: EINVAL -- after the hook stored the call)
             assert L.sige_hip_plan_calls(p, 1) == 1
+            assert L.sige_hip_plan_unbound(p) == want_unbound and L.sige_hip_plan_shape_bound(p) == (1 if want_unbound else 0)
             assert L.sige_hip_plan_truncate(p, 1, 0) == 0 and L.sige_hip_plan_calls(p, 1) == 0   # what hip._Guarded does on an error status
             assert L.sige_hip_plan_end(p) == 0
-            assert L.sige_hip_plan_unbound(p) == want_unbound and L.sige_hip_plan_shape_bound(p) == (1 if want_unbound else 0)
+            # the failed probe takes what it had marked with it -- the plan is not left shape bound by a call it no longer holds
+            assert L.sige_hip_plan_unbound(p) == 0 and L.sige_hip_plan_shape_bound(p) == 0
         finally:
             assert L.sige_hip_plan_destroy(p) == 0

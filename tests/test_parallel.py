@@ -319,3 +319,67 @@ def test_choose_distribution_eight_ranks(tmp_path):
     m = res[0]["merit"]
     assert m["method_chosen"] == "recompute" and m["fallback"] is None and m["methods_ms"]["slow"] >= 600
     assert all("no method worked" in r["nothing"] for r in res)
+
+
+# ---- a collective that HANGS, and one that raises on a rank while the others are already inside it -------------------
+def _hang_worker(rank, world, port, out_dir):
+    import time
+
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sige_amd import parallel
+
+    buf = torch.full((1024,), float(rank))
+    log = []
+
+    def raises_inside():  # rank 1 fails AFTER the others have entered the collective: they wait for a peer that never comes
+        log.append("raises_inside")
+        if rank == 1:
+            time.sleep(0.2)
+            raise RuntimeError("died inside")
+        dist.broadcast(buf, src=0)
+
+    def never_tried():
+        log.append("never_tried")
+        dist.broadcast(buf, src=0)
+
+    def recompute():
+        log.append("recompute")
+        buf.fill_(0.0)
+
+    t0 = time.perf_counter()
+    res = parallel.choose_distribution({"raises_inside": raises_inside, "never_tried": never_tried}, recompute=recompute,
+                                       watchdog_s=0.3, sync=lambda: None, hang_timeout_s=1.5)
+    res["seconds"] = time.perf_counter() - t0
+    res["log"] = list(log)
+    torch.save(res, os.path.join(out_dir, "hang%d.pt" % rank))
+    os._exit(0)  # (the trial thread of the other ranks is still blocked inside gloo's broadcast: no orderly teardown)
+
+
+def test_choose_distribution_survives_a_hung_collective(tmp_path):
+    """The watchdog of round 5 was only read after a candidate returned.  Now: rank 1 raises while ranks 0 and 2 are inside the
+    broadcast (which therefore never completes on them) -- every rank is out of the trial after hang_timeout_s, learns through
+    the store that a rank hung, does not touch the communicator again (`never_tried` is skipped) and falls back to recompute."""
+    world = 3
+    ctx = mp.spawn(_hang_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=False)
+    deadline = 60.0
+    import time
+
+    t0 = time.time()
+    while time.time() - t0 < deadline and not all((tmp_path / ("hang%d.pt" % r)).exists() for r in range(world)):
+        time.sleep(0.2)
+    time.sleep(0.5)
+    for p_ in ctx.processes:
+        if p_.is_alive():
+            p_.terminate()
+    res = [torch.load(tmp_path / ("hang%d.pt" % r)) for r in range(world)]
+    for r in res:
+        assert r["method_chosen"] == "recompute" and r["poisoned"] is True
+        assert r["methods_ms"]["raises_inside"] is None and r["methods_ms"]["never_tried"] is None
+        assert "skipped" in r["errors"]["never_tried"]
+        assert "hung" in r["fallback"] or "no return" in r["fallback"] or "died inside" in r["fallback"]
+        assert r["log"] == ["raises_inside", "recompute", "recompute"]
+        assert r["seconds"] < 20.0
+    assert "died inside" in res[1]["errors"]["raises_inside"]
+    assert "no return" in res[0]["errors"]["raises_inside"]
