@@ -134,6 +134,22 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// 16-byte store of a kernel's OUTPUT (an epilogue's result that only later launches read).  Write-through (`sc1`): the bytes go to
+// the memory side while the kernel still runs instead of staying dirty in the XCD's write-back L2 until the end-of-kernel release
+// writes them back.  Measured (tools/probe/store_probe.hip, profiles/r6_store_probe.json: dependent launches each writing B bytes,
+// us per launch incl. the 1.7 us boundary): 1 MB 1.73 vs 1.93 plain, 4 MB 1.89 vs 2.29, 16 MB 3.47 vs 4.62, 32 MB 5.75 vs 7.15.
+// Not for data the SAME launch reads back (the line leaves this XCD's L2), nor for 4-byte stores (one fabric write each).
+// -DSIGE_PLAIN_STORES: plain stores everywhere (the A/B build).
+__device__ __forceinline__ void store_out4(float *p, float4 v) {
+#ifdef SIGE_PLAIN_STORES
+    *reinterpret_cast<float4 *>(p) = v;
+#else
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    const f32x4_t q = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(q) : "memory");
+#endif
+}
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

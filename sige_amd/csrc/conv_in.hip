@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256) void conv_in_gemm_kernel(const float *__restri
     // A operand first (the longest dependency chain): lane (kq, j) owns pixel j and the K indices 2s + kq = ci*9 + tap
     float a[KS];
     {
+        unsigned okm = 0;
         const int b = (int)(p / ((long)H * W));
         const int rem = (int)(p - (long)b * H * W);
         const int h = rem / W, ww = rem - h * W;
@@ -46,8 +47,14 @@ __global__ __launch_bounds__(256) void conv_in_gemm_kernel(const float *__restri
             const int tap = kq ? (2 * s + 1) % 9 : (2 * s) % 9;
             const int ih = h + tap / 3 - 1, iw = ww + tap % 3 - 1;
             const bool ok = live && k < K && ih >= 0 && ih < H && iw >= 0 && iw < W;
-            a[s] = ok ? x[b * sb + ci * sc + ih * sh + iw * sw] : 0.f;
+            okm |= ok ? (1u << s) : 0u;
+            // (branch-free: a conditional load compiles to an exec-masked branch per element with s_waitcnt vmcnt(0) between groups --
+            //  five dependent round trips in front of the first matrix instruction, measured in the ISA of the round-5 kernel.  Here
+            //  every lane loads a valid address -- element 0 when the tap is padding -- and the select follows, all 14 loads in flight)
+            a[s] = x[ok ? b * sb + ci * sc + ih * sh + iw * sw : 0];
         }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) a[s] = (okm >> s) & 1u ? a[s] : 0.f;
     }
     for (int i = tid; i < COUT * K; i += 256) wl[(i / K) * KP + i % K] = w[i];
     if (K < 2 * KS)
@@ -81,7 +88,7 @@ __global__ __launch_bounds__(256) void conv_in_gemm_kernel(const float *__restri
 #pragma unroll
     for (int i = 0; i < 32 * COUT / 256; ++i) {
         const int o = (i * 64 + lane) * 4;
-        if (o < left) *reinterpret_cast<float4 *>(ob + o) = *reinterpret_cast<const float4 *>(tl + o);
+        if (o < left) store_out4(ob + o, *reinterpret_cast<const float4 *>(tl + o));
     }
 }
 

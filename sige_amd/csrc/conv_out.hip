@@ -123,14 +123,8 @@ __global__ __launch_bounds__(256) void conv_out_nhwc_kernel(const float *__restr
 constexpr int kGT = 16, kGP = kGT + 2, kGPix = kGP * kGP, kGBlocks = (kGPix + 31) / 32;
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-// Round 6 (21.7 us = 1.55 TB/s): 8 waves per workgroup instead of 4.  The grid is one workgroup per CU (256
-// tiles of 16 x 16), and with one wave per SIMD a wave's affine + SiLU (VALU), its 64 dependent matrix instructions and its wait
-// for the next block's pixels ran one after the other; with two waves per SIMD one wave's VALU / load wait sits under the other's
-// matrix instructions (the two pipes are separate per SIMD).  The 11 blocks of a tile split 3 / 3 / 3 / 2 over the SIMDs as before.
-constexpr int kGW = 11;  // waves per workgroup = blocks of a 16 x 16 tile with its halo: every wave owns exactly one block
-
 template <int CIN, int COUT, int ACT>
-__global__ __launch_bounds__(64 * kGW) void conv_out_gemm_kernel(const float *__restrict__ x, int B, int H, int W,
+__global__ __launch_bounds__(256) void conv_out_gemm_kernel(const float *__restrict__ x, int B, int H, int W,
                                                            const float *__restrict__ scale, const float *__restrict__ shift, int aff_sb,
                                                            const float *__restrict__ w,  // [COUT, CIN, 3, 3]
                                                            const float *__restrict__ bias, float *__restrict__ out, float slope, int out_act) {
@@ -165,16 +159,14 @@ __global__ __launch_bounds__(64 * kGW) void conv_out_gemm_kernel(const float *__
 #pragma unroll
         for (int s = 0; s < KS; ++s) breg[s] = j < NP ? wp[s * 9] : 0.f;
     }
-    for (int c = tid; c < CIN; c += 64 * kGW) {
+    for (int c = tid; c < CIN; c += 256) {
         s_sc[c] = scale ? scale[b * aff_sb + c] : 1.f;
         s_sh[c] = shift ? shift[b * aff_sb + c] : 0.f;
     }
     __syncthreads();
 
-    for (int blk = wave; blk < kGBlocks; blk += kGW) {
-        // (activated IN PLACE: a second 64-register array next to `raw` and the weights spills at two waves per SIMD; and the affine
-        //  table is re-read from LDS per block: hoisted out of the loop it is 128 more live registers)
-        asm volatile("" ::: "memory");
+    for (int blk = wave; blk < kGBlocks; blk += 4) {
+        float a[KS];
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const float4 s4 = *reinterpret_cast<const float4 *>(s_sc + kq * KS + 4 * i);
@@ -187,31 +179,27 @@ __global__ __launch_bounds__(64 * kGW) void conv_out_gemm_kernel(const float *__
                 v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
                 v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
             }
-            raw[i] = v;
+            a[4 * i] = v.x; a[4 * i + 1] = v.y; a[4 * i + 2] = v.z; a[4 * i + 3] = v.w;
+        }
+        if (blk + 4 < kGBlocks) {  // (wave-uniform) next block's pixel while this one is in the matrix pipe
+            const float4 *src = pixel(blk + 4);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) raw[i] = src[i];
         }
         floatx16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const float4 q = raw[s >> 2];
-            const float av = (s & 3) == 0 ? q.x : (s & 3) == 1 ? q.y : (s & 3) == 2 ? q.z : q.w;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, breg[s], acc, 0, 0, 0);
-        }
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], breg[s], acc, 0, 0, 0);
         // reg r of lane (kq, j): pixel row m = (r & 3) + 8 * (r >> 2) + 4 * kq, column j
         if (j < NP) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) P[(blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq) * NP + j] = acc[r];
-        }
-        if (blk + kGW < kGBlocks) {  // (wave-uniform; three of the eight waves own a second block.  Not prefetched under the matrix
-            const float4 *src = pixel(blk + kGW);  //  instructions as with 4 waves: 64 more live registers spill at the 256 a wave
-#pragma unroll                                     //  has here, and the SIMD's other wave covers the wait)
-            for (int i = 0; i < NV; ++i) raw[i] = src[i];
         }
     }
     __syncthreads();
 
     const int oy = tid / kGT, ox = tid % kGT;
     const int h = h0 + oy, ww = w0 + ox;
-    if (tid < kGT * kGT && h < H && ww < W) {
+    if (h < H && ww < W) {
         float o[COUT];
 #pragma unroll
         for (int co = 0; co < COUT; ++co) o[co] = bias ? bias[co] : 0.f;
@@ -260,11 +248,11 @@ static int conv3x3_small_cout_impl(const float *x, int B, int C, int H, int W,
         if (tiles > 0x7fffffffL) return SIGE_HIP_EUNSUPPORTED;
 #define SIGE_CG(CI, N)                                                                                                 \
     if (activation == SIGE_HIP_ACT_SWISH)                                                                             \
-        conv_out_gemm_kernel<CI, N, SIGE_HIP_ACT_SWISH><<<(int)tiles, 64 * kGW, 0, st>>>(x, B, H, W, scale, shift, aff_sb, weight, bias, out, slope, out_act); \
+        conv_out_gemm_kernel<CI, N, SIGE_HIP_ACT_SWISH><<<(int)tiles, 256, 0, st>>>(x, B, H, W, scale, shift, aff_sb, weight, bias, out, slope, out_act); \
     else if (activation == SIGE_HIP_ACT_LEAKY)                                                                        \
-        conv_out_gemm_kernel<CI, N, SIGE_HIP_ACT_LEAKY><<<(int)tiles, 64 * kGW, 0, st>>>(x, B, H, W, scale, shift, aff_sb, weight, bias, out, slope, out_act); \
+        conv_out_gemm_kernel<CI, N, SIGE_HIP_ACT_LEAKY><<<(int)tiles, 256, 0, st>>>(x, B, H, W, scale, shift, aff_sb, weight, bias, out, slope, out_act); \
     else                                                                                                              \
-        conv_out_gemm_kernel<CI, N, SIGE_HIP_ACT_IDENTITY><<<(int)tiles, 64 * kGW, 0, st>>>(x, B, H, W, scale, shift, aff_sb, weight, bias, out, slope, out_act);
+        conv_out_gemm_kernel<CI, N, SIGE_HIP_ACT_IDENTITY><<<(int)tiles, 256, 0, st>>>(x, B, H, W, scale, shift, aff_sb, weight, bias, out, slope, out_act);
         if (C == 128) { if (Cout == 1) { SIGE_CG(128, 1) } else if (Cout == 2) { SIGE_CG(128, 2) } else { SIGE_CG(128, 3) } }
         else { if (Cout == 1) { SIGE_CG(64, 1) } else if (Cout == 2) { SIGE_CG(64, 2) } else { SIGE_CG(64, 3) } }
 #undef SIGE_CG

@@ -359,7 +359,7 @@ __device__ __forceinline__ void conv_tile3_body(const Tile3Args &a, const int bx
                 tv.x = sc.x * s.x; tv.y = sc.y * s.y; tv.z = sc.z * s.z; tv.w = sc.w * s.w;
                 tv.x = sh.x + tv.x; tv.y = sh.y + tv.y; tv.z = sh.z + tv.z; tv.w = sh.w + tv.w;
                 tv.x = swish(tv.x); tv.y = swish(tv.y); tv.z = swish(tv.z); tv.w = swish(tv.w);
-                *reinterpret_cast<float4 *>(dst2 + addr) = tv;
+                store_out4(dst2 + addr, tv);
             };
             if (a.twin0) twin(a.twin0, a.tscale0, a.tshift0);
             if (a.twin1) twin(a.twin1, a.tscale1, a.tshift1);
@@ -372,7 +372,7 @@ __device__ __forceinline__ void conv_tile3_body(const Tile3Args &a, const int bx
             s.x = oh.x + s.x; s.y = oh.y + s.y; s.z = oh.z + s.z; s.w = oh.w + s.w;
             if (a.oact == SIGE_HIP_ACT_SWISH) { s.x = swish(s.x); s.y = swish(s.y); s.z = swish(s.z); s.w = swish(s.w); }
         }
-        *reinterpret_cast<float4 *>(a.out + addr) = s;
+        store_out4(a.out + addr, s);
     }
 }
 

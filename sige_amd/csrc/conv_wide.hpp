@@ -418,7 +418,7 @@ __device__ __forceinline__ void conv_wide_body(const WideArgs &a, const int bx, 
             t.x = sc.x * s.x; t.y = sc.y * s.y; t.z = sc.z * s.z; t.w = sc.w * s.w;
             t.x = sh.x + t.x; t.y = sh.y + t.y; t.z = sh.z + t.z; t.w = sh.w + t.w;
             t.x = swish(t.x); t.y = swish(t.y); t.z = swish(t.z); t.w = swish(t.w);
-            *reinterpret_cast<float4 *>(dst2 + u.addr) = t;
+            store_out4(dst2 + u.addr, t);
         };
         if (a.twin0) twin(a.twin0, a.tscale0, a.tshift0);
         if (a.twin1) twin(a.twin1, a.tscale1, a.tshift1);
@@ -428,7 +428,7 @@ __device__ __forceinline__ void conv_wide_body(const WideArgs &a, const int bx, 
             s.x = oh.x + s.x; s.y = oh.y + s.y; s.z = oh.z + s.z; s.w = oh.w + s.w;
             if (a.oact == SIGE_HIP_ACT_SWISH) { s.x = swish(s.x); s.y = swish(s.y); s.z = swish(s.z); s.w = swish(s.w); }
         }
-        *reinterpret_cast<float4 *>((split_k ? a.fout : a.out) + u.addr) = s;
+        store_out4((split_k ? a.fout : a.out) + u.addr, s);  // (write-through: common.hpp)
     };
     // the workgroup's (sum, sum of squares) per output channel: 16 lanes per channel quad (4 in each wave) -> LDS -> one row
     // of `stats`; fixed order, no atomics: the same launch gives the same bits every time
