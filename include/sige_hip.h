@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SIGE_HIP_VERSION 308 /* 0.3.8: round 5 -- tile conv v3, GauGAN helpers, stacked SPADE */
+#define SIGE_HIP_VERSION 309 /* 0.3.9: round 6 -- tile conv v3 on fp16 operands (configs[4]), write-through epilogue stores */
 
 enum {
     SIGE_HIP_OK = 0,
@@ -518,6 +518,49 @@ int sige_hip_scatter_gather_conv_scatter_nhwc_v3_f32(
         const float *scale, int scaleB, int scaleC, const float *shift, int shiftB, int shiftC, int activation,
         const float *packed, const float *bias, int Cout, int kH, int kW,
         int offsetH, int offsetW, const float *residual,
+        const float *x1, const int32_t *table1, int gH1, int gW1, int N1, int R1, int S1,
+        float *twin0, const float *twin0_scale, const float *twin0_shift,
+        float *twin1, const float *twin1_scale, const float *twin1_shift,
+        const float *packed_tile3, int min_blocks,
+        float *out, void *stream);
+
+/* ... and the fp16-operand form of the three (round 6; BASELINE.json configs[4]): `packed` / `packed_tile3` =
+ * sige_hip_wide_conv_pack(prec = 0) of the weight; activations fp32 in HBM, rounded to fp16 (RNE) in the staging path, products exact
+ * in fp32, accumulation fp32 (v_mfma_f32_32x32x16_f16).  y_f16: the cached tensor of source 2 (x2 / y) holds halves; residual_f16:
+ * `residual` holds halves -- the fp16-stored caches of the _c16 entry points.  The two routing entry points replace
+ * sige_hip_gather_conv_nhwc_f16c and sige_hip_scatter_gather_conv_scatter_nhwc_f16c / _c16(compute = 1). */
+int sige_hip_tile_conv3_nhwc_f16c(
+        int source, const float *x, const void *x2, int y_f16, int B, int C1, int C2, int H, int W, int upsample2x,
+        const int32_t *active_indices, int N, const int32_t *scatter_map, int Rx, int Sx,
+        const float *scale, const float *shift, int affineB, int activation,
+        const float *packed, const float *bias, int Cout,
+        int to_full, int offsetH, int offsetW, int Ho, int Wo, const void *residual, int residual_f16,
+        const float *x1, const int32_t *table1, int gH1, int gW1, int N1, int R1, int S1,
+        const float *out_scale, const float *out_shift, int out_activation,
+        float *twin0, const float *twin_scale0, const float *twin_shift0,
+        float *twin1, const float *twin_scale1, const float *twin_shift1,
+        float *out, void *stream);
+int sige_hip_gather_conv_nhwc_v3_f16c(const float *x, const float *x2, int B, int C1, int C2, int H, int W,
+                                      int bH, int bW, const int32_t *active_indices, int N,
+                                      const float *scale, int scaleB, int scaleC,
+                                      const float *shift, int shiftB, int shiftC,
+                                      int activation,
+                                      const float *packed, const float *bias, int Cout, int kH, int kW,
+                                      int strideH, int strideW,
+                                      int to_full, int offsetH, int offsetW, const float *residual, int Ho, int Wo,
+                                      float *workspace, size_t workspace_floats,
+                                      const float *out_scale, const float *out_shift, int out_activation,
+                                      int upsample2x,
+                                      float *twin0, const float *twin0_scale, const float *twin0_shift,
+                                      float *twin1, const float *twin1_scale, const float *twin1_shift,
+                                      const float *packed_tile3, int min_blocks,
+                                      float *out, void *stream);
+int sige_hip_scatter_gather_conv_scatter_nhwc_v3_f16c(
+        const float *x, const void *y, int y_f16, int B, int Cin, int H, int W, int Rx, int Sx, int bH, int bW,
+        const int32_t *active_indices, int N, const int32_t *scatter_map,
+        const float *scale, int scaleB, int scaleC, const float *shift, int shiftB, int shiftC, int activation,
+        const float *packed, const float *bias, int Cout, int kH, int kW,
+        int offsetH, int offsetW, const void *residual, int residual_f16,
         const float *x1, const int32_t *table1, int gH1, int gW1, int N1, int R1, int S1,
         float *twin0, const float *twin0_scale, const float *twin0_shift,
         float *twin1, const float *twin1_scale, const float *twin1_shift,

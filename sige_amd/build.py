@@ -15,7 +15,7 @@ LIB_DIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIB_DIR, "libsige_hip.so")
 SOURCES = ["api.hip", "plan.hip", "gather.hip", "scatter.hip", "reduce_mask.hip", "mask_pipeline.hip", "block_conv.hip", "conv_k3s1.hip", "conv_k1.hip",
            "conv_k3s2.hip", "conv_k3s1_nhwc.hip", "conv_k1_nhwc.hip", "conv_k3s2_nhwc.hip", "conv_k3s1_nhwc_w8.hip", "conv_k1_nhwc_w8.hip", "conv_k3s1_nhwc_h.hip", "conv_k1_nhwc_h.hip", "conv_k3s1_nhwc_x.hip", "conv_k1_nhwc_x.hip", "conv_k3s1_nhwc_c16.hip", "conv_k3s1_nhwc_h_c16.hip", "conv_k3s1_nhwc_x_c16.hip", "conv_pair_nhwc_x_t4.hip", "conv_pair_nhwc_x_f4.hip",
-           "conv_pair_nhwc_t4.hip", "conv_pair_nhwc_t8.hip", "conv_pair_nhwc_f4.hip", "conv_pair_nhwc_f8.hip", "conv_pair_nhwc_h_t4.hip", "conv_pair_nhwc_h_f4.hip", "conv_wide.hip", "conv_wide_k3_p8.hip", "conv_wide_k3_f32.hip", "conv_wide_k1_p8.hip", "conv_wide_pair_f32.hip", "conv_wide_pair_x3.hip", "conv_wide_pair_f16.hip", "group_norm.hip", "attention.hip", "attention_fused.hip", "attention_tokens.hip", "nhwc_ops.hip", "conv_out.hip", "conv_in.hip", "spade_ops.hip", "conv_tile3.hip", "conv_tile3_f32.hip", "token_ops.hip"]
+           "conv_pair_nhwc_t4.hip", "conv_pair_nhwc_t8.hip", "conv_pair_nhwc_f4.hip", "conv_pair_nhwc_f8.hip", "conv_pair_nhwc_h_t4.hip", "conv_pair_nhwc_h_f4.hip", "conv_wide.hip", "conv_wide_k3_p8.hip", "conv_wide_k3_f32.hip", "conv_wide_k1_p8.hip", "conv_wide_pair_f32.hip", "conv_wide_pair_x3.hip", "conv_wide_pair_f16.hip", "group_norm.hip", "attention.hip", "attention_fused.hip", "attention_tokens.hip", "nhwc_ops.hip", "conv_out.hip", "conv_in.hip", "spade_ops.hip", "conv_tile3.hip", "conv_tile3_f32.hip", "token_ops.hip", "conv_tile3_f16.hip"]
 # -ffp-contract=off: the reference applies scale then shift as two separately
 # rounded fp32 ops (sige/cpu/gather.cpp:33-53); an fma would differ in the last bit.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]

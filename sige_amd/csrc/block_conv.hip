@@ -1396,3 +1396,62 @@ extern "C" int sige_hip_scatter_gather_conv_scatter_nhwc_v3_f32(
     }
     return scatter_gather_conv_scatter_nhwc_impl<0>(SIGE_SGS_CONV_ARGS);
 }
+
+
+// ... and for fp16 operands (round 6, BASELINE.json configs[4]): sige_hip_gather_conv_nhwc_f16c /
+// sige_hip_scatter_gather_conv_scatter_nhwc_f16c | _c16(compute = 1) with the weights in the v3 fp16 layout
+// (`packed_tile3` = sige_hip_wide_conv_pack(prec = 0)) and a threshold beside them; routed exactly like the fp32 pair above.
+extern "C" int sige_hip_gather_conv_nhwc_v3_f16c(const float *x, const float *x2, int B, int C1, int C2, int H, int W,
+                                                 int bH, int bW, const int32_t *active_indices, int N,
+                                                 const float *scale, int scaleB, int scaleC,
+                                                 const float *shift, int shiftB, int shiftC,
+                                                 int activation,
+                                                 const float *packed, const float *bias, int Cout, int kH, int kW,
+                                                 int strideH, int strideW,
+                                                 int to_full, int offsetH, int offsetW, const float *residual, int Ho, int Wo,
+                                                 float *workspace, size_t workspace_floats,
+                                                 const float *out_scale, const float *out_shift, int out_activation,
+                                                 int upsample2x,
+                                                 float *twin0, const float *twin0_scale, const float *twin0_shift,
+                                                 float *twin1, const float *twin1_scale, const float *twin1_shift,
+                                                 const float *packed_tile3, int min_blocks,
+                                                 float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_gather_conv_nhwc_v3_f16c, (sige::CountOf<9, 10>), x, x2, B, C1, C2, H, W, bH, bW, active_indices, N, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, packed, bias, Cout, kH, kW, strideH, strideW, to_full, offsetH, offsetW, residual, Ho, Wo, workspace, workspace_floats, out_scale, out_shift, out_activation, upsample2x, twin0, twin0_scale, twin0_shift, twin1, twin1_scale, twin1_shift, packed_tile3, min_blocks, out, stream);
+    const int Cin = C1 + C2;
+    const bool aff_ok = (!scale && !shift) || (scale && shift && scaleC == Cin && shiftC == Cin && scaleB == shiftB && (scaleB == 1 || scaleB == B));
+    if (B > 0 && N > 0 && aff_ok && tile3_takes(packed_tile3, min_blocks, B, N, C1, C2, Cout, kH, kW, bH, bW, strideH, strideW, as_stream(stream))) {
+        const int rc = tile_conv3_launch(T3_GATHER, x, x2, B, C1, C2, H, W, upsample2x, active_indices, N, nullptr, 0, 0, scale, shift,
+                                         scale ? scaleB : 0, activation, packed_tile3, bias, Cout, to_full, offsetH, offsetW, Ho, Wo,
+                                         to_full ? residual : nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, out_scale, out_shift, out_activation,
+                                         twin0, twin0_scale, twin0_shift, twin1, twin1_scale, twin1_shift, out, stream, WIDE_F16, 0, 0);
+        if (rc != SIGE_HIP_EUNSUPPORTED) return rc;
+    }
+    return gather_conv_nhwc_impl<1>(SIGE_GATHER_CONV_ARGS);
+}
+
+// y_f16 / residual_f16: the cached tensor / the cached shortcut tensor hold halves (the _c16 form); 0 / 0 = the _f16c form
+extern "C" int sige_hip_scatter_gather_conv_scatter_nhwc_v3_f16c(
+        const float *x, const void *y, int y_f16, int B, int Cin, int H, int W, int Rx, int Sx, int bH, int bW,
+        const int32_t *active_indices, int N, const int32_t *scatter_map,
+        const float *scale, int scaleB, int scaleC, const float *shift, int shiftB, int shiftC, int activation,
+        const float *packed, const float *bias, int Cout, int kH, int kW,
+        int offsetH, int offsetW, const void *residual, int residual_f16,
+        const float *x1, const int32_t *table1, int gH1, int gW1, int N1, int R1, int S1,
+        float *twin0, const float *twin0_scale, const float *twin0_shift,
+        float *twin1, const float *twin1_scale, const float *twin1_shift,
+        const float *packed_tile3, int min_blocks,
+        float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_scatter_gather_conv_scatter_nhwc_v3_f16c, (sige::CountOf<11, 12>, sige::CountOf<31, 34>), x, y, y_f16, B, Cin, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, packed, bias, Cout, kH, kW, offsetH, offsetW, residual, residual_f16, x1, table1, gH1, gW1, N1, R1, S1, twin0, twin0_scale, twin0_shift, twin1, twin1_scale, twin1_shift, packed_tile3, min_blocks, out, stream);
+    const float *yh = static_cast<const float *>(y), *rh = static_cast<const float *>(residual);
+    if (B > 0 && N > 0 && !scale && !shift && activation == SIGE_HIP_ACT_IDENTITY &&
+        tile3_takes(packed_tile3, min_blocks, B, N, Cin, 0, Cout, kH, kW, bH, bW, 1, 1, as_stream(stream))) {
+        const int rc = tile_conv3_launch(T3_SCATTER_GATHER, x, yh, B, Cin, 0, H, W, 0, active_indices, N, scatter_map, Rx, Sx, nullptr, nullptr, 0,
+                                         SIGE_HIP_ACT_IDENTITY, packed_tile3, bias, Cout, 1, offsetH, offsetW, H, W, rh,
+                                         x1, table1, gH1, gW1, N1, R1, S1, nullptr, nullptr, 0,
+                                         twin0, twin0_scale, twin0_shift, twin1, twin1_scale, twin1_shift, out, stream, WIDE_F16, y_f16, residual_f16);
+        if (rc != SIGE_HIP_EUNSUPPORTED) return rc;
+    }
+    return scatter_gather_conv_scatter_nhwc_impl<1>(x, yh, B, Cin, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB,
+                                                    shiftC, activation, packed, bias, Cout, kH, kW, offsetH, offsetW, rh, x1, table1, gH1, gW1, N1, R1, S1,
+                                                    twin0, twin0_scale, twin0_shift, twin1, twin1_scale, twin1_shift, out, stream, y_f16, residual_f16);
+}

@@ -4,7 +4,9 @@
 
 namespace sige {
 template <> void launch_conv_tile3_gather<2>(const Tile3Args &, bool, bool, bool, hipStream_t);
-template <> void launch_conv_tile3_sg<2>(const Tile3Args &, bool, hipStream_t);
+template <> void launch_conv_tile3_sg<2>(const Tile3Args &, bool, bool, hipStream_t);
+template <> void launch_conv_tile3_gather<2, WIDE_F16>(const Tile3Args &, bool, bool, bool, hipStream_t);
+template <> void launch_conv_tile3_sg<2, WIDE_F16>(const Tile3Args &, bool, bool, hipStream_t);
 int flush_held_conv();  // (block_conv.hip: a shortcut conv held by sige_hip_conv_pair_begin is launched on its own first)
 }  // namespace sige
 
@@ -25,8 +27,11 @@ int sige::tile_conv3_launch(
         const float *out_scale, const float *out_shift, int out_activation,
         float *twin0, const float *twin_scale0, const float *twin_shift0,
         float *twin1, const float *twin_scale1, const float *twin_shift1,
-        float *out, void *stream) {
+        float *out, void *stream, int prec, int y_f16, int residual_f16) {
     if (source != T3_GATHER && source != T3_SCATTER_GATHER) return SIGE_HIP_EINVAL;
+    if (prec != WIDE_F32 && prec != WIDE_F16) return SIGE_HIP_EUNSUPPORTED;
+    if (y_f16 && source != T3_SCATTER_GATHER) return SIGE_HIP_EINVAL;
+    if ((y_f16 || residual_f16) && prec != WIDE_F16) return SIGE_HIP_EUNSUPPORTED;  // (fp16-stored caches: the f16 form only)
     if (B < 0 || N < 0 || C1 <= 0 || C2 < 0 || Cout <= 0 || H <= 0 || W <= 0) return SIGE_HIP_EINVAL;
     if ((long)B * N == 0) return SIGE_HIP_OK;
     const bool sg = source == T3_SCATTER_GATHER;
@@ -63,11 +68,17 @@ int sige::tile_conv3_launch(
     a.ntn = Cout / 64; a.nchunks = Cin / 64; a.nchunks1 = C1 / 64;
     a.hp_shift = stacked_shift(H);
     if (a.hp_shift < 0 || (a.hp_shift && B != 1)) return SIGE_HIP_EUNSUPPORTED;
+    a.res_f16 = residual_f16 ? 1 : 0;
     const int rc = flush_held_conv();
     if (rc != SIGE_HIP_OK) return rc;
     hipStream_t st = as_stream(stream);
-    if (sg) launch_conv_tile3_sg<2>(a, to_full != 0, st);
-    else launch_conv_tile3_gather<2>(a, scale != nullptr, C2 > 0, to_full != 0, st);
+    if (prec == WIDE_F16) {
+        if (sg) launch_conv_tile3_sg<2, WIDE_F16>(a, to_full != 0, y_f16 != 0, st);
+        else launch_conv_tile3_gather<2, WIDE_F16>(a, scale != nullptr, C2 > 0, to_full != 0, st);
+    } else {
+        if (sg) launch_conv_tile3_sg<2>(a, to_full != 0, false, st);
+        else launch_conv_tile3_gather<2>(a, scale != nullptr, C2 > 0, to_full != 0, st);
+    }
     return launch_status(1);
 }
 
@@ -86,4 +97,25 @@ extern "C" int sige_hip_tile_conv3_nhwc_f32(
     return tile_conv3_launch(source, x, x2, B, C1, C2, H, W, upsample2x, active_indices, N, scatter_map, Rx, Sx, scale, shift, affineB, activation,
                              packed, bias, Cout, to_full, offsetH, offsetW, Ho, Wo, residual, x1, table1, gH1, gW1, N1, R1, S1,
                              out_scale, out_shift, out_activation, twin0, twin_scale0, twin_shift0, twin1, twin_scale1, twin_shift1, out, stream);
+}
+
+// fp16 operands (BASELINE.json configs[4]): `packed` = sige_hip_wide_conv_pack(prec = 0) of the same weight; activations are fp32 in
+// HBM and rounded to fp16 (RNE) in the staging path, products exact, accumulation fp32.  y_f16: source 2's cached tensor x2 holds
+// halves; residual_f16: `residual` holds halves (the fp16-stored caches of SIGEModel.set_cache_dtype("f16")).
+extern "C" int sige_hip_tile_conv3_nhwc_f16c(
+        int source, const float *x, const void *x2, int y_f16, int B, int C1, int C2, int H, int W, int upsample2x,
+        const int32_t *active_indices, int N, const int32_t *scatter_map, int Rx, int Sx,
+        const float *scale, const float *shift, int affineB, int activation,
+        const float *packed, const float *bias, int Cout,
+        int to_full, int offsetH, int offsetW, int Ho, int Wo, const void *residual, int residual_f16,
+        const float *x1, const int32_t *table1, int gH1, int gW1, int N1, int R1, int S1,
+        const float *out_scale, const float *out_shift, int out_activation,
+        float *twin0, const float *twin_scale0, const float *twin_shift0,
+        float *twin1, const float *twin_scale1, const float *twin_shift1,
+        float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_tile_conv3_nhwc_f16c, (sige::CountOf<10, 11>, sige::CountOf<30, 33>), source, x, x2, y_f16, B, C1, C2, H, W, upsample2x, active_indices, N, scatter_map, Rx, Sx, scale, shift, affineB, activation, packed, bias, Cout, to_full, offsetH, offsetW, Ho, Wo, residual, residual_f16, x1, table1, gH1, gW1, N1, R1, S1, out_scale, out_shift, out_activation, twin0, twin_scale0, twin_shift0, twin1, twin_scale1, twin_shift1, out, stream);
+    return tile_conv3_launch(source, x, static_cast<const float *>(x2), B, C1, C2, H, W, upsample2x, active_indices, N, scatter_map, Rx, Sx, scale, shift,
+                             affineB, activation, packed, bias, Cout, to_full, offsetH, offsetW, Ho, Wo, static_cast<const float *>(residual),
+                             x1, table1, gH1, gW1, N1, R1, S1, out_scale, out_shift, out_activation, twin0, twin_scale0, twin_shift0,
+                             twin1, twin_scale1, twin_shift1, out, stream, WIDE_F16, y_f16, residual_f16);
 }

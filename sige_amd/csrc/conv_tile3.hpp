@@ -26,23 +26,32 @@ namespace sige {
 
 enum { T3_GATHER = 1, T3_SCATTER_GATHER = 2 };
 
-template <int TPW_>
+// PREC_: WIDE_F32 -- exact fp32 (v_mfma_f32_32x32x2_f32); WIDE_F16 (round 6, BASELINE.json configs[4]) -- operands rounded to fp16
+// (RNE) in the staging path, fp32 accumulation on v_mfma_f32_32x32x16_f16: ONE matrix instruction per tap and tile pair contracts
+// the wave's 16 channels (eight in the fp32 form), the stage of a pixel is 32 bytes instead of 64 and a k-step of packed weights 2 KB
+// instead of 4 -- so the whole chunk's weights (9 steps) ride in the register ring.
+template <int TPW_, int PREC_ = WIDE_F32>
 struct Tile3Geo {
     static constexpr int TPW = TPW_;                   // tiles per workgroup
+    static constexpr int PREC = PREC_;
+    static constexpr bool F32 = PREC_ == WIDE_F32;
+    static_assert(PREC_ == WIDE_F32 || PREC_ == WIDE_F16, "tile conv v3: exact fp32 or fp16 operands");
     static constexpr int KK = 9;
     static constexpr int MTN = TPW_ / 2;               // 32-pixel M tiles per wave (two 4x4 tiles each)
     static constexpr int BM = 16 * TPW_;               // output pixels per workgroup
-    static constexpr int NP = 2, CW = 16, CC = 64, STEPS = 9;
+    static constexpr int NP = F32 ? 2 : 1, CW = 16, CC = 64, STEPS = 9;
     static constexpr int NPX = 36 * TPW_;              // staged pixels: TPW windows of 6x6
     static constexpr int QP = CW / 4;                  // float4 units per staged pixel (per wave)
     static constexpr int UNITS = NPX * QP;
     static constexpr int NS = (UNITS + 63) / 64;       // staging slots per lane
-    static constexpr int KSB = 64, KQB = 32, PLB = 16; // exact fp32 row: 8 even channels | 8 odd channels (conv_wide.hpp WIDE_F32)
+    // exact fp32 row: 8 even channels | 8 odd channels (conv_wide.hpp WIDE_F32); fp16 row: 16 halves
+    static constexpr int KSB = 32 * NP, KQB = F32 ? 32 : 16, PLB = F32 ? 16 : 32;
     static constexpr int ROWB = KSB + 16;              // LDS row of one staged pixel (padded against bank conflicts)
     static constexpr int ABUF = NPX * ROWB;            // bytes of one stage of one wave
-    static constexpr int STEPB = 2 * NP * 1024;        // packed weight bytes per k-step of one wave (sige_hip_wide_conv_pack, WIDE_F32)
-    static constexpr int RB = 3;                       // weight ring, in k-steps
-    static constexpr int OCC = TPW_ == 2 ? 3 : 1;   // (46 KB of LDS and <= 168 registers: three workgroups per CU)
+    static constexpr int STEPB = 2 * NP * 1024;        // packed weight bytes per k-step of one wave (sige_hip_wide_conv_pack)
+    static constexpr int RB = F32 ? 3 : 9;             // weight ring, in k-steps
+    // (fp32: 46 KB of LDS and <= 168 registers: three workgroups per CU)
+    static constexpr int OCC = F32 ? (TPW_ == 2 ? 3 : 1) : (TPW_ == 2 ? 2 : 1);
     static constexpr int LDS_BYTES = cmax(4 * 2 * ABUF, 4 * BM * 68 * 4);
     static_assert((2 * STEPS) % RB == 0, "the ring position of a step must not depend on the chunk");
 };
@@ -64,13 +73,17 @@ struct Tile3Args {
     int Ho, Wo, offH, offW;     // full destination
     int ntn, nchunks, nchunks1;
     int hp_shift;
+    int res_f16;                // `residual` (a fused ScatterWithBlockResidual's cached shortcut tensor) holds halves (fp16-stored caches)
 };
 
 // One workgroup: tiles [mtile * TPW, (mtile + 1) * TPW) x output channels [64 ntile, 64 ntile + 64).
-template <typename G, int SRC, bool AFF, bool CAT, bool FULL>
+// Y16: SCATTER_GATHER only -- the cached tensor (x2) holds halves (SIGEModel.set_cache_dtype("f16"))
+template <typename G, int SRC, bool AFF, bool CAT, bool FULL, bool Y16 = false>
 __device__ __forceinline__ void conv_tile3_body(const Tile3Args &a, const int bx, unsigned char *const smem) {
     constexpr int NS = G::NS, STEPS = G::STEPS, RB = G::RB, NP = G::NP, MTN = G::MTN;
     constexpr bool SG = SRC == T3_SCATTER_GATHER;
+    constexpr bool F32 = G::F32;
+    static_assert(!Y16 || SG, "fp16-stored cache: the scatter_gather source");
     constexpr bool TWO = CAT || SG;  // a slot may come from the second tensor
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -123,7 +136,7 @@ __device__ __forceinline__ void conv_tile3_body(const Tile3Args &a, const int bx
         if constexpr (SG) {
             const int blk = z_m0[i];
             voff[i] = (in && blk >= 0) ? (unsigned)((((z_b[i] * a.N + blk) * a.Rx + z_m1[i]) * a.Sx + z_m2[i]) * Cin + cb) * 4u : kOOB;
-            voff2[i] = (in && blk < 0) ? (unsigned)(((z_b[i] * a.H + z_h[i]) * a.W + z_w[i]) * Cin + cb) * 4u : kOOB;
+            voff2[i] = (in && blk < 0) ? (unsigned)(((z_b[i] * a.H + z_h[i]) * a.W + z_w[i]) * Cin + cb) * (Y16 ? 2u : 4u) : kOOB;
         } else {
             const int spx = (z_b[i] * Hs + (z_h[i] >> a.up)) * Ws + (z_w[i] >> a.up);
             voff[i] = in ? (unsigned)(spx * a.C1 + cb) * 4u : kOOB;
@@ -141,11 +154,17 @@ __device__ __forceinline__ void conv_tile3_body(const Tile3Args &a, const int bx
         if (CAT && chunk >= a.nchunks1) return make_rsrc(a.x2, (long)(chunk - a.nchunks1) * G::CC, (long)a.B * Hs * Ws * a.C2);
         return make_rsrc(a.x, (long)chunk * G::CC, (long)a.B * Hs * Ws * a.C1);
     };
-    auto rsrc_y = [&](int chunk) -> rsrc_t { return make_rsrc(a.x2, (long)chunk * G::CC, (long)a.B * a.H * a.W * Cin); };
+    auto rsrc_y = [&](int chunk) -> rsrc_t {
+        if constexpr (Y16) return make_rsrc_h(a.x2, (long)chunk * G::CC, (long)a.B * a.H * a.W * Cin);
+        return make_rsrc(a.x2, (long)chunk * G::CC, (long)a.B * a.H * a.W * Cin);
+    };
     auto slot_load = [&](auto i_tag, const rsrc_t r, const rsrc_t ry, const bool use2) {
         constexpr int i = decltype(i_tag)::value;
         if constexpr (SG) {
-            const float4 p = buf_f32x4(r, voff[i], 0), q = buf_f32x4(ry, voff2[i], 0);
+            const float4 p = buf_f32x4(r, voff[i], 0);
+            float4 q;
+            if constexpr (Y16) q = buf_h4(ry, voff2[i], 0);
+            else q = buf_f32x4(ry, voff2[i], 0);
             st[i] = make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
         } else {
             unsigned o = voff[i];
@@ -178,7 +197,8 @@ __device__ __forceinline__ void conv_tile3_body(const Tile3Args &a, const int bx
             if (do_act) z = swish_fast(z);
             z = live ? z : 0.0f;
         }
-        return z;
+        if constexpr (F32) return z;
+        return __builtin_fminf(__builtin_fmaxf(z, -65504.0f), 65504.0f);  // (fp16 range: saturate instead of +-inf)
     };
     auto a_store = [&](auto i_tag, unsigned char *buf, const float4 sc, const float4 sh) {
         constexpr int i = decltype(i_tag)::value;
@@ -187,9 +207,14 @@ __device__ __forceinline__ void conv_tile3_body(const Tile3Args &a, const int bx
         const float4 q = st[i];
         const float z0 = fin(q.x, sc.x, sh.x, live), z1 = fin(q.y, sc.y, sh.y, live);
         const float z2 = fin(q.z, sc.z, sh.z, live), z3 = fin(q.w, sc.w, sh.w, live);
-        // the even channels of the unit go to lane group 0's half of the row, the odd ones to group 1's
-        *reinterpret_cast<float2 *>(buf + ldsw[i]) = make_float2(z0, z2);
-        *reinterpret_cast<float2 *>(buf + ldsw[i] + 32) = make_float2(z1, z3);
+        if constexpr (F32) {
+            // the even channels of the unit go to lane group 0's half of the row, the odd ones to group 1's
+            *reinterpret_cast<float2 *>(buf + ldsw[i]) = make_float2(z0, z2);
+            *reinterpret_cast<float2 *>(buf + ldsw[i] + 32) = make_float2(z1, z3);
+        } else {
+            const f16x4 hv = {(_Float16)z0, (_Float16)z1, (_Float16)z2, (_Float16)z3};  // RNE
+            *reinterpret_cast<f16x4 *>(buf + ldsw[i]) = hv;
+        }
     };
 
     // ---- B: this wave's stream of packed weights, contiguous over (chunk, k-step) ----
@@ -238,7 +263,8 @@ __device__ __forceinline__ void conv_tile3_body(const Tile3Args &a, const int bx
     static_for<0, NS>([&](auto i_tag) { a_store(i_tag, mybuf, sc_c, sh_c); });
     a_load(min(first + 1, last));
     __builtin_amdgcn_wave_barrier();
-    AHalf a_hi = a_read(std::integral_constant<int, 0>{}, mybuf, 0), a_lo = a_read(std::integral_constant<int, 0>{}, mybuf, 1);
+    AHalf a_hi = a_read(std::integral_constant<int, 0>{}, mybuf, 0), a_lo = a_hi;
+    if constexpr (F32) a_lo = a_read(std::integral_constant<int, 0>{}, mybuf, 1);
 
     auto body = [&](auto par_tag, int chunk) {
         constexpr int PAR = decltype(par_tag)::value;
@@ -256,21 +282,30 @@ __device__ __forceinline__ void conv_tile3_body(const Tile3Args &a, const int bx
             AHalf n_hi = a_hi, n_lo = a_lo;
             if constexpr (s + 1 < STEPS) {
                 n_hi = a_read(std::integral_constant<int, s + 1>{}, cur, 0);
-                n_lo = a_read(std::integral_constant<int, s + 1>{}, cur, 1);
+                if constexpr (F32) n_lo = a_read(std::integral_constant<int, s + 1>{}, cur, 1);
             }
-            // eight v_mfma_f32_32x32x2_f32 per tile contract the wave's 16 channels at this tap (k-step ss: channels 2 ss + kq)
-            static_for<0, 8>([&](auto ss_tag) {
-                constexpr int ss = decltype(ss_tag)::value;
+            if constexpr (F32) {
+                // eight v_mfma_f32_32x32x2_f32 per tile contract the wave's 16 channels at this tap (k-step ss: channels 2 ss + kq)
+                static_for<0, 8>([&](auto ss_tag) {
+                    constexpr int ss = decltype(ss_tag)::value;
 #pragma unroll
-                for (int mt = 0; mt < MTN; ++mt) {
-                    const f32x4 av = __builtin_bit_cast(f32x4, ss < 4 ? a_hi.v[mt] : a_lo.v[mt]);
+                    for (int mt = 0; mt < MTN; ++mt) {
+                        const f32x4 av = __builtin_bit_cast(f32x4, ss < 4 ? a_hi.v[mt] : a_lo.v[mt]);
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        const f32x4 bv = __builtin_bit_cast(f32x4, bring[slot][nt][ss / 4]);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss & 3], bv[ss & 3], acc[mt][nt], 0, 0, 0);
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const f32x4 bv = __builtin_bit_cast(f32x4, bring[slot][nt][ss / 4]);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss & 3], bv[ss & 3], acc[mt][nt], 0, 0, 0);
+                        }
                     }
-                }
-            });
+                });
+            } else {
+                // fp16 operands: one v_mfma_f32_32x32x16_f16 per tile pair and 32 output channels contracts all 16 channels
+#pragma unroll
+                for (int mt = 0; mt < MTN; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi.v[mt], bring[slot][nt][0], acc[mt][nt], 0, 0, 0);
+            }
             // staging slots of chunk+1 spread over the steps before the last one: finish a slot into the other stage, re-issue it as chunk+2
             if constexpr (s < STEPS - 1) {
                 constexpr int SD = STEPS - 1;
@@ -285,7 +320,7 @@ __device__ __forceinline__ void conv_tile3_body(const Tile3Args &a, const int bx
             if constexpr (s + 1 == STEPS) {
                 __builtin_amdgcn_wave_barrier();  // (the stage was written by other lanes of this wave: LDS is in order per wave)
                 n_hi = a_read(std::integral_constant<int, 0>{}, nxt, 0);
-                n_lo = a_read(std::integral_constant<int, 0>{}, nxt, 1);
+                if constexpr (F32) n_lo = a_read(std::integral_constant<int, 0>{}, nxt, 1);
             }
             a_hi = n_hi;
             a_lo = n_lo;
@@ -343,7 +378,7 @@ __device__ __forceinline__ void conv_tile3_body(const Tile3Args &a, const int bx
             if (h < 0 || h >= a.Ho || w < 0 || w >= a.Wo) continue;
             addr = (((size_t)b * a.Ho + h) * a.Wo + w) * a.Cout + co;
             if (a.residual) {  // out = conv + residual; with a block residual: + (x1 - residual) where a shortcut tile covers the pixel
-                const float4 rr = *reinterpret_cast<const float4 *>(a.residual + addr);
+                const float4 rr = ld_f32x4_or_h4(a.residual, addr, a.res_f16 != 0);
                 s.x += rr.x; s.y += rr.y; s.z += rr.z; s.w += rr.w;
                 if (a.x1) {
                     const int t1 = a.table1[(h / a.R1) * a.gW1 + w / a.S1];
@@ -376,10 +411,10 @@ __device__ __forceinline__ void conv_tile3_body(const Tile3Args &a, const int bx
     }
 }
 
-template <typename G, int SRC, bool AFF, bool CAT, bool FULL>
+template <typename G, int SRC, bool AFF, bool CAT, bool FULL, bool Y16 = false>
 __global__ __launch_bounds__(256, G::OCC) void conv_tile3_kernel(const Tile3Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];
-    conv_tile3_body<G, SRC, AFF, CAT, FULL>(a, blockIdx.x, smem);
+    conv_tile3_body<G, SRC, AFF, CAT, FULL, Y16>(a, blockIdx.x, smem);
 }
 
 // the host side of a v3 launch (conv_tile3.hip): argument checks, Tile3Args, launch.  SIGE_HIP_EUNSUPPORTED: the caller falls back
@@ -392,12 +427,12 @@ int tile_conv3_launch(int source, const float *x, const float *x2, int B, int C1
                       const float *out_scale, const float *out_shift, int out_activation,
                       float *twin0, const float *twin_scale0, const float *twin_shift0,
                       float *twin1, const float *twin_scale1, const float *twin_shift1,
-                      float *out, void *stream);
+                      float *out, void *stream, int prec = WIDE_F32, int y_f16 = 0, int residual_f16 = 0);
 
 // launchers (instantiated in conv_tile3_*.hip)
-template <int TPW>
+template <int TPW, int PREC = WIDE_F32>
 void launch_conv_tile3_gather(const Tile3Args &a, bool aff, bool cat, bool full, hipStream_t st);
-template <int TPW>
-void launch_conv_tile3_sg(const Tile3Args &a, bool full, hipStream_t st);
+template <int TPW, int PREC = WIDE_F32>
+void launch_conv_tile3_sg(const Tile3Args &a, bool full, bool y16, hipStream_t st);
 
 }  // namespace sige

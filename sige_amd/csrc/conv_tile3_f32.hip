@@ -15,7 +15,7 @@ template <> void launch_conv_tile3_gather<2>(const Tile3Args &a, bool aff, bool 
     else SIGE_T3(false, false);
 #undef SIGE_T3
 }
-template <> void launch_conv_tile3_sg<2>(const Tile3Args &a, bool full, hipStream_t st) {
+template <> void launch_conv_tile3_sg<2>(const Tile3Args &a, bool full, bool, hipStream_t st) {
     const dim3 grid(ceil_div(a.T, G2::TPW) * a.ntn);
     if (full) conv_tile3_kernel<G2, T3_SCATTER_GATHER, false, false, true><<<grid, 256, 0, st>>>(a);
     else conv_tile3_kernel<G2, T3_SCATTER_GATHER, false, false, false><<<grid, 256, 0, st>>>(a);

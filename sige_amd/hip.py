@@ -191,6 +191,16 @@ _SIGNATURES = {
     "sige_hip_tile_conv3_nhwc_f32": (
         _c_int, [_c_int, _c_vp, _c_vp] + [_c_int] * 6 + [_c_vp, _c_int, _c_vp, _c_int, _c_int] + [_c_vp, _c_vp, _c_int, _c_int]
         + [_c_vp, _c_vp, _c_int] + [_c_int] * 5 + [_c_vp] + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp, _c_vp, _c_int] + [_c_vp] * 6 + [_c_vp, _c_vp]),
+    "sige_hip_tile_conv3_nhwc_f16c": (
+        _c_int, [_c_int, _c_vp, _c_vp, _c_int] + [_c_int] * 6 + [_c_vp, _c_int, _c_vp, _c_int, _c_int] + [_c_vp, _c_vp, _c_int, _c_int]
+        + [_c_vp, _c_vp, _c_int] + [_c_int] * 5 + [_c_vp, _c_int] + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp, _c_vp, _c_int] + [_c_vp] * 6 + [_c_vp, _c_vp]),
+    "sige_hip_gather_conv_nhwc_v3_f16c": (
+        _c_int, [_c_vp, _c_vp] + [_c_int] * 7 + [_c_vp, _c_int] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
+        + [_c_int] * 5 + [_c_int, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_vp, _c_sz, _c_vp, _c_vp, _c_int, _c_int] + [_c_vp] * 6
+        + [_c_vp, _c_int] + [_c_vp, _c_vp]),
+    "sige_hip_scatter_gather_conv_scatter_nhwc_v3_f16c": (
+        _c_int, [_c_vp, _c_vp, _c_int] + [_c_int] * 8 + [_c_vp, _c_int, _c_vp] + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp]
+        + [_c_int] * 3 + [_c_int, _c_int, _c_vp, _c_int] + [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp] * 6 + [_c_vp, _c_int] + [_c_vp, _c_vp]),
     "sige_hip_add_layer_norm_tokens_f32": (_c_int, [_c_vp] * 5 + [ctypes.c_int64, _c_int, ctypes.c_float, _c_vp, _c_vp, _c_vp]),
     "sige_hip_geglu_tokens_f32": (_c_int, [_c_vp, ctypes.c_int64, _c_int, _c_vp, _c_vp]),
     "sige_hip_add_bias_tokens_f32": (_c_int, [_c_vp, _c_vp, _c_vp, ctypes.c_int64, _c_int, _c_vp, _c_vp]),
@@ -826,7 +836,7 @@ def conv_pack_weights(weight: torch.Tensor, R: int, S: int, stride: Tuple[int, i
     fn = {"f16": lib().sige_hip_block_conv_pack_f16c, "f16x3": lib().sige_hip_block_conv_pack_f16x3,
           "f32": lib().sige_hip_block_conv_pack_f32}[compute]
     _check(fn(w.data_ptr(), Cout, Cin, kH, kW, packed.data_ptr(), _stream(w)), "conv_pack_weights")
-    if compute == "f32" and (kH, kW) == (3, 3) and (R, S) == (6, 6) and tuple(stride) == (1, 1) and Cin % 64 == 0 and Cout % 64 == 0:
+    if compute in ("f32", "f16") and (kH, kW) == (3, 3) and (R, S) == (6, 6) and tuple(stride) == (1, 1) and Cin % 64 == 0 and Cout % 64 == 0:
         # the tile conv v3 (csrc/conv_tile3.hpp) reads the same weights in the dense-layer kernel's exact-fp32 order.  Packed HERE when
         # the router is on, whatever the first mask's tile count: the routing entry points decide per launch, in C, from the
         # count -- also when a launch plan replays this call under a larger mask later
@@ -1480,10 +1490,16 @@ def block_conv_cl(x, packed, bias, Cout: int, kernel: Tuple[int, int], stride: T
 # TILE3 = True sends every eligible call to sige_hip_tile_conv3_nhwc_f32 directly, whatever its grid (tests, tools/tile3_bench.py).
 TILE3 = None
 TILE3_MIN_BLOCKS = 512
+# fp16 operands (round 6; conv_tile3.hpp Tile3Geo<2, WIDE_F16>): the same routing for compute dtype "f16" (sige_hip_*_v3_f16c)
+TILE3_MIN_BLOCKS_F16 = 256
+
+
+def _tile3_min_blocks(packed) -> int:
+    return int(TILE3_MIN_BLOCKS_F16 if getattr(packed, "compute", "f32") == "f16" else TILE3_MIN_BLOCKS)
 
 
 def _tile3_pack_now(packed):
-    t3 = wide_conv_pack_weights(packed._tile3_src, "f32")
+    t3 = wide_conv_pack_weights(packed._tile3_src, "f16" if getattr(packed, "compute", "f32") == "f16" else "f32")
     packed.tile3 = False if t3 is None else t3  # (False: asked once, there is no v3 layout for this shape -- not asked again)
     packed._tile3_src = None                    # (the contiguous copy of a channels-last weight is not kept alive)
     return t3
@@ -1514,8 +1530,8 @@ def _tile3_route(packed, T: int, C1: int, C2: int, Cout: int, kernel, stride, bl
 
 
 def tile_conv3_cl(source: int, x, x2, B, C1, C2, H, W, up, idx, smap, rx_sx, scale, shift, activationName, t3, bias, Cout,
-                  full, residual, bargs, out_affine, targs, out):
-    """One launch of sige_hip_tile_conv3_nhwc_f32 (include/sige_hip.h); `full` = None (tiles) | (offH, offW, Ho, Wo).
+                  full, residual, bargs, out_affine, targs, out, f16: bool = False):
+    """One launch of sige_hip_tile_conv3_nhwc_f32 / _f16c (include/sige_hip.h); `full` = None (tiles) | (offH, offW, Ho, Wo).
     UNSUPPORTED -> None."""
     bias_keep = _vec(bias, "bias")
     sc = sh = None
@@ -1534,11 +1550,20 @@ def tile_conv3_cl(source: int, x, x2, B, C1, C2, H, W, up, idx, smap, rx_sx, sca
     else:
         oargs = (None, None, 0)
     fargs = (0, 0, 0, 0, 0) if full is None else (1, *full)
-    status = lib().sige_hip_tile_conv3_nhwc_f32(
-        source, x.data_ptr(), None if x2 is None else x2.data_ptr(), B, C1, C2, H, W, int(bool(up)), idx.data_ptr(), idx.shape[0],
-        None if smap is None else smap.data_ptr(), rx_sx[0], rx_sx[1], sc, sh, affB, _act(activationName),
-        t3.data_ptr(), _p(bias_keep), Cout, *fargs, None if residual is None else residual.data_ptr(), *bargs, *oargs, *targs,
-        out.data_ptr(), _stream(x))
+    if f16:  # (fp16 operands; x2 / residual may be fp16-stored caches)
+        y16 = int(x2 is not None and x2.dtype == torch.float16)
+        r16 = int(residual is not None and residual.dtype == torch.float16)
+        status = lib().sige_hip_tile_conv3_nhwc_f16c(
+            source, x.data_ptr(), None if x2 is None else x2.data_ptr(), y16, B, C1, C2, H, W, int(bool(up)), idx.data_ptr(), idx.shape[0],
+            None if smap is None else smap.data_ptr(), rx_sx[0], rx_sx[1], sc, sh, affB, _act(activationName),
+            t3.data_ptr(), _p(bias_keep), Cout, *fargs, None if residual is None else residual.data_ptr(), r16, *bargs, *oargs, *targs,
+            out.data_ptr(), _stream(x))
+    else:
+        status = lib().sige_hip_tile_conv3_nhwc_f32(
+            source, x.data_ptr(), None if x2 is None else x2.data_ptr(), B, C1, C2, H, W, int(bool(up)), idx.data_ptr(), idx.shape[0],
+            None if smap is None else smap.data_ptr(), rx_sx[0], rx_sx[1], sc, sh, affB, _act(activationName),
+            t3.data_ptr(), _p(bias_keep), Cout, *fargs, None if residual is None else residual.data_ptr(), *bargs, *oargs, *targs,
+            out.data_ptr(), _stream(x))
     if status == UNSUPPORTED:
         return None
     _check(status, "tile_conv3_cl")
@@ -1588,7 +1613,8 @@ def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, a
         targs3, twin_keep3 = _twin_args(twins if twins else None, out, Cout, "gather_conv_cl")
         got = tile_conv3_cl(1, x, x2, B, C1, C2, H, W, upsample2x, idx, None, (0, 0), scale, shift, activationName, t3, bias, Cout,
                             None if full is None else (full["offset"][0], full["offset"][1], Ho, Wo),
-                            None if full is None else r, (None, None, 0, 0, 0, 0, 0), out_affine, targs3, out)
+                            None if full is None else r, (None, None, 0, 0, 0, 0, 0), out_affine, targs3, out,
+                            f16=getattr(packed, "compute", "f32") == "f16")
         if got is not None:
             return got if full is not None else tag_tiles(got, idx, B)
     # deep-K convs over a handful of tiles: workspace for the cross-workgroup K split
@@ -1622,12 +1648,14 @@ def gather_conv_cl(x, x2, block: Tuple[int, int], activeIndices, scale, shift, a
         raise RuntimeError("gather_conv_cl: twins need a full-tensor destination")
     targs, twin_keep = _twin_args(twins if twins else None, out, Cout, "gather_conv_cl")
     fargs = fargs + (int(bool(upsample2x)), *targs)
-    t3r = _tile3_packed(packed) if (TILE3 is None and getattr(packed, "compute", "f32") == "f32") else None
+    compute = getattr(packed, "compute", "f32")
+    t3r = _tile3_packed(packed) if (TILE3 is None and compute in ("f32", "f16")) else None
     if t3r is not None:  # (the routing entry point: conv_mfma.hpp or the v3 kernel, decided in C from N)
-        status = lib().sige_hip_gather_conv_nhwc_v3_f32(
+        fn = lib().sige_hip_gather_conv_nhwc_v3_f16c if compute == "f16" else lib().sige_hip_gather_conv_nhwc_v3_f32
+        status = fn(
             x.data_ptr(), None if x2 is None else x2.data_ptr(), B, C1, C2, H, W, block[0], block[1], idx.data_ptr(), N,
             *sa, *ta, _act(activationName), packed.data_ptr(), _p(bias_keep), Cout, kernel[0], kernel[1],
-            stride[0], stride[1], *fargs, t3r.data_ptr(), int(TILE3_MIN_BLOCKS), out.data_ptr(), _stream(x))
+            stride[0], stride[1], *fargs, t3r.data_ptr(), _tile3_min_blocks(packed), out.data_ptr(), _stream(x))
     else:
         status = _conv_fn("sige_hip_gather_conv_nhwc", packed)(
             x.data_ptr(), None if x2 is None else x2.data_ptr(), B, C1, C2, H, W, block[0], block[1], idx.data_ptr(), N,
@@ -1694,22 +1722,27 @@ def scatter_gather_conv_scatter_cl(x, y, block, activeIndices, scatterMap, scale
         bargs = (None, None, 0, 0, 0, 0, 0)
     targs, twin_keep = _twin_args(twins if twins else None, out, Cout, "scatter_gather_conv_scatter_cl")
     t3 = _tile3_route(packed, B * idx.shape[0], C, 0, Cout, kernel, (1, 1), block)
-    if (t3 is not None and idx.shape[0] > 0 and y.dtype == torch.float32 and (r is None or r.dtype == torch.float32)
+    f16c = getattr(packed, "compute", "f32") == "f16"
+    if (t3 is not None and idx.shape[0] > 0 and (f16c or (y.dtype == torch.float32 and (r is None or r.dtype == torch.float32)))
             and scale is None and shift is None and activationName == "identity"):
         got = tile_conv3_cl(2, x, y, B, C, 0, H, W, False, idx, smap, (x.shape[2], x.shape[3]), None, None, "identity", t3, bias, Cout,
-                            (offset[0], offset[1], H, W), r, bargs, None, targs, out)
+                            (offset[0], offset[1], H, W), r, bargs, None, targs, out, f16=f16c)
         if got is not None:
             return got
     head = (x.data_ptr(), y.data_ptr(), B, C, H, W, x.shape[2], x.shape[3], block[0], block[1], idx.data_ptr(), idx.shape[0],
             smap.data_ptr(), *sa, *ta, _act(activationName), packed.data_ptr(), _p(bias_keep), Cout, kernel[0], kernel[1],
             offset[0], offset[1], None if r is None else r.data_ptr())
-    t3r = _tile3_packed(packed) if (TILE3 is None and getattr(packed, "compute", "f32") == "f32" and y.dtype == torch.float32) else None
-    if y.dtype == torch.float16:  # (fp16-stored caches)
+    t3r = _tile3_packed(packed) if (TILE3 is None and ((getattr(packed, "compute", "f32") == "f32" and y.dtype == torch.float32) or f16c)) else None
+    if f16c and t3r is not None:  # (fp16 operands, fp32- or fp16-stored caches: routed in C like the fp32 pair)
+        status = lib().sige_hip_scatter_gather_conv_scatter_nhwc_v3_f16c(
+            head[0], head[1], int(y.dtype == torch.float16), *head[2:], int(r is not None and r.dtype == torch.float16), *bargs, *targs,
+            t3r.data_ptr(), _tile3_min_blocks(packed), out.data_ptr(), _stream(y))
+    elif y.dtype == torch.float16:  # (fp16-stored caches)
         status = lib().sige_hip_scatter_gather_conv_scatter_nhwc_c16(
             _COMPUTE_ID[getattr(packed, "compute", "f32")], *head, int(r is not None and r.dtype == torch.float16), *bargs, *targs,
             out.data_ptr(), _stream(y))
     elif t3r is not None:  # (the routing entry point: conv_mfma.hpp or the v3 kernel, decided in C from N)
-        status = lib().sige_hip_scatter_gather_conv_scatter_nhwc_v3_f32(*head, *bargs, *targs, t3r.data_ptr(), int(TILE3_MIN_BLOCKS),
+        status = lib().sige_hip_scatter_gather_conv_scatter_nhwc_v3_f32(*head, *bargs, *targs, t3r.data_ptr(), _tile3_min_blocks(packed),
                                                                         out.data_ptr(), _stream(y))
     else:
         status = _conv_fn("sige_hip_scatter_gather_conv_scatter_nhwc", packed)(*head, *bargs, *targs, out.data_ptr(), _stream(y))

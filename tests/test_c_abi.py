@@ -105,7 +105,7 @@ def test_preload_without_a_gpu(lib):
 def test_version_and_error_strings(lib):
     lib.sige_hip_version.restype = ctypes.c_int
     lib.sige_hip_error_string.restype = ctypes.c_char_p
-    assert lib.sige_hip_version() == 308
+    assert lib.sige_hip_version() == 309
     assert lib.sige_hip_error_string(0) == b"ok"
     assert b"invalid" in lib.sige_hip_error_string(-1)
 

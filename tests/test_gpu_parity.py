@@ -33,7 +33,7 @@ def _close(case, got, want):
 
 
 def test_native_library_is_loaded(hip):
-    assert hip.lib().sige_hip_version() == 308
+    assert hip.lib().sige_hip_version() == 309
     arch = hip.lib().sige_hip_device_arch()
     assert arch is not None and arch.decode().startswith("gfx950"), arch
     assert "libsige_hip.so" in open("/proc/self/maps").read()

@@ -22,6 +22,8 @@ import bench  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
+    ap.add_argument("--compute", default="f32", choices=["f32", "f16"], help="operand form of both kernels (f16: round 6, Tile3Geo<2, WIDE_F16>)")
+    ap.add_argument("--cache-dtype", default="f32", choices=["f32", "f16"], help="the forward's cache storage (bench.py --dtype f16 uses f16)")
     a = ap.parse_args()
     from sige_amd import hip
     from sige_amd.utils import dilate_mask, downsample_mask, reduce_mask
@@ -43,7 +45,7 @@ def main():
             w = torch.randn(Cout, C, 3, 3, device=dev) / (3 * C ** 0.5)
             bias = torch.randn(Cout, device=dev)
             sc, sh = torch.randn(1, C, 1, 1, device=dev), torch.randn(1, C, 1, 1, device=dev)
-            packed = hip.conv_pack_weights(w, 6, 6, (1, 1))
+            packed = hip.conv_pack_weights(w, 6, 6, (1, 1), a.compute)
             smap = hip.get_scatter_map(R, R, 6, 6, 3, 3, 1, 1, 1, 1, idx)
             t4 = cl(torch.randn(N, C, 4, 4, device=dev))
             y1 = cl(torch.randn(1, Cout, R, R, device=dev))
@@ -68,6 +70,11 @@ def main():
     # the whole forward
     model = DDPMSparseUNet(DDPMConfig()).eval().to(dev).to(memory_format=torch.channels_last)
     model.set_scatter_inplace(True)
+    if a.compute != "f32":
+        model.set_compute_dtype(a.compute)
+    if a.cache_dtype != "f32":
+        model.set_cache_dtype(a.cache_dtype)
+    res["compute"], res["cache_dtype"] = a.compute, a.cache_dtype
     x0, noise = bench.make_inputs()
     x0, noise, t = cl(x0.to(dev)), cl(noise.to(dev)), torch.zeros(1, device=dev)
     with torch.no_grad():
@@ -79,9 +86,15 @@ def main():
             model.set_mode("sparse")
             x1 = x0 + noise * mask
             row = {"edit_ratio": ratio}
-            hip.TILE3_MIN_BLOCKS = 512  # (the opt-in routing rule; the library's default is None = never)
-            for tag, flag in (("conv_mfma_only", False), ("tile3_everywhere", True), ("router", None)):
+            hip.TILE3_MIN_BLOCKS = 512
+            for tag, flag, th in (("conv_mfma_only", False, None), ("tile3_everywhere", True, None), ("router", None, None),
+                                  ("router_from_128", None, 128), ("router_from_256", None, 256), ("router_from_1024", None, 1024)):
+                if th is not None and a.compute != "f16":
+                    continue
                 hip.TILE3 = flag
+                keep_th = hip.TILE3_MIN_BLOCKS_F16
+                if th is not None:
+                    hip.TILE3_MIN_BLOCKS_F16 = th
                 try:
                     model(x1, t)
                     model(x1, t)
@@ -93,6 +106,7 @@ def main():
                     del g
                 finally:
                     hip.TILE3 = None
+                    hip.TILE3_MIN_BLOCKS_F16 = keep_th
                 row[tag] = {"forward_ms": round(ms, 4), "launches": launches}
             res["forward"].append(row)
     text = json.dumps(res, indent=1)
