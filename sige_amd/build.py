@@ -59,7 +59,7 @@ def _stale(obj: str, src: str, headers) -> bool:
 
 # translation units that read a dispatch knob (csrc/tuning.hpp): compiled a second time with -DSIGE_HIP_TUNING for the
 # measurement library lib/libsige_hip_tuning.so; every other object is shared with the product build
-TUNING_UNITS = ("api.hip", "block_conv.hip", "gather.hip", "conv_wide.hip", "attention_tokens.hip", "conv_out.hip")
+TUNING_UNITS = ("api.hip", "block_conv.hip", "gather.hip", "conv_wide.hip", "attention_tokens.hip", "conv_out.hip", "conv_tile3.hip")
 TUNING_LIB = os.path.join(LIB_DIR, "libsige_hip_tuning.so")
 
 

@@ -1334,15 +1334,25 @@ extern "C" int sige_hip_release_graph_tickets(void) { return sige::release_graph
 // recorded ENTRY POINT under a new mask's tile count, routes like the module-level forward under that mask does: plan and
 // module path stay bit-identical (round 5: the first router lived in Python and test_launch_plan_follows_mask_changes caught
 // the two running different kernels).
+// fp16 operands: a conv1 whose shortcut is held goes to the v3 kernel anyway from this many workgroups on (the shortcut is then
+// launched on its own: tile_conv3_launch -> flush_held_conv); SIGE_HIP_TUNE_TILE3_F16_PAIR_MIN = -1: this value, 0 = never
+constexpr int kTile3F16PairMin = 256;  // (profiles/r6j_tile3_f16_pairs_bench.json: -2.6 % at a 15 % edit, -3.3 % at 20 %, nothing lost below)
+
 static bool tile3_takes(const float *packed_tile3, int min_blocks, int B, int N, int C1, int C2, int Cout, int kH, int kW, int bH, int bW,
-                        int strideH, int strideW, hipStream_t st) {
+                        int strideH, int strideW, hipStream_t st, bool f16 = false) {
     if (!packed_tile3 || min_blocks <= 0) return false;
     if (kH != 3 || kW != 3 || bH != 6 || bW != 6 || strideH != 1 || strideW != 1) return false;
     if (!sige_hip_tile_conv3_supported(C1, C2, Cout)) return false;
-    if ((long)((B * (long)N + 1) / 2) * (Cout / 64) < min_blocks) return false;
+    const long blocks = (long)((B * (long)N + 1) / 2) * (Cout / 64);
+    if (blocks < min_blocks) return false;
     // a 1x1 shortcut held by conv_pair_begin() shares the conv_mfma.hpp launch of this conv1: keeping the pair beats the v3 kernel
     // plus a launch of its own for the shortcut (46.7 vs 39.5 + 8.7 us at a 15 % edit: profiles/r5j_sequence_15pct_*.csv)
-    if (g_held.active && g_held.st == st) return false;
+    if (g_held.active && g_held.st == st) {
+        if (!f16) return false;
+        int pm = tuning(SIGE_HIP_TUNE_TILE3_F16_PAIR_MIN);
+        if (pm < 0) pm = kTile3F16PairMin;
+        if (pm == 0 || blocks < pm) return false;
+    }
     return true;
 }
 
@@ -1419,7 +1429,7 @@ extern "C" int sige_hip_gather_conv_nhwc_v3_f16c(const float *x, const float *x2
     SIGE_PLAN_HOOK_N(sige_hip_gather_conv_nhwc_v3_f16c, (sige::CountOf<9, 10>), x, x2, B, C1, C2, H, W, bH, bW, active_indices, N, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, packed, bias, Cout, kH, kW, strideH, strideW, to_full, offsetH, offsetW, residual, Ho, Wo, workspace, workspace_floats, out_scale, out_shift, out_activation, upsample2x, twin0, twin0_scale, twin0_shift, twin1, twin1_scale, twin1_shift, packed_tile3, min_blocks, out, stream);
     const int Cin = C1 + C2;
     const bool aff_ok = (!scale && !shift) || (scale && shift && scaleC == Cin && shiftC == Cin && scaleB == shiftB && (scaleB == 1 || scaleB == B));
-    if (B > 0 && N > 0 && aff_ok && tile3_takes(packed_tile3, min_blocks, B, N, C1, C2, Cout, kH, kW, bH, bW, strideH, strideW, as_stream(stream))) {
+    if (B > 0 && N > 0 && aff_ok && tile3_takes(packed_tile3, min_blocks, B, N, C1, C2, Cout, kH, kW, bH, bW, strideH, strideW, as_stream(stream), true)) {
         const int rc = tile_conv3_launch(T3_GATHER, x, x2, B, C1, C2, H, W, upsample2x, active_indices, N, nullptr, 0, 0, scale, shift,
                                          scale ? scaleB : 0, activation, packed_tile3, bias, Cout, to_full, offsetH, offsetW, Ho, Wo,
                                          to_full ? residual : nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, out_scale, out_shift, out_activation,

@@ -7,6 +7,10 @@ template <> void launch_conv_tile3_gather<2>(const Tile3Args &, bool, bool, bool
 template <> void launch_conv_tile3_sg<2>(const Tile3Args &, bool, bool, hipStream_t);
 template <> void launch_conv_tile3_gather<2, WIDE_F16>(const Tile3Args &, bool, bool, bool, hipStream_t);
 template <> void launch_conv_tile3_sg<2, WIDE_F16>(const Tile3Args &, bool, bool, hipStream_t);
+template <> void launch_conv_tile3_gather<4, WIDE_F16>(const Tile3Args &, bool, bool, bool, hipStream_t);
+template <> void launch_conv_tile3_sg<4, WIDE_F16>(const Tile3Args &, bool, bool, hipStream_t);
+// fp16 operands: 4 tiles per workgroup from this many 2-tile workgroups on (SIGE_HIP_TUNE_TILE3_F16_TPW4_MIN = -1: this value)
+constexpr int kTile3F16Tpw4Min = 0;  // (measured, profiles/r6i_tile3_f16_tpw4_bench.json: wins at 834 workgroups only, -0.2 % on the forward: never)
 int flush_held_conv();  // (block_conv.hip: a shortcut conv held by sige_hip_conv_pair_begin is launched on its own first)
 }  // namespace sige
 
@@ -73,7 +77,13 @@ int sige::tile_conv3_launch(
     if (rc != SIGE_HIP_OK) return rc;
     hipStream_t st = as_stream(stream);
     if (prec == WIDE_F16) {
-        if (sg) launch_conv_tile3_sg<2, WIDE_F16>(a, to_full != 0, y_f16 != 0, st);
+        int t4min = tuning(SIGE_HIP_TUNE_TILE3_F16_TPW4_MIN);
+        if (t4min < 0) t4min = kTile3F16Tpw4Min;
+        const bool four = t4min > 0 && (long)((a.T + 1) / 2) * a.ntn >= t4min && !(a.aff_sb && N % 4);
+        if (four) {
+            if (sg) launch_conv_tile3_sg<4, WIDE_F16>(a, to_full != 0, y_f16 != 0, st);
+            else launch_conv_tile3_gather<4, WIDE_F16>(a, scale != nullptr, C2 > 0, to_full != 0, st);
+        } else if (sg) launch_conv_tile3_sg<2, WIDE_F16>(a, to_full != 0, y_f16 != 0, st);
         else launch_conv_tile3_gather<2, WIDE_F16>(a, scale != nullptr, C2 > 0, to_full != 0, st);
     } else {
         if (sg) launch_conv_tile3_sg<2>(a, to_full != 0, false, st);

@@ -51,7 +51,7 @@ struct Tile3Geo {
     static constexpr int STEPB = 2 * NP * 1024;        // packed weight bytes per k-step of one wave (sige_hip_wide_conv_pack)
     static constexpr int RB = F32 ? 3 : 9;             // weight ring, in k-steps
     // (fp32: 46 KB of LDS and <= 168 registers: three workgroups per CU)
-    static constexpr int OCC = F32 ? (TPW_ == 2 ? 3 : 1) : (TPW_ == 2 ? 2 : 1);
+    static constexpr int OCC = F32 ? (TPW_ == 2 ? 3 : 1) : 2;  // (fp16, 4 tiles: 70 KB of LDS -- two workgroups per CU)
     static constexpr int LDS_BYTES = cmax(4 * 2 * ABUF, 4 * BM * 68 * 4);
     static_assert((2 * STEPS) % RB == 0, "the ring position of a step must not depend on the chunk");
 };

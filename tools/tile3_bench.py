@@ -30,6 +30,7 @@ def main():
     from sige_amd.workloads.ddpm_unet import DDPMConfig, DDPMSparseUNet
 
     dev = torch.device("cuda:0")
+    tunable = hasattr(hip.lib(), "sige_hip_tuning_set") or os.path.basename(hip.LIB_PATH).startswith("libsige_hip_tuning")
     cl = lambda t_: t_.contiguous(memory_format=torch.channels_last)  # noqa: E731
     res = {"layers": [], "forward": []}
     torch.manual_seed(0)
@@ -65,6 +66,16 @@ def main():
                         us[tag] = round(bench.time_graph_of(fn, 20), 2)
                     finally:
                         hip.TILE3 = None
+                if a.compute == "f16" and tunable:  # (4 tiles per workgroup: never / always)
+                    hip.TILE3 = True
+                    try:
+                        hip.tuning_set("tile3_f16_tpw4_min", 0)
+                        us["tile3"] = round(bench.time_graph_of(fn, 20), 2)
+                        hip.tuning_set("tile3_f16_tpw4_min", 1)
+                        us["tile3_tpw4"] = round(bench.time_graph_of(fn, 20), 2)
+                    finally:
+                        hip.TILE3 = None
+                        hip.tuning_set("tile3_f16_tpw4_min", -1)
                 row[name] = dict(us, TFLOPs_conv_mfma=round(flop / us["conv_mfma"] / 1e6, 1), TFLOPs_tile3=round(flop / us["tile3"] / 1e6, 1))
             res["layers"].append(row)
     # the whole forward
@@ -87,14 +98,20 @@ def main():
             x1 = x0 + noise * mask
             row = {"edit_ratio": ratio}
             hip.TILE3_MIN_BLOCKS = 512
-            for tag, flag, th in (("conv_mfma_only", False, None), ("tile3_everywhere", True, None), ("router", None, None),
-                                  ("router_from_128", None, 128), ("router_from_256", None, 256), ("router_from_1024", None, 1024)):
-                if th is not None and a.compute != "f16":
+            for tag, flag, th, t4 in (("conv_mfma_only", False, None, None), ("router", None, None, None),
+                                      ("router_pairs_to_v3_from_256", None, None, ("tile3_f16_pair_min", 256)),
+                                      ("router_pairs_to_v3_from_512", None, None, ("tile3_f16_pair_min", 512)),
+                                      ("router_pairs_to_v3_from_768", None, None, ("tile3_f16_pair_min", 768))):
+                if (th is not None or t4 is not None) and a.compute != "f16":
+                    continue
+                if t4 is not None and not tunable:
                     continue
                 hip.TILE3 = flag
                 keep_th = hip.TILE3_MIN_BLOCKS_F16
                 if th is not None:
                     hip.TILE3_MIN_BLOCKS_F16 = th
+                if t4 is not None:
+                    hip.tuning_set(*t4)
                 try:
                     model(x1, t)
                     model(x1, t)
@@ -107,6 +124,8 @@ def main():
                 finally:
                     hip.TILE3 = None
                     hip.TILE3_MIN_BLOCKS_F16 = keep_th
+                    if t4 is not None:
+                        hip.tuning_set(t4[0], -1)
                 row[tag] = {"forward_ms": round(ms, 4), "launches": launches}
             res["forward"].append(row)
     text = json.dumps(res, indent=1)
