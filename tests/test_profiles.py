@@ -17,7 +17,7 @@ def test_traffic_table_rederives_from_the_raw_counter_rows(tmp_path, suffix):
     """tools/pmc_traffic.py over the kept FETCH_SIZE / WRITE_SIZE rows of the conv kernels (profiles/r4_pmc_*_rows*.csv.gz) and
     the manifest gives the per-family figures of profiles/pmc_traffic*.json (what `roofline.traffic` prints)."""
     table = os.path.join(PROF, "pmc_traffic%s.json" % suffix)
-    tag = "r5" if os.path.exists(os.path.join(PROF, "r5_pmc_fetch_rows%s.csv.gz" % suffix)) else "r4"
+    tag = next((t for t in ("r6", "r5") if os.path.exists(os.path.join(PROF, "%s_pmc_fetch_rows%s.csv.gz" % (t, suffix)))), "r4")
     rows = {c: os.path.join(PROF, "%s_pmc_%s_rows%s.csv.gz" % (tag, c, suffix)) for c in ("fetch", "write")}
     manifest = os.path.join(PROF, "%s_manifest%s.json" % (tag, suffix))
     for f in [table, manifest, *rows.values()]:
@@ -62,7 +62,7 @@ def test_bench_lines_carry_the_contract(name):
 
 
 def test_design_tables_are_generated_from_the_final_evidence():
-    """DESIGN.md's round-5 result tables ARE tools/design_tables.py over profiles/r5_bench*.json (the document
+    """DESIGN.md's result tables ARE tools/design_tables.py over profiles/<TAG>_bench*.json (the document
     quotes the final evidence files and nothing else)."""
     sys.path.insert(0, os.path.join(REPO, "tools"))
     try:
@@ -71,13 +71,14 @@ def test_design_tables_are_generated_from_the_final_evidence():
         sys.path.pop(0)
     want = design_tables.block()
     if want is None:
-        pytest.skip("profiles/r5_bench.json / r5_bench_detail.json not committed yet")
+        pytest.skip("profiles/%s_bench.json / _bench_detail.json not committed yet" % design_tables.TAG)
     text = open(os.path.join(REPO, "DESIGN.md")).read()
     i, j = text.index(design_tables.BEGIN), text.index(design_tables.END)
     assert text[i + len(design_tables.BEGIN):j].strip() == want.strip()
 
 
-@pytest.mark.parametrize("name", ["r5_bench.json", "r5_bench_f16.json", "r5_bench_2ranks_gloo.json", "r5_bench_sd.json"])
+@pytest.mark.parametrize("name", ["r5_bench.json", "r5_bench_f16.json", "r5_bench_2ranks_gloo.json", "r5_bench_sd.json",
+                                  "r6_bench.json", "r6_bench_f16.json", "r6_bench_2ranks_gloo.json", "r6_bench_sd.json"])
 def test_round5_bench_lines_are_small_and_carry_the_contract(name):
     path = os.path.join(PROF, name)
     if not os.path.exists(path):
@@ -89,9 +90,11 @@ def test_round5_bench_lines_are_small_and_carry_the_contract(name):
               "data", "config"):
         assert k in d, k
     assert d["higher_is_better"] is True and d["data"] == "synthetic" and "workload" in d["config"] and d["value"] > 0
-    if name in ("r5_bench.json", "r5_bench_f16.json"):
+    if name[3:] in ("bench.json", "bench_f16.json"):
         r = d["roofline"]
         assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["frac"] < 1.0
-    if name == "r5_bench.json":
+    if name[3:] == "bench.json":
         assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["cores"] >= 1 and d["parity_ok"] is True
-        assert os.path.exists(os.path.join(PROF, "r5_bench_detail.json"))
+        assert os.path.exists(os.path.join(PROF, name[:3] + "bench_detail.json"))
+        if name.startswith("r6"):
+            assert d["cpu_baseline"]["model"]  # (which model ran on the CPU leg: VERDICT r5 next #8)

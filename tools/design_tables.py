@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""DESIGN.md's round-5 result tables, generated from the committed evidence (profiles/r5_bench*.json = the bench lines and detail
+"""DESIGN.md's result tables of the current round (TAG), generated from the committed evidence (profiles/<TAG>_bench*.json = the bench lines and detail
 files of the final GPU session) -- so that the document quotes the final evidence and nothing else.
 
     python tools/design_tables.py            # print the block
@@ -12,7 +12,8 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(REPO, "profiles")
-BEGIN, END = "<!-- r5-tables:begin (tools/design_tables.py) -->", "<!-- r5-tables:end -->"
+TAG = "r6"
+BEGIN, END = "<!-- %s-tables:begin (tools/design_tables.py) -->" % TAG, "<!-- %s-tables:end -->" % TAG
 
 
 def load(name):
@@ -43,14 +44,14 @@ def fmt(v, nd=3):
 
 
 def block():
-    line, det = load("r5_bench.json"), load("r5_bench_detail.json")
+    line, det = load(TAG + "_bench.json"), load(TAG + "_bench_detail.json")
     if line is None or det is None:
         return None
-    f16, sd, gl = load("r5_bench_f16_detail.json"), load("r5_bench_sd_detail.json"), load("r5_bench_2ranks_gloo_detail.json")
+    f16, sd, gl = load(TAG + "_bench_f16_detail.json"), load(TAG + "_bench_sd_detail.json"), load(TAG + "_bench_2ranks_gloo_detail.json")
     out = []
-    out.append("Source: `profiles/r5_bench.json` (the <= 4 KB contract line as the driver reads it), `profiles/r5_bench_detail.json` (everything), "
-               "`r5_bench_f16*`, `r5_bench_sd*`, `r5_bench_2ranks_gloo*`; kernel sources `%s` (= `sige_amd.build.source_hash()`, the hash `profiles/pmc_traffic.json` "
-               "was measured on)." % g(load("pmc_traffic.json"), "source_hash", default="?"))
+    out.append("Source: `profiles/%s_bench.json` (the <= 4 KB contract line as the driver reads it), `profiles/%s_bench_detail.json` (everything), "
+               "`%s_bench_f16*`, `%s_bench_sd*`, `%s_bench_2ranks_gloo*`; kernel sources `%s` (= `sige_amd.build.source_hash()`, the hash `profiles/pmc_traffic.json` "
+               "was measured on)." % (TAG, TAG, TAG, TAG, TAG, g(load("pmc_traffic.json"), "source_hash", default="?")))
     out.append("")
     out.append("| DDPM-256 sparse forward, 1×MI355X, exact fp32 | value |")
     out.append("|---|---|")
@@ -162,7 +163,7 @@ def block():
 def main():
     b = block()
     if b is None:
-        print("no profiles/r5_bench.json + r5_bench_detail.json yet", file=sys.stderr)
+        print("no profiles/%s_bench.json + %s_bench_detail.json yet" % (TAG, TAG), file=sys.stderr)
         return 1
     if "--write" in sys.argv:
         path = os.path.join(REPO, "DESIGN.md")
