@@ -29,7 +29,7 @@ enum { T3_GATHER = 1, T3_SCATTER_GATHER = 2 };
 // PREC_: WIDE_F32 -- exact fp32 (v_mfma_f32_32x32x2_f32); WIDE_F16 (round 6, BASELINE.json configs[4]) -- operands rounded to fp16
 // (RNE) in the staging path, fp32 accumulation on v_mfma_f32_32x32x16_f16: ONE matrix instruction per tap and tile pair contracts
 // the wave's 16 channels (eight in the fp32 form), the stage of a pixel is 32 bytes instead of 64 and a k-step of packed weights 2 KB
-// instead of 4 -- so the whole chunk's weights (9 steps) ride in the register ring.
+// instead of 4; a three-step weight ring as in the fp32 form (108-128 registers: three workgroups per CU).
 template <int TPW_, int PREC_ = WIDE_F32>
 struct Tile3Geo {
     static constexpr int TPW = TPW_;                   // tiles per workgroup
@@ -49,9 +49,18 @@ struct Tile3Geo {
     static constexpr int ROWB = KSB + 16;              // LDS row of one staged pixel (padded against bank conflicts)
     static constexpr int ABUF = NPX * ROWB;            // bytes of one stage of one wave
     static constexpr int STEPB = 2 * NP * 1024;        // packed weight bytes per k-step of one wave (sige_hip_wide_conv_pack)
-    static constexpr int RB = F32 ? 3 : 9;             // weight ring, in k-steps
+    // fp16: (workgroups per CU, ring) measured at (2, 9) / (3, 9: spills) / (3, 6) / (3, 3) / (4, 3: spills) -- profiles/r6l_*, r6m_*:
+    // three workgroups per CU with the fp32 form's three-step ring is the fastest launch by launch (15 % edit, 256^2: gather
+    // 17.8 -> 16.2 us, scatter_gather 25.4 -> 22.1 us against (2, 9)); -D overrides for A/B builds (tools/build_variant.py)
+#ifndef SIGE_T3H_RB
+#define SIGE_T3H_RB 3
+#endif
+#ifndef SIGE_T3H_OCC
+#define SIGE_T3H_OCC 3
+#endif
+    static constexpr int RB = F32 ? 3 : SIGE_T3H_RB;   // weight ring, in k-steps
     // (fp32: 46 KB of LDS and <= 168 registers: three workgroups per CU)
-    static constexpr int OCC = F32 ? (TPW_ == 2 ? 3 : 1) : 2;  // (fp16, 4 tiles: 70 KB of LDS -- two workgroups per CU)
+    static constexpr int OCC = F32 ? (TPW_ == 2 ? 3 : 1) : (TPW_ == 2 ? SIGE_T3H_OCC : 2);  // (fp16, 4 tiles: 70 KB of LDS -- two workgroups per CU)
     static constexpr int LDS_BYTES = cmax(4 * 2 * ABUF, 4 * BM * 68 * 4);
     static_assert((2 * STEPS) % RB == 0, "the ring position of a step must not depend on the chunk");
 };

@@ -295,7 +295,9 @@ def test_f16_cache_ddpm_forward_whole_sweep(hip, ddpm_reference, ddpm_gpu, ratio
             x1 = cl(ref["x0"] + ref["noise"] * bench.edit_mask(ratio))
             n0 = hip.launch_count()
             again = model(x1, torch.zeros(1, device=DEV))
-            assert hip.launch_count() - n0 <= 102  # (a steady-state forward: no conversion pass in front of or behind any launch)
+            # (a steady-state forward: no conversion pass in front of or behind any launch.  102 launches; since round 6 a conv1 that the
+            #  router sends to the fp16 tile conv v3 launches its held 1x1 shortcut on its own: at most the 9 paired blocks of the up path)
+            assert hip.launch_count() - n0 <= 102 + 9
             assert torch.equal(again, out)
     finally:
         model.set_compute_dtype("f32")

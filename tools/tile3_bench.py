@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--compute", default="f32", choices=["f32", "f16"], help="operand form of both kernels (f16: round 6, Tile3Geo<2, WIDE_F16>)")
     ap.add_argument("--cache-dtype", default="f32", choices=["f32", "f16"], help="the forward's cache storage (bench.py --dtype f16 uses f16)")
+    ap.add_argument("--skip-forward", action="store_true")
+    ap.add_argument("--skip-layers", action="store_true")
+    ap.add_argument("--ratios", default="0.012,0.05,0.10,0.15,0.20")
     a = ap.parse_args()
     from sige_amd import hip
     from sige_amd.utils import dilate_mask, downsample_mask, reduce_mask
@@ -34,7 +37,8 @@ def main():
     cl = lambda t_: t_.contiguous(memory_format=torch.channels_last)  # noqa: E731
     res = {"layers": [], "forward": []}
     torch.manual_seed(0)
-    for ratio in (0.012, 0.05, 0.10, 0.15, 0.20):
+    ratios = tuple(float(v) for v in a.ratios.split(","))
+    for ratio in (() if a.skip_layers else ratios):
         pyr = downsample_mask(dilate_mask(bench.square_mask(ratio).to(dev), 5), 8)
         for (R, C, Cout) in ((256, 128, 128), (128, 128, 128), (64, 256, 256)):
             m = pyr[(R, R)]
@@ -91,7 +95,7 @@ def main():
     with torch.no_grad():
         model.set_mode("full")
         model(x0, t)
-        for ratio in (0.012, 0.05, 0.10, 0.15, 0.20):
+        for ratio in (() if a.skip_forward else ratios):
             mask = bench.square_mask(ratio).to(dev)
             model.set_masks(downsample_mask(dilate_mask(mask, 5), 8))
             model.set_mode("sparse")
