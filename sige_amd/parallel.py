@@ -436,7 +436,8 @@ def choose_distribution(candidates: Dict[str, Callable[[], None]], recompute: Op
       * SLOW: the run took longer than `watchdog_s` on the slowest rank -> the candidate is out after that one run;
       * RAISED on any rank -> out; the ranks learn of it through the rendezvous store, not through a collective, so the rank that
         raised never enters a collective the others are not in;
-      * HUNG: no return within `hang_timeout_s` (default max(10 s, 5 x watchdog_s)) on any rank -> out, and the communicator counts
+      * HUNG: no return within `hang_timeout_s` (default max(60 s, 30 x watchdog_s): well above the slowest collective that does
+        finish -- gloo's scatter + all-gather between two ranks sharing one GPU takes 14 s) on any rank -> out, and the communicator counts
         as poisoned: no further collective candidate is tried (a hung collective cannot be cancelled from Python; its thread stays
         blocked, its stream is abandoned), the decision falls to `recompute`, which needs no communication.
     Survivors run `repeats - 1` more times; the figure is the best run, max over ranks.  The fastest survivor wins, `recompute`
@@ -451,7 +452,7 @@ def choose_distribution(candidates: Dict[str, Callable[[], None]], recompute: Op
     if sync is None:
         sync = (lambda: torch.cuda.synchronize()) if torch.cuda.is_available() else (lambda: None)
     if hang_timeout_s is None:
-        hang_timeout_s = max(10.0, 5.0 * watchdog_s)
+        hang_timeout_s = max(60.0, 30.0 * watchdog_s)
     multi = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if multi else 1
     rank = dist.get_rank(group) if multi else 0

@@ -90,7 +90,7 @@ def block():
     t3 = det.get("tile_conv3") or {}
     if t3.get("rows"):
         out.append("")
-        out.append("| tile conv v3 (routed from %s v3 workgroups on; §3.14) | router off | default | max \\|Δ\\| |" % t3.get("min_blocks"))
+        out.append("| tile conv v3 (exact fp32; routed from %s v3 workgroups on; docs/history.md §3.14) | router off | default | max \\|Δ\\| |" % t3.get("min_blocks"))
         out.append("|---|---|---|---|")
         for row in t3["rows"]:
             out.append("| forward at %.0f %% | %s ms | **%s ms** | %s |" % (100 * row["edit_ratio"], fmt(row.get("router_off_ms")), fmt(row.get("default_ms")),

@@ -103,9 +103,10 @@ def main():
             row = {"edit_ratio": ratio}
             hip.TILE3_MIN_BLOCKS = 512
             for tag, flag, th, t4 in (("conv_mfma_only", False, None, None), ("router", None, None, None),
-                                      ("router_pairs_to_v3_from_256", None, None, ("tile3_f16_pair_min", 256)),
-                                      ("router_pairs_to_v3_from_512", None, None, ("tile3_f16_pair_min", 512)),
-                                      ("router_pairs_to_v3_from_768", None, None, ("tile3_f16_pair_min", 768))):
+                                      ("router_from_64", None, 64, ("tile3_f16_pair_min", 64)),
+                                      ("router_from_96", None, 96, ("tile3_f16_pair_min", 96)),
+                                      ("router_from_128", None, 128, ("tile3_f16_pair_min", 128)),
+                                      ("router_from_192", None, 192, ("tile3_f16_pair_min", 192))):
                 if (th is not None or t4 is not None) and a.compute != "f16":
                     continue
                 if t4 is not None and not tunable:
