@@ -84,7 +84,8 @@ enum {
     SIGE_HIP_TUNE_ATTENTION_FORM = 10,       /* attention_tokens: 1 = 16 queries per workgroup | 2 = 32 (0 = automatic) */
     SIGE_HIP_TUNE_TILE3_F16_TPW4_MIN = 11,  /* tile conv v3, fp16 operands: 4 tiles per workgroup from this many 2-tile workgroups on (-1 = library; 0 never) */
     SIGE_HIP_TUNE_TILE3_F16_PAIR_MIN = 12,  /* tile conv v3, fp16 operands: a conv1 whose 1x1 shortcut is held for the pair kernel goes to v3 anyway (the shortcut launched on its own) from this many workgroups on (-1 = library; 0 never) */
-    SIGE_HIP_TUNE_COUNT = 13
+    SIGE_HIP_TUNE_TILE3_F16_SPARSE_MIN = 13, /* tile conv v3, fp16 operands: launches over a SPARSE tile list (fewer tiles than 4x4 cells) go to v3 from this many workgroups on, below the general threshold (-1 = library; 0 = no separate rule) */
+    SIGE_HIP_TUNE_COUNT = 14
 };
 #ifdef SIGE_HIP_TUNING
 int sige_hip_tuning_set(int key, int value); /* SIGE_HIP_EINVAL for an unknown key or a value outside the key's range */

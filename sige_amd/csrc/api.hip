@@ -11,9 +11,9 @@
 namespace sige {
 std::atomic<int> g_tuning[SIGE_HIP_TUNE_COUNT] = {{kTuningDefaults[0]}, {kTuningDefaults[1]}, {kTuningDefaults[2]}, {kTuningDefaults[3]},
                                                   {kTuningDefaults[4]}, {kTuningDefaults[5]}, {kTuningDefaults[6]}, {kTuningDefaults[7]},
-                                                  {kTuningDefaults[8]}, {kTuningDefaults[9]}, {kTuningDefaults[10]}, {kTuningDefaults[11]}, {kTuningDefaults[12]}};
+                                                  {kTuningDefaults[8]}, {kTuningDefaults[9]}, {kTuningDefaults[10]}, {kTuningDefaults[11]}, {kTuningDefaults[12]}, {kTuningDefaults[13]}};
 }
-static_assert(SIGE_HIP_TUNE_COUNT == 13, "g_tuning's initialiser lists every key");
+static_assert(SIGE_HIP_TUNE_COUNT == 14, "g_tuning's initialiser lists every key");
 
 extern "C" int sige_hip_tuning_set(int key, int value) {
     bool ok = false;
@@ -26,6 +26,7 @@ extern "C" int sige_hip_tuning_set(int key, int value) {
         case SIGE_HIP_TUNE_CONV_KSPLIT_SECOND_PASS: ok = value == 0 || value == 1; break;
         case SIGE_HIP_TUNE_TILE3_F16_TPW4_MIN: ok = value >= -1; break;
         case SIGE_HIP_TUNE_TILE3_F16_PAIR_MIN: ok = value >= -1; break;
+        case SIGE_HIP_TUNE_TILE3_F16_SPARSE_MIN: ok = value >= -1; break;
         case SIGE_HIP_TUNE_GATHER_ONE_TILE_ROWS: ok = value == 0 || value == 1; break;
         case SIGE_HIP_TUNE_SCATTER_GATHER_FORM: ok = value >= 0 && value <= 3; break;
         case SIGE_HIP_TUNE_SMALL_COUT_SCALAR: ok = value == 0 || value == 1; break;

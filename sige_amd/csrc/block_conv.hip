@@ -1338,13 +1338,24 @@ extern "C" int sige_hip_release_graph_tickets(void) { return sige::release_graph
 // launched on its own: tile_conv3_launch -> flush_held_conv); SIGE_HIP_TUNE_TILE3_F16_PAIR_MIN = -1: this value, 0 = never
 constexpr int kTile3F16PairMin = 256;  // (profiles/r6j_tile3_f16_pairs_bench.json: -2.6 % at a 15 % edit, -3.3 % at 20 %, nothing lost below)
 
+// fp16 operands: launches over a SPARSE tile list (fewer tiles than the tensor has 4 x 4 cells) go to v3 from this many workgroups
+// on; dense layers (every tile active: deep K over a few pixels, where conv_mfma.hpp's K split wins) keep `min_blocks`.
+// SIGE_HIP_TUNE_TILE3_F16_SPARSE_MIN = -1: this value, 0 = no separate rule
+constexpr int kTile3F16SparseMin = 128;  // (profiles/r6o_tile3_f16_sparse_min.json: -1 % at 10 - 20 % edits, nothing lost at 1.2 / 5 %; 32 - 96 lose at 1.2 %)
+
 static bool tile3_takes(const float *packed_tile3, int min_blocks, int B, int N, int C1, int C2, int Cout, int kH, int kW, int bH, int bW,
-                        int strideH, int strideW, hipStream_t st, bool f16 = false) {
+                        int strideH, int strideW, hipStream_t st, bool f16 = false, int H = 0, int W = 0) {
     if (!packed_tile3 || min_blocks <= 0) return false;
     if (kH != 3 || kW != 3 || bH != 6 || bW != 6 || strideH != 1 || strideW != 1) return false;
     if (!sige_hip_tile_conv3_supported(C1, C2, Cout)) return false;
     const long blocks = (long)((B * (long)N + 1) / 2) * (Cout / 64);
-    if (blocks < min_blocks) return false;
+    int need = min_blocks;
+    if (f16 && H > 0 && (long)N * 16 < (long)H * W) {  // a sparse tile list
+        int sm = tuning(SIGE_HIP_TUNE_TILE3_F16_SPARSE_MIN);
+        if (sm < 0) sm = kTile3F16SparseMin;
+        if (sm > 0 && sm < need) need = sm;
+    }
+    if (blocks < need) return false;
     // a 1x1 shortcut held by conv_pair_begin() shares the conv_mfma.hpp launch of this conv1: keeping the pair beats the v3 kernel
     // plus a launch of its own for the shortcut (46.7 vs 39.5 + 8.7 us at a 15 % edit: profiles/r5j_sequence_15pct_*.csv)
     if (g_held.active && g_held.st == st) {
@@ -1429,7 +1440,7 @@ extern "C" int sige_hip_gather_conv_nhwc_v3_f16c(const float *x, const float *x2
     SIGE_PLAN_HOOK_N(sige_hip_gather_conv_nhwc_v3_f16c, (sige::CountOf<9, 10>), x, x2, B, C1, C2, H, W, bH, bW, active_indices, N, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, packed, bias, Cout, kH, kW, strideH, strideW, to_full, offsetH, offsetW, residual, Ho, Wo, workspace, workspace_floats, out_scale, out_shift, out_activation, upsample2x, twin0, twin0_scale, twin0_shift, twin1, twin1_scale, twin1_shift, packed_tile3, min_blocks, out, stream);
     const int Cin = C1 + C2;
     const bool aff_ok = (!scale && !shift) || (scale && shift && scaleC == Cin && shiftC == Cin && scaleB == shiftB && (scaleB == 1 || scaleB == B));
-    if (B > 0 && N > 0 && aff_ok && tile3_takes(packed_tile3, min_blocks, B, N, C1, C2, Cout, kH, kW, bH, bW, strideH, strideW, as_stream(stream), true)) {
+    if (B > 0 && N > 0 && aff_ok && tile3_takes(packed_tile3, min_blocks, B, N, C1, C2, Cout, kH, kW, bH, bW, strideH, strideW, as_stream(stream), true, H, W)) {
         const int rc = tile_conv3_launch(T3_GATHER, x, x2, B, C1, C2, H, W, upsample2x, active_indices, N, nullptr, 0, 0, scale, shift,
                                          scale ? scaleB : 0, activation, packed_tile3, bias, Cout, to_full, offsetH, offsetW, Ho, Wo,
                                          to_full ? residual : nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, out_scale, out_shift, out_activation,
@@ -1454,7 +1465,7 @@ extern "C" int sige_hip_scatter_gather_conv_scatter_nhwc_v3_f16c(
     SIGE_PLAN_HOOK_N(sige_hip_scatter_gather_conv_scatter_nhwc_v3_f16c, (sige::CountOf<11, 12>, sige::CountOf<31, 34>), x, y, y_f16, B, Cin, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, packed, bias, Cout, kH, kW, offsetH, offsetW, residual, residual_f16, x1, table1, gH1, gW1, N1, R1, S1, twin0, twin0_scale, twin0_shift, twin1, twin1_scale, twin1_shift, packed_tile3, min_blocks, out, stream);
     const float *yh = static_cast<const float *>(y), *rh = static_cast<const float *>(residual);
     if (B > 0 && N > 0 && !scale && !shift && activation == SIGE_HIP_ACT_IDENTITY &&
-        tile3_takes(packed_tile3, min_blocks, B, N, Cin, 0, Cout, kH, kW, bH, bW, 1, 1, as_stream(stream))) {
+        tile3_takes(packed_tile3, min_blocks, B, N, Cin, 0, Cout, kH, kW, bH, bW, 1, 1, as_stream(stream), true, H, W)) {
         const int rc = tile_conv3_launch(T3_SCATTER_GATHER, x, yh, B, Cin, 0, H, W, 0, active_indices, N, scatter_map, Rx, Sx, nullptr, nullptr, 0,
                                          SIGE_HIP_ACT_IDENTITY, packed_tile3, bias, Cout, 1, offsetH, offsetW, H, W, rh,
                                          x1, table1, gH1, gW1, N1, R1, S1, nullptr, nullptr, 0,

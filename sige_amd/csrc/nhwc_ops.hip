@@ -16,6 +16,8 @@ constexpr int kT = 256;
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+// a kernel's OUTPUT in global memory: write-through (common.hpp store_out4; round 6) -- never for LDS pointers (st4 above)
+__device__ __forceinline__ void st4_out(float *p, float4 v) { store_out4(p, v); }
 // fp16 storage (the resident cache of the "_f16" entry points: SURVEY.md 8b / 8f row 4): 4 consecutive halves = one 8-byte
 // load, widened exactly; stores round to nearest even
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(kT) void gather_nhwc_kernel(const XT *__restrict__ 
         float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         if (h >= hlo && h < hhi && w >= 0 && w < W)
             z = affine_act4<ACT>(ld4(x + (((size_t)b * H + h) * W + w) * C + c), scale, shift, b * aff_sb, c);
-        st4(out + (size_t)u * 4, z);
+        st4_out(out + (size_t)u * 4, z);
     }
 }
 
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(kT) void scatter_gather_nhwc_kernel(const float *__
                                       : ld4(y + (((size_t)b * H + h) * W + w) * C + c);
             z = affine_act4<ACT>(v, scale, shift, b * aff_sb, c);
         }
-        st4(out + (size_t)u * 4, z);
+        st4_out(out + (size_t)u * 4, z);
     }
 }
 
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(kT) void spade_modulate_nhwc_kernel(SpadeArgs a, lo
                 z.z = z.z > 0.f ? z.z : z.z * a.slope; z.w = z.w > 0.f ? z.w : z.w * a.slope;
             }
         }
-        st4(a.out + (size_t)u * 4, z);
+        st4_out(a.out + (size_t)u * 4, z);
     }
 }
 
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(kT) void scatter_full_nhwc_kernel(ScatterNhwcArgsT<
         const int h = (int)(bh % a.H), b = (int)(bh / a.H);
         const int t0 = a.table0[(h / a.R0) * a.gW0 + w / a.S0];
         const int t1 = BLOCK_RES ? a.table1[(h / a.R1) * a.gW1 + w / a.S1] : -1;
-        st4(a.out + (size_t)u * 4, scatter_value<BLOCK_RES, CT>(a, b, h, w, c, t0, t1, (size_t)u * 4));
+        st4_out(a.out + (size_t)u * 4, scatter_value<BLOCK_RES, CT>(a, b, h, w, c, t0, t1, (size_t)u * 4));
     }
 }
 
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(kT) void scatter_tiles_nhwc_kernel(ScatterNhwcArgsT
         if (main) { t0 = n; t1 = BLOCK_RES ? a.table1[(h / a.R1) * a.gW1 + w / a.S1] : -1; }
         else { t1 = n; t0 = a.table0[(h / a.R0) * a.gW0 + w / a.S0]; if (t0 >= 0) continue; }  // a main tile writes this pixel
         const size_t q = ((((size_t)b * a.H + h) * a.W + w) * a.C) + c;
-        st4(a.out + q, scatter_value<BLOCK_RES, CT>(a, b, h, w, c, t0, t1, q));
+        st4_out(a.out + q, scatter_value<BLOCK_RES, CT>(a, b, h, w, c, t0, t1, q));
     }
 }
 

@@ -17,7 +17,7 @@ namespace sige {
 constexpr int kTuningDefaults[SIGE_HIP_TUNE_COUNT] = {
     /* CONV_TILE_MT */ 0, /* CONV_TILE_NB */ 0, /* CONV_WAVES */ 0, /* CONV_LARGE_GRID_NB1 */ -1, /* CONV_KSPLIT */ 0,
     /* CONV_KSPLIT_SECOND_PASS */ 0, /* GATHER_ONE_TILE_ROWS */ 0, /* SCATTER_GATHER_FORM */ 0, /* SMALL_COUT_SCALAR */ 0,
-    /* WIDE_KSPLIT */ 0, /* ATTENTION_FORM */ 0, /* TILE3_F16_TPW4_MIN */ -1, /* TILE3_F16_PAIR_MIN */ -1};
+    /* WIDE_KSPLIT */ 0, /* ATTENTION_FORM */ 0, /* TILE3_F16_TPW4_MIN */ -1, /* TILE3_F16_PAIR_MIN */ -1, /* TILE3_F16_SPARSE_MIN */ -1};
 
 #ifdef SIGE_HIP_TUNING
 extern std::atomic<int> g_tuning[SIGE_HIP_TUNE_COUNT];

@@ -235,7 +235,7 @@ _TUNING_SIGNATURES = {
 TUNING_LIB_PATH = os.path.join(_PKG, "lib", "libsige_hip_tuning.so")
 # include/sige_hip.h: SIGE_HIP_TUNE_*
 TUNE = {"conv_tile_mt": 0, "conv_tile_nb": 1, "conv_waves": 2, "conv_large_grid_nb1": 3, "conv_ksplit": 4, "conv_ksplit_second_pass": 5,
-        "gather_one_tile_rows": 6, "scatter_gather_form": 7, "small_cout_scalar": 8, "wide_ksplit": 9, "attention_form": 10, "tile3_f16_tpw4_min": 11, "tile3_f16_pair_min": 12}
+        "gather_one_tile_rows": 6, "scatter_gather_form": 7, "small_cout_scalar": 8, "wide_ksplit": 9, "attention_form": 10, "tile3_f16_tpw4_min": 11, "tile3_f16_pair_min": 12, "tile3_f16_sparse_min": 13}
 
 
 # how many guarded entry-point calls had to switch HIP's current device to the tensor's ("switched") and how many found it current

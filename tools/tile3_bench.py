@@ -103,10 +103,12 @@ def main():
             row = {"edit_ratio": ratio}
             hip.TILE3_MIN_BLOCKS = 512
             for tag, flag, th, t4 in (("conv_mfma_only", False, None, None), ("router", None, None, None),
-                                      ("router_from_64", None, 64, ("tile3_f16_pair_min", 64)),
-                                      ("router_from_96", None, 96, ("tile3_f16_pair_min", 96)),
-                                      ("router_from_128", None, 128, ("tile3_f16_pair_min", 128)),
-                                      ("router_from_192", None, 192, ("tile3_f16_pair_min", 192))):
+                                      ("sparse_from_32", None, None, ("tile3_f16_sparse_min", 32)),
+                                      ("sparse_from_64", None, None, ("tile3_f16_sparse_min", 64)),
+                                      ("sparse_from_96", None, None, ("tile3_f16_sparse_min", 96)),
+                                      ("sparse_from_128", None, None, ("tile3_f16_sparse_min", 128)),
+                                      ("sparse_from_64_pairs_64", None, None, ("tile3_f16_sparse_min", 64, "tile3_f16_pair_min", 64)),
+                                      ("sparse_from_128_pairs_128", None, None, ("tile3_f16_sparse_min", 128, "tile3_f16_pair_min", 128))):
                 if (th is not None or t4 is not None) and a.compute != "f16":
                     continue
                 if t4 is not None and not tunable:
@@ -116,7 +118,8 @@ def main():
                 if th is not None:
                     hip.TILE3_MIN_BLOCKS_F16 = th
                 if t4 is not None:
-                    hip.tuning_set(*t4)
+                    for q in range(0, len(t4), 2):
+                        hip.tuning_set(t4[q], t4[q + 1])
                 try:
                     model(x1, t)
                     model(x1, t)
@@ -130,7 +133,8 @@ def main():
                     hip.TILE3 = None
                     hip.TILE3_MIN_BLOCKS_F16 = keep_th
                     if t4 is not None:
-                        hip.tuning_set(t4[0], -1)
+                        for q in range(0, len(t4), 2):
+                            hip.tuning_set(t4[q], -1)
                 row[tag] = {"forward_ms": round(ms, 4), "launches": launches}
             res["forward"].append(row)
     text = json.dumps(res, indent=1)
