@@ -164,26 +164,58 @@ def test_tile_conv3_f16_scatter_gather_to_full(hip, cache_f16):
 
 def test_tile_conv3_f16_router_decides_from_the_tile_count(hip):
     """The routing entry points (sige_hip_gather_conv_nhwc_v3_f16c): below TILE3_MIN_BLOCKS_F16 workgroups the conv_mfma.hpp launch,
-    bit for bit; from the threshold on the v3 kernel, bit for bit the forced v3 launch."""
+    bit for bit; from the threshold on the v3 kernel, bit for bit the forced v3 launch.  A SPARSE tile list (fewer tiles than 4 x 4
+    cells) is routed from 128 workgroups on whatever the general threshold (block_conv.hip kTile3F16SparseMin); a dense one is not."""
     torch.manual_seed(5)
-    C, cout, res = 128, 128, 64
+    C, res = 128, 64
     idx, _ = _masks(res)
     x = _cl(torch.randn(1, C, res, res, device=DEV))
-    w = torch.randn(cout, C, 3, 3, device=DEV) / (3 * C ** 0.5)
-    packed = hip.conv_pack_weights(w, 6, 6, (1, 1), "f16")
-    call = lambda: hip.gather_conv_cl(x, None, (6, 6), idx, None, None, "identity", packed, None, cout, (3, 3), (1, 1))  # noqa: E731
-    blocks = ((idx.shape[0] + 1) // 2) * (cout // 64)
+
+    def setup(cout, tiles):
+        w = torch.randn(cout, C, 3, 3, device=DEV) / (3 * C ** 0.5)
+        packed = hip.conv_pack_weights(w, 6, 6, (1, 1), "f16")
+        call = lambda: hip.gather_conv_cl(x, None, (6, 6), tiles, None, None, "identity", packed, None, cout, (3, 3), (1, 1))  # noqa: E731
+        return call, ((tiles.shape[0] + 1) // 2) * (cout // 64)
+
+    def forced_and_old(call):
+        try:
+            hip.TILE3 = True
+            forced = call().clone()
+            hip.TILE3 = False
+            old = call().clone()
+        finally:
+            hip.TILE3 = None
+        d = float((forced - old).abs().max())
+        assert d < 1e-3, d
+        distinct.append(not torch.equal(forced, old))  # (the two kernels sum in different orders: normally not the same bits)
+        return forced, old
+
+    distinct = []
+
     keep = hip.TILE3_MIN_BLOCKS_F16
     try:
-        hip.TILE3 = True
-        forced = call().clone()
-        hip.TILE3 = False
-        old = call().clone()
-        hip.TILE3 = None
+        # below the sparse rule's 128 workgroups: the general threshold decides
+        call, blocks = setup(64, idx)
+        assert blocks < 128
+        forced, old = forced_and_old(call)
         hip.TILE3_MIN_BLOCKS_F16 = blocks
         assert torch.equal(call(), forced)
         hip.TILE3_MIN_BLOCKS_F16 = blocks + 1
         assert torch.equal(call(), old)
+        # a sparse list with >= 128 workgroups goes to v3 whatever the general threshold ...
+        call, blocks = setup(128, idx)
+        assert 128 <= blocks and idx.shape[0] * 16 < res * res
+        forced, old = forced_and_old(call)
+        hip.TILE3_MIN_BLOCKS_F16 = 100000
+        assert torch.equal(call(), forced)
+        # ... a DENSE list (every tile active: the dense layers of a sparse forward) does not
+        dense = hip.all_tiles(res, res, (4, 4), (1, 1), (1, 1), DEV)
+        call, blocks = setup(128, dense)
+        assert blocks >= 128 and dense.shape[0] * 16 >= res * res
+        forced, old = forced_and_old(call)
+        assert torch.equal(call(), old)
+        hip.TILE3_MIN_BLOCKS_F16 = blocks
+        assert torch.equal(call(), forced)
     finally:
         hip.TILE3, hip.TILE3_MIN_BLOCKS_F16 = None, keep
-    assert not torch.equal(forced, old) and float((forced - old).abs().max()) < 1e-3
+    assert any(distinct), "forced v3 and conv_mfma.hpp gave the same bits in every case: the routing checks above prove nothing"
