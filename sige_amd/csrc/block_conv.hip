@@ -1407,10 +1407,12 @@ extern "C" int sige_hip_scatter_gather_conv_scatter_nhwc_v3_f32(
         const float *packed_tile3, int min_blocks,
         float *out, void *stream) {
     SIGE_PLAN_HOOK_N(sige_hip_scatter_gather_conv_scatter_nhwc_v3_f32, (sige::CountOf<10, 11>, sige::CountOf<29, 32>), x, y, B, Cin, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, packed, bias, Cout, kH, kW, offsetH, offsetW, residual, x1, table1, gH1, gW1, N1, R1, S1, twin0, twin0_scale, twin0_shift, twin1, twin1_scale, twin1_shift, packed_tile3, min_blocks, out, stream);
-    if (B > 0 && N > 0 && !scale && !shift && activation == SIGE_HIP_ACT_IDENTITY &&
+    const bool aff_ok = (!scale && !shift && activation == SIGE_HIP_ACT_IDENTITY) ||
+                        (scale && shift && scaleC == Cin && shiftC == Cin && scaleB == shiftB && (scaleB == 1 || scaleB == B));
+    if (B > 0 && N > 0 && aff_ok &&
         tile3_takes(packed_tile3, min_blocks, B, N, Cin, 0, Cout, kH, kW, bH, bW, 1, 1, as_stream(stream))) {
-        const int rc = tile_conv3_launch(T3_SCATTER_GATHER, x, y, B, Cin, 0, H, W, 0, active_indices, N, scatter_map, Rx, Sx, nullptr, nullptr, 0,
-                                         SIGE_HIP_ACT_IDENTITY, packed_tile3, bias, Cout, 1, offsetH, offsetW, H, W, residual,
+        const int rc = tile_conv3_launch(T3_SCATTER_GATHER, x, y, B, Cin, 0, H, W, 0, active_indices, N, scatter_map, Rx, Sx, scale, shift, scale ? scaleB : 0,
+                                         activation, packed_tile3, bias, Cout, 1, offsetH, offsetW, H, W, residual,
                                          x1, table1, gH1, gW1, N1, R1, S1, nullptr, nullptr, 0,
                                          twin0, twin0_scale, twin0_shift, twin1, twin1_scale, twin1_shift, out, stream);
         if (rc != SIGE_HIP_EUNSUPPORTED) return rc;
@@ -1464,10 +1466,12 @@ extern "C" int sige_hip_scatter_gather_conv_scatter_nhwc_v3_f16c(
         float *out, void *stream) {
     SIGE_PLAN_HOOK_N(sige_hip_scatter_gather_conv_scatter_nhwc_v3_f16c, (sige::CountOf<11, 12>, sige::CountOf<31, 34>), x, y, y_f16, B, Cin, H, W, Rx, Sx, bH, bW, active_indices, N, scatter_map, scale, scaleB, scaleC, shift, shiftB, shiftC, activation, packed, bias, Cout, kH, kW, offsetH, offsetW, residual, residual_f16, x1, table1, gH1, gW1, N1, R1, S1, twin0, twin0_scale, twin0_shift, twin1, twin1_scale, twin1_shift, packed_tile3, min_blocks, out, stream);
     const float *yh = static_cast<const float *>(y), *rh = static_cast<const float *>(residual);
-    if (B > 0 && N > 0 && !scale && !shift && activation == SIGE_HIP_ACT_IDENTITY &&
+    const bool aff_ok = (!scale && !shift && activation == SIGE_HIP_ACT_IDENTITY) ||
+                        (scale && shift && scaleC == Cin && shiftC == Cin && scaleB == shiftB && (scaleB == 1 || scaleB == B));
+    if (B > 0 && N > 0 && aff_ok &&
         tile3_takes(packed_tile3, min_blocks, B, N, Cin, 0, Cout, kH, kW, bH, bW, 1, 1, as_stream(stream), true, H, W)) {
-        const int rc = tile_conv3_launch(T3_SCATTER_GATHER, x, yh, B, Cin, 0, H, W, 0, active_indices, N, scatter_map, Rx, Sx, nullptr, nullptr, 0,
-                                         SIGE_HIP_ACT_IDENTITY, packed_tile3, bias, Cout, 1, offsetH, offsetW, H, W, rh,
+        const int rc = tile_conv3_launch(T3_SCATTER_GATHER, x, yh, B, Cin, 0, H, W, 0, active_indices, N, scatter_map, Rx, Sx, scale, shift, scale ? scaleB : 0,
+                                         activation, packed_tile3, bias, Cout, 1, offsetH, offsetW, H, W, rh,
                                          x1, table1, gH1, gW1, N1, R1, S1, nullptr, nullptr, 0,
                                          twin0, twin0_scale, twin0_shift, twin1, twin1_scale, twin1_shift, out, stream, WIDE_F16, y_f16, residual_f16);
         if (rc != SIGE_HIP_EUNSUPPORTED) return rc;

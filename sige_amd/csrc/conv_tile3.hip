@@ -40,7 +40,7 @@ int sige::tile_conv3_launch(
     if ((long)B * N == 0) return SIGE_HIP_OK;
     const bool sg = source == T3_SCATTER_GATHER;
     if (!x || !packed || !out || !active_indices || ((C2 || sg) && !x2) || (sg && (!scatter_map || Rx <= 0 || Sx <= 0))) return SIGE_HIP_EINVAL;
-    if (sg && (C2 || upsample2x || scale || shift)) return SIGE_HIP_EUNSUPPORTED;  // (conv2 stages final values: raw, one channel range)
+    if (sg && (C2 || upsample2x)) return SIGE_HIP_EUNSUPPORTED;  // (one channel range; round 6: the cached affine + SiLU in the staging path too -- SD's conv2)
     if (!sige_hip_tile_conv3_supported(C1, C2, Cout)) return SIGE_HIP_EUNSUPPORTED;
     if ((scale == nullptr) != (shift == nullptr)) return SIGE_HIP_EINVAL;
     if (scale && affineB != 1 && affineB != B) return SIGE_HIP_EINVAL;

@@ -18,14 +18,23 @@ template <> void launch_conv_tile3_gather<2, WIDE_F16>(const Tile3Args &a, bool 
 }
 template <> void launch_conv_tile3_sg<2, WIDE_F16>(const Tile3Args &a, bool full, bool y16, hipStream_t st) {
     const dim3 grid(ceil_div(a.T, H2::TPW) * a.ntn);
-    if (y16) {
-        if (full) conv_tile3_kernel<H2, T3_SCATTER_GATHER, false, false, true, true><<<grid, 256, 0, st>>>(a);
-        else conv_tile3_kernel<H2, T3_SCATTER_GATHER, false, false, false, true><<<grid, 256, 0, st>>>(a);
-    } else {
-        if (full) conv_tile3_kernel<H2, T3_SCATTER_GATHER, false, false, true><<<grid, 256, 0, st>>>(a);
-        else conv_tile3_kernel<H2, T3_SCATTER_GATHER, false, false, false><<<grid, 256, 0, st>>>(a);
-    }
+#define SIGE_T3S(AFF)                                                                                                   \
+    do {                                                                                                                \
+        if (y16) {                                                                                                      \
+            if (full) conv_tile3_kernel<H2, T3_SCATTER_GATHER, AFF, false, true, true><<<grid, 256, 0, st>>>(a);        \
+            else conv_tile3_kernel<H2, T3_SCATTER_GATHER, AFF, false, false, true><<<grid, 256, 0, st>>>(a);            \
+        } else {                                                                                                        \
+            if (full) conv_tile3_kernel<H2, T3_SCATTER_GATHER, AFF, false, true><<<grid, 256, 0, st>>>(a);              \
+            else conv_tile3_kernel<H2, T3_SCATTER_GATHER, AFF, false, false><<<grid, 256, 0, st>>>(a);                  \
+        }                                                                                                               \
+    } while (0)
+    if (a.scale) SIGE_T3S(true);
+    else SIGE_T3S(false);
+#undef SIGE_T3S
 }
+}  // namespace sige
+
+namespace sige {
 
 // four tiles (64 pixels) x 64 output channels per workgroup: a weight byte pulled from L2 feeds twice the matrix work -- for launches
 // whose 2-tile grid covers the chip several times over (tile_conv3_launch: kTile3F16Tpw4Min)

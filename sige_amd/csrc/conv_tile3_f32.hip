@@ -17,7 +17,12 @@ template <> void launch_conv_tile3_gather<2>(const Tile3Args &a, bool aff, bool 
 }
 template <> void launch_conv_tile3_sg<2>(const Tile3Args &a, bool full, bool, hipStream_t st) {
     const dim3 grid(ceil_div(a.T, G2::TPW) * a.ntn);
-    if (full) conv_tile3_kernel<G2, T3_SCATTER_GATHER, false, false, true><<<grid, 256, 0, st>>>(a);
-    else conv_tile3_kernel<G2, T3_SCATTER_GATHER, false, false, false><<<grid, 256, 0, st>>>(a);
+    if (a.scale) {  // (the cached affine (+ SiLU) applied to the scatter_gathered window: scatter_gather.cpp:58-84)
+        if (full) conv_tile3_kernel<G2, T3_SCATTER_GATHER, true, false, true><<<grid, 256, 0, st>>>(a);
+        else conv_tile3_kernel<G2, T3_SCATTER_GATHER, true, false, false><<<grid, 256, 0, st>>>(a);
+    } else {
+        if (full) conv_tile3_kernel<G2, T3_SCATTER_GATHER, false, false, true><<<grid, 256, 0, st>>>(a);
+        else conv_tile3_kernel<G2, T3_SCATTER_GATHER, false, false, false><<<grid, 256, 0, st>>>(a);
+    }
 }
 }  // namespace sige

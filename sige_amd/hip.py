@@ -1724,8 +1724,8 @@ def scatter_gather_conv_scatter_cl(x, y, block, activeIndices, scatterMap, scale
     t3 = _tile3_route(packed, B * idx.shape[0], C, 0, Cout, kernel, (1, 1), block)
     f16c = getattr(packed, "compute", "f32") == "f16"
     if (t3 is not None and idx.shape[0] > 0 and (f16c or (y.dtype == torch.float32 and (r is None or r.dtype == torch.float32)))
-            and scale is None and shift is None and activationName == "identity"):
-        got = tile_conv3_cl(2, x, y, B, C, 0, H, W, False, idx, smap, (x.shape[2], x.shape[3]), None, None, "identity", t3, bias, Cout,
+            and ((scale is None and shift is None and activationName == "identity") or (scale is not None and shift is not None))):
+        got = tile_conv3_cl(2, x, y, B, C, 0, H, W, False, idx, smap, (x.shape[2], x.shape[3]), scale, shift, activationName, t3, bias, Cout,
                             (offset[0], offset[1], H, W), r, bargs, None, targs, out, f16=f16c)
         if got is not None:
             return got

@@ -219,3 +219,56 @@ def test_tile_conv3_f16_router_decides_from_the_tile_count(hip):
     finally:
         hip.TILE3, hip.TILE3_MIN_BLOCKS_F16 = None, keep
     assert any(distinct), "forced v3 and conv_mfma.hpp gave the same bits in every case: the routing checks above prove nothing"
+
+
+@pytest.mark.parametrize("compute", ["f32", "f16"])
+def test_tile_conv3_scatter_gather_with_cached_affine(hip, compute):
+    """Source 2 with the cached GroupNorm affine + SiLU in the staging path (the Stable-Diffusion U-Net's conv2: a per-sample affine,
+    CFG batch 2 -- sige_openaimodel.py; scatter_gather.cpp:58-84 applies scale / shift / activation to the re-tiled window, padding
+    stays 0): the v3 kernel against conv_mfma.hpp's launch of the same call and, tile by tile, against an fp64 conv of the
+    standalone scatter_gather's tiles (pinned to the oracle)."""
+    torch.manual_seed(21)
+    B, C, cout, res = 2, 128, 128, 64
+    idx, idx1 = _masks(res)
+    if idx.shape[0] % 2:
+        idx = idx[:-1].contiguous()  # (a per-sample affine needs whole tile pairs per image)
+    smap = hip.get_scatter_map(res, res, 6, 6, 3, 3, 1, 1, 1, 1, idx)
+    y = _cl(torch.randn(B, C, res, res, device=DEV))
+    t4 = _cl(torch.randn(B * idx.shape[0], C, 4, 4, device=DEV))
+    w = torch.randn(cout, C, 3, 3, device=DEV) / (3 * C ** 0.5)
+    bias = torch.randn(cout, device=DEV)
+    packed = hip.conv_pack_weights(w, 6, 6, (1, 1), compute)
+    scale, shift = torch.randn(B, C, 1, 1, device=DEV), torch.randn(B, C, 1, 1, device=DEV)
+    y1 = _cl(torch.randn(B, cout, res, res, device=DEV))
+    cache_out = _cl(torch.randn(B, cout, res, res, device=DEV))
+    outs = []
+    n0 = hip.launch_count()
+    for flag in (True, False):
+        hip.TILE3 = flag
+        try:
+            out = cache_out.clone(memory_format=torch.preserve_format)
+            o = hip.scatter_gather_conv_scatter_cl(t4, y, (6, 6), idx, smap, scale, shift, "swish", packed, bias, cout, (3, 3), (1, 1), out,
+                                                   residual=y1)
+            assert o is not None
+            outs.append(o.clone())
+        finally:
+            hip.TILE3 = None
+    assert hip.launch_count() == n0 + 2
+    tol = 2e-4 if compute == "f32" else 3e-3
+    assert float((outs[0] - outs[1]).abs().max()) < tol and float((outs[0] - outs[1]).abs().mean()) < 2e-5
+    sg = hip.scatter_gather_cl(t4, y, 6, 6, idx, smap, scale, shift, "swish")
+    wd, sgd = (w.double(), sg.double()) if compute == "f32" else (w.half().double(), sg.half().double())
+    conv = F.conv2d(sgd, wd, bias.double()).float()
+    N = idx.shape[0]
+    for b in range(B):
+        for n in (0, 1, N // 2, N - 2):
+            h0, w0 = int(idx[n, 0]) + 1, int(idx[n, 1]) + 1
+            if h0 >= res or w0 >= res:
+                continue
+            h1, w1 = min(h0 + 4, res), min(w0 + 4, res)
+            want = conv[b * N + n][:, :h1 - h0, :w1 - w0] + y1[b, :, h0:h1, w0:w1]
+            got = outs[0][b, :, h0:h1, w0:w1]
+            if compute == "f32":
+                torch.testing.assert_close(got, want, rtol=0, atol=3e-4)
+            else:  # (swish_fast vs the standalone kernel's swish: a staged value may round to the neighbouring half)
+                assert float((got - want).abs().mean()) < 5e-5 and float((got - want).abs().max()) < 5e-3
