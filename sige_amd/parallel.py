@@ -468,7 +468,10 @@ def choose_distribution(candidates: Dict[str, Callable[[], None]], recompute: Op
         """(every rank ok, max time over the ranks); a rank that does not answer = a hang somewhere."""
         if world == 1:
             return ok, dt
-        if agree is None:  # (no store: the collectives of the group itself, as before round 6)
+        if agree is None:  # (no store: the collectives of the group itself, as before round 6 -- never on a communicator a trial hung in)
+            if state["poisoned"] or hung:
+                state["poisoned"] = True
+                return False, dt
             all_ok = _all_ok(ok, device=device, group=group)
             return all_ok, (max_over_ranks(dt, device=device, group=group) if all_ok else dt)
         # 1 = ran, 0 = raised, 2 = hung here (every rank must then stop using the communicator, not only this one)
