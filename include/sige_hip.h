@@ -624,6 +624,13 @@ int sige_hip_conv3x3_small_cin_nhwc_f32(const float *x, int64_t strideB, int64_t
                                         int B, int Cin, int H, int W,
                                         const float *weight, const float *bias, int Cout,
                                         float *out, void *stream);
+/* ... evaluated only on the bH x bW windows at active_indices (clipped), written in place into `out` [B,H,W,Cout]; other pixels of
+ * `out` keep their contents (round 6: in sparse mode the first conv's output is only read through Gather windows). */
+int sige_hip_conv3x3_small_cin_tiles_nhwc_f32(const float *x, int64_t strideB, int64_t strideC, int64_t strideH, int64_t strideW,
+                                              int B, int Cin, int H, int W,
+                                              const float *weight, const float *bias, int Cout,
+                                              const int32_t *active_indices, int N, int bH, int bW,
+                                              float *out, void *stream);
 
 /* per-group mean / rstd of a [B,C,H,W] tensor -> per-channel (scale, shift) with
  * GroupNorm(x) == x*scale + shift  (scale = gamma*rstd, shift = beta - mean*scale):

@@ -23,23 +23,40 @@ typedef float floatx16_in __attribute__((ext_vector_type(16)));
 template <int CIN, int NBK>
 __global__ __launch_bounds__(256) void conv_in_gemm_kernel(const float *__restrict__ x, long sb, long sc, long sh, long sw,
                                                           int B, int H, int W, const float *__restrict__ w,  // [Cout, CIN, 3, 3]
-                                                          const float *__restrict__ bias, float *__restrict__ out, long npix) {
+                                                          const float *__restrict__ bias, float *__restrict__ out, long npix,
+                                                          const int32_t *__restrict__ idx, int N, int bH, int bW) {
     constexpr int K = 9 * CIN, KS = (K + 1) / 2, COUT = 32 * NBK;
     constexpr int KP = 2 * KS + 1;  // odd row pitch of the weight stage: lane j reads row j -> 32 different banks
     __shared__ __attribute__((aligned(16))) float wl[COUT * KP];
     __shared__ __attribute__((aligned(16))) float tile[4][32 * COUT];
+    __shared__ long opix[4][32];  // tile-list form: the output pixel of each row of a wave's block (-1: none)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kq = lane >> 5;
     const long blk = (long)blockIdx.x * 4 + wave;
     const long p = blk * 32 + j;
-    const bool live = p < npix;
+    bool live = p < npix;
 
     // A operand first (the longest dependency chain): lane (kq, j) owns pixel j and the K indices 2s + kq = ci*9 + tap
     float a[KS];
     {
         unsigned okm = 0;
-        const int b = (int)(p / ((long)H * W));
-        const int rem = (int)(p - (long)b * H * W);
-        const int h = rem / W, ww = rem - h * W;
+        int b, h, ww;
+        if (idx) {
+            // tile-list form (round 6): pixel p of the launch = pixel (p % (bH*bW)) of window (p / (bH*bW)) % N of image p / (N*bH*bW);
+            // windows are clipped to the image, overlapping windows recompute the same values
+            const int win = bH * bW;
+            const long t = p / win;
+            const int q = (int)(p - t * win);
+            b = (int)(t / N);
+            const int n = (int)(t - (long)b * N);
+            const int2 o = live ? *reinterpret_cast<const int2 *>(idx + 2 * n) : make_int2(0, 0);
+            h = o.x + q / bW; ww = o.y + q % bW;
+            live = live && h >= 0 && h < H && ww >= 0 && ww < W;
+            if (kq == 0) opix[wave][j] = live ? ((long)b * H + h) * W + ww : -1;
+        } else {
+            b = (int)(p / ((long)H * W));
+            const int rem = (int)(p - (long)b * H * W);
+            h = rem / W; ww = rem - h * W;
+        }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int k = 2 * s + kq;
@@ -82,6 +99,16 @@ __global__ __launch_bounds__(256) void conv_in_gemm_kernel(const float *__restri
 #pragma unroll
         for (int nb = 0; nb < NBK; ++nb) tl[((r & 3) + 8 * (r >> 2) + 4 * kq) * COUT + nb * 32 + j] = acc[nb][r];
     __builtin_amdgcn_wave_barrier();  // (LDS is in order per wave: the tile is this wave's own)
+    if (idx) {
+        // tile-list form: row m of the tile goes to output pixel opix[m] (COUT consecutive floats each)
+#pragma unroll
+        for (int i = 0; i < 32 * COUT / 256; ++i) {
+            const int o = (i * 64 + lane) * 4;
+            const long px = opix[wave][o / COUT];
+            if (px >= 0) store_out4(out + px * COUT + o % COUT, *reinterpret_cast<const float4 *>(tl + o));
+        }
+        return;
+    }
     // the tile is 32 * COUT consecutive floats of the output: 64 lanes x 16 bytes = 1 KB per store instruction
     float *const ob = out + blk * 32 * COUT;
     const long left = (npix - blk * 32) * COUT;  // floats of the output from this block on
@@ -96,25 +123,48 @@ __global__ __launch_bounds__(256) void conv_in_gemm_kernel(const float *__restri
 
 using namespace sige;
 
-extern "C" int sige_hip_conv3x3_small_cin_nhwc_f32(const float *x, int64_t strideB, int64_t strideC, int64_t strideH, int64_t strideW,
-                                                   int B, int Cin, int H, int W,
-                                                   const float *weight, const float *bias, int Cout,
-                                                   float *out, void *stream) {
-    SIGE_PLAN_HOOK(sige_hip_conv3x3_small_cin_nhwc_f32, x, strideB, strideC, strideH, strideW, B, Cin, H, W, weight, bias, Cout, out, stream);
+static int conv3x3_small_cin_impl(const float *x, int64_t strideB, int64_t strideC, int64_t strideH, int64_t strideW,
+                                  int B, int Cin, int H, int W, const float *weight, const float *bias, int Cout,
+                                  const int32_t *active_indices, int N, int bH, int bW, float *out, void *stream) {
     if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return SIGE_HIP_EINVAL;
     if (!x || !weight || !out) return SIGE_HIP_EINVAL;
     if (Cin > 3 || !(Cout == 32 || Cout == 64 || Cout == 128)) return SIGE_HIP_EUNSUPPORTED;
-    const long npix = (long)B * H * W;
-    if (npix * Cout >= (1L << 40)) return SIGE_HIP_EUNSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(out) & 15) return SIGE_HIP_EUNSUPPORTED;
+    const long npix = active_indices ? (long)B * N * bH * bW : (long)B * H * W;
+    if (npix == 0) return SIGE_HIP_OK;
+    if ((long)B * H * W * Cout >= (1L << 40)) return SIGE_HIP_EUNSUPPORTED;
     const long nblk = (npix + 31) / 32, grid = (nblk + 3) / 4;  // one 32-pixel block per wave
     if (grid > 0x7fffffffL) return SIGE_HIP_EUNSUPPORTED;
     hipStream_t st = as_stream(stream);
 #define SIGE_CI(CI, NBK) \
-    conv_in_gemm_kernel<CI, NBK><<<(int)grid, 256, 0, st>>>(x, strideB, strideC, strideH, strideW, B, H, W, weight, bias, out, npix);
+    conv_in_gemm_kernel<CI, NBK><<<(int)grid, 256, 0, st>>>(x, strideB, strideC, strideH, strideW, B, H, W, weight, bias, out, npix, active_indices, N, bH, bW);
 #define SIGE_CI_N(CI)                                                                         \
     if (Cout == 32) { SIGE_CI(CI, 1) } else if (Cout == 64) { SIGE_CI(CI, 2) } else { SIGE_CI(CI, 4) }
     if (Cin == 1) { SIGE_CI_N(1) } else if (Cin == 2) { SIGE_CI_N(2) } else { SIGE_CI_N(3) }
 #undef SIGE_CI_N
 #undef SIGE_CI
     return launch_status();
+}
+
+extern "C" int sige_hip_conv3x3_small_cin_nhwc_f32(const float *x, int64_t strideB, int64_t strideC, int64_t strideH, int64_t strideW,
+                                                   int B, int Cin, int H, int W,
+                                                   const float *weight, const float *bias, int Cout,
+                                                   float *out, void *stream) {
+    SIGE_PLAN_HOOK(sige_hip_conv3x3_small_cin_nhwc_f32, x, strideB, strideC, strideH, strideW, B, Cin, H, W, weight, bias, Cout, out, stream);
+    return conv3x3_small_cin_impl(x, strideB, strideC, strideH, strideW, B, Cin, H, W, weight, bias, Cout, nullptr, 0, 0, 0, out, stream);
+}
+
+// The same conv evaluated ONLY on the bH x bW windows at active_indices (clipped to the image), written into `out` [B,H,W,Cout] in
+// place; every other pixel of `out` is left as it is.  In sparse mode the first conv's output is only ever read through Gather
+// windows (sige_fused_unet.py:395-400: hs[0] feeds down[0].block[0] and, as a skip, the last up block -- both tiled at this
+// resolution with the same index list), so the 94 % of it outside the active windows of a 1.2 % edit is never looked at.
+extern "C" int sige_hip_conv3x3_small_cin_tiles_nhwc_f32(const float *x, int64_t strideB, int64_t strideC, int64_t strideH, int64_t strideW,
+                                                         int B, int Cin, int H, int W,
+                                                         const float *weight, const float *bias, int Cout,
+                                                         const int32_t *active_indices, int N, int bH, int bW,
+                                                         float *out, void *stream) {
+    SIGE_PLAN_HOOK_N(sige_hip_conv3x3_small_cin_tiles_nhwc_f32, (sige::CountOf<12, 13>), x, strideB, strideC, strideH, strideW, B, Cin, H, W, weight, bias, Cout, active_indices, N, bH, bW, out, stream);
+    if (N < 0 || bH <= 0 || bW <= 0 || (N > 0 && !active_indices)) return SIGE_HIP_EINVAL;
+    if (N == 0) return SIGE_HIP_OK;
+    return conv3x3_small_cin_impl(x, strideB, strideC, strideH, strideW, B, Cin, H, W, weight, bias, Cout, active_indices, N, bH, bW, out, stream);
 }

@@ -129,6 +129,8 @@ _SIGNATURES = {
         _c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_int, _c_int] * 2 + [_c_int, _c_vp, _c_vp, _c_int, _c_vp, _c_vp]),
     "sige_hip_conv3x3_small_cin_nhwc_f32": (
         _c_int, [_c_vp] + [ctypes.c_int64] * 4 + [_c_int] * 4 + [_c_vp, _c_vp, _c_int, _c_vp, _c_vp]),
+    "sige_hip_conv3x3_small_cin_tiles_nhwc_f32": (
+        _c_int, [_c_vp] + [ctypes.c_int64] * 4 + [_c_int] * 4 + [_c_vp, _c_vp, _c_int, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
     "sige_hip_attention_nhwc_f32": (_c_int, [_c_vp, _c_int, _c_int, _c_int, ctypes.c_float, _c_vp, _c_vp, _c_vp]),
     "sige_hip_attention_fused_workspace": (_c_sz, [_c_int] * 3),
     "sige_hip_attention_fused_nhwc_f32": (_c_int, [_c_vp, _c_int, _c_int, _c_int, ctypes.c_float, _c_vp, _c_vp, _c_vp]),
@@ -2104,9 +2106,10 @@ def conv3x3_small_cout_force_scalar(on: bool):
     tuning_set("small_cout_scalar", int(bool(on)))
 
 
-def conv3x3_small_cin_cl(x, weight, bias):
+def conv3x3_small_cin_cl(x, weight, bias, tiles=None, out=None):
     """conv(x) + bias for a 3x3 / padding-1 conv with <= 3 input channels and 32 / 64 / 128 output channels
-    over a full image (the U-Net's conv_in); x in any dense layout, result channels-last.  None if unsupported."""
+    over a full image (the U-Net's conv_in); x in any dense layout, result channels-last.  `tiles` = (index list, (bH, bW)):
+    only those windows, written into `out`.  None if unsupported."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
         raise ValueError("x must be a 4-D fp32 GPU tensor")
     bias_keep = _vec(bias, "bias")
@@ -2115,10 +2118,21 @@ def conv3x3_small_cin_cl(x, weight, bias):
     Cout = w.shape[0]
     if tuple(w.shape[1:]) != (C, 3, 3) or C > 3 or Cout not in (32, 64, 128):
         return None
-    out = _empty_cl((B, Cout, H, W), x.device)
     sb, sc, sh, sw = x.stride()
-    status = lib().sige_hip_conv3x3_small_cin_nhwc_f32(x.data_ptr(), sb, sc, sh, sw, B, C, H, W, w.data_ptr(), _p(bias_keep),
-                                                       Cout, out.data_ptr(), _stream(x))
+    if tiles is not None:
+        # (round 6) only the block[0] x block[1] windows at the index list are evaluated, in place in `out` (a persistent buffer the
+        # caller owns: every other pixel keeps whatever it held -- nobody reads it: sige_hip_conv3x3_small_cin_tiles_nhwc_f32)
+        idx, block = tiles
+        idx = _req(idx, torch.int32, "activeIndices", 2)
+        if out is None or tuple(out.shape) != (B, Cout, H, W) or not out.is_contiguous(memory_format=CL) or out.dtype != torch.float32:
+            raise RuntimeError("conv3x3_small_cin_cl: the tile-list form writes into a channels-last fp32 [B,Cout,H,W] buffer")
+        status = lib().sige_hip_conv3x3_small_cin_tiles_nhwc_f32(x.data_ptr(), sb, sc, sh, sw, B, C, H, W, w.data_ptr(), _p(bias_keep),
+                                                                 Cout, idx.data_ptr(), idx.shape[0], block[0], block[1], out.data_ptr(),
+                                                                 _stream(x))
+    else:
+        out = _empty_cl((B, Cout, H, W), x.device)
+        status = lib().sige_hip_conv3x3_small_cin_nhwc_f32(x.data_ptr(), sb, sc, sh, sw, B, C, H, W, w.data_ptr(), _p(bias_keep),
+                                                           Cout, out.data_ptr(), _stream(x))
     if status == UNSUPPORTED:
         return None
     _check(status, "conv3x3_small_cin_cl")

@@ -296,19 +296,25 @@ def _fused_conv2d(conv, x, scale, shift, activation_name, x2, residual, pad_bott
     return h if out_affine is None else (h, out_affine)
 
 
-def input_conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
+def input_conv2d(conv: nn.Conv2d, x: torch.Tensor, tiles=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """`conv(x)` for the network's first layer (3x3 / padding 1, <= 3 input channels, e.g. DDPM's conv_in,
     sige_fused_unet.py:395).  On a channels-last GPU image: one thin-GEMM launch writing the channels-last
-    result directly (libsige_hip.so); anything else is the plain `conv(x)`."""
+    result directly (libsige_hip.so); anything else is the plain `conv(x)`.
+    `tiles` = (index list, block) with `out` a persistent channels-last buffer: the conv is evaluated only on those windows, in
+    place (a sparse pass reads the first conv's output through Gather windows only); ignored where the launch does not apply."""
     if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] <= 3 and conv.groups == 1
             and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1)
             and tuple(conv.dilation) == (1, 1) and conv.padding_mode == "zeros"
             and x.is_contiguous(memory_format=torch.channels_last) and (x.shape[1] == 1 or not x.is_contiguous())):
         from .. import hip
 
-        out = hip.conv3x3_small_cin_cl(x, _plain_weight(conv), conv.bias)
-        if out is not None:
-            return out
+        if tiles is not None and out is not None:
+            r = hip.conv3x3_small_cin_cl(x, _plain_weight(conv), conv.bias, tiles=tiles, out=out)
+            if r is not None:
+                return r
+        r = hip.conv3x3_small_cin_cl(x, _plain_weight(conv), conv.bias)
+        if r is not None:
+            return r
     return conv(x)
 
 

@@ -272,3 +272,66 @@ def test_tile_conv3_scatter_gather_with_cached_affine(hip, compute):
                 torch.testing.assert_close(got, want, rtol=0, atol=3e-4)
             else:  # (swish_fast vs the standalone kernel's swish: a staged value may round to the neighbouring half)
                 assert float((got - want).abs().mean()) < 5e-5 and float((got - want).abs().max()) < 5e-3
+
+
+# ---- the first conv on the active windows only (sige_hip_conv3x3_small_cin_tiles_nhwc_f32) --------------------------------------------
+def test_conv_in_on_the_active_windows_only(hip):
+    """The tile-list form of the first conv: inside every 6 x 6 window of the index list (border windows clipped) bit for bit the
+    dense launch's values, outside them the buffer untouched."""
+    torch.manual_seed(2)
+    B, res, cout = 2, 64, 128
+    idx, _ = _masks(res)
+    x = _cl(torch.randn(B, 3, res, res, device=DEV))
+    w, b = torch.randn(cout, 3, 3, 3, device=DEV) / 5, torch.randn(cout, device=DEV)
+    dense = hip.conv3x3_small_cin_cl(x, w, b)
+    torch.testing.assert_close(dense, F.conv2d(x, w, b, 1, 1), rtol=0, atol=2e-5)
+    buf = _cl(torch.full((B, cout, res, res), 7.0, device=DEV))
+    n0 = hip.launch_count()
+    got = hip.conv3x3_small_cin_cl(x, w, b, tiles=(idx, (6, 6)), out=buf)
+    assert got is buf and hip.launch_count() == n0 + 1
+    cover = torch.zeros(res, res, dtype=torch.bool)
+    for h0, w0 in idx.cpu().tolist():
+        cover[max(h0, 0):h0 + 6, max(w0, 0):w0 + 6] = True
+    assert cover.any() and not cover.all()
+    assert torch.equal(buf[:, :, cover], dense[:, :, cover])
+    assert bool((buf[:, :, ~cover] == 7.0).all())
+
+
+@pytest.mark.selfcheck
+def test_ddpm_forward_sparse_conv_in_on_off(hip):
+    """The benchmark network with conv_in evaluated on the active windows only and with the dense conv_in the reference runs
+    (sige_fused_unet.py:395): the SAME output bit for bit -- a sparse pass reads hs[0] through Gather windows only -- and both within
+    the north_star tolerance of the CPU oracle; also after a mask change (the buffer then holds stale values outside the new
+    windows: unread)."""
+    import bench
+    from sige_amd.utils import dilate_mask, downsample_mask
+    from sige_amd.workloads.ddpm_unet import DDPMConfig, DDPMSparseUNet
+
+    torch.manual_seed(0)
+    model = DDPMSparseUNet(DDPMConfig()).eval().to(DEV).to(memory_format=torch.channels_last)
+    model.set_scatter_inplace(True)
+    x0, noise = bench.make_inputs()
+    t = torch.zeros(1, device=DEV)
+    ratios = (0.15, 0.012)
+    _, wants = util.ddpm_cpu_oracle([bench.edit_mask(r) for r in ratios])
+    try:
+        with util.native_full_pass(), torch.no_grad():
+            model.set_mode("full")
+            model(_cl(x0.to(DEV)), t)
+            for ratio, want in zip(ratios, wants):
+                mask = bench.edit_mask(ratio)
+                x1 = _cl((x0 + noise * mask).to(DEV))
+                model.set_masks(downsample_mask(dilate_mask(mask.to(DEV), 5), 8))
+                model.set_mode("sparse")
+                outs = {}
+                for on in (True, False):
+                    model.SPARSE_CONV_IN = on
+                    for _ in range(3):
+                        model(x1, t)
+                    outs[on] = model(x1, t).clone()
+                assert getattr(model, "_h0_buf", None) is not None  # (the tile-list form DID run: no silent dense fallback)
+                assert torch.equal(outs[True], outs[False]), float((outs[True] - outs[False]).abs().max())
+                err = util.record_margin("sparse_conv_in", "ratio %g vs cpu oracle" % ratio, (outs[True].cpu() - want).abs().max(), util.CONV_ATOL)
+                assert err <= util.CONV_ATOL, (ratio, err)
+    finally:
+        model.SPARSE_CONV_IN = True
