@@ -16,8 +16,11 @@
 //   P = exp(S - m) goes through a wave-private 16 x 16 LDS tile (C layout -> A layout); O += P V with V[key 4t + kq][16n + j]
 //   straight from global memory (16 lanes = 64 contiguous bytes of a key's row).  Row maxima / sums over the 16 lanes of a
 //   score row on the DPP path (common.hpp row16_max / row16_sum), not through LDS shuffles.
-//   Measured at SD's shapes (1008 queries x 4096 keys x 8 heads x 40, batch 2: 10.6 GFLOP): 224 us = 47 TFLOP/s (0.30 of the
-//   fp32 MFMA peak; d = 40 fills 40 / 48 of the padded tiles).  Variants measured and not kept (profiles/r4h_bench_sd.json,
+//   Measured at SD's shapes (1008 queries x 4096 keys x 8 heads x 40, batch 2: 10.6 GFLOP): rounds 4-5 217 us = 49 TFLOP/s; round 6
+//   189 us = 56 TFLOP/s (0.36 of the fp32 MFMA peak; d = 40 fills 40 / 48 of the padded tiles), 160 x 1024 x 8 x 80: 38.3 -> 25.6 us
+//   (tools/attention_tokens_bench.py, profiles/r6x_attention_tokens.jsonl): the K / V operands as branch-free buffer loads issued
+//   one key block ahead (they were 15 loads behind exec-masked branches, waited for at once: -9 % / -12 % without the look-ahead,
+//   another -5 % / -24 % with it), the (batch, head) pairs dealt to the XCDs (-1 %).  Variants measured and not kept (profiles/r4h_bench_sd.json,
 //   r4i_bench_sd.json): 64 queries per workgroup with the K / V blocks staged through LDS (4x fewer L2 reads, but one wave per
 //   SIMD: 1.5x slower); two query tiles per wave sharing each K / V fragment (template parameter QT: equal); LDS shuffles
 //   instead of DPP (equal) -- the kernel is bound by the dependent chain scores -> softmax -> P through LDS -> values of a
@@ -32,9 +35,11 @@ namespace sige {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int UNITS, int QT>  // 16-channel units covering the head dimension (d <= 16 * UNITS); 16-query tiles per workgroup
-__global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__restrict__ q, const float *__restrict__ k,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UNITS * QT <= 3 ? 4 : 1)))  // (SD's d = 40: 1 008 workgroups on 1 024 slots)
+void attention_tokens_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                                const float *__restrict__ v, float *__restrict__ out,
-                                                               int Nq, int Nk, int C, int heads, int d, float scale_log2e) {
+                                                               int Nq, int Nk, int C, int heads, int d, float scale_log2e,
+                                                               int q_tiles, int xcd_pairs) {
     constexpr int DT = UNITS;            // 16-column tiles of O
     constexpr int OS = UNITS * 16 + 4;   // padded row of the merge buffer
     constexpr int QR = 16 * QT;          // query rows of the workgroup
@@ -44,8 +49,21 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kq = lane >> 4, j = lane & 15;
-    const int head = blockIdx.y % heads, b = blockIdx.y / heads;
-    const int q0 = blockIdx.x * QR;
+    // workgroup -> (batch * head pair, query tile).  The hardware deals consecutive workgroup ids round-robin to the 8 XCDs, each with
+    // its own 4 MB L2: with `xcd_pairs` > 0 (the host sets it when B * heads is a multiple of 8) the pairs are dealt to the XCDs --
+    // pair = xcd * xcd_pairs + ... -- so that one L2 holds the K / V of ITS pairs (SD, 64 x 64 latent: 2 x 1.3 MB) instead of every
+    // L2 streaming all of them (16 x 1.3 MB: each key block re-read from the Infinity Cache by every XCD)
+    int pair, qtile;
+    if (xcd_pairs > 0) {
+        const int id = blockIdx.x, xcd = id & 7, local = id >> 3;
+        pair = xcd * xcd_pairs + local / q_tiles;
+        qtile = local - (local / q_tiles) * q_tiles;
+    } else {
+        pair = blockIdx.x / q_tiles;
+        qtile = blockIdx.x - pair * q_tiles;
+    }
+    const int head = pair % heads, b = pair / heads;
+    const int q0 = qtile * QR;
     const size_t hoff = (size_t)head * d;
     const float *kb = k + (size_t)b * Nk * C + hoff;
     const float *vb = v + (size_t)b * Nk * C + hoff;
@@ -76,29 +94,49 @@ __global__ __launch_bounds__(256) void attention_tokens_kernel(const float *__re
     }
 
     const int nkb = (Nk + 15) / 16;
-    for (int kblk = wave; kblk < nkb; kblk += 4) {
+    // K and V of a key block: loaded ONCE, used by every query tile of the workgroup -- and one block AHEAD (the operands of block
+    // kblk + 4 are requested before block kblk is computed on: a block's 15 loads come from another XCD's half of the Infinity Cache
+    // as often as not, 1 - 2 us away, and nothing else of this wave can run under them: its next step needs exactly these values)
+    // Branch-free buffer loads, one 32-bit offset register per key row: a lane whose channels lie past d (the padding of the last
+    // unit) reads the next head's channels -- or, past the end of this batch's [Nk, C] matrix, the zeros a buffer load returns out of
+    // range --, a lane whose key lies past Nk (the tail block) the last key's; what it reads meets a ZERO on the other side of the
+    // product (Q is zero on padded channels, P is zero on masked keys) or lands in a padded column of O that is never stored
+    const unsigned kv_bytes = (unsigned)(((size_t)Nk * C - hoff) * sizeof(float));
+    const __amdgpu_buffer_rsrc_t r_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(kb), 0, kv_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(vb), 0, kv_bytes, 0x00020000);
+    const int row_bytes = C * (int)sizeof(float);
+    float4 kn[UNITS];
+    float vn[4][DT];
+    auto fetch = [&](int kblk) {
         const int key0 = kblk * 16;
-        const int key = min(key0 + j, Nk - 1);  // (tail: a valid address; the column is masked below)
-        // K and V of this block: loaded ONCE, used by every query tile of the workgroup.  The V operands do not depend on the
-        // scores: in flight under the score MFMAs and the softmax
-        float4 kr[UNITS];
+        const int ko = min(key0 + j, Nk - 1) * row_bytes + 16 * kq;
 #pragma unroll
-        for (int u = 0; u < UNITS; ++u) {
-            const int c = 16 * u + 4 * kq;
-            kr[u] = c < d ? *reinterpret_cast<const float4 *>(kb + (size_t)key * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        float vr[4][DT];
+        for (int u = 0; u < UNITS; ++u)
+            kn[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_k, ko + 64 * u, 0, 0));
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int vk = key0 + 4 * t + kq;
-            const bool ok = vk < Nk;
-            const float *vp = vb + (size_t)(ok ? vk : Nk - 1) * C;
+            const int vo = min(key0 + 4 * t + kq, Nk - 1) * row_bytes + 4 * j;
 #pragma unroll
-            for (int n = 0; n < DT; ++n) {
-                const int c = 16 * n + j;
-                vr[t][n] = (ok && c < d) ? vp[c] : 0.f;
-            }
+            for (int n = 0; n < DT; ++n) vn[t][n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_v, vo + 64 * n, 0, 0));
         }
+    };
+    if (wave < nkb) fetch(wave);
+    for (int kblk = wave; kblk < nkb; kblk += 4) {
+        const int key0 = kblk * 16;
+        float4 kr[UNITS];
+        float vr[4][DT];
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) kr[u] = kn[u];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int n = 0; n < DT; ++n) vr[t][n] = vn[t][n];
+        }
+#ifndef SIGE_ATTENTION_NO_PREFETCH
+        fetch(min(kblk + 4, nkb - 1));  // (past the end: the last block again -- a valid address, never used)
+#else
+        if (kblk + 4 < nkb) { __builtin_amdgcn_s_waitcnt(0); fetch(kblk + 4); __builtin_amdgcn_s_waitcnt(0); }
+#endif
         const bool live = key0 + j < Nk;
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
@@ -195,7 +233,7 @@ extern "C" int sige_hip_attention_tokens_f32(const float *q, const float *k, con
     if (!q || !k || !v || !out) return SIGE_HIP_EINVAL;
     if (!sige_hip_attention_tokens_supported(Nq, Nk, C, heads)) return SIGE_HIP_EUNSUPPORTED;
     auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    if (!al(q) || !al(k) || !al(v) || !al(out) || (long)B * heads > 65535) return SIGE_HIP_EUNSUPPORTED;
+    if (!al(q) || !al(k) || !al(v) || !al(out) || (size_t)Nk * C * sizeof(float) >= 0x7fffffffu) return SIGE_HIP_EUNSUPPORTED;
     const int d = C / heads;
     const int units = (d + 15) / 16;
     const float sl = scale * 1.44269504088896341f;
@@ -204,11 +242,17 @@ extern "C" int sige_hip_attention_tokens_f32(const float *q, const float *k, con
     // fragment a wave loads: half the loads per MFMA; d <= 96) -- measured equal at SD's shapes (profiles/r4i_bench_sd.json:
     // 11.46 vs 11.47 ms per forward), so the kernel is not load-bound there and the simpler form is the default.
     const int form = (tuning(SIGE_HIP_TUNE_ATTENTION_FORM) == 2 && units <= 6) ? 2 : 1;
-    const dim3 grid16(Nq / 16, B * heads), grid32((Nq + 31) / 32, B * heads);
+    const int pairs = B * heads, t16 = Nq / 16, t32 = (Nq + 31) / 32;
+    if ((long)pairs * t16 > 0x7fffffffL) return SIGE_HIP_EUNSUPPORTED;
+#ifdef SIGE_ATTENTION_PLAIN_ORDER
+    const int xp = 0;
+#else
+    const int xp = pairs % 8 == 0 ? pairs / 8 : 0;
+#endif
 #define SIGE_ATT_GO(U)                                                                                             \
     do {                                                                                                           \
-        if (form == 2) attention_tokens_kernel<(U <= 6 ? U : 1), 2><<<grid32, 256, (size_t)4 * 32 * (U * 16 + 4) * sizeof(float), st>>>(q, k, v, out, Nq, Nk, C, heads, d, sl); \
-        else attention_tokens_kernel<U, 1><<<grid16, 256, (size_t)4 * 16 * (U * 16 + 4) * sizeof(float), st>>>(q, k, v, out, Nq, Nk, C, heads, d, sl); \
+        if (form == 2) attention_tokens_kernel<(U <= 6 ? U : 1), 2><<<dim3(t32 * pairs), 256, (size_t)4 * 32 * (U * 16 + 4) * sizeof(float), st>>>(q, k, v, out, Nq, Nk, C, heads, d, sl, t32, xp); \
+        else attention_tokens_kernel<U, 1><<<dim3(t16 * pairs), 256, (size_t)4 * 16 * (U * 16 + 4) * sizeof(float), st>>>(q, k, v, out, Nq, Nk, C, heads, d, sl, t16, xp); \
     } while (0)
     switch (units) {
         case 1: SIGE_ATT_GO(1); break;
