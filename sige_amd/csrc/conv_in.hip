@@ -31,11 +31,22 @@ __global__ __launch_bounds__(256) void conv_in_gemm_kernel(const float *__restri
     __shared__ __attribute__((aligned(16))) float tile[4][32 * COUT];
     __shared__ long opix[4][32];  // tile-list form: the output pixel of each row of a wave's block (-1: none)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kq = lane >> 5;
-    const long blk = (long)blockIdx.x * 4 + wave;
-    const long p = blk * 32 + j;
-    bool live = p < npix;
+    // (32-bit index arithmetic throughout: the host refuses a launch whose pixel count or largest input offset does not fit -- a
+    //  64-bit division by a run-time value is a branchy ~130-instruction routine, and there were three of them in front of the
+    //  first load)
+    const int blk = (int)blockIdx.x * 4 + wave;
+    const int p = blk * 32 + j;
+    bool live = p < (int)npix;
 
-    // A operand first (the longest dependency chain): lane (kq, j) owns pixel j and the K indices 2s + kq = ci*9 + tap
+    // the weights: every lane's share requested NOW, written to LDS after the A operand's loads are out as well (the rolled
+    // `for (i = tid; ...) wl[..] = w[i]` was 14 dependent load -> wait -> ds_write round trips in front of the barrier: 12 of the
+    // kernel's 14 us inside the forward, where each trip goes to a cold L2)
+    constexpr int WN = COUT * K, WIT = (WN + 255) / 256;
+    float wv[WIT];
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) wv[it] = w[min(tid + 256 * it, WN - 1)];
+
+    // A operand: lane (kq, j) owns pixel j and the K indices 2s + kq = ci*9 + tap
     float a[KS];
     {
         unsigned okm = 0;
@@ -43,44 +54,53 @@ __global__ __launch_bounds__(256) void conv_in_gemm_kernel(const float *__restri
         if (idx) {
             // tile-list form (round 6): pixel p of the launch = pixel (p % (bH*bW)) of window (p / (bH*bW)) % N of image p / (N*bH*bW);
             // windows are clipped to the image, overlapping windows recompute the same values
-            const int win = bH * bW;
-            const long t = p / win;
-            const int q = (int)(p - t * win);
-            b = (int)(t / N);
-            const int n = (int)(t - (long)b * N);
-            const int2 o = live ? *reinterpret_cast<const int2 *>(idx + 2 * n) : make_int2(0, 0);
-            h = o.x + q / bW; ww = o.y + q % bW;
+            const unsigned win = (unsigned)(bH * bW);
+            const unsigned t = (unsigned)p / win;
+            const int q = (int)((unsigned)p - t * win);
+            b = (int)(t / (unsigned)N);
+            const int n = (int)(t - (unsigned)b * (unsigned)N);
+            const int2 o = *reinterpret_cast<const int2 *>(idx + 2 * (live ? n : 0));
+            const int qh = (int)((unsigned)q / (unsigned)bW);
+            h = o.x + qh; ww = o.y + (q - qh * bW);
             live = live && h >= 0 && h < H && ww >= 0 && ww < W;
             if (kq == 0) opix[wave][j] = live ? ((long)b * H + h) * W + ww : -1;
         } else {
-            b = (int)(p / ((long)H * W));
-            const int rem = (int)(p - (long)b * H * W);
-            h = rem / W; ww = rem - h * W;
+            const unsigned hw = (unsigned)(H * W);
+            b = (int)((unsigned)p / hw);
+            const int rem = (int)((unsigned)p - (unsigned)b * hw);
+            h = (int)((unsigned)rem / (unsigned)W); ww = rem - h * W;
         }
+        const int isb = (int)sb, isc = (int)sc, ish = (int)sh, isw = (int)sw;
+        const int base = b * isb + h * ish + ww * isw;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const int k = 2 * s + kq;
-            const int ci = kq ? (2 * s + 1) / 9 : (2 * s) / 9;
+            // (the two candidates of a lane -- K index 2s or 2s + 1 -- are wave-uniform offsets: scalar arithmetic, one select)
+            const int k0 = 2 * s, k1 = min(2 * s + 1, K - 1);
+            const int off0 = (k0 / 9) * isc + ((k0 % 9) / 3 - 1) * ish + ((k0 % 9) % 3 - 1) * isw;
+            const int off1 = (k1 / 9) * isc + ((k1 % 9) / 3 - 1) * ish + ((k1 % 9) % 3 - 1) * isw;
             const int tap = kq ? (2 * s + 1) % 9 : (2 * s) % 9;
             const int ih = h + tap / 3 - 1, iw = ww + tap % 3 - 1;
-            const bool ok = live && k < K && ih >= 0 && ih < H && iw >= 0 && iw < W;
+            const bool ok = live && 2 * s + kq < K && ih >= 0 && ih < H && iw >= 0 && iw < W;
             okm |= ok ? (1u << s) : 0u;
-            // (branch-free: a conditional load compiles to an exec-masked branch per element with s_waitcnt vmcnt(0) between groups --
-            //  five dependent round trips in front of the first matrix instruction, measured in the ISA of the round-5 kernel.  Here
-            //  every lane loads a valid address -- element 0 when the tap is padding -- and the select follows, all 14 loads in flight)
-            a[s] = x[ok ? b * sb + ci * sc + ih * sh + iw * sw : 0];
+            // (branch-free: a conditional load compiles to an exec-masked branch per element with s_waitcnt vmcnt(0) between groups.
+            //  Here every lane loads a valid address -- element 0 when the tap is padding -- and the select follows, all loads in flight)
+            a[s] = x[ok ? base + (kq ? off1 : off0) : 0];
         }
 #pragma unroll
         for (int s = 0; s < KS; ++s) a[s] = (okm >> s) & 1u ? a[s] : 0.f;
     }
-    for (int i = tid; i < COUT * K; i += 256) wl[(i / K) * KP + i % K] = w[i];
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+        const int i = min(tid + 256 * it, WN - 1);  // (past the end: the last element again, the same value to the same place)
+        wl[(i / K) * KP + i % K] = wv[it];
+    }
     if (K < 2 * KS)
         for (int n = tid; n < COUT; n += 256) wl[n * KP + K] = 0.f;  // (K odd: the padded k index)
     float biasr[NBK];
 #pragma unroll
     for (int nb = 0; nb < NBK; ++nb) biasr[nb] = bias ? bias[nb * 32 + j] : 0.f;
     __syncthreads();
-    if (blk * 32 >= npix) return;  // (wave-uniform; after the only barrier)
+    if ((long)blk * 32 >= npix) return;  // (wave-uniform; after the only barrier)
 
     floatx16_in acc[NBK];
 #pragma unroll
@@ -110,8 +130,8 @@ __global__ __launch_bounds__(256) void conv_in_gemm_kernel(const float *__restri
         return;
     }
     // the tile is 32 * COUT consecutive floats of the output: 64 lanes x 16 bytes = 1 KB per store instruction
-    float *const ob = out + blk * 32 * COUT;
-    const long left = (npix - blk * 32) * COUT;  // floats of the output from this block on
+    float *const ob = out + (long)blk * 32 * COUT;
+    const long left = (npix - (long)blk * 32) * COUT;  // floats of the output from this block on
 #pragma unroll
     for (int i = 0; i < 32 * COUT / 256; ++i) {
         const int o = (i * 64 + lane) * 4;
@@ -134,7 +154,11 @@ static int conv3x3_small_cin_impl(const float *x, int64_t strideB, int64_t strid
     if (npix == 0) return SIGE_HIP_OK;
     if ((long)B * H * W * Cout >= (1L << 40)) return SIGE_HIP_EUNSUPPORTED;
     const long nblk = (npix + 31) / 32, grid = (nblk + 3) / 4;  // one 32-pixel block per wave
-    if (grid > 0x7fffffffL) return SIGE_HIP_EUNSUPPORTED;
+    // (the kernel's index arithmetic is 32-bit: pixel count -- padded to whole workgroups -- and the largest input element offset)
+    auto mag = [](int64_t v) { return v < 0 ? -v : v; };
+    const int64_t reach = (int64_t)(B - 1) * mag(strideB) + (int64_t)(Cin - 1) * mag(strideC) + (int64_t)H * mag(strideH) + (int64_t)W * mag(strideW);
+    if (grid * 128 > 0x7fffffffL || reach > 0x7fffffffL || (long)H * W > 0x7fffffffL || (active_indices && (long)N * bH * bW > 0x7fffffffL))
+        return SIGE_HIP_EUNSUPPORTED;
     hipStream_t st = as_stream(stream);
 #define SIGE_CI(CI, NBK) \
     conv_in_gemm_kernel<CI, NBK><<<(int)grid, 256, 0, st>>>(x, strideB, strideC, strideH, strideW, B, H, W, weight, bias, out, npix, active_indices, N, bH, bW);

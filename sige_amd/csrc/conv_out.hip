@@ -154,10 +154,13 @@ __global__ __launch_bounds__(256) void conv_out_gemm_kernel(const float *__restr
     // B operand: column j = tap*COUT + co of the channels of this lane's half
     float breg[KS];
     {
-        const int co = j % COUT, tap = j / COUT;
+        // (columns j >= NP are never written to P: they read column NP - 1's weights instead of taking an exec-masked branch
+        //  around each of the KS loads)
+        const int jc = min(j, NP - 1);
+        const int co = jc % COUT, tap = jc / COUT;
         const float *wp = w + ((size_t)co * CIN + kq * KS) * 9 + tap;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) breg[s] = j < NP ? wp[s * 9] : 0.f;
+        for (int s = 0; s < KS; ++s) breg[s] = wp[s * 9];
     }
     for (int c = tid; c < CIN; c += 256) {
         s_sc[c] = scale ? scale[b * aff_sb + c] : 1.f;

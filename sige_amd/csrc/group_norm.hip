@@ -115,12 +115,17 @@ __global__ __launch_bounds__(kGNThreads) void gn_partial_nhwc_kernel(const float
         float4 v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int p = p0 + u * ppb;
-            v[u] = p < hi ? *reinterpret_cast<const float4 *>(xb + (size_t)p * C + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p < hi) { v[u].x += cb.x; v[u].y += cb.y; v[u].z += cb.z; v[u].w += cb.w; }
+            // (branch-free: `p < hi ? load : 0` compiled to an exec-masked branch around every load with s_waitcnt vmcnt(0) inside it --
+            //  16 DEPENDENT round trips per lane, not 16 loads in flight.  A slot past the slice reads the slice's last pixel and
+            //  is zeroed by the select below)
+            const int p = min(p0 + u * ppb, hi - 1);
+            v[u] = *reinterpret_cast<const float4 *>(xb + (size_t)p * C + cq * 4);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            const bool ok = p0 + u * ppb < hi;
+            v[u].x = ok ? v[u].x + cb.x : 0.f; v[u].y = ok ? v[u].y + cb.y : 0.f;
+            v[u].z = ok ? v[u].z + cb.z : 0.f; v[u].w = ok ? v[u].w + cb.w : 0.f;
             s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
             ss += (v[u].x * v[u].x + v[u].y * v[u].y) + (v[u].z * v[u].z + v[u].w * v[u].w);
         }
