@@ -592,7 +592,7 @@ def test_attention_one_launch_under_a_graph(hip, monkeypatch):
 
 
 # ---- Stable Diffusion: the attention core and the token linears on the library -----------------------------
-@pytest.mark.parametrize("form", [1, 2])
+@pytest.mark.parametrize("form", [0, 1, 2])  # (0 = the default: round 6's transposed-score kernel)
 @pytest.mark.parametrize("B,Nq,Nk,heads,d", [(2, 1008, 4096, 8, 40), (2, 160, 1024, 8, 80), (2, 48, 256, 8, 160), (2, 1008, 77, 8, 40),
                                              (1, 16, 5, 1, 64), (3, 32, 16, 2, 8), (1, 64, 100, 4, 96), (1, 80, 33, 2, 20)])
 def test_attention_tokens_vs_fp64(hip, B, Nq, Nk, heads, d, form, tuning):

@@ -23,16 +23,28 @@ SHAPES = [("self_64", 2, 1008, 4096, 320, 8), ("self_32", 2, 160, 1024, 640, 8),
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", default="")
+    ap.add_argument("--eager", type=int, default=0, help="N eager launches per shape and nothing else (for rocprofv3 --pmc)")
+    ap.add_argument("--only", default="", help="comma-separated shape names")
+    ap.add_argument("--form", type=int, default=None, help="attention_form knob (needs SIGE_HIP_LIB=.../libsige_hip_tuning.so)")
     args = ap.parse_args()
     import bench
     from sige_amd import hip
 
     dev = torch.device("cuda", 0)
+    if args.form is not None:
+        hip.tuning_set("attention_form", args.form)
     torch.manual_seed(0)
     rows = []
     for name, B, Nq, Nk, C, heads in SHAPES:
         q, k, v = (torch.randn(B, n, C, device=dev) for n in (Nq, Nk, Nk))
         scale = (C // heads) ** -0.5
+        if args.only and name not in args.only.split(","):
+            continue
+        if args.eager:
+            for _ in range(args.eager):
+                hip.attention_tokens(q, k, v, heads, scale)
+            torch.cuda.synchronize()
+            continue
         g, out = bench.capture_fn(lambda: [hip.attention_tokens(q, k, v, heads, scale) for _ in range(8)][-1], warm=2)
         for _ in range(3):
             g.replay()
