@@ -134,6 +134,20 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// Grid-stride loop over `units` work items of a T-thread workgroup, with the item index a 32-bit unsigned whenever the count allows:
+// the kernels that use it split the index by run-time divisors (channel quads, pixels of a tile, tiles of an image), and a 64-bit
+// division by a run-time value is a branchy ~130-instruction routine -- four of them were most of the instructions of a scatter
+// launch (round 6).  `body(u)`: `return` where a loop body would `continue`.
+template <int T, typename F>
+__device__ __forceinline__ void for_units(long units, F &&body) {
+    if (units <= 0x7fffffffL) {
+        const unsigned n = (unsigned)units, step = gridDim.x * T;
+        for (unsigned u = blockIdx.x * T + threadIdx.x; u < n; u += step) body(u);
+    } else {
+        for (long u = (long)blockIdx.x * T + threadIdx.x; u < units; u += (long)gridDim.x * T) body(u);
+    }
+}
+
 // 16-byte store of a kernel's OUTPUT (an epilogue's result that only later launches read).  Write-through (`sc1`): the bytes go to
 // the memory side while the kernel still runs instead of staying dirty in the XCD's write-back L2 until the end-of-kernel release
 // writes them back.  Measured (tools/probe/store_probe.hip, profiles/r6_store_probe.json: dependent launches each writing B bytes,

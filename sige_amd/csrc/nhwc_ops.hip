@@ -53,9 +53,9 @@ __global__ __launch_bounds__(kT) void gather_nhwc_kernel(const XT *__restrict__ 
                                                         const float *scale, const float *shift, int aff_sb,
                                                         float *__restrict__ out, long units, int hp_shift) {
     const int C4 = C / 4, RS = bH * bW;
-    for (long u = (long)blockIdx.x * kT + threadIdx.x; u < units; u += (long)gridDim.x * kT) {
+    for_units<kT>(units, [&](auto u) {
         const int c = (int)(u % C4) * 4;
-        const long tp = u / C4;
+        const decltype(u) tp = u / C4;
         const int p = (int)(tp % RS);
         const int t = (int)(tp / RS);
         const int b = t / N, n = t - b * N;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kT) void gather_nhwc_kernel(const XT *__restrict__ 
         if (h >= hlo && h < hhi && w >= 0 && w < W)
             z = affine_act4<ACT>(ld4(x + (((size_t)b * H + h) * W + w) * C + c), scale, shift, b * aff_sb, c);
         st4_out(out + (size_t)u * 4, z);
-    }
+    });
 }
 
 // ---------------------------------------------------------- scatter_gather ----
@@ -79,9 +79,9 @@ __global__ __launch_bounds__(kT) void scatter_gather_nhwc_kernel(const float *__
                                                                 const float *scale, const float *shift, int aff_sb,
                                                                 float *__restrict__ out, long units, int hp_shift) {
     const int C4 = C / 4, RS = bH * bW;
-    for (long u = (long)blockIdx.x * kT + threadIdx.x; u < units; u += (long)gridDim.x * kT) {
+    for_units<kT>(units, [&](auto u) {
         const int c = (int)(u % C4) * 4;
-        const long tp = u / C4;
+        const decltype(u) tp = u / C4;
         const int p = (int)(tp % RS);
         const int t = (int)(tp / RS);
         const int b = t / N, n = t - b * N;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kT) void scatter_gather_nhwc_kernel(const float *__
             z = affine_act4<ACT>(v, scale, shift, b * aff_sb, c);
         }
         st4_out(out + (size_t)u * 4, z);
-    }
+    });
 }
 
 // ---------------------------------------------------------- SPADE modulation ----
@@ -128,9 +128,9 @@ struct SpadeArgs {
 
 __global__ __launch_bounds__(kT) void spade_modulate_nhwc_kernel(SpadeArgs a, long units) {
     const int C4 = a.C / 4, RS = a.bH * a.bW, C2 = 2 * a.C;
-    for (long u = (long)blockIdx.x * kT + threadIdx.x; u < units; u += (long)gridDim.x * kT) {
+    for_units<kT>(units, [&](auto u) {
         const int c = (int)(u % C4) * 4;
-        const long tp = u / C4;
+        const decltype(u) tp = u / C4;
         const int p = (int)(tp % RS);
         const int t = (int)(tp / RS);
         const int b = t / a.N, n = t - b * a.N;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kT) void spade_modulate_nhwc_kernel(SpadeArgs a, lo
             }
         }
         st4_out(a.out + (size_t)u * 4, z);
-    }
+    });
 }
 
 // ------------------------------------------------------------------ scatter ----
@@ -205,16 +205,16 @@ __device__ __forceinline__ float4 scatter_value(const ScatterNhwcArgsT<CT> &a, i
 template <bool BLOCK_RES, typename CT = float>
 __global__ __launch_bounds__(kT) void scatter_full_nhwc_kernel(ScatterNhwcArgsT<CT> a, long units) {
     const int C4 = a.C / 4;
-    for (long u = (long)blockIdx.x * kT + threadIdx.x; u < units; u += (long)gridDim.x * kT) {
+    for_units<kT>(units, [&](auto u) {
         const int c = (int)(u % C4) * 4;
-        const long pix = u / C4;
+        const decltype(u) pix = u / C4;
         const int w = (int)(pix % a.W);
-        const long bh = pix / a.W;
+        const decltype(u) bh = pix / a.W;
         const int h = (int)(bh % a.H), b = (int)(bh / a.H);
         const int t0 = a.table0[(h / a.R0) * a.gW0 + w / a.S0];
         const int t1 = BLOCK_RES ? a.table1[(h / a.R1) * a.gW1 + w / a.S1] : -1;
         st4_out(a.out + (size_t)u * 4, scatter_value<BLOCK_RES, CT>(a, b, h, w, c, t0, t1, (size_t)u * 4));
-    }
+    });
 }
 
 // in-place form: `out` already holds y0 outside the covered pixels (a persistent buffer of the
@@ -223,25 +223,25 @@ __global__ __launch_bounds__(kT) void scatter_full_nhwc_kernel(ScatterNhwcArgsT<
 template <bool BLOCK_RES, typename CT = float>
 __global__ __launch_bounds__(kT) void scatter_tiles_nhwc_kernel(ScatterNhwcArgsT<CT> a, long units0, long units) {
     const int C4 = a.C / 4;
-    for (long u = (long)blockIdx.x * kT + threadIdx.x; u < units; u += (long)gridDim.x * kT) {
+    for_units<kT>(units, [&](auto u) {
         const bool main = u < units0;
-        const long v = main ? u : u - units0;
+        const decltype(u) v = main ? u : u - units0;
         const int R = main ? a.R0 : a.R1, S = main ? a.S0 : a.S1, N = main ? a.N0 : a.N1;
         const int c = (int)(v % C4) * 4;
-        const long tp = v / C4;
+        const decltype(u) tp = v / C4;
         const int p = (int)(tp % (R * S));
         const int t = (int)(tp / (R * S));
         const int b = t / N, n = t - b * N;
         int h, w;
         if (main) { h = (a.offH + a.idx0[2 * n]) / a.strH + p / S; w = (a.offW + a.idx0[2 * n + 1]) / a.strW + p % S; }
         else { h = a.idx1[2 * n] + p / S; w = a.idx1[2 * n + 1] + p % S; }
-        if (h < 0 || h >= a.H || w < 0 || w >= a.W) continue;
+        if (h < 0 || h >= a.H || w < 0 || w >= a.W) return;
         int t0, t1;
         if (main) { t0 = n; t1 = BLOCK_RES ? a.table1[(h / a.R1) * a.gW1 + w / a.S1] : -1; }
-        else { t1 = n; t0 = a.table0[(h / a.R0) * a.gW0 + w / a.S0]; if (t0 >= 0) continue; }  // a main tile writes this pixel
+        else { t1 = n; t0 = a.table0[(h / a.R0) * a.gW0 + w / a.S0]; if (t0 >= 0) return; }  // a main tile writes this pixel
         const size_t q = ((((size_t)b * a.H + h) * a.W + w) * a.C) + c;
         st4_out(a.out + q, scatter_value<BLOCK_RES, CT>(a, b, h, w, c, t0, t1, q));
-    }
+    });
 }
 
 static int grid_for(long units) {

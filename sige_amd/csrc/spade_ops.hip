@@ -40,27 +40,27 @@ inline int grid_of(long units) {
 // x [B,H,W,C] -> out [B,Ho,Wo,C], source pixel (ho * H / Ho, wo * W / Wo): exact for integer factors either way
 __global__ __launch_bounds__(kT) void resize_nearest_nhwc_kernel(const float *__restrict__ x, int C4, int H, int W, int Ho, int Wo,
                                                                 float *__restrict__ out, long units) {
-    for (long u = (long)blockIdx.x * kT + threadIdx.x; u < units; u += (long)gridDim.x * kT) {
+    for_units<kT>(units, [&](auto u) {
         const int c = (int)(u % C4);
-        const long p = u / C4;
+        const decltype(u) p = u / C4;
         const int wo = (int)(p % Wo);
-        const long bh = p / Wo;
+        const decltype(u) bh = p / Wo;
         const int ho = (int)(bh % Ho);
-        const long b = bh / Ho;
+        const long b = (long)(bh / Ho);
         const int h = (int)((long)ho * H / Ho), w = (int)((long)wo * W / Wo);
-        st4(out + u * 4, ld4(x + (((b * H + h) * W + w) * C4 + c) * 4));
-    }
+        st4(out + (size_t)u * 4, ld4(x + (((b * H + h) * W + w) * C4 + c) * 4));
+    });
 }
 
 // x [P, C] -> out [parts][P, C / parts]
 __global__ __launch_bounds__(kT) void act_split_nhwc_kernel(const float *__restrict__ x, long part_stride, int C4, int Cp4, int act, float slope,
                                                            float *__restrict__ out, long units) {
-    for (long u = (long)blockIdx.x * kT + threadIdx.x; u < units; u += (long)gridDim.x * kT) {
+    for_units<kT>(units, [&](auto u) {
         const int c = (int)(u % C4);
-        const long p = u / C4;
+        const decltype(u) p = u / C4;
         const int part = c / Cp4;
-        st4(out + (long)part * part_stride + (p * Cp4 + (c - part * Cp4)) * 4, act4(ld4(x + u * 4), act, slope));
-    }
+        st4(out + (long)part * part_stride + ((long)p * Cp4 + (c - part * Cp4)) * 4, act4(ld4(x + (size_t)u * 4), act, slope));
+    });
 }
 
 // x [B*N, Rx, Sx, C] conv tiles, y [B,H,W,C] cached, map [H,W,3] -> out [parts][B*N, bH, bW, C / parts]
@@ -70,9 +70,9 @@ __global__ __launch_bounds__(kT) void scatter_gather_split_nhwc_kernel(const flo
                                                                       const int32_t *__restrict__ map, int act, float slope, int Cp4,
                                                                       long part_stride, float *__restrict__ out, long units, int hp_shift) {
     const int C4 = C / 4, RS = bH * bW;
-    for (long u = (long)blockIdx.x * kT + threadIdx.x; u < units; u += (long)gridDim.x * kT) {
+    for_units<kT>(units, [&](auto u) {
         const int c4 = (int)(u % C4);
-        const long tp = u / C4;
+        const decltype(u) tp = u / C4;
         const int p = (int)(tp % RS);
         const int t = (int)(tp / RS);
         const int b = t / N, n = t - b * N;
@@ -89,8 +89,8 @@ __global__ __launch_bounds__(kT) void scatter_gather_split_nhwc_kernel(const flo
             z = act4(v, act, slope);
         }
         const int part = c4 / Cp4;
-        st4(out + (long)part * part_stride + (tp * Cp4 + (c4 - part * Cp4)) * 4, z);
-    }
+        st4(out + (long)part * part_stride + ((long)tp * Cp4 + (c4 - part * Cp4)) * 4, z);
+    });
 }
 
 // x [B,H,W,C], gb [B,H,W,2C] (gamma | beta), scale / shift [1|B, C]
@@ -98,11 +98,11 @@ __global__ __launch_bounds__(kT) void spade_modulate_dense_nhwc_kernel(const flo
                                                                       const float *__restrict__ shift, int aff_sb,
                                                                       const float *__restrict__ gb, int C4, long hw, int leaky,
                                                                       float slope, float *__restrict__ out, long units) {
-    for (long u = (long)blockIdx.x * kT + threadIdx.x; u < units; u += (long)gridDim.x * kT) {
+    for_units<kT>(units, [&](auto u) {
         const int c = (int)(u % C4) * 4;
-        const long p = u / C4;
-        const long b = p / hw;
-        const float4 v = ld4(x + u * 4), gamma = ld4(gb + p * 8 * C4 + c), beta = ld4(gb + p * 8 * C4 + 4 * C4 + c);
+        const decltype(u) p = u / C4;
+        const long b = (long)(p / (decltype(u))hw);  // (hw <= units: it fits whenever u's type does)
+        const float4 v = ld4(x + (size_t)u * 4), gamma = ld4(gb + (size_t)p * 8 * C4 + c), beta = ld4(gb + (size_t)p * 8 * C4 + 4 * C4 + c);
         const float4 sc = ld4(scale + b * aff_sb + c), sh = ld4(shift + b * aff_sb + c);
         // scale, then shift (two separately rounded ops: -ffp-contract=off), 1 + gamma, product, + beta, leaky: the order of
         // sige_normalization.py:74-88 with the param-free norm folded into the cached affine
@@ -112,8 +112,8 @@ __global__ __launch_bounds__(kT) void spade_modulate_dense_nhwc_kernel(const flo
         float4 z = make_float4(n.x * g1.x, n.y * g1.y, n.z * g1.z, n.w * g1.w);
         z = make_float4(z.x + beta.x, z.y + beta.y, z.z + beta.z, z.w + beta.w);
         if (leaky) z = act4(z, SIGE_HIP_ACT_LEAKY, slope);
-        st4(out + u * 4, z);
-    }
+        st4(out + (size_t)u * 4, z);
+    });
 }
 
 inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

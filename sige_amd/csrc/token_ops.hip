@@ -30,20 +30,27 @@ __global__ __launch_bounds__(256) void add_layer_norm_kernel(const float *__rest
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= T) return;
     const float *xr = x + row * C;
-    float v[PER];
+    // (branch-free: `if (c < C) { load; add; store }` per element compiled to an exec-masked block with its own s_waitcnt vmcnt(0) --
+    //  PER dependent round trips per row.  Every lane loads a valid column -- the last one past the end --, all loads go out
+    //  together, the selects follow)
+    float v[PER], dv[PER], bv[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = min(lane + 64 * i, C - 1);
+        v[i] = xr[c];
+        dv[i] = delta ? delta[row * C + c] : 0.f;
+        bv[i] = bias ? bias[c] : 0.f;
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int c = lane + 64 * i;
-        float z = 0.f;
-        if (c < C) {
-            z = xr[c];
-            if (delta) z = z + delta[row * C + c];
-            if (bias) z = z + bias[c];
-            if (sum_out) sum_out[row * C + c] = z;
-        }
-        v[i] = z;
-        s += z;
+        float z = v[i];
+        if (delta) z = z + dv[i];
+        if (bias) z = z + bv[i];
+        if (c < C && sum_out) sum_out[row * C + c] = z;
+        v[i] = c < C ? z : 0.f;
+        s += v[i];
     }
     const float mean = wave_sum(s) / (float)C;
     float q = 0.f;
@@ -54,36 +61,42 @@ __global__ __launch_bounds__(256) void add_layer_norm_kernel(const float *__rest
         q += d * d;
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    float gv[PER], ev[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = min(lane + 64 * i, C - 1);
+        gv[i] = gamma[c]; ev[i] = beta[c];
+    }
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int c = lane + 64 * i;
-        if (c < C) out[row * C + c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+        if (c < C) out[row * C + c] = (v[i] - mean) * rstd * gv[i] + ev[i];
     }
 }
 
 __global__ __launch_bounds__(256) void geglu_kernel(const float *__restrict__ x, long T, int D4, float *__restrict__ out, long units) {
-    for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long)gridDim.x * 256) {
-        const long t = u / D4;
+    for_units<256>(units, [&](auto u) {
+        const decltype(u) t = u / D4;
         const int d = (int)(u - t * D4) * 4;
-        const float4 a = *reinterpret_cast<const float4 *>(x + t * 8 * D4 + d);
-        const float4 g = *reinterpret_cast<const float4 *>(x + t * 8 * D4 + 4 * D4 + d);
+        const float4 a = *reinterpret_cast<const float4 *>(x + (size_t)t * 8 * D4 + d);
+        const float4 g = *reinterpret_cast<const float4 *>(x + (size_t)t * 8 * D4 + 4 * D4 + d);
         auto gelu = [](float z) { return 0.5f * z * (1.0f + erff(z * 0.70710678118654752440f)); };
-        *reinterpret_cast<float4 *>(out + t * 4 * D4 + d) = make_float4(a.x * gelu(g.x), a.y * gelu(g.y), a.z * gelu(g.z), a.w * gelu(g.w));
-    }
+        *reinterpret_cast<float4 *>(out + (size_t)t * 4 * D4 + d) = make_float4(a.x * gelu(g.x), a.y * gelu(g.y), a.z * gelu(g.z), a.w * gelu(g.w));
+    });
 }
 
 __global__ __launch_bounds__(256) void add_bias_kernel(const float *__restrict__ x, const float *__restrict__ delta,
                                                       const float *__restrict__ bias, int C4, float *__restrict__ out, long units) {
-    for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long)gridDim.x * 256) {
+    for_units<256>(units, [&](auto u) {
         const int c = (int)(u % C4) * 4;
-        const float4 a = *reinterpret_cast<const float4 *>(x + u * 4), b = *reinterpret_cast<const float4 *>(delta + u * 4);
+        const float4 a = *reinterpret_cast<const float4 *>(x + (size_t)u * 4), b = *reinterpret_cast<const float4 *>(delta + (size_t)u * 4);
         float4 r = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
         if (bias) {
             const float4 bb = *reinterpret_cast<const float4 *>(bias + c);
             r = make_float4(r.x + bb.x, r.y + bb.y, r.z + bb.z, r.w + bb.w);
         }
-        *reinterpret_cast<float4 *>(out + u * 4) = r;
-    }
+        *reinterpret_cast<float4 *>(out + (size_t)u * 4) = r;
+    });
 }
 
 inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -38,14 +38,16 @@ from ..nn import Gather, Scatter, SIGEConv2d, SIGEModule
 #                     against the stacked weights [3, C, inner]: three dense outputs, one launch instead of three)
 #   FUSED_TOKENS      (round 5) what sits between the GEMMs of a block as one library launch each (csrc/token_ops.hip): residual add
 #                     + the projection's bias + the next LayerNorm; GEGLU's a * gelu(gate); the block's last residual add + bias --
-#                     48 kernels fewer per forward of the SD v1 U-Net (16 blocks x 3), same arithmetic.  MEASURED SLOWER and therefore
-#                     OFF: 10.98 vs 10.84 ms per forward (profiles/r5m_bench_sd_fused_tokens.json): every kernel involved sits at
-#                     the ~5 us launch floor either way, and the bias-free projections (aten.mm) cost more than the addmm they
-#                     replace saves -- the bias has to move into the fused add for the fusion to exist at all
+#                     48 kernels fewer per forward of the SD v1 U-Net (16 blocks x 3), same arithmetic.  Round 5 measured it SLOWER
+#                     (10.98 vs 10.84 ms per forward, profiles/r5m_bench_sd_fused_tokens.json) and left it off; round 6 found why --
+#                     the add + LayerNorm kernel's loads sat behind exec-masked branches, one dependent round trip per element of a
+#                     lane, and the elementwise kernels divided 64-bit indices by run-time values -- and with both fixed it is
+#                     FASTER and on: 10.08 vs 10.24 ms (tools/sd_fused_tokens_ab.py, profiles/r6ac_sd_fused_tokens.json; the
+#                     round-5 kernels in the same run: 10.46 vs 10.27)
 NATIVE_ATTENTION = True
 NATIVE_LINEAR = False
 BATCHED_QKV = True
-FUSED_TOKENS = False
+FUSED_TOKENS = True
 
 
 def linear(lin: nn.Linear, x: torch.Tensor) -> torch.Tensor:
