@@ -134,6 +134,23 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// One dword of every 64-byte line of the kernel-argument segment, read (and waited for) at the top of a kernel with a large argument
+// struct.  The compiler fetches kernel arguments where it first needs them: a conv kernel reads its ~400-byte struct in three to
+// five dependent phases (grid decomposition -> pointers -> epilogue options ...), each one a scalar-cache miss of its own; after this
+// call every later fetch hits the scalar cache, and the one miss it pays is the one the first phase would have paid anyway.
+// `-DSIGE_NO_KERNARG_TOUCH` removes it (the A/B build).
+template <int BYTES>
+__device__ __forceinline__ void kernarg_touch() {
+#ifndef SIGE_NO_KERNARG_TOUCH
+    typedef const __attribute__((address_space(4))) unsigned *kptr_t;
+    kptr_t k = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned acc = 0;
+#pragma unroll
+    for (int o = 0; o < BYTES; o += 64) acc ^= k[o / 4];
+    asm volatile("" ::"s"(acc));
+#endif
+}
+
 // Grid-stride loop over `units` work items of a T-thread workgroup, with the item index a 32-bit unsigned whenever the count allows:
 // the kernels that use it split the index by run-time divisors (channel quads, pixels of a tile, tiles of an image), and a 64-bit
 // division by a run-time value is a branchy ~130-instruction routine -- four of them were most of the instructions of a scatter

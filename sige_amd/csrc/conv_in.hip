@@ -25,6 +25,7 @@ __global__ __launch_bounds__(256) void conv_in_gemm_kernel(const float *__restri
                                                           int B, int H, int W, const float *__restrict__ w,  // [Cout, CIN, 3, 3]
                                                           const float *__restrict__ bias, float *__restrict__ out, long npix,
                                                           const int32_t *__restrict__ idx, int N, int bH, int bW) {
+    kernarg_touch<128>();
     constexpr int K = 9 * CIN, KS = (K + 1) / 2, COUT = 32 * NBK;
     constexpr int KP = 2 * KS + 1;  // odd row pitch of the weight stage: lane j reads row j -> 32 different banks
     __shared__ __attribute__((aligned(16))) float wl[COUT * KP];

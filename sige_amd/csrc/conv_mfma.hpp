@@ -1149,6 +1149,7 @@ inline int conv_grid_x(const ConvArgs &a) { return a.ng_fast == 2 ? 8 * ((a.mbk 
 
 template <typename G, int NB, int SRC, int MODE, int DST, int LAYOUT = LAYOUT_NCHW, int W = 4, bool Y16 = false>
 __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
+    kernarg_touch<sizeof(ConvArgs)>();
     __shared__ __attribute__((aligned(16))) float smem[conv_lds_floats<G, NB, MODE, LAYOUT, W>()];
     conv_mfma_body<G, NB, SRC, MODE, DST, LAYOUT, W, Y16>(a, blockIdx.x, blockIdx.y, smem);
 }
@@ -1161,6 +1162,7 @@ __global__ __launch_bounds__(64 * W) void conv_mfma_kernel(const ConvArgs a) {
 // activated twin: ConvArgs::twin0/1)
 template <typename GA, int NBA, typename GB, int DST, int W, int MODEA>
 __global__ __launch_bounds__(64 * W) void conv_pair_kernel(const ConvArgs a, const ConvArgs b, const int na) {
+    kernarg_touch<2 * sizeof(ConvArgs)>();
     constexpr int LA = conv_lds_floats<GA, NBA, MODEA, LAYOUT_NHWC, W>();
     constexpr int LB = conv_lds_floats<GB, 1, MODE_RAW, LAYOUT_NHWC, W>();
     __shared__ __attribute__((aligned(16))) float smem[cmax(LA, LB)];

@@ -128,6 +128,7 @@ __global__ __launch_bounds__(256) void conv_out_gemm_kernel(const float *__restr
                                                            const float *__restrict__ scale, const float *__restrict__ shift, int aff_sb,
                                                            const float *__restrict__ w,  // [COUT, CIN, 3, 3]
                                                            const float *__restrict__ bias, float *__restrict__ out, float slope, int out_act) {
+    kernarg_touch<128>();
     constexpr int KS = CIN / 2;  // MFMA steps (K = 2 each: one channel of either half)
     constexpr int NV = KS / 4;   // 16-byte loads per lane and block
     constexpr int NP = 9 * COUT;

@@ -422,6 +422,7 @@ __device__ __forceinline__ void conv_tile3_body(const Tile3Args &a, const int bx
 
 template <typename G, int SRC, bool AFF, bool CAT, bool FULL, bool Y16 = false>
 __global__ __launch_bounds__(256, G::OCC) void conv_tile3_kernel(const Tile3Args a) {
+    kernarg_touch<sizeof(Tile3Args)>();
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];
     conv_tile3_body<G, SRC, AFF, CAT, FULL, Y16>(a, blockIdx.x, smem);
 }

@@ -517,6 +517,7 @@ __device__ __forceinline__ void conv_wide_body(const WideArgs &a, const int bx, 
 
 template <typename G, bool AFF, bool CAT>
 __global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a) {
+    kernarg_touch<sizeof(WideArgs)>();
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];
     conv_wide_body<G, AFF, CAT>(a, blockIdx.x, blockIdx.y, smem);
 }
@@ -527,6 +528,7 @@ __global__ __launch_bounds__(256, G::OCC) void conv_wide_kernel(const WideArgs a
 // lanes; LDS = the larger of the two; the register budget is this kernel's (two workgroups per CU).
 template <typename G, bool AFF, bool CAT, typename GB>
 __global__ __launch_bounds__(256, G::OCC) void conv_wide_pair_kernel(const WideArgs a, const ConvArgs b, const int na) {
+    kernarg_touch<sizeof(WideArgs) + sizeof(ConvArgs)>();
     constexpr int LB = conv_lds_floats<GB, 1, MODE_RAW, LAYOUT_NHWC, 4>() * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[cmax(G::LDS_BYTES, LB)];
     if ((int)blockIdx.x < na) conv_wide_body<G, AFF, CAT>(a, blockIdx.x, blockIdx.y, smem);

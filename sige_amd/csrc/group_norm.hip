@@ -54,6 +54,7 @@ __global__ __launch_bounds__(64) void gn_finish_kernel(const float *__restrict__
                                                       double group_elems, float eps, const float *__restrict__ gamma,
                                                       const float *__restrict__ beta, float *__restrict__ scale,
                                                       float *__restrict__ shift, const float *__restrict__ cbias = nullptr) {
+    kernarg_touch<128>();
     const int bg = blockIdx.x;  // b*groups + g
     const int b = bg / groups, g = bg - b * groups;
     const int lane = threadIdx.x;
@@ -157,6 +158,7 @@ __global__ __launch_bounds__(256) void gn_from_stats_kernel(StatsPart p1, StatsP
                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
                                                             const float *__restrict__ cbias, float *__restrict__ scale,
                                                             float *__restrict__ shift) {
+    kernarg_touch<128>();
     const int C = p1.C + p2.C, cg = C / groups;
     const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
     const int c0 = g * cg;

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(kT) void gather_nhwc_kernel(const XT *__restrict__ 
                                                         const int32_t *__restrict__ idx, int N,
                                                         const float *scale, const float *shift, int aff_sb,
                                                         float *__restrict__ out, long units, int hp_shift) {
+    kernarg_touch<128>();
     const int C4 = C / 4, RS = bH * bW;
     for_units<kT>(units, [&](auto u) {
         const int c = (int)(u % C4) * 4;
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(kT) void scatter_gather_nhwc_kernel(const float *__
                                                                 const int32_t *__restrict__ map,
                                                                 const float *scale, const float *shift, int aff_sb,
                                                                 float *__restrict__ out, long units, int hp_shift) {
+    kernarg_touch<192>();
     const int C4 = C / 4, RS = bH * bW;
     for_units<kT>(units, [&](auto u) {
         const int c = (int)(u % C4) * 4;
@@ -127,6 +129,7 @@ struct SpadeArgs {
 };
 
 __global__ __launch_bounds__(kT) void spade_modulate_nhwc_kernel(SpadeArgs a, long units) {
+    kernarg_touch<sizeof(SpadeArgs) + 8>();
     const int C4 = a.C / 4, RS = a.bH * a.bW, C2 = 2 * a.C;
     for_units<kT>(units, [&](auto u) {
         const int c = (int)(u % C4) * 4;
@@ -204,6 +207,7 @@ __device__ __forceinline__ float4 scatter_value(const ScatterNhwcArgsT<CT> &a, i
 // reference semantics: a fresh full tensor, ONE streaming pass (no clone + overwrite)
 template <bool BLOCK_RES, typename CT = float>
 __global__ __launch_bounds__(kT) void scatter_full_nhwc_kernel(ScatterNhwcArgsT<CT> a, long units) {
+    kernarg_touch<sizeof(ScatterNhwcArgsT<CT>) + 8>();
     const int C4 = a.C / 4;
     for_units<kT>(units, [&](auto u) {
         const int c = (int)(u % C4) * 4;
@@ -222,6 +226,7 @@ __global__ __launch_bounds__(kT) void scatter_full_nhwc_kernel(ScatterNhwcArgsT<
 // that no main tile covers -- are written.  Traffic ~ active tiles instead of the full tensor.
 template <bool BLOCK_RES, typename CT = float>
 __global__ __launch_bounds__(kT) void scatter_tiles_nhwc_kernel(ScatterNhwcArgsT<CT> a, long units0, long units) {
+    kernarg_touch<sizeof(ScatterNhwcArgsT<CT>) + 16>();
     const int C4 = a.C / 4;
     for_units<kT>(units, [&](auto u) {
         const bool main = u < units0;

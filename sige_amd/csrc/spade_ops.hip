@@ -69,6 +69,7 @@ __global__ __launch_bounds__(kT) void scatter_gather_split_nhwc_kernel(const flo
                                                                       const int32_t *__restrict__ idx, int N,
                                                                       const int32_t *__restrict__ map, int act, float slope, int Cp4,
                                                                       long part_stride, float *__restrict__ out, long units, int hp_shift) {
+    kernarg_touch<192>();
     const int C4 = C / 4, RS = bH * bW;
     for_units<kT>(units, [&](auto u) {
         const int c4 = (int)(u % C4);
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(kT) void spade_modulate_dense_nhwc_kernel(const flo
                                                                       const float *__restrict__ shift, int aff_sb,
                                                                       const float *__restrict__ gb, int C4, long hw, int leaky,
                                                                       float slope, float *__restrict__ out, long units) {
+    kernarg_touch<128>();
     for_units<kT>(units, [&](auto u) {
         const int c = (int)(u % C4) * 4;
         const decltype(u) p = u / C4;

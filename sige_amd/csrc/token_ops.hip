@@ -26,6 +26,7 @@ __global__ __launch_bounds__(256) void add_layer_norm_kernel(const float *__rest
                                                             const float *__restrict__ bias, const float *__restrict__ gamma,
                                                             const float *__restrict__ beta, long T, int C, float eps,
                                                             float *__restrict__ sum_out, float *__restrict__ out) {
+    kernarg_touch<128>();
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= T) return;
