@@ -40,7 +40,6 @@ void attention_tokens_kernel(const float *__restrict__ q, const float *__restric
                                                                const float *__restrict__ v, float *__restrict__ out,
                                                                int Nq, int Nk, int C, int heads, int d, float scale_log2e,
                                                                int q_tiles, int xcd_pairs) {
-    kernarg_touch<128>();
     constexpr int DT = UNITS;            // 16-column tiles of O
     constexpr int OS = UNITS * 16 + 4;   // padded row of the merge buffer
     constexpr int QR = 16 * QT;          // query rows of the workgroup
@@ -254,7 +253,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UNITS <= 3 
 void attention_tokens_t_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
                                float *__restrict__ out, int Nq, int Nk, int C, int heads, int d, float scale_log2e,
                                int q_tiles, int xcd_pairs) {
-    kernarg_touch<128>();
     constexpr int DT = UNITS;           // 16-channel tiles of O
     constexpr int OS = UNITS * 16 + 4;  // padded row of the merge buffer (a multiple of 4 floats: 16-byte rows)
     __shared__ float m_lds[4][16], l_lds[4][4][16];

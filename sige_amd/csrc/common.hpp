@@ -138,7 +138,8 @@ __device__ __forceinline__ float row16_sum(float v) {
 // struct.  The compiler fetches kernel arguments where it first needs them: a conv kernel reads its ~400-byte struct in three to
 // five dependent phases (grid decomposition -> pointers -> epilogue options ...), each one a scalar-cache miss of its own; after this
 // call every later fetch hits the scalar cache, and the one miss it pays is the one the first phase would have paid anyway.
-// `-DSIGE_NO_KERNARG_TOUCH` removes it (the A/B build).
+// `-DSIGE_NO_KERNARG_TOUCH` removes it (the A/B build).  BYTES must not exceed the kernel's argument segment (the last dword read is at
+// 64 * ((BYTES - 1) / 64)): a kernel that uses no hidden argument has none, its segment ends with its last explicit argument.
 template <int BYTES>
 __device__ __forceinline__ void kernarg_touch() {
 #ifndef SIGE_NO_KERNARG_TOUCH

@@ -301,6 +301,25 @@ __device__ __forceinline__ float4 ld_f32x4_or_h4(const float *base, size_t elem,
     return *reinterpret_cast<const float4 *>(base + elem);
 }
 
+// The same load with the conversion LEFT OUT (halves: the 8 bytes as they lie, in .x / .y) and done where the value is used: a
+// residual requested with the prologue's loads must not be converted there -- the conversion is its first use, and the wait in
+// front of it drains every load of the prologue (s_waitcnt vmcnt(0): the weights of two chunks, the index entries, the tables).
+__device__ __forceinline__ float4 ld_raw_f32x4_or_h4(const float *base, size_t elem, bool halves) {
+    if (halves) {
+        const float2 h = *reinterpret_cast<const float2 *>(reinterpret_cast<const _Float16 *>(base) + elem);
+        return make_float4(h.x, h.y, 0.f, 0.f);
+    }
+    return *reinterpret_cast<const float4 *>(base + elem);
+}
+__device__ __forceinline__ float4 cvt_raw_f32x4_or_h4(float4 raw, bool halves) {
+    if (halves) {
+        const float2 r2 = make_float2(raw.x, raw.y);
+        const f16x4 h = __builtin_bit_cast(f16x4, r2);
+        return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    }
+    return raw;
+}
+
 // Memory layout of every activation / tile tensor a launch touches:
 //   NCHW  [B,C,H,W] / tiles [T,C,R,S]            -- the reference's layout (torch contiguous)
 //   NHWC  [B,H,W,C] / tiles [T,R,S,C]            -- torch channels_last
@@ -608,7 +627,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
                 e_h[k] = h; e_w[k] = w; e_in[k] = in;
                 e_q[k] = in ? (((size_t)b * a.Ho + h) * a.Wo + w) * a.Cout + co : 0;  // (dead units: a valid address, never stored)
                 e_res[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e_first_pass && a.residual) e_res[k] = ld_f32x4_or_h4(a.residual, e_q[k], a.res_f16 != 0);
+                if (e_first_pass && a.residual) e_res[k] = ld_raw_f32x4_or_h4(a.residual, e_q[k], a.res_f16 != 0);  // (converted at its use)
             });
         }
     } else {
@@ -974,7 +993,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
                 u.addr = ((size_t)t * G::PX + pxo) * a.Cout + u.co;
             } else if constexpr (EPRE) {
                 // (4 waves: pixel, address and residual were fetched with the prologue's loads)
-                u.ok = e_in[k]; u.h = e_h[k]; u.w = e_w[k]; u.addr = e_q[k]; u.rr = e_res[k];
+                u.ok = e_in[k]; u.h = e_h[k]; u.w = e_w[k]; u.addr = e_q[k]; u.rr = cvt_raw_f32x4_or_h4(e_res[k], a.res_f16 != 0);
             } else {
                 const int n = t - u.b * a.N;
                 u.h = (a.offH + a.idx[2 * n]) / a.strH + pxo / G::RO;

@@ -74,6 +74,9 @@ def _dense_conv(conv: nn.Conv2d, x: torch.Tensor, residual: Optional[torch.Tenso
     return out if residual is None else residual + out
 
 
+_RESIZE_MEMO = None  # {(data_ptr, shape, size): tensor} while a generator forward runs (set and cleared by SPADEGenerator.forward)
+
+
 def _resize(x: torch.Tensor, size) -> torch.Tensor:
     """F.interpolate(x, size=size, mode="nearest"); on channels-last GPU tensors one library launch (csrc/spade_ops.hip), so that
     a launch plan sees it."""
@@ -83,8 +86,15 @@ def _resize(x: torch.Tensor, size) -> torch.Tensor:
     if _cl_gpu(x):
         from .. import hip
 
+        # (within ONE generator forward the label map is resized to the same size by every block of a resolution -- fc and head_0,
+        #  G_middle_0 and G_middle_1: the second asks for the tensor the first made)
+        key = (x.data_ptr(), tuple(x.shape), size)
+        if _RESIZE_MEMO is not None and key in _RESIZE_MEMO:
+            return _RESIZE_MEMO[key]
         out = hip.resize_nearest_cl(x, size)
         if out is not None:
+            if _RESIZE_MEMO is not None:
+                _RESIZE_MEMO[key] = out
             return out
     _refuse_in_stacked_mode(x, "the nearest resize")
     return F.interpolate(x, size=size, mode="nearest")
@@ -378,6 +388,14 @@ class SpadeGenerator(SIGEModel):
         return torch.tanh(self.conv_img(F.leaky_relu(x, cfg.leaky_slope)))
 
     def forward(self, seg: torch.Tensor) -> torch.Tensor:
+        global _RESIZE_MEMO
+        _RESIZE_MEMO = {}
+        try:
+            return self._forward(seg)
+        finally:
+            _RESIZE_MEMO = None
+
+    def _forward(self, seg: torch.Tensor) -> torch.Tensor:
         cfg = self.cfg
         E = self.edit_batch
         if E > 1:
