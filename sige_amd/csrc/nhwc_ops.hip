@@ -309,34 +309,43 @@ __global__ __launch_bounds__(kT) void attn_apply_nhwc_kernel(const float *__rest
     const int kq = lane >> 4, n = lane & 15;
     const int c = c0 + wave * 16 + n;
     const bool cok = c < C;
-    const float *vb = qkv + (size_t)b * HW * 3 * C + 2 * C + (cok ? c : 0);
     const size_t rs = (size_t)3 * C;
     // 256 keys per block: all 64 value loads of a block are issued before the first MFMA needs one (a loop that
     // loads one step ahead pays the memory latency every step: 16 x ~0.6 us for 256 tokens); the first block's
     // are issued before the softmax, which does not depend on them
+    // (one buffer descriptor over this batch's qkv rows from the value columns on, ONE 32-bit offset register per lane, the key step
+    //  as a scalar offset: the 64 loads of a block are 64 instructions, not 64 x ten of 64-bit address arithmetic -- 1 us of issue
+    //  in front of everything else, round 6)
+    const __amdgpu_buffer_rsrc_t r_v = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(qkv + (size_t)b * HW * 3 * C + 2 * C), 0,
+        (unsigned)min((size_t)0x7fffffff, ((size_t)HW * 3 * C - 2 * C) * sizeof(float)), 0x00020000);
+    const int v_lane = ((cok ? c : 0) + kq * (int)rs) * (int)sizeof(float);
+    const int v_step = 4 * (int)rs * (int)sizeof(float);  // bytes between key steps
     float bv[64];
     auto load_values = [&](int j0) {
         const int nk = min(256, HW - j0) / 4;  // k-steps in this block (HW % 16 == 0)
 #pragma unroll
-        for (int u = 0; u < 64; ++u) bv[u] = vb[(size_t)(j0 + 4 * min(u, nk - 1) + kq) * rs];
+        for (int u = 0; u < 64; ++u)
+            bv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_v, v_lane, (j0 / 4 + min(u, nk - 1)) * v_step, 0));
     };
-    load_values(0);
     {
         const int row = tid >> 4, l16 = tid & 15;
         const float *srow = S + ((size_t)b * HW + i0 + row) * HW;
         if (HW <= 256) {
-            // the whole score row of this lane group in registers: 4 loads in flight, one pass
+            // the whole score row of this lane group in registers: 4 loads in flight, one pass -- requested AHEAD of the values (the
+            // softmax is the dependent chain; the values are not needed before the first MFMA)
             float4 t[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int j = l16 * 4 + 64 * u;
-                t[u] = j < HW ? ld4(srow + j) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                const float4 q4 = ld4(srow + min(j, HW - 4));  // (branch-free: a group past the row reads its last four, masked below)
+                t[u] = j < HW ? q4 : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
             }
+            load_values(0);
             float m = -INFINITY;
 #pragma unroll
             for (int u = 0; u < 4; ++u) m = fmaxf(fmaxf(m, fmaxf(t[u].x, t[u].y)), fmaxf(t[u].z, t[u].w));
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
+            m = row16_max(m);  // (lane groups of 16 = DPP rows: no LDS crossbar round trips)
             float sum = 0.f;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -345,8 +354,7 @@ __global__ __launch_bounds__(kT) void attn_apply_nhwc_kernel(const float *__rest
                     sum += (t[u].x + t[u].y) + (t[u].z + t[u].w);
                 }
             }
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
+            sum = row16_sum(sum);
             const float inv = 1.0f / sum;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -357,6 +365,7 @@ __global__ __launch_bounds__(kT) void attn_apply_nhwc_kernel(const float *__rest
                 }
             }
         } else {
+            load_values(0);
             float m = -INFINITY;
             for (int j = l16 * 4; j < HW; j += 64) {
                 const float4 t = ld4(srow + j);
@@ -719,7 +728,7 @@ extern "C" int sige_hip_attention_nhwc_f32(const float *qkv, int B, int C, int H
     // 16x16 tiles; 4 waves x 16-channel steps of 16-byte loads; P rows in LDS
     if (HW % 16 || C % 64 || B > 65535 || !al16(qkv) || !al16(workspace)) return SIGE_HIP_EUNSUPPORTED;
     const size_t lds = (size_t)16 * (HW + 4) * sizeof(float);
-    if (lds > 64 * 1024) return SIGE_HIP_EUNSUPPORTED;
+    if (lds > 64 * 1024 || (size_t)HW * 3 * C * sizeof(float) >= 0x7fffffffu) return SIGE_HIP_EUNSUPPORTED;  // (32-bit value offsets)
     hipStream_t st = as_stream(stream);
     attn_scores_nhwc_kernel<<<dim3(HW / 16, HW / 16, B), kT, 0, st>>>(qkv, C, HW, scale, workspace);
     attn_apply_nhwc_kernel<<<dim3(ceil_div(C, 64), HW / 16, B), kT, lds, st>>>(qkv, workspace, C, HW, out);
