@@ -503,6 +503,27 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
     float wsc = 1.0f;  // split fp16 operands: the weights were packed as w * 2^S, the sums come out times 2^S
     if constexpr (X3) wsc = *a.wscale_ptr;
 
+    // the epilogue's output units (pixel, address, residual) from the tile origins requested above.  Called BEHIND the prologue's
+    // activation loads: ahead of them (where it was until round 6) it put 370 instructions between the index values arriving and
+    // those loads going out (forward 1.345 -> 1.341 ms at 1.2 %, 1.697 -> 1.684 at 5 %, f16 -0.9 %: profiles/r6an_*)
+    auto epre_setup = [&]() {
+        if constexpr (EPRE)
+            static_for<0, EU>([&](auto k_tag) {
+                constexpr int k = decltype(k_tag)::value;
+                const int o = tid + k * NT;
+                const int nb = o / UNITS_NB, o1 = o - nb * UNITS_NB;
+                const int n4 = o1 % (G::MT / 4), m = o1 / (G::MT / 4);
+                const int pxo = m % G::PX;
+                const int t = mb * G::TPB + m / G::PX, co = (ng * NB + nb) * G::MT + 4 * n4;
+                const int b = min(t, a.T - 1) / a.N;
+                const int h = (a.offH + e_h[k]) / a.strH + pxo / G::RO, w = (a.offW + e_w[k]) / a.strW + pxo % G::RO;
+                const bool in = o < OUT_UNITS && t < a.T && co < a.Cout && h >= 0 && h < a.Ho && w >= 0 && w < a.Wo;
+                e_h[k] = h; e_w[k] = w; e_in[k] = in;
+                e_q[k] = in ? (((size_t)b * a.Ho + h) * a.Wo + w) * a.Cout + co : 0;  // (dead units: a valid address, never stored)
+                e_res[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e_first_pass && a.residual) e_res[k] = ld_raw_f32x4_or_h4(a.residual, e_q[k], a.res_f16 != 0);  // (converted at its use)
+            });
+    };
     if constexpr (NHWC) {
         // Channels-last: the slot set-up in load-batched, branch-free form.  Written slot by slot (index load ->
         // bounds test -> offset, as in the NCHW branch below) every slot costs a dependent memory round trip behind the
@@ -611,23 +632,6 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
                 s_off[i] = off;
                 s_off2[i] = off2;
                 if (AFF) s_tab[i] = in ? c_l : CCk;
-            });
-        }
-        if constexpr (EPRE) {
-            static_for<0, EU>([&](auto k_tag) {
-                constexpr int k = decltype(k_tag)::value;
-                const int o = tid + k * NT;
-                const int nb = o / UNITS_NB, o1 = o - nb * UNITS_NB;
-                const int n4 = o1 % (G::MT / 4), m = o1 / (G::MT / 4);
-                const int pxo = m % G::PX;
-                const int t = mb * G::TPB + m / G::PX, co = (ng * NB + nb) * G::MT + 4 * n4;
-                const int b = min(t, a.T - 1) / a.N;
-                const int h = (a.offH + e_h[k]) / a.strH + pxo / G::RO, w = (a.offW + e_w[k]) / a.strW + pxo % G::RO;
-                const bool in = o < OUT_UNITS && t < a.T && co < a.Cout && h >= 0 && h < a.Ho && w >= 0 && w < a.Wo;
-                e_h[k] = h; e_w[k] = w; e_in[k] = in;
-                e_q[k] = in ? (((size_t)b * a.Ho + h) * a.Wo + w) * a.Cout + co : 0;  // (dead units: a valid address, never stored)
-                e_res[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e_first_pass && a.residual) e_res[k] = ld_raw_f32x4_or_h4(a.residual, e_q[k], a.res_f16 != 0);  // (converted at its use)
             });
         }
     } else {
@@ -820,6 +824,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const int bx, 
     static_for<0, NS>([&](auto i_tag) { slot_load(0, decltype(i_tag)::value, first); });
     set_chunk(min(first + 1, last));
     static_for<0, NS>([&](auto i_tag) { slot_load(1, decltype(i_tag)::value, min(first + 1, last)); });
+    if constexpr (NHWC && EPRE) epre_setup();
     if (AFF) {
         if (!NHWC) {  // (channels-last: both entries are already in flight, see the slot set-up)
             tab_fetch(first, t_sc, t_sh);
