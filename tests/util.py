@@ -150,6 +150,9 @@ def record_margin(test, what, value, tol):
 
     out = os.path.join(os.path.dirname(GOLDEN), os.pardir, "gpurun_out")
     if os.path.isdir(out):
-        with open(os.path.join(out, "test_margins.jsonl"), "a") as f:
-            f.write(json.dumps({"test": test, "what": what, "value": float(value), "tol": float(tol)}) + "\n")
+        try:
+            with open(os.path.join(out, "test_margins.jsonl"), "a") as f:
+                f.write(json.dumps({"test": test, "what": what, "value": float(value), "tol": float(tol)}) + "\n")
+        except OSError:  # (a read-only scratch directory must not fail a parity test)
+            pass
     return float(value)
