@@ -491,6 +491,11 @@ def main_sd(args, world, rank, dev):
     from sige_amd.workloads.sd_unet import SDConfig, SDUNet
 
     hip.lib()
+    # the token GEMMs (nn.Linear as in the reference) on the fp32 solutions TunableOp measured fastest for these shapes on gfx950
+    # (sige_amd/workloads/gemm_tuning.py); dense and sparse forwards alike
+    from sige_amd.workloads import gemm_tuning
+
+    tuned_gemms = False if args.no_tuned_gemms else gemm_tuning.enable_tuned_gemms()
     torch.manual_seed(0)
     model = SDUNet(SDConfig()).eval()
     n_params = sum(p.numel() for p in model.parameters())
@@ -670,7 +675,8 @@ def main_sd(args, world, rank, dev):
                 "forward_ms": round(ms_steady, 4), "dense_forward_ms": round(dense_ms, 3), "speedup_vs_dense": round(dense_ms / ms_steady, 2),
                 "hip_kernel_launches_per_forward": launches, "cache_bytes": int(flat.numel() * 4), "cached_tensors": n_cached,
                 "active_token_ratio_64": round(float(masks[(64, 64)].float().mean()), 4),
-                "native_attention": bool(_sdt.NATIVE_ATTENTION), "native_linear": bool(_sdt.NATIVE_LINEAR), "batched_qkv": bool(_sdt.BATCHED_QKV)}
+                "native_attention": bool(_sdt.NATIVE_ATTENTION), "native_linear": bool(_sdt.NATIVE_LINEAR), "batched_qkv": bool(_sdt.BATCHED_QKV),
+                "tuned_token_gemms": bool(tuned_gemms)}
         if routing:
             line["attention_routing"] = routing
         if roof_sd is not None:
@@ -777,6 +783,8 @@ def main():
                     help="edit ratios of the split-fp16-operand (f16x3) section a default (f32) run appends ('' = skip)")
     ap.add_argument("--no-dynamic", action="store_true", help="skip the mask-change / multi-step section")
     ap.add_argument("--no-extras", action="store_true", help="skip the GauGAN (configs[2]) and SD transformer (configs[3]) sections")
+    ap.add_argument("--no-tuned-gemms", action="store_true", help="--workload sd: the token GEMMs on the libraries' default solutions "
+                    "instead of the table of sige_amd/workloads/gemm_tuning.py")
     ap.add_argument("--workload", default="ddpm", choices=["ddpm", "sd"],
                     help="ddpm = BASELINE configs[1] (the headline; what a plain `bench.py` measures); sd = configs[3], the Stable "
                          "Diffusion v1 U-Net, N different edits of one original image one per GPU")

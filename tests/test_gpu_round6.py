@@ -335,3 +335,32 @@ def test_ddpm_forward_sparse_conv_in_on_off(hip):
                 assert err <= util.CONV_ATOL, (ratio, err)
     finally:
         model.SPARSE_CONV_IN = True
+
+
+@pytest.mark.gpu
+def test_tuned_token_gemms_table_loads_and_computes_the_same_product():
+    """sige_amd/workloads/gemm_tuning.py: the TunableOp table of SD's token GEMMs is accepted by this stack (else skipped: PyTorch
+    rejects a table whose validator lines -- library versions, gfx950 -- differ), holds the benchmarked shapes, and a Linear of one
+    of them gives the product the default solution gives (every candidate is an fp32 GEMM)."""
+    import torch.nn.functional as F
+    from sige_amd.workloads import gemm_tuning
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(8192, 320, generator=g).cuda()
+    w = torch.randn(2560, 320, generator=g).cuda()
+    b = torch.randn(2560, generator=g).cuda()
+    want = F.linear(x, w, b)
+    ok = gemm_tuning.enable_tuned_gemms()
+    try:
+        if not ok:
+            assert not torch.cuda.tunable.is_enabled()
+            pytest.skip("PyTorch rejected the table (validators of another stack)")
+        assert torch.cuda.tunable.is_enabled() and not torch.cuda.tunable.tuning_is_enabled()
+        assert len(torch.cuda.tunable.get_results()) >= 40
+        got = F.linear(x, w, b)
+    finally:
+        gemm_tuning.disable_tuned_gemms()
+    assert not torch.cuda.tunable.is_enabled()
+    exact = x.double() @ w.double().t() + b.double()
+    assert float((got.double() - exact).abs().max()) <= 1e-3 and float((want.double() - exact).abs().max()) <= 1e-3
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-3)

@@ -98,3 +98,14 @@ def test_round5_bench_lines_are_small_and_carry_the_contract(name):
         assert os.path.exists(os.path.join(PROF, name[:3] + "bench_detail.json"))
         if name.startswith("r6"):
             assert d["cpu_baseline"]["model"]  # (which model ran on the CPU leg: VERDICT r5 next #8)
+
+
+def test_tuned_gemm_table_is_a_gfx950_tunableop_file():
+    """sige_amd/workloads/tunableop_sd_gfx950.csv: validator lines first (PyTorch checks them against the running stack), then
+    fp32 GEMM rows only."""
+    path = os.path.join(REPO, "sige_amd", "workloads", "tunableop_sd_gfx950.csv")
+    rows = [l.strip().split(",") for l in open(path) if l.strip()]
+    val = {r[1]: r[2] for r in rows if r[0] == "Validator"}
+    assert val["GCN_ARCH_NAME"].startswith("gfx950") and "PT_VERSION" in val and "ROCBLAS_VERSION" in val and "HIPBLASLT_VERSION" in val
+    ops = [r for r in rows if r[0] != "Validator"]
+    assert len(ops) >= 40 and all(r[0].endswith(("_float_TN", "_float_NN", "_float_NT", "_float_TT")) for r in ops)

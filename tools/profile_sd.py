@@ -21,7 +21,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--replays", type=int, default=10)
     ap.add_argument("--mc", type=int, default=320)
+    ap.add_argument("--no-tuned-gemms", action="store_true")
     a = ap.parse_args()
+    if not a.no_tuned_gemms:  # (as bench.py --workload sd runs it)
+        from sige_amd.workloads import gemm_tuning
+
+        print("tuned token GEMMs:", gemm_tuning.enable_tuned_gemms())
     dev = torch.device("cuda")
     torch.manual_seed(0)
     model = SDUNet(SDConfig(model_channels=a.mc)).eval().to(dev).to(memory_format=torch.channels_last)
