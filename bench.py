@@ -496,6 +496,9 @@ def main_sd(args, world, rank, dev):
     from sige_amd.workloads import gemm_tuning
 
     tuned_gemms = False if args.no_tuned_gemms else gemm_tuning.enable_tuned_gemms()
+    # MIOpen picks its convs (the dense baseline's, and the sparse forward's four plain ones) by measurement, as in the DDPM job: the
+    # dense forward is 8 % faster for it (25.0 -> 23.0 ms: speedup_vs_dense is quoted against the better baseline), the sparse 0.5 %
+    torch.backends.cudnn.benchmark = True
     torch.manual_seed(0)
     model = SDUNet(SDConfig()).eval()
     n_params = sum(p.numel() for p in model.parameters())

@@ -28,6 +28,7 @@ def main():
 
         print("tuned token GEMMs:", gemm_tuning.enable_tuned_gemms())
     dev = torch.device("cuda")
+    torch.backends.cudnn.benchmark = True  # (as bench.py --workload sd)
     torch.manual_seed(0)
     model = SDUNet(SDConfig(model_channels=a.mc)).eval().to(dev).to(memory_format=torch.channels_last)
     model.set_scatter_inplace(True)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6, GPU session 48: the SD evidence re-taken with the tuned token GEMMs (sige_amd/workloads/gemm_tuning.py; kernel sources
+# round 6, GPU session 48 (run twice: the second time with MIOpen choosing its convs by measurement in the SD job too): the SD evidence re-taken with the tuned token GEMMs (sige_amd/workloads/gemm_tuning.py; kernel sources
 # unchanged): the driver's test command first, then the SD bench lines (one rank, two gloo ranks on one GPU), the same line
 # without the table, and the SD kernel trace
 cd "$GRAFT_REPO_ROOT" || exit 1
