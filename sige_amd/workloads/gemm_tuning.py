@@ -21,7 +21,8 @@ TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_sd_g
 
 def enable_tuned_gemms(table: str = TABLE, tune: bool = False, results_file: str = "") -> bool:
     """Turn TunableOp on with `table` loaded.  Returns False (and leaves TunableOp off) when there is no GPU or PyTorch rejects the
-    table (validators).  `tune`: also time shapes the table does not hold; they are written to `results_file` at exit if given."""
+    table (validators).  `tune`: also time shapes the table does not hold; they are written to `results_file` at exit if given
+    (timing runs the candidates: do one eager forward under every new mask BEFORE capturing a hipGraph of it)."""
     if not torch.cuda.is_available():
         return False
     from torch.cuda import tunable
